@@ -1,0 +1,131 @@
+// extern "C" entry points of libeks_hip.so (declared in include/eks_hip.h): argument checks and
+// dispatch between the scalar-chain path (EKS_FLAG_DIAG_MODEL) and the general small-matrix path.
+#include <hip/hip_runtime.h>
+
+#include "eks_diag_lane.hpp"
+#include "eks_internal.hpp"
+
+using namespace eks;
+
+static int check_dims(const eks_dims_t* d) {
+  if (!d) return EKS_ERR_NULL;
+  if (d->n_keypoints <= 0 || d->n_frames <= 0 || d->state_dim <= 0 || d->obs_dim <= 0)
+    return EKS_ERR_SHAPE;
+  if ((d->flags & EKS_FLAG_DIAG_MODEL) && d->state_dim != d->obs_dim) return EKS_ERR_SHAPE;
+  if ((d->flags & EKS_FLAG_UNIT_AC) && !(d->flags & EKS_FLAG_DIAG_MODEL)) return EKS_ERR_UNSUPPORTED;
+  if ((long)d->n_keypoints * d->state_dim > (1L << 24)) return EKS_ERR_SHAPE;
+  return EKS_OK;
+}
+
+extern "C" {
+
+const char* eks_version(void) { return "eks_hip 0.1 (gfx950)"; }
+
+const char* eks_status_string(int status) {
+  switch (status) {
+    case EKS_OK: return "ok";
+    case EKS_ERR_NULL: return "null pointer";
+    case EKS_ERR_SHAPE: return "bad shape";
+    case EKS_ERR_UNSUPPORTED: return "unsupported (D, O) / flag combination";
+    case EKS_ERR_WORKSPACE: return "workspace missing or too small";
+    default: return status <= EKS_ERR_HIP_BASE ? hipGetErrorString((hipError_t)(EKS_ERR_HIP_BASE - status))
+                                               : "unknown status";
+  }
+}
+
+size_t eks_smooth_workspace_bytes(const eks_dims_t* d) {
+  if (check_dims(d) != EKS_OK) return 0;
+  if (d->flags & EKS_FLAG_DIAG_MODEL)
+    return diag_smooth_workspace_bytes(d->n_frames, d->n_keypoints * d->state_dim);
+  return dense_smooth_workspace_bytes(d->n_frames, d->n_keypoints, d->state_dim, d->obs_dim);
+}
+
+int eks_smooth(const eks_dims_t* d, const float* y, const float* var, const double* m0,
+               const double* S0, const double* A, const double* C, const double* Q,
+               const double* s, float* ms, float* Vs, void* workspace, size_t workspace_bytes,
+               eks_stream_t stream) {
+  const int rc = check_dims(d);
+  if (rc != EKS_OK) return rc;
+  if (!y || !var || !m0 || !S0 || !A || !C || !Q || !s || !ms || !Vs) return EKS_ERR_NULL;
+  if (!workspace) return EKS_ERR_WORKSPACE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->flags & EKS_FLAG_DIAG_MODEL) {
+    const DiagModel M{m0, S0, A, C, Q, s, d->state_dim};
+    return diag_smooth(*d, y, var, M, ms, Vs, workspace, workspace_bytes, st);
+  }
+  const DenseModel M{m0, S0, A, C, Q, s};
+  return dense_smooth(*d, y, var, M, ms, Vs, workspace, workspace_bytes, st);
+}
+
+size_t eks_const_r_workspace_bytes(const eks_dims_t* d) {
+  if (check_dims(d) != EKS_OK) return 0;
+  return const_r_workspace_bytes(d->n_keypoints * d->obs_dim);
+}
+
+int eks_const_r(const eks_dims_t* d, const float* var, double min_var, double* rconst,
+                void* workspace, size_t workspace_bytes, eks_stream_t stream) {
+  const int rc = check_dims(d);
+  if (rc != EKS_OK) return rc;
+  if (!var || !rconst) return EKS_ERR_NULL;
+  if (!workspace) return EKS_ERR_WORKSPACE;
+  return const_r(d->n_frames, d->n_keypoints * d->obs_dim, var, min_var, rconst, workspace,
+                 workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
+size_t eks_nll_workspace_bytes(const eks_dims_t* d, int32_t n_cand) {
+  if (check_dims(d) != EKS_OK || n_cand <= 0) return 0;
+  if (d->flags & EKS_FLAG_DIAG_MODEL)
+    return diag_nll_workspace_bytes(d->n_frames, d->n_keypoints * d->state_dim, n_cand);
+  return dense_nll_workspace_bytes(d->n_frames, d->n_keypoints, d->state_dim, d->obs_dim, n_cand);
+}
+
+int eks_nll(const eks_dims_t* d, const float* y, const double* rconst, const double* m0,
+            const double* S0, const double* A, const double* C, const double* Q,
+            const double* s_cand, int32_t n_cand, int32_t per_keypoint, double* nll, double* dnll,
+            void* workspace, size_t workspace_bytes, eks_stream_t stream) {
+  const int rc = check_dims(d);
+  if (rc != EKS_OK) return rc;
+  if (n_cand <= 0) return EKS_ERR_SHAPE;
+  if (!y || !rconst || !m0 || !S0 || !A || !C || !Q || !s_cand || !nll) return EKS_ERR_NULL;
+  if (!workspace) return EKS_ERR_WORKSPACE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->flags & EKS_FLAG_DIAG_MODEL) {
+    const DiagModel M{m0, S0, A, C, Q, nullptr, d->state_dim};
+    return diag_nll(*d, y, rconst, M, s_cand, n_cand, per_keypoint, nll, dnll, workspace,
+                    workspace_bytes, st);
+  }
+  const DenseModel M{m0, S0, A, C, Q, nullptr};
+  return dense_nll(*d, y, rconst, M, s_cand, n_cand, per_keypoint, nll, dnll, workspace,
+                   workspace_bytes, st);
+}
+
+int eks_argmin_s(int32_t n_keypoints, int32_t n_cand, const double* nll, const double* s_cand,
+                 double* s_out, int32_t* idx_out, eks_stream_t stream) {
+  if (n_keypoints <= 0 || n_cand <= 0) return EKS_ERR_SHAPE;
+  if (!nll || !s_cand || !s_out) return EKS_ERR_NULL;
+  return argmin_s(n_keypoints, n_cand, nll, s_cand, s_out, idx_out,
+                  reinterpret_cast<hipStream_t>(stream));
+}
+
+int eks_adam_step(int32_t n_blocks, const int32_t* block_offsets, const int32_t* block_members,
+                  const double* nll, const double* dnll, double lr, double lo, double hi,
+                  double tol, int32_t safety_cap, double* state, double* s_keypoint,
+                  int32_t* n_active, eks_stream_t stream) {
+  if (n_blocks <= 0) return EKS_ERR_SHAPE;
+  if (!block_offsets || !block_members || !nll || !dnll || !state || !s_keypoint || !n_active)
+    return EKS_ERR_NULL;
+  return adam_step(n_blocks, block_offsets, block_members, nll, dnll, lr, lo, hi, tol, safety_cap,
+                   state, s_keypoint, n_active, reinterpret_cast<hipStream_t>(stream));
+}
+
+int eks_ensemble(int32_t n_models, int32_t n_cameras, int32_t n_frames, int32_t n_keypoints,
+                 const float* markers, int32_t avg_mode, int32_t var_mode, float nan_replacement,
+                 float* stats, eks_stream_t stream) {
+  if (n_models <= 0 || n_cameras <= 0 || n_frames <= 0 || n_keypoints <= 0) return EKS_ERR_SHAPE;
+  if (avg_mode < 0 || avg_mode > 1 || var_mode < 0 || var_mode > 1) return EKS_ERR_UNSUPPORTED;
+  if (!markers || !stats) return EKS_ERR_NULL;
+  return ensemble_stats(n_models, n_cameras, n_frames, n_keypoints, markers, avg_mode, var_mode,
+                        nan_replacement, stats, reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

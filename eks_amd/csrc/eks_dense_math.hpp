@@ -1,0 +1,364 @@
+// Small dense Kalman algebra in registers for the general (D, O) path: multicam linear,
+// D = n_latent, O = 2 * n_cameras (reference eks/multicam_smoother.py:412-443, :554-597).
+// Everything is float64 (inputs/outputs stay float32): the covariance-form updates subtract, and
+// float64 keeps that harmless.  Scalar type S is double or a dual number, so
+// the same code yields d/dlog s.  All loops have compile-time bounds: matrices live in VGPRs.
+//
+// R_t is diagonal on this path (eks/utils.py:368-377), so a frame's O observations are absorbed
+// one scalar at a time (rank-1 updates): exact, and no O x O or D x D inverse is ever formed in
+// the per-frame code.
+#pragma once
+#include "eks_nll_lane.hpp"
+
+namespace eks {
+
+EKS_HD double sqrt_s(double x) { return sqrt(x); }
+EKS_HD DualD sqrt_s(DualD x) {
+  const double r = sqrt(x.v);
+  return DualD(r, x.d / (2.0 * r));
+}
+EKS_HD double log_s(double x) { return log(x); }
+EKS_HD DualD log_s(DualD x) { return DualD(log(x.v), x.d / x.v); }
+
+template <typename S, int D>
+struct Mat {
+  S a[D][D];
+};
+template <typename S, int D>
+struct Vec {
+  S a[D];
+};
+
+template <typename S, int D>
+EKS_HD Mat<S, D> mat_zero() {
+  Mat<S, D> m;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) m.a[i][j] = S(0.0);
+  return m;
+}
+template <typename S, int D>
+EKS_HD Mat<S, D> mat_eye() {
+  Mat<S, D> m = mat_zero<S, D>();
+#pragma unroll
+  for (int i = 0; i < D; ++i) m.a[i][i] = S(1.0);
+  return m;
+}
+template <typename S, int D>
+EKS_HD Vec<S, D> vec_zero() {
+  Vec<S, D> v;
+#pragma unroll
+  for (int i = 0; i < D; ++i) v.a[i] = S(0.0);
+  return v;
+}
+template <typename S, int D>
+EKS_HD Mat<S, D> mat_mul(const Mat<S, D>& x, const Mat<S, D>& y) {
+  Mat<S, D> o;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      S acc = S(0.0);
+#pragma unroll
+      for (int k = 0; k < D; ++k) acc = acc + x.a[i][k] * y.a[k][j];
+      o.a[i][j] = acc;
+    }
+  return o;
+}
+// x * y^T
+template <typename S, int D>
+EKS_HD Mat<S, D> mat_mul_nt(const Mat<S, D>& x, const Mat<S, D>& y) {
+  Mat<S, D> o;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      S acc = S(0.0);
+#pragma unroll
+      for (int k = 0; k < D; ++k) acc = acc + x.a[i][k] * y.a[j][k];
+      o.a[i][j] = acc;
+    }
+  return o;
+}
+// x^T * y
+template <typename S, int D>
+EKS_HD Mat<S, D> mat_mul_tn(const Mat<S, D>& x, const Mat<S, D>& y) {
+  Mat<S, D> o;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      S acc = S(0.0);
+#pragma unroll
+      for (int k = 0; k < D; ++k) acc = acc + x.a[k][i] * y.a[k][j];
+      o.a[i][j] = acc;
+    }
+  return o;
+}
+template <typename S, int D>
+EKS_HD Vec<S, D> mat_vec(const Mat<S, D>& x, const Vec<S, D>& v) {
+  Vec<S, D> o;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    S acc = S(0.0);
+#pragma unroll
+    for (int k = 0; k < D; ++k) acc = acc + x.a[i][k] * v.a[k];
+    o.a[i] = acc;
+  }
+  return o;
+}
+template <typename S, int D>
+EKS_HD Vec<S, D> mat_t_vec(const Mat<S, D>& x, const Vec<S, D>& v) {
+  Vec<S, D> o;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    S acc = S(0.0);
+#pragma unroll
+    for (int k = 0; k < D; ++k) acc = acc + x.a[k][i] * v.a[k];
+    o.a[i] = acc;
+  }
+  return o;
+}
+template <typename S, int D>
+EKS_HD S dot(const Vec<S, D>& x, const Vec<S, D>& y) {
+  S acc = S(0.0);
+#pragma unroll
+  for (int k = 0; k < D; ++k) acc = acc + x.a[k] * y.a[k];
+  return acc;
+}
+template <typename S, int D>
+EKS_HD Mat<S, D> mat_add(const Mat<S, D>& x, const Mat<S, D>& y) {
+  Mat<S, D> o;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) o.a[i][j] = x.a[i][j] + y.a[i][j];
+  return o;
+}
+template <typename S, int D>
+EKS_HD Mat<S, D> mat_sub(const Mat<S, D>& x, const Mat<S, D>& y) {
+  Mat<S, D> o;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) o.a[i][j] = x.a[i][j] - y.a[i][j];
+  return o;
+}
+template <typename S, int D>
+EKS_HD Mat<S, D> mat_symmetrize(const Mat<S, D>& x) {
+  Mat<S, D> o;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) o.a[i][j] = S(0.5) * (x.a[i][j] + x.a[j][i]);
+  return o;
+}
+
+// Lower Cholesky factor of a symmetric PSD matrix; a non-positive pivot zeroes its column
+// (semi-definite factor) so singular covariances do not poison the recursion.
+template <typename S, int D>
+EKS_HD Mat<S, D> chol_psd(const Mat<S, D>& P) {
+  Mat<S, D> L = mat_zero<S, D>();
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    S sum = P.a[j][j];
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+      if (k < j) sum = sum - L.a[j][k] * L.a[j][k];
+    const bool ok = val(sum) > 0.0;
+    const S ljj = ok ? sqrt_s(sum) : S(0.0);
+    const S inv = ok ? rcp(ljj) : S(0.0);
+    L.a[j][j] = ljj;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      if (i > j) {
+        S t = P.a[i][j];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+          if (k < j) t = t - L.a[i][k] * L.a[j][k];
+        L.a[i][j] = t * inv;
+      }
+  }
+  return L;
+}
+
+// Solve (Lg Lg^T) x = z for a vector (Lg lower, positive diagonal).
+template <typename S, int D>
+EKS_HD Vec<S, D> chol_solve(const Mat<S, D>& Lg, const Vec<S, D>& z) {
+  Vec<S, D> w;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    S t = z.a[i];
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+      if (k < i) t = t - Lg.a[i][k] * w.a[k];
+    w.a[i] = t * rcp(Lg.a[i][i]);
+  }
+  Vec<S, D> x;
+#pragma unroll
+  for (int ii = 0; ii < D; ++ii) {
+    const int i = D - 1 - ii;
+    S t = w.a[i];
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+      if (k > i) t = t - Lg.a[k][i] * x.a[k];
+    x.a[i] = t * rcp(Lg.a[i][i]);
+  }
+  return x;
+}
+// Solve (Lg Lg^T) X = Z column by column.
+template <typename S, int D>
+EKS_HD Mat<S, D> chol_solve_mat(const Mat<S, D>& Lg, const Mat<S, D>& Z) {
+  Mat<S, D> X;
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    Vec<S, D> z;
+#pragma unroll
+    for (int i = 0; i < D; ++i) z.a[i] = Z.a[i][c];
+    const Vec<S, D> x = chol_solve(Lg, z);
+#pragma unroll
+    for (int i = 0; i < D; ++i) X.a[i][c] = x.a[i];
+  }
+  return X;
+}
+
+template <typename S, int D>
+struct DElem {
+  Mat<S, D> A, C, J;
+  Vec<S, D> b, eta;
+  S ell;
+};
+
+template <typename S, int D>
+EKS_HD DElem<S, D> delem_identity() {
+  DElem<S, D> e;
+  e.A = mat_eye<S, D>();
+  e.C = mat_zero<S, D>();
+  e.J = mat_zero<S, D>();
+  e.b = vec_zero<S, D>();
+  e.eta = vec_zero<S, D>();
+  e.ell = S(0.0);
+  return e;
+}
+
+// Absorb one scalar observation y = h.x + N(0, r) into a running element (rank-1 forms; the
+// matrix generalisation of eks_math.hpp's elem_append without the predict half).
+template <typename S, int D>
+EKS_HD void delem_observe(DElem<S, D>& e, const Vec<S, D>& h, S y, S r, bool want_ell) {
+  const Vec<S, D> u = mat_vec(e.C, h);     // C h
+  const Vec<S, D> w = mat_t_vec(e.A, h);   // A^T h
+  const S sigma = r + dot(h, u);
+  const S g = rcp(sigma);
+  const S d = y - dot(h, e.b);
+  const S gd = g * d;
+  if (want_ell) e.ell = e.ell - S(0.5) * (S(kLog2Pi) + log_s(sigma) + d * gd);
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    e.eta.a[i] = e.eta.a[i] + w.a[i] * gd;
+    e.b.a[i] = e.b.a[i] + u.a[i] * gd;
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      e.J.a[i][j] = e.J.a[i][j] + w.a[i] * w.a[j] * g;
+      e.A.a[i][j] = e.A.a[i][j] - u.a[i] * w.a[j] * g;
+      e.C.a[i][j] = e.C.a[i][j] - u.a[i] * u.a[j] * g;
+    }
+}
+
+// Predict half of a frame: x' = F x + N(0, sQ).
+template <typename S, int D>
+EKS_HD void delem_predict(DElem<S, D>& e, const Mat<S, D>& F, const Mat<S, D>& sQ, bool f_identity) {
+  if (!f_identity) {
+    e.A = mat_mul(F, e.A);
+    e.b = mat_vec(F, e.b);
+    e.C = mat_mul_nt(mat_mul(F, e.C), F);
+  }
+  e.C = mat_add(e.C, sQ);
+}
+
+// Posterior of the belief N(m, P) on x_in given the element's information (eta, J):
+//   P_in = (P^-1 + J)^-1 = L (I + L^T J L)^-1 L^T,  P = L L^T   (stable: the inner matrix is >= I)
+//   m_in = w - L (I + L^T J L)^-1 L^T J w,          w = m + P eta
+// Also returns log|I + P J| (for the likelihood).
+template <typename S, int D>
+EKS_HD void condition_on_info(const Vec<S, D>& m, const Mat<S, D>& P, const Vec<S, D>& eta,
+                              const Mat<S, D>& J, Vec<S, D>& m_in, Mat<S, D>& P_in, S& logdet) {
+  const Mat<S, D> L = chol_psd(P);
+  Mat<S, D> G = mat_mul_tn(L, mat_mul(J, L));
+#pragma unroll
+  for (int i = 0; i < D; ++i) G.a[i][i] = G.a[i][i] + S(1.0);
+  const Mat<S, D> Lg = chol_psd(mat_symmetrize(G));
+  logdet = S(0.0);
+#pragma unroll
+  for (int i = 0; i < D; ++i) logdet = logdet + S(2.0) * log_s(Lg.a[i][i]);
+  Vec<S, D> w = mat_vec(P, eta);
+#pragma unroll
+  for (int i = 0; i < D; ++i) w.a[i] = w.a[i] + m.a[i];
+  const Vec<S, D> x = chol_solve(Lg, mat_t_vec(L, mat_vec(J, w)));
+  const Vec<S, D> Lx = mat_vec(L, x);
+#pragma unroll
+  for (int i = 0; i < D; ++i) m_in.a[i] = w.a[i] - Lx.a[i];
+  // X = G^-1 L^T  ->  P_in = L X
+  Mat<S, D> Lt;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) Lt.a[i][j] = L.a[j][i];
+  P_in = mat_symmetrize(mat_mul(L, chol_solve_mat(Lg, Lt)));
+}
+
+// Push N(m, P) through an element; returns the element's log marginal likelihood under it.
+template <typename S, int D>
+EKS_HD S delem_apply(const DElem<S, D>& e, Vec<S, D>& m, Mat<S, D>& P) {
+  Vec<S, D> m_in;
+  Mat<S, D> P_in;
+  S logdet;
+  condition_on_info(m, P, e.eta, e.J, m_in, P_in, logdet);
+  const Vec<S, D> Jm = mat_vec(e.J, m);
+  Vec<S, D> v;
+#pragma unroll
+  for (int i = 0; i < D; ++i) v.a[i] = e.eta.a[i] - Jm.a[i];
+  const S ll = e.ell - S(0.5) * logdet + dot(m, e.eta) - S(0.5) * dot(m, Jm) +
+               S(0.5) * dot(v, mat_vec(P_in, v));
+  const Vec<S, D> Am = mat_vec(e.A, m_in);
+#pragma unroll
+  for (int i = 0; i < D; ++i) m.a[i] = Am.a[i] + e.b.a[i];
+  P = mat_symmetrize(mat_add(mat_mul_nt(mat_mul(e.A, P_in), e.A), e.C));
+  return ll;
+}
+
+// Pull information (eta, J) about x_out back through an element:
+//   M^T = (I + J C)^-1 = I - J L (I + L^T J L)^-1 L^T,  C = L L^T
+template <typename S, int D>
+EKS_HD void delem_back(const DElem<S, D>& e, Vec<S, D>& eta, Mat<S, D>& J) {
+  const Mat<S, D> L = chol_psd(e.C);
+  const Mat<S, D> JL = mat_mul(J, L);
+  Mat<S, D> G = mat_mul_tn(L, JL);
+#pragma unroll
+  for (int i = 0; i < D; ++i) G.a[i][i] = G.a[i][i] + S(1.0);
+  const Mat<S, D> Lg = chol_psd(mat_symmetrize(G));
+  const Vec<S, D> Jb = mat_vec(J, e.b);
+  Vec<S, D> v;
+#pragma unroll
+  for (int i = 0; i < D; ++i) v.a[i] = eta.a[i] - Jb.a[i];
+  const Vec<S, D> x = chol_solve(Lg, mat_t_vec(L, v));
+  const Vec<S, D> JLx = mat_vec(JL, x);
+#pragma unroll
+  for (int i = 0; i < D; ++i) v.a[i] = v.a[i] - JLx.a[i];
+  const Vec<S, D> Atv = mat_t_vec(e.A, v);
+#pragma unroll
+  for (int i = 0; i < D; ++i) eta.a[i] = Atv.a[i] + e.eta.a[i];
+  // J' = J - J L G^-1 L^T J  (symmetric), then A^T J' A + J_e
+  Mat<S, D> JLt;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) JLt.a[i][j] = JL.a[j][i];
+  const Mat<S, D> Jp = mat_symmetrize(mat_sub(J, mat_mul(JL, chol_solve_mat(Lg, JLt))));
+  J = mat_symmetrize(mat_add(mat_mul_tn(e.A, mat_mul(Jp, e.A)), e.J));
+}
+
+}  // namespace eks

@@ -1,0 +1,209 @@
+// gfx950 kernels for the constant-R filter NLL on scalar chains (the loss of eks/core.py:640-650)
+// evaluated for many smoothing-parameter values at once:
+//   * grid mode  : n_cand values shared by all keypoints (BASELINE.json config 3: 64 candidates)
+//   * Adam mode  : one value per keypoint, with d nll / d log s (forward-mode dual numbers)
+//
+//   N1 diag_nll_summarize : wave = (64-chain tile, time chunk, group of NCL candidates); the waves of
+//                           a block are the candidate groups of ONE (tile, chunk), so the y tile is
+//                           pulled from HBM once and re-read from L1/L2 by the sibling waves.  Each
+//                           lane keeps NCL candidate filters in registers (ILP across candidates
+//                           hides the dependent-FMA latency of each scalar recursion).
+//   N2 diag_nll_assemble  : thread = (keypoint, candidate): walks the chunk summaries in time
+//                           order in float64 and writes nll[K][n_cand] (and dnll).
+// y is read once from HBM: 4 B per chain-frame regardless of the candidate count.
+#include <hip/hip_runtime.h>
+
+#include "eks_internal.hpp"
+#include "eks_nll_lane.hpp"
+
+namespace eks {
+
+constexpr int kNllChunk = 2048;      // frames per lane, grid mode
+constexpr int kNllChunkGrad = 512;   // frames per lane, Adam mode (one candidate: needs more lanes)
+constexpr int kNclGrid = 8;
+
+struct NllWs {
+  // planes indexed [(j * ncp + c) * N + n]
+  float *A, *b, *C, *eta, *J;            // values
+  float *dA, *db, *dC, *deta, *dJ;       // derivatives (grad mode only)
+  double *ell, *dell;
+  int ncp;                               // padded candidate count
+};
+
+struct NllGeom {
+  int N, T, D, ncn, BN;
+  int nt_log2, ntile, ngrp, n_cand, per_keypoint;
+};
+
+template <typename R, int NCL, bool UNIT>
+__global__ __launch_bounds__(512) void diag_nll_summarize_kernel(NllGeom G, DiagModel M, NllWs W,
+                                          const float* __restrict__ y,
+                                          const double* __restrict__ rconst,
+                                          const double* __restrict__ s_cand) {
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int g = wave % G.ngrp;
+  const int rest = wave / G.ngrp;
+  const int tile = rest % G.ntile;
+  const int cg = rest / G.ntile;
+  const int nt = 1 << G.nt_log2;
+  const int n = tile * nt + (lane & (nt - 1));
+  const int j = cg * (64 >> G.nt_log2) + (lane >> G.nt_log2);
+  if (n >= G.N || j >= G.ncn) return;
+  const int k = n / G.D, d = n - k * G.D;
+  const size_t dd = (size_t)k * G.D * G.D + (size_t)d * (G.D + 1);
+  const double q = M.Q[dd];
+  double sq[NCL];
+#pragma unroll
+  for (int c = 0; c < NCL; ++c) {
+    const int ci = min(g * NCL + c, G.n_cand - 1);
+    const double s = G.per_keypoint ? s_cand[(size_t)k * G.n_cand + ci] : s_cand[ci];
+    sq[c] = s * q;
+  }
+  const int t0 = j * G.BN;
+  const int len = min(G.BN, G.T - t0);
+  NllElem<R> out[NCL];
+  nll_summarize_chunk<R, NCL, UNIT>(y, G.N, n, t0, len, rconst[n], M.A[dd], M.C[dd], sq, out);
+#pragma unroll
+  for (int c = 0; c < NCL; ++c) {
+    const size_t o = ((size_t)j * W.ncp + (g * NCL + c)) * G.N + n;
+    W.A[o] = val(out[c].e.A);
+    W.b[o] = val(out[c].e.b);
+    W.C[o] = val(out[c].e.C);
+    W.eta[o] = val(out[c].e.eta);
+    W.J[o] = val(out[c].e.J);
+    W.ell[o] = out[c].ell;
+    if constexpr (sizeof(R) == sizeof(Dual)) {
+      W.dA[o] = der(out[c].e.A);
+      W.db[o] = der(out[c].e.b);
+      W.dC[o] = der(out[c].e.C);
+      W.deta[o] = der(out[c].e.eta);
+      W.dJ[o] = der(out[c].e.J);
+      W.dell[o] = out[c].dell;
+    }
+  }
+}
+
+template <bool GRAD>
+__global__ __launch_bounds__(256) void diag_nll_assemble_kernel(NllGeom G, DiagModel M, NllWs W,
+                                                               int K, double* __restrict__ nll,
+                                                               double* __restrict__ dnll) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= K * G.n_cand) return;
+  const int k = idx % K, ci = idx / K;
+  using RD = typename std::conditional<GRAD, DualD, double>::type;
+  RD tot = RD(0.0);
+  for (int d = 0; d < G.D; ++d) {
+    const int n = k * G.D + d;
+    const size_t dd = (size_t)k * G.D * G.D + (size_t)d * (G.D + 1);
+    auto get = [&](int j, Elem<RD>& e, RD& ell) {
+      const size_t o = ((size_t)j * W.ncp + ci) * G.N + n;
+      if constexpr (GRAD) {
+        e.A = DualD(W.A[o], W.dA[o]);
+        e.b = DualD(W.b[o], W.db[o]);
+        e.C = DualD(W.C[o], W.dC[o]);
+        e.eta = DualD(W.eta[o], W.deta[o]);
+        e.J = DualD(W.J[o], W.dJ[o]);
+        ell = DualD(W.ell[o], W.dell[o]);
+      } else {
+        e.A = W.A[o];
+        e.b = W.b[o];
+        e.C = W.C[o];
+        e.eta = W.eta[o];
+        e.J = W.J[o];
+        ell = W.ell[o];
+      }
+    };
+    tot = tot + nll_assemble<RD>(G.ncn, M.m0[(size_t)k * G.D + d], M.S0[dd], get);
+  }
+  // eks/core.py:650: non-finite -> 1e12 (gradient of the constant branch is 0)
+  const double v = -val(tot);
+  const bool fin = isfinite(v);
+  nll[(size_t)k * G.n_cand + ci] = fin ? v : 1e12;
+  if constexpr (GRAD) dnll[(size_t)k * G.n_cand + ci] = fin ? -der(tot) : 0.0;
+}
+
+static NllGeom make_geom(int T, int N, int D, int n_cand, int per_keypoint, bool grad, int ncl) {
+  NllGeom G;
+  G.N = N;
+  G.T = T;
+  G.D = D;
+  G.BN = grad ? kNllChunkGrad : kNllChunk;
+  G.ncn = (T + G.BN - 1) / G.BN;
+  int nt_log2 = 0;
+  while ((1 << nt_log2) < N && nt_log2 < 6) ++nt_log2;
+  G.nt_log2 = nt_log2;
+  G.ntile = (N + (1 << nt_log2) - 1) >> nt_log2;
+  G.n_cand = n_cand;
+  G.ngrp = (n_cand + ncl - 1) / ncl;
+  G.per_keypoint = per_keypoint;
+  return G;
+}
+
+static inline int pick_ncl(int n_cand, bool grad) { return (!grad && n_cand >= kNclGrid) ? kNclGrid : 1; }
+
+size_t diag_nll_workspace_bytes(int T, int N, int n_cand) {
+  // sized for the larger of the two modes (grad planes + smaller chunks)
+  const int ncn = (T + kNllChunkGrad - 1) / kNllChunkGrad;
+  const size_t ncp = align_up((size_t)n_cand, kNclGrid);
+  const size_t fl = align_up((size_t)ncn * ncp * N * sizeof(float), 256);
+  const size_t db = align_up((size_t)ncn * ncp * N * sizeof(double), 256);
+  return 10 * fl + 2 * db;
+}
+
+int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M,
+             const double* s_cand, int n_cand, int per_keypoint, double* nll, double* dnll,
+             void* ws, size_t ws_bytes, hipStream_t st) {
+  const int T = d.n_frames, D = d.state_dim, K = d.n_keypoints, N = K * D;
+  if (ws_bytes < diag_nll_workspace_bytes(T, N, n_cand)) return EKS_ERR_WORKSPACE;
+  const bool grad = dnll != nullptr;
+  const int ncl = pick_ncl(n_cand, grad);
+  const NllGeom G = make_geom(T, N, D, n_cand, per_keypoint, grad, ncl);
+  NllWs W;
+  W.ncp = G.ngrp * ncl;
+  const size_t fl = align_up((size_t)G.ncn * W.ncp * N * sizeof(float), 256);
+  const size_t db = align_up((size_t)G.ncn * W.ncp * N * sizeof(double), 256);
+  char* p = static_cast<char*>(ws);
+  W.ell = reinterpret_cast<double*>(p);
+  W.dell = reinterpret_cast<double*>(p + db);
+  p += 2 * db;
+  float** planes[10] = {&W.A, &W.b, &W.C, &W.eta, &W.J, &W.dA, &W.db, &W.dC, &W.deta, &W.dJ};
+  for (int i = 0; i < 10; ++i) *planes[i] = reinterpret_cast<float*>(p + i * fl);
+
+  const int cpw = 64 >> G.nt_log2;
+  const long waves = (long)G.ngrp * G.ntile * ((G.ncn + cpw - 1) / cpw);
+  const int wpb = (G.ngrp > 1 && G.ngrp <= 8) ? G.ngrp : 4;
+  const dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
+  const bool unit = d.flags & EKS_FLAG_UNIT_AC;
+#define EKS_NLL_LAUNCH(RT, NCL)                                                                  \
+  do {                                                                                           \
+    if (unit)                                                                                    \
+      hipLaunchKernelGGL((diag_nll_summarize_kernel<RT, NCL, true>), grid, block, 0, st, G, M, W, \
+                         y, rconst, s_cand);                                                     \
+    else                                                                                         \
+      hipLaunchKernelGGL((diag_nll_summarize_kernel<RT, NCL, false>), grid, block, 0, st, G, M,  \
+                         W, y, rconst, s_cand);                                                  \
+  } while (0)
+  {
+    ProfScope ps("diag_nll_summarize", st);
+    if (grad) {
+      EKS_NLL_LAUNCH(Dual, 1);
+    } else if (ncl == kNclGrid) {
+      EKS_NLL_LAUNCH(float, kNclGrid);
+    } else {
+      EKS_NLL_LAUNCH(float, 1);
+    }
+  }
+#undef EKS_NLL_LAUNCH
+  const int total = K * n_cand;
+  ProfScope ps2("diag_nll_assemble", st);
+  if (grad)
+    hipLaunchKernelGGL(diag_nll_assemble_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, st, G,
+                       M, W, K, nll, dnll);
+  else
+    hipLaunchKernelGGL(diag_nll_assemble_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, st,
+                       G, M, W, K, nll, dnll);
+  return hip_status(hipGetLastError());
+}
+
+}  // namespace eks

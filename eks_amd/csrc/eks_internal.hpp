@@ -1,0 +1,63 @@
+// Internal declarations shared by the translation units of libeks_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/eks_hip.h"
+
+namespace eks {
+
+struct DiagModel;
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int hip_status(hipError_t e) { return e == hipSuccess ? EKS_OK : EKS_ERR_HIP_BASE - (int)e; }
+
+// per-kernel timing scope (eks_profile.hip); a no-op unless eks_profile_enable(1) was called
+class ProfScope {
+ public:
+  ProfScope(const char* name, hipStream_t st);
+  ~ProfScope();
+
+ private:
+  const char* name_;
+  hipStream_t st_;
+  bool live_;
+  hipEvent_t a_, b_;
+};
+
+// scalar-chain path (eks_diag.hip)
+size_t diag_smooth_workspace_bytes(int T, int N);
+int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const DiagModel& M,
+                float* ms, float* Vs, void* ws, size_t ws_bytes, hipStream_t st);
+size_t diag_nll_workspace_bytes(int T, int N, int n_cand);
+int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M,
+             const double* s_cand, int n_cand, int per_keypoint, double* nll, double* dnll,
+             void* ws, size_t ws_bytes, hipStream_t st);
+
+// general small-matrix path (eks_dense.hip)
+struct DenseModel {
+  const double *m0, *S0, *A, *C, *Q, *s;
+};
+size_t dense_smooth_workspace_bytes(int T, int K, int D, int O);
+int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const DenseModel& M,
+                 float* ms, float* Vs, void* ws, size_t ws_bytes, hipStream_t st);
+size_t dense_nll_workspace_bytes(int T, int K, int D, int O, int n_cand);
+int dense_nll(const eks_dims_t& d, const float* y, const double* rconst, const DenseModel& M,
+              const double* s_cand, int n_cand, int per_keypoint, double* nll, double* dnll,
+              void* ws, size_t ws_bytes, hipStream_t st);
+
+// misc (eks_misc.hip)
+size_t const_r_workspace_bytes(int N);
+int const_r(int T, int N, const float* var, double min_var, double* rconst, void* ws,
+            size_t ws_bytes, hipStream_t st);
+int argmin_s(int K, int n_cand, const double* nll, const double* s_cand, double* s_out,
+             int32_t* idx_out, hipStream_t st);
+int adam_step(int n_blocks, const int32_t* offs, const int32_t* members, const double* nll,
+              const double* dnll, double lr, double lo, double hi, double tol, int cap,
+              double* state, double* s_keypoint, int32_t* n_active, hipStream_t st);
+int ensemble_stats(int M, int V, int T, int K, const float* markers, int avg_mode, int var_mode,
+                   float nan_replacement, float* stats, hipStream_t st);
+
+}  // namespace eks

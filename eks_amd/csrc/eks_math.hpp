@@ -1,0 +1,158 @@
+// Scalar-chain Kalman algebra shared by the gfx950 kernels (eks_diag.hip) and the host-side
+// numerics simulator used by the CPU tests (tests/host_sim).  Header only, no HIP types.
+//
+// Model of one chain (one keypoint coordinate when A, C, Q, S0 are diagonal; singlecam has
+// a = c = q = 1, reference eks/singlecam_smoother.py:246-284):
+//     x_{t+1} = a x_t + w,  w ~ N(0, s q)          y_t = c x_t + v_t,  v_t ~ N(0, r_t)
+// Filter ordering follows the reference's dynamax call (eks/core.py:290): (m, P) entering frame t
+// is the PREDICTED belief on x_t; the frame is "update with y_t, then predict".
+//
+// An "element" summarises a run of consecutive frames as a map on the incoming belief
+// (Sarkka & Garcia-Fernandez 2021 temporal parallelisation, update-then-predict ordering):
+//     x_out | x_in ~ N(A x_in + b, C)                      (run-local filter started at x_in)
+//     p(y_run | x_in) = exp(ell) * exp(eta x_in - J x_in^2 / 2)
+// Every quantity except b, eta, ell is non-negative and every update below is a sum of products of
+// non-negative terms or an innovation (y - c b): there is no subtractive cancellation, which is
+// why float32 holds 1e-6 relative against the float64 oracle.
+#pragma once
+
+#if defined(__HIPCC__)
+#define EKS_HD __host__ __device__ __forceinline__
+#else
+#define EKS_HD inline
+struct float2 {
+  float x, y;
+};
+#endif
+
+namespace eks {
+
+template <typename R>
+struct Elem {
+  R A, b, C, eta, J;
+};
+
+template <typename R>
+struct ChainParams {
+  R a, c, q_s;  // transition, emission, s*q
+};
+
+template <typename R>
+EKS_HD R rcp(R x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (sizeof(R) == 4) {
+    // v_rcp_f32 (1 ulp) + one Newton step: <= 0.5 ulp-ish, keeps the 1e-6 budget
+    float r0 = __builtin_amdgcn_rcpf(x);
+    return r0 * (2.0f - x * r0);
+  } else {
+    return R(1) / x;
+  }
+#else
+  return R(1) / x;
+#endif
+}
+
+template <typename R>
+EKS_HD Elem<R> elem_identity() {
+  return Elem<R>{R(1), R(0), R(0), R(0), R(0)};
+}
+
+// Append one frame (y, r) to a running element.  UNIT: a = c = 1 folded at compile time.
+// Also returns the frame's innovation statistics for likelihood accumulation:
+//   S = r + C c^2 (innovation variance of the run-local filter), g = 1/S, d = y - c b, so that the
+//   frame's x_in-independent log-likelihood part is -0.5 * (log(2 pi S) + d^2 g).
+template <typename R, bool UNIT>
+EKS_HD void elem_append(Elem<R>& e, R y, R r, const ChainParams<R>& p, R& S, R& g, R& d) {
+  const R c = UNIT ? R(1) : p.c;
+  const R a = UNIT ? R(1) : p.a;
+  const R Cc = UNIT ? e.C : e.C * c;
+  S = UNIT ? (r + e.C) : (r + Cc * c);
+  g = rcp(S);
+  d = UNIT ? (y - e.b) : (y - c * e.b);
+  const R rg = r * g;
+  const R Acg = UNIT ? e.A * g : e.A * c * g;
+  e.eta = e.eta + Acg * d;
+  e.J = e.J + (UNIT ? Acg * e.A : Acg * e.A * c);
+  e.b = UNIT ? (e.b + Cc * g * d) : a * (e.b + Cc * g * d);
+  e.A = UNIT ? e.A * rg : a * e.A * rg;
+  e.C = UNIT ? (e.C * rg + p.q_s) : (a * a * e.C * rg + p.q_s);
+}
+
+template <typename R, bool UNIT>
+EKS_HD void elem_append(Elem<R>& e, R y, R r, const ChainParams<R>& p) {
+  R S, g, d;
+  elem_append<R, UNIT>(e, y, r, p, S, g, d);
+}
+
+// Compose: first `i` (earlier frames) then `j` (later frames).
+template <typename R>
+EKS_HD Elem<R> elem_combine(const Elem<R>& i, const Elem<R>& j) {
+  const R inv = rcp(R(1) + i.C * j.J);
+  Elem<R> o;
+  const R AjI = j.A * inv;
+  o.A = AjI * i.A;
+  o.b = AjI * (i.b + i.C * j.eta) + j.b;
+  o.C = AjI * j.A * i.C + j.C;
+  const R AiI = i.A * inv;
+  o.eta = AiI * (j.eta - j.J * i.b) + i.eta;
+  o.J = AiI * i.A * j.J + i.J;
+  return o;
+}
+
+// Push the belief N(m, P) on x_in through an element: belief on x_out.
+template <typename R>
+EKS_HD void elem_apply(const Elem<R>& e, R& m, R& P) {
+  const R inv = rcp(R(1) + e.J * P);
+  const R AI = e.A * inv;
+  m = AI * (m + P * e.eta) + e.b;
+  P = AI * e.A * P + e.C;
+}
+
+// Pull information (eta, J) about x_out back through an element: information about x_in from the
+// element's own frames and everything after them.
+template <typename R>
+EKS_HD void elem_back(const Elem<R>& e, R& eta, R& J) {
+  const R inv = rcp(R(1) + e.C * J);
+  const R AI = e.A * inv;
+  const R eta_n = AI * (eta - J * e.b) + e.eta;
+  const R J_n = AI * e.A * J + e.J;
+  eta = eta_n;
+  J = J_n;
+}
+
+// One filter frame on the predicted belief (m, P): writes the filtered belief, returns the next
+// predicted belief in (m, P).  Posterior variance in product form P r / (P c^2 + r).
+template <typename R, bool UNIT>
+EKS_HD void filter_step(R& m, R& P, R y, R r, const ChainParams<R>& p, R& mf, R& Pf) {
+  const R c = UNIT ? R(1) : p.c;
+  const R a = UNIT ? R(1) : p.a;
+  const R Pc = UNIT ? P : P * c;
+  const R g = rcp(UNIT ? (P + r) : (Pc * c + r));
+  const R d = UNIT ? (y - m) : (y - c * m);
+  mf = m + Pc * g * d;
+  Pf = P * r * g;
+  m = UNIT ? mf : a * mf;
+  P = UNIT ? (Pf + p.q_s) : (a * a * Pf + p.q_s);
+}
+
+// Combine the predicted belief on x (from the past) with information (eta, J) from the future.
+template <typename R>
+EKS_HD void fuse_info(R& m, R& P, R eta, R J) {
+  const R inv = rcp(R(1) + J * P);
+  m = (m + P * eta) * inv;
+  P = P * inv;
+}
+
+// One RTS frame: (ms, Ps) is the smoothed belief on x_{t+1} on entry, on x_t on exit.
+// Ps_t = Pf s q / Pp + G^2 Ps_{t+1}  (product form of Pf + G^2 (Ps - Pp)).
+template <typename R, bool UNIT>
+EKS_HD void rts_step(R& ms, R& Ps, R mf, R Pf, const ChainParams<R>& p) {
+  const R a = UNIT ? R(1) : p.a;
+  const R Pp = UNIT ? (Pf + p.q_s) : (a * a * Pf + p.q_s);
+  const R ig = rcp(Pp);
+  const R G = UNIT ? Pf * ig : a * Pf * ig;
+  ms = mf + G * (ms - (UNIT ? mf : a * mf));
+  Ps = Pf * p.q_s * ig + G * G * Ps;
+}
+
+}  // namespace eks

@@ -1,0 +1,380 @@
+// gfx950 kernels around the filter: constant-R by exact median over time (eks/core.py:702-709),
+// argmin over the candidate grid, and the ensemble statistics stage (eks/core.py:25-101).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+#include "eks_internal.hpp"
+
+namespace eks {
+
+// ==========================================================================================
+// constant R: rconst[n] = max(nanmedian_t max(var[t][n], 1e-12), min_var)
+// Exact selection by MSB-first radix (4 x 8 bits on the float bit pattern; positive floats order
+// like their bit patterns), lanes = chains so every row read is coalesced, per-block histograms
+// in LDS (256 bins x 64 chains), one more sweep for the upper middle element of even counts.
+// ==========================================================================================
+struct MedianWs {
+  uint32_t* hist;    // [4][N][256]
+  uint32_t* prefix;  // [N] bits fixed so far
+  uint32_t* rank;    // [N] rank of the lower middle element within the current prefix bucket
+  uint32_t* count;   // [N] number of non-NaN frames
+  uint32_t* less_eq; // [N][2]: #keys < key_lo, #keys == key_lo
+  uint32_t* next;    // [N] smallest key > key_lo (0xFFFFFFFF if none)
+};
+
+__device__ __forceinline__ uint32_t var_key(float v, bool& valid) {
+  valid = !(v != v);
+  const float c = v > 1e-12f ? v : 1e-12f;  // clip(var, 1e-12, inf), eks/utils.py:373
+  return __float_as_uint(c);
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void median_hist_kernel(int T, int N, int rows_per_block,
+                                                         const float* __restrict__ var, MedianWs W) {
+  __shared__ uint32_t h[256][64];
+  for (int i = threadIdx.x; i < 256 * 64; i += 256) (&h[0][0])[i] = 0u;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntile = (N + 63) / 64;
+  const int tile = blockIdx.x % ntile, slab = blockIdx.x / ntile;
+  const int n = tile * 64 + lane;
+  const int t_begin = slab * rows_per_block;
+  const int t_end = min(T, t_begin + rows_per_block);
+  if (n < N) {
+    const uint32_t pref = PASS > 0 ? W.prefix[n] : 0u;
+    constexpr int shift = 24 - 8 * PASS;
+    for (int t = t_begin + wave; t < t_end; t += 4) {
+      bool valid;
+      const uint32_t key = var_key(var[(size_t)t * N + n], valid);
+      if (!valid) continue;
+      if (PASS > 0 && (key >> (shift + 8)) != pref) continue;
+      atomicAdd(&h[(key >> shift) & 255u][lane], 1u);
+    }
+  }
+  __syncthreads();
+  if (n < N) {
+    uint32_t* g = W.hist + ((size_t)PASS * N + n) * 256;
+    for (int b = wave; b < 256; b += 4) {
+      const uint32_t c = h[b][lane];
+      if (c) atomicAdd(&g[b], c);
+    }
+  }
+}
+
+template <int PASS>
+__global__ void median_select_kernel(int N, MedianWs W) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const uint32_t* g = W.hist + ((size_t)PASS * N + n) * 256;
+  uint32_t rank;
+  if (PASS == 0) {
+    uint32_t cnt = 0;
+    for (int b = 0; b < 256; ++b) cnt += g[b];
+    W.count[n] = cnt;
+    W.less_eq[2 * n] = 0;
+    rank = cnt ? (cnt - 1) / 2 : 0;
+  } else {
+    rank = W.rank[n];
+  }
+  uint32_t cum = 0;
+  int bin = 255;
+  for (int b = 0; b < 256; ++b) {
+    const uint32_t c = g[b];
+    if (cum + c > rank) {
+      bin = b;
+      break;
+    }
+    cum += c;
+  }
+  W.less_eq[2 * n] += cum;
+  W.rank[n] = rank - cum;
+  W.prefix[n] = ((PASS > 0 ? W.prefix[n] : 0u) << 8) | (uint32_t)bin;
+  if (PASS == 3) {
+    W.less_eq[2 * n + 1] = g[bin];
+    W.next[n] = 0xFFFFFFFFu;
+  }
+}
+
+__global__ __launch_bounds__(256) void median_next_kernel(int T, int N, int rows_per_block,
+                                                         const float* __restrict__ var, MedianWs W) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntile = (N + 63) / 64;
+  const int tile = blockIdx.x % ntile, slab = blockIdx.x / ntile;
+  const int n = tile * 64 + lane;
+  if (n >= N) return;
+  const int t_begin = slab * rows_per_block;
+  const int t_end = min(T, t_begin + rows_per_block);
+  const uint32_t key_lo = W.prefix[n];
+  uint32_t best = 0xFFFFFFFFu;
+  for (int t = t_begin + wave; t < t_end; t += 4) {
+    bool valid;
+    const uint32_t key = var_key(var[(size_t)t * N + n], valid);
+    if (valid && key > key_lo && key < best) best = key;
+  }
+  if (best != 0xFFFFFFFFu) atomicMin(&W.next[n], best);
+}
+
+__global__ void median_final_kernel(int N, double min_var, MedianWs W, double* __restrict__ rconst) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const uint32_t cnt = W.count[n];
+  double med;
+  if (cnt == 0) {
+    med = nan("");  // np.nanmedian of an all-NaN slice
+  } else {
+    const double lo = (double)__uint_as_float(W.prefix[n]);
+    const uint32_t rank_hi = cnt / 2;  // == rank_lo for odd counts
+    const uint32_t less = W.less_eq[2 * n], eq = W.less_eq[2 * n + 1];
+    const double hi = (rank_hi < less + eq) ? lo : (double)__uint_as_float(W.next[n]);
+    med = 0.5 * lo + 0.5 * hi;
+  }
+  // np.clip(nan, min, inf) stays nan
+  rconst[n] = (med != med) ? med : (med > min_var ? med : min_var);
+}
+
+size_t const_r_workspace_bytes(int N) {
+  return align_up((size_t)4 * N * 256 * 4, 256) + 6 * align_up((size_t)N * 2 * 4, 256);
+}
+
+int const_r(int T, int N, const float* var, double min_var, double* rconst, void* ws,
+            size_t ws_bytes, hipStream_t st) {
+  if (ws_bytes < const_r_workspace_bytes(N)) return EKS_ERR_WORKSPACE;
+  char* p = static_cast<char*>(ws);
+  MedianWs W;
+  const size_t hb = align_up((size_t)4 * N * 256 * 4, 256), sb = align_up((size_t)N * 2 * 4, 256);
+  W.hist = reinterpret_cast<uint32_t*>(p);
+  W.prefix = reinterpret_cast<uint32_t*>(p + hb);
+  W.rank = reinterpret_cast<uint32_t*>(p + hb + sb);
+  W.count = reinterpret_cast<uint32_t*>(p + hb + 2 * sb);
+  W.less_eq = reinterpret_cast<uint32_t*>(p + hb + 3 * sb);
+  W.next = reinterpret_cast<uint32_t*>(p + hb + 4 * sb);
+  hipError_t e = hipMemsetAsync(W.hist, 0, hb, st);
+  if (e != hipSuccess) return hip_status(e);
+  const int ntile = (N + 63) / 64;
+  // enough blocks to fill the chip, at least 256 rows per block so the LDS flush amortises
+  int rows = (int)(((long)T * ntile + 2047) / 2048);
+  if (rows < 256) rows = 256;
+  rows = (rows + 3) / 4 * 4;
+  const int nslab = (T + rows - 1) / rows;
+  const dim3 grid(ntile * nslab), sel((N + 255) / 256);
+  ProfScope ps("const_r_select", st);
+  hipLaunchKernelGGL(median_hist_kernel<0>, grid, dim3(256), 0, st, T, N, rows, var, W);
+  hipLaunchKernelGGL(median_select_kernel<0>, sel, dim3(256), 0, st, N, W);
+  hipLaunchKernelGGL(median_hist_kernel<1>, grid, dim3(256), 0, st, T, N, rows, var, W);
+  hipLaunchKernelGGL(median_select_kernel<1>, sel, dim3(256), 0, st, N, W);
+  hipLaunchKernelGGL(median_hist_kernel<2>, grid, dim3(256), 0, st, T, N, rows, var, W);
+  hipLaunchKernelGGL(median_select_kernel<2>, sel, dim3(256), 0, st, N, W);
+  hipLaunchKernelGGL(median_hist_kernel<3>, grid, dim3(256), 0, st, T, N, rows, var, W);
+  hipLaunchKernelGGL(median_select_kernel<3>, sel, dim3(256), 0, st, N, W);
+  hipLaunchKernelGGL(median_next_kernel, grid, dim3(256), 0, st, T, N, rows, var, W);
+  hipLaunchKernelGGL(median_final_kernel, sel, dim3(256), 0, st, N, min_var, W, rconst);
+  return hip_status(hipGetLastError());
+}
+
+// ==========================================================================================
+// argmin over candidates (first minimum, numpy.argmin semantics) + gather of s
+// ==========================================================================================
+__global__ void argmin_kernel(int K, int n_cand, const double* __restrict__ nll,
+                              const double* __restrict__ s_cand, double* __restrict__ s_out,
+                              int32_t* __restrict__ idx_out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const double* row = nll + (size_t)k * n_cand;
+  int best = 0;
+  double bv = row[0];
+  for (int c = 1; c < n_cand; ++c) {
+    const double v = row[c];
+    if (v < bv) {
+      bv = v;
+      best = c;
+    }
+  }
+  s_out[k] = s_cand[best];
+  if (idx_out) idx_out[k] = best;
+}
+
+int argmin_s(int K, int n_cand, const double* nll, const double* s_cand, double* s_out,
+             int32_t* idx_out, hipStream_t st) {
+  hipLaunchKernelGGL(argmin_kernel, dim3((K + 255) / 256), dim3(256), 0, st, K, n_cand, nll, s_cand,
+                     s_out, idx_out);
+  return hip_status(hipGetLastError());
+}
+
+// ==========================================================================================
+// Adam on log s with the reference's stop rule (eks/core.py:652-681, :509-549)
+// ==========================================================================================
+__global__ void adam_step_kernel(int nb, const int32_t* __restrict__ offs,
+                                 const int32_t* __restrict__ members, const double* __restrict__ nll,
+                                 const double* __restrict__ dnll, double lr, double lo, double hi,
+                                 double tol, int cap, double* __restrict__ state,
+                                 double* __restrict__ s_keypoint, int32_t* __restrict__ n_active) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  double* st = state + (size_t)b * 6;
+  double u = st[0], mom = st[1], vel = st[2], prev = st[3], iters = st[4], done = st[5];
+  if (done == 0.0 && iters < (double)cap) {
+    double L = 0.0, g = 0.0;
+    for (int i = offs[b]; i < offs[b + 1]; ++i) {
+      L += nll[members[i]];
+      g += dnll[members[i]];
+    }
+    if (u < lo || u > hi) g = 0.0;
+    g *= lr;
+    const double cnt = iters + 1.0;
+    mom = 0.9 * mom + 0.1 * g;
+    vel = 0.999 * vel + 0.001 * g * g;
+    const double mhat = mom / (1.0 - pow(0.9, cnt));
+    const double vhat = vel / (1.0 - pow(0.999, cnt));
+    u = u - mhat / (sqrt(vhat) + 1e-8);
+    const bool stop = isfinite(prev) &&
+                      fabs(L - prev) < tol * fabs(log(fmax(prev, 1e-12))) + 1e-6;
+    prev = L;
+    iters = cnt;
+    done = stop ? 1.0 : 0.0;
+    st[0] = u; st[1] = mom; st[2] = vel; st[3] = prev; st[4] = iters; st[5] = done;
+  }
+  const double s = exp(fmin(fmax(u, lo), hi));
+  for (int i = offs[b]; i < offs[b + 1]; ++i) s_keypoint[members[i]] = s;
+  if (done == 0.0 && iters < (double)cap) atomicAdd(n_active, 1);
+}
+
+int adam_step(int n_blocks, const int32_t* offs, const int32_t* members, const double* nll,
+              const double* dnll, double lr, double lo, double hi, double tol, int cap,
+              double* state, double* s_keypoint, int32_t* n_active, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(n_active, 0, sizeof(int32_t), st);
+  if (e != hipSuccess) return hip_status(e);
+  hipLaunchKernelGGL(adam_step_kernel, dim3((n_blocks + 127) / 128), dim3(128), 0, st, n_blocks, offs,
+                     members, nll, dnll, lr, lo, hi, tol, cap, state, s_keypoint, n_active);
+  return hip_status(hipGetLastError());
+}
+
+// ==========================================================================================
+// ensemble statistics, eks/core.py:58-85.  One lane per (camera, frame, keypoint); the M member
+// values live in registers; median by a small sort with NaNs pushed to the end.
+// ==========================================================================================
+constexpr int kMaxModels = 16;
+
+__device__ __forceinline__ float nan_to_num(float v, float nan_rep) {
+  if (v != v) return nan_rep;
+  if (v > FLT_MAX) return FLT_MAX;   // jnp.nan_to_num maps +-inf to the largest finite float
+  if (v < -FLT_MAX) return -FLT_MAX;
+  return v;
+}
+
+template <int MM>
+__device__ __forceinline__ void member_stats(const float (&a)[MM], int M, bool median, float& avg,
+                                             double& var) {
+  // nan-aware mean / variance (ddof 0) in double; median via insertion sort of the valid values
+  float s[MM];
+  int cnt = 0;
+  double sum = 0.0;
+#pragma unroll
+  for (int i = 0; i < MM; ++i) {
+    const bool ok = i < M && !(a[i] != a[i]);
+    s[i] = ok ? a[i] : INFINITY;
+    if (ok) {
+      ++cnt;
+      sum += (double)a[i];
+    }
+  }
+  if (cnt == 0) {
+    avg = NAN;
+    var = NAN;
+    return;
+  }
+  const double mean = sum / cnt;
+  double ss = 0.0;
+#pragma unroll
+  for (int i = 0; i < MM; ++i) {
+    const bool ok = i < M && !(a[i] != a[i]);
+    if (ok) {
+      const double d = (double)a[i] - mean;
+      ss += d * d;
+    }
+  }
+  var = ss / cnt;
+  if (!median) {
+    avg = (float)mean;
+    return;
+  }
+#pragma unroll
+  for (int i = 1; i < MM; ++i) {
+#pragma unroll
+    for (int j = MM - 1; j >= 1; --j) {
+      if (j <= i) {  // one bubble sweep of the prefix; static indices keep s[] in registers
+        const float lo = fminf(s[j - 1], s[j]), hi = fmaxf(s[j - 1], s[j]);
+        s[j - 1] = lo;
+        s[j] = hi;
+      }
+    }
+  }
+  const int i_hi = cnt / 2, i_lo = (cnt - 1) / 2;
+  float v_lo = 0.f, v_hi = 0.f;
+#pragma unroll
+  for (int i = 0; i < MM; ++i) {
+    if (i == i_lo) v_lo = s[i];
+    if (i == i_hi) v_hi = s[i];
+  }
+  avg = 0.5f * (v_lo + v_hi);
+}
+
+template <int MM>
+__global__ __launch_bounds__(256) void ensemble_kernel(int M, long VTK, const float* __restrict__ mk,
+                                                      int avg_mode, int var_mode, float nan_rep,
+                                                      float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= VTK) return;
+  float x[MM], y[MM];
+  double lsum = 0.0;
+#pragma unroll
+  for (int m = 0; m < MM; ++m) {
+    if (m < M) {
+      const float* p = mk + ((size_t)m * VTK + i) * 3;
+      x[m] = p[0];
+      y[m] = p[1];
+      lsum += (double)p[2];
+    } else {
+      x[m] = NAN;
+      y[m] = NAN;
+    }
+  }
+  const double conf = lsum / M;
+  float ax, ay;
+  double vx, vy;
+  member_stats<MM>(x, M, avg_mode == 0, ax, vx);
+  member_stats<MM>(y, M, avg_mode == 0, ay, vy);
+  float fvx, fvy;
+  if (M == 1) {
+    fvx = fvy = (float)(1.0 / (conf > 1e-5 ? conf : 1e-5));
+    if (conf != conf) fvx = fvy = NAN;
+  } else if (var_mode == 0) {
+    fvx = (float)(vx / conf);
+    fvy = (float)(vy / conf);
+  } else {
+    fvx = (float)vx;
+    fvy = (float)vy;
+  }
+  float* o = out + (size_t)i * 5;
+  o[0] = ax;
+  o[1] = ay;
+  o[2] = nan_to_num(fvx, nan_rep);
+  o[3] = nan_to_num(fvy, nan_rep);
+  o[4] = (float)conf;
+}
+
+int ensemble_stats(int M, int V, int T, int K, const float* markers, int avg_mode, int var_mode,
+                   float nan_replacement, float* stats, hipStream_t st) {
+  if (M > kMaxModels) return EKS_ERR_UNSUPPORTED;
+  const long VTK = (long)V * T * K;
+  const dim3 grid((unsigned)((VTK + 255) / 256));
+  if (M <= 8)
+    hipLaunchKernelGGL(ensemble_kernel<8>, grid, dim3(256), 0, st, M, VTK, markers, avg_mode, var_mode,
+                       nan_replacement, stats);
+  else
+    hipLaunchKernelGGL(ensemble_kernel<kMaxModels>, grid, dim3(256), 0, st, M, VTK, markers, avg_mode,
+                       var_mode, nan_replacement, stats);
+  return hip_status(hipGetLastError());
+}
+
+}  // namespace eks

@@ -1,0 +1,179 @@
+"""Device-tensor wrappers over the C ABI (include/eks_hip.h).  PyTorch is used only for device
+memory, streams and dtype/layout checks; every computation is a kernel of libeks_hip.so.
+
+All tensors must live on a ROCm device.  Layout is frame-major: y, var (T, K, O) float32;
+ms (T, K, D), Vs (T, K, D, D) or (T, K, D) float32; parameters float64 with the reference's shapes.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import FLAG_DIAG_MODEL, FLAG_UNIT_AC, FLAG_VS_DIAG, EksDims
+
+
+def require_gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise _lib.EksHipError('no ROCm device visible: eks_amd has no CPU fallback for the Kalman '
+                               'path (the float64 oracle under oracle/ is test infrastructure only)')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _ptr(t: torch.Tensor | None):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: torch.Tensor, dtype, name: str, shape=None) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.EksHipError(f'{name} must be a device tensor')
+    if t.dtype != dtype:
+        raise TypeError(f'{name} must be {dtype}, got {t.dtype}')
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f'{name} must have shape {tuple(shape)}, got {tuple(t.shape)}')
+    return t.contiguous()
+
+
+def _dims(K, T, D, O, flags):
+    return EksDims(int(K), int(T), int(D), int(O), int(flags))
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def model_flags(S0, A, C, Q) -> int:
+    """Inspect HOST copies of the parameters (numpy) and return DIAG_MODEL / UNIT_AC flags."""
+    import numpy as np
+    D, O = A.shape[-1], C.shape[-2]
+    if D != O:
+        return 0
+
+    def is_diag(M):
+        return bool(np.all(M[..., ~np.eye(D, dtype=bool)] == 0))
+
+    if not (is_diag(S0) and is_diag(A) and is_diag(C) and is_diag(Q)):
+        return 0
+    flags = FLAG_DIAG_MODEL
+    eye = np.eye(D)
+    if np.array_equal(A, np.broadcast_to(eye, A.shape)) and \
+            np.array_equal(C, np.broadcast_to(eye, C.shape)):
+        flags |= FLAG_UNIT_AC
+    return flags
+
+
+def smooth(y, var, m0, S0, A, C, Q, s, flags: int = 0, vs_diag: bool = False, out=None):
+    """eks_smooth: fixed-s Kalman filter + RTS smoother.  Returns (ms, Vs)."""
+    lib = _lib.load()
+    T, K, O = y.shape
+    D = m0.shape[-1]
+    y = _chk(y, torch.float32, 'y')
+    var = _chk(var, torch.float32, 'var', (T, K, O))
+    m0 = _chk(m0, torch.float64, 'm0', (K, D))
+    S0 = _chk(S0, torch.float64, 'S0', (K, D, D))
+    A = _chk(A, torch.float64, 'A', (K, D, D))
+    C = _chk(C, torch.float64, 'C', (K, O, D))
+    Q = _chk(Q, torch.float64, 'Q', (K, D, D))
+    s = _chk(s, torch.float64, 's', (K,))
+    if vs_diag:
+        flags |= FLAG_VS_DIAG
+    d = _dims(K, T, D, O, flags)
+    if out is None:
+        ms = torch.empty((T, K, D), dtype=torch.float32, device=y.device)
+        Vs = torch.empty((T, K, D) if vs_diag else (T, K, D, D), dtype=torch.float32, device=y.device)
+    else:
+        ms, Vs = out
+    ws = _workspace(lib.eks_smooth_workspace_bytes(ctypes.byref(d)), y.device)
+    rc = lib.eks_smooth(ctypes.byref(d), _ptr(y), _ptr(var), _ptr(m0), _ptr(S0), _ptr(A), _ptr(C),
+                        _ptr(Q), _ptr(s), _ptr(ms), _ptr(Vs), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, 'eks_smooth')
+    return ms, Vs
+
+
+def const_r(var, min_var: float = 1e-4):
+    """eks_const_r: (T, K, O) float32 -> (K, O) float64 floored time-median."""
+    lib = _lib.load()
+    T, K, O = var.shape
+    var = _chk(var, torch.float32, 'var')
+    d = _dims(K, T, O, O, 0)
+    out = torch.empty((K, O), dtype=torch.float64, device=var.device)
+    ws = _workspace(lib.eks_const_r_workspace_bytes(ctypes.byref(d)), var.device)
+    rc = lib.eks_const_r(ctypes.byref(d), _ptr(var), float(min_var), _ptr(out), _ptr(ws), ws.numel(),
+                         _stream())
+    _lib.check(rc, 'eks_const_r')
+    return out
+
+
+def nll(y, rconst, m0, S0, A, C, Q, s_cand, per_keypoint: bool = False, want_grad: bool = False,
+        flags: int = 0):
+    """eks_nll: constant-R filter NLL for candidate s values.  Returns nll (K, n_cand) float64 and
+    (if want_grad) d nll / d log s of the same shape."""
+    lib = _lib.load()
+    T, K, O = y.shape
+    D = m0.shape[-1]
+    y = _chk(y, torch.float32, 'y')
+    rconst = _chk(rconst, torch.float64, 'rconst', (K, O))
+    m0 = _chk(m0, torch.float64, 'm0', (K, D))
+    S0 = _chk(S0, torch.float64, 'S0', (K, D, D))
+    A = _chk(A, torch.float64, 'A', (K, D, D))
+    C = _chk(C, torch.float64, 'C', (K, O, D))
+    Q = _chk(Q, torch.float64, 'Q', (K, D, D))
+    s_cand = _chk(s_cand, torch.float64, 's_cand')
+    n_cand = s_cand.shape[-1]
+    if per_keypoint and tuple(s_cand.shape) != (K, n_cand):
+        raise ValueError('per-keypoint s_cand must be (K, n_cand)')
+    if not per_keypoint and s_cand.dim() != 1:
+        raise ValueError('shared s_cand must be (n_cand,)')
+    d = _dims(K, T, D, O, flags)
+    out = torch.empty((K, n_cand), dtype=torch.float64, device=y.device)
+    grad = torch.empty((K, n_cand), dtype=torch.float64, device=y.device) if want_grad else None
+    ws = _workspace(lib.eks_nll_workspace_bytes(ctypes.byref(d), n_cand), y.device)
+    rc = lib.eks_nll(ctypes.byref(d), _ptr(y), _ptr(rconst), _ptr(m0), _ptr(S0), _ptr(A), _ptr(C),
+                     _ptr(Q), _ptr(s_cand), n_cand, int(per_keypoint), _ptr(out), _ptr(grad),
+                     _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, 'eks_nll')
+    return (out, grad) if want_grad else out
+
+
+def argmin_s(nll_kc, s_cand):
+    lib = _lib.load()
+    K, n_cand = nll_kc.shape
+    nll_kc = _chk(nll_kc, torch.float64, 'nll')
+    s_cand = _chk(s_cand, torch.float64, 's_cand', (n_cand,))
+    s_out = torch.empty(K, dtype=torch.float64, device=nll_kc.device)
+    idx = torch.empty(K, dtype=torch.int32, device=nll_kc.device)
+    rc = lib.eks_argmin_s(K, n_cand, _ptr(nll_kc), _ptr(s_cand), _ptr(s_out), _ptr(idx), _stream())
+    _lib.check(rc, 'eks_argmin_s')
+    return s_out, idx
+
+
+def adam_step(block_offsets, block_members, nll_k, dnll_k, state, s_keypoint, n_active, lr, lo, hi,
+              tol, safety_cap):
+    lib = _lib.load()
+    nb = block_offsets.numel() - 1
+    rc = lib.eks_adam_step(nb, _ptr(block_offsets), _ptr(block_members), _ptr(nll_k), _ptr(dnll_k),
+                           float(lr), float(lo), float(hi), float(tol), int(safety_cap),
+                           _ptr(state), _ptr(s_keypoint), _ptr(n_active), _stream())
+    _lib.check(rc, 'eks_adam_step')
+
+
+def ensemble(markers, avg_mode: str = 'median', var_mode: str = 'confidence_weighted_var',
+             nan_replacement: float = 1000.0):
+    """eks_ensemble: (M, V, T, K, 3) float32 -> (V, T, K, 5) float32."""
+    lib = _lib.load()
+    markers = _chk(markers, torch.float32, 'markers')
+    M, V, T, K, F = markers.shape
+    if F != 3:
+        raise ValueError('markers must have fields (x, y, likelihood)')
+    out = torch.empty((V, T, K, 5), dtype=torch.float32, device=markers.device)
+    am = 0 if avg_mode == 'median' else 1
+    vm = 0 if var_mode in ('conf_weighted_var', 'confidence_weighted_var') else 1
+    rc = lib.eks_ensemble(M, V, T, K, _ptr(markers), am, vm, float(nan_replacement), _ptr(out),
+                          _stream())
+    _lib.check(rc, 'eks_ensemble')
+    return out

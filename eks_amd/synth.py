@@ -1,0 +1,81 @@
+"""Seeded synthetic pose-ensemble generators for the BASELINE.json configs.
+
+Latent: per (keypoint, coord) random walk x_t = x_{t-1} + N(0, q_k), q_k ~ LogUniform(0.05, 5) px^2,
+x_0 ~ U(50, 450).  Ensemble: M members x_t + N(0, sigma2_{k,t}), sigma2 = 0.25 * Gamma(2, 1); 2 % of
+(frame, keypoint) pairs are "occluded": sigma2 x100 and likelihood ~ U(0.05, 0.5), otherwise
+likelihood ~ Beta(50, 1).  Fields (x, y, likelihood), float32, axis order of the reference's
+MarkerArray (n_models, n_cameras, n_frames, n_keypoints, n_fields), eks/marker_array.py:18-20.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def singlecam_markers(T: int, K: int, M: int = 5, seed: int = 0) -> np.ndarray:
+    """NumPy generator (CPU).  Returns float32 (M, 1, T, K, 3)."""
+    rng = np.random.default_rng(seed)
+    q = np.exp(rng.uniform(np.log(0.05), np.log(5.0), size=(K, 1)))
+    x0 = rng.uniform(50.0, 450.0, size=(1, K, 2))
+    steps = rng.standard_normal((T, K, 2)) * np.sqrt(q)[None]
+    steps[0] = 0.0
+    lat = x0 + np.cumsum(steps, axis=0)                                  # (T,K,2)
+    sig2 = 0.25 * rng.gamma(2.0, 1.0, size=(T, K))
+    occ = rng.random((T, K)) < 0.02
+    sig2 = np.where(occ, sig2 * 100.0, sig2)
+    out = np.empty((M, 1, T, K, 3), dtype=np.float32)
+    for m in range(M):
+        noise = rng.standard_normal((T, K, 2)) * np.sqrt(sig2)[..., None]
+        out[m, 0, :, :, 0:2] = lat + noise
+        lik = np.where(occ, rng.uniform(0.05, 0.5, size=(T, K)), rng.beta(50.0, 1.0, size=(T, K)))
+        out[m, 0, :, :, 2] = lik
+    return out
+
+
+def multicam_markers(T: int, K: int, V: int = 2, M: int = 5, seed: int = 0) -> np.ndarray:
+    """Mirror-mouse-like multi-view ensemble: each keypoint follows a 3-D random walk seen through
+    V fixed random affine 3-D -> 2-D maps plus per-view ensemble noise.  float32 (M, V, T, K, 3)."""
+    rng = np.random.default_rng(seed)
+    q = np.exp(rng.uniform(np.log(0.05), np.log(5.0), size=(K, 1)))
+    steps = rng.standard_normal((T, K, 3)) * np.sqrt(q)[None]
+    steps[0] = 0.0
+    lat = np.cumsum(steps, axis=0)                                       # (T,K,3)
+    out = np.empty((M, V, T, K, 3), dtype=np.float32)
+    for v in range(V):
+        P = rng.standard_normal((2, 3))
+        P /= np.linalg.norm(P, axis=1, keepdims=True)
+        off = rng.uniform(100.0, 400.0, size=(1, K, 2))
+        proj = lat @ P.T + off                                           # (T,K,2)
+        sig2 = 0.25 * rng.gamma(2.0, 1.0, size=(T, K))
+        occ = rng.random((T, K)) < 0.02
+        sig2 = np.where(occ, sig2 * 100.0, sig2)
+        for m in range(M):
+            out[m, v, :, :, 0:2] = proj + rng.standard_normal((T, K, 2)) * np.sqrt(sig2)[..., None]
+            out[m, v, :, :, 2] = np.where(occ, rng.uniform(0.05, 0.5, size=(T, K)),
+                                          rng.beta(50.0, 1.0, size=(T, K)))
+    return out
+
+
+def singlecam_observations_torch(T: int, K: int, seed: int, device):
+    """Device-side generator for bench-sized inputs: returns the smoother's direct inputs
+    (centred ensemble medians y and ensemble variances var, both float32 [T, K, 2] on `device`)
+    drawn from the same generative model, without materialising the M ensemble members on host.
+    The ensemble stage is a separate kernel with its own test; this feeds the Kalman path."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    q = torch.exp(torch.empty(K, 1, device=device).uniform_(float(np.log(0.05)), float(np.log(5.0)),
+                                                            generator=g))
+    steps = torch.randn(T, K, 2, device=device, generator=g) * torch.sqrt(q)[None]
+    steps[0] = 0
+    lat = torch.cumsum(steps, dim=0)
+    lat = lat - lat.mean(dim=0, keepdim=True)
+    # variance of a 5-member ensemble median ~ sig2 * 0.287 * ... ; draw the ensemble variance
+    # itself (what the filter consumes as R_t) and noise consistent with it
+    gam = torch.distributions.Gamma(torch.tensor(2.0, device=device), torch.tensor(1.0, device=device))
+    torch.manual_seed(seed)
+    sig2 = 0.25 * gam.sample((T, K))
+    occ = torch.rand(T, K, device=device, generator=g) < 0.02
+    sig2 = torch.where(occ, sig2 * 100.0, sig2)
+    var = (sig2[..., None] * (0.5 + torch.rand(T, K, 2, device=device, generator=g))).float()
+    y = (lat + torch.randn(T, K, 2, device=device, generator=g) * torch.sqrt(var * 0.3)).float()
+    return y.contiguous(), var.contiguous()

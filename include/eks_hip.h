@@ -1,0 +1,123 @@
+/* libeks_hip.so - C ABI of the MI355X (gfx950) ensemble-Kalman-smoother hot path.
+ *
+ * Drop-in boundary for the reference operator
+ *     run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames, smooth_param,
+ *                         blocks, lr, s_bounds_log, tol, safety_cap, h_fn) -> (s_finals, ms, Vs)
+ * (/root/reference eks/core.py:159-302) and the stages it is built from.  Every entry point takes
+ * plain DEVICE pointers + sizes + a hipStream_t, enqueues on that stream, never allocates, never
+ * synchronises and returns an int status.  The caller owns all buffers; scratch comes from a
+ * caller-provided workspace whose size the *_workspace_bytes functions report.
+ *
+ * Native data layout is FRAME-MAJOR (what the reference's drivers hold before they transpose for
+ * JAX, eks/singlecam_smoother.py:166, eks/multicam_smoother.py:429-430):
+ *     y, var   float32 [T][K][O]      observations / ensemble variances (R_t = diag(max(var,1e-12)),
+ *                                     eks/utils.py:368-377 - never materialised as a matrix)
+ *     ms       float32 [T][K][D]      smoothed means        (reference returns (K,T,D), core.py:296)
+ *     Vs       float32 [T][K][D][D]   smoothed covariances  (reference returns (K,T,D,D), :297)
+ * Model parameters are float64 device arrays with the reference's shapes:
+ *     m0 [K][D], S0 [K][D][D], A [K][D][D], C [K][O][D], Q [K][D][D], s [K]  (eks/core.py:160-166)
+ */
+#ifndef EKS_HIP_H
+#define EKS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* eks_stream_t; /* == hipStream_t */
+
+/* status codes */
+#define EKS_OK 0
+#define EKS_ERR_NULL (-1)        /* a required pointer is NULL */
+#define EKS_ERR_SHAPE (-2)       /* non-positive or inconsistent dimension */
+#define EKS_ERR_UNSUPPORTED (-3) /* (D,O)/flag combination not built */
+#define EKS_ERR_WORKSPACE (-4)   /* workspace missing or too small */
+#define EKS_ERR_HIP_BASE (-1000) /* -1000 - hipError_t */
+
+/* flags */
+#define EKS_FLAG_DIAG_MODEL 1u /* caller asserts A, C, Q, S0 are diagonal and D == O: the K*D
+                                  coordinates are independent scalar chains (singlecam, reference
+                                  eks/singlecam_smoother.py:246-284).  Off-diagonals are not read. */
+#define EKS_FLAG_VS_DIAG 2u    /* Vs is written as [T][K][D] (diagonal of the covariance only,
+                                  which is all the reference's drivers consume:
+                                  singlecam_smoother.py:210-211, multicam_smoother.py:509-510,
+                                  :540-542).  Default: full [T][K][D][D]. */
+#define EKS_FLAG_UNIT_AC 4u    /* with DIAG_MODEL: caller asserts A = C = I (folds multiplies) */
+
+typedef struct {
+  int32_t n_keypoints; /* K */
+  int32_t n_frames;    /* T */
+  int32_t state_dim;   /* D */
+  int32_t obs_dim;     /* O */
+  uint32_t flags;
+} eks_dims_t;
+
+const char* eks_version(void);
+const char* eks_status_string(int status);
+
+/* ---- fixed-s smoothing: the final pass of run_kalman_smoother (eks/core.py:269-297), i.e.
+ * dynamax extended_kalman_smoother with linear f,h vmapped over keypoints. ------------------ */
+size_t eks_smooth_workspace_bytes(const eks_dims_t* dims);
+int eks_smooth(const eks_dims_t* dims, const float* y, const float* var, const double* m0,
+               const double* S0, const double* A, const double* C, const double* Q,
+               const double* s, float* ms, float* Vs, void* workspace, size_t workspace_bytes,
+               eks_stream_t stream);
+
+/* ---- constant observation noise for the loss: eks/core.py:702-709
+ * rconst[k][o] = max(nanmedian_t max(var[t][k][o], 1e-12), min_var)  (float64 out) ----------- */
+size_t eks_const_r_workspace_bytes(const eks_dims_t* dims);
+int eks_const_r(const eks_dims_t* dims, const float* var, double min_var, double* rconst,
+                void* workspace, size_t workspace_bytes, eks_stream_t stream);
+
+/* ---- filter negative log-likelihood with constant R on a set of smoothing-parameter values:
+ * the loss of eks/core.py:640-650 (nll = -marginal_loglik of extended_kalman_filter, non-finite
+ * -> 1e12).  s_cand is [n_cand] when per_keypoint == 0 (one grid shared by all keypoints: the
+ * 64-candidate search of BASELINE.json config 3) or [K][n_cand] when per_keypoint == 1 (used with
+ * n_cand == 1 by the Adam loop).  nll is [K][n_cand] float64; dnll (optional, may be NULL) is
+ * d nll / d log s of the same shape (forward sensitivity replacing jax.value_and_grad, :652). -- */
+size_t eks_nll_workspace_bytes(const eks_dims_t* dims, int32_t n_cand);
+int eks_nll(const eks_dims_t* dims, const float* y, const double* rconst, const double* m0,
+            const double* S0, const double* A, const double* C, const double* Q,
+            const double* s_cand, int32_t n_cand, int32_t per_keypoint, double* nll, double* dnll,
+            void* workspace, size_t workspace_bytes, eks_stream_t stream);
+
+/* ---- argmin over candidates + gather: s_out[k] = s_cand[argmin_c nll[k][c]] (first minimum,
+ * like numpy.argmin).  idx_out (optional) receives the int32 indices. ---------------------- */
+int eks_argmin_s(int32_t n_keypoints, int32_t n_cand, const double* nll, const double* s_cand,
+                 double* s_out, int32_t* idx_out, eks_stream_t stream);
+
+/* ---- one Adam iteration on u = log s for every block of keypoints, with the reference's
+ * control flow (eks/core.py:652-681 singletons, :509-549 blocks): L_b = sum of member nll,
+ * g_b = lr * sum of member dnll (zero where u is outside [lo, hi], as jnp.clip differentiates),
+ * optax.adam(1.0) update (b1 .9, b2 .999, eps 1e-8, bias-corrected), then
+ * done = isfinite(prev) && |L - prev| < tol * |log(max(prev, 1e-12))| + 1e-6; prev = L; ++iters.
+ * Blocks that are done or at safety_cap are left untouched.  Blocks are given in CSR form
+ * (block_offsets [n_blocks+1], block_members [K]).  state is [n_blocks][6] float64:
+ * {u, mom, vel, prev_loss, iters, done}.  Writes s_keypoint[k] = exp(clip(u_block(k), lo, hi)) for
+ * the next evaluation and *n_active = number of blocks still running after this step. -------- */
+int eks_adam_step(int32_t n_blocks, const int32_t* block_offsets, const int32_t* block_members,
+                  const double* nll, const double* dnll, double lr, double lo, double hi,
+                  double tol, int32_t safety_cap, double* state, double* s_keypoint,
+                  int32_t* n_active, eks_stream_t stream);
+
+/* ---- ensemble statistics, eks/core.py:25-101: markers float32 [M][V][T][K][3] (x,y,likelihood)
+ * -> stats float32 [V][T][K][5] (x, y, var_x, var_y, likelihood).  avg_mode 0 median / 1 mean,
+ * var_mode 0 confidence_weighted_var / 1 var. ------------------------------------------------ */
+int eks_ensemble(int32_t n_models, int32_t n_cameras, int32_t n_frames, int32_t n_keypoints,
+                 const float* markers, int32_t avg_mode, int32_t var_mode, float nan_replacement,
+                 float* stats, eks_stream_t stream);
+
+/* ---- optional per-kernel timing (used by bench.py's roofline object).  When enabled, each
+ * kernel launch is bracketed by hipEvents on the caller's stream; eks_profile_drain waits for the
+ * recorded events, writes up to max_n NUL-terminated kernel names back to back into `names` and
+ * their durations in milliseconds into `ms`, clears the record and returns the count. -------- */
+int eks_profile_enable(int on);
+int eks_profile_drain(char* names, size_t names_bytes, float* ms, int32_t max_n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EKS_HIP_H */

@@ -1,0 +1,134 @@
+// Host-side simulator of the scalar-chain kernels' float32 arithmetic.  TEST INFRASTRUCTURE ONLY:
+// it calls the same lane bodies the gfx950 kernels call (eks_amd/csrc/eks_diag_lane.hpp) from
+// plain loops, so the chunked-scan numerics can be compared with the float64 oracle on a CPU-only
+// box.  It is not a fallback: nothing under eks_amd/ loads it.
+#include <algorithm>
+#include <vector>
+
+#include "eks_diag_lane.hpp"
+
+using namespace eks;
+
+template <int B>
+static void run(int T, int N, int D, bool unit, const float* y, const float* var,
+                const DiagModel& M, float* ms, float* Vs_diag) {
+  const int nc = (T + B - 1) / B;
+  std::vector<Elem<float>> el((size_t)nc * N);
+  for (int j = 0; j < nc; ++j)
+    for (int n = 0; n < N; ++n) {
+      ChainParams<float> p = load_chain_params(M, n);
+      const int t0 = j * B, len = std::min(B, T - t0);
+      el[(size_t)j * N + n] = unit ? summarize_chunk<B, true>(y, var, N, n, t0, len, p)
+                                   : summarize_chunk<B, false>(y, var, N, n, t0, len, p);
+    }
+  std::vector<float> pm((size_t)nc * N), pP((size_t)nc * N), se((size_t)nc * N), sJ((size_t)nc * N);
+  for (int n = 0; n < N; ++n) {
+    float m, P;
+    load_chain_prior(M, n, m, P);
+    for (int j = 0; j < nc; ++j) {
+      pm[(size_t)j * N + n] = m;
+      pP[(size_t)j * N + n] = P;
+      elem_apply(el[(size_t)j * N + n], m, P);
+    }
+    float eta = 0.f, J = 0.f;
+    for (int j = nc - 1; j >= 0; --j) {
+      se[(size_t)j * N + n] = eta;
+      sJ[(size_t)j * N + n] = J;
+      elem_back(el[(size_t)j * N + n], eta, J);
+    }
+  }
+  for (int j = 0; j < nc; ++j)
+    for (int n = 0; n < N; ++n) {
+      ChainParams<float> p = load_chain_params(M, n);
+      const int t0 = j * B, len = std::min(B, T - t0);
+      const size_t i = (size_t)j * N + n;
+      if (unit)
+        replay_chunk<B, true, 0>(y, var, ms, Vs_diag, N, n, n % D, t0, len, p, pm[i], pP[i], se[i], sJ[i]);
+      else
+        replay_chunk<B, false, 0>(y, var, ms, Vs_diag, N, n, n % D, t0, len, p, pm[i], pP[i], se[i], sJ[i]);
+    }
+}
+
+extern "C" int sim_diag_smooth(int T, int N, int D, int B, int unit, const float* y,
+                               const float* var, const double* m0, const double* S0,
+                               const double* A, const double* C, const double* Q, const double* s,
+                               float* ms, float* Vs_diag) {
+  DiagModel M{m0, S0, A, C, Q, s, D};
+  switch (B) {
+    case 8: run<8>(T, N, D, unit, y, var, M, ms, Vs_diag); break;
+    case 16: run<16>(T, N, D, unit, y, var, M, ms, Vs_diag); break;
+    case 32: run<32>(T, N, D, unit, y, var, M, ms, Vs_diag); break;
+    case 64: run<64>(T, N, D, unit, y, var, M, ms, Vs_diag); break;
+    default: return -1;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// constant-R filter NLL (+ d/dlog s) through the same lane bodies as the GPU kernels
+// ---------------------------------------------------------------------------------------------
+#include "eks_nll_lane.hpp"
+
+template <typename R, typename RD, int NCL>
+static void run_nll(int T, int N, int D, int BN, bool unit, const float* y, const double* rconst,
+                    const DiagModel& M, const double* s_cand, int n_cand, int per_kp, double* nll,
+                    double* dnll) {
+  const int K = N / D;
+  const int ncn = (T + BN - 1) / BN;
+  const int ngrp = (n_cand + NCL - 1) / NCL;
+  std::vector<NllElem<R>> el((size_t)ncn * N * ngrp * NCL);
+  for (int j = 0; j < ncn; ++j)
+    for (int n = 0; n < N; ++n)
+      for (int g = 0; g < ngrp; ++g) {
+        const int k = n / D, d = n % D;
+        const size_t dd = (size_t)k * D * D + (size_t)d * (D + 1);
+        double sq[NCL];
+        for (int c = 0; c < NCL; ++c) {
+          int ci = std::min(g * NCL + c, n_cand - 1);
+          double s = per_kp ? s_cand[(size_t)k * n_cand + ci] : s_cand[ci];
+          sq[c] = s * M.Q[dd];
+        }
+        const int t0 = j * BN, len = std::min(BN, T - t0);
+        NllElem<R>* o = &el[(((size_t)j * N + n) * ngrp + g) * NCL];
+        if (unit)
+          nll_summarize_chunk<R, NCL, true>(y, N, n, t0, len, rconst[n], M.A[dd], M.C[dd], sq, o);
+        else
+          nll_summarize_chunk<R, NCL, false>(y, N, n, t0, len, rconst[n], M.A[dd], M.C[dd], sq, o);
+      }
+  for (int k = 0; k < K; ++k)
+    for (int ci = 0; ci < n_cand; ++ci) {
+      RD tot = RD(0.0);
+      for (int d = 0; d < D; ++d) {
+        const int n = k * D + d;
+        const size_t dd = (size_t)k * D * D + (size_t)d * (D + 1);
+        auto get = [&](int j, Elem<RD>& e, RD& ell) {
+          const NllElem<R>& s = el[(((size_t)j * N + n) * ngrp + ci / NCL) * NCL + ci % NCL];
+          e.A = make_real(RD(), (double)val(s.e.A), (double)der(s.e.A));
+          e.b = make_real(RD(), (double)val(s.e.b), (double)der(s.e.b));
+          e.C = make_real(RD(), (double)val(s.e.C), (double)der(s.e.C));
+          e.eta = make_real(RD(), (double)val(s.e.eta), (double)der(s.e.eta));
+          e.J = make_real(RD(), (double)val(s.e.J), (double)der(s.e.J));
+          ell = make_real(RD(), s.ell, s.dell);
+        };
+        tot = tot + nll_assemble<RD>(ncn, M.m0[(size_t)k * D + d], M.S0[dd], get);
+      }
+      nll[(size_t)k * n_cand + ci] = -val(tot);
+      if (dnll) dnll[(size_t)k * n_cand + ci] = -der(tot);
+    }
+}
+
+extern "C" int sim_diag_nll(int T, int N, int D, int BN, int unit, int grad, const float* y,
+                            const double* rconst, const double* m0, const double* S0,
+                            const double* A, const double* C, const double* Q,
+                            const double* s_cand, int n_cand, int per_kp, double* nll,
+                            double* dnll) {
+  DiagModel M{m0, S0, A, C, Q, nullptr, D};
+  if (grad) {
+    if (n_cand >= 8) run_nll<Dual, DualD, 8>(T, N, D, BN, unit, y, rconst, M, s_cand, n_cand, per_kp, nll, dnll);
+    else run_nll<Dual, DualD, 1>(T, N, D, BN, unit, y, rconst, M, s_cand, n_cand, per_kp, nll, dnll);
+  } else {
+    if (n_cand >= 8) run_nll<float, double, 8>(T, N, D, BN, unit, y, rconst, M, s_cand, n_cand, per_kp, nll, nullptr);
+    else run_nll<float, double, 1>(T, N, D, BN, unit, y, rconst, M, s_cand, n_cand, per_kp, nll, nullptr);
+  }
+  return 0;
+}

@@ -1,0 +1,301 @@
+"""GPU parity tests: every entry point of libeks_hip.so against the float64 CPU oracle on seeded
+inputs small enough for the oracle to finish in seconds.  Tolerances (stated per test) derive from
+BASELINE.json's bar: smoothed means / covariances within 1e-5 relative, indices bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import eks_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+def _dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def _singlecam_problem(T, K, seed, unit=True):
+    from eks_amd import synth
+    mk = synth.singlecam_markers(T, K, seed=seed)
+    arrs = orc.singlecam_arrays(mk)
+    rng = np.random.default_rng(seed)
+    if not unit:
+        eye = np.eye(2)
+        arrs['As'] = eye * rng.uniform(0.9, 1.0, (K, 2))[:, :, None]
+        arrs['Cs'] = eye * rng.uniform(0.5, 1.5, (K, 2))[:, :, None]
+        arrs['Qs'] = eye * rng.uniform(0.5, 2.0, (K, 2))[:, :, None]
+        arrs['m0s'] = rng.standard_normal((K, 2))
+    y_tk = np.transpose(arrs['ys'], (1, 0, 2)).astype(np.float32)          # (T,K,2)
+    var_tk = arrs['ensemble_vars'].astype(np.float32)                      # (T,K,2)
+    arrs['ys'] = np.transpose(y_tk, (1, 0, 2)).astype(np.float64)          # oracle sees f32 inputs
+    arrs['ensemble_vars'] = var_tk.astype(np.float64)
+    return arrs, y_tk, var_tk
+
+
+def _rel(a, b, axis_scale=None):
+    """max |a-b| relative to the per-keypoint max magnitude of b (BASELINE's 'relative', H4)."""
+    sc = np.abs(b).max(axis=axis_scale, keepdims=True) if axis_scale is not None else np.abs(b).max()
+    return float((np.abs(a - b) / np.maximum(sc, 1e-300)).max())
+
+
+def _params_dev(arrs):
+    return [_dev(arrs[k], torch.float64) for k in ('m0s', 'S0s', 'As', 'Cs', 'Qs')]
+
+
+@pytest.mark.parametrize('T,K,unit,vs_diag', [
+    (2000, 4, True, False),      # ibl-pupil-like: 8 chains, several chunks per wave
+    (1537, 37, True, True),      # ragged T (not a multiple of the 32-frame chunk), ragged N
+    (3000, 64, False, False),    # general diagonal a, c, q
+    (33, 3, True, False),        # two chunks
+    (1, 2, True, False),         # single frame
+    (700, 200, False, True),     # several chain tiles
+])
+def test_smooth_diag_matches_oracle(T, K, unit, vs_diag):
+    from eks_amd import hip_ops
+    arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=T + K, unit=unit)
+    rng = np.random.default_rng(1)
+    s = np.exp(rng.uniform(-8, 8, K))
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    assert flags & 1 and bool(flags & 4) == unit
+    ms, Vs = hip_ops.smooth(_dev(y_tk), _dev(var_tk), *_params_dev(arrs), _dev(s), flags=flags,
+                            vs_diag=vs_diag)
+    ms = ms.cpu().numpy().astype(np.float64)
+    Vs = Vs.cpu().numpy().astype(np.float64)
+    Rd = orc.build_R_from_vars(np.swapaxes(arrs['ensemble_vars'], 0, 1))
+    ms_o, Vs_o, _ = orc.kalman_smoother(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'],
+                                        arrs['Cs'], arrs['Qs'], s, Rd)
+    ms_k = np.transpose(ms, (1, 0, 2))
+    assert _rel(ms_k, ms_o, axis_scale=(1, 2)) < 1e-5
+    if vs_diag:
+        Vd_o = np.diagonal(Vs_o, axis1=2, axis2=3)
+        assert (np.abs(np.transpose(Vs, (1, 0, 2)) - Vd_o) / Vd_o).max() < 1e-5   # elementwise
+    else:
+        Vk = np.transpose(Vs, (1, 0, 2, 3))
+        assert np.all(Vk[:, :, 0, 1] == 0) and np.all(Vk[:, :, 1, 0] == 0)
+        Vd = np.diagonal(Vk, axis1=2, axis2=3)
+        Vd_o = np.diagonal(Vs_o, axis1=2, axis2=3)
+        assert (np.abs(Vd - Vd_o) / Vd_o).max() < 1e-5
+
+
+def _dense_problem(T, K, D, O, seed):
+    rng = np.random.default_rng(seed)
+    x = np.cumsum(rng.standard_normal((K, T, D)) * 0.5, axis=1)
+    C = rng.standard_normal((K, O, D))
+    var = (rng.gamma(2.0, 0.4, (T, K, O)) + 0.02).astype(np.float32)
+    y = np.einsum('kod,ktd->tko', C, x) + rng.standard_normal((T, K, O)) * np.sqrt(var)
+    y = y.astype(np.float32)
+    L = rng.standard_normal((K, D, D)) * 0.3
+    Q = L @ np.swapaxes(L, 1, 2) + 0.2 * np.eye(D)
+    Q = Q / np.abs(Q).max(axis=(1, 2), keepdims=True)
+    S0 = np.eye(D) * rng.uniform(1.0, 5.0, (K, D))[:, :, None]
+    A = np.tile(np.eye(D), (K, 1, 1))
+    m0 = np.zeros((K, D))
+    return dict(ys=np.transpose(y, (1, 0, 2)).astype(np.float64), m0s=m0, S0s=S0, As=A, Cs=C, Qs=Q,
+                ensemble_vars=var.astype(np.float64)), y, var
+
+
+@pytest.mark.parametrize('T,K,D,O,general_A', [
+    (1200, 4, 3, 4, False),      # mirror-mouse shape: 2 views, n_latent 3
+    (300, 3, 3, 6, False),
+    (257, 2, 4, 8, False),       # 4 cameras, n_latent 4
+    (200, 2, 5, 8, True),
+    (150, 5, 2, 2, True),        # non-diagonal 2x2 goes through the dense path
+    (64, 2, 1, 3, False),
+    (100, 2, 6, 8, False),
+])
+def test_smooth_dense_matches_oracle(T, K, D, O, general_A):
+    from eks_amd import hip_ops
+    arrs, y, var = _dense_problem(T, K, D, O, seed=T + D)
+    if general_A:
+        rng = np.random.default_rng(9)
+        arrs['As'] = arrs['As'] * 0.97 + 0.02 * rng.standard_normal((K, D, D))
+    s = np.exp(np.random.default_rng(2).uniform(-3, 4, K))
+    for vs_diag in (False, True):
+        ms, Vs = hip_ops.smooth(_dev(y), _dev(var), *_params_dev(arrs), _dev(s), flags=0,
+                                vs_diag=vs_diag)
+        ms = np.transpose(ms.cpu().numpy().astype(np.float64), (1, 0, 2))
+        Vs = Vs.cpu().numpy().astype(np.float64)
+        Rd = orc.build_R_from_vars(np.swapaxes(arrs['ensemble_vars'], 0, 1))
+        ms_o, Vs_o, _ = orc.kalman_smoother(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'],
+                                            arrs['Cs'], arrs['Qs'], s, Rd)
+        assert _rel(ms, ms_o, axis_scale=(1, 2)) < 1e-5
+        if vs_diag:
+            Vk = np.transpose(Vs, (1, 0, 2))
+            ref = np.diagonal(Vs_o, axis1=2, axis2=3)
+        else:
+            Vk = np.transpose(Vs, (1, 0, 2, 3))
+            ref = Vs_o
+        assert _rel(Vk, ref, axis_scale=tuple(range(1, ref.ndim))) < 1e-5
+
+
+@pytest.mark.parametrize('T,N', [(2001, 7), (2000, 70), (1, 3), (2, 5), (300, 130)])
+def test_const_r_is_exact_median(T, N):
+    from eks_amd import hip_ops
+    rng = np.random.default_rng(T + N)
+    var = rng.gamma(2.0, 0.3, (T, N, 1)).astype(np.float32)
+    var[rng.random((T, N, 1)) < 0.05] = 0.0                    # below the 1e-12 clip
+    if T > 10:
+        var[3:9, 0, 0] = var[5, 0, 0]                          # duplicates around the middle
+        var[:, 1, 0] = 0.25                                    # constant column
+        var[rng.random(T) < 0.3, 2, 0] = np.nan                # NaNs are ignored (nanmedian)
+    got = hip_ops.const_r(_dev(var), 1e-4).cpu().numpy()
+    ref = orc.constant_R_from_timevarying(
+        np.clip(var.astype(np.float64), 1e-12, None)[:, :, 0].T[:, :, None], 1e-4)[:, 0]
+    # selection is exact: the only arithmetic is the mean of the two middle float32 values
+    np.testing.assert_allclose(got[:, 0], ref, rtol=1e-15, atol=0)
+
+
+def test_const_r_all_nan_column():
+    from eks_amd import hip_ops
+    var = np.full((50, 2, 1), np.nan, np.float32)
+    var[:, 1, 0] = 2.0
+    got = hip_ops.const_r(_dev(var), 1e-4).cpu().numpy()
+    assert np.isnan(got[0, 0]) and got[1, 0] == 2.0
+
+
+@pytest.mark.parametrize('T,K,unit', [(5000, 6, True), (2500, 3, False), (100, 2, True)])
+def test_nll_grid_diag_matches_oracle(T, K, unit):
+    from eks_amd import hip_ops
+    arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=7 + T, unit=unit)
+    cand = np.exp(np.linspace(-8, 8, 64))
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    rconst = hip_ops.const_r(_dev(var_tk), 1e-4)
+    Rc = orc.constant_R_from_timevarying(orc.build_R_from_vars(np.swapaxes(arrs['ensemble_vars'], 0, 1)))
+    np.testing.assert_allclose(rconst.cpu().numpy(), Rc, rtol=1e-15)
+    nll = hip_ops.nll(_dev(y_tk), rconst, *_params_dev(arrs), _dev(cand), flags=flags).cpu().numpy()
+    ref = np.stack([orc.filter_nll(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'],
+                                   arrs['Qs'], np.full(K, sc), Rc) for sc in cand], axis=1)
+    assert (np.abs(nll - ref) / np.abs(ref)).max() < 1e-5
+    # indices bit-exact wherever the oracle's own margin is above the value tolerance
+    srt = np.sort(ref, axis=1)
+    clear = (srt[:, 1] - srt[:, 0]) > 2e-5 * np.abs(srt[:, 0])
+    s_sel, idx = hip_ops.argmin_s(_dev(nll), _dev(cand))
+    np.testing.assert_array_equal(idx.cpu().numpy(), nll.argmin(axis=1))
+    np.testing.assert_array_equal(idx.cpu().numpy()[clear], ref.argmin(axis=1)[clear])
+    np.testing.assert_array_equal(s_sel.cpu().numpy(), cand[nll.argmin(axis=1)])
+    assert clear.all()
+
+
+@pytest.mark.parametrize('T,K,unit', [(3000, 5, True), (1500, 3, False)])
+def test_nll_grad_diag_matches_oracle(T, K, unit):
+    from eks_amd import hip_ops
+    arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=3 + T, unit=unit)
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    rconst = hip_ops.const_r(_dev(var_tk), 1e-4)
+    Rc = rconst.cpu().numpy()
+    s = np.exp(np.random.default_rng(0).uniform(-6, 6, K))
+    nll, g = hip_ops.nll(_dev(y_tk), rconst, *_params_dev(arrs), _dev(s[:, None]), per_keypoint=True,
+                         want_grad=True, flags=flags)
+    ref, gref = orc.filter_nll(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'],
+                               arrs['Qs'], s, Rc, want_grad=True)
+    assert (np.abs(nll.cpu().numpy()[:, 0] - ref) / np.abs(ref)).max() < 1e-5
+    assert (np.abs(g.cpu().numpy()[:, 0] - gref) / np.abs(gref).max()).max() < 1e-4
+
+
+@pytest.mark.parametrize('T,K,D,O', [(800, 3, 3, 4), (300, 2, 4, 8), (200, 2, 2, 2)])
+def test_nll_dense_matches_oracle(T, K, D, O):
+    from eks_amd import hip_ops
+    arrs, y, var = _dense_problem(T, K, D, O, seed=11 + T)
+    rconst = hip_ops.const_r(_dev(var), 1e-4)
+    Rc = rconst.cpu().numpy()
+    cand = np.exp(np.linspace(-8, 8, 9))
+    nll = hip_ops.nll(_dev(y), rconst, *_params_dev(arrs), _dev(cand), flags=0).cpu().numpy()
+    ref = np.stack([orc.filter_nll(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'],
+                                   arrs['Qs'], np.full(K, sc), Rc) for sc in cand], axis=1)
+    assert (np.abs(nll - ref) / np.abs(ref)).max() < 1e-8          # float64 path
+    s = np.exp(np.random.default_rng(0).uniform(-4, 4, K))
+    nll1, g1 = hip_ops.nll(_dev(y), rconst, *_params_dev(arrs), _dev(s[:, None]), per_keypoint=True,
+                           want_grad=True, flags=0)
+    ref1, gref = orc.filter_nll(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'],
+                                arrs['Qs'], s, Rc, want_grad=True)
+    assert (np.abs(nll1.cpu().numpy()[:, 0] - ref1) / np.abs(ref1)).max() < 1e-8
+    assert (np.abs(g1.cpu().numpy()[:, 0] - gref) / np.abs(gref).max()).max() < 1e-7
+
+
+def test_adam_step_matches_oracle_sequence():
+    """Drive eks_adam_step with a synthetic quadratic loss and compare the whole trajectory with
+    the oracle's restatement of eks/core.py:652-681 (including blocks and the clip gradient)."""
+    from eks_amd import hip_ops
+    blocks = [[0, 2], [1], [3]]
+    u0 = np.array([2.5, -9.0, 0.3])           # block 1 starts outside the [-8, 8] bounds
+    centers = np.array([1.0, -2.0, 0.5, 1.5])  # per keypoint
+
+    def per_kp(u_kp):
+        return 50.0 + (u_kp - centers) ** 2, 2.0 * (u_kp - centers)
+
+    member_block = np.array([0, 1, 0, 2])
+
+    def lg(u_b):
+        L, g = per_kp(u_b[member_block])
+        Lb = np.zeros(3)
+        gb = np.zeros(3)
+        np.add.at(Lb, member_block, L)
+        np.add.at(gb, member_block, g)
+        return Lb, gb
+
+    u_ref, last_ref, it_ref = orc.adam_optimize_s(lg, u0, tol=1e-3, safety_cap=40)
+    offs = _dev(np.array([0, 2, 3, 4], np.int32))
+    mem = _dev(np.array([0, 2, 1, 3], np.int32))
+    state = np.zeros((3, 6))
+    state[:, 0] = u0
+    state[:, 3] = np.inf
+    state = _dev(state)
+    s_kp = torch.empty(4, dtype=torch.float64, device='cuda')
+    n_act = torch.zeros(1, dtype=torch.int32, device='cuda')
+    u_now = u0.copy()
+    for it in range(60):
+        L, g = per_kp(np.clip(u_now, -8, 8)[member_block])
+        hip_ops.adam_step(offs, mem, _dev(L), _dev(g), state, s_kp, n_act, 0.25, -8.0, 8.0, 1e-3, 40)
+        u_now = state.cpu().numpy()[:, 0]
+        if int(n_act.item()) == 0:
+            break
+    st = state.cpu().numpy()
+    np.testing.assert_allclose(st[:, 0], u_ref, rtol=1e-12, atol=1e-12)
+    np.testing.assert_array_equal(st[:, 4].astype(int), it_ref)
+    np.testing.assert_allclose(st[:, 3], last_ref, rtol=1e-12)
+    np.testing.assert_allclose(s_kp.cpu().numpy(), np.exp(np.clip(u_ref, -8, 8))[member_block], rtol=1e-12)
+
+
+@pytest.mark.parametrize('M,avg,varm', [(5, 'median', 'confidence_weighted_var'), (4, 'mean', 'var'),
+                                        (1, 'median', 'confidence_weighted_var'), (9, 'median', 'var'),
+                                        (2, 'median', 'confidence_weighted_var')])
+def test_ensemble_matches_oracle(M, avg, varm):
+    from eks_amd import hip_ops
+    rng = np.random.default_rng(M)
+    a = rng.random((M, 2, 40, 5, 3)).astype(np.float32)
+    a[..., :2] *= 300
+    if M > 1:
+        a[0, 0, 3, 1, 0] = np.nan            # one member missing
+        a[:, 1, 5, 2, 1] = np.nan            # all members missing -> var replaced by 1000
+        a[:, 0, 7, 0, 2] = 0.0               # zero confidence -> inf -> float32 max
+    got = hip_ops.ensemble(_dev(a), avg, varm).cpu().numpy().astype(np.float64)
+    ref = orc.ensemble(a, avg, varm)[0]
+    both_nan = np.isnan(got) & np.isnan(ref)
+    np.testing.assert_allclose(np.where(both_nan, 0, got), np.where(both_nan, 0, ref), rtol=2e-6)
+    if M > 1:
+        assert got[1, 5, 2, 3] == 1000.0 and np.isnan(got[1, 5, 2, 1])
+
+
+def test_abi_error_codes():
+    import ctypes
+    from eks_amd import _lib
+    lib = _lib.load()
+    d = _lib.EksDims(4, 0, 2, 2, 1)
+    assert lib.eks_smooth_workspace_bytes(ctypes.byref(d)) == 0
+    assert lib.eks_smooth(ctypes.byref(d), *([None] * 11), 0, None) == -2       # bad shape
+    d = _lib.EksDims(4, 10, 2, 2, 1)
+    assert lib.eks_smooth(ctypes.byref(d), *([None] * 11), 0, None) == -1       # null pointers
+    d = _lib.EksDims(4, 10, 2, 3, 1)
+    assert lib.eks_smooth_workspace_bytes(ctypes.byref(d)) == 0                 # DIAG needs D == O
+    d = _lib.EksDims(2, 10, 7, 7, 0)
+    x = torch.zeros(10 * 2 * 7 * 7, dtype=torch.float64, device='cuda')
+    xf = torch.zeros(10 * 2 * 7 * 7, dtype=torch.float32, device='cuda')
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = lib.eks_smooth(ctypes.byref(d), p(xf), p(xf), p(x), p(x), p(x), p(x), p(x), p(x), p(xf), p(xf),
+                        p(x), x.numel() * 8, None)
+    assert rc == -3                                                             # D = 7 not built
+    assert b'unsupported' in lib.eks_status_string(rc)
