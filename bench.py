@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""bench.py - headline benchmark of the MI355X-native ensemble Kalman smoother.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): singlecam,
+T = 100 000 frames x K = 256 keypoints, smoothing parameter chosen per keypoint on a 64-candidate
+NLL grid (candidates exp(linspace(-8, 8, 64)), constant-R loss of eks/core.py:602/:640-650), then
+the final fixed-s filter + RTS smoother with the full `ms (T,K,2)`, `Vs (T,K,2,2)` contract.
+One "step" = one pass of that whole path over one session already resident in HBM:
+    eks_const_r -> eks_nll (64 candidates) -> eks_argmin_s -> eks_smooth.
+1 unit = one keypoint at one frame.  Inputs are synthetic (seeded, generated on device).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1 is launched by torch.distributed.run, one rank per GPU; every rank smooths its own
+independent session of the same shape (sessions shard with no data-path collective, "weak"
+scaling) and the per-keypoint s_finals are all-gathered over RCCL inside the timed region.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (T, K, n_cand)
+    'c3': (100_000, 256, 64),
+    'c2': (10_000, 64, 0),       # fixed smoothing parameter, no search (parity-sized)
+}
+SMOOTH_BYTES_PER_UNIT = 40       # y 8 + var 8 in, ms 8 + Vs 16 out  
+NLL_BYTES_PER_UNIT = 8           # y read once regardless of candidate count
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-kernel-events', action='store_true',
+                   help='do not bracket kernels with HIP events inside the timed region')
+    p.add_argument('--cpu-seconds', type=float, default=15.0)
+    return p.parse_args()
+
+
+def drain_profile(lib):
+    buf = ctypes.create_string_buffer(1 << 16)
+    ms = (ctypes.c_float * 4096)()
+    n = lib.eks_profile_drain(buf, len(buf), ms, 4096)
+    names = buf.raw.split(b'\0')[:n]
+    out = {}
+    for nm, t in zip(names, list(ms)[:n]):
+        out.setdefault(nm.decode(), []).append(float(t))
+    return out
+
+
+def cpu_baseline(y_dev, var_dev, T, n_cand, budget_s):
+    """Time the C twin of the oracle (general-matrix port of the reference recursion, OpenMP over
+    keypoints) on a bounded sample of the same workload: the first Kc keypoints, all T frames."""
+    from oracle import c_oracle, eks_oracle as orc
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    cores = max(1, min(cores, c_oracle.max_threads()))
+    # ~0.3 us per frame per filter pass per core for the 2x2 general-matrix port (measured here)
+    per_kp = T * 0.3e-6 * (max(n_cand, 0) + 2.5)
+    Kc = int(max(cores, min(y_dev.shape[1], round(budget_s * cores / per_kp))))
+    Kc = min(Kc, y_dev.shape[1])
+    y = np.transpose(y_dev[:, :Kc].cpu().numpy().astype(np.float64), (1, 0, 2)).copy()
+    var = np.transpose(var_dev[:, :Kc].cpu().numpy().astype(np.float64), (1, 0, 2)).copy()
+    eye = np.tile(np.eye(2), (Kc, 1, 1))
+    m0 = np.zeros((Kc, 2))
+    S0 = eye * np.var(y, axis=1)[:, :, None]
+    c_oracle.smooth(y[:1, :64], np.clip(var[:1, :64], 1e-12, None), m0[:1], S0[:1], eye[:1], eye[:1],
+                    eye[:1], np.ones(1))                                   # build / warm the .so
+    t0 = time.perf_counter()
+    Rd = np.clip(var, 1e-12, None)
+    if n_cand:
+        Rc = orc.constant_R_from_timevarying(Rd)
+        cand = np.exp(np.linspace(-8.0, 8.0, n_cand))
+        nll = c_oracle.nll_grid(y, Rc, m0, S0, eye, eye, eye, cand, nthreads=cores)
+        s = cand[np.argmin(nll, axis=1)]
+    else:
+        s = np.full(Kc, 10.0)
+    c_oracle.smooth(y, Rd, m0, S0, eye, eye, eye, s, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return dict(value=T * Kc / dt, unit='frames*keypoints/s', cores=cores, kind='port',
+                sample=f'first {Kc} of the keypoints x all {T} frames of the same workload '
+                       f'({n_cand}-candidate NLL grid + smooth), float64 C port of the reference '
+                       f'recursion (oracle/eks_oracle.c), OpenMP over keypoints, {dt:.1f} s'), s
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch multi-GPU runs with torch.distributed.run (one rank per GPU)')
+    from eks_amd import _lib, hip_ops, synth
+    hip_ops.require_gpu()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=dev)
+    lib = _lib.load()
+
+    T, K, n_cand = WORKLOADS[args.workload]
+    # every rank owns an independent session of the same shape (seed = 3 + rank)
+    y, var = synth.singlecam_observations_torch(T, K, seed=3 + rank, device=dev)
+    eye = torch.eye(2, dtype=torch.float64, device=dev).expand(K, 2, 2).contiguous()
+    m0 = torch.zeros(K, 2, dtype=torch.float64, device=dev)
+    S0 = torch.diag_embed(y.double().var(dim=0, unbiased=False)).contiguous()
+    flags = _lib.FLAG_DIAG_MODEL | _lib.FLAG_UNIT_AC
+    cand = torch.exp(torch.linspace(-8.0, 8.0, max(n_cand, 1), dtype=torch.float64, device=dev))
+    s_fixed = torch.full((K,), 10.0, dtype=torch.float64, device=dev)
+    ms = torch.empty((T, K, 2), dtype=torch.float32, device=dev)
+    Vs = torch.empty((T, K, 2, 2), dtype=torch.float32, device=dev)
+    gathered = [torch.empty(K, dtype=torch.float64, device=dev) for _ in range(world)]
+
+    def step():
+        if n_cand:
+            rc = hip_ops.const_r(var, 1e-4)
+            nll = hip_ops.nll(y, rc, m0, S0, eye, eye, eye, cand, flags=flags)
+            s, _ = hip_ops.argmin_s(nll, cand)
+        else:
+            s = s_fixed
+        hip_ops.smooth(y, var, m0, S0, eye, eye, eye, s, flags=flags, out=(ms, Vs))
+        if world > 1:
+            dist.all_gather(gathered, s)
+        return s
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    lib.eks_profile_drain(None, 0, None, 0)
+    events_on = not args.no_kernel_events
+    lib.eks_profile_enable(1 if events_on else 0)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s_last = step()
+    sync()
+    dt = time.perf_counter() - t0
+    lib.eks_profile_enable(0)
+    prof = drain_profile(lib) if events_on else {}
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    units_per_step = T * K
+    value = world * args.steps * units_per_step / dt
+    out = {
+        'metric': 'frames*keypoints smoothed/s + achieved HBM GB/s fraction, singlecam 100k x 256',
+        'value': value, 'unit': 'frames*keypoints/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'singlecam T={T} x K={K} keypoints (D=O=2), '
+                               + (f'{n_cand}-candidate NLL grid + ' if n_cand else 'fixed s=10, ')
+                               + 'filter+RTS smooth, full ms/Vs outputs; one session per GPU',
+                   'frames': T, 'keypoints': K, 'candidates': n_cand,
+                   'parallelism': f'sessions x{world}' if world > 1 else 'single GPU'},
+    }
+    if rank == 0:
+        if prof:
+            avg = {k: float(np.mean(v)) for k, v in prof.items()}
+            k3 = avg.get('diag_replay')
+            smooth_ms = sum(avg.get(k, 0.0) for k in ('diag_summarize', 'diag_scan', 'diag_replay'))
+            achieved = SMOOTH_BYTES_PER_UNIT * units_per_step / (k3 * 1e-3) / 1e9
+            out['roofline'] = {
+                'bound': 'hbm', 'kernel': 'diag_replay_kernel', 'achieved': achieved,
+                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                'traffic': None,
+                'algorithmic_bytes_per_launch': SMOOTH_BYTES_PER_UNIT * units_per_step,
+                'kernel_avg_ms': k3, 'launches_timed': len(prof.get('diag_replay', [])),
+                'stage_avg_ms': avg,
+                'smooth_stage_frac': SMOOTH_BYTES_PER_UNIT * units_per_step / (smooth_ms * 1e-3)
+                                     / 1e9 / HBM_PEAK_GBS,
+                'whole_step_frac': ((SMOOTH_BYTES_PER_UNIT + (NLL_BYTES_PER_UNIT if n_cand else 0))
+                                    * units_per_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS),
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cb, s_cpu = cpu_baseline(y, var, T, n_cand, args.cpu_seconds)
+                out['cpu_baseline'] = cb
+                out['gpu_over_cpu'] = value / cb['value']
+                if n_cand:
+                    s_gpu = s_last[:len(s_cpu)].cpu().numpy()
+                    out['cpu_baseline']['s_agree'] = float(np.mean(s_gpu == s_cpu))
+            except Exception as e:                      # the baseline must never sink the bench line
+                out['cpu_baseline'] = {'value': None, 'unit': 'frames*keypoints/s', 'cores': 0,
+                                       'kind': 'port', 'sample': f'failed: {e!r}'}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

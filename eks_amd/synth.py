@@ -57,25 +57,32 @@ def multicam_markers(T: int, K: int, V: int = 2, M: int = 5, seed: int = 0) -> n
 
 def singlecam_observations_torch(T: int, K: int, seed: int, device):
     """Device-side generator for bench-sized inputs: returns the smoother's direct inputs
-    (centred ensemble medians y and ensemble variances var, both float32 [T, K, 2] on `device`)
-    drawn from the same generative model, without materialising the M ensemble members on host.
-    The ensemble stage is a separate kernel with its own test; this feeds the Kalman path."""
+    (centred ensemble averages y and ensemble variances var, both float32 [T, K, 2] on `device`)
+    drawn from the generative model above without materialising the M ensemble members: the latent
+    random walk, per-frame member variance sig2 (2 % occluded frames x100), `var` = a chi-square-ish
+    estimate of sig2 per coordinate (what a 5-member ensemble variance looks like), and
+    y = latent + N(0, 0.29 sig2) (the sampling variance of a 5-member median)."""
     import torch
     g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    q = torch.exp(torch.empty(K, 1, device=device).uniform_(float(np.log(0.05)), float(np.log(5.0)),
-                                                            generator=g))
-    steps = torch.randn(T, K, 2, device=device, generator=g) * torch.sqrt(q)[None]
+    g.manual_seed(int(seed))
+
+    def rand(*shape):
+        return torch.rand(*shape, device=device, generator=g)
+
+    def randn(*shape):
+        return torch.randn(*shape, device=device, generator=g)
+
+    q = torch.exp(rand(K, 1) * float(np.log(5.0 / 0.05)) + float(np.log(0.05)))
+    steps = randn(T, K, 2) * torch.sqrt(q)[None]
     steps[0] = 0
     lat = torch.cumsum(steps, dim=0)
-    lat = lat - lat.mean(dim=0, keepdim=True)
-    # variance of a 5-member ensemble median ~ sig2 * 0.287 * ... ; draw the ensemble variance
-    # itself (what the filter consumes as R_t) and noise consistent with it
-    gam = torch.distributions.Gamma(torch.tensor(2.0, device=device), torch.tensor(1.0, device=device))
-    torch.manual_seed(seed)
-    sig2 = 0.25 * gam.sample((T, K))
-    occ = torch.rand(T, K, device=device, generator=g) < 0.02
+    del steps
+    lat -= lat.mean(dim=0, keepdim=True)
+    sig2 = 0.25 * (-torch.log(rand(T, K).clamp_min(1e-12)) - torch.log(rand(T, K).clamp_min(1e-12)))
+    occ = rand(T, K) < 0.02
     sig2 = torch.where(occ, sig2 * 100.0, sig2)
-    var = (sig2[..., None] * (0.5 + torch.rand(T, K, 2, device=device, generator=g))).float()
-    y = (lat + torch.randn(T, K, 2, device=device, generator=g) * torch.sqrt(var * 0.3)).float()
-    return y.contiguous(), var.contiguous()
+    # ensemble variance of 5 members ~ sig2 * chi2_4 / 4 (mean 1, never exactly 0)
+    chi = (randn(T, K, 2, 4) ** 2).mean(dim=-1)
+    var = (sig2[..., None] * chi.clamp_min(1e-3)).float().contiguous()
+    y = (lat + randn(T, K, 2) * torch.sqrt(0.29 * sig2)[..., None]).float().contiguous()
+    return y, var
