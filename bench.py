@@ -202,8 +202,13 @@ def main():
                 out['cpu_baseline'] = cb
                 out['gpu_over_cpu'] = value / cb['value']
                 if n_cand:
+                    # compare grid INDICES (the candidate values differ by an ulp between
+                    # torch.linspace and numpy.linspace)
+                    cand_np = np.exp(np.linspace(-8.0, 8.0, n_cand))
                     s_gpu = s_last[:len(s_cpu)].cpu().numpy()
-                    out['cpu_baseline']['s_agree'] = float(np.mean(s_gpu == s_cpu))
+                    i_gpu = np.abs(np.log(s_gpu)[:, None] - np.log(cand_np)[None]).argmin(1)
+                    i_cpu = np.abs(np.log(s_cpu)[:, None] - np.log(cand_np)[None]).argmin(1)
+                    out['cpu_baseline']['argmin_index_agreement'] = float(np.mean(i_gpu == i_cpu))
             except Exception as e:                      # the baseline must never sink the bench line
                 out['cpu_baseline'] = {'value': None, 'unit': 'frames*keypoints/s', 'cores': 0,
                                        'kind': 'port', 'sample': f'failed: {e!r}'}

@@ -6,9 +6,10 @@
 //
 //   K1 diag_summarize : lane = (chain, chunk of B frames).  Reads y, var once, composes the chunk's
 //                       element (A, b, C, eta, J) in registers, writes 20 B per chunk.
-//   K2 diag_scan      : per chain, scans the chunk elements: forward -> predicted belief entering
+//   K2 diag_scan_*    : per chain, scans the chunk elements: forward -> predicted belief entering
 //                       every chunk; backward -> information about the state just after every
-//                       chunk from all later frames.  Two-level (segments through LDS).
+//                       chunk from all later frames.  Block-local LDS scans + a short pass
+//                       over block aggregates (three small launches).
 //   K3 diag_replay    : lane = (chain, chunk).  Reads y, var again, replays the exact filter from
 //                       the chunk's incoming belief keeping the B filtered (m, P) pairs IN
 //                       REGISTERS, fuses the outgoing belief with the future information and runs
@@ -87,64 +88,131 @@ __global__ __launch_bounds__(256) void diag_replay_kernel(LaneMap L, DiagModel M
 }
 
 // ------------------------------------------------------------------------------------------
-// K2: scan of the chunk elements.  Block = CH chains x NSEG time segments (CH * NSEG threads).
+// K2: scan of the chunk elements, three small launches.  Block = kScanCH chains x kScanCB
+// consecutive chunks (one thread per element, so every load is issued at once):
+//   S1 reduce : ordered tree reduction of the block's kScanCB elements -> block aggregate
+//   S2 blocks : one thread per chain walks the (few) block aggregates: belief entering each
+//               block (forward) and information leaving each block (backward)
+//   S3 local  : Hillis-Steele inclusive scans of the block's elements in LDS, forward and
+//               reverse; exclusive prefixes applied to the block's incoming belief / pulled
+//               back from the block's outgoing information -> per-chunk (pm, pP, sEta, sJ)
 // ------------------------------------------------------------------------------------------
 constexpr int kScanCH = 16;
-constexpr int kScanNSEG = 64;
+constexpr int kScanCB = 64;
+
+struct ScanWs {
+  float *gA, *gb, *gC, *gEta, *gJ;   // block aggregates [nblk][N]
+  float *bm, *bP, *bEta, *bJ;        // block-level scan results [nblk][N]
+  int nblk;
+};
 
 __device__ __forceinline__ Elem<float> load_elem(const DiagWs& W, size_t o) {
   return Elem<float>{W.eA[o], W.eb[o], W.eC[o], W.eEta[o], W.eJ[o]};
 }
 
-__global__ __launch_bounds__(kScanCH* kScanNSEG) void diag_scan_kernel(int N, int nc, DiagModel M,
-                                                                      DiagWs W) {
-  __shared__ float sA[kScanNSEG][kScanCH], sb[kScanNSEG][kScanCH], sC[kScanNSEG][kScanCH],
-      sEta[kScanNSEG][kScanCH], sJ[kScanNSEG][kScanCH];
-  const int cl = threadIdx.x % kScanCH;
-  const int seg = threadIdx.x / kScanCH;
-  const int n = blockIdx.x * kScanCH + cl;
-  const bool live = n < N;
-  const int seglen = (nc + kScanNSEG - 1) / kScanNSEG;
-  const int j0 = min(nc, seg * seglen);
-  const int j1 = min(nc, j0 + seglen);
+struct ScanLds {
+  float A[kScanCB][kScanCH], b[kScanCB][kScanCH], C[kScanCB][kScanCH], eta[kScanCB][kScanCH],
+      J[kScanCB][kScanCH];
+  __device__ __forceinline__ void put(int i, int c, const Elem<float>& e) {
+    A[i][c] = e.A; b[i][c] = e.b; C[i][c] = e.C; eta[i][c] = e.eta; J[i][c] = e.J;
+  }
+  __device__ __forceinline__ Elem<float> get(int i, int c) const {
+    return Elem<float>{A[i][c], b[i][c], C[i][c], eta[i][c], J[i][c]};
+  }
+};
 
-  // up-sweep: composite element of this segment
-  Elem<float> acc = elem_identity<float>();
-  if (live)
-    for (int j = j0; j < j1; ++j) acc = elem_combine(acc, load_elem(W, (size_t)j * N + n));
-  sA[seg][cl] = acc.A;
-  sb[seg][cl] = acc.b;
-  sC[seg][cl] = acc.C;
-  sEta[seg][cl] = acc.eta;
-  sJ[seg][cl] = acc.J;
+__global__ __launch_bounds__(kScanCH* kScanCB) void diag_scan_reduce_kernel(int N, int nc, DiagWs W,
+                                                                           ScanWs S) {
+  __shared__ ScanLds L;
+  const int cl = threadIdx.x % kScanCH, i = threadIdx.x / kScanCH;
+  const int n = blockIdx.x * kScanCH + cl, j = blockIdx.y * kScanCB + i;
+  Elem<float> e = (n < N && j < nc) ? load_elem(W, (size_t)j * N + n) : elem_identity<float>();
+  L.put(i, cl, e);
   __syncthreads();
-  if (!live) return;
+#pragma unroll
+  for (int off = 1; off < kScanCB; off <<= 1) {
+    const bool act = (i & (2 * off - 1)) == 0;
+    if (act) e = elem_combine(e, L.get(i + off, cl));
+    __syncthreads();
+    if (act) L.put(i, cl, e);
+    __syncthreads();
+  }
+  if (i == 0 && n < N) {
+    const size_t o = (size_t)blockIdx.y * N + n;
+    S.gA[o] = e.A; S.gb[o] = e.b; S.gC[o] = e.C; S.gEta[o] = e.eta; S.gJ[o] = e.J;
+  }
+}
 
-  // belief entering this segment / information leaving it
-  float m, P;
-  load_chain_prior(M, n, m, P);
-  for (int q = 0; q < seg; ++q) {
-    const Elem<float> e{sA[q][cl], sb[q][cl], sC[q][cl], sEta[q][cl], sJ[q][cl]};
-    elem_apply(e, m, P);
+__global__ __launch_bounds__(64) void diag_scan_blocks_kernel(int N, DiagModel M, ScanWs S) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 2 * N) return;
+  const int n = idx % N;
+  if (idx < N) {
+    float m, P;
+    load_chain_prior(M, n, m, P);
+    for (int q = 0; q < S.nblk; ++q) {
+      const size_t o = (size_t)q * N + n;
+      S.bm[o] = m;
+      S.bP[o] = P;
+      elem_apply(Elem<float>{S.gA[o], S.gb[o], S.gC[o], S.gEta[o], S.gJ[o]}, m, P);
+    }
+  } else {
+    float eta = 0.f, J = 0.f;
+    for (int q = S.nblk - 1; q >= 0; --q) {
+      const size_t o = (size_t)q * N + n;
+      S.bEta[o] = eta;
+      S.bJ[o] = J;
+      elem_back(Elem<float>{S.gA[o], S.gb[o], S.gC[o], S.gEta[o], S.gJ[o]}, eta, J);
+    }
   }
-  float eta = 0.f, J = 0.f;
-  for (int q = kScanNSEG - 1; q > seg; --q) {
-    const Elem<float> e{sA[q][cl], sb[q][cl], sC[q][cl], sEta[q][cl], sJ[q][cl]};
-    elem_back(e, eta, J);
+}
+
+__global__ __launch_bounds__(kScanCH* kScanCB) void diag_scan_local_kernel(int N, int nc, DiagWs W,
+                                                                          ScanWs S) {
+  __shared__ ScanLds L;
+  const int cl = threadIdx.x % kScanCH, i = threadIdx.x / kScanCH;
+  const int n = blockIdx.x * kScanCH + cl, j = blockIdx.y * kScanCB + i;
+  const bool live = n < N && j < nc;
+  const Elem<float> own = live ? load_elem(W, (size_t)j * N + n) : elem_identity<float>();
+  // forward inclusive scan: F[i] = e_0 o ... o e_i
+  Elem<float> e = own;
+  L.put(i, cl, e);
+  __syncthreads();
+#pragma unroll
+  for (int off = 1; off < kScanCB; off <<= 1) {
+    const bool has = i >= off;
+    Elem<float> other = has ? L.get(i - off, cl) : elem_identity<float>();
+    __syncthreads();
+    if (has) e = elem_combine(other, e);
+    L.put(i, cl, e);
+    __syncthreads();
   }
-  // down-sweeps
-  for (int j = j0; j < j1; ++j) {
-    const size_t o = (size_t)j * N + n;
-    W.pm[o] = m;
-    W.pP[o] = P;
-    elem_apply(load_elem(W, o), m, P);
+  const Elem<float> excl = i > 0 ? L.get(i - 1, cl) : elem_identity<float>();
+  __syncthreads();
+  // reverse inclusive scan: R[i] = e_i o ... o e_last
+  e = own;
+  L.put(i, cl, e);
+  __syncthreads();
+#pragma unroll
+  for (int off = 1; off < kScanCB; off <<= 1) {
+    const bool has = i + off < kScanCB;
+    Elem<float> other = has ? L.get(i + off, cl) : elem_identity<float>();
+    __syncthreads();
+    if (has) e = elem_combine(e, other);
+    L.put(i, cl, e);
+    __syncthreads();
   }
-  for (int j = j1 - 1; j >= j0; --j) {
-    const size_t o = (size_t)j * N + n;
-    W.sEta[o] = eta;
-    W.sJ[o] = J;
-    elem_back(load_elem(W, o), eta, J);
-  }
+  const Elem<float> after = i + 1 < kScanCB ? L.get(i + 1, cl) : elem_identity<float>();
+  if (!live) return;
+  const size_t ob = (size_t)blockIdx.y * N + n, o = (size_t)j * N + n;
+  float m = S.bm[ob], P = S.bP[ob];
+  elem_apply(excl, m, P);
+  W.pm[o] = m;
+  W.pP[o] = P;
+  float eta = S.bEta[ob], J = S.bJ[ob];
+  elem_back(after, eta, J);
+  W.sEta[o] = eta;
+  W.sJ[o] = J;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -156,7 +224,8 @@ static inline size_t plane_bytes(int nc, int N) { return align_up((size_t)nc * N
 
 size_t diag_smooth_workspace_bytes(int T, int N) {
   const int nc = (T + kChunk - 1) / kChunk;
-  return 9 * plane_bytes(nc, N);
+  const int nblk = (nc + kScanCB - 1) / kScanCB;
+  return 9 * plane_bytes(nc, N) + 9 * plane_bytes(nblk, N);
 }
 
 static LaneMap make_lane_map(int T, int N, int B) {
@@ -205,6 +274,11 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
   DiagWs W;
   float** planes[9] = {&W.eA, &W.eb, &W.eC, &W.eEta, &W.eJ, &W.pm, &W.pP, &W.sEta, &W.sJ};
   for (int i = 0; i < 9; ++i) *planes[i] = reinterpret_cast<float*>(base + i * pb);
+  ScanWs S;
+  S.nblk = (L.nc + kScanCB - 1) / kScanCB;
+  const size_t sb = plane_bytes(S.nblk, N);
+  float** splanes[9] = {&S.gA, &S.gb, &S.gC, &S.gEta, &S.gJ, &S.bm, &S.bP, &S.bEta, &S.bJ};
+  for (int i = 0; i < 9; ++i) *splanes[i] = reinterpret_cast<float*>(base + 9 * pb + i * sb);
 
   const int cpw = 64 >> L.nt_log2;
   const long waves = (long)L.ntile * ((L.nc + cpw - 1) / cpw);
@@ -219,8 +293,10 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
   }
   {
     ProfScope ps("diag_scan", st);
-    hipLaunchKernelGGL(diag_scan_kernel, dim3((N + kScanCH - 1) / kScanCH), dim3(kScanCH * kScanNSEG),
-                       0, st, N, L.nc, M, W);
+    const dim3 sgrid((N + kScanCH - 1) / kScanCH, S.nblk), sblock(kScanCH * kScanCB);
+    hipLaunchKernelGGL(diag_scan_reduce_kernel, sgrid, sblock, 0, st, N, L.nc, W, S);
+    hipLaunchKernelGGL(diag_scan_blocks_kernel, dim3((2 * N + 63) / 64), dim3(64), 0, st, N, M, S);
+    hipLaunchKernelGGL(diag_scan_local_kernel, sgrid, sblock, 0, st, N, L.nc, W, S);
   }
   const int vs_row = vs_diag ? 0 : D;
   {

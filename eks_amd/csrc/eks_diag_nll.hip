@@ -13,12 +13,14 @@
 // y is read once from HBM: 4 B per chain-frame regardless of the candidate count.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "eks_internal.hpp"
 #include "eks_nll_lane.hpp"
 
 namespace eks {
 
-constexpr int kNllChunk = 2048;      // frames per lane, grid mode
+constexpr int kNllChunk = 4096;      // frames per lane, grid mode (measured best with NCL = 8)
 constexpr int kNllChunkGrad = 512;   // frames per lane, Adam mode (one candidate: needs more lanes)
 constexpr int kNclGrid = 8;
 
@@ -123,12 +125,21 @@ __global__ __launch_bounds__(256) void diag_nll_assemble_kernel(NllGeom G, DiagM
   if constexpr (GRAD) dnll[(size_t)k * G.n_cand + ci] = fin ? -der(tot) : 0.0;
 }
 
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
 static NllGeom make_geom(int T, int N, int D, int n_cand, int per_keypoint, bool grad, int ncl) {
   NllGeom G;
   G.N = N;
   G.T = T;
   G.D = D;
   G.BN = grad ? kNllChunkGrad : kNllChunk;
+  if (!grad) {
+    const int bn = env_int("EKS_NLL_CHUNK", kNllChunk);
+    if (bn >= kNllChunkGrad) G.BN = bn;
+  }
   G.ncn = (T + G.BN - 1) / G.BN;
   int nt_log2 = 0;
   while ((1 << nt_log2) < N && nt_log2 < 6) ++nt_log2;
@@ -140,7 +151,15 @@ static NllGeom make_geom(int T, int N, int D, int n_cand, int per_keypoint, bool
   return G;
 }
 
-static inline int pick_ncl(int n_cand, bool grad) { return (!grad && n_cand >= kNclGrid) ? kNclGrid : 1; }
+// Tuning knobs (read once): EKS_NLL_NCL in {1,2,4,8} candidates per lane, EKS_NLL_CHUNK >= 512
+// frames per lane.  Defaults are what bench.py measured best on MI355X.
+static inline int pick_ncl(int n_cand, bool grad) {
+  if (grad || n_cand < 2) return 1;
+  int ncl = env_int("EKS_NLL_NCL", kNclGrid);
+  if (ncl != 1 && ncl != 2 && ncl != 4 && ncl != 8) ncl = kNclGrid;
+  while (ncl > 1 && n_cand < ncl) ncl >>= 1;
+  return ncl;
+}
 
 size_t diag_nll_workspace_bytes(int T, int N, int n_cand) {
   // sized for the larger of the two modes (grad planes + smaller chunks)
@@ -172,7 +191,12 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
 
   const int cpw = 64 >> G.nt_log2;
   const long waves = (long)G.ngrp * G.ntile * ((G.ncn + cpw - 1) / cpw);
-  const int wpb = (G.ngrp > 1 && G.ngrp <= 8) ? G.ngrp : 4;
+  int wpb = 4;
+  for (int w = 8; w >= 2; w >>= 1)
+    if (G.ngrp % w == 0) {
+      wpb = w;
+      break;
+    }
   const dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
   const bool unit = d.flags & EKS_FLAG_UNIT_AC;
 #define EKS_NLL_LAUNCH(RT, NCL)                                                                  \
@@ -188,8 +212,12 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
     ProfScope ps("diag_nll_summarize", st);
     if (grad) {
       EKS_NLL_LAUNCH(Dual, 1);
-    } else if (ncl == kNclGrid) {
-      EKS_NLL_LAUNCH(float, kNclGrid);
+    } else if (ncl == 8) {
+      EKS_NLL_LAUNCH(float, 8);
+    } else if (ncl == 4) {
+      EKS_NLL_LAUNCH(float, 4);
+    } else if (ncl == 2) {
+      EKS_NLL_LAUNCH(float, 2);
     } else {
       EKS_NLL_LAUNCH(float, 1);
     }

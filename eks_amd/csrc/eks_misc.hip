@@ -15,7 +15,7 @@ namespace eks {
 // in LDS (256 bins x 64 chains), one more sweep for the upper middle element of even counts.
 // ==========================================================================================
 struct MedianWs {
-  uint32_t* hist;    // [4][N][256]
+  uint32_t* hist;    // [4][256][N]  (bin-major: a wave's flush / scan touches consecutive chains)
   uint32_t* prefix;  // [N] bits fixed so far
   uint32_t* rank;    // [N] rank of the lower middle element within the current prefix bucket
   uint32_t* count;   // [N] number of non-NaN frames
@@ -29,11 +29,13 @@ __device__ __forceinline__ uint32_t var_key(float v, bool& valid) {
   return __float_as_uint(c);
 }
 
+constexpr int kMedWaves = 16;  // waves per block (2 blocks of 64 KiB LDS fill a CU's 32 wave slots)
+
 template <int PASS>
-__global__ __launch_bounds__(256) void median_hist_kernel(int T, int N, int rows_per_block,
+__global__ __launch_bounds__(64 * kMedWaves) void median_hist_kernel(int T, int N, int rows_per_block,
                                                          const float* __restrict__ var, MedianWs W) {
   __shared__ uint32_t h[256][64];
-  for (int i = threadIdx.x; i < 256 * 64; i += 256) (&h[0][0])[i] = 0u;
+  for (int i = threadIdx.x; i < 256 * 64; i += 64 * kMedWaves) (&h[0][0])[i] = 0u;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ntile = (N + 63) / 64;
@@ -44,20 +46,30 @@ __global__ __launch_bounds__(256) void median_hist_kernel(int T, int N, int rows
   if (n < N) {
     const uint32_t pref = PASS > 0 ? W.prefix[n] : 0u;
     constexpr int shift = 24 - 8 * PASS;
-    for (int t = t_begin + wave; t < t_end; t += 4) {
-      bool valid;
-      const uint32_t key = var_key(var[(size_t)t * N + n], valid);
-      if (!valid) continue;
-      if (PASS > 0 && (key >> (shift + 8)) != pref) continue;
-      atomicAdd(&h[(key >> shift) & 255u][lane], 1u);
+    // 8 rows in flight per lane: the loop is otherwise bound by one HBM round trip per row
+    for (int t = t_begin + wave; t < t_end; t += 8 * kMedWaves) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int tt = t + kMedWaves * u;
+        v[u] = tt < t_end ? var[(size_t)tt * N + n] : __uint_as_float(0x7FC00000u);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        bool valid;
+        const uint32_t key = var_key(v[u], valid);
+        if (!valid) continue;
+        if (PASS > 0 && (key >> (shift + 8)) != pref) continue;
+        atomicAdd(&h[(key >> shift) & 255u][lane], 1u);
+      }
     }
   }
   __syncthreads();
   if (n < N) {
-    uint32_t* g = W.hist + ((size_t)PASS * N + n) * 256;
-    for (int b = wave; b < 256; b += 4) {
+    uint32_t* g = W.hist + (size_t)PASS * 256 * N + n;
+    for (int b = wave; b < 256; b += kMedWaves) {
       const uint32_t c = h[b][lane];
-      if (c) atomicAdd(&g[b], c);
+      if (c) atomicAdd(&g[(size_t)b * N], c);
     }
   }
 }
@@ -66,11 +78,11 @@ template <int PASS>
 __global__ void median_select_kernel(int N, MedianWs W) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
-  const uint32_t* g = W.hist + ((size_t)PASS * N + n) * 256;
+  const uint32_t* g = W.hist + (size_t)PASS * 256 * N + n;
   uint32_t rank;
   if (PASS == 0) {
     uint32_t cnt = 0;
-    for (int b = 0; b < 256; ++b) cnt += g[b];
+    for (int b = 0; b < 256; ++b) cnt += g[(size_t)b * N];
     W.count[n] = cnt;
     W.less_eq[2 * n] = 0;
     rank = cnt ? (cnt - 1) / 2 : 0;
@@ -80,7 +92,7 @@ __global__ void median_select_kernel(int N, MedianWs W) {
   uint32_t cum = 0;
   int bin = 255;
   for (int b = 0; b < 256; ++b) {
-    const uint32_t c = g[b];
+    const uint32_t c = g[(size_t)b * N];
     if (cum + c > rank) {
       bin = b;
       break;
@@ -91,12 +103,12 @@ __global__ void median_select_kernel(int N, MedianWs W) {
   W.rank[n] = rank - cum;
   W.prefix[n] = ((PASS > 0 ? W.prefix[n] : 0u) << 8) | (uint32_t)bin;
   if (PASS == 3) {
-    W.less_eq[2 * n + 1] = g[bin];
+    W.less_eq[2 * n + 1] = g[(size_t)bin * N];
     W.next[n] = 0xFFFFFFFFu;
   }
 }
 
-__global__ __launch_bounds__(256) void median_next_kernel(int T, int N, int rows_per_block,
+__global__ __launch_bounds__(64 * kMedWaves) void median_next_kernel(int T, int N, int rows_per_block,
                                                          const float* __restrict__ var, MedianWs W) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ntile = (N + 63) / 64;
@@ -107,10 +119,19 @@ __global__ __launch_bounds__(256) void median_next_kernel(int T, int N, int rows
   const int t_end = min(T, t_begin + rows_per_block);
   const uint32_t key_lo = W.prefix[n];
   uint32_t best = 0xFFFFFFFFu;
-  for (int t = t_begin + wave; t < t_end; t += 4) {
-    bool valid;
-    const uint32_t key = var_key(var[(size_t)t * N + n], valid);
-    if (valid && key > key_lo && key < best) best = key;
+  for (int t = t_begin + wave; t < t_end; t += 8 * kMedWaves) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int tt = t + kMedWaves * u;
+      v[u] = tt < t_end ? var[(size_t)tt * N + n] : __uint_as_float(0x7FC00000u);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      bool valid;
+      const uint32_t key = var_key(v[u], valid);
+      if (valid && key > key_lo && key < best) best = key;
+    }
   }
   if (best != 0xFFFFFFFFu) atomicMin(&W.next[n], best);
 }
@@ -153,21 +174,21 @@ int const_r(int T, int N, const float* var, double min_var, double* rconst, void
   if (e != hipSuccess) return hip_status(e);
   const int ntile = (N + 63) / 64;
   // enough blocks to fill the chip, at least 256 rows per block so the LDS flush amortises
-  int rows = (int)(((long)T * ntile + 2047) / 2048);
-  if (rows < 256) rows = 256;
-  rows = (rows + 3) / 4 * 4;
+  int rows = (int)(((long)T * ntile + 511) / 512);
+  if (rows < 8 * kMedWaves) rows = 8 * kMedWaves;
+  rows = (rows + kMedWaves - 1) / kMedWaves * kMedWaves;
   const int nslab = (T + rows - 1) / rows;
   const dim3 grid(ntile * nslab), sel((N + 255) / 256);
   ProfScope ps("const_r_select", st);
-  hipLaunchKernelGGL(median_hist_kernel<0>, grid, dim3(256), 0, st, T, N, rows, var, W);
+  hipLaunchKernelGGL(median_hist_kernel<0>, grid, dim3(64 * kMedWaves), 0, st, T, N, rows, var, W);
   hipLaunchKernelGGL(median_select_kernel<0>, sel, dim3(256), 0, st, N, W);
-  hipLaunchKernelGGL(median_hist_kernel<1>, grid, dim3(256), 0, st, T, N, rows, var, W);
+  hipLaunchKernelGGL(median_hist_kernel<1>, grid, dim3(64 * kMedWaves), 0, st, T, N, rows, var, W);
   hipLaunchKernelGGL(median_select_kernel<1>, sel, dim3(256), 0, st, N, W);
-  hipLaunchKernelGGL(median_hist_kernel<2>, grid, dim3(256), 0, st, T, N, rows, var, W);
+  hipLaunchKernelGGL(median_hist_kernel<2>, grid, dim3(64 * kMedWaves), 0, st, T, N, rows, var, W);
   hipLaunchKernelGGL(median_select_kernel<2>, sel, dim3(256), 0, st, N, W);
-  hipLaunchKernelGGL(median_hist_kernel<3>, grid, dim3(256), 0, st, T, N, rows, var, W);
+  hipLaunchKernelGGL(median_hist_kernel<3>, grid, dim3(64 * kMedWaves), 0, st, T, N, rows, var, W);
   hipLaunchKernelGGL(median_select_kernel<3>, sel, dim3(256), 0, st, N, W);
-  hipLaunchKernelGGL(median_next_kernel, grid, dim3(256), 0, st, T, N, rows, var, W);
+  hipLaunchKernelGGL(median_next_kernel, grid, dim3(64 * kMedWaves), 0, st, T, N, rows, var, W);
   hipLaunchKernelGGL(median_final_kernel, sel, dim3(256), 0, st, N, min_var, W, rconst);
   return hip_status(hipGetLastError());
 }

@@ -9,9 +9,11 @@
 //
 // With R constant the run-local variance C converges geometrically to the Riccati fixed point, so
 // the chunk is processed in three wave-uniform regimes of decreasing cost:
-//   0  full recursion (rcp + log per frame) until C is within 1e-6 of the closed-form fixed point,
+//   0  full recursion (rcp + log per frame) until C is within ~1e-6 (plus the float32 stall
+//      distance ulp / (1 - rho)) of the closed-form fixed point, then C is snapped onto it,
 //   1  C frozen: gains are constants; A (memory of x_in) still decays, eta/J still accumulate,
-//   2  A < 1e-12: only the local mean b and the sum of squared innovations advance (3 flops/frame).
+//   2  A < 1e-12: only the innovation d' = rho d + (y' - a y) and the sum of its squares advance:
+//      two FMAs per frame and candidate, fused over the lane's candidates.
 // d nll / d log s comes from running the same code on dual numbers (forward-mode AD; replaces
 // jax.value_and_grad at eks/core.py:652).
 #pragma once
@@ -26,6 +28,14 @@
 #endif
 
 namespace eks {
+
+// two float32 lanes in one 64-bit register pair: arithmetic on it compiles to gfx950's packed
+// VALU (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32), i.e. two candidate filters per instruction
+#if defined(__clang__)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#else
+typedef float f32x2 __attribute__((vector_size(8)));
+#endif
 
 constexpr double kLog2Pi = 1.8378770664093454835606594728112;
 
@@ -112,82 +122,41 @@ EKS_HD void riccati_fixed_point(double a, double c, double r, double sq, double&
   dCinf = sq * (r + c2 * Cinf) / (2.0 * c2 * Cinf + beta);
 }
 
-// One lane: chunk [t0, t0+len) of chain n for NCL candidates.  y: [T][N] float.
-// sq[c] = s_c * q of the chain (value; its derivative w.r.t. log s is itself).
+// State of one lane: NCL candidate filters of one chain over one chunk.
 template <typename R, int NCL, bool UNIT>
-EKS_HD void nll_summarize_chunk(const float* __restrict__ y, int N, int n, int t0, int len,
-                                double r_d, double a_d, double c_d, const double* sq_d,
-                                NllElem<R>* out) {
-  const float r = (float)r_d;
-  const R rR = R(r);
+struct NllLane {
   ChainParams<R> pc[NCL];
   R CinfR[NCL], gI[NCL], rgI[NCL], tI[NCL], cgI[NCL], logSinf[NCL];
   Elem<R> e[NCL];
+  R dl[NCL];          // innovation of the last consumed frame
+  float y_last;       // last consumed observation
   Acc64<R> quad[NCL], logacc[NCL], acc2[NCL];
-  const float af = (float)a_d, cf = (float)c_d;
-#pragma unroll
-  for (int k = 0; k < NCL; ++k) {
-    pc[k].a = R(af);
-    pc[k].c = R(cf);
-    pc[k].q_s = make_real(R(), (float)sq_d[k], (float)sq_d[k]);
-    double Ci, dCi;
-    riccati_fixed_point(UNIT ? 1.0 : a_d, UNIT ? 1.0 : c_d, r_d, sq_d[k], Ci, dCi);
-    CinfR[k] = make_real(R(), (float)Ci, (float)dCi);
-    const R Sinf = UNIT ? (rR + CinfR[k]) : (rR + CinfR[k] * pc[k].c * pc[k].c);
-    gI[k] = rcp(Sinf);
-    rgI[k] = rR * gI[k];
-    cgI[k] = UNIT ? gI[k] : pc[k].c * gI[k];
-    tI[k] = CinfR[k] * cgI[k];
-    logSinf[k] = log_with_rcp(Sinf, gI[k]);
-    e[k] = elem_identity<R>();
-  }
-  int n_post = 0, i = 0;
-  // ---- regime 0: full recursion until every candidate of every lane sits on its fixed point
-  while (i < len) {
-    const int nb = (len - i) < 8 ? (len - i) : 8;
-    float yb[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-      if (q < nb) yb[q] = y[(size_t)(t0 + i + q) * N + n];
-    bool ok = true;
+  int phase[NCL], n_post[NCL];
+  float tolC[NCL];
+  R rR;
+
+  // Transient code: consume NB (<= 8) frames with per-candidate regimes (wave-uniform).
+  template <int NB>
+  EKS_HD void consume(const float (&yb)[8]) {
 #pragma unroll
     for (int k = 0; k < NCL; ++k) {
-      R qs = R(0.f), ls = R(0.f);
+      if (phase[k] == 2) {
+        // ---- regime 2: only the run-local mean and the squared innovations advance
+        R s2 = R(0.f);
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (q < nb) {
-          R S, g, d;
-          elem_append<R, UNIT>(e[k], R(yb[q]), rR, pc[k], S, g, d);
-          qs = qs + d * d * g;
-          ls = ls + log_with_rcp(S, g);
+        for (int q = 0; q < NB; ++q) {
+          const R d = UNIT ? (R(yb[q]) - e[k].b) : (R(yb[q]) - pc[k].c * e[k].b);
+          s2 = s2 + d * d;
+          e[k].b = UNIT ? (e[k].b + tI[k] * d) : pc[k].a * (e[k].b + tI[k] * d);
+          dl[k] = d;
         }
-      quad[k].add(qs);
-      logacc[k].add(ls);
-      const float tol = 1e-6f;
-      ok = ok && fabsf(val(e[k].C) - val(CinfR[k])) <= tol * val(CinfR[k]) &&
-           fabsf(der(e[k].C) - der(CinfR[k])) <= tol * fabsf(der(CinfR[k])) + 1e-30f;
-    }
-    i += nb;
-    if (EKS_WAVE_ALL(ok)) {
+        acc2[k].add(s2);
+        n_post[k] += NB;
+      } else if (phase[k] == 1) {
+        // ---- regime 1: C frozen; A still decays, eta / J still accumulate
+        R s2 = R(0.f);
 #pragma unroll
-      for (int k = 0; k < NCL; ++k) e[k].C = CinfR[k];
-      break;
-    }
-  }
-  // ---- regime 1: C frozen at the fixed point; A still decays, eta / J still accumulate
-  while (i < len) {
-    const int nb = (len - i) < 8 ? (len - i) : 8;
-    float yb[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-      if (q < nb) yb[q] = y[(size_t)(t0 + i + q) * N + n];
-    bool dead = true;
-#pragma unroll
-    for (int k = 0; k < NCL; ++k) {
-      R s2 = R(0.f);
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (q < nb) {
+        for (int q = 0; q < NB; ++q) {
           const R d = UNIT ? (R(yb[q]) - e[k].b) : (R(yb[q]) - pc[k].c * e[k].b);
           s2 = s2 + d * d;
           const R Acg = e[k].A * cgI[k];
@@ -195,51 +164,178 @@ EKS_HD void nll_summarize_chunk(const float* __restrict__ y, int N, int n, int t
           e[k].J = e[k].J + (UNIT ? Acg * e[k].A : Acg * e[k].A * pc[k].c);
           e[k].b = UNIT ? (e[k].b + tI[k] * d) : pc[k].a * (e[k].b + tI[k] * d);
           e[k].A = UNIT ? e[k].A * rgI[k] : pc[k].a * e[k].A * rgI[k];
+          dl[k] = d;
         }
-      acc2[k].add(s2);
-      dead = dead && fabsf(val(e[k].A)) < 1e-12f && fabsf(der(e[k].A)) < 1e-12f;
-    }
-    n_post += nb;
-    i += nb;
-    if (EKS_WAVE_ALL(dead)) {
+        acc2[k].add(s2);
+        n_post[k] += NB;
+        const bool dead = fabsf(val(e[k].A)) < 1e-12f && fabsf(der(e[k].A)) < 1e-12f;
+        if (EKS_WAVE_ALL(dead)) {
+          phase[k] = 2;
+          e[k].A = R(0.f);
+        }
+      } else {
+        // ---- regime 0: full recursion until C sits on its fixed point
+        R qs = R(0.f), ls = R(0.f);
 #pragma unroll
-      for (int k = 0; k < NCL; ++k) e[k].A = R(0.f);
-      break;
+        for (int q = 0; q < NB; ++q) {
+          R S, g, d;
+          elem_append<R, UNIT>(e[k], R(yb[q]), rR, pc[k], S, g, d);
+          qs = qs + d * d * g;
+          ls = ls + log_with_rcp(S, g);
+          dl[k] = d;
+        }
+        quad[k].add(qs);
+        logacc[k].add(ls);
+        const bool ok = fabsf(val(e[k].C) - val(CinfR[k])) <= tolC[k] * val(CinfR[k]) &&
+                        fabsf(der(e[k].C) - der(CinfR[k])) <=
+                            4.f * tolC[k] * fabsf(der(CinfR[k])) + 1e-30f;
+        if (EKS_WAVE_ALL(ok)) {
+          phase[k] = 1;
+          e[k].C = CinfR[k];
+        }
+      }
     }
+    y_last = yb[NB - 1];
   }
-  // ---- regime 2: only the run-local mean and the squared innovations advance
-  while (i < len) {
-    const int nb = (len - i) < 8 ? (len - i) : 8;
+
+  EKS_HD bool all_steady() const {
+    bool all2 = true;
+#pragma unroll
+    for (int k = 0; k < NCL; ++k) all2 = all2 && phase[k] == 2;
+    return all2;
+  }
+};
+
+// One lane: chunk [t0, t0+len) of chain n for NCL candidates.  y: [T][N] float.
+// sq[c] = s_c * q of the chain (value; its derivative w.r.t. log s is itself).
+template <typename R, int NCL, bool UNIT>
+EKS_HD void nll_summarize_chunk(const float* __restrict__ y, int N, int n, int t0, int len,
+                                double r_d, double a_d, double c_d, const double* sq_d,
+                                NllElem<R>* out) {
+  NllLane<R, NCL, UNIT> L;
+  const float r = (float)r_d;
+  L.rR = R(r);
+  L.y_last = 0.f;
+  const float af = (float)a_d, cf = (float)c_d;
+#pragma unroll
+  for (int k = 0; k < NCL; ++k) {
+    L.pc[k].a = R(af);
+    L.pc[k].c = R(cf);
+    L.pc[k].q_s = make_real(R(), (float)sq_d[k], (float)sq_d[k]);
+    double Ci, dCi;
+    riccati_fixed_point(UNIT ? 1.0 : a_d, UNIT ? 1.0 : c_d, r_d, sq_d[k], Ci, dCi);
+    L.CinfR[k] = make_real(R(), (float)Ci, (float)dCi);
+    const R Sinf = UNIT ? (L.rR + L.CinfR[k]) : (L.rR + L.CinfR[k] * L.pc[k].c * L.pc[k].c);
+    L.gI[k] = rcp(Sinf);
+    L.rgI[k] = L.rR * L.gI[k];
+    L.cgI[k] = UNIT ? L.gI[k] : L.pc[k].c * L.gI[k];
+    L.tI[k] = L.CinfR[k] * L.cgI[k];
+    L.logSinf[k] = log_with_rcp(Sinf, L.gI[k]);
+    L.e[k] = elem_identity<R>();
+    L.dl[k] = R(0.f);
+    L.phase[k] = 0;
+    L.n_post[k] = 0;
+    // the float32 recursion stalls within ~ulp / (1 - rho) of the true fixed point, rho = (a r g)^2
+    const float rho = UNIT ? val(L.rgI[k]) * val(L.rgI[k]) : af * af * val(L.rgI[k]) * val(L.rgI[k]);
+    L.tolC[k] = 1e-6f + 2.4e-7f / fmaxf(1.0f - rho, 1e-6f);
+  }
+  const float* yp = y + (size_t)t0 * N + n;
+  const size_t rs = (size_t)N;
+  const int nfull = len / 8;
+  int blk = 0;
+  // ---- transient: 8-frame blocks with per-candidate regimes until every candidate is steady
+  bool steady = false;
+  while (blk < nfull && !steady) {
     float yb[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-      if (q < nb) yb[q] = y[(size_t)(t0 + i + q) * N + n];
+    for (int q = 0; q < 8; ++q) yb[q] = yp[(size_t)(blk * 8 + q) * rs];
+    L.template consume<8>(yb);
+    ++blk;
+    steady = L.all_steady();
+  }
+  // ---- steady state, fused over candidates.  With frozen gains the innovation obeys
+  //      d' = rho d + (y' - a y),  rho = a (1 - c t):  two FMAs per frame and candidate, the
+  //      candidates interleaved inside the frame loop (independent chains issue back to back).
+  //      Loads are double-buffered: the next 8 frames are in flight while 8 are consumed.
+  if (steady && blk < nfull) {
+    R rho[NCL], dk[NCL], s2[NCL];
 #pragma unroll
     for (int k = 0; k < NCL; ++k) {
-      R s2 = R(0.f);
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (q < nb) {
-          const R d = UNIT ? (R(yb[q]) - e[k].b) : (R(yb[q]) - pc[k].c * e[k].b);
-          s2 = s2 + d * d;
-          e[k].b = UNIT ? (e[k].b + tI[k] * d) : pc[k].a * (e[k].b + tI[k] * d);
-        }
-      acc2[k].add(s2);
+      rho[k] = UNIT ? (R(1.f) - L.tI[k]) : L.pc[k].a * (R(1.f) - L.pc[k].c * L.tI[k]);
+      dk[k] = L.dl[k];
+      s2[k] = R(0.f);
     }
-    n_post += nb;
-    i += nb;
+    float yprev = L.y_last;
+    float ya[8], yb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ya[q] = yp[(size_t)(blk * 8 + q) * rs];
+    const int first = blk;
+    auto eat = [&](const float (&yy)[8]) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float dy = UNIT ? (yy[q] - yprev) : (yy[q] - af * yprev);
+        yprev = yy[q];
+#pragma unroll
+        for (int k = 0; k < NCL; ++k) {
+          dk[k] = rho[k] * dk[k] + R(dy);
+          s2[k] = s2[k] + dk[k] * dk[k];
+        }
+      }
+    };
+    auto flush = [&]() {
+#pragma unroll
+      for (int k = 0; k < NCL; ++k) {
+        L.acc2[k].add(s2[k]);
+        s2[k] = R(0.f);
+      }
+    };
+    for (; blk + 2 <= nfull; blk += 2) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) yb[q] = yp[(size_t)((blk + 1) * 8 + q) * rs];
+      eat(ya);
+      if (blk + 2 < nfull) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ya[q] = yp[(size_t)((blk + 2) * 8 + q) * rs];
+      }
+      eat(yb);
+      if ((blk & 2) != 0) flush();          // float32 partial sums span at most 32 frames
+    }
+    if (blk < nfull) {
+      eat(ya);
+      ++blk;
+    }
+    flush();
+    // back to the (b, d) state of the transient code so a ragged tail can continue
+    const int eaten = (blk - first) * 8;
+#pragma unroll
+    for (int k = 0; k < NCL; ++k) {
+      L.n_post[k] += eaten;
+      L.dl[k] = dk[k];
+      if (UNIT) {
+        L.e[k].b = R(yprev) - rho[k] * dk[k];                  // b_n = y_n - (1 - t) d_n
+      } else {
+        const R bprev = (R(yprev) - dk[k]) * rcp(L.pc[k].c);   // c b_{n-1} = y_n - d_n
+        L.e[k].b = L.pc[k].a * (bprev + L.tI[k] * dk[k]);
+      }
+    }
+    L.y_last = yprev;
+  }
+  for (int i = blk * 8; i < len; ++i) {        // ragged tail (or a chunk shorter than 8 frames)
+    float y1[8];
+    y1[0] = yp[(size_t)i * rs];
+    L.template consume<1>(y1);
   }
 #pragma unroll
   for (int k = 0; k < NCL; ++k) {
-    out[k].e = e[k];
+    out[k].e = L.e[k];
     // ell = -0.5 * (len log 2pi + sum log S + sum d^2 / S)
-    double q_v = quad[k].v + (double)val(gI[k]) * acc2[k].v;
-    double l_v = logacc[k].v + (double)n_post * (double)val(logSinf[k]);
+    double q_v = L.quad[k].v + (double)val(L.gI[k]) * L.acc2[k].v;
+    double l_v = L.logacc[k].v + (double)L.n_post[k] * (double)val(L.logSinf[k]);
     out[k].ell = -0.5 * ((double)len * kLog2Pi + l_v + q_v);
     double q_d = 0.0, l_d = 0.0;
     if constexpr (sizeof(R) == sizeof(Dual)) {
-      q_d = quad[k].d + (double)der(gI[k]) * acc2[k].v + (double)val(gI[k]) * acc2[k].d;
-      l_d = logacc[k].d + (double)n_post * (double)der(logSinf[k]);
+      q_d = L.quad[k].d + (double)der(L.gI[k]) * L.acc2[k].v + (double)val(L.gI[k]) * L.acc2[k].d;
+      l_d = L.logacc[k].d + (double)L.n_post[k] * (double)der(L.logSinf[k]);
     }
     out[k].dell = -0.5 * (l_d + q_d);
   }
