@@ -1,0 +1,259 @@
+"""Core operators of the ensemble Kalman smoother on MI355X (mirror of the reference's
+eks/core.py, same names / arguments / return types).
+
+    ensemble(marker_array, avg_mode, var_mode, nan_replacement) -> MarkerArray (1,V,T,K,5)
+    compute_initial_guesses(ensemble_vars) -> float
+    run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames, smooth_param, blocks,
+                        lr, s_bounds_log, tol, safety_cap, h_fn) -> (s_finals, ms, Vs)
+    optimize_smooth_param(...)           -> fills s_finals in place
+    constant_R_from_timevarying(R_t, min_var)
+
+All arithmetic of the Kalman path runs in the HIP kernels of libeks_hip.so (eks_amd/csrc); this
+module only moves arrays to the device in the kernels' frame-major layout and drives the search
+for the smoothing parameter.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import logging
+import time
+from typing import Callable, Literal
+
+import numpy as np
+
+from . import hip_ops
+from .marker_array import MarkerArray
+from .utils import frame_spans
+
+logger = logging.getLogger(__name__)
+
+
+# ------------------------------------------------------------------------------------------
+def _torch():
+    import torch
+    return torch
+
+
+def _to_numpy(a, dtype=None) -> np.ndarray:
+    if hasattr(a, 'detach'):                      # torch tensor
+        a = a.detach().cpu().numpy()
+    return np.asarray(a, dtype=dtype)
+
+
+def ensemble(marker_array: MarkerArray, avg_mode: Literal['mean', 'median'] = 'median',
+             var_mode: Literal['var', 'confidence_weighted_var'] = 'confidence_weighted_var',
+             nan_replacement: float = 1000.0) -> MarkerArray:
+    """Ensemble mean/median and variance over models (reference eks/core.py:25-101), computed by
+    the `eks_ensemble` kernel.  Input (M,V,T,K,3) fields x,y,likelihood; output float32
+    (1,V,T,K,5) fields x,y,var_x,var_y,likelihood."""
+    torch = _torch()
+    dev = hip_ops.require_gpu()
+    fields = list(marker_array.data_fields)
+    arr = _to_numpy(marker_array.array)
+    if fields != ['x', 'y', 'likelihood']:
+        arr = arr[..., [fields.index(f) for f in ('x', 'y', 'likelihood')]]
+    mk = torch.as_tensor(np.ascontiguousarray(arr, dtype=np.float32), device=dev)
+    stats = hip_ops.ensemble(mk, avg_mode, var_mode, nan_replacement)
+    return MarkerArray(stats.cpu().numpy()[None], data_fields=['x', 'y', 'var_x', 'var_y', 'likelihood'])
+
+
+def compute_initial_guesses(ensemble_vars) -> float:
+    """Initial guess for s: std of frame-to-frame changes of the ensemble variance over the first
+    2000 frames, rounded to 5 decimals (reference eks/core.py:104-133)."""
+    ev = np.asarray(ensemble_vars)[:2000]
+    if ev.shape[0] < 2:
+        raise ValueError('Not enough frames to compute temporal differences.')
+    return float(round(float(np.nanstd(ev[1:] - ev[:-1])), 5))
+
+
+def constant_R_from_timevarying(R_t_np: np.ndarray, min_var: float = 1e-4) -> np.ndarray:
+    """(T', O, O) -> constant diagonal R by median over time, floored (reference
+    eks/core.py:702-709).  Host helper kept for API parity; the optimiser uses `eks_const_r`."""
+    d = np.diagonal(np.asarray(R_t_np), axis1=-2, axis2=-1)
+    return np.diag(np.clip(np.nanmedian(d, axis=0), min_var, np.inf)).astype(R_t_np.dtype)
+
+
+# ------------------------------------------------------------------------------------------
+class _DeviceProblem:
+    """Inputs of run_kalman_smoother on the device, frame-major."""
+
+    def __init__(self, ys, m0s, S0s, As, Cs, Qs, ensemble_vars):
+        torch = _torch()
+        self.dev = hip_ops.require_gpu()
+        host = {k: np.ascontiguousarray(_to_numpy(v, np.float64))
+                for k, v in dict(m0=m0s, S0=S0s, A=As, C=Cs, Q=Qs).items()}
+        self.K, self.D = host['m0'].shape
+        self.O = host['C'].shape[1]
+        self.flags = hip_ops.model_flags(host['S0'], host['A'], host['C'], host['Q'])
+        self.params = [torch.as_tensor(host[k], device=self.dev) for k in ('m0', 'S0', 'A', 'C', 'Q')]
+        # ys arrives (K,T,O) like upstream; a torch tensor that is a transposed view of a
+        # frame-major buffer is taken zero-copy, anything else is transposed once
+        if hasattr(ys, 'detach'):
+            y = ys.to(self.dev, dtype=torch.float32).transpose(0, 1).contiguous()
+        else:
+            y = torch.as_tensor(np.ascontiguousarray(np.swapaxes(_to_numpy(ys), 0, 1),
+                                                     dtype=np.float32), device=self.dev)
+        if hasattr(ensemble_vars, 'detach'):
+            var = ensemble_vars.to(self.dev, dtype=torch.float32).contiguous()
+        else:
+            var = torch.as_tensor(np.ascontiguousarray(_to_numpy(ensemble_vars), dtype=np.float32),
+                                  device=self.dev)
+        self.T = y.shape[0]
+        if tuple(y.shape) != (self.T, self.K, self.O) or tuple(var.shape) != (self.T, self.K, self.O):
+            raise ValueError(f'ys must be (K,T,O) and ensemble_vars (T,K,O); got {tuple(ys.shape)} '
+                             f'and {tuple(ensemble_vars.shape)}')
+        self.y, self.var = y, var
+
+    def cropped(self, s_frames):
+        """(y, var) restricted to the s_frames spans (loss only, reference eks/core.py:599-601)."""
+        if not s_frames or (len(s_frames) == 1 and s_frames[0] == (None, None)):
+            return self.y, self.var
+        if not isinstance(s_frames, list):
+            raise TypeError('s_frames must be a list of (start, end) tuples or None.')
+        torch = _torch()
+        spans = frame_spans(self.T, s_frames)
+        idx = torch.cat([torch.arange(a, b, device=self.dev) for a, b in spans])
+        return self.y.index_select(0, idx).contiguous(), self.var.index_select(0, idx).contiguous()
+
+
+def _block_csr(blocks, K):
+    members = np.concatenate([np.asarray(b, dtype=np.int32) for b in blocks])
+    offs = np.zeros(len(blocks) + 1, dtype=np.int32)
+    offs[1:] = np.cumsum([len(b) for b in blocks])
+    of_kp = np.empty(K, dtype=np.int64)
+    for i, b in enumerate(blocks):
+        of_kp[np.asarray(b, dtype=int)] = i
+    return offs, members, of_kp
+
+
+def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, s_bounds_log, tol,
+                        safety_cap, min_R_var, s_mode, n_grid):
+    """Returns (s per keypoint as a device float64 tensor, info dict)."""
+    torch = _torch()
+    y_c, var_c = P.cropped(s_frames)
+    rconst = hip_ops.const_r(var_c, min_R_var)
+    lo, hi = float(s_bounds_log[0]), float(s_bounds_log[1])
+    offs, members, of_kp = _block_csr(blocks, P.K)
+    nb = len(blocks)
+    if s_mode == 'grid':
+        cand = torch.exp(torch.linspace(lo, hi, n_grid, dtype=torch.float64, device=P.dev))
+        nll = hip_ops.nll(y_c, rconst, *P.params, cand, flags=P.flags)
+        if nb != P.K:                                   # blocks share one s: sum member losses
+            blk = torch.zeros((nb, n_grid), dtype=torch.float64, device=P.dev)
+            blk.index_add_(0, torch.as_tensor(of_kp, device=P.dev), nll)
+            s_blk, idx = hip_ops.argmin_s(blk, cand)
+            s = s_blk[torch.as_tensor(of_kp, device=P.dev)]
+        else:
+            s, idx = hip_ops.argmin_s(nll, cand)
+        return s, dict(mode='grid', nll=nll, argmin=idx, candidates=cand)
+    # Adam on u = log s (reference eks/core.py:612-613, :439-441: float32 initial value)
+    u0 = np.array([np.float32(np.log(np.clip(np.mean([s_guess_per_k[k] for k in b]), 1e-6, 1e3)))
+                   for b in blocks], dtype=np.float64)
+    state = np.zeros((nb, 6))
+    state[:, 0] = u0
+    state[:, 3] = np.inf
+    state = torch.as_tensor(state, device=P.dev)
+    offs_d = torch.as_tensor(offs, device=P.dev)
+    mem_d = torch.as_tensor(members, device=P.dev)
+    s_kp = torch.as_tensor(np.exp(np.clip(u0, lo, hi))[of_kp], device=P.dev)
+    n_active = torch.zeros(1, dtype=torch.int32, device=P.dev)
+    iters = 0
+    for iters in range(1, int(safety_cap) + 1):
+        nll, g = hip_ops.nll(y_c, rconst, *P.params, s_kp[:, None].contiguous(), per_keypoint=True,
+                             want_grad=True, flags=P.flags)
+        hip_ops.adam_step(offs_d, mem_d, nll[:, 0].contiguous(), g[:, 0].contiguous(), state, s_kp,
+                          n_active, lr, lo, hi, tol, safety_cap)
+        if int(n_active.item()) == 0:
+            break
+    return s_kp, dict(mode='adam', state=state, launches=iters)
+
+
+def optimize_smooth_param(ys, m0s, S0s, As, Cs, Qs, Rs, blocks, s_finals, s_frames, s_guess_per_k,
+                          lr: float = 0.25, s_bounds_log=(-8.0, 8.0), tol: float = 1e-3,
+                          safety_cap: int = 300, min_R_var: float = 1e-4,
+                          h_fn_combined: Callable | None = None) -> None:
+    """One s per block of keypoints by Adam on log s over the summed constant-R filter NLL
+    (reference eks/core.py:306-559, :562-699).  `Rs` is the reference's (K,T,O,O) stack of
+    diagonal R_t; only its diagonal is used.  Writes `s_finals` in place."""
+    if h_fn_combined is not None:
+        raise NotImplementedError('nonlinear emission functions are outside the accelerated path')
+    K = np.shape(ys)[0]
+    if not blocks:
+        blocks = [[k] for k in range(K)]
+    Rd = np.diagonal(_to_numpy(Rs), axis1=-2, axis2=-1)                 # (K,T,O)
+    P = _DeviceProblem(ys, m0s, S0s, As, Cs, Qs, np.swapaxes(Rd, 0, 1))
+    s, info = _optimize_on_device(P, blocks, s_frames, np.asarray(s_guess_per_k, float), lr,
+                                  s_bounds_log, tol, safety_cap, min_R_var, 'adam', 0)
+    s_finals[:] = s.cpu().numpy()
+    _log_opt(blocks, s_finals, info)
+
+
+def _log_opt(blocks, s_finals, info) -> None:
+    if not logger.isEnabledFor(logging.DEBUG) or info.get('mode') != 'adam':
+        return
+    st = info['state'].cpu().numpy()
+    for b, blk in enumerate(blocks):
+        logger.debug(f'[opt s | block {list(blk)}] s={s_finals[blk[0]]:.6g}, '
+                     f'iters={int(st[b, 4])}, NLL={st[b, 3]:.6f}')
+
+
+def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list | None = None,
+                        smooth_param: float | list | None = None,
+                        blocks: list[list[int]] | None = None, lr: float = 0.25,
+                        s_bounds_log: tuple = (-8.0, 8.0), tol: float = 1e-2, safety_cap: int = 300,
+                        h_fn: Callable | None = None, *, s_mode: str = 'adam', n_grid: int = 64,
+                        vs_diag: bool = False, return_device: bool = False):
+    """Choose (or optimise) the process-noise scale s per keypoint, then run the Kalman filter +
+    RTS smoother.  Drop-in for the reference's eks/core.py:159-302.
+
+    ys (K,T,O); m0s (K,D); S0s, As, Qs (K,D,D); Cs (K,O,D); ensemble_vars (T,K,O) (note T-major);
+    R_{k,t} = diag(clip(ensemble_vars[t,k], 1e-12)).  Returns (s_finals float64 (K,), ms float32
+    (K,T,D), Vs float32 (K,T,D,D)) as NumPy arrays; ms / Vs are transposed views of the kernels'
+    frame-major buffers.
+
+    Extensions (keyword-only, not in the reference): s_mode 'adam' (reference behaviour) or 'grid'
+    (n_grid candidates exp(linspace(*s_bounds_log)), BASELINE.json config 3); vs_diag returns only
+    the diagonal of Vs as (K,T,D); return_device keeps ms / Vs as device tensors.
+    """
+    if h_fn is not None:
+        raise NotImplementedError('nonlinear emission functions (calibrated multicam, reference '
+                                  'eks/multicam_smoother.py:369-407) are outside the accelerated path')
+    if s_mode not in ('adam', 'grid'):
+        raise ValueError("s_mode must be 'adam' or 'grid'")
+    torch = _torch()
+    t0 = time.perf_counter()
+    P = _DeviceProblem(ys, m0s, S0s, As, Cs, Qs, ensemble_vars)
+    K = P.K
+    if not blocks:
+        blocks = [[k] for k in range(K)]
+    logger.debug(f'correlated keypoint blocks: {blocks}')
+    logger.debug(f'[profile]   build_R: {time.perf_counter() - t0:.3f}s')   # upload; R is never built
+
+    s_finals = np.empty(K, dtype=float)
+    if smooth_param is not None:
+        if isinstance(smooth_param, (int, float)):
+            s_finals[:] = float(smooth_param)
+        else:
+            s_finals[:] = np.asarray(smooth_param, dtype=float)
+        s_dev = torch.as_tensor(s_finals, device=P.dev)
+    else:
+        t1 = time.perf_counter()
+        ev_host = _to_numpy(ensemble_vars)[:2000] if not hasattr(ensemble_vars, 'detach') \
+            else ensemble_vars[:2000].detach().cpu().numpy()
+        guesses = np.empty(K)
+        for k in range(K):
+            g = float(compute_initial_guesses(ev_host[:, k, :]) or 2.0)
+            guesses[k] = g if (np.isfinite(g) and g > 0.0) else 2.0
+        s_dev, info = _optimize_on_device(P, blocks, s_frames, guesses, lr, s_bounds_log, tol,
+                                          safety_cap, 1e-4, s_mode, n_grid)
+        s_finals[:] = s_dev.cpu().numpy()
+        _log_opt(blocks, s_finals, info)
+        logger.debug(f'[profile]   optimize_smooth_param: {time.perf_counter() - t1:.3f}s')
+
+    t2 = time.perf_counter()
+    ms, Vs = hip_ops.smooth(P.y, P.var, *P.params, s_dev.contiguous(), flags=P.flags, vs_diag=vs_diag)
+    if return_device:
+        out = s_finals, ms.transpose(0, 1), Vs.transpose(0, 1)
+    else:
+        out = s_finals, np.swapaxes(ms.cpu().numpy(), 0, 1), np.swapaxes(Vs.cpu().numpy(), 0, 1)
+    logger.debug(f'[profile]   final smoother pass ({K} keypoints): {time.perf_counter() - t2:.3f}s')
+    return out

@@ -1,0 +1,175 @@
+"""Multi-camera ensemble Kalman smoother, linear (PCA-subspace) path - mirror of the reference's
+eks/multicam_smoother.py.
+
+    fit_eks_mirrored_multicam(...) -> (final_df, s_finals, input_dfs, bodypart_list)
+    fit_eks_multicam(...)          -> (camera_dfs, s_finals, input_dfs, bodypart_list, df_3d)
+    ensemble_kalman_smoother_multicam(...) -> (camera_dfs, s_finals, df_3d)
+    initialize_kalman_filter_pca(good_pcs_list, ensemble_pca, n_latent)
+
+Out of scope (raise NotImplementedError): the calibrated nonlinear path (`calibration` /
+`camgroup`, reference :369-407, :771-946) and Mahalanobis variance inflation (`inflate_vars`,
+reference :653-764) - SURVEY.md section 8(f).
+"""
+from __future__ import annotations
+
+import logging
+import os
+import time
+from typing import Literal
+
+import numpy as np
+import pandas as pd
+
+from .core import ensemble, run_kalman_smoother
+from .marker_array import MarkerArray, input_dfs_to_markerArray, mA_to_stacked_array
+from .stats import compute_pca
+from .utils import center_predictions, format_data, make_dlc_pandas_index
+
+__all__ = ['fit_eks_mirrored_multicam', 'fit_eks_multicam', 'ensemble_kalman_smoother_multicam']
+
+logger = logging.getLogger(__name__)
+
+OUTPUT_LABELS = ['x', 'y', 'likelihood', 'x_ens_median', 'y_ens_median', 'x_ens_var', 'y_ens_var',
+                 'x_posterior_var', 'y_posterior_var']
+
+
+def fit_eks_mirrored_multicam(input_source, save_file: str, bodypart_list: list | None = None,
+                              smooth_param: float | list | None = None,
+                              s_frames: list | None = None, camera_names: list = [],
+                              quantile_keep_pca: float = 50.0,
+                              avg_mode: Literal['mean', 'median'] = 'median',
+                              var_mode: Literal['var', 'confidence_weighted_var'] =
+                              'confidence_weighted_var', inflate_vars: bool = False,
+                              n_latent: int = 3) -> tuple:
+    """Mirrored data: every CSV holds all views, columns '{bodypart}_{camera}_{coord}'
+    (reference eks/multicam_smoother.py:37-153)."""
+    input_dfs, keypoint_names = format_data(input_source)
+    if bodypart_list is None:
+        bodypart_list = list(dict.fromkeys(name.split('_')[0] for name in keypoint_names))
+    per_cam = []
+    for cam in camera_names:
+        tag = f'_{cam}_'
+        dfs = []
+        for df in input_dfs:
+            cols = [c for c in df.columns if tag in c]
+            dfs.append(df[cols].rename(columns={c: c.replace(f'_{cam}', '') for c in cols}))
+        per_cam.append(dfs)
+    marker_array = input_dfs_to_markerArray(per_cam, bodypart_list, camera_names)
+    camera_dfs, s_finals, _ = ensemble_kalman_smoother_multicam(
+        marker_array=marker_array, keypoint_names=bodypart_list, smooth_param=smooth_param,
+        quantile_keep_pca=quantile_keep_pca, camera_names=camera_names, s_frames=s_frames,
+        avg_mode=avg_mode, var_mode=var_mode, inflate_vars=inflate_vars, n_latent=n_latent)
+    for cam, df in zip(camera_names, camera_dfs):
+        df.columns = pd.MultiIndex.from_tuples(
+            [(scorer, f'{kp}_{cam}', coord) for scorer, kp, coord in df.columns],
+            names=df.columns.names)
+    final_df = pd.concat(camera_dfs, axis=1) if len(camera_dfs) > 1 else camera_dfs[0]
+    os.makedirs(os.path.dirname(save_file), exist_ok=True)
+    final_df.to_csv(f'{save_file}')
+    return final_df, s_finals, input_dfs, bodypart_list
+
+
+def fit_eks_multicam(input_source, save_dir: str, bodypart_list: list | None = None,
+                     smooth_param: float | list | None = None, s_frames: list | None = None,
+                     camera_names: list | None = None, quantile_keep_pca: float = 50.0,
+                     avg_mode: Literal['mean', 'median'] = 'median',
+                     var_mode: Literal['var', 'confidence_weighted_var'] = 'confidence_weighted_var',
+                     inflate_vars: bool = False, n_latent: int = 3, calibration: str | None = None,
+                     save_3d_outputs: bool = True) -> tuple:
+    """One set of CSVs per camera (reference eks/multicam_smoother.py:156-276)."""
+    if calibration is not None:
+        raise NotImplementedError('calibrated (nonlinear) multicam is outside the accelerated path')
+    if camera_names is None:
+        raise ValueError('camera_names must be provided when no calibration file is given')
+    input_dfs, keypoint_names = format_data(input_source, camera_names=camera_names)
+    if bodypart_list is None:
+        bodypart_list = keypoint_names
+    marker_array = input_dfs_to_markerArray(input_dfs, bodypart_list, camera_names)
+    camera_dfs, s_finals, df_3d = ensemble_kalman_smoother_multicam(
+        marker_array=marker_array, keypoint_names=bodypart_list, smooth_param=smooth_param,
+        quantile_keep_pca=quantile_keep_pca, camera_names=camera_names, s_frames=s_frames,
+        avg_mode=avg_mode, var_mode=var_mode, inflate_vars=inflate_vars, n_latent=n_latent)
+    os.makedirs(save_dir, exist_ok=True)
+    for cam, df in zip(camera_names, camera_dfs):
+        df.to_csv(os.path.join(save_dir, f'multicam_{cam}_results.csv'))
+    return camera_dfs, s_finals, input_dfs, bodypart_list, df_3d
+
+
+def ensemble_kalman_smoother_multicam(marker_array: MarkerArray, keypoint_names: list,
+                                      camera_names: list, smooth_param: float | list | None = None,
+                                      quantile_keep_pca: float = 50.0, s_frames: list | None = None,
+                                      avg_mode: Literal['mean', 'median'] = 'median',
+                                      var_mode: Literal['var', 'confidence_weighted_var'] =
+                                      'confidence_weighted_var', inflate_vars: bool = False,
+                                      inflate_vars_kwargs: dict = {}, pca_object=None,
+                                      n_latent: int = 3, camgroup=None, **kalman_kwargs) -> tuple:
+    """Ensemble -> centre -> per-keypoint PCA subspace (D = n_latent, O = 2V, C = components^T)
+    -> Kalman filter / RTS smoother -> per-camera reprojection (reference
+    eks/multicam_smoother.py:279-551, linear branch)."""
+    if camera_names is None or len(camera_names) == 0:
+        raise ValueError('camera_names must be provided')
+    if camgroup is not None:
+        raise NotImplementedError('calibrated (nonlinear) multicam is outside the accelerated path')
+    if inflate_vars:
+        raise NotImplementedError('Mahalanobis variance inflation is not implemented yet '
+                                  '(SURVEY.md 8f rank 2); pass inflate_vars=False')
+    M, V, T, K, _ = marker_array.shape
+    t_all = time.perf_counter()
+    ens = ensemble(marker_array, avg_mode=avg_mode, var_mode=var_mode)       # (1,V,T,K,5)
+    valid_mask, centered, good_centered, means = center_predictions(ens, quantile_keep_pca)
+    vars_ma = ens.slice_fields('var_x', 'var_y')
+    pcas, good_pcs = compute_pca(valid_mask, centered, good_centered, n_components=n_latent,
+                                 pca_object=pca_object)
+    m0s, S0s, As, Qs, Cs = initialize_kalman_filter_pca(good_pcs, pcas, n_latent)
+    ys = np.stack([mA_to_stacked_array(centered, k) for k in range(K)])      # (K,T,2V)
+    evs = np.stack([mA_to_stacked_array(vars_ma, k) for k in range(K)])      # (K,T,2V)
+    t0 = time.perf_counter()
+    s_finals, ms, Vs = run_kalman_smoother(
+        ys=ys, m0s=m0s, S0s=S0s, As=As, Qs=Qs, Cs=Cs, ensemble_vars=np.swapaxes(evs, 0, 1),
+        s_frames=s_frames, smooth_param=smooth_param, **kalman_kwargs)
+    logger.debug(f'[profile] run_kalman_smoother (total): {time.perf_counter() - t0:.3f}s')
+
+    # reprojection: y = C m + mean; posterior variance = diag(C V C') + ensemble variance
+    # (the + ensemble variance is the reference's multicam convention, :509-510)
+    ym = np.einsum('kod,ktd->tko', Cs, ms)                                   # (T,K,2V)
+    yv = np.einsum('kod,ktde,koe->tko', Cs, Vs, Cs) + np.swapaxes(evs, 0, 1)
+    stats = np.asarray(ens.array)[0]                                         # (V,T,K,5)
+    mu = np.asarray(means.array)[0, :, 0]                                    # (V,K,2)
+    index = make_dlc_pandas_index(keypoint_names, labels=OUTPUT_LABELS)
+    camera_dfs = []
+    for c in range(V):
+        out = np.empty((T, K, 9))
+        out[:, :, 0:2] = ym[:, :, 2 * c:2 * c + 2] + mu[c][None]
+        out[:, :, 2] = stats[c, :, :, 4]
+        out[:, :, 3:5] = stats[c, :, :, 0:2]
+        out[:, :, 5:7] = stats[c, :, :, 2:4]
+        out[:, :, 7:9] = yv[:, :, 2 * c:2 * c + 2]
+        camera_dfs.append(pd.DataFrame(out.reshape(T, K * 9), columns=index))
+    # latent states and their posterior variances (reference :529-544; the labels say x/y/z but
+    # the state is the n_latent PCA subspace)
+    lat = np.concatenate([np.swapaxes(ms, 0, 1),
+                          np.swapaxes(np.diagonal(Vs, axis1=2, axis2=3), 0, 1)], axis=2)
+    base = ['x', 'y', 'z'] if n_latent == 3 else [f'latent{i}' for i in range(n_latent)]
+    labels_3d = base + [f'{b}_posterior_var' for b in base]
+    df_3d = pd.DataFrame(lat.reshape(T, K * 2 * n_latent),
+                         columns=make_dlc_pandas_index(keypoint_names, labels=labels_3d))
+    logger.debug(f'[profile] ensemble_kalman_smoother_multicam total: '
+                 f'{time.perf_counter() - t_all:.3f}s')
+    return camera_dfs, s_finals, df_3d
+
+
+def initialize_kalman_filter_pca(good_pcs_list, ensemble_pca, n_latent: int) -> tuple:
+    """m0 = 0, S0 = diag(var of good-frame PCs), A = I, C = components^T (2V x n_latent),
+    Q = cov(diff of PCs) / max|cov| (reference eks/multicam_smoother.py:554-597).
+    Returns (m0s, S0s, As, Qs, Cs)."""
+    K = len(good_pcs_list)
+    m0s = np.zeros((K, n_latent))
+    S0s = np.stack([np.diag(np.var(p[:, :n_latent], axis=0)) for p in good_pcs_list])
+    As = np.tile(np.eye(n_latent), (K, 1, 1))
+    Cs = np.stack([np.asarray(p.components_).T for p in ensemble_pca])
+    Qs = []
+    for pcs in good_pcs_list:
+        cov = np.atleast_2d(np.cov((pcs[1:] - pcs[:-1]).T))
+        top = np.max(np.abs(cov))
+        Qs.append(cov / top if top > 0 else cov)
+    return m0s, S0s, As, np.stack(Qs), Cs

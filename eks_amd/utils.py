@@ -1,0 +1,187 @@
+"""Host-side data formats either side of the Kalman path (reference eks/utils.py).
+
+CSV in: DLC / Lightning Pose prediction files with a 3-row header (scorer / bodyparts / coords).
+DataFrame out: MultiIndex columns ('ensemble-kalman_tracker', keypoint, coord).
+"""
+from __future__ import annotations
+
+import logging
+import os
+
+import numpy as np
+import pandas as pd
+
+from .marker_array import MarkerArray
+
+logger = logging.getLogger(__name__)
+
+SCORER = 'ensemble-kalman_tracker'
+
+
+def make_dlc_pandas_index(keypoint_names, labels=('x', 'y', 'likelihood')) -> pd.MultiIndex:
+    """scorer / bodyparts / coords column index (reference eks/utils.py:15-32)."""
+    return pd.MultiIndex.from_product([[SCORER], list(keypoint_names), list(labels)],
+                                      names=['scorer', 'bodyparts', 'coords'])
+
+
+def get_keypoint_names(df: pd.DataFrame) -> list:
+    """Body-part names in file order (one per 'x' column), reference eks/utils.py:125-135."""
+    is_x = df.columns.get_level_values('coords') == 'x'
+    return df.columns[is_x].get_level_values('bodyparts').tolist()
+
+
+def convert_lp_dlc(df_lp: pd.DataFrame, keypoint_names, model_name=None) -> pd.DataFrame:
+    """3-level header DataFrame -> flat columns '{keypoint}_{x|y|likelihood}' (reference
+    eks/utils.py:35-69).  Missing columns and 'Unnamed' levels are skipped."""
+    if model_name is None:
+        model_name = str(df_lp.columns[0][0])
+    flat = {}
+    for kp in keypoint_names:
+        for coord in ('x', 'y', 'likelihood'):
+            key = (model_name, kp, coord)
+            if any(isinstance(lv, str) and lv.startswith('Unnamed') for lv in key):
+                continue
+            if key in df_lp.columns:
+                flat[f'{kp}_{coord}'] = df_lp[key]
+    return pd.DataFrame(flat, index=df_lp.index)
+
+
+def _read_prediction_file(path: str):
+    if path.endswith('.slp'):
+        raise NotImplementedError(
+            'SLEAP .slp input needs the sleap_io reader (reference eks/utils.py:72-122); '
+            'convert to CSV first - it is outside the accelerated path')
+    raw = pd.read_csv(path, header=[0, 1, 2], index_col=0)
+    names = get_keypoint_names(raw)
+    return convert_lp_dlc(raw, names), names
+
+
+def format_data(input_source, camera_names=None):
+    """Load prediction files (reference eks/utils.py:138-232).
+
+    input_source: directory, list of paths, or {camera: [paths]}.  Paths are sorted
+    lexicographically; with `camera_names`, files are matched to a camera when the camera name is a
+    substring of the file's basename.  Returns (list of DataFrames | list per camera of lists,
+    keypoint_names)."""
+    if isinstance(input_source, str) and os.path.isdir(input_source):
+        paths = sorted(os.path.join(input_source, f) for f in os.listdir(input_source))
+    elif isinstance(input_source, list):
+        paths = sorted(input_source)
+    elif isinstance(input_source, dict):
+        paths = input_source
+    else:
+        raise ValueError('input_source must be a directory path, a list of file paths, or a map '
+                         'from camera names to list of file paths')
+    out, names = [], None
+    if camera_names is None:
+        for p in paths:
+            if not (p.endswith('.csv') or p.endswith('.slp')):
+                continue
+            df, names = _read_prediction_file(p)
+            out.append(df)
+    else:
+        for cam in camera_names:
+            files = paths if isinstance(paths, list) else paths.get(cam, [])
+            hits = [p for p in files if cam in os.path.basename(p)
+                    and (p.endswith('.csv') or p.endswith('.slp'))]
+            if not hits:
+                raise FileNotFoundError(
+                    f"no files matching camera '{cam}' found in {input_source}. "
+                    f'ensure the camera name appears as a substring of each filename.')
+            per_cam = []
+            for p in hits:
+                df, names = _read_prediction_file(p)
+                per_cam.append(df)
+            out.append(per_cam)
+        counts = [len(x) for x in out]
+        if len(set(counts)) > 1:
+            logger.warning('unequal number of seed files per camera (%s)',
+                           ', '.join(f'{c}: {n}' for c, n in zip(camera_names, counts)))
+    if not out:
+        raise FileNotFoundError(f'no valid marker input files found in {input_source}')
+    assert names is not None
+    return out, names
+
+
+def crop_frames(y, s_frames):
+    """Keep the frames in `s_frames` (list of 0-based half-open (start, end) tuples, None = open
+    end); None / [] / [(None, None)] returns `y` itself.  Reference eks/utils.py:235-290."""
+    if s_frames is None or len(s_frames) == 0 or \
+            (len(s_frames) == 1 and s_frames[0] == (None, None)):
+        return y
+    if not isinstance(s_frames, list):
+        raise TypeError('s_frames must be a list of (start, end) tuples or None.')
+    idx = frame_spans(len(y), s_frames)
+    if len(idx) == 1:
+        return y[idx[0][0]:idx[0][1]]
+    return np.concatenate([y[a:b] for a, b in idx], axis=0)
+
+
+def frame_spans(n: int, s_frames) -> list[tuple[int, int]]:
+    """Validated, sorted (start, end) spans of `crop_frames` for a sequence of length n."""
+    spans = []
+    for i, fr in enumerate(s_frames):
+        if not (isinstance(fr, tuple) and len(fr) == 2):
+            raise ValueError(f's_frames[{i}] must be a (start, end) tuple, got {fr!r}')
+        lo, hi = fr
+        if lo is not None and not isinstance(lo, int):
+            raise ValueError(f's_frames[{i}].start must be int or None, got {lo!r}')
+        if hi is not None and not isinstance(hi, int):
+            raise ValueError(f's_frames[{i}].end must be int or None, got {hi!r}')
+        lo = 0 if lo is None else lo
+        hi = n if hi is None else hi
+        if lo < 0 or hi > n:
+            raise ValueError(f'Range ({lo}, {hi}) out of bounds for length {n}.')
+        if lo >= hi:
+            raise ValueError(f'Invalid range ({lo}, {hi}).')
+        spans.append((lo, hi))
+    spans.sort(key=lambda ab: ab[0])
+    for prev, cur in zip(spans, spans[1:]):
+        if cur[0] < prev[1]:
+            raise ValueError(f'Overlapping or out-of-order intervals: {prev} and {cur}')
+    return spans
+
+
+def build_R_from_vars(ev: np.ndarray) -> np.ndarray:
+    """(..., T, O) variances -> (..., T, O, O) diagonal matrices, variances clipped at 1e-12
+    (reference eks/utils.py:368-377).  Kept for API parity; the kernels read the O variances and
+    never materialise R."""
+    v = np.clip(np.asarray(ev), 1e-12, None)
+    return v[..., :, None] * np.eye(v.shape[-1], dtype=v.dtype)
+
+
+def crop_R(R: np.ndarray, s_frames) -> np.ndarray:
+    """Crop (..., T, O, O) along T with `crop_frames` semantics (reference eks/utils.py:380-398)."""
+    R = np.asarray(R)
+    if not s_frames:
+        return R
+    lead = R.shape[:-3]
+    T, O, O2 = R.shape[-3:]
+    assert O == O2, 'R_tv must be square in its last two dims'
+    flat = R.reshape((-1, T, O, O))
+    cropped = np.stack([crop_frames(b, s_frames) for b in flat], axis=0)
+    return cropped.reshape((*lead, -1, O, O))
+
+
+def center_predictions(ensemble_marker_array: MarkerArray, quantile_keep_pca: float):
+    """Per-keypoint low-variance frame mask, mean over the kept frames, centred predictions
+    (reference eks/utils.py:293-365).
+
+    Returns (valid_frames_mask (T,K) bool, emA_centered_preds (1,V,T,K,2),
+    emA_good_centered_preds (1,V,min_frames,K,2), emA_means (1,V,1,K,2))."""
+    M, V, T, K, _ = ensemble_marker_array.shape
+    assert M == 1, 'MarkerArray should have n_models = 1 after ensembling.'
+    preds = np.asarray(ensemble_marker_array.slice_fields('x', 'y').array)
+    vars_ = np.asarray(ensemble_marker_array.slice_fields('var_x', 'var_y').array)
+    worst = vars_.max(axis=(0, 1, 4))                                   # (T, K)
+    mask = worst <= np.percentile(worst, quantile_keep_pca, axis=0)
+    n_good = int(mask.sum(axis=0).min())
+    # first n_good kept frames of every keypoint (the reference truncates to the shortest list)
+    order = np.argsort(~mask, axis=0, kind='stable')[:n_good]           # (n_good, K) frame indices
+    kk = np.arange(K)[None, :]
+    good = preds[:, :, order, kk, :]                                    # (1, V, n_good, K, 2)
+    means = good.mean(axis=2, keepdims=True)                            # (1, V, 1, K, 2)
+    centered = preds - means
+    fields = ['x', 'y']
+    return (mask, MarkerArray(centered, data_fields=fields),
+            MarkerArray(good - means, data_fields=fields), MarkerArray(means, data_fields=fields))

@@ -1,0 +1,78 @@
+"""CPU: the oracle reproduces the committed golden vectors from the committed inputs (guards the
+oracle against drift), and the fixtures carry the reference's data-format pins."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import eks_oracle as orc
+
+
+@pytest.fixture(scope='module')
+def pupil(golden_dir):
+    return np.load(os.path.join(golden_dir, 'ibl_pupil_singlecam.npz'))
+
+
+@pytest.fixture(scope='module')
+def mouse(golden_dir):
+    return np.load(os.path.join(golden_dir, 'mirror_mouse_multicam.npz'))
+
+
+def _check(full, g, prefix, rtol=2e-6):
+    rows = full[g['keep_idx']]
+    ref = g[f'{prefix}_rows'].astype(np.float64)
+    scale = np.abs(ref).max(axis=0)
+    assert (np.abs(rows - ref) / scale).max() < rtol + 1e-7          # rows are stored as float32
+    np.testing.assert_allclose(full.sum(axis=0), g[f'{prefix}_colsum'], rtol=1e-9,
+                               atol=1e-9 * g[f'{prefix}_colabs'].max())
+
+
+def test_fixture_shapes_and_format_pins(pupil, mouse):
+    assert pupil['markers'].shape == (5, 1, 2000, 4, 3) and pupil['markers'].dtype == np.float32
+    assert list(pupil['keypoints']) == ['pupil_top_r', 'pupil_right_r', 'pupil_bottom_r', 'pupil_left_r']
+    assert not np.isnan(pupil['markers']).any()
+    hdr = list(pupil['csv_header'])
+    assert hdr[0].startswith('scorer,') and hdr[1].startswith('bodyparts,') and hdr[2].startswith('coords,x,y,likelihood')
+    assert mouse['markers'].shape == (5, 2, 2000, 4, 3)
+    assert 'paw1LH_top' in mouse['csv_header'][1] and 'paw1LH_bot' in mouse['csv_header'][1]
+
+
+def test_oracle_reproduces_singlecam_fixed_s(pupil):
+    arrs = orc.singlecam_arrays(pupil['markers'])
+    s, ms, Vs, _ = orc.run_kalman_smoother(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'],
+                                           arrs['Qs'], arrs['ensemble_vars'], smooth_param=[10.0])
+    np.testing.assert_array_equal(s, 10.0)
+    _check(orc.singlecam_outputs(arrs, s, ms, Vs), pupil, 's10')
+
+
+def test_oracle_reproduces_singlecam_adam(pupil):
+    arrs = orc.singlecam_arrays(pupil['markers'])
+    np.testing.assert_allclose([orc.compute_initial_guess(arrs['ensemble_vars'][:, k]) for k in range(4)],
+                               pupil['guesses'])
+    s, ms, Vs, info = orc.run_kalman_smoother(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'],
+                                              arrs['Cs'], arrs['Qs'], arrs['ensemble_vars'])
+    np.testing.assert_allclose(s, pupil['adam_s'], rtol=1e-9)
+    np.testing.assert_array_equal(info['iters'], pupil['adam_iters'])
+    _check(orc.singlecam_outputs(arrs, s, ms, Vs), pupil, 'adam')
+    # Adam and the 64-point grid land in the same basin of the same loss
+    assert np.all(np.abs(np.log(pupil['adam_s']) - np.log(pupil['grid_s'])) < 0.3)
+
+
+def test_oracle_reproduces_multicam_fixed_s(mouse):
+    from sklearn.decomposition import PCA
+
+    def sk_pca(X, n):
+        p = PCA(n_components=n).fit(X)
+        return p.components_, p.mean_
+
+    arrs = orc.multicam_arrays(mouse['markers'], quantile_keep_pca=95.0, n_latent=3, pca_fit=sk_pca)
+    np.testing.assert_array_equal(arrs['mask'], mouse['valid_mask'])          # indices bit-exact
+    np.testing.assert_array_equal(arrs['good_idx'], mouse['good_idx'])
+    # PCA directions up to sign
+    sgn = np.sign(np.einsum('kod,kod->kd', arrs['Cs'], mouse['Cs']))
+    np.testing.assert_allclose(arrs['Cs'] * sgn[:, None, :], mouse['Cs'], atol=1e-9)
+    s, ms, Vs, _ = orc.run_kalman_smoother(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'],
+                                           arrs['Qs'], arrs['ensemble_vars'], smooth_param=[10.0])
+    cams, lat = orc.multicam_outputs(arrs, ms, Vs)
+    for c, co in enumerate(cams):
+        _check(co, mouse, f's10_cam{c}')        # observation space: PCA-sign invariant

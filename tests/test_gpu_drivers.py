@@ -1,0 +1,207 @@
+"""GPU: the reference-shaped operator / drivers of eks_amd against the committed golden vectors
+(inputs = the reference's own data/ibl-pupil and data/mirror-mouse files, expected outputs = the
+float64 oracle) and against the oracle on seeded synthetic shapes.  Mirrors what the reference's
+unit tests assert (tests/test_singlecam_smoother.py:9-95, tests/test_multicam_smoother.py:22-228)
+plus numeric parity.  Tolerance: 1e-5 relative to the column's magnitude (BASELINE.json)."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from oracle import eks_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+LABELS = ['x', 'y', 'likelihood', 'x_ens_median', 'y_ens_median', 'x_ens_var', 'y_ens_var',
+          'x_posterior_var', 'y_posterior_var']
+
+
+@pytest.fixture(scope='module')
+def pupil(golden_dir):
+    return np.load(os.path.join(golden_dir, 'ibl_pupil_singlecam.npz'))
+
+
+@pytest.fixture(scope='module')
+def mouse(golden_dir):
+    return np.load(os.path.join(golden_dir, 'mirror_mouse_multicam.npz'))
+
+
+def _against_golden(df_values, g, prefix, tol=1e-5):
+    rows = df_values[g['keep_idx']]
+    ref = g[f'{prefix}_rows'].astype(np.float64)
+    scale = np.abs(ref).max(axis=0)
+    assert (np.abs(rows - ref) / scale).max() < tol
+    assert (np.abs(df_values.sum(axis=0) - g[f'{prefix}_colsum']) / g[f'{prefix}_colabs']).max() < tol
+
+
+def test_singlecam_fixed_s_matches_golden(pupil):
+    from eks_amd import MarkerArray
+    from eks_amd.singlecam_smoother import ensemble_kalman_smoother_singlecam
+    ma = MarkerArray(pupil['markers'].astype(np.float64), data_fields=['x', 'y', 'likelihood'])
+    names = list(pupil['keypoints'])
+    df, s = ensemble_kalman_smoother_singlecam(ma, names, smooth_param=[10.0])
+    assert isinstance(df, pd.DataFrame) and df.shape == (2000, 36) and df.values.dtype == np.float64
+    assert list(df.columns.get_level_values('coords')[:9]) == LABELS
+    assert list(df.columns.get_level_values('bodyparts')[::9]) == names
+    assert set(df.columns.get_level_values('scorer')) == {'ensemble-kalman_tracker'}
+    np.testing.assert_array_equal(s, 10.0)
+    _against_golden(df.values, pupil, 's10')
+
+
+@pytest.mark.parametrize('sp', [5.0, 7, [3.0], [1.0, 2.0, 3.0, 4.0]])
+def test_singlecam_smooth_param_passthrough(pupil, sp):
+    from eks_amd import MarkerArray
+    from eks_amd.singlecam_smoother import ensemble_kalman_smoother_singlecam
+    ma = MarkerArray(pupil['markers'][:2, :, :300].astype(np.float64), data_fields=['x', 'y', 'likelihood'])
+    df, s = ensemble_kalman_smoother_singlecam(ma, list(pupil['keypoints']), smooth_param=sp)
+    np.testing.assert_array_equal(s, np.broadcast_to(np.asarray(sp, float), (4,)))
+    assert isinstance(s, np.ndarray) and s.dtype == np.float64 and np.isfinite(df.values).all()
+
+
+def test_singlecam_adam_matches_golden_basin_and_oracle_at_same_s(pupil):
+    from eks_amd import MarkerArray
+    from eks_amd.singlecam_smoother import ensemble_kalman_smoother_singlecam
+    ma = MarkerArray(pupil['markers'].astype(np.float64), data_fields=['x', 'y', 'likelihood'])
+    df, s = ensemble_kalman_smoother_singlecam(ma, list(pupil['keypoints']))      # smooth_param=None
+    # the Adam stop test is chaotic in the last digits: s is compared loosely ...
+    assert np.all(np.abs(np.log(s) - np.log(pupil['adam_s'])) < 0.25)
+    # ... and the smoothed output strictly, against the oracle run at the SAME s
+    arrs = orc.singlecam_arrays(pupil['markers'])
+    Rd = orc.build_R_from_vars(np.swapaxes(arrs['ensemble_vars'], 0, 1))
+    ms, Vs, _ = orc.kalman_smoother(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'],
+                                    arrs['Qs'], s, Rd)
+    ref = orc.singlecam_outputs(arrs, s, ms, Vs)
+    assert (np.abs(df.values - ref) / np.abs(ref).max(axis=0)).max() < 1e-5
+
+
+def test_singlecam_grid_indices_match_golden(pupil):
+    from eks_amd import MarkerArray
+    from eks_amd.singlecam_smoother import ensemble_kalman_smoother_singlecam
+    ma = MarkerArray(pupil['markers'].astype(np.float64), data_fields=['x', 'y', 'likelihood'])
+    df, s = ensemble_kalman_smoother_singlecam(ma, list(pupil['keypoints']), s_mode='grid')
+    nll = pupil['grid_nll']
+    srt = np.sort(nll, axis=1)
+    assert np.all((srt[:, 1] - srt[:, 0]) > 2e-5 * np.abs(srt[:, 0]))             # margins are clear
+    cand = np.exp(np.linspace(-8, 8, 64))
+    idx = np.abs(np.log(s)[:, None] - np.log(cand)[None]).argmin(axis=1)
+    np.testing.assert_array_equal(idx, pupil['grid_idx'])                         # indices bit-exact
+    _against_golden(df.values, pupil, 'grid')
+
+
+def test_run_kalman_smoother_contract_and_blocks(pupil):
+    from eks_amd.core import run_kalman_smoother
+    arrs = orc.singlecam_arrays(pupil['markers'][:, :, :600])
+    args = (arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], arrs['ensemble_vars'])
+    s, ms, Vs = run_kalman_smoother(*args, smooth_param=2.5)
+    assert s.shape == (4,) and ms.shape == (4, 600, 2) and Vs.shape == (4, 600, 2, 2)
+    assert isinstance(ms, np.ndarray) and ms.dtype == np.float32
+    s_b, _, _ = run_kalman_smoother(*args, blocks=[[0, 1], [2], [3]], safety_cap=5)
+    assert s_b[0] == s_b[1] and np.all(np.isfinite(s_b)) and np.all(s_b > 0)
+    s_o, _, _, _ = orc.run_kalman_smoother(*args, blocks=[[0, 1], [2], [3]], safety_cap=5)
+    np.testing.assert_allclose(s_b, s_o, rtol=1e-3)           # 5 Adam steps, no stop-test chaos yet
+    s_f, _, _ = run_kalman_smoother(*args, s_frames=[(0, 200), (300, None)])
+    s_fo, _, _, _ = orc.run_kalman_smoother(*args, s_frames=[(0, 200), (300, None)])
+    assert np.all(np.abs(np.log(s_f) - np.log(s_fo)) < 0.25)
+    with pytest.raises(NotImplementedError):
+        run_kalman_smoother(*args, smooth_param=1.0, h_fn=lambda x: x)
+    with pytest.raises(ValueError):
+        run_kalman_smoother(*args, s_frames=[(5, 5)])
+    with pytest.raises(ValueError):
+        run_kalman_smoother(arrs['ys'][:, :1], *args[1:6], arrs['ensemble_vars'][:1])   # < 2 frames
+
+
+def test_fit_eks_singlecam_from_csv(pupil, tmp_path):
+    from eks_amd.singlecam_smoother import fit_eks_singlecam
+    names = list(pupil['keypoints'])
+    cols = pd.MultiIndex.from_product([[str(pupil['scorer'])], names, ['x', 'y', 'likelihood']],
+                                      names=['scorer', 'bodyparts', 'coords'])
+    for m in range(5):
+        pd.DataFrame(pupil['markers'][m, 0].reshape(2000, 12).astype(np.float64), columns=cols
+                     ).to_csv(tmp_path / f'session.rng={m}.csv')
+    save = tmp_path / 'out' / 'eks_singlecam.csv'
+    df, s, input_dfs, bps = fit_eks_singlecam(str(tmp_path), str(save), smooth_param=[10.0])
+    assert bps == names and len(input_dfs) == 5 and save.exists()
+    _against_golden(df.values, pupil, 's10')
+    back = pd.read_csv(save, header=[0, 1, 2], index_col=0)
+    assert list(back.columns) == list(df.columns)
+    np.testing.assert_allclose(back.values, df.values, rtol=1e-12)
+
+
+def test_multicam_fixed_s_matches_golden(mouse):
+    from eks_amd import MarkerArray
+    from eks_amd.multicam_smoother import ensemble_kalman_smoother_multicam
+    ma = MarkerArray(mouse['markers'].astype(np.float64), data_fields=['x', 'y', 'likelihood'])
+    names, cams = list(mouse['keypoints']), list(mouse['cameras'])
+    dfs, s, df_3d = ensemble_kalman_smoother_multicam(ma, names, cams, smooth_param=[10.0],
+                                                      quantile_keep_pca=95.0, n_latent=3)
+    assert isinstance(dfs, list) and len(dfs) == 2 and isinstance(s, np.ndarray)
+    assert dfs[0].shape == (2000, 36) and df_3d.shape == (2000, 24)
+    assert list(df_3d.columns.get_level_values('coords')[:6]) == \
+        ['x', 'y', 'z', 'x_posterior_var', 'y_posterior_var', 'z_posterior_var']
+    for c in range(2):
+        _against_golden(dfs[c].values, mouse, f's10_cam{c}')
+    # latent means agree up to the PCA sign; latent variances exactly
+    lat = df_3d.values[mouse['keep_idx']].reshape(-1, 4, 6)
+    ref = mouse['s10_latent_rows'].astype(np.float64).reshape(-1, 4, 6)
+    assert (np.abs(np.abs(lat[..., :3]) - np.abs(ref[..., :3])) / np.abs(ref[..., :3]).max()).max() < 1e-5
+    assert (np.abs(lat[..., 3:] - ref[..., 3:]) / ref[..., 3:].max()).max() < 1e-5
+
+
+@pytest.mark.parametrize('n_latent', [3, 4, 5])
+def test_multicam_four_views_latent_dims(n_latent):
+    from eks_amd import MarkerArray, synth
+    from eks_amd.multicam_smoother import ensemble_kalman_smoother_multicam
+    mk = synth.multicam_markers(400, 2, V=4, M=3, seed=n_latent)
+    ma = MarkerArray(mk.astype(np.float64), data_fields=['x', 'y', 'likelihood'])
+    dfs, s, df_3d = ensemble_kalman_smoother_multicam(ma, ['a', 'b'], ['c0', 'c1', 'c2', 'c3'],
+                                                      smooth_param=4.0, n_latent=n_latent)
+    assert len(dfs) == 4 and df_3d.shape == (400, 2 * 2 * n_latent)
+    arrs = orc.multicam_arrays(mk, quantile_keep_pca=50.0, n_latent=n_latent,
+                               pca_fit=lambda X, n: _sk(X, n))
+    s_o, ms, Vs, _ = orc.run_kalman_smoother(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'],
+                                             arrs['Qs'], arrs['ensemble_vars'], smooth_param=4.0)
+    cams, _ = orc.multicam_outputs(arrs, ms, Vs)
+    for c in range(4):
+        assert (np.abs(dfs[c].values - cams[c]) / np.abs(cams[c]).max(axis=0)).max() < 1e-5
+
+
+def _sk(X, n):
+    from sklearn.decomposition import PCA
+    p = PCA(n_components=n).fit(X)
+    return p.components_, p.mean_
+
+
+def test_multicam_adam_and_errors(mouse):
+    from eks_amd import MarkerArray
+    from eks_amd.multicam_smoother import ensemble_kalman_smoother_multicam
+    ma = MarkerArray(mouse['markers'][:, :, :800, :2].astype(np.float64), data_fields=['x', 'y', 'likelihood'])
+    dfs, s, _ = ensemble_kalman_smoother_multicam(ma, ['p1', 'p2'], ['top', 'bot'], quantile_keep_pca=95.0)
+    assert np.all(np.isfinite(s)) and np.all(s > 0) and np.isfinite(dfs[0].values).all()
+    arrs = orc.multicam_arrays(mouse['markers'][:, :, :800, :2], quantile_keep_pca=95.0, n_latent=3, pca_fit=_sk)
+    s_o, _, _, _ = orc.run_kalman_smoother(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'],
+                                           arrs['Qs'], arrs['ensemble_vars'])
+    assert np.all(np.abs(np.log(s) - np.log(s_o)) < 0.25)
+    with pytest.raises(ValueError):
+        ensemble_kalman_smoother_multicam(ma, ['p1', 'p2'], [])
+    with pytest.raises(NotImplementedError):
+        ensemble_kalman_smoother_multicam(ma, ['p1', 'p2'], ['top', 'bot'], inflate_vars=True)
+
+
+def test_ensemble_operator_properties():
+    """Properties the reference asserts in tests/test_core.py:8-152."""
+    from eks_amd import MarkerArray
+    from eks_amd.core import ensemble
+    rng = np.random.default_rng(0)
+    a = rng.random((4, 2, 5, 3, 3))
+    ma = MarkerArray(a, data_fields=['x', 'y', 'likelihood'])
+    for kw in ({}, {'avg_mode': 'mean'}, {'var_mode': 'var'}):
+        e = ensemble(ma, **kw)
+        assert e.shape == (1, 2, 5, 3, 5) and np.isfinite(e.array).all()
+        assert e.data_fields == ['x', 'y', 'var_x', 'var_y', 'likelihood']
+    a[:, 0, 1, 1, 0] = np.nan
+    e = ensemble(MarkerArray(a, data_fields=['x', 'y', 'likelihood']), nan_replacement=123.0)
+    assert e.array[0, 0, 1, 1, 2] == 123.0
+    e1 = ensemble(MarkerArray(a[:1], data_fields=['x', 'y', 'likelihood']))
+    assert np.all(e1.array[..., 2] > 0)
+    np.testing.assert_allclose(e1.array[0, ..., 2], 1.0 / np.maximum(a[0, ..., 2].astype(np.float32), 1e-5), rtol=1e-6)

@@ -1,0 +1,186 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU, no kernels): MarkerArray,
+CSV formats, frame cropping, centring, KF initialisation.  Modelled on what the reference's own
+tests assert (tests/test_marker_array.py, test_utils.py, test_singlecam_smoother.py:98-140,
+test_multicam_smoother.py:284-341)."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from eks_amd.marker_array import (MarkerArray, input_dfs_to_markerArray, mA_to_stacked_array,
+                                  stacked_array_to_mA)
+from eks_amd import utils
+from oracle import eks_oracle as orc
+
+
+def _write_dlc_csv(path, names, T, rng, scorer='tracker'):
+    cols = pd.MultiIndex.from_product([[scorer], names, ['x', 'y', 'likelihood']],
+                                      names=['scorer', 'bodyparts', 'coords'])
+    df = pd.DataFrame(rng.random((T, len(names) * 3)), columns=cols)
+    df.to_csv(path)
+    return df
+
+
+def test_marker_array_basics():
+    a = np.arange(2 * 3 * 4 * 5 * 3, dtype=float).reshape(2, 3, 4, 5, 3)
+    ma = MarkerArray(a, data_fields=['x', 'y', 'likelihood'])
+    assert ma.shape == (2, 3, 4, 5, 3)
+    assert (ma.n_models, ma.n_cameras, ma.n_frames, ma.n_keypoints, ma.n_fields) == (2, 3, 4, 5, 3)
+    np.testing.assert_array_equal(ma.slice('keypoints', 2).array, a[:, :, :, 2:3])
+    np.testing.assert_array_equal(ma.slice('frames', [0, 3]).array, a[:, :, [0, 3]])
+    sub = ma.slice_fields('likelihood', 'x')
+    assert sub.data_fields == ['likelihood', 'x']
+    np.testing.assert_array_equal(sub.array, a[..., [2, 0]])
+    re = ma.reorder_data_fields(['y', 'x', 'likelihood'])
+    np.testing.assert_array_equal(re.array[..., 0], a[..., 1])
+    st = MarkerArray.stack([ma.slice('cameras', 0), ma.slice('cameras', 2)], 'cameras')
+    np.testing.assert_array_equal(st.array, a[:, [0, 2]])
+    sf = MarkerArray.stack_fields(ma.slice_fields('x'), ma.slice_fields('y', 'likelihood'))
+    assert sf.data_fields == ['x', 'y', 'likelihood']
+    np.testing.assert_array_equal(sf.array, a)
+    assert MarkerArray(shape=(1, 1, 2, 2, 2), data_fields=['x', 'y']).array.dtype == np.float32
+    clone = MarkerArray(marker_array=ma)
+    assert clone.array is not ma.array and clone.data_fields == ma.data_fields
+    assert ma.get_array(squeeze=True).shape == (2, 3, 4, 5, 3)
+    assert 'models=2' in repr(ma)
+    for bad in (lambda: MarkerArray(), lambda: MarkerArray(np.zeros((2, 2))),
+                lambda: ma.slice('nope', 0), lambda: ma.slice_fields('z'),
+                lambda: MarkerArray.stack([ma, MarkerArray(a[:, :, :2], data_fields=ma.data_fields)], 'cameras'),
+                lambda: ma.reorder_data_fields(['x', 'y'])):
+        with pytest.raises(AssertionError):
+            bad()
+
+
+def test_stacked_array_round_trip():
+    rng = np.random.default_rng(0)
+    a = rng.random((1, 3, 7, 4, 2))
+    ma = MarkerArray(a, data_fields=['x', 'y'])
+    s = mA_to_stacked_array(ma, 2)
+    assert s.shape == (7, 6)
+    np.testing.assert_array_equal(s[:, 2:4], a[0, 1, :, 2, :])         # [c0x, c0y, c1x, c1y, ...]
+    back = stacked_array_to_mA(s, 3, ['x', 'y'])
+    np.testing.assert_array_equal(back.array[0, :, :, 0, :], a[0, :, :, 2, :])
+    with pytest.raises(AssertionError):
+        mA_to_stacked_array(ma, 4)
+
+
+def test_format_data_and_marker_array_from_csv(tmp_path):
+    rng = np.random.default_rng(1)
+    names = ['nose', 'ear']
+    dfs = [_write_dlc_csv(tmp_path / f'pred.rng={i}.csv', names, 11, rng) for i in (1, 0)]
+    (tmp_path / 'notes.txt').write_text('skip me')
+    out, kp = utils.format_data(str(tmp_path))
+    assert kp == names and len(out) == 2
+    assert list(out[0].columns) == ['nose_x', 'nose_y', 'nose_likelihood', 'ear_x', 'ear_y', 'ear_likelihood']
+    # directory listing is sorted: rng=0 (written second) comes first
+    np.testing.assert_allclose(out[0]['nose_x'].to_numpy(), dfs[1][('tracker', 'nose', 'x')].to_numpy())
+    ma = input_dfs_to_markerArray([out], kp, [''])
+    assert ma.shape == (2, 1, 11, 2, 3) and ma.array.dtype == np.float64
+    np.testing.assert_allclose(ma.array[1, 0, :, 1, 2], dfs[0][('tracker', 'ear', 'likelihood')].to_numpy())
+    out2, _ = utils.format_data([str(tmp_path / 'pred.rng=1.csv'), str(tmp_path / 'pred.rng=0.csv')])
+    np.testing.assert_allclose(out2[0].to_numpy(), out[0].to_numpy())
+    with pytest.raises(FileNotFoundError):
+        utils.format_data(str(tmp_path / 'notes.txt').replace('notes.txt', 'empty') if os.makedirs(
+            tmp_path / 'empty', exist_ok=True) is None else '')
+    with pytest.raises(ValueError):
+        utils.format_data(3)
+    with pytest.raises(NotImplementedError):
+        utils.format_data([str(tmp_path / 'x.slp')])
+
+
+def test_format_data_per_camera(tmp_path):
+    rng = np.random.default_rng(2)
+    for cam in ('top', 'bot'):
+        for i in range(2):
+            _write_dlc_csv(tmp_path / f'vid_{cam}_rng{i}.csv', ['paw'], 5, rng)
+    out, kp = utils.format_data(str(tmp_path), camera_names=['top', 'bot'])
+    assert kp == ['paw'] and [len(x) for x in out] == [2, 2]
+    out, _ = utils.format_data({'top': [str(tmp_path / 'vid_top_rng0.csv')],
+                                'bot': [str(tmp_path / 'vid_bot_rng1.csv')]}, camera_names=['top', 'bot'])
+    assert [len(x) for x in out] == [1, 1]
+    with pytest.raises(FileNotFoundError):
+        utils.format_data(str(tmp_path), camera_names=['side'])
+
+
+def test_output_index_layout():
+    idx = utils.make_dlc_pandas_index(['a', 'b'], labels=['x', 'y'])
+    assert idx.names == ['scorer', 'bodyparts', 'coords']
+    assert list(idx) == [('ensemble-kalman_tracker', 'a', 'x'), ('ensemble-kalman_tracker', 'a', 'y'),
+                         ('ensemble-kalman_tracker', 'b', 'x'), ('ensemble-kalman_tracker', 'b', 'y')]
+
+
+def test_crop_frames_matches_oracle_semantics():
+    y = np.arange(20).reshape(10, 2)
+    assert utils.crop_frames(y, None) is y and utils.crop_frames(y, []) is y
+    assert utils.crop_frames(y, [(None, None)]) is y
+    for spec in ([(None, 3)], [(7, None), (0, 2)], [(2, 5)], [(0, 1), (1, 2), (5, 10)]):
+        np.testing.assert_array_equal(utils.crop_frames(y, spec), orc.crop_frames(y, spec))
+    for bad in ([(3, 3)], [(0, 11)], [(0, 5), (4, 6)], [(0.0, 3)], [[0, 3]], [(-1, 3)]):
+        with pytest.raises(ValueError):
+            utils.crop_frames(y, bad)
+    with pytest.raises(TypeError):
+        utils.crop_frames(y, ((0, 3),))
+    R = utils.build_R_from_vars(np.array([[[0.0, 2.0], [3.0, 4.0]]]))
+    assert R.shape == (1, 2, 2, 2) and R[0, 0, 0, 0] == 1e-12 and R[0, 1, 1, 1] == 4.0 and R[0, 0, 0, 1] == 0
+    assert utils.crop_R(np.tile(np.eye(2), (3, 10, 1, 1)), [(2, 6)]).shape == (3, 4, 2, 2)
+
+
+@pytest.mark.parametrize('q', [100, 50, 95, 5])
+def test_center_predictions_matches_oracle(q):
+    rng = np.random.default_rng(3)
+    ens = rng.random((1, 2, 60, 4, 5))
+    ens[0, :, :, :, 2:4] = np.round(ens[0, :, :, :, 2:4], 1)            # ties at the threshold
+    ma = MarkerArray(ens, data_fields=['x', 'y', 'var_x', 'var_y', 'likelihood'])
+    mask, cen, good, means = utils.center_predictions(ma, q)
+    mask_o, cen_o, good_o, means_o, _ = orc.center_predictions(ens, q)
+    np.testing.assert_array_equal(mask, mask_o)                          # indices bit-exact
+    np.testing.assert_allclose(cen.array, cen_o, rtol=1e-13)
+    np.testing.assert_allclose(good.array, good_o, rtol=1e-13)
+    np.testing.assert_allclose(means.array, means_o, rtol=1e-13)
+    assert cen.data_fields == ['x', 'y'] and means.shape == (1, 2, 1, 4, 2)
+    with pytest.raises(AssertionError):
+        utils.center_predictions(MarkerArray(np.zeros((2, 1, 3, 1, 5)), data_fields=ma.data_fields), 50)
+
+
+def test_initialize_kalman_filter_shapes():
+    from eks_amd.singlecam_smoother import initialize_kalman_filter
+    rng = np.random.default_rng(4)
+    cen = MarkerArray(rng.standard_normal((1, 1, 50, 3, 2)), data_fields=['x', 'y'])
+    m0s, S0s, As, Qs, Cs = initialize_kalman_filter(cen)
+    assert m0s.shape == (3, 2) and np.all(m0s == 0)
+    eye = np.tile(np.eye(2), (3, 1, 1))
+    for M in (As, Qs, Cs):
+        np.testing.assert_array_equal(M, eye)
+    np.testing.assert_allclose(S0s[:, 0, 0], cen.array[0, 0, :, :, 0].var(axis=0))
+    assert np.all(S0s[:, 0, 1] == 0)
+
+
+def test_initialize_kalman_filter_pca_matches_oracle(golden_dir):
+    from sklearn.decomposition import PCA
+    from eks_amd.multicam_smoother import initialize_kalman_filter_pca
+    from eks_amd.stats import compute_pca
+    g = np.load(os.path.join(golden_dir, 'mirror_mouse_multicam.npz'))
+    ens = orc.ensemble(g['markers'])
+    ma = MarkerArray(ens, data_fields=['x', 'y', 'var_x', 'var_y', 'likelihood'])
+    mask, cen, good, means = utils.center_predictions(ma, 95.0)
+    np.testing.assert_array_equal(mask, g['valid_mask'])
+    pcas, good_pcs = compute_pca(mask, cen, good, n_components=3)
+    assert all(isinstance(p, PCA) for p in pcas) and good_pcs[0].shape == (int(mask[:, 0].sum()), 3)
+    m0s, S0s, As, Qs, Cs = initialize_kalman_filter_pca(good_pcs, pcas, 3)
+    assert Cs.shape == (4, 4, 3) and Qs.shape == (4, 3, 3)
+    sgn = np.sign(np.einsum('kod,kod->kd', Cs, g['Cs']))
+    np.testing.assert_allclose(Cs * sgn[:, None, :], g['Cs'], atol=1e-7)
+    np.testing.assert_allclose(S0s, g['S0s'], rtol=1e-6)
+    np.testing.assert_allclose(Qs * sgn[:, :, None] * sgn[:, None, :], g['Qs'], atol=1e-7)
+    assert np.abs(Qs).max(axis=(1, 2)) == pytest.approx(1.0)
+
+
+def test_compute_initial_guesses_and_constant_R():
+    from eks_amd.core import compute_initial_guesses, constant_R_from_timevarying
+    ev = np.arange(40, dtype=float).reshape(20, 2) ** 2
+    assert compute_initial_guesses(ev) == round(float(np.std(ev[1:] - ev[:-1])), 5)
+    with pytest.raises(ValueError):
+        compute_initial_guesses(np.ones((1, 2)))
+    Rt = utils.build_R_from_vars(np.array([[1.0, 5e-5], [3.0, 2e-5], [2.0, 9e-5]]))
+    np.testing.assert_allclose(np.diag(constant_R_from_timevarying(Rt)), [2.0, 1e-4])
