@@ -622,10 +622,11 @@ def center_predictions(ens, quantile_keep_pca):
     return mask, centered, good_c, means, good
 
 
-def singlecam_arrays(marker, avg_mode='median', var_mode='confidence_weighted_var'):
+def singlecam_arrays(marker, avg_mode='median', var_mode='confidence_weighted_var', ens=None):
     """Inputs of run_kalman_smoother as eks/singlecam_smoother.py:140-181 + :246-284 build them.
-    marker (M,1,T,K,3).  Everything downstream of `ensemble` is float64 here."""
-    ens = ensemble(marker, avg_mode, var_mode)
+    marker (M,1,T,K,3).  Everything downstream of `ensemble` is float64 here.  `ens` (1,1,T,K,5)
+    overrides the ensemble stage (to isolate the stages after it)."""
+    ens = ensemble(marker, avg_mode, var_mode) if ens is None else np.asarray(ens, np.float64)
     _, centered, _, means, _ = center_predictions(ens, 100)
     ys = np.transpose(centered[0, 0], (1, 0, 2))                 # (K,T,2)
     K = ys.shape[0]
@@ -669,11 +670,12 @@ def stacked_views(a, k):
 
 
 def multicam_arrays(marker, quantile_keep_pca=50.0, n_latent=3, avg_mode='median',
-                    var_mode='confidence_weighted_var', pca_fit=None):
+                    var_mode='confidence_weighted_var', pca_fit=None, ens=None):
     """Linear multicam inputs as eks/multicam_smoother.py:342-348, :412-430 and :554-597 build
     them (no variance inflation).  ``pca_fit(X, n) -> (components (n,F), mean (F,))`` defaults to
-    an SVD PCA with sklearn's sign convention left to the caller."""
-    ens = ensemble(marker, avg_mode, var_mode)
+    an SVD PCA with sklearn's sign convention left to the caller.  `ens` (1,V,T,K,5) overrides the
+    ensemble stage."""
+    ens = ensemble(marker, avg_mode, var_mode) if ens is None else np.asarray(ens, np.float64)
     mask, centered, good_c, means, good_idx = center_predictions(ens, quantile_keep_pca)
     V, T, K = ens.shape[1], ens.shape[2], ens.shape[3]
     if pca_fit is None:
