@@ -4,10 +4,14 @@
 //   * Adam mode  : one value per keypoint, with d nll / d log s (forward-mode dual numbers)
 //
 //   N1 diag_nll_summarize : wave = (64-chain tile, time chunk, group of NCL candidates); the waves of
-//                           a block are the candidate groups of ONE (tile, chunk), so the y tile is
-//                           pulled from HBM once and re-read from L1/L2 by the sibling waves.  Each
-//                           lane keeps NCL candidate filters in registers (ILP across candidates
-//                           hides the dependent-FMA latency of each scalar recursion).
+//                           a block are the candidate groups of ONE (tile, chunk).  Each lane keeps
+//                           NCL candidate filters in registers; once every candidate of the lane
+//                           is steady the work is two FMAs per frame and candidate, the
+//                           candidates interleaved in the frame loop (independent chains issue
+//                           back to back), loads double-buffered 8 frames ahead.  The chunk
+//                           length is chosen so that the grid is a whole number of 256-CU rounds.
+//                           (Tried and dropped, round 1: packed fp32, a transient/steady kernel
+//                           split with LDS-staged tiles - see DESIGN.md.)
 //   N2 diag_nll_assemble  : thread = (keypoint, candidate): walks the chunk summaries in time
 //                           order in float64 and writes nll[K][n_cand] (and dnll).
 // y is read once from HBM: 4 B per chain-frame regardless of the candidate count.
@@ -23,6 +27,7 @@ namespace eks {
 constexpr int kNllChunk = 4096;      // frames per lane, grid mode (measured best with NCL = 8)
 constexpr int kNllChunkGrad = 512;   // frames per lane, Adam mode (one candidate: needs more lanes)
 constexpr int kNclGrid = 8;
+constexpr int kNllChunkMin = 2048;
 
 struct NllWs {
   // planes indexed [(j * ncp + c) * N + n]
@@ -58,6 +63,8 @@ __global__ __launch_bounds__(512) void diag_nll_summarize_kernel(NllGeom G, Diag
   double sq[NCL];
 #pragma unroll
   for (int c = 0; c < NCL; ++c) {
+    // contiguous candidate groups: neighbours on the log-s grid converge at similar speed, so a
+    // wave leaves the transient regimes as early as its candidates allow
     const int ci = min(g * NCL + c, G.n_cand - 1);
     const double s = G.per_keypoint ? s_cand[(size_t)k * G.n_cand + ci] : s_cand[ci];
     sq[c] = s * q;
@@ -68,7 +75,9 @@ __global__ __launch_bounds__(512) void diag_nll_summarize_kernel(NllGeom G, Diag
   nll_summarize_chunk<R, NCL, UNIT>(y, G.N, n, t0, len, rconst[n], M.A[dd], M.C[dd], sq, out);
 #pragma unroll
   for (int c = 0; c < NCL; ++c) {
-    const size_t o = ((size_t)j * W.ncp + (g * NCL + c)) * G.N + n;
+    const int ci = g * NCL + c;
+    if (ci >= G.n_cand) continue;
+    const size_t o = ((size_t)j * W.ncp + ci) * G.N + n;
     W.A[o] = val(out[c].e.A);
     W.b[o] = val(out[c].e.b);
     W.C[o] = val(out[c].e.C);
@@ -85,6 +94,7 @@ __global__ __launch_bounds__(512) void diag_nll_summarize_kernel(NllGeom G, Diag
     }
   }
 }
+
 
 template <bool GRAD>
 __global__ __launch_bounds__(256) void diag_nll_assemble_kernel(NllGeom G, DiagModel M, NllWs W,
@@ -125,6 +135,7 @@ __global__ __launch_bounds__(256) void diag_nll_assemble_kernel(NllGeom G, DiagM
   if constexpr (GRAD) dnll[(size_t)k * G.n_cand + ci] = fin ? -der(tot) : 0.0;
 }
 
+constexpr int kTileF_fwd = 64;
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
@@ -137,8 +148,19 @@ static NllGeom make_geom(int T, int N, int D, int n_cand, int per_keypoint, bool
   G.D = D;
   G.BN = grad ? kNllChunkGrad : kNllChunk;
   if (!grad) {
-    const int bn = env_int("EKS_NLL_CHUNK", kNllChunk);
-    if (bn >= kNllChunkGrad) G.BN = bn;
+    // one block per (64-chain tile, chunk): pick the chunk length so that the grid is a whole
+    // number of 256-CU rounds (C3: 8 tiles x 32 chunks of 3136 frames = 256 blocks)
+    const int ntile64 = (N + 63) / 64;
+    long rounds = ((long)T * ntile64 + 128L * kNllChunk) / (256L * kNllChunk);
+    if (rounds < 1) rounds = 1;
+    long chunks = (256 * rounds + ntile64 - 1) / ntile64;
+    if (chunks < 1) chunks = 1;
+    int bn = (int)((T + chunks - 1) / chunks);
+    bn = (bn + kTileF_fwd - 1) / kTileF_fwd * kTileF_fwd;
+    if (bn < kNllChunkMin) bn = kNllChunkMin;   // short chunks cost accuracy (one float32 element
+                                                // per chunk) and transient work
+    G.BN = env_int("EKS_NLL_CHUNK", bn);
+    if (G.BN < kNllChunkGrad) G.BN = kNllChunkGrad;
   }
   G.ncn = (T + G.BN - 1) / G.BN;
   int nt_log2 = 0;

@@ -10,9 +10,10 @@ namespace eks {
 
 // ==========================================================================================
 // constant R: rconst[n] = max(nanmedian_t max(var[t][n], 1e-12), min_var)
-// Exact selection by MSB-first radix (4 x 8 bits on the float bit pattern; positive floats order
-// like their bit patterns), lanes = chains so every row read is coalesced, per-block histograms
-// in LDS (256 bins x 64 chains), one more sweep for the upper middle element of even counts.
+// General path: exact selection by MSB-first radix (4 x 8 bits on the float bit pattern; positive
+// floats order like their bit patterns), lanes = chains so every row read is coalesced, per-block
+// histograms in LDS (256 bins x 64 chains), one more sweep for the upper middle element of even
+// counts: five full passes.  It serves only the chains the two-pass bracket path (below) flags.
 // ==========================================================================================
 struct MedianWs {
   uint32_t* hist;    // [4][256][N]  (bin-major: a wave's flush / scan touches consecutive chains)
@@ -21,6 +22,8 @@ struct MedianWs {
   uint32_t* count;   // [N] number of non-NaN frames
   uint32_t* less_eq; // [N][2]: #keys < key_lo, #keys == key_lo
   uint32_t* next;    // [N] smallest key > key_lo (0xFFFFFFFF if none)
+  const uint32_t* need;      // [N] chains this path must serve (bracket path fell back)
+  const uint32_t* any_need;  // [1] 0 -> nothing to do
 };
 
 __device__ __forceinline__ uint32_t var_key(float v, bool& valid) {
@@ -35,6 +38,7 @@ template <int PASS>
 __global__ __launch_bounds__(64 * kMedWaves) void median_hist_kernel(int T, int N, int rows_per_block,
                                                          const float* __restrict__ var, MedianWs W) {
   __shared__ uint32_t h[256][64];
+  if (*W.any_need == 0u) return;
   for (int i = threadIdx.x; i < 256 * 64; i += 64 * kMedWaves) (&h[0][0])[i] = 0u;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -43,7 +47,8 @@ __global__ __launch_bounds__(64 * kMedWaves) void median_hist_kernel(int T, int 
   const int n = tile * 64 + lane;
   const int t_begin = slab * rows_per_block;
   const int t_end = min(T, t_begin + rows_per_block);
-  if (n < N) {
+  const bool mine = n < N && W.need[n] != 0u;
+  if (mine) {
     const uint32_t pref = PASS > 0 ? W.prefix[n] : 0u;
     constexpr int shift = 24 - 8 * PASS;
     // 8 rows in flight per lane: the loop is otherwise bound by one HBM round trip per row
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(64 * kMedWaves) void median_hist_kernel(int T, int 
     }
   }
   __syncthreads();
-  if (n < N) {
+  if (mine) {
     uint32_t* g = W.hist + (size_t)PASS * 256 * N + n;
     for (int b = wave; b < 256; b += kMedWaves) {
       const uint32_t c = h[b][lane];
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(64 * kMedWaves) void median_hist_kernel(int T, int 
 template <int PASS>
 __global__ void median_select_kernel(int N, MedianWs W) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+  if (*W.any_need == 0u || n >= N || W.need[n] == 0u) return;
   const uint32_t* g = W.hist + (size_t)PASS * 256 * N + n;
   uint32_t rank;
   if (PASS == 0) {
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(64 * kMedWaves) void median_next_kernel(int T, int 
   const int ntile = (N + 63) / 64;
   const int tile = blockIdx.x % ntile, slab = blockIdx.x / ntile;
   const int n = tile * 64 + lane;
-  if (n >= N) return;
+  if (*W.any_need == 0u || n >= N || W.need[n] == 0u) return;
   const int t_begin = slab * rows_per_block;
   const int t_end = min(T, t_begin + rows_per_block);
   const uint32_t key_lo = W.prefix[n];
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(64 * kMedWaves) void median_next_kernel(int T, int 
 
 __global__ void median_final_kernel(int N, double min_var, MedianWs W, double* __restrict__ rconst) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+  if (*W.any_need == 0u || n >= N || W.need[n] == 0u) return;
   const uint32_t cnt = W.count[n];
   double med;
   if (cnt == 0) {
@@ -154,13 +159,242 @@ __global__ void median_final_kernel(int N, double min_var, MedianWs W, double* _
   rconst[n] = (med != med) ? med : (med > min_var ? med : min_var);
 }
 
+// ------------------------------------------------------------------------------------------
+// Fast path (T > kMedCap): two full passes instead of five.
+//   B0 sample   : 256 evenly spaced rows per chain; the sample's order statistics 4 sigma either
+//                 side of its median bracket the true median: [lo, hi] holds ~25 % of the frames.
+//   B1 hist     : full pass; frames below lo are counted, frames inside [lo, hi] go to 256 linear
+//                 bins of the KEY range (LDS histograms as above).
+//   B2 narrow   : per chain, the bin(s) holding the two middle ranks -> [lo2, hi2] (~100 frames).
+//   B3 collect  : full pass; frames inside [lo2, hi2] are appended to a per-chain list.
+//   B4 finish   : exact selection of the middle ranks inside the list (rank by counting in LDS).
+// A chain whose bracket misses the median, or whose bin holds more than kMedCap frames (heavy
+// duplicates), is flagged and served by the radix kernels above, which then run masked.
+// Short sequences (T <= kMedCap) are selected directly from the whole column.
+// ------------------------------------------------------------------------------------------
+constexpr int kMedCap = 1024;
+constexpr int kMedSamples = 256;
+
+struct BracketWs {
+  uint32_t *lo, *hi, *less, *valid;     // [N]
+  uint32_t* hist;                        // [256][N]
+  uint32_t *lo2, *hi2, *less2, *cnt2;    // [N]
+  uint32_t* list;                        // [N][kMedCap]
+  uint32_t* fallback;                    // [N] 1 -> use the radix path for this chain
+  uint32_t* any_fallback;                // [1]
+};
+
+// exact middle-rank selection inside `vals[0..L)` (LDS), ranks a <= b, by counting
+__device__ __forceinline__ void select_two(const uint32_t* vals, int L, uint32_t a, uint32_t b,
+                                           uint32_t* out_lo, uint32_t* out_hi) {
+  for (int i = threadIdx.x; i < L; i += blockDim.x) {
+    const uint32_t v = vals[i];
+    uint32_t less = 0, eq = 0;
+    for (int jj = 0; jj < L; ++jj) {
+      const uint32_t u = vals[jj];
+      less += u < v;
+      eq += u == v;
+    }
+    if (a >= less && a < less + eq) *out_lo = v;
+    if (b >= less && b < less + eq) *out_hi = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void median_small_kernel(int T, int N, const float* __restrict__ var,
+                                                          double min_var, double* __restrict__ rconst) {
+  __shared__ uint32_t vals[kMedCap];
+  __shared__ uint32_t cnt, v_lo, v_hi;
+  const int n = blockIdx.x;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    bool valid;
+    const uint32_t key = var_key(var[(size_t)t * N + n], valid);
+    if (valid) vals[atomicAdd(&cnt, 1u)] = key;
+  }
+  __syncthreads();
+  const uint32_t c = cnt;
+  if (c) select_two(vals, (int)c, (c - 1) / 2, c / 2, &v_lo, &v_hi);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double med = c ? 0.5 * (double)__uint_as_float(v_lo) + 0.5 * (double)__uint_as_float(v_hi) : nan("");
+    rconst[n] = (med != med) ? med : (med > min_var ? med : min_var);
+  }
+}
+
+__global__ __launch_bounds__(kMedSamples) void bracket_sample_kernel(int T, int N,
+                                                                    const float* __restrict__ var,
+                                                                    BracketWs B) {
+  __shared__ uint32_t smp[kMedSamples];
+  __shared__ uint32_t nvalid;
+  const int n = blockIdx.x, i = threadIdx.x;
+  if (i == 0) nvalid = 0;
+  __syncthreads();
+  bool valid;
+  const uint32_t key = var_key(var[(size_t)(((long)i * T) / kMedSamples) * N + n], valid);
+  smp[i] = valid ? key : 0xFFFFFFFFu;                      // NaNs sort last
+  if (valid) atomicAdd(&nvalid, 1u);
+  __syncthreads();
+  const uint32_t nv = nvalid;
+  if (i == 0) {
+    B.less[n] = 0; B.valid[n] = 0; B.cnt2[n] = 0;
+    B.fallback[n] = nv < 64 ? 1u : 0u;
+    if (nv < 64) atomicOr(B.any_fallback, 1u);
+  }
+  if (nv < 64) return;
+  // rank of my sample (stable for ties), then the bracket ranks 4 sigma (sigma = sqrt(nv)/2) out
+  uint32_t rank = 0;
+  for (int jj = 0; jj < kMedSamples; ++jj) rank += (smp[jj] < smp[i]) || (smp[jj] == smp[i] && jj < i);
+  const int delta = (int)(2.0f * sqrtf((float)nv)) + 1;
+  const int mid = ((int)nv - 1) / 2;
+  const int r_lo = max(0, mid - delta), r_hi = min((int)nv - 1, mid + 1 + delta);
+  if ((int)rank == r_lo) B.lo[n] = smp[i];
+  if ((int)rank == r_hi) B.hi[n] = smp[i];
+}
+
+__global__ __launch_bounds__(64 * kMedWaves) void bracket_hist_kernel(int T, int N, int rows_per_block,
+                                                                     const float* __restrict__ var,
+                                                                     BracketWs B) {
+  __shared__ uint32_t h[256][64];
+  for (int i = threadIdx.x; i < 256 * 64; i += 64 * kMedWaves) (&h[0][0])[i] = 0u;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntile = (N + 63) / 64;
+  const int tile = blockIdx.x % ntile, slab = blockIdx.x / ntile;
+  const int n = tile * 64 + lane;
+  const int t_begin = slab * rows_per_block;
+  const int t_end = min(T, t_begin + rows_per_block);
+  uint32_t less = 0, nvalid = 0;
+  if (n < N && !B.fallback[n]) {
+    const uint32_t lo = B.lo[n], hi = B.hi[n];
+    const unsigned long long width = (unsigned long long)(hi - lo) + 1ull;
+    for (int t = t_begin + wave; t < t_end; t += 8 * kMedWaves) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int tt = t + kMedWaves * u;
+        v[u] = tt < t_end ? var[(size_t)tt * N + n] : __uint_as_float(0x7FC00000u);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        bool valid;
+        const uint32_t key = var_key(v[u], valid);
+        if (!valid) continue;
+        ++nvalid;
+        if (key < lo) {
+          ++less;
+        } else if (key <= hi) {
+          const uint32_t bin = (uint32_t)(((unsigned long long)(key - lo) * 256ull) / width);
+          atomicAdd(&h[bin][lane], 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (n < N && !B.fallback[n]) {
+    for (int b = wave; b < 256; b += kMedWaves) {
+      const uint32_t c = h[b][lane];
+      if (c) atomicAdd(&B.hist[(size_t)b * N + n], c);
+    }
+    if (less) atomicAdd(&B.less[n], less);
+    if (nvalid) atomicAdd(&B.valid[n], nvalid);
+  }
+}
+
+__global__ void bracket_narrow_kernel(int N, BracketWs B) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N || B.fallback[n]) return;
+  const uint32_t cnt = B.valid[n], less = B.less[n];
+  const uint32_t lo = B.lo[n], hi = B.hi[n];
+  const unsigned long long width = (unsigned long long)(hi - lo) + 1ull;
+  const uint32_t r_lo = cnt ? (cnt - 1) / 2 : 0, r_hi = cnt / 2;
+  uint32_t cum = less, less2 = 0, inside = 0;
+  int b_lo = -1, b_hi = -1;
+  for (int b = 0; b < 256; ++b) {
+    const uint32_t c = B.hist[(size_t)b * N + n];
+    if (b_lo < 0 && r_lo >= cum && r_lo < cum + c) {
+      b_lo = b;
+      less2 = cum;
+    }
+    if (b_lo >= 0 && b_hi < 0) inside += c;
+    if (b_hi < 0 && r_hi >= cum && r_hi < cum + c) b_hi = b;
+    cum += c;
+  }
+  if (cnt == 0 || b_lo < 0 || b_hi < 0 || inside > (uint32_t)kMedCap) {
+    B.fallback[n] = 1u;                               // bracket missed the median / heavy duplicates
+    atomicOr(B.any_fallback, 1u);
+    return;
+  }
+  // key range of bins b_lo .. b_hi: bin b starts at lo + ceil(b * width / 256)
+  B.lo2[n] = lo + (uint32_t)(((unsigned long long)b_lo * width + 255ull) / 256ull);
+  B.hi2[n] = lo + (uint32_t)(((unsigned long long)(b_hi + 1) * width + 255ull) / 256ull) - 1u;
+  B.less2[n] = less2;
+}
+
+__global__ __launch_bounds__(64 * kMedWaves) void bracket_collect_kernel(int T, int N, int rows_per_block,
+                                                                        const float* __restrict__ var,
+                                                                        BracketWs B) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntile = (N + 63) / 64;
+  const int tile = blockIdx.x % ntile, slab = blockIdx.x / ntile;
+  const int n = tile * 64 + lane;
+  if (n >= N || B.fallback[n]) return;
+  const int t_begin = slab * rows_per_block;
+  const int t_end = min(T, t_begin + rows_per_block);
+  const uint32_t lo2 = B.lo2[n], hi2 = B.hi2[n];
+  uint32_t* list = B.list + (size_t)n * kMedCap;
+  for (int t = t_begin + wave; t < t_end; t += 8 * kMedWaves) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int tt = t + kMedWaves * u;
+      v[u] = tt < t_end ? var[(size_t)tt * N + n] : __uint_as_float(0x7FC00000u);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      bool valid;
+      const uint32_t key = var_key(v[u], valid);
+      if (valid && key >= lo2 && key <= hi2) {
+        const uint32_t pos = atomicAdd(&B.cnt2[n], 1u);
+        if (pos < (uint32_t)kMedCap) list[pos] = key;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bracket_finish_kernel(int N, double min_var, BracketWs B,
+                                                            double* __restrict__ rconst) {
+  __shared__ uint32_t vals[kMedCap];
+  __shared__ uint32_t v_lo, v_hi;
+  const int n = blockIdx.x;
+  if (B.fallback[n]) return;                            // the radix path writes this chain
+  const uint32_t L = min(B.cnt2[n], (uint32_t)kMedCap);
+  for (int i = threadIdx.x; i < (int)L; i += blockDim.x) vals[i] = B.list[(size_t)n * kMedCap + i];
+  __syncthreads();
+  const uint32_t cnt = B.valid[n];
+  select_two(vals, (int)L, (cnt - 1) / 2 - B.less2[n], cnt / 2 - B.less2[n], &v_lo, &v_hi);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double med = 0.5 * (double)__uint_as_float(v_lo) + 0.5 * (double)__uint_as_float(v_hi);
+    rconst[n] = med > min_var ? med : min_var;
+  }
+}
+
+static inline size_t arr_bytes(size_t n) { return align_up(n * 4, 256); }
+
 size_t const_r_workspace_bytes(int N) {
-  return align_up((size_t)4 * N * 256 * 4, 256) + 6 * align_up((size_t)N * 2 * 4, 256);
+  return align_up((size_t)4 * N * 256 * 4, 256) + 6 * align_up((size_t)N * 2 * 4, 256)   // radix path
+         + 10 * arr_bytes(N) + arr_bytes((size_t)256 * N) + arr_bytes((size_t)N * kMedCap) + 256;
 }
 
 int const_r(int T, int N, const float* var, double min_var, double* rconst, void* ws,
             size_t ws_bytes, hipStream_t st) {
   if (ws_bytes < const_r_workspace_bytes(N)) return EKS_ERR_WORKSPACE;
+  ProfScope ps("const_r_select", st);
+  if (T <= kMedCap) {
+    hipLaunchKernelGGL(median_small_kernel, dim3(N), dim3(256), 0, st, T, N, var, min_var, rconst);
+    return hip_status(hipGetLastError());
+  }
   char* p = static_cast<char*>(ws);
   MedianWs W;
   const size_t hb = align_up((size_t)4 * N * 256 * 4, 256), sb = align_up((size_t)N * 2 * 4, 256);
@@ -170,25 +404,46 @@ int const_r(int T, int N, const float* var, double min_var, double* rconst, void
   W.count = reinterpret_cast<uint32_t*>(p + hb + 2 * sb);
   W.less_eq = reinterpret_cast<uint32_t*>(p + hb + 3 * sb);
   W.next = reinterpret_cast<uint32_t*>(p + hb + 4 * sb);
+  p += hb + 6 * sb;
+  BracketWs B;
+  uint32_t** arrs[10] = {&B.lo, &B.hi, &B.less, &B.valid, &B.lo2, &B.hi2, &B.less2, &B.cnt2,
+                         &B.fallback, &B.any_fallback};
+  for (int i = 0; i < 10; ++i) {
+    *arrs[i] = reinterpret_cast<uint32_t*>(p);
+    p += arr_bytes(N);
+  }
+  B.hist = reinterpret_cast<uint32_t*>(p);
+  p += arr_bytes((size_t)256 * N);
+  B.list = reinterpret_cast<uint32_t*>(p);
+  W.need = B.fallback;
+  W.any_need = B.any_fallback;
+
   hipError_t e = hipMemsetAsync(W.hist, 0, hb, st);
+  if (e == hipSuccess) e = hipMemsetAsync(B.hist, 0, arr_bytes((size_t)256 * N), st);
+  if (e == hipSuccess) e = hipMemsetAsync(B.any_fallback, 0, 4, st);
   if (e != hipSuccess) return hip_status(e);
   const int ntile = (N + 63) / 64;
-  // enough blocks to fill the chip, at least 256 rows per block so the LDS flush amortises
+  // enough blocks to fill the chip, each long enough to amortise its LDS flush
   int rows = (int)(((long)T * ntile + 511) / 512);
   if (rows < 8 * kMedWaves) rows = 8 * kMedWaves;
   rows = (rows + kMedWaves - 1) / kMedWaves * kMedWaves;
   const int nslab = (T + rows - 1) / rows;
-  const dim3 grid(ntile * nslab), sel((N + 255) / 256);
-  ProfScope ps("const_r_select", st);
-  hipLaunchKernelGGL(median_hist_kernel<0>, grid, dim3(64 * kMedWaves), 0, st, T, N, rows, var, W);
+  const dim3 grid(ntile * nslab), big(64 * kMedWaves), sel((N + 255) / 256);
+  hipLaunchKernelGGL(bracket_sample_kernel, dim3(N), dim3(kMedSamples), 0, st, T, N, var, B);
+  hipLaunchKernelGGL(bracket_hist_kernel, grid, big, 0, st, T, N, rows, var, B);
+  hipLaunchKernelGGL(bracket_narrow_kernel, sel, dim3(256), 0, st, N, B);
+  hipLaunchKernelGGL(bracket_collect_kernel, grid, big, 0, st, T, N, rows, var, B);
+  hipLaunchKernelGGL(bracket_finish_kernel, dim3(N), dim3(256), 0, st, N, min_var, B, rconst);
+  // masked exact radix path for the flagged chains (all kernels return at once if none is)
+  hipLaunchKernelGGL(median_hist_kernel<0>, grid, big, 0, st, T, N, rows, var, W);
   hipLaunchKernelGGL(median_select_kernel<0>, sel, dim3(256), 0, st, N, W);
-  hipLaunchKernelGGL(median_hist_kernel<1>, grid, dim3(64 * kMedWaves), 0, st, T, N, rows, var, W);
+  hipLaunchKernelGGL(median_hist_kernel<1>, grid, big, 0, st, T, N, rows, var, W);
   hipLaunchKernelGGL(median_select_kernel<1>, sel, dim3(256), 0, st, N, W);
-  hipLaunchKernelGGL(median_hist_kernel<2>, grid, dim3(64 * kMedWaves), 0, st, T, N, rows, var, W);
+  hipLaunchKernelGGL(median_hist_kernel<2>, grid, big, 0, st, T, N, rows, var, W);
   hipLaunchKernelGGL(median_select_kernel<2>, sel, dim3(256), 0, st, N, W);
-  hipLaunchKernelGGL(median_hist_kernel<3>, grid, dim3(64 * kMedWaves), 0, st, T, N, rows, var, W);
+  hipLaunchKernelGGL(median_hist_kernel<3>, grid, big, 0, st, T, N, rows, var, W);
   hipLaunchKernelGGL(median_select_kernel<3>, sel, dim3(256), 0, st, N, W);
-  hipLaunchKernelGGL(median_next_kernel, grid, dim3(64 * kMedWaves), 0, st, T, N, rows, var, W);
+  hipLaunchKernelGGL(median_next_kernel, grid, big, 0, st, T, N, rows, var, W);
   hipLaunchKernelGGL(median_final_kernel, sel, dim3(256), 0, st, N, min_var, W, rconst);
   return hip_status(hipGetLastError());
 }

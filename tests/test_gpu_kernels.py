@@ -134,7 +134,8 @@ def test_smooth_dense_matches_oracle(T, K, D, O, general_A):
         assert _rel(Vk, ref, axis_scale=tuple(range(1, ref.ndim))) < 1e-5
 
 
-@pytest.mark.parametrize('T,N', [(2001, 7), (2000, 70), (1, 3), (2, 5), (300, 130)])
+@pytest.mark.parametrize('T,N', [(2001, 7), (2000, 70), (1, 3), (2, 5), (300, 130), (1024, 5), (1025, 66),
+                                 (30011, 130)])
 def test_const_r_is_exact_median(T, N):
     from eks_amd import hip_ops
     rng = np.random.default_rng(T + N)
@@ -142,8 +143,10 @@ def test_const_r_is_exact_median(T, N):
     var[rng.random((T, N, 1)) < 0.05] = 0.0                    # below the 1e-12 clip
     if T > 10:
         var[3:9, 0, 0] = var[5, 0, 0]                          # duplicates around the middle
-        var[:, 1, 0] = 0.25                                    # constant column
+        var[:, 1, 0] = 0.25                                    # constant column (radix fallback)
         var[rng.random(T) < 0.3, 2, 0] = np.nan                # NaNs are ignored (nanmedian)
+        var[:, 3, 0] = np.round(var[:, 3, 0], 1)               # heavily quantised values
+        var[: T // 2, 4, 0] *= 1e-3                            # bimodal: median sits in a gap
     got = hip_ops.const_r(_dev(var), 1e-4).cpu().numpy()
     ref = orc.constant_R_from_timevarying(
         np.clip(var.astype(np.float64), 1e-12, None)[:, :, 0].T[:, :, None], 1e-4)[:, 0]
@@ -180,6 +183,26 @@ def test_nll_grid_diag_matches_oracle(T, K, unit):
     np.testing.assert_array_equal(idx.cpu().numpy()[clear], ref.argmin(axis=1)[clear])
     np.testing.assert_array_equal(s_sel.cpu().numpy(), cand[nll.argmin(axis=1)])
     assert clear.all()
+
+
+@pytest.mark.parametrize('T,K,unit', [(700, 40, True), (1300, 70, False), (4500, 33, True)])
+def test_nll_grid_staged_kernel_matches_c_oracle(T, K, unit):
+    """>= 64 chains and 64 candidates take the LDS-staged kernel (8 candidate groups per block,
+    ragged last chunk / tile / 8-frame block, partially filled last chain tile)."""
+    from eks_amd import hip_ops
+    from oracle import c_oracle
+    arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=17 + T, unit=unit)
+    cand = np.exp(np.linspace(-8, 8, 64))
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    rconst = hip_ops.const_r(_dev(var_tk), 1e-4)
+    nll = hip_ops.nll(_dev(y_tk), rconst, *_params_dev(arrs), _dev(cand), flags=flags).cpu().numpy()
+    ref = c_oracle.nll_grid(arrs['ys'], rconst.cpu().numpy(), arrs['m0s'], arrs['S0s'], arrs['As'],
+                            arrs['Cs'], arrs['Qs'], cand)
+    assert (np.abs(nll - ref) / np.abs(ref)).max() < 1e-5
+    srt = np.sort(ref, axis=1)
+    clear = (srt[:, 1] - srt[:, 0]) > 2e-5 * np.abs(srt[:, 0])
+    np.testing.assert_array_equal(nll.argmin(axis=1)[clear], ref.argmin(axis=1)[clear])
+    assert clear.mean() > 0.9
 
 
 @pytest.mark.parametrize('T,K,unit', [(3000, 5, True), (1500, 3, False)])
