@@ -173,6 +173,7 @@ __global__ void median_final_kernel(int N, double min_var, MedianWs W, double* _
 // Short sequences (T <= kMedCap) are selected directly from the whole column.
 // ------------------------------------------------------------------------------------------
 constexpr int kMedCap = 1024;
+constexpr int kMedFlight = 16;   // rows in flight per lane in the two full passes (measured best with 256 blocks)
 constexpr int kMedSamples = 256;
 
 struct BracketWs {
@@ -268,15 +269,15 @@ __global__ __launch_bounds__(64 * kMedWaves) void bracket_hist_kernel(int T, int
   if (n < N && !B.fallback[n]) {
     const uint32_t lo = B.lo[n], hi = B.hi[n];
     const unsigned long long width = (unsigned long long)(hi - lo) + 1ull;
-    for (int t = t_begin + wave; t < t_end; t += 8 * kMedWaves) {
-      float v[8];
+    for (int t = t_begin + wave; t < t_end; t += kMedFlight * kMedWaves) {
+      float v[kMedFlight];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kMedFlight; ++u) {
         const int tt = t + kMedWaves * u;
         v[u] = tt < t_end ? var[(size_t)tt * N + n] : __uint_as_float(0x7FC00000u);
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kMedFlight; ++u) {
         bool valid;
         const uint32_t key = var_key(v[u], valid);
         if (!valid) continue;
@@ -301,34 +302,66 @@ __global__ __launch_bounds__(64 * kMedWaves) void bracket_hist_kernel(int T, int
   }
 }
 
-__global__ void bracket_narrow_kernel(int N, BracketWs B) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N || B.fallback[n]) return;
+// one wave per chain: lane l owns bins 4l .. 4l+3, wave-level exclusive scan of the lane sums
+__global__ __launch_bounds__(256) void bracket_narrow_kernel(int N, BracketWs B) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (n >= N || B.fallback[n]) return;                  // wave-uniform
   const uint32_t cnt = B.valid[n], less = B.less[n];
   const uint32_t lo = B.lo[n], hi = B.hi[n];
   const unsigned long long width = (unsigned long long)(hi - lo) + 1ull;
   const uint32_t r_lo = cnt ? (cnt - 1) / 2 : 0, r_hi = cnt / 2;
-  uint32_t cum = less, less2 = 0, inside = 0;
+  uint32_t c[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) c[i] = B.hist[(size_t)(4 * lane + i) * N + n];
+  const uint32_t mine = c[0] + c[1] + c[2] + c[3];
+  uint32_t incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(incl, off);
+    if (lane >= off) incl += up;
+  }
+  uint32_t cum = less + incl - mine;                    // frames below my first bin
   int b_lo = -1, b_hi = -1;
-  for (int b = 0; b < 256; ++b) {
-    const uint32_t c = B.hist[(size_t)b * N + n];
-    if (b_lo < 0 && r_lo >= cum && r_lo < cum + c) {
-      b_lo = b;
+  uint32_t less2 = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (r_lo >= cum && r_lo < cum + c[i]) {
+      b_lo = 4 * lane + i;
       less2 = cum;
     }
-    if (b_lo >= 0 && b_hi < 0) inside += c;
-    if (b_hi < 0 && r_hi >= cum && r_hi < cum + c) b_hi = b;
-    cum += c;
+    if (r_hi >= cum && r_hi < cum + c[i]) b_hi = 4 * lane + i;
+    cum += c[i];
   }
-  if (cnt == 0 || b_lo < 0 || b_hi < 0 || inside > (uint32_t)kMedCap) {
-    B.fallback[n] = 1u;                               // bracket missed the median / heavy duplicates
+  // at most one lane holds each of b_lo / b_hi: broadcast them
+  const unsigned long long m_lo = __ballot(b_lo >= 0), m_hi = __ballot(b_hi >= 0);
+  const bool ok = cnt != 0 && m_lo != 0 && m_hi != 0;
+  int g_lo = 0, g_hi = 0;
+  uint32_t g_less2 = 0;
+  if (ok) {
+    const int l_lo = __ffsll((long long)m_lo) - 1, l_hi = __ffsll((long long)m_hi) - 1;
+    g_lo = __shfl(b_lo, l_lo);
+    g_less2 = __shfl(less2, l_lo);
+    g_hi = __shfl(b_hi, l_hi);
+  }
+  uint32_t inside = 0;                                  // frames inside bins g_lo .. g_hi
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int bb = 4 * lane + i;
+    if (ok && bb >= g_lo && bb <= g_hi) inside += c[i];
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) inside += __shfl_xor(inside, off);
+  if (lane != 0) return;
+  if (!ok || inside > (uint32_t)kMedCap) {
+    B.fallback[n] = 1u;                                 // bracket missed the median / heavy duplicates
     atomicOr(B.any_fallback, 1u);
     return;
   }
-  // key range of bins b_lo .. b_hi: bin b starts at lo + ceil(b * width / 256)
-  B.lo2[n] = lo + (uint32_t)(((unsigned long long)b_lo * width + 255ull) / 256ull);
-  B.hi2[n] = lo + (uint32_t)(((unsigned long long)(b_hi + 1) * width + 255ull) / 256ull) - 1u;
-  B.less2[n] = less2;
+  // key range of bins g_lo .. g_hi: bin b starts at lo + ceil(b * width / 256)
+  B.lo2[n] = lo + (uint32_t)(((unsigned long long)g_lo * width + 255ull) / 256ull);
+  B.hi2[n] = lo + (uint32_t)(((unsigned long long)(g_hi + 1) * width + 255ull) / 256ull) - 1u;
+  B.less2[n] = g_less2;
 }
 
 __global__ __launch_bounds__(64 * kMedWaves) void bracket_collect_kernel(int T, int N, int rows_per_block,
@@ -343,15 +376,15 @@ __global__ __launch_bounds__(64 * kMedWaves) void bracket_collect_kernel(int T, 
   const int t_end = min(T, t_begin + rows_per_block);
   const uint32_t lo2 = B.lo2[n], hi2 = B.hi2[n];
   uint32_t* list = B.list + (size_t)n * kMedCap;
-  for (int t = t_begin + wave; t < t_end; t += 8 * kMedWaves) {
-    float v[8];
+  for (int t = t_begin + wave; t < t_end; t += kMedFlight * kMedWaves) {
+    float v[kMedFlight];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < kMedFlight; ++u) {
       const int tt = t + kMedWaves * u;
       v[u] = tt < t_end ? var[(size_t)tt * N + n] : __uint_as_float(0x7FC00000u);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < kMedFlight; ++u) {
       bool valid;
       const uint32_t key = var_key(v[u], valid);
       if (valid && key >= lo2 && key <= hi2) {
@@ -424,14 +457,14 @@ int const_r(int T, int N, const float* var, double min_var, double* rconst, void
   if (e != hipSuccess) return hip_status(e);
   const int ntile = (N + 63) / 64;
   // enough blocks to fill the chip, each long enough to amortise its LDS flush
-  int rows = (int)(((long)T * ntile + 511) / 512);
-  if (rows < 8 * kMedWaves) rows = 8 * kMedWaves;
+  int rows = (int)(((long)T * ntile + 255) / 256);     // one 16-wave block per CU
+  if (rows < kMedFlight * kMedWaves) rows = kMedFlight * kMedWaves;
   rows = (rows + kMedWaves - 1) / kMedWaves * kMedWaves;
   const int nslab = (T + rows - 1) / rows;
   const dim3 grid(ntile * nslab), big(64 * kMedWaves), sel((N + 255) / 256);
   hipLaunchKernelGGL(bracket_sample_kernel, dim3(N), dim3(kMedSamples), 0, st, T, N, var, B);
   hipLaunchKernelGGL(bracket_hist_kernel, grid, big, 0, st, T, N, rows, var, B);
-  hipLaunchKernelGGL(bracket_narrow_kernel, sel, dim3(256), 0, st, N, B);
+  hipLaunchKernelGGL(bracket_narrow_kernel, dim3((N + 3) / 4), dim3(256), 0, st, N, B);
   hipLaunchKernelGGL(bracket_collect_kernel, grid, big, 0, st, T, N, rows, var, B);
   hipLaunchKernelGGL(bracket_finish_kernel, dim3(N), dim3(256), 0, st, N, min_var, B, rconst);
   // masked exact radix path for the flagged chains (all kernels return at once if none is)
@@ -451,28 +484,44 @@ int const_r(int T, int N, const float* var, double min_var, double* rconst, void
 // ==========================================================================================
 // argmin over candidates (first minimum, numpy.argmin semantics) + gather of s
 // ==========================================================================================
-__global__ void argmin_kernel(int K, int n_cand, const double* __restrict__ nll,
-                              const double* __restrict__ s_cand, double* __restrict__ s_out,
-                              int32_t* __restrict__ idx_out) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per keypoint: lanes stride over the candidates, (value, index) min-reduction that
+// keeps the FIRST minimum (numpy.argmin semantics)
+__global__ __launch_bounds__(256) void argmin_kernel(int K, int n_cand, const double* __restrict__ nll,
+                                                    const double* __restrict__ s_cand,
+                                                    double* __restrict__ s_out,
+                                                    int32_t* __restrict__ idx_out) {
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (k >= K) return;
   const double* row = nll + (size_t)k * n_cand;
-  int best = 0;
-  double bv = row[0];
-  for (int c = 1; c < n_cand; ++c) {
+  constexpr int kNone = 0x7FFFFFFF;
+  double bv = 0.0;
+  int best = kNone;
+  for (int c = lane; c < n_cand; c += 64) {
     const double v = row[c];
-    if (v < bv) {
+    if (best == kNone || v < bv) {
       bv = v;
       best = c;
     }
   }
-  s_out[k] = s_cand[best];
-  if (idx_out) idx_out[k] = best;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double ov = __shfl_xor(bv, off);
+    const int oi = __shfl_xor(best, off);
+    if (oi != kNone && (best == kNone || ov < bv || (ov == bv && oi < best))) {
+      bv = ov;
+      best = oi;
+    }
+  }
+  if (lane == 0) {
+    s_out[k] = s_cand[best];
+    if (idx_out) idx_out[k] = best;
+  }
 }
 
 int argmin_s(int K, int n_cand, const double* nll, const double* s_cand, double* s_out,
              int32_t* idx_out, hipStream_t st) {
-  hipLaunchKernelGGL(argmin_kernel, dim3((K + 255) / 256), dim3(256), 0, st, K, n_cand, nll, s_cand,
+  hipLaunchKernelGGL(argmin_kernel, dim3((K + 3) / 4), dim3(256), 0, st, K, n_cand, nll, s_cand,
                      s_out, idx_out);
   return hip_status(hipGetLastError());
 }
