@@ -31,9 +31,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (T, K, n_cand)
-    'c3': (100_000, 256, 64),
-    'c2': (10_000, 64, 0),       # fixed smoothing parameter, no search (parity-sized)
+    # name: (T, K, n_cand)     singlecam (D = O = 2); n_cand = 0 -> fixed smoothing parameter s = 10
+    'c3': (100_000, 256, 64),    # BASELINE.json configs[2]: the headline metric
+    'c2': (10_000, 64, 0),       # configs[1]
+    'c5': (50_000, 128 * 32, 0), # configs[4], one GPU's share: 128 sessions x 32 keypoints batched
 }
 SMOOTH_BYTES_PER_UNIT = 40       # y 8 + var 8 in, ms 8 + Vs 16 out  
 NLL_BYTES_PER_UNIT = 8           # y read once regardless of candidate count
@@ -51,6 +52,17 @@ def parse():
                    help='do not bracket kernels with HIP events inside the timed region')
     p.add_argument('--cpu-seconds', type=float, default=15.0)
     return p.parse_args()
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` on the C3 shape, from the committed rocprofv3 PMC passes
+    (profiles/r01_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
+    MI355X_MICROARCH.md; separate --pmc runs of this same command).  None if not recorded."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as f:
+            return json.load(f)['hbm_bytes_per_launch'].get(kernel)
+    except Exception:
+        return None
 
 
 def drain_profile(lib):
@@ -110,11 +122,15 @@ def main():
             raise SystemExit('launch multi-GPU runs with torch.distributed.run (one rank per GPU)')
     from eks_amd import _lib, hip_ops, synth
     hip_ops.require_gpu()
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    backend = os.environ.get('EKS_BENCH_BACKEND', 'nccl')       # nccl == RCCL over xGMI on ROCm
     if world > 1:
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:                                                    # test hook: ranks may share a GPU
+            dist.init_process_group(backend, rank=rank, world_size=world)
     lib = _lib.load()
 
     T, K, n_cand = WORKLOADS[args.workload]
@@ -129,6 +145,7 @@ def main():
     ms = torch.empty((T, K, 2), dtype=torch.float32, device=dev)
     Vs = torch.empty((T, K, 2, 2), dtype=torch.float32, device=dev)
     gathered = [torch.empty(K, dtype=torch.float64, device=dev) for _ in range(world)]
+    gathered_host = [torch.empty(K, dtype=torch.float64) for _ in range(world)]
 
     def step():
         if n_cand:
@@ -139,10 +156,14 @@ def main():
             s = s_fixed
         hip_ops.smooth(y, var, m0, S0, eye, eye, eye, s, flags=flags, out=(ms, Vs))
         if world > 1:
-            dist.all_gather(gathered, s)
+            if backend == 'nccl':
+                dist.all_gather(gathered, s)
+            else:
+                dist.all_gather(gathered_host, s.cpu())
         return s
 
     def sync():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -161,7 +182,7 @@ def main():
     lib.eks_profile_enable(0)
     prof = drain_profile(lib) if events_on else {}
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -187,7 +208,7 @@ def main():
             out['roofline'] = {
                 'bound': 'hbm', 'kernel': 'diag_replay_kernel', 'achieved': achieved,
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                'traffic': None,
+                'traffic': measured_traffic('diag_replay_kernel') if args.workload == 'c3' else None,
                 'algorithmic_bytes_per_launch': SMOOTH_BYTES_PER_UNIT * units_per_step,
                 'kernel_avg_ms': k3, 'launches_timed': len(prof.get('diag_replay', [])),
                 'stage_avg_ms': avg,

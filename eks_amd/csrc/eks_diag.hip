@@ -21,6 +21,8 @@
 // is a contiguous 256 B (x4 for the four waves of a block: 1 KiB contiguous per frame).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "eks_diag_lane.hpp"
 #include "eks_internal.hpp"
 
@@ -33,6 +35,7 @@ struct LaneMap {
   int N, T, nc;       // chains, frames, chunks
   int nt_log2;        // log2 of chains per wave row (NT = min(64, pow2ceil(N)))
   int ntile;          // ceil(N / NT)
+  int reverse;        // K3 only: walk the chunks backwards in time
 };
 
 __device__ __forceinline__ bool lane_coords(const LaneMap& L, int& n, int& j) {
@@ -79,6 +82,9 @@ __global__ __launch_bounds__(256) void diag_replay_kernel(LaneMap L, DiagModel M
                                                          float* __restrict__ Vs) {
   int n, j;
   if (!lane_coords(L, n, j)) return;
+  // K1 streamed y, var forwards in time; walking the chunks backwards here lets the tail of that
+  // stream be served from the 256 MiB Infinity Cache (EKS_REPLAY_FORWARD=1 disables, for A/B)
+  if (L.reverse) j = L.nc - 1 - j;
   const ChainParams<float> p = load_chain_params(M, n);
   const int t0 = j * B;
   const int len = min(B, L.T - t0);
@@ -237,6 +243,7 @@ static LaneMap make_lane_map(int T, int N, int B) {
   while ((1 << nt_log2) < N && nt_log2 < 6) ++nt_log2;
   L.nt_log2 = nt_log2;
   L.ntile = (N + (1 << nt_log2) - 1) >> nt_log2;
+  L.reverse = 0;
   return L;
 }
 
@@ -268,7 +275,8 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
   const bool vs_diag = d.flags & EKS_FLAG_VS_DIAG;
   if (!vs_diag && D > 8) return EKS_ERR_UNSUPPORTED;
   if (ws_bytes < diag_smooth_workspace_bytes(T, N)) return EKS_ERR_WORKSPACE;
-  const LaneMap L = make_lane_map(T, N, kChunk);
+  const LaneMap Lf = make_lane_map(T, N, kChunk);
+  const LaneMap& L = Lf;
   const size_t pb = plane_bytes(L.nc, N);
   char* base = static_cast<char*>(ws);
   DiagWs W;
@@ -301,6 +309,9 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
   const int vs_row = vs_diag ? 0 : D;
   {
     ProfScope ps("diag_replay", st);
+    LaneMap L = Lf;
+    const char* fwd = getenv("EKS_REPLAY_FORWARD");
+    L.reverse = (fwd && fwd[0] == '1') ? 0 : 1;
     if (unit)
       launch_replay<true>(vs_row, grid, st, L, M, W, y, var, ms, Vs);
     else

@@ -171,7 +171,9 @@ def center_predictions(ensemble_marker_array: MarkerArray, quantile_keep_pca: fl
     emA_good_centered_preds (1,V,min_frames,K,2), emA_means (1,V,1,K,2))."""
     M, V, T, K, _ = ensemble_marker_array.shape
     assert M == 1, 'MarkerArray should have n_models = 1 after ensembling.'
-    preds = np.asarray(ensemble_marker_array.slice_fields('x', 'y').array)
+    # float64 on the host: the reference does this in float32 (its ensemble arrays are float32,
+    # SURVEY.md A.4); the means feed every output column, so the extra digits are kept
+    preds = np.asarray(ensemble_marker_array.slice_fields('x', 'y').array, dtype=np.float64)
     vars_ = np.asarray(ensemble_marker_array.slice_fields('var_x', 'var_y').array)
     worst = vars_.max(axis=(0, 1, 4))                                   # (T, K)
     mask = worst <= np.percentile(worst, quantile_keep_pca, axis=0)
