@@ -35,6 +35,7 @@ WORKLOADS = {
     'c3': (100_000, 256, 64),    # BASELINE.json configs[2]: the headline metric
     'c2': (10_000, 64, 0),       # configs[1]
     'c5': (50_000, 128 * 32, 0), # configs[4], one GPU's share: 128 sessions x 32 keypoints batched
+    'c4': (50_000, 4, 0),        # configs[3]: mirrored multicam, 2 views x 4 paws, D = 3, O = 4 (dense path)
 }
 SMOOTH_BYTES_PER_UNIT = 40       # y 8 + var 8 in, ms 8 + Vs 16 out  
 NLL_BYTES_PER_UNIT = 8           # y read once regardless of candidate count
@@ -110,6 +111,53 @@ def cpu_baseline(y_dev, var_dev, T, n_cand, budget_s):
                        f'recursion (oracle/eks_oracle.c), OpenMP over keypoints, {dt:.1f} s'), s
 
 
+def bench_dense(args, T, K, dev, rank, world, lib):
+    """configs[3] shape through the general (D, O) kernels: 2 views x 4 paws, n_latent 3, fixed s.
+    Latency-bound by construction (4 keypoints): reported for the record, not the headline."""
+    import torch
+    from eks_amd import hip_ops
+    D, O = 3, 4
+    g = torch.Generator(device=dev)
+    g.manual_seed(4 + rank)
+    lat = torch.cumsum(torch.randn(T, K, D, device=dev, generator=g) * 0.7, dim=0)
+    C = torch.linalg.qr(torch.randn(K, O, D, device=dev, generator=g, dtype=torch.float64))[0].contiguous()
+    var = (0.25 * (-torch.log(torch.rand(T, K, O, device=dev, generator=g).clamp_min(1e-12))
+                   - torch.log(torch.rand(T, K, O, device=dev, generator=g).clamp_min(1e-12)))
+           ).clamp_min(1e-3).float().contiguous()
+    y = (torch.einsum('kod,tkd->tko', C.float(), lat)
+         + torch.randn(T, K, O, device=dev, generator=g) * var.sqrt()).float().contiguous()
+    L = torch.randn(K, D, D, device=dev, generator=g, dtype=torch.float64) * 0.3
+    Q = L @ L.transpose(1, 2) + 0.2 * torch.eye(D, dtype=torch.float64, device=dev)
+    Q = (Q / Q.abs().amax(dim=(1, 2), keepdim=True)).contiguous()
+    eye = torch.eye(D, dtype=torch.float64, device=dev).expand(K, D, D).contiguous()
+    m0 = torch.zeros(K, D, dtype=torch.float64, device=dev)
+    s = torch.full((K,), 10.0, dtype=torch.float64, device=dev)
+    for _ in range(args.warmup):
+        hip_ops.smooth(y, var, m0, eye * 4.0, eye, C, Q, s)
+    torch.cuda.synchronize()
+    lib.eks_profile_drain(None, 0, None, 0)
+    lib.eks_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hip_ops.smooth(y, var, m0, eye * 4.0, eye, C, Q, s)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lib.eks_profile_enable(0)
+    prof = {k: float(np.mean(v)) for k, v in drain_profile(lib).items()}
+    out = {'metric': 'frames*keypoints smoothed/s, mirrored multicam 50k x 4 (D=3, O=4)',
+           'value': args.steps * T * K / dt, 'unit': 'frames*keypoints/s', 'n_gpus': 1,
+           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+           'data': 'synthetic',
+           'config': {'workload': f'multicam linear T={T} x K={K} keypoints, D={D}, O={O}, fixed s=10'},
+           'roofline': {'bound': 'hbm', 'kernel': 'dense_replay_kernel', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS,
+                        'achieved': 80 * T * K / (prof.get('dense_replay', float('nan')) * 1e-3) / 1e9,
+                        'frac': 80 * T * K / (prof.get('dense_replay', float('nan')) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        'traffic': None, 'stage_avg_ms': prof,
+                        'note': 'latency-bound: 4 keypoints give 4 x ceil(T/256) lanes; not an HBM-bound shape'}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
     import torch
@@ -134,6 +182,8 @@ def main():
     lib = _lib.load()
 
     T, K, n_cand = WORKLOADS[args.workload]
+    if args.workload == 'c4':
+        return bench_dense(args, T, K, dev, rank, world, lib)
     # every rank owns an independent session of the same shape (seed = 3 + rank)
     y, var = synth.singlecam_observations_torch(T, K, seed=3 + rank, device=dev)
     eye = torch.eye(2, dtype=torch.float64, device=dev).expand(K, 2, 2).contiguous()

@@ -135,7 +135,6 @@ __global__ __launch_bounds__(256) void diag_nll_assemble_kernel(NllGeom G, DiagM
   if constexpr (GRAD) dnll[(size_t)k * G.n_cand + ci] = fin ? -der(tot) : 0.0;
 }
 
-constexpr int kTileF_fwd = 64;
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
@@ -156,7 +155,7 @@ static NllGeom make_geom(int T, int N, int D, int n_cand, int per_keypoint, bool
     long chunks = (256 * rounds + ntile64 - 1) / ntile64;
     if (chunks < 1) chunks = 1;
     int bn = (int)((T + chunks - 1) / chunks);
-    bn = (bn + kTileF_fwd - 1) / kTileF_fwd * kTileF_fwd;
+    bn = (bn + 64 - 1) / 64 * 64;
     if (bn < kNllChunkMin) bn = kNllChunkMin;   // short chunks cost accuracy (one float32 element
                                                 // per chunk) and transient work
     G.BN = env_int("EKS_NLL_CHUNK", bn);
