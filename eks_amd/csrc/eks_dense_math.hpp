@@ -361,4 +361,60 @@ EKS_HD void delem_back(const DElem<S, D>& e, Vec<S, D>& eta, Mat<S, D>& J) {
   J = mat_symmetrize(mat_add(mat_mul_tn(e.A, mat_mul(Jp, e.A)), e.J));
 }
 
+// Compose two elements, `i` (earlier frames) then `j` (later frames):
+//   M = (I + C_i J_j)^-1 = I - L G^-1 L^T J_j,   C_i = L L^T,  G = I + L^T J_j L  (>= I: no pivoting)
+//   A = A_j M A_i           b = A_j M (b_i + C_i eta_j) + b_j        C = A_j M C_i A_j^T + C_j
+//   eta = A_i^T M^T (eta_j - J_j b_i) + eta_i                        J = A_i^T M^T J_j A_i + J_i
+//   ell = ell_i + ell_j - log|G|/2 + b_i.eta_j - b_i^T J_j b_i / 2 + v^T (M C_i) v / 2,  v = eta_j - J_j b_i
+template <typename S, int D>
+EKS_HD DElem<S, D> delem_combine(const DElem<S, D>& ei, const DElem<S, D>& ej) {
+  const Mat<S, D> L = chol_psd(ei.C);
+  const Mat<S, D> JL = mat_mul(ej.J, L);
+  Mat<S, D> G = mat_mul_tn(L, JL);
+#pragma unroll
+  for (int i = 0; i < D; ++i) G.a[i][i] = G.a[i][i] + S(1.0);
+  const Mat<S, D> Lg = chol_psd(mat_symmetrize(G));
+  Mat<S, D> JLt;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) JLt.a[i][j] = JL.a[j][i];
+  // M X = X - L G^-1 (JL)^T X
+  const Mat<S, D> MA = mat_sub(ei.A, mat_mul(L, chol_solve_mat(Lg, mat_mul(JLt, ei.A))));
+  const Mat<S, D> MC = mat_symmetrize(mat_sub(ei.C, mat_mul(L, chol_solve_mat(Lg, mat_mul(JLt, ei.C)))));
+  Vec<S, D> w = mat_vec(ei.C, ej.eta);
+#pragma unroll
+  for (int i = 0; i < D; ++i) w.a[i] = w.a[i] + ei.b.a[i];
+  const Vec<S, D> Lx = mat_vec(L, chol_solve(Lg, mat_vec(JLt, w)));
+  Vec<S, D> Mw;
+#pragma unroll
+  for (int i = 0; i < D; ++i) Mw.a[i] = w.a[i] - Lx.a[i];
+  DElem<S, D> o;
+  o.A = mat_mul(ej.A, MA);
+  const Vec<S, D> AMw = mat_vec(ej.A, Mw);
+#pragma unroll
+  for (int i = 0; i < D; ++i) o.b.a[i] = AMw.a[i] + ej.b.a[i];
+  o.C = mat_symmetrize(mat_add(mat_mul_nt(mat_mul(ej.A, MC), ej.A), ej.C));
+  // M^T x = x - JL G^-1 L^T x
+  const Vec<S, D> Jb = mat_vec(ej.J, ei.b);
+  Vec<S, D> v;
+#pragma unroll
+  for (int i = 0; i < D; ++i) v.a[i] = ej.eta.a[i] - Jb.a[i];
+  const Vec<S, D> JLx = mat_vec(JL, chol_solve(Lg, mat_t_vec(L, v)));
+  Vec<S, D> Mtv;
+#pragma unroll
+  for (int i = 0; i < D; ++i) Mtv.a[i] = v.a[i] - JLx.a[i];
+  const Vec<S, D> AtMtv = mat_t_vec(ei.A, Mtv);
+#pragma unroll
+  for (int i = 0; i < D; ++i) o.eta.a[i] = AtMtv.a[i] + ei.eta.a[i];
+  const Mat<S, D> MtJ = mat_symmetrize(mat_sub(ej.J, mat_mul(JL, chol_solve_mat(Lg, JLt))));
+  o.J = mat_symmetrize(mat_add(mat_mul_tn(ei.A, mat_mul(MtJ, ei.A)), ei.J));
+  S logdet = S(0.0);
+#pragma unroll
+  for (int i = 0; i < D; ++i) logdet = logdet + S(2.0) * log_s(Lg.a[i][i]);
+  o.ell = ei.ell + ej.ell - S(0.5) * logdet + dot(ei.b, ej.eta) - S(0.5) * dot(ei.b, Jb) +
+          S(0.5) * dot(v, mat_vec(MC, v));
+  return o;
+}
+
 }  // namespace eks
