@@ -6,9 +6,11 @@ eks/multicam_smoother.py.
     ensemble_kalman_smoother_multicam(...) -> (camera_dfs, s_finals, df_3d)
     initialize_kalman_filter_pca(good_pcs_list, ensemble_pca, n_latent)
 
+    mA_compute_maha / inflate_variance: Mahalanobis variance inflation (reference :653-764),
+        host-side like upstream but vectorised over frames
+
 Out of scope (raise NotImplementedError): the calibrated nonlinear path (`calibration` /
-`camgroup`, reference :369-407, :771-946) and Mahalanobis variance inflation (`inflate_vars`,
-reference :653-764) - SURVEY.md section 8(f).
+`camgroup`, reference :369-407, :771-946) - SURVEY.md section 8(f).
 """
 from __future__ import annotations
 
@@ -21,8 +23,9 @@ import numpy as np
 import pandas as pd
 
 from .core import ensemble, run_kalman_smoother
-from .marker_array import MarkerArray, input_dfs_to_markerArray, mA_to_stacked_array
-from .stats import compute_pca
+from .marker_array import (MarkerArray, input_dfs_to_markerArray, mA_to_stacked_array,
+                           stacked_array_to_mA)
+from .stats import compute_mahalanobis, compute_pca
 from .utils import center_predictions, format_data, make_dlc_pandas_index
 
 __all__ = ['fit_eks_mirrored_multicam', 'fit_eks_multicam', 'ensemble_kalman_smoother_multicam']
@@ -110,14 +113,17 @@ def ensemble_kalman_smoother_multicam(marker_array: MarkerArray, keypoint_names:
         raise ValueError('camera_names must be provided')
     if camgroup is not None:
         raise NotImplementedError('calibrated (nonlinear) multicam is outside the accelerated path')
-    if inflate_vars:
-        raise NotImplementedError('Mahalanobis variance inflation is not implemented yet '
-                                  '(SURVEY.md 8f rank 2); pass inflate_vars=False')
     M, V, T, K, _ = marker_array.shape
     t_all = time.perf_counter()
     ens = ensemble(marker_array, avg_mode=avg_mode, var_mode=var_mode)       # (1,V,T,K,5)
     valid_mask, centered, good_centered, means = center_predictions(ens, quantile_keep_pca)
     vars_ma = ens.slice_fields('var_x', 'var_y')
+    if inflate_vars:
+        if inflate_vars_kwargs.get('mean', None) is not None:
+            # the predictions are centred, so a supplied mean becomes zero (reference :355-357)
+            inflate_vars_kwargs['mean'] = np.zeros_like(inflate_vars_kwargs['mean'])
+        vars_ma = mA_compute_maha(centered, vars_ma, ens.slice_fields('likelihood'), n_latent,
+                                  inflate_vars_kwargs=inflate_vars_kwargs)
     pcas, good_pcs = compute_pca(valid_mask, centered, good_centered, n_components=n_latent,
                                  pca_object=pca_object)
     m0s, S0s, As, Qs, Cs = initialize_kalman_filter_pca(good_pcs, pcas, n_latent)
@@ -142,7 +148,8 @@ def ensemble_kalman_smoother_multicam(marker_array: MarkerArray, keypoint_names:
         out[:, :, 0:2] = ym[:, :, 2 * c:2 * c + 2] + mu[c][None]
         out[:, :, 2] = stats[c, :, :, 4]
         out[:, :, 3:5] = stats[c, :, :, 0:2]
-        out[:, :, 5:7] = stats[c, :, :, 2:4]
+        # x/y_ens_var carry the (possibly inflated) variances on the linear path (reference :505-508)
+        out[:, :, 5:7] = np.swapaxes(evs[:, :, 2 * c:2 * c + 2], 0, 1)
         out[:, :, 7:9] = yv[:, :, 2 * c:2 * c + 2]
         camera_dfs.append(pd.DataFrame(out.reshape(T, K * 9), columns=index))
     # latent states and their posterior variances (reference :529-544; the labels say x/y/z but
@@ -156,6 +163,51 @@ def ensemble_kalman_smoother_multicam(marker_array: MarkerArray, keypoint_names:
     logger.debug(f'[profile] ensemble_kalman_smoother_multicam total: '
                  f'{time.perf_counter() - t_all:.3f}s')
     return camera_dfs, s_finals, df_3d
+
+
+def mA_compute_maha(centered_emA_preds: MarkerArray, emA_vars: MarkerArray, emA_likes: MarkerArray,
+                    n_latent: int, inflate_vars_kwargs: dict = {}, threshold: float = 5.0,
+                    scalar: float = 10.0) -> MarkerArray:
+    """Per keypoint: inflate the ensemble variances of frames whose per-view Mahalanobis distance
+    (factor-analysis residual) exceeds `threshold`, re-fitting until nothing is inflated
+    (reference eks/multicam_smoother.py:653-721).  Like upstream, missing defaults are written
+    INTO `inflate_vars_kwargs` (likelihood_threshold 0.9, v_quantile_threshold 50.0)."""
+    _, V, _, K, _ = centered_emA_preds.shape
+    inflate_vars_kwargs.setdefault('likelihood_threshold', 0.9)
+    inflate_vars_kwargs.setdefault('v_quantile_threshold', 50.0)
+    per_kp = []
+    for k in range(K):
+        preds = mA_to_stacked_array(centered_emA_preds, k)
+        cur = mA_to_stacked_array(emA_vars, k)
+        likes = mA_to_stacked_array(emA_likes, k)
+        logger.info(f'inflating keypoint: {k}')
+        changed = True
+        while changed:
+            kw = dict(inflate_vars_kwargs)
+            if kw.get('likelihoods', None) is not None:
+                kw['likelihoods'] = likes
+            res = compute_mahalanobis(preds, cur, n_latent=n_latent, **kw)
+            cur, changed = inflate_variance(cur, res['mahalanobis'], threshold, scalar)
+        per_kp.append(stacked_array_to_mA(cur, V, data_fields=['var_x', 'var_y']))
+    return MarkerArray.stack(per_kp, 'keypoints')
+
+
+def inflate_variance(v: np.ndarray, maha_dict: dict, threshold: float = 5.0,
+                     scalar: float = 10.0) -> tuple:
+    """Multiply by `scalar` the variances of every (frame, view) whose Mahalanobis distance exceeds
+    `threshold`; with exactly two views the whole frame is inflated if either view is
+    (reference eks/multicam_smoother.py:724-764).  Returns (new variances, anything inflated?)."""
+    assert len(maha_dict) >= 2, 'must have >=2 views to inflate variance'
+    n_views = len(maha_dict)
+    hit = np.zeros((v.shape[0], n_views), dtype=bool)
+    for view, dist in maha_dict.items():
+        hit[:, view] = dist[:, 0] > threshold
+    mask = np.repeat(hit, 2, axis=1)
+    if n_views == 2:
+        mask |= mask.any(axis=1, keepdims=True)
+    out = v.copy()
+    out[mask] *= scalar
+    return out, bool(mask.any())
 
 
 def initialize_kalman_filter_pca(good_pcs_list, ensemble_pca, n_latent: int) -> tuple:

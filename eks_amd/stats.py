@@ -1,11 +1,13 @@
 """Host-side statistics around the multicam smoother (reference eks/stats.py).
 
 compute_pca: one small PCA per keypoint on the low-variance frames; stays on the host (it is
-set-up for the observation matrices C, not part of the Kalman path)."""
+set-up for the observation matrices C, not part of the Kalman path).
+compute_mahalanobis: factor-analysis reconstruction residuals per view, used by the variance
+inflation that precedes the multicam smoother (vectorised over frames; the reference loops)."""
 from __future__ import annotations
 
 import numpy as np
-from sklearn.decomposition import PCA
+from sklearn.decomposition import PCA, FactorAnalysis
 
 from .marker_array import MarkerArray, mA_to_stacked_array
 
@@ -26,3 +28,49 @@ def compute_pca(valid_frames_mask: np.ndarray, emA_centered_preds: MarkerArray,
         models.append(model)
         good_pcs.append(model.transform(all_frames)[np.flatnonzero(valid_frames_mask[:, k])])
     return models, good_pcs
+
+
+def compute_mahalanobis(x: np.ndarray, v: np.ndarray, n_latent: int = 3,
+                        v_quantile_threshold: float | None = 50.0,
+                        likelihoods: np.ndarray | None = None,
+                        likelihood_threshold: float | None = 0.9, epsilon: float | None = 1e-6,
+                        loading_matrix: np.ndarray | None = None,
+                        mean: np.ndarray | None = None) -> dict:
+    """Mahalanobis distance of each view's 2-D residual under a linear latent-variable model
+    x = W z + mu + noise(v) (reference eks/stats.py:67-157).
+
+    W, mu come from sklearn FactorAnalysis fitted on the rows whose largest variance is below the
+    `v_quantile_threshold` percentile (and whose smallest likelihood is >= `likelihood_threshold`
+    when likelihoods are given), unless `loading_matrix` / `mean` are supplied.  Returns the same
+    dict as the reference: 'mahalanobis' {view: (N,1)}, 'posterior_variance' {view: (N,2,2)},
+    'reconstructed' (N,2C)."""
+    x = np.asarray(x)
+    v = np.asarray(v)
+    if loading_matrix is None or mean is None:
+        rows = np.ones(x.shape[0], dtype=bool)
+        if likelihoods is not None and likelihood_threshold is not None:
+            rows &= np.min(likelihoods, axis=1) >= likelihood_threshold
+        if v_quantile_threshold is not None:
+            worst = v.max(axis=1)
+            rows &= worst < np.percentile(worst, v_quantile_threshold)
+        fa = FactorAnalysis(n_components=n_latent).fit(x[rows])
+        W, mu = fa.components_.T, fa.mean_
+    else:
+        W, mu = np.asarray(loading_matrix), np.asarray(mean)
+    prec = 1.0 / (v + epsilon)                                        # (N, 2C)
+    WtP = W.T[None, :, :] * prec[:, None, :]                          # (N, L, 2C) = W' diag(prec)
+    B = np.linalg.inv(WtP @ W)                                        # (N, L, L)
+    z = (B @ (WtP @ (x - mu)[:, :, None]))[:, :, 0]                   # (N, L)
+    xhat = z @ W.T + mu
+    diff = x - xhat
+    n_views = x.shape[1] // 2
+    Q, M = {}, {}
+    for c in range(n_views):
+        Wc = W[2 * c:2 * c + 2]                                       # (2, L)
+        Qc = Wc[None] @ B @ Wc.T[None]                                # (N, 2, 2)
+        Qc[:, 0, 0] += v[:, 2 * c]
+        Qc[:, 1, 1] += v[:, 2 * c + 1]
+        dc = diff[:, 2 * c:2 * c + 2]
+        M[c] = np.einsum('ni,nij,nj->n', dc, np.linalg.inv(Qc), dc)[:, None]
+        Q[c] = Qc
+    return {'mahalanobis': M, 'posterior_variance': Q, 'reconstructed': xhat}

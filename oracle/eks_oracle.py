@@ -670,7 +670,7 @@ def stacked_views(a, k):
 
 
 def multicam_arrays(marker, quantile_keep_pca=50.0, n_latent=3, avg_mode='median',
-                    var_mode='confidence_weighted_var', pca_fit=None, ens=None):
+                    var_mode='confidence_weighted_var', pca_fit=None, ens=None, inflate_vars=False):
     """Linear multicam inputs as eks/multicam_smoother.py:342-348, :412-430 and :554-597 build
     them (no variance inflation).  ``pca_fit(X, n) -> (components (n,F), mean (F,))`` defaults to
     an SVD PCA with sklearn's sign convention left to the caller.  `ens` (1,V,T,K,5) overrides the
@@ -685,6 +685,9 @@ def multicam_arrays(marker, quantile_keep_pca=50.0, n_latent=3, avg_mode='median
             # sklearn svd_flip(u_based_decision=False): largest |entry| of each row of Vt positive
             sgn = np.sign(Vt[np.arange(Vt.shape[0]), np.argmax(np.abs(Vt), axis=1)])
             return (Vt * sgn[:, None])[:n], mu
+    vars_used = ens[..., 2:4]
+    if inflate_vars:
+        vars_used = inflate_variances(centered, vars_used, n_latent)
     ys, evs, Cs, S0s, Qs = [], [], [], [], []
     for k in range(K):
         Xg = stacked_views(good_c, k)
@@ -699,13 +702,57 @@ def multicam_arrays(marker, quantile_keep_pca=50.0, n_latent=3, avg_mode='median
         Qs.append(cov / mx if mx > 0 else cov)
         Cs.append(comp.T)
         ys.append(Xa)
-        evs.append(stacked_views(ens[..., 2:4], k))
+        evs.append(stacked_views(vars_used, k))
     ys = np.stack(ys)
     evs = np.stack(evs)                                          # (K,T,2V)
     eye = np.tile(np.eye(n_latent), (K, 1, 1))
     return dict(ys=ys, m0s=np.zeros((K, n_latent)), S0s=np.stack(S0s), As=eye,
                 Cs=np.stack(Cs), Qs=np.stack(Qs), ensemble_vars=np.swapaxes(evs, 0, 1),
                 means=means, ens=ens, mask=mask, good_idx=good_idx)
+
+
+def mahalanobis_loop(x, v, n_latent=3, v_quantile_threshold=50.0, epsilon=1e-6):
+    """Loop-style restatement of eks/stats.py:67-157 (default call: no likelihood filter, no
+    supplied loading matrix).  Returns {view: (N,) Mahalanobis distance}."""
+    from sklearn.decomposition import FactorAnalysis
+    worst = v.max(axis=1)
+    rows = worst < np.percentile(worst, v_quantile_threshold)
+    fa = FactorAnalysis(n_components=n_latent).fit(x[rows])
+    W, mu = fa.components_.T, fa.mean_
+    N, n_views = x.shape[0], x.shape[1] // 2
+    out = {c: np.zeros(N) for c in range(n_views)}
+    for i in range(N):
+        Dinv = np.diag(1.0 / (v[i] + epsilon))
+        B = np.linalg.inv(W.T @ Dinv @ W)
+        z = B @ W.T @ Dinv @ (x[i] - mu)
+        diff = x[i] - (W @ z + mu)
+        for c in range(n_views):
+            sl = slice(2 * c, 2 * c + 2)
+            Qc = np.diag(v[i, sl]) + W[sl] @ B @ W[sl].T
+            out[c][i] = diff[sl] @ np.linalg.inv(Qc) @ diff[sl]
+    return out
+
+
+def inflate_variances(centered, vars_, n_latent=3, threshold=5.0, scalar=10.0):
+    """eks/multicam_smoother.py:653-764 with the default kwargs: per keypoint, inflate x10 the
+    variances of (frame, view) pairs with Mahalanobis distance > 5 (whole frame when there are two
+    views), refit, repeat until nothing changes.  centered, vars_ (1,V,T,K,2) -> inflated vars."""
+    V, K = centered.shape[1], centered.shape[3]
+    out = np.array(vars_, dtype=np.float64, copy=True)
+    for k in range(K):
+        x = stacked_views(centered, k)
+        cur = stacked_views(vars_, k).astype(np.float64)
+        while True:
+            M = mahalanobis_loop(x, cur, n_latent)
+            hit = np.stack([M[c] > threshold for c in range(V)], axis=1)
+            mask = np.repeat(hit, 2, axis=1)
+            if V == 2:
+                mask = mask | mask.any(axis=1, keepdims=True)
+            if not mask.any():
+                break
+            cur = np.where(mask, cur * scalar, cur)
+        out[0, :, :, k, :] = np.transpose(cur.reshape(cur.shape[0], V, 2), (1, 0, 2))
+    return out
 
 
 def multicam_outputs(arrs, ms, Vs):
@@ -727,8 +774,8 @@ def multicam_outputs(arrs, ms, Vs):
         out[:, :, 2] = ens[0, c, :, :, 4]
         out[:, :, 3] = ens[0, c, :, :, 0]
         out[:, :, 4] = ens[0, c, :, :, 1]
-        out[:, :, 5] = ens[0, c, :, :, 2]
-        out[:, :, 6] = ens[0, c, :, :, 3]
+        out[:, :, 5] = ev[:, :, xi].T           # (inflated) ensemble variances, :505-508
+        out[:, :, 6] = ev[:, :, yi].T
         out[:, :, 7] = (yv[:, :, xi, xi] + ev[:, :, xi]).T
         out[:, :, 8] = (yv[:, :, yi, yi] + ev[:, :, yi]).T
         cams.append(out.reshape(T, K * 9))

@@ -193,7 +193,35 @@ def test_multicam_adam_and_errors(mouse):
     with pytest.raises(ValueError):
         ensemble_kalman_smoother_multicam(ma, ['p1', 'p2'], [])
     with pytest.raises(NotImplementedError):
-        ensemble_kalman_smoother_multicam(ma, ['p1', 'p2'], ['top', 'bot'], inflate_vars=True)
+        ensemble_kalman_smoother_multicam(ma, ['p1', 'p2'], ['top', 'bot'], camgroup=object())
+
+
+def test_mirrored_multicam_upstream_integration_config(mouse, tmp_path):
+    """The reference's integration configuration (tests/integration/test_mirrored_multicam.py:19-30):
+    two paws, camera_names top/bot, quantile_keep_pca=95, inflate_vars=True, smooth_param=[10.0],
+    from CSV files with '{bodypart}_{camera}_{coord}' columns, through fit_eks_mirrored_multicam."""
+    from eks_amd.multicam_smoother import fit_eks_mirrored_multicam
+    paws, cams = list(mouse['keypoints']), list(mouse['cameras'])
+    names = [f'{p}_{c}' for c in cams for p in paws]
+    cols = pd.MultiIndex.from_product([[str(mouse['scorer'])], names, ['x', 'y', 'likelihood']],
+                                      names=['scorer', 'bodyparts', 'coords'])
+    for m in range(5):
+        block = np.concatenate([mouse['markers'][m, v].reshape(2000, -1) for v in range(2)], axis=1)
+        pd.DataFrame(block.astype(np.float64), columns=cols).to_csv(tmp_path / f'vid.rng={m}.csv')
+    save = tmp_path / 'out' / 'eks_mirrored.csv'
+    df, s, input_dfs, bps = fit_eks_mirrored_multicam(
+        str(tmp_path), str(save), bodypart_list=['paw1LH', 'paw2LF'], camera_names=['top', 'bot'],
+        smooth_param=[10.0], quantile_keep_pca=95, inflate_vars=True)
+    assert save.exists() and df.shape == (2000, 2 * 2 * 9) and bps == ['paw1LH', 'paw2LF']
+    assert list(df.columns.get_level_values('bodyparts')[::9]) == ['paw1LH_top', 'paw2LF_top',
+                                                                   'paw1LH_bot', 'paw2LF_bot']
+    np.testing.assert_array_equal(s, 10.0)
+    for c in range(2):
+        _against_golden(df.values[:, c * 18:(c + 1) * 18], mouse, f'infl_s10_cam{c}')
+    # default bodypart_list: prefixes before the first underscore, in file order
+    _, _, _, bps2 = fit_eks_mirrored_multicam(str(tmp_path), str(tmp_path / 'o2' / 'x.csv'),
+                                              camera_names=['top', 'bot'], smooth_param=1.0)
+    assert bps2 == paws
 
 
 def test_ensemble_operator_properties():

@@ -184,3 +184,73 @@ def test_compute_initial_guesses_and_constant_R():
         compute_initial_guesses(np.ones((1, 2)))
     Rt = utils.build_R_from_vars(np.array([[1.0, 5e-5], [3.0, 2e-5], [2.0, 9e-5]]))
     np.testing.assert_allclose(np.diag(constant_R_from_timevarying(Rt)), [2.0, 1e-4])
+
+
+def test_inflate_variance_semantics():
+    from eks_amd.multicam_smoother import inflate_variance
+    T = 10
+    v = np.ones((T, 6))
+    calm = {c: np.ones((T, 1)) for c in range(3)}
+    out, changed = inflate_variance(v=v, maha_dict=calm, threshold=5, scalar=2)
+    assert not changed and np.array_equal(out, v) and out is not v
+    out, changed = inflate_variance(v=v, maha_dict=calm, threshold=0.5, scalar=2)
+    assert changed and np.array_equal(out, 2 * v)
+    mixed = {0: np.ones((T, 1)), 1: 2 * np.ones((T, 1)), 2: 4 * np.ones((T, 1))}
+    out, changed = inflate_variance(v=v, maha_dict=mixed, threshold=1.5, scalar=3)
+    assert changed and np.array_equal(out[:, :2], v[:, :2]) and np.array_equal(out[:, 2:], 3 * v[:, 2:])
+    # exactly two views: one offending view inflates the whole frame
+    out, changed = inflate_variance(v=np.ones((T, 4)), maha_dict={0: np.ones((T, 1)), 1: 2 * np.ones((T, 1))},
+                                    threshold=1.5, scalar=3)
+    assert changed and np.array_equal(out, 3 * np.ones((T, 4)))
+    with pytest.raises(AssertionError):
+        inflate_variance(v=np.ones((T, 2)), maha_dict={0: np.ones((T, 1))})
+
+
+def test_compute_mahalanobis_properties_and_oracle():
+    from eks_amd.stats import compute_mahalanobis
+    rng = np.random.default_rng(0)
+    n_t, n_cams, L = 120, 4, 3
+    W = rng.standard_normal((2 * n_cams, L))
+    x = rng.standard_normal((n_t, L)) @ W.T
+    v = np.ones((n_t, 2 * n_cams))
+    out = compute_mahalanobis(x, v, n_latent=L, v_quantile_threshold=None)
+    assert set(out) == {'mahalanobis', 'posterior_variance', 'reconstructed'}
+    assert len(out['mahalanobis']) == n_cams and out['mahalanobis'][0].shape == (n_t, 1)
+    assert out['posterior_variance'][2].shape == (n_t, 2, 2)
+    np.testing.assert_allclose(out['reconstructed'], x, atol=1e-6)          # exact-rank data is recovered
+    assert not np.allclose(compute_mahalanobis(x, v, n_latent=1, v_quantile_threshold=None)['reconstructed'], x)
+    # larger observation variance: distance shrinks, predictive variance grows, by the same factor
+    x2, v2 = np.vstack([x, x]), np.vstack([v, 10 * v])
+    o2 = compute_mahalanobis(x2, v2, n_latent=L - 1)
+    assert o2['mahalanobis'][0][0, 0] == pytest.approx(10 * o2['mahalanobis'][0][n_t, 0], rel=1e-4)
+    np.testing.assert_allclose(10 * o2['posterior_variance'][0][0], o2['posterior_variance'][0][n_t], rtol=1e-4)
+    # supplied loading matrix / mean skip the fit; likelihood filter is accepted
+    compute_mahalanobis(x, v, n_latent=L, loading_matrix=rng.standard_normal((2 * n_cams, L)),
+                        mean=rng.standard_normal(2 * n_cams))
+    compute_mahalanobis(x, v, n_latent=L, likelihoods=rng.random((n_t, n_cams)), likelihood_threshold=0.1,
+                        v_quantile_threshold=None)
+    # vectorised implementation == loop-style oracle restatement
+    xn = x + 0.3 * rng.standard_normal(x.shape)
+    vn = rng.gamma(2.0, 0.3, x.shape) + 0.01
+    got = compute_mahalanobis(xn, vn, n_latent=2)
+    ref = orc.mahalanobis_loop(xn, vn, n_latent=2)
+    for c in range(n_cams):
+        np.testing.assert_allclose(got['mahalanobis'][c][:, 0], ref[c], rtol=1e-10)
+
+
+def test_variance_inflation_pipeline_matches_oracle(golden_dir):
+    from eks_amd.multicam_smoother import mA_compute_maha
+    g = np.load(os.path.join(golden_dir, 'mirror_mouse_multicam.npz'))
+    ens = orc.ensemble(g['markers'][:, :, :, :2])
+    ma = MarkerArray(ens, data_fields=['x', 'y', 'var_x', 'var_y', 'likelihood'])
+    _, cen, _, _ = utils.center_predictions(ma, 95.0)
+    kw = {}
+    infl = mA_compute_maha(cen, ma.slice_fields('var_x', 'var_y'), ma.slice_fields('likelihood'), 3,
+                           inflate_vars_kwargs=kw)
+    assert kw == {'likelihood_threshold': 0.9, 'v_quantile_threshold': 50.0}    # defaults written back
+    assert infl.shape == (1, 2, 2000, 2, 2) and infl.data_fields == ['var_x', 'var_y']
+    got = np.stack([mA_to_stacked_array(infl, k) for k in range(2)])                # (K,T,2V)
+    np.testing.assert_allclose(got, g['infl_vars'].astype(np.float64), rtol=1e-6)
+    raw = np.stack([mA_to_stacked_array(ma.slice_fields('var_x', 'var_y'), k) for k in range(2)])
+    ratio = got / raw
+    assert np.all(np.isclose(ratio, 1) | (ratio > 9.99)) and (ratio > 9.99).any()   # only x10^n inflations

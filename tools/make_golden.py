@@ -122,6 +122,17 @@ def main():
     for c, co in enumerate(cams_out):
         for k, v in pack(co).items():
             out[f'adam_cam{c}_{k}'] = v
+    # the configuration of the reference's integration test (tests/integration/
+    # test_mirrored_multicam.py:19-30): two paws, quantile_keep_pca=95, inflate_vars=True, s=10
+    arrs = orc.multicam_arrays(mk[:, :, :, :2], quantile_keep_pca=95.0, n_latent=3, pca_fit=sk_pca,
+                               inflate_vars=True)
+    out['infl_vars'] = np.swapaxes(arrs['ensemble_vars'], 0, 1).astype(np.float32)      # (K,T,2V)
+    s, ms, Vs, _ = orc.run_kalman_smoother(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'],
+                                           arrs['Qs'], arrs['ensemble_vars'], smooth_param=[10.0])
+    cams_out, lat = orc.multicam_outputs(arrs, ms, Vs)
+    for c, co in enumerate(cams_out):
+        for k, v in pack(co).items():
+            out[f'infl_s10_cam{c}_{k}'] = v
     np.savez_compressed(os.path.join(OUT, 'mirror_mouse_multicam.npz'), **out)
     print('mirror-mouse: s_adam', s_a, 'iters', out['adam_iters'])
 
