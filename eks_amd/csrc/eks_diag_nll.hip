@@ -218,6 +218,10 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
       wpb = w;
       break;
     }
+  {
+    const int ew = env_int("EKS_NLL_WPB", 0);
+    if (ew == 1 || ew == 2 || ew == 4 || ew == 8) wpb = ew;
+  }
   const dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
   const bool unit = d.flags & EKS_FLAG_UNIT_AC;
 #define EKS_NLL_LAUNCH(RT, NCL)                                                                  \

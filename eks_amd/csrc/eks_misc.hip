@@ -9,154 +9,15 @@
 namespace eks {
 
 // ==========================================================================================
-// constant R: rconst[n] = max(nanmedian_t max(var[t][n], 1e-12), min_var)
-// General path: exact selection by MSB-first radix (4 x 8 bits on the float bit pattern; positive
-// floats order like their bit patterns), lanes = chains so every row read is coalesced, per-block
-// histograms in LDS (256 bins x 64 chains), one more sweep for the upper middle element of even
-// counts: five full passes.  It serves only the chains the two-pass bracket path (below) flags.
+// constant R: rconst[n] = max(nanmedian_t max(var[t][n], 1e-12), min_var)     (eks/core.py:702-709)
+// Exact selection on the float bit patterns (positive floats order like their bits).
 // ==========================================================================================
-struct MedianWs {
-  uint32_t* hist;    // [4][256][N]  (bin-major: a wave's flush / scan touches consecutive chains)
-  uint32_t* prefix;  // [N] bits fixed so far
-  uint32_t* rank;    // [N] rank of the lower middle element within the current prefix bucket
-  uint32_t* count;   // [N] number of non-NaN frames
-  uint32_t* less_eq; // [N][2]: #keys < key_lo, #keys == key_lo
-  uint32_t* next;    // [N] smallest key > key_lo (0xFFFFFFFF if none)
-  const uint32_t* need;      // [N] chains this path must serve (bracket path fell back)
-  const uint32_t* any_need;  // [1] 0 -> nothing to do
-};
+constexpr int kMedWaves = 16;  // waves per block of the two full passes
 
 __device__ __forceinline__ uint32_t var_key(float v, bool& valid) {
   valid = !(v != v);
   const float c = v > 1e-12f ? v : 1e-12f;  // clip(var, 1e-12, inf), eks/utils.py:373
   return __float_as_uint(c);
-}
-
-constexpr int kMedWaves = 16;  // waves per block (2 blocks of 64 KiB LDS fill a CU's 32 wave slots)
-
-template <int PASS>
-__global__ __launch_bounds__(64 * kMedWaves) void median_hist_kernel(int T, int N, int rows_per_block,
-                                                         const float* __restrict__ var, MedianWs W) {
-  __shared__ uint32_t h[256][64];
-  if (*W.any_need == 0u) return;
-  for (int i = threadIdx.x; i < 256 * 64; i += 64 * kMedWaves) (&h[0][0])[i] = 0u;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ntile = (N + 63) / 64;
-  const int tile = blockIdx.x % ntile, slab = blockIdx.x / ntile;
-  const int n = tile * 64 + lane;
-  const int t_begin = slab * rows_per_block;
-  const int t_end = min(T, t_begin + rows_per_block);
-  const bool mine = n < N && W.need[n] != 0u;
-  if (mine) {
-    const uint32_t pref = PASS > 0 ? W.prefix[n] : 0u;
-    constexpr int shift = 24 - 8 * PASS;
-    // 8 rows in flight per lane: the loop is otherwise bound by one HBM round trip per row
-    for (int t = t_begin + wave; t < t_end; t += 8 * kMedWaves) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int tt = t + kMedWaves * u;
-        v[u] = tt < t_end ? var[(size_t)tt * N + n] : __uint_as_float(0x7FC00000u);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        bool valid;
-        const uint32_t key = var_key(v[u], valid);
-        if (!valid) continue;
-        if (PASS > 0 && (key >> (shift + 8)) != pref) continue;
-        atomicAdd(&h[(key >> shift) & 255u][lane], 1u);
-      }
-    }
-  }
-  __syncthreads();
-  if (mine) {
-    uint32_t* g = W.hist + (size_t)PASS * 256 * N + n;
-    for (int b = wave; b < 256; b += kMedWaves) {
-      const uint32_t c = h[b][lane];
-      if (c) atomicAdd(&g[(size_t)b * N], c);
-    }
-  }
-}
-
-template <int PASS>
-__global__ void median_select_kernel(int N, MedianWs W) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (*W.any_need == 0u || n >= N || W.need[n] == 0u) return;
-  const uint32_t* g = W.hist + (size_t)PASS * 256 * N + n;
-  uint32_t rank;
-  if (PASS == 0) {
-    uint32_t cnt = 0;
-    for (int b = 0; b < 256; ++b) cnt += g[(size_t)b * N];
-    W.count[n] = cnt;
-    W.less_eq[2 * n] = 0;
-    rank = cnt ? (cnt - 1) / 2 : 0;
-  } else {
-    rank = W.rank[n];
-  }
-  uint32_t cum = 0;
-  int bin = 255;
-  for (int b = 0; b < 256; ++b) {
-    const uint32_t c = g[(size_t)b * N];
-    if (cum + c > rank) {
-      bin = b;
-      break;
-    }
-    cum += c;
-  }
-  W.less_eq[2 * n] += cum;
-  W.rank[n] = rank - cum;
-  W.prefix[n] = ((PASS > 0 ? W.prefix[n] : 0u) << 8) | (uint32_t)bin;
-  if (PASS == 3) {
-    W.less_eq[2 * n + 1] = g[(size_t)bin * N];
-    W.next[n] = 0xFFFFFFFFu;
-  }
-}
-
-__global__ __launch_bounds__(64 * kMedWaves) void median_next_kernel(int T, int N, int rows_per_block,
-                                                         const float* __restrict__ var, MedianWs W) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ntile = (N + 63) / 64;
-  const int tile = blockIdx.x % ntile, slab = blockIdx.x / ntile;
-  const int n = tile * 64 + lane;
-  if (*W.any_need == 0u || n >= N || W.need[n] == 0u) return;
-  const int t_begin = slab * rows_per_block;
-  const int t_end = min(T, t_begin + rows_per_block);
-  const uint32_t key_lo = W.prefix[n];
-  uint32_t best = 0xFFFFFFFFu;
-  for (int t = t_begin + wave; t < t_end; t += 8 * kMedWaves) {
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int tt = t + kMedWaves * u;
-      v[u] = tt < t_end ? var[(size_t)tt * N + n] : __uint_as_float(0x7FC00000u);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      bool valid;
-      const uint32_t key = var_key(v[u], valid);
-      if (valid && key > key_lo && key < best) best = key;
-    }
-  }
-  if (best != 0xFFFFFFFFu) atomicMin(&W.next[n], best);
-}
-
-__global__ void median_final_kernel(int N, double min_var, MedianWs W, double* __restrict__ rconst) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (*W.any_need == 0u || n >= N || W.need[n] == 0u) return;
-  const uint32_t cnt = W.count[n];
-  double med;
-  if (cnt == 0) {
-    med = nan("");  // np.nanmedian of an all-NaN slice
-  } else {
-    const double lo = (double)__uint_as_float(W.prefix[n]);
-    const uint32_t rank_hi = cnt / 2;  // == rank_lo for odd counts
-    const uint32_t less = W.less_eq[2 * n], eq = W.less_eq[2 * n + 1];
-    const double hi = (rank_hi < less + eq) ? lo : (double)__uint_as_float(W.next[n]);
-    med = 0.5 * lo + 0.5 * hi;
-  }
-  // np.clip(nan, min, inf) stays nan
-  rconst[n] = (med != med) ? med : (med > min_var ? med : min_var);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -169,7 +30,9 @@ __global__ void median_final_kernel(int N, double min_var, MedianWs W, double* _
 //   B3 collect  : full pass; frames inside [lo2, hi2] are appended to a per-chain list.
 //   B4 finish   : exact selection of the middle ranks inside the list (rank by counting in LDS).
 // A chain whose bracket misses the median, or whose bin holds more than kMedCap frames (heavy
-// duplicates), is flagged and served by the radix kernels above, which then run masked.
+// duplicates), is flagged and served by median_column_kernel: one block per flagged chain, an
+// MSB-first radix select (4 x 8 bits + one sweep for the upper middle of even counts) over the
+// chain's column - five strided sweeps, slow but exact, and a single (normally empty) launch.
 // Short sequences (T <= kMedCap) are selected directly from the whole column.
 // ------------------------------------------------------------------------------------------
 constexpr int kMedCap = 1024;
@@ -413,11 +276,83 @@ __global__ __launch_bounds__(256) void bracket_finish_kernel(int N, double min_v
   }
 }
 
+// exact median of one chain's column by radix select inside one block (fallback path)
+__global__ __launch_bounds__(256) void median_column_kernel(int T, int N, const float* __restrict__ var,
+                                                           double min_var, BracketWs B,
+                                                           double* __restrict__ rconst) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sh_prefix, sh_rank, sh_cnt, sh_less, sh_eq, sh_next;
+  const int n = blockIdx.x;
+  if (*B.any_fallback == 0u || B.fallback[n] == 0u) return;
+  uint32_t prefix = 0, rank = 0, less = 0;
+  for (int pass = 0; pass < 4; ++pass) {
+    hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const int shift = 24 - 8 * pass;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+      bool valid;
+      const uint32_t key = var_key(var[(size_t)t * N + n], valid);
+      if (!valid) continue;
+      if (pass > 0 && (key >> (shift + 8)) != prefix) continue;
+      atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (pass == 0) {
+        uint32_t cnt = 0;
+        for (int b = 0; b < 256; ++b) cnt += hist[b];
+        sh_cnt = cnt;
+        rank = cnt ? (cnt - 1) / 2 : 0;
+      }
+      uint32_t cum = 0;
+      int bin = 255;
+      for (int b = 0; b < 256; ++b) {
+        if (cum + hist[b] > rank) {
+          bin = b;
+          break;
+        }
+        cum += hist[b];
+      }
+      less += cum;
+      rank -= cum;
+      prefix = (prefix << 8) | (uint32_t)bin;
+      sh_prefix = prefix;
+      sh_rank = rank;
+      sh_less = less;
+      sh_eq = hist[bin];
+      sh_next = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    prefix = sh_prefix;
+    rank = sh_rank;
+    less = sh_less;
+  }
+  const uint32_t cnt = sh_cnt, eq = sh_eq, key_lo = prefix;
+  uint32_t best = 0xFFFFFFFFu;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    bool valid;
+    const uint32_t key = var_key(var[(size_t)t * N + n], valid);
+    if (valid && key > key_lo && key < best) best = key;
+  }
+  if (best != 0xFFFFFFFFu) atomicMin(&sh_next, best);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double med;
+    if (cnt == 0) {
+      med = nan("");                                    // np.nanmedian of an all-NaN slice
+    } else {
+      const double lo = (double)__uint_as_float(key_lo);
+      const double hi = (cnt / 2 < less + eq) ? lo : (double)__uint_as_float(sh_next);
+      med = 0.5 * lo + 0.5 * hi;
+    }
+    rconst[n] = (med != med) ? med : (med > min_var ? med : min_var);   // clip(nan) stays nan
+  }
+}
+
 static inline size_t arr_bytes(size_t n) { return align_up(n * 4, 256); }
 
 size_t const_r_workspace_bytes(int N) {
-  return align_up((size_t)4 * N * 256 * 4, 256) + 6 * align_up((size_t)N * 2 * 4, 256)   // radix path
-         + 10 * arr_bytes(N) + arr_bytes((size_t)256 * N) + arr_bytes((size_t)N * kMedCap) + 256;
+  return 10 * arr_bytes(N) + arr_bytes((size_t)256 * N) + arr_bytes((size_t)N * kMedCap) + 256;
 }
 
 int const_r(int T, int N, const float* var, double min_var, double* rconst, void* ws,
@@ -429,15 +364,6 @@ int const_r(int T, int N, const float* var, double min_var, double* rconst, void
     return hip_status(hipGetLastError());
   }
   char* p = static_cast<char*>(ws);
-  MedianWs W;
-  const size_t hb = align_up((size_t)4 * N * 256 * 4, 256), sb = align_up((size_t)N * 2 * 4, 256);
-  W.hist = reinterpret_cast<uint32_t*>(p);
-  W.prefix = reinterpret_cast<uint32_t*>(p + hb);
-  W.rank = reinterpret_cast<uint32_t*>(p + hb + sb);
-  W.count = reinterpret_cast<uint32_t*>(p + hb + 2 * sb);
-  W.less_eq = reinterpret_cast<uint32_t*>(p + hb + 3 * sb);
-  W.next = reinterpret_cast<uint32_t*>(p + hb + 4 * sb);
-  p += hb + 6 * sb;
   BracketWs B;
   uint32_t** arrs[10] = {&B.lo, &B.hi, &B.less, &B.valid, &B.lo2, &B.hi2, &B.less2, &B.cnt2,
                          &B.fallback, &B.any_fallback};
@@ -448,36 +374,23 @@ int const_r(int T, int N, const float* var, double min_var, double* rconst, void
   B.hist = reinterpret_cast<uint32_t*>(p);
   p += arr_bytes((size_t)256 * N);
   B.list = reinterpret_cast<uint32_t*>(p);
-  W.need = B.fallback;
-  W.any_need = B.any_fallback;
 
-  hipError_t e = hipMemsetAsync(W.hist, 0, hb, st);
-  if (e == hipSuccess) e = hipMemsetAsync(B.hist, 0, arr_bytes((size_t)256 * N), st);
+  hipError_t e = hipMemsetAsync(B.hist, 0, arr_bytes((size_t)256 * N), st);
   if (e == hipSuccess) e = hipMemsetAsync(B.any_fallback, 0, 4, st);
   if (e != hipSuccess) return hip_status(e);
   const int ntile = (N + 63) / 64;
-  // enough blocks to fill the chip, each long enough to amortise its LDS flush
-  int rows = (int)(((long)T * ntile + 255) / 256);     // one 16-wave block per CU
+  // one 16-wave block per CU, each long enough to amortise its LDS flush
+  int rows = (int)(((long)T * ntile + 255) / 256);
   if (rows < kMedFlight * kMedWaves) rows = kMedFlight * kMedWaves;
   rows = (rows + kMedWaves - 1) / kMedWaves * kMedWaves;
   const int nslab = (T + rows - 1) / rows;
-  const dim3 grid(ntile * nslab), big(64 * kMedWaves), sel((N + 255) / 256);
+  const dim3 grid(ntile * nslab), big(64 * kMedWaves);
   hipLaunchKernelGGL(bracket_sample_kernel, dim3(N), dim3(kMedSamples), 0, st, T, N, var, B);
   hipLaunchKernelGGL(bracket_hist_kernel, grid, big, 0, st, T, N, rows, var, B);
   hipLaunchKernelGGL(bracket_narrow_kernel, dim3((N + 3) / 4), dim3(256), 0, st, N, B);
   hipLaunchKernelGGL(bracket_collect_kernel, grid, big, 0, st, T, N, rows, var, B);
   hipLaunchKernelGGL(bracket_finish_kernel, dim3(N), dim3(256), 0, st, N, min_var, B, rconst);
-  // masked exact radix path for the flagged chains (all kernels return at once if none is)
-  hipLaunchKernelGGL(median_hist_kernel<0>, grid, big, 0, st, T, N, rows, var, W);
-  hipLaunchKernelGGL(median_select_kernel<0>, sel, dim3(256), 0, st, N, W);
-  hipLaunchKernelGGL(median_hist_kernel<1>, grid, big, 0, st, T, N, rows, var, W);
-  hipLaunchKernelGGL(median_select_kernel<1>, sel, dim3(256), 0, st, N, W);
-  hipLaunchKernelGGL(median_hist_kernel<2>, grid, big, 0, st, T, N, rows, var, W);
-  hipLaunchKernelGGL(median_select_kernel<2>, sel, dim3(256), 0, st, N, W);
-  hipLaunchKernelGGL(median_hist_kernel<3>, grid, big, 0, st, T, N, rows, var, W);
-  hipLaunchKernelGGL(median_select_kernel<3>, sel, dim3(256), 0, st, N, W);
-  hipLaunchKernelGGL(median_next_kernel, grid, big, 0, st, T, N, rows, var, W);
-  hipLaunchKernelGGL(median_final_kernel, sel, dim3(256), 0, st, N, min_var, W, rconst);
+  hipLaunchKernelGGL(median_column_kernel, dim3(N), dim3(256), 0, st, T, N, var, min_var, B, rconst);
   return hip_status(hipGetLastError());
 }
 
