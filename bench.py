@@ -36,6 +36,7 @@ WORKLOADS = {
     'c2': (10_000, 64, 0),       # configs[1]
     'c5': (50_000, 128 * 32, 0), # configs[4], one GPU's share: 128 sessions x 32 keypoints batched
     'c4': (50_000, 4, 0),        # configs[3]: mirrored multicam, 2 views x 4 paws, D = 3, O = 4 (dense path)
+    'pupil': (100_000, 1, 0),    # IBL pupil AR(1) session, one optimiser iteration per step
 }
 SMOOTH_BYTES_PER_UNIT = 40       # y 8 + var 8 in, ms 8 + Vs 16 out  
 NLL_BYTES_PER_UNIT = 8           # y read once regardless of candidate count
@@ -158,6 +159,71 @@ def bench_dense(args, T, K, dev, rank, world, lib):
     print(json.dumps(out), flush=True)
 
 
+def bench_pupil(args, T, dev, lib):
+    """IBL pupil path (reference eks/ibl_pupil_smoother.py): one chain, D=3, O=8, time-varying R.
+    One step = one iteration of the two-parameter optimiser: eks_ar1_nll (loss + 2 forward
+    sensitivities) -> eks_pupil_adam_step.  Depth-bound (a single chain offers only time
+    parallelism): reported for the record, not the headline."""
+    import torch
+    from eks_amd import hip_ops, synth
+    from eks_amd import ibl_pupil_smoother as ips
+    ys, ev, m0, S0, lv = synth.pupil_observations(T, seed=1)
+    P = ips._PupilProblem(ys, m0, S0, ips.PUPIL_C, ev, lv)
+    loss = hip_ops.Ar1Loss(P.y, P.var, P.m0, P.S0, P.C, n_tan=2)
+    state = np.zeros((1, 9))
+    state[0, 0:2] = np.log(np.array([0.99, 0.98]) / (1 - np.array([0.99, 0.98])))
+    state[0, 6] = np.inf
+    state = torch.as_tensor(state, device=dev)
+    latent = torch.as_tensor(lv[None], device=dev)
+    n_active = torch.zeros(1, dtype=torch.int32, device=dev)
+    hip_ops.pupil_adam_step(loss, latent, state, n_active, 5e-3, 0.0, 1 << 30, init=True)
+
+    def step():
+        loss.evaluate()
+        hip_ops.pupil_adam_step(loss, latent, state, n_active, 5e-3, 0.0, 1 << 30)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    lib.eks_profile_drain(None, 0, None, 0)
+    lib.eks_profile_enable(0 if args.no_kernel_events else 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lib.eks_profile_enable(0)
+    prof = {k: float(np.mean(v)) for k, v in drain_profile(lib).items()}
+    nll_ms = prof.get('ar1_nll', float('nan'))
+    out = {'metric': 'frames x optimiser iterations / s, IBL pupil AR(1) session (D=3, O=8, time-varying R)',
+           'value': args.steps * T / dt, 'unit': 'frames*iterations/s', 'n_gpus': 1, 'steps': args.steps,
+           'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+           'config': {'workload': f'pupil AR(1) T={T} frames, one chain; step = loss + 2 sensitivities + Adam'},
+           'roofline': {'bound': 'hbm', 'kernel': 'ar1_chunks_kernel + ar1_reduce_kernel', 'unit': 'GB/s',
+                        'peak': HBM_PEAK_GBS, 'achieved': 64 * T / (nll_ms * 1e-3) / 1e9,
+                        'frac': 64 * T / (nll_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                        'stage_avg_ms': prof,
+                        'note': 'depth-bound, not HBM-bound: 64 B/frame (y, var) per stream is nothing; '
+                                'the time is ~8 frames + log2(T/8) element compositions of dependent '
+                                'float64 dual-number arithmetic'}}
+    if not args.no_cpu_baseline:
+        from oracle import eks_oracle as orc
+        Tc = min(T, 20_000)
+        u = np.array([4.6, 3.9])
+        t1 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t1 < min(args.cpu_seconds, 10.0):
+            orc.pupil_nll_and_grad(u, ys[:Tc], m0, S0, orc.PUPIL_C, ev[:Tc], lv, use_c=True)
+            reps += 1
+        cdt = (time.perf_counter() - t1) / reps
+        out['cpu_baseline'] = {'value': Tc / cdt, 'unit': 'frames*iterations/s', 'cores': 1, 'kind': 'port',
+                               'sample': f'first {Tc} frames, loss + 2 directional derivatives by complex-step '
+                                         f'through the C port of the reference recursion '
+                                         f'(oracle/eks_oracle.c), {reps} evaluations'}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
     import torch
@@ -184,6 +250,8 @@ def main():
     T, K, n_cand = WORKLOADS[args.workload]
     if args.workload == 'c4':
         return bench_dense(args, T, K, dev, rank, world, lib)
+    if args.workload == 'pupil':
+        return bench_pupil(args, T, dev, lib)
     # every rank owns an independent session of the same shape (seed = 3 + rank)
     y, var = synth.singlecam_observations_torch(T, K, seed=3 + rank, device=dev)
     eye = torch.eye(2, dtype=torch.float64, device=dev).expand(K, 2, 2).contiguous()

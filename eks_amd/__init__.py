@@ -14,6 +14,7 @@ def __getattr__(name):          # lazy: pandas/sklearn/torch are only imported w
         'fit_eks_singlecam': 'singlecam_smoother', 'ensemble_kalman_smoother_singlecam': 'singlecam_smoother',
         'fit_eks_mirrored_multicam': 'multicam_smoother', 'fit_eks_multicam': 'multicam_smoother',
         'ensemble_kalman_smoother_multicam': 'multicam_smoother',
+        'fit_eks_pupil': 'ibl_pupil_smoother', 'ensemble_kalman_smoother_ibl_pupil': 'ibl_pupil_smoother',
         'run_kalman_smoother': 'core', 'ensemble': 'core', 'optimize_smooth_param': 'core',
     }
     if name in table:

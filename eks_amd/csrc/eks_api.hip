@@ -118,6 +118,36 @@ int eks_adam_step(int32_t n_blocks, const int32_t* block_offsets, const int32_t*
                    state, s_keypoint, n_active, reinterpret_cast<hipStream_t>(stream));
 }
 
+size_t eks_ar1_nll_workspace_bytes(const eks_dims_t* d, int32_t n_tan) {
+  if (check_dims(d) != EKS_OK || n_tan < 0) return 0;
+  return ar1_nll_workspace_bytes(d->n_frames, d->n_keypoints, d->state_dim, n_tan);
+}
+
+int eks_ar1_nll(const eks_dims_t* d, const float* y, const float* var, const double* m0,
+                const double* S0, const double* C, const double* a, const double* q,
+                const double* da, const double* dq, int32_t n_tan, double* nll, double* dnll,
+                void* workspace, size_t workspace_bytes, eks_stream_t stream) {
+  const int rc = check_dims(d);
+  if (rc != EKS_OK) return rc;
+  if (n_tan < 0) return EKS_ERR_SHAPE;
+  if (!y || !var || !m0 || !S0 || !C || !a || !q || !nll) return EKS_ERR_NULL;
+  if (n_tan > 0 && (!da || !dq || !dnll)) return EKS_ERR_NULL;
+  if (!workspace) return EKS_ERR_WORKSPACE;
+  return ar1_nll(*d, y, var, m0, S0, C, a, q, da, dq, n_tan, nll, dnll, workspace, workspace_bytes,
+                 reinterpret_cast<hipStream_t>(stream));
+}
+
+int eks_pupil_adam_step(int32_t n_chains, const double* latent_var, const double* nll,
+                        const double* dnll, double lr, double tol, int32_t safety_cap,
+                        double* state, double* a, double* q, double* da, double* dq,
+                        int32_t* n_active, eks_stream_t stream) {
+  if (n_chains <= 0) return EKS_ERR_SHAPE;
+  if (!latent_var || !state || !a || !q || !da || !dq || !n_active) return EKS_ERR_NULL;
+  if (nll && !dnll) return EKS_ERR_NULL;
+  return pupil_adam_step(n_chains, latent_var, nll, dnll, lr, tol, safety_cap, state, a, q, da, dq,
+                         n_active, reinterpret_cast<hipStream_t>(stream));
+}
+
 int eks_ensemble(int32_t n_models, int32_t n_cameras, int32_t n_frames, int32_t n_keypoints,
                  const float* markers, int32_t avg_mode, int32_t var_mode, float nan_replacement,
                  float* stats, eks_stream_t stream) {

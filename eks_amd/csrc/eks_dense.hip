@@ -251,14 +251,11 @@ __global__ __launch_bounds__(64) void dense_nll_summarize_kernel(DenseGeom G, De
   store_delem<S, D>(elems + (size_t)idx * NREC, e);
 }
 
+// marginal log-likelihood of chain k through record stream c (candidate or tangent): the chunk
+// elements applied in time order to the prior belief
 template <typename S, int D>
-__global__ __launch_bounds__(64) void dense_nll_assemble_kernel(DenseGeom G, DenseModelPtrs M,
-                                                               const double* __restrict__ elems,
-                                                               double* __restrict__ nll,
-                                                               double* __restrict__ dnll) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= G.K * G.n_cand) return;
-  const int k = idx % G.K, c = idx / G.K;
+__device__ S dense_assemble_ll(const DenseGeom& G, const DenseModelPtrs& M,
+                               const double* __restrict__ elems, int k, int c) {
   constexpr int NREC = delem_doubles<D>() * (sizeof(S) > sizeof(double) ? 2 : 1);
   Vec<double, D> m0;
   Mat<double, D> P0;
@@ -277,10 +274,121 @@ __global__ __launch_bounds__(64) void dense_nll_assemble_kernel(DenseGeom G, Den
     const DElem<S, D> e = load_delem<S, D>(elems + rec * NREC);
     ll = ll + delem_apply(e, m, P);
   }
+  return ll;
+}
+
+template <typename S, int D>
+__global__ __launch_bounds__(64) void dense_nll_assemble_kernel(DenseGeom G, DenseModelPtrs M,
+                                                               const double* __restrict__ elems,
+                                                               double* __restrict__ nll,
+                                                               double* __restrict__ dnll) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= G.K * G.n_cand) return;
+  const int k = idx % G.K, c = idx / G.K;
+  const S ll = dense_assemble_ll<S, D>(G, M, elems, k, c);
   const double v = -val(ll);
   const bool fin = isfinite(v);
   nll[(size_t)k * G.n_cand + c] = fin ? v : 1e12;  // eks/core.py:650
   if (dnll) dnll[(size_t)k * G.n_cand + c] = fin ? -der(ll) : 0.0;
+}
+
+// ---- AR(1) loss with the time-varying R_t (pupil smoother, eks/ibl_pupil_smoother.py:540-552).
+// One or a few chains, evaluated thousands of times per session: everything is arranged for
+// depth, not throughput.  A "stream" is one (chain, tangent) pair; tangent i differentiates along
+// (da[i], dq[i]) with dual numbers.
+//   A1 ar1_chunks : workgroup = 64 consecutive chunks of one stream (frames 1..T-1 as predict-
+//                   then-observe pairs, eks_dense_lane.hpp); each lane summarises its chunk
+//                   (ar1_summarize_chunk), then the 64 elements are composed in time order
+//                   by a 6-level tree through LDS (delem_combine carries the log-likelihood)
+//   A2 ar1_reduce : the same tree over the previous level's aggregates, repeated until one
+//                   element per stream remains; that launch updates the prior belief with frame
+//                   0, applies the element and writes nll / dnll.
+constexpr int kAr1CB = 64;
+
+struct Ar1Geom {
+  int K, T, O, B, nc, ns;   // ns = record streams per chain = max(n_tan, 1)
+};
+
+// Ordered tree reduction of the workgroup's elements (lane i holds element i of n); the result
+// is in lane 0.  lds: kAr1CB * NREC doubles, field-major.
+template <typename S, int D>
+__device__ void ar1_tree_reduce(DElem<S, D>& e, int i, int n, double* lds) {
+  for (int half = 1; half < n; half <<= 1) {
+    const int span = half << 1;
+    const bool send = (i & (span - 1)) == half, recv = (i & (span - 1)) == 0 && i + half < n;
+    if (send && i < n) store_delem<S, D>(lds + i, e, kAr1CB);
+    __syncthreads();
+    if (recv) e = delem_combine(e, load_delem<S, D>(lds + i + half, kAr1CB));
+  }
+}
+
+template <typename S, int D>
+__device__ void ar1_finish(const Ar1Geom& G, const DenseModelPtrs& M, const float* __restrict__ y,
+                           const float* __restrict__ var, const DElem<S, D>& e, int k, int c,
+                           double* __restrict__ nll, double* __restrict__ dnll) {
+  Vec<double, D> m0;
+  Mat<double, D> P0;
+  load_prior<D>(M, k, m0, P0);
+  Vec<S, D> m;
+  Mat<S, D> P;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    m.a[a] = S(m0.a[a]);
+#pragma unroll
+    for (int b = 0; b < D; ++b) P.a[a][b] = S(P0.a[a][b]);
+  }
+  S ll = ar1_first_frame<S, D>(y, var, G.K, G.O, k, M, m, P);
+  if (G.T > 1) ll = ll + delem_apply(e, m, P);
+  if (c == 0) nll[k] = -val(ll);   // no 1e12 substitution in this loss (:551-552)
+  if (dnll) dnll[(size_t)c * G.K + k] = -der(ll);
+}
+
+template <typename S, int D>
+__global__ __launch_bounds__(kAr1CB) void ar1_chunks_kernel(
+    Ar1Geom G, DenseModelPtrs M, const double* __restrict__ a, const double* __restrict__ q,
+    const double* __restrict__ da, const double* __restrict__ dq, const float* __restrict__ y,
+    const float* __restrict__ var, double* __restrict__ out, double* __restrict__ nll,
+    double* __restrict__ dnll) {
+  constexpr int NREC = delem_doubles<D>() * (sizeof(S) > sizeof(double) ? 2 : 1);
+  __shared__ double lds[kAr1CB * NREC];
+  const int i = threadIdx.x, stream = blockIdx.y, k = stream % G.K, c = stream / G.K;
+  const int j0 = blockIdx.x * kAr1CB, n = min(kAr1CB, G.nc - j0), j = j0 + i;
+  DElem<S, D> e;
+  if (i < n) {
+    Vec<S, D> av, qv;
+    const size_t toff = (size_t)c * G.K * D;
+    load_ar1_dynamics<S, D>(a, q, da ? da + toff : nullptr, dq ? dq + toff : nullptr, k, av, qv);
+    const int t0 = 1 + j * G.B;
+    e = ar1_summarize_chunk<S, D>(y, var, G.K, G.O, k, t0, min(G.B, G.T - t0), M, av, qv);
+  }
+  ar1_tree_reduce<S, D>(e, i, n, lds);
+  if (i != 0) return;
+  if (gridDim.x == 1)
+    ar1_finish<S, D>(G, M, y, var, e, k, c, nll, dnll);
+  else
+    store_delem<S, D>(out + ((size_t)stream * gridDim.x + blockIdx.x) * NREC, e);
+}
+
+template <typename S, int D>
+__global__ __launch_bounds__(kAr1CB) void ar1_reduce_kernel(Ar1Geom G, DenseModelPtrs M,
+                                                           const float* __restrict__ y,
+                                                           const float* __restrict__ var, int n_in,
+                                                           const double* __restrict__ in,
+                                                           double* __restrict__ out,
+                                                           double* __restrict__ nll,
+                                                           double* __restrict__ dnll) {
+  constexpr int NREC = delem_doubles<D>() * (sizeof(S) > sizeof(double) ? 2 : 1);
+  __shared__ double lds[kAr1CB * NREC];
+  const int i = threadIdx.x, stream = blockIdx.y, k = stream % G.K, c = stream / G.K;
+  const int j0 = blockIdx.x * kAr1CB, n = min(kAr1CB, n_in - j0);
+  DElem<S, D> e;
+  if (i < n) e = load_delem<S, D>(in + ((size_t)stream * n_in + j0 + i) * NREC);
+  ar1_tree_reduce<S, D>(e, i, n, lds);
+  if (i != 0) return;
+  if (gridDim.x == 1)
+    ar1_finish<S, D>(G, M, y, var, e, k, c, nll, dnll);
+  else
+    store_delem<S, D>(out + ((size_t)stream * gridDim.x + blockIdx.x) * NREC, e);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -388,6 +496,73 @@ int dense_nll(const eks_dims_t& d, const float* y, const double* rconst, const D
       hipLaunchKernelGGL((dense_nll_assemble_kernel<double, DD>), dim3((lanes2 + 63) / 64), dim3(64),
                          0, st, G, M, elems, nll, dnll);
     })
+  }
+  return hip_status(hipGetLastError());
+}
+
+// frames per lane: short chunks keep the per-lane recursion short (a frame costs about a fifth
+// of an element composition, and the tree adds one composition per doubling of the chunk
+// count); they grow only when the launch would exceed a few waves per SIMD
+static int ar1_chunk(int T, int streams) {
+  int b = 8;
+  while ((long)((T + b - 1) / b) * streams > (1L << 18)) b <<= 1;
+  return b;
+}
+
+// chunks cover frames 1..T-1 (frame 0 updates the prior in the finishing launch); at least one
+// (possibly empty) chunk so that a launch exists to finish
+static int ar1_chunks(int T, int B) { return T > 1 ? (T - 1 + B - 1) / B : 1; }
+
+size_t ar1_nll_workspace_bytes(int T, int K, int D, int n_tan) {
+  const int ns = n_tan > 0 ? n_tan : 1, B = ar1_chunk(T, K * ns), nc = ar1_chunks(T, B);
+  const size_t nv = 3 * D * D + 2 * D + 1;
+  size_t total = 0;
+  for (int n = (nc + kAr1CB - 1) / kAr1CB; n > 1; n = (n + kAr1CB - 1) / kAr1CB) {
+    total += align_up((size_t)n * K * ns * nv * 2 * 8, 256);
+    if (n <= kAr1CB) break;
+  }
+  return total + 256;
+}
+
+template <typename S, int DD>
+static void ar1_launch(const Ar1Geom& G, const DenseModelPtrs& M, const double* a, const double* q,
+                       const double* da, const double* dq, const float* y, const float* var,
+                       double* nll, double* dnll, char* ws, hipStream_t st) {
+  constexpr size_t rec_bytes = (3 * DD * DD + 2 * DD + 1) * (sizeof(S) > sizeof(double) ? 2 : 1) * 8;
+  const int streams = G.K * G.ns;
+  int n = (G.nc + kAr1CB - 1) / kAr1CB;
+  double* out = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL((ar1_chunks_kernel<S, DD>), dim3(n, streams), dim3(kAr1CB), 0, st, G, M, a, q, da,
+                     dq, y, var, out, nll, dnll);
+  while (n > 1) {
+    const int n_out = (n + kAr1CB - 1) / kAr1CB;
+    double* in = out;
+    out = reinterpret_cast<double*>(reinterpret_cast<char*>(in) +
+                                    align_up((size_t)n * streams * rec_bytes, 256));
+    hipLaunchKernelGGL((ar1_reduce_kernel<S, DD>), dim3(n_out, streams), dim3(kAr1CB), 0, st, G, M, y,
+                       var, n, in, out, nll, dnll);
+    n = n_out;
+  }
+}
+
+int ar1_nll(const eks_dims_t& d, const float* y, const float* var, const double* m0,
+            const double* S0, const double* C, const double* a, const double* q, const double* da,
+            const double* dq, int n_tan, double* nll, double* dnll, void* ws, size_t ws_bytes,
+            hipStream_t st) {
+  const int T = d.n_frames, K = d.n_keypoints, D = d.state_dim, O = d.obs_dim;
+  if (D < 1 || D > 6 || O < 1 || O > 64) return EKS_ERR_UNSUPPORTED;
+  if (ws_bytes < ar1_nll_workspace_bytes(T, K, D, n_tan)) return EKS_ERR_WORKSPACE;
+  const int ns = n_tan > 0 ? n_tan : 1;
+  Ar1Geom G{K, T, O, ar1_chunk(T, K * ns), 0, ns};
+  G.nc = ar1_chunks(T, G.B);
+  const DenseModelPtrs M{m0, S0, nullptr, C, nullptr};
+  ProfScope ps("ar1_nll", st);
+  if (n_tan > 0) {
+    EKS_DISPATCH_D(D, (ar1_launch<DualD, DD>(G, M, a, q, da, dq, y, var, nll, dnll,
+                                             static_cast<char*>(ws), st)))
+  } else {
+    EKS_DISPATCH_D(D, (ar1_launch<double, DD>(G, M, a, q, nullptr, nullptr, y, var, nll, nullptr,
+                                              static_cast<char*>(ws), st)))
   }
   return hip_status(hipGetLastError());
 }

@@ -24,6 +24,20 @@ EKS_HD void load_dynamics(const DenseModelPtrs& M, int k, S s, Mat<S, D>& F, Mat
     }
 }
 
+// AR(1) dynamics given explicitly per chain: F = diag(a[k]), process noise diag(q[k]); with a
+// dual scalar the tangents (da, dq) seed the derivative parts (eks/ibl_pupil_smoother.py:542-548)
+template <typename S, int D>
+EKS_HD void load_ar1_dynamics(const double* __restrict__ a, const double* __restrict__ q,
+                              const double* __restrict__ da, const double* __restrict__ dq, int k,
+                              Vec<S, D>& av, Vec<S, D>& qv) {
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    const size_t p = (size_t)k * D + i;
+    av.a[i] = make_real(S(), a[p], da ? da[p] : 0.0);
+    qv.a[i] = make_real(S(), q[p], dq ? dq[p] : 0.0);
+  }
+}
+
 template <typename S, int D>
 EKS_HD Vec<S, D> load_obs_row(const DenseModelPtrs& M, int k, int O, int o) {
   Vec<S, D> h;
@@ -33,8 +47,10 @@ EKS_HD Vec<S, D> load_obs_row(const DenseModelPtrs& M, int k, int O, int o) {
 }
 
 // K1: element of frames [t0, t0+len) of keypoint k.  CONST_R: constant observation variances
-// rconst[k][o] (the loss, eks/core.py:602) and ell is accumulated; otherwise R_t from var.
-template <typename S, int D, bool CONST_R>
+// rconst[k][o] (the loss, eks/core.py:602); otherwise R_t from var.  WANT_ELL accumulates the
+// log-likelihood part (the losses; the pupil loss keeps the time-varying R_t,
+// eks/ibl_pupil_smoother.py:514-518).
+template <typename S, int D, bool CONST_R, bool WANT_ELL = CONST_R>
 EKS_HD DElem<S, D> dense_summarize_chunk(const float* __restrict__ y, const float* __restrict__ var,
                                          const double* __restrict__ rconst, int K, int O, int k,
                                          int t0, int len, const DenseModelPtrs& M,
@@ -50,11 +66,87 @@ EKS_HD DElem<S, D> dense_summarize_chunk(const float* __restrict__ y, const floa
         const float v = var[row + o];
         r = v > kVarFloor ? (double)v : (double)kVarFloor;
       }
-      delem_observe(e, load_obs_row<S, D>(M, k, O, o), S((double)y[row + o]), S(r), CONST_R);
+      delem_observe(e, load_obs_row<S, D>(M, k, O, o), S((double)y[row + o]), S(r), WANT_ELL);
     }
     delem_predict(e, F, sQ, f_identity);
   }
   return e;
+}
+
+// AR(1) loss with the time-varying R_t (eks/ibl_pupil_smoother.py:514-518, :540-552).
+//
+// Frame 0 updates the prior belief directly (ar1_first_frame); every later frame t enters a chunk
+// element as the pair (predict into t, observe t).  With the predict FIRST the element's
+// information about its entry state is bounded by the process noise, so its (eta, J, ell) stay
+// moderate even when an ensemble variance sits at the 1e-12 clip - an element that opened with an
+// observation would carry y^2 / r ~ 1e14 terms that only cancel in the final assembly.
+//
+// Per frame the O observations are folded into information form in plain doubles (they do not
+// depend on the parameters) and absorbed as D pseudo-observations (delem_observe_info).  A frame
+// whose variances span more than 8 decades is absorbed observation by observation instead (the
+// information matrix would lose the large-variance rows to rounding).
+template <typename S, int D>
+EKS_HD DElem<S, D> ar1_summarize_chunk(const float* __restrict__ y, const float* __restrict__ var,
+                                       int K, int O, int k, int t0, int len,
+                                       const DenseModelPtrs& M, const Vec<S, D>& av,
+                                       const Vec<S, D>& qv) {
+  DElem<S, D> e = delem_identity<S, D>();
+  for (int t = t0; t < t0 + len; ++t) {
+    delem_predict_diag(e, av, qv);
+    const size_t row = ((size_t)t * K + k) * O;
+    Mat<double, D> Lam = mat_zero<double, D>();
+    Vec<double, D> nu = vec_zero<double, D>();
+    double c = O * kLog2Pi, rmin = 1e300, rmax = 0.0;
+    for (int o = 0; o < O; ++o) {
+      const float v = var[row + o];
+      const double r = v > kVarFloor ? (double)v : (double)kVarFloor;
+      const double yo = (double)y[row + o], w = 1.0 / r;
+      rmin = fmin(rmin, r);
+      rmax = fmax(rmax, r);
+      const Vec<double, D> h = load_obs_row<double, D>(M, k, O, o);
+      c += log(r) + yo * yo * w;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        nu.a[i] += h.a[i] * (w * yo);
+#pragma unroll
+        for (int j = 0; j < D; ++j) Lam.a[i][j] += h.a[i] * (w * h.a[j]);
+      }
+    }
+    if (rmax <= 1e8 * rmin) {
+      delem_observe_info(e, Lam, nu, c);
+    } else {
+      for (int o = 0; o < O; ++o) {
+        const float v = var[row + o];
+        const double r = v > kVarFloor ? (double)v : (double)kVarFloor;
+        delem_observe(e, load_obs_row<S, D>(M, k, O, o), S((double)y[row + o]), S(r), true);
+      }
+    }
+  }
+  return e;
+}
+
+// Measurement update of the belief N(m, P) with frame 0 (scalar observation at a time); returns
+// the frame's log-likelihood.
+template <typename S, int D>
+EKS_HD S ar1_first_frame(const float* __restrict__ y, const float* __restrict__ var, int K, int O,
+                         int k, const DenseModelPtrs& M, Vec<S, D>& m, Mat<S, D>& P) {
+  S ll = S(0.0);
+  const size_t row = (size_t)k * O;
+  for (int o = 0; o < O; ++o) {
+    const Vec<S, D> h = load_obs_row<S, D>(M, k, O, o);
+    const float v = var[row + o];
+    const S r = S(v > kVarFloor ? (double)v : (double)kVarFloor);
+    const Vec<S, D> u = mat_vec(P, h);
+    const S sigma = r + dot(h, u), g = rcp(sigma), d = S((double)y[row + o]) - dot(h, m), gd = g * d;
+    ll = ll - S(0.5) * (S(kLog2Pi) + log_s(sigma) + d * gd);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      m.a[i] = m.a[i] + u.a[i] * gd;
+#pragma unroll
+      for (int j = 0; j < D; ++j) P.a[i][j] = P.a[i][j] - u.a[i] * u.a[j] * g;
+    }
+  }
+  return ll;
 }
 
 // K3: exact replay.  (m, P): predicted belief entering the chunk; (eta_s, J_s): information about
@@ -145,9 +237,16 @@ EKS_HD void dense_replay_chunk(const float* __restrict__ y, const float* __restr
 template <int D>
 constexpr int delem_doubles() { return 3 * D * D + 2 * D + 1; }
 
+// `stride` = distance in doubles between consecutive fields of one record (1: a contiguous
+// record in global memory; CB: field-major records of a workgroup in LDS, conflict-free)
 template <typename S, int D>
-EKS_HD void store_delem(double* __restrict__ rec, const DElem<S, D>& e) {
+EKS_HD void store_delem(double* __restrict__ rec_, const DElem<S, D>& e, int stride = 1) {
   constexpr int NV = delem_doubles<D>();
+  struct Strided {
+    double* p;
+    int s;
+    EKS_HD double& operator[](int i) const { return p[(size_t)i * s]; }
+  } rec{rec_, stride};
   int p = 0;
 #pragma unroll
   for (int i = 0; i < D; ++i)
@@ -177,8 +276,13 @@ EKS_HD void store_delem(double* __restrict__ rec, const DElem<S, D>& e) {
 }
 
 template <typename S, int D>
-EKS_HD DElem<S, D> load_delem(const double* __restrict__ rec) {
+EKS_HD DElem<S, D> load_delem(const double* __restrict__ rec_, int stride = 1) {
   constexpr int NV = delem_doubles<D>();
+  struct Strided {
+    const double* p;
+    int s;
+    EKS_HD double operator[](int i) const { return p[(size_t)i * s]; }
+  } rec{rec_, stride};
   DElem<S, D> e;
   auto get = [&](int p) -> S {
     if constexpr (sizeof(S) > sizeof(double))

@@ -279,6 +279,52 @@ EKS_HD void delem_predict(DElem<S, D>& e, const Mat<S, D>& F, const Mat<S, D>& s
   e.C = mat_add(e.C, sQ);
 }
 
+// Predict half of a frame for diagonal dynamics: x' = diag(a) x + N(0, diag(q)).
+template <typename S, int D>
+EKS_HD void delem_predict_diag(DElem<S, D>& e, const Vec<S, D>& a, const Vec<S, D>& q) {
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    e.b.a[i] = a.a[i] * e.b.a[i];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      e.A.a[i][j] = a.a[i] * e.A.a[i][j];
+      e.C.a[i][j] = a.a[i] * a.a[j] * e.C.a[i][j];
+    }
+    e.C.a[i][i] = e.C.a[i][i] + q.a[i];
+  }
+}
+
+// Absorb a whole frame given in information form, Lambda = H^T R^-1 H (symmetric D x D),
+// nu = H^T R^-1 y and c = O log 2pi + sum log r + sum y^2 / r - all three independent of the
+// model parameters, so plain doubles.  Lambda = Ll Ll^T (Cholesky, semi-definite safe) turns
+// the frame into D unit-variance scalar pseudo-observations z = Ll^-1 nu with rows Ll^T:
+// H'^T H' = Lambda, H'^T z = nu, and the log-likelihood differs from the true one by the
+// constant -(c - D log 2pi - z.z)/2.  D rank-1 updates instead of O.
+template <typename S, int D>
+EKS_HD void delem_observe_info(DElem<S, D>& e, const Mat<double, D>& Lam, const Vec<double, D>& nu,
+                               double c) {
+  const Mat<double, D> Ll = chol_psd(Lam);
+  Vec<double, D> z;
+  double zz = 0.0;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    double t = nu.a[i];
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+      if (k < i) t -= Ll.a[i][k] * z.a[k];
+    z.a[i] = Ll.a[i][i] > 0.0 ? t / Ll.a[i][i] : 0.0;
+    zz += z.a[i] * z.a[i];
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    Vec<S, D> h;
+#pragma unroll
+    for (int j = 0; j < D; ++j) h.a[j] = S(j >= i ? Ll.a[j][i] : 0.0);
+    delem_observe(e, h, S(z.a[i]), S(1.0), true);
+  }
+  e.ell = e.ell - S(0.5 * (c - D * kLog2Pi - zz));
+}
+
 // Posterior of the belief N(m, P) on x_in given the element's information (eta, J):
 //   P_in = (P^-1 + J)^-1 = L (I + L^T J L)^-1 L^T,  P = L L^T   (stable: the inner matrix is >= I)
 //   m_in = w - L (I + L^T J L)^-1 L^T J w,          w = m + P eta

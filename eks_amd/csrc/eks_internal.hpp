@@ -48,6 +48,12 @@ int dense_nll(const eks_dims_t& d, const float* y, const double* rconst, const D
               const double* s_cand, int n_cand, int per_keypoint, double* nll, double* dnll,
               void* ws, size_t ws_bytes, hipStream_t st);
 
+size_t ar1_nll_workspace_bytes(int T, int K, int D, int n_tan);
+int ar1_nll(const eks_dims_t& d, const float* y, const float* var, const double* m0,
+            const double* S0, const double* C, const double* a, const double* q, const double* da,
+            const double* dq, int n_tan, double* nll, double* dnll, void* ws, size_t ws_bytes,
+            hipStream_t st);
+
 // misc (eks_misc.hip)
 size_t const_r_workspace_bytes(int N);
 int const_r(int T, int N, const float* var, double min_var, double* rconst, void* ws,
@@ -57,6 +63,9 @@ int argmin_s(int K, int n_cand, const double* nll, const double* s_cand, double*
 int adam_step(int n_blocks, const int32_t* offs, const int32_t* members, const double* nll,
               const double* dnll, double lr, double lo, double hi, double tol, int cap,
               double* state, double* s_keypoint, int32_t* n_active, hipStream_t st);
+int pupil_adam_step(int n, const double* latent_var, const double* nll, const double* dnll, double lr,
+                    double tol, int cap, double* state, double* a, double* q, double* da, double* dq,
+                    int32_t* n_active, hipStream_t st);
 int ensemble_stats(int M, int V, int T, int K, const float* markers, int avg_mode, int var_mode,
                    float nan_replacement, float* stats, hipStream_t st);
 

@@ -177,3 +177,55 @@ def ensemble(markers, avg_mode: str = 'median', var_mode: str = 'confidence_weig
                           _stream())
     _lib.check(rc, 'eks_ensemble')
     return out
+
+
+class Ar1Loss:
+    """eks_ar1_nll with every buffer allocated once: the pupil optimiser evaluates this loss (and
+    its two sensitivities) thousands of times on the same arrays (reference
+    eks/ibl_pupil_smoother.py:540-594).  y, var (T, K, O) float32; m0 (K, D), S0 (K, D, D),
+    C (K, O, D) float64.  `a`, `q` (K, D) and the tangents `da`, `dq` (n_tan, K, D) are device
+    buffers owned here that the caller (or eks_pupil_adam_step) fills before `evaluate()`."""
+
+    def __init__(self, y, var, m0, S0, C, n_tan: int = 2):
+        self.lib = _lib.load()
+        T, K, O = y.shape
+        D = m0.shape[-1]
+        self.y = _chk(y, torch.float32, 'y')
+        self.var = _chk(var, torch.float32, 'var', (T, K, O))
+        self.m0 = _chk(m0, torch.float64, 'm0', (K, D))
+        self.S0 = _chk(S0, torch.float64, 'S0', (K, D, D))
+        self.C = _chk(C, torch.float64, 'C', (K, O, D))
+        self.n_tan, self.K, self.D = int(n_tan), K, D
+        dev = y.device
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.a = torch.zeros((K, D), **f64)
+        self.q = torch.zeros((K, D), **f64)
+        self.da = torch.zeros((max(n_tan, 1), K, D), **f64)
+        self.dq = torch.zeros((max(n_tan, 1), K, D), **f64)
+        self.nll = torch.empty(K, **f64)
+        self.dnll = torch.empty((max(n_tan, 1), K), **f64)
+        self.dims = _dims(K, T, D, O, 0)
+        self.ws = _workspace(self.lib.eks_ar1_nll_workspace_bytes(ctypes.byref(self.dims), self.n_tan),
+                             dev)
+
+    def evaluate(self):
+        """Enqueue one evaluation; results land in self.nll (K,) and self.dnll (n_tan, K)."""
+        t = self.n_tan > 0
+        rc = self.lib.eks_ar1_nll(ctypes.byref(self.dims), _ptr(self.y), _ptr(self.var), _ptr(self.m0),
+                                  _ptr(self.S0), _ptr(self.C), _ptr(self.a), _ptr(self.q),
+                                  _ptr(self.da if t else None), _ptr(self.dq if t else None),
+                                  self.n_tan, _ptr(self.nll), _ptr(self.dnll if t else None),
+                                  _ptr(self.ws), self.ws.numel(), _stream())
+        _lib.check(rc, 'eks_ar1_nll')
+        return self.nll, self.dnll
+
+
+def pupil_adam_step(loss: Ar1Loss, latent_var, state, n_active, lr, tol, safety_cap,
+                    init: bool = False):
+    """eks_pupil_adam_step on the buffers of `loss`; init=True only derives a, q, da, dq from the
+    state's u (no update)."""
+    rc = loss.lib.eks_pupil_adam_step(loss.K, _ptr(latent_var), _ptr(None if init else loss.nll),
+                                      _ptr(None if init else loss.dnll), float(lr), float(tol),
+                                      int(safety_cap), _ptr(state), _ptr(loss.a), _ptr(loss.q),
+                                      _ptr(loss.da), _ptr(loss.dq), _ptr(n_active), _stream())
+    _lib.check(rc, 'eks_pupil_adam_step')

@@ -86,3 +86,26 @@ def singlecam_observations_torch(T: int, K: int, seed: int, device):
     var = (sig2[..., None] * chi.clamp_min(1e-3)).float().contiguous()
     y = (lat + randn(T, K, 2) * torch.sqrt(0.29 * sig2)[..., None]).float().contiguous()
     return y, var
+
+
+def pupil_observations(T: int, seed: int, noise: float = 0.6):
+    """Synthetic pupil session for the AR(1) path (reference eks/ibl_pupil_smoother.py): latent
+    (diameter, com_x, com_y) AR(1) with s = (0.995, 0.97, 0.97), eight observations through the
+    fixed 8x3 matrix, per-frame ensemble variances ~ noise * Gamma(2, 0.5) + 0.05.
+    Returns float32-rounded float64 (ys (T,8), ensemble_vars (T,8)) and m0 (3,), S0 (3,3),
+    latent_vars (3,)."""
+    rng = np.random.default_rng(seed)
+    C = np.array([[0, 1, 0], [-.5, 0, 1], [0, 1, 0], [.5, 0, 1],
+                  [.5, 1, 0], [0, 0, 1], [-.5, 1, 0], [0, 0, 1]], dtype=np.float64)
+    a = np.array([0.995, 0.97, 0.97])
+    drive = rng.normal(size=(T, 3)) * np.array([0.15, 0.5, 0.5])
+    lat = np.empty((T, 3))
+    x = np.zeros(3)
+    for t in range(T):
+        x = a * x + drive[t]
+        lat[t] = x
+    lat[:, 0] += 12.0
+    ev = (noise * rng.gamma(2.0, 0.5, size=(T, 8)) + 0.05).astype(np.float32).astype(np.float64)
+    ys = (lat @ C.T + rng.normal(size=(T, 8)) * np.sqrt(ev)).astype(np.float32).astype(np.float64)
+    lv = lat.var(axis=0)
+    return ys, ev, np.array([lat[:, 0].mean(), 0.0, 0.0]), np.diag(lv), lv

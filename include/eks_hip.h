@@ -103,6 +103,33 @@ int eks_adam_step(int32_t n_blocks, const int32_t* block_offsets, const int32_t*
                   double tol, int32_t safety_cap, double* state, double* s_keypoint,
                   int32_t* n_active, eks_stream_t stream);
 
+/* ---- IBL pupil smoother, eks/ibl_pupil_smoother.py:363-607.
+ * Independent chains k < n_keypoints (one per session), AR(1) dynamics A_k = diag(a[k][:]),
+ * process noise diag(q[k][:]), observation matrix C [K][O][D], TIME-VARYING R_t = diag(max(var,
+ * 1e-12)) also in the loss (:514-518).  eks_ar1_nll: nll[k] = -marginal_loglik of the filter
+ * (_nll_from_u, :540-552); with n_tan > 0, dnll[i][k] = derivative of nll[k] along the tangent
+ * (da[i][k][:], dq[i][k][:]) - forward sensitivities replacing jax.value_and_grad (:570).  The
+ * final smoothing pass is eks_smooth with A = diag(a), Q = diag(q), s = 1 (:427-445). -------- */
+size_t eks_ar1_nll_workspace_bytes(const eks_dims_t* dims, int32_t n_tan);
+int eks_ar1_nll(const eks_dims_t* dims, const float* y, const float* var, const double* m0,
+                const double* S0, const double* C, const double* a, const double* q,
+                const double* da, const double* dq, int32_t n_tan, double* nll, double* dnll,
+                void* workspace, size_t workspace_bytes, eks_stream_t stream);
+
+/* ---- one iteration of the pupil optimiser per chain (:560-594): optax.adam(lr) (b1 .9, b2 .999,
+ * eps 1e-8, bias-corrected) on u = (u_diam, u_com) with the gradient dnll [2][n] w.r.t. u, then
+ * done = isfinite(prev) && |L - prev| < tol * |log(max(prev, 1e-12))| + 1e-6; prev = L; ++iters.
+ * Chains that are done or at safety_cap are left untouched.  state is [n][9] float64
+ * {u_d, u_c, mom_d, mom_c, vel_d, vel_c, prev_loss, iters, done}.  Always (re)writes the inputs
+ * of the next eks_ar1_nll call from u: s = sigmoid(u) * (1 - 2e-3) + 1e-3 (:506-508),
+ * a [n][3] = (s_d, s_c, s_c), q [n][3] = latent_var * (1 - a^2), and the two tangents
+ * da, dq [2][n][3] = d(a, q)/du_d, d(a, q)/du_c.  nll == NULL: only that (initialisation).
+ * *n_active = number of chains still running after this step. ------------------------------- */
+int eks_pupil_adam_step(int32_t n_chains, const double* latent_var, const double* nll,
+                        const double* dnll, double lr, double tol, int32_t safety_cap,
+                        double* state, double* a, double* q, double* da, double* dq,
+                        int32_t* n_active, eks_stream_t stream);
+
 /* ---- ensemble statistics, eks/core.py:25-101: markers float32 [M][V][T][K][3] (x,y,likelihood)
  * -> stats float32 [V][T][K][5] (x, y, var_x, var_y, likelihood).  avg_mode 0 median / 1 mean,
  * var_mode 0 confidence_weighted_var / 1 var. ------------------------------------------------ */

@@ -75,3 +75,20 @@ def nll_grid(y, Rc, m0, S0, A, C, Q, s_cand, nthreads: int = 0):
     if rc:
         raise RuntimeError(f'eksc_nll_grid rc={rc}')
     return out
+
+
+def nll_directional(y, Rd, m0, S0, A, C, Q, dA, dQ):
+    """One chain: y (T,O), Rd (T,O) or (O,), directions dA, dQ (n_dir,D,D).  Returns
+    (nll, dnll (n_dir,)) - complex-step derivatives of the C filter."""
+    lib = load()
+    y, Rd, m0, S0, A, C, Q, dA, dQ = map(_c, (y, Rd, m0, S0, A, C, Q, dA, dQ))
+    T, O = y.shape
+    D = m0.shape[-1]
+    n_dir = dA.shape[0]
+    nll = np.empty(1)
+    dnll = np.empty(max(n_dir, 1))
+    rc = lib.eksc_nll_directional(T, D, O, _p(y), _p(Rd), int(Rd.ndim == 1), _p(m0), _p(S0), _p(A),
+                                  _p(C), _p(Q), _p(dA), _p(dQ), n_dir, _p(nll), _p(dnll))
+    if rc:
+        raise RuntimeError(f'eksc_nll_directional rc={rc}')
+    return float(nll[0]), dnll[:n_dir].copy()

@@ -14,6 +14,7 @@
  * Layout (keypoint-major like the reference's JAX arrays): y [K][T][O]; R diag [K][T][O] or
  * [K][O] (r_const); ms [K][T][D]; Vs [K][T][D][D].
  */
+#include <complex.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -251,6 +252,141 @@ int eksc_nll_grid(int K, int T, int D, int O, const double* y, const double* Rc,
                                      Q + (size_t)k * D * D, s_cand[c], NULL, NULL, NULL, NULL);
       nll[(size_t)k * n_cand + c] = isfinite(ll) ? -ll : 1e12;
     }
+  return 0;
+}
+
+/* ---- directional derivatives of the filter log-likelihood by complex-step differentiation:
+ * the same update-then-predict recursion in complex arithmetic with A + i h dA, Q + i h dQ
+ * (h = 1e-30, no conjugations anywhere), d ll = Im(ll) / h to machine precision.  Serves the
+ * loss of the pupil smoother, whose two parameters enter A and Q (eks/ibl_pupil_smoother.py:
+ * 540-552); an independent route to the number the NumPy oracle gets by forward sensitivities.
+ * R diagonal, time-varying [T][O] (r_const = 0) or constant [O]. */
+typedef double complex cplx;
+
+static int cchol(cplx* a, int n) { /* lower factor in place, plain (non-Hermitian) transposes */
+  for (int j = 0; j < n; ++j) {
+    cplx d = a[j * n + j];
+    for (int k = 0; k < j; ++k) d -= a[j * n + k] * a[j * n + k];
+    if (!(creal(d) > 0.0)) return 1;
+    d = csqrt(d);
+    a[j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      cplx v = a[i * n + j];
+      for (int k = 0; k < j; ++k) v -= a[i * n + k] * a[j * n + k];
+      a[i * n + j] = v / d;
+    }
+  }
+  return 0;
+}
+
+static void cchol_solve(const cplx* L, int n, cplx* b) {
+  for (int i = 0; i < n; ++i) {
+    cplx v = b[i];
+    for (int k = 0; k < i; ++k) v -= L[i * n + k] * b[k];
+    b[i] = v / L[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    cplx v = b[i];
+    for (int k = i + 1; k < n; ++k) v -= L[k * n + i] * b[k];
+    b[i] = v / L[i * n + i];
+  }
+}
+
+static cplx filter_ll_cplx(int T, int D, int O, const double* y, const double* Rd, int r_const,
+                           const double* m0, const double* S0, const cplx* A, const double* C,
+                           const cplx* Q) {
+  cplx m[MAXD], P[MAXD * MAXD], S[MAXO * MAXO], PCt[MAXD * MAXO], Kg[MAXD * MAXO], e[MAXO],
+      tmp[MAXO], ll = 0.0;
+  for (int i = 0; i < D; ++i) m[i] = m0[i];
+  for (int i = 0; i < D * D; ++i) P[i] = S0[i];
+  for (int t = 0; t < T; ++t) {
+    const double* yt = y + (size_t)t * O;
+    const double* rt = r_const ? Rd : Rd + (size_t)t * O;
+    for (int i = 0; i < D; ++i)
+      for (int o = 0; o < O; ++o) {
+        cplx a = 0.0;
+        for (int k = 0; k < D; ++k) a += P[i * D + k] * C[o * D + k];
+        PCt[i * O + o] = a;
+      }
+    for (int o = 0; o < O; ++o) {
+      cplx pred = 0.0;
+      for (int k = 0; k < D; ++k) pred += C[o * D + k] * m[k];
+      e[o] = yt[o] - pred;
+      for (int p = 0; p < O; ++p) {
+        cplx a = 0.0;
+        for (int k = 0; k < D; ++k) a += C[o * D + k] * PCt[k * O + p];
+        S[o * O + p] = a + (o == p ? rt[o] : 0.0);
+      }
+    }
+    if (cchol(S, O)) return NAN;
+    cplx logdet = 0.0, quad = 0.0;
+    for (int o = 0; o < O; ++o) logdet += 2.0 * clog(S[o * O + o]);
+    memcpy(tmp, e, sizeof(cplx) * O);
+    cchol_solve(S, O, tmp);
+    for (int o = 0; o < O; ++o) quad += e[o] * tmp[o];
+    ll += -0.5 * (O * LOG2PI + logdet + quad);
+    for (int i = 0; i < D; ++i) {   /* K = P C' S^-1, row by row */
+      memcpy(tmp, PCt + i * O, sizeof(cplx) * O);
+      cchol_solve(S, O, tmp);
+      memcpy(Kg + i * O, tmp, sizeof(cplx) * O);
+    }
+    for (int i = 0; i < D; ++i) {
+      cplx a = 0.0;
+      for (int o = 0; o < O; ++o) a += Kg[i * O + o] * e[o];
+      m[i] += a;
+    }
+    for (int i = 0; i < D; ++i)     /* P - K S K' = P - K (P C')' */
+      for (int j = 0; j < D; ++j) {
+        cplx a = 0.0;
+        for (int o = 0; o < O; ++o) a += Kg[i * O + o] * PCt[j * O + o];
+        P[i * D + j] -= a;
+      }
+    for (int i = 0; i < D; ++i)
+      for (int j = i + 1; j < D; ++j) {
+        const cplx v = 0.5 * (P[i * D + j] + P[j * D + i]);
+        P[i * D + j] = v;
+        P[j * D + i] = v;
+      }
+    cplx mn[MAXD], AP[MAXD * MAXD];
+    for (int i = 0; i < D; ++i) {
+      cplx a = 0.0;
+      for (int k = 0; k < D; ++k) a += A[i * D + k] * m[k];
+      mn[i] = a;
+      for (int j = 0; j < D; ++j) {
+        cplx b = 0.0;
+        for (int k = 0; k < D; ++k) b += A[i * D + k] * P[k * D + j];
+        AP[i * D + j] = b;
+      }
+    }
+    for (int i = 0; i < D; ++i) {
+      m[i] = mn[i];
+      for (int j = 0; j < D; ++j) {
+        cplx b = 0.0;
+        for (int k = 0; k < D; ++k) b += AP[i * D + k] * A[j * D + k];
+        P[i * D + j] = b + Q[i * D + j];
+      }
+    }
+  }
+  return ll;
+}
+
+/* nll and dnll[d] = directional derivative of nll along (dA[d], dQ[d]), d < n_dir */
+int eksc_nll_directional(int T, int D, int O, const double* y, const double* Rd, int r_const,
+                         const double* m0, const double* S0, const double* A, const double* C,
+                         const double* Q, const double* dA, const double* dQ, int n_dir,
+                         double* nll, double* dnll) {
+  if (D > MAXD || O > MAXO) return -3;
+  const double h = 1e-30;
+  cplx Ac[MAXD * MAXD], Qc[MAXD * MAXD];
+  for (int d = 0; d < (n_dir > 0 ? n_dir : 1); ++d) {
+    for (int i = 0; i < D * D; ++i) {
+      Ac[i] = A[i] + (n_dir > 0 ? I * (h * dA[(size_t)d * D * D + i]) : 0.0);
+      Qc[i] = Q[i] + (n_dir > 0 ? I * (h * dQ[(size_t)d * D * D + i]) : 0.0);
+    }
+    const cplx ll = filter_ll_cplx(T, D, O, y, Rd, r_const, m0, S0, Ac, C, Qc);
+    *nll = -creal(ll);
+    if (n_dir > 0) dnll[d] = -cimag(ll) / h;
+  }
   return 0;
 }
 

@@ -27,6 +27,7 @@ What each function follows (file:line relative to /root/reference):
 * ``center_predictions``                   - eks/utils.py:293-365
 * ``singlecam_arrays`` / ``multicam_arrays`` - eks/singlecam_smoother.py:140-243, :246-284 and
   eks/multicam_smoother.py:335-348, :409-443, :481-551, :554-597
+* ``pupil_*`` / ``run_pupil_kalman_smoother`` - eks/ibl_pupil_smoother.py:34-91, :233-359, :363-607
 """
 from __future__ import annotations
 
@@ -75,7 +76,8 @@ def _as_R_getter(R, K, T, O):
 # --------------------------------------------------------------------------------------------
 # forward filter (covariance form; the dynamax recursion)
 # --------------------------------------------------------------------------------------------
-def kalman_filter(y, m0, S0, A, C, Q, s, R, *, jitter=0.0, symmetrize=True, want_grad=False):
+def kalman_filter(y, m0, S0, A, C, Q, s, R, *, jitter=0.0, symmetrize=True, want_grad=False,
+                  tangent=None):
     """Update-then-predict Kalman filter, batched over keypoints.
 
     y (K,T,O); m0 (K,D); S0,A,Q (K,D,D); C (K,O,D); s (K,) process-noise scale (cov = s*Q);
@@ -84,6 +86,9 @@ def kalman_filter(y, m0, S0, A, C, Q, s, R, *, jitter=0.0, symmetrize=True, want
 
     Returns dict with filtered means/covs (K,T,D)/(K,T,D,D), predicted ones, ``ll`` (K,) marginal
     log-likelihood, and if ``want_grad`` also ``dll`` = d ll / d log s (forward sensitivity).
+    ``tangent=(dA, dQ)`` (each (K,D,D)) instead returns ``dll`` = the directional derivative of
+    ll for the perturbation A + h dA, s*Q + h dQ (used by the pupil loss, whose two parameters
+    enter both A and Q: eks/ibl_pupil_smoother.py:540-552).
     """
     y = np.asarray(y, np.float64)
     K, T, O = y.shape
@@ -105,6 +110,13 @@ def kalman_filter(y, m0, S0, A, C, Q, s, R, *, jitter=0.0, symmetrize=True, want
     ll = np.zeros(K)
     m = m0.copy()
     P = S0.copy()
+    if tangent is not None:
+        want_grad = True
+        dA = np.asarray(tangent[0], np.float64)
+        dsQ = np.asarray(tangent[1], np.float64)
+    else:
+        dA = None
+        dsQ = sQ                                # d(sQ)/d log s = sQ
     if want_grad:
         dm = np.zeros_like(m)
         dP = np.zeros_like(P)
@@ -141,11 +153,15 @@ def kalman_filter(y, m0, S0, A, C, Q, s, R, *, jitter=0.0, symmetrize=True, want
                 dP = _sym(dP)
         mf[:, t] = m
         Pf[:, t] = P
-        m = np.einsum('kde,ke->kd', A, m)
-        P = _bmm(A, P, At) + sQ
         if want_grad:
             dm = np.einsum('kde,ke->kd', A, dm)
-            dP = _bmm(A, dP, At) + sQ           # d(sQ)/d log s = sQ
+            dP = _bmm(A, dP, At) + dsQ
+            if dA is not None:
+                dm = dm + np.einsum('kde,ke->kd', dA, m)
+                APdAt = _bmm(A, P, _T(dA))
+                dP = dP + APdAt + _T(APdAt)
+        m = np.einsum('kde,ke->kd', A, m)
+        P = _bmm(A, P, At) + sQ
     out = dict(mf=mf, Pf=Pf, mp=mp, Pp=Pp, ll=ll, m_next=m, P_next=P)
     if want_grad:
         out['dll'] = dll
@@ -783,3 +799,183 @@ def multicam_outputs(arrs, ms, Vs):
     lat[:, :, :D] = np.transpose(ms, (1, 0, 2))
     lat[:, :, D:] = np.transpose(np.diagonal(Vs, axis1=2, axis2=3), (1, 0, 2))
     return cams, lat.reshape(T, K * 2 * D)
+
+
+# --------------------------------------------------------------------------------------------
+# IBL pupil smoother: eks/ibl_pupil_smoother.py:34-607
+# --------------------------------------------------------------------------------------------
+PUPIL_KEYPOINTS = ('pupil_top_r', 'pupil_bottom_r', 'pupil_right_r', 'pupil_left_r')
+# rows: top x,y / bottom x,y / right x,y / left x,y ; columns: diameter, com_x, com_y
+# (eks/ibl_pupil_smoother.py:271-276)
+PUPIL_C = np.array([[0, 1, 0], [-.5, 0, 1], [0, 1, 0], [.5, 0, 1],
+                    [.5, 1, 0], [0, 0, 1], [-.5, 1, 0], [0, 0, 1]], dtype=np.float64)
+
+
+def _median2(a, b, skip_nan):
+    """Median of two numbers per frame: their mean; with skip_nan the non-NaN one survives
+    (np.nanmedian) - otherwise a NaN poisons the result (np.median)."""
+    both = 0.5 * (a + b)
+    if not skip_nan:
+        return both
+    return np.where(np.isnan(a), b, np.where(np.isnan(b), a, both))
+
+
+def pupil_location(p):
+    """eks/ibl_pupil_smoother.py:34-60.  p (T,8) in PUPIL_KEYPOINTS x/y order -> centre (T,2).
+    x: nan-tolerant over (top, bottom), strict over (right, left), then nan-tolerant over the two;
+    y: strict over (top, bottom), nan-tolerant over (right, left), then nan-tolerant."""
+    tx, ty, bx, by, rx, ry, lx, ly = (p[:, i] for i in range(8))
+    cx = _median2(_median2(tx, bx, True), _median2(rx, lx, False), True)
+    cy = _median2(_median2(ty, by, False), _median2(ry, ly, True), True)
+    return np.stack([cx, cy], axis=1)
+
+
+def pupil_diameter(p):
+    """eks/ibl_pupil_smoother.py:63-91: nanmedian of six estimates - the two direct diameters and
+    sqrt(2) x the four adjacent-point distances (circle assumption)."""
+    pts = {n: p[:, 2 * i:2 * i + 2] for i, n in enumerate(('top', 'bottom', 'right', 'left'))}
+
+    def dist(a, b):
+        d = pts[a] - pts[b]
+        return np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1])
+
+    est = [dist('top', 'bottom'), dist('left', 'right')]
+    for a, b in (('top', 'left'), ('top', 'right'), ('bottom', 'left'), ('bottom', 'right')):
+        est.append(dist(a, b) * 2 ** 0.5)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', category=RuntimeWarning)
+        return np.nanmedian(np.stack(est), axis=0)
+
+
+def pupil_arrays(marker, avg_mode='median', var_mode='confidence_weighted_var', ens=None):
+    """Inputs of run_pupil_kalman_smoother as eks/ibl_pupil_smoother.py:233-289 builds them.
+    marker (M,1,T,4,3) with keypoints in PUPIL_KEYPOINTS order."""
+    ens = ensemble(marker, avg_mode, var_mode) if ens is None else np.asarray(ens, np.float64)
+    T = ens.shape[2]
+    preds = ens[0, 0, :, :, 0:2].reshape(T, 8)
+    evars = ens[0, 0, :, :, 2:4].reshape(T, 8)
+    likes = ens[0, 0, :, :, 4]
+    diam = pupil_diameter(preds)
+    loc = pupil_location(preds)
+    mean_x, mean_y = np.mean(loc[:, 0]), np.mean(loc[:, 1])
+    xo, yo = loc[:, 0] - mean_x, loc[:, 1] - mean_y
+    m0 = np.array([np.mean(diam), 0.0, 0.0])
+    S0 = np.diag([np.nanvar(diam), np.nanvar(xo), np.nanvar(yo)])
+    ys = preds.copy()
+    ys[:, 0::2] -= mean_x
+    ys[:, 1::2] -= mean_y
+    return dict(ys=ys, m0=m0, S0=S0, C=PUPIL_C.copy(), ensemble_vars=evars, likes=likes,
+                preds=preds, mean_x=mean_x, mean_y=mean_y,
+                latent_vars=np.array([np.var(diam), np.var(xo), np.var(yo)]))
+
+
+def pupil_dynamics(s_d, s_c, latent_vars):
+    """A = diag(s_d, s_c, s_c), Q = diag(var * (1 - s^2)); eks/ibl_pupil_smoother.py:427-432."""
+    a = np.array([s_d, s_c, s_c], dtype=np.float64)
+    return np.diag(a), np.diag(np.asarray(latent_vars, np.float64) * (1.0 - a * a))
+
+
+def pupil_to_stable_s(u, eps=1e-3):
+    """sigmoid(u) * (1 - 2 eps) + eps and its derivative; eks/ibl_pupil_smoother.py:506-508."""
+    sig = 1.0 / (1.0 + np.exp(-np.asarray(u, np.float64)))
+    return sig * (1.0 - 2 * eps) + eps, sig * (1.0 - sig) * (1.0 - 2 * eps)
+
+
+def pupil_nll_and_grad(u, ys, m0, S0, C, ensemble_vars, latent_vars, use_c=True):
+    """Loss of eks/ibl_pupil_smoother.py:540-552 (filter NLL with the time-varying R_t) and its
+    gradient w.r.t. u = (u_diam, u_com).  Gradient by forward sensitivities through the filter
+    (``kalman_filter(tangent=...)``), or - with use_c and the C twin built - by complex-step
+    differentiation of the C filter (an independent route to the same number)."""
+    s, ds = pupil_to_stable_s(u)
+    lv = np.asarray(latent_vars, np.float64)
+    A, Q = pupil_dynamics(s[0], s[1], lv)
+    dA = [np.diag([ds[0], 0.0, 0.0]), np.diag([0.0, ds[1], ds[1]])]
+    dQ = [np.diag([-2 * s[0] * ds[0] * lv[0], 0.0, 0.0]),
+          np.diag([0.0, -2 * s[1] * ds[1] * lv[1], -2 * s[1] * ds[1] * lv[2]])]
+    Rd = np.maximum(np.asarray(ensemble_vars, np.float64), 1e-12)
+    if use_c:
+        from . import c_oracle
+        return c_oracle.nll_directional(ys, Rd, m0, S0, A, C, Q, dA, dQ)
+    g = np.empty(2)
+    for i in range(2):
+        f = kalman_filter(ys[None], m0[None], S0[None], A[None], C[None], Q[None], 1.0, Rd[None],
+                          tangent=(dA[i][None], dQ[i][None]))
+        g[i] = -f['dll'][0]
+    return -f['ll'][0], g
+
+
+def pupil_optimize_smooth(ys, m0, S0, C, ensemble_vars, latent_vars, s_frames=None,
+                          smooth_params=None, lr=5e-3, tol=1e-6, safety_cap=5000, use_c=True):
+    """eks/ibl_pupil_smoother.py:451-607.  Both parameters given: clip to [1e-3, 1-1e-3] after
+    rounding to float32 (:555-557).  Otherwise Adam (optax.adam(lr): b1 .9, b2 .999, eps 1e-8,
+    bias-corrected) on u from s0 = (0.99, 0.98), one loss for both parameters, stop when
+    |L - prev| < tol*|log(max(prev,1e-12))| + 1e-6 (prev finite) or at ``safety_cap`` (:571-594).
+    Returns (s_diam, s_com, iters, last_loss)."""
+    if smooth_params is not None and all(v is not None for v in smooth_params):
+        s = np.clip(np.asarray(smooth_params, dtype=np.float32), np.float32(1e-3),
+                    np.float32(1 - 1e-3))
+        return float(s[0]), float(s[1]), 0, float('nan')
+    y_loss = crop_frames(np.asarray(ys, np.float64), s_frames)
+    v_loss = crop_frames(np.asarray(ensemble_vars, np.float64), s_frames)
+    s0 = np.array([0.99, 0.98], dtype=np.float32).astype(np.float64)
+    u = np.log(s0 / (1.0 - s0))
+    mom = np.zeros(2)
+    vel = np.zeros(2)
+    prev, iters, last = np.inf, 0, np.nan
+    b1, b2, eps = 0.9, 0.999, 1e-8
+    while iters < safety_cap:
+        L, g = pupil_nll_and_grad(u, y_loss, m0, S0, C, v_loss, latent_vars, use_c=use_c)
+        iters += 1
+        mom = b1 * mom + (1 - b1) * g
+        vel = b2 * vel + (1 - b2) * g * g
+        u = u - lr * (mom / (1 - b1 ** iters)) / (np.sqrt(vel / (1 - b2 ** iters)) + eps)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            stop = np.isfinite(prev) and \
+                abs(L - prev) < tol * abs(np.log(max(prev, 1e-12))) + 1e-6
+        prev = last = L
+        if stop:
+            break
+    s, _ = pupil_to_stable_s(u)
+    return float(s[0]), float(s[1]), iters, float(last)
+
+
+def run_pupil_kalman_smoother(ys, m0, S0, C, ensemble_vars, latent_vars, s_frames=None,
+                              smooth_params=None, **opt):
+    """eks/ibl_pupil_smoother.py:363-448: optimise (s_diam, s_com) on the (cropped) loss, then the
+    smoother over all frames with A(s), Q(s) and the time-varying R_t.
+    Returns ([s_d, s_c], ms (T,3), Vs (T,3,3), info)."""
+    s_d, s_c, iters, last = pupil_optimize_smooth(ys, m0, S0, C, ensemble_vars, latent_vars,
+                                                  s_frames, smooth_params, **opt)
+    A, Q = pupil_dynamics(s_d, s_c, latent_vars)
+    Rd = np.maximum(np.asarray(ensemble_vars, np.float64), 1e-12)
+    ms, Vs, nll = kalman_smoother(np.asarray(ys, np.float64)[None], m0[None], S0[None], A[None],
+                                  C[None], Q[None], 1.0, Rd[None])
+    return [s_d, s_c], ms[0], Vs[0], dict(iters=iters, last_loss=last, nll=float(nll[0]))
+
+
+def pupil_outputs(arrs, ms, Vs):
+    """The (T, 36) output table of eks/ibl_pupil_smoother.py:303-359, column order = the
+    DataFrame's: for each position i in (top, right, bottom, left) the nine fields x, y,
+    likelihood, x/y_ens_median, x/y_ens_var, x/y_posterior_var.  Upstream quirks kept because
+    the CSV is the contract: the data are gathered in (top, right, bottom, left) order while the
+    column header is built from keypoint_names (top, bottom, right, left); likelihood i is
+    keypoint_names[i]'s; the posterior variances are entries (i, i) and (i+1, i+1) of C V C'."""
+    C = arrs['C']
+    ym = ms @ C.T
+    ym[:, 0::2] += arrs['mean_x']
+    ym[:, 1::2] += arrs['mean_y']
+    yv = np.einsum('od,tde,pe->top', C, Vs, C)
+    T = ms.shape[0]
+    out = np.empty((T, 4, 9))
+    for i, (cx, cy) in enumerate(((0, 1), (4, 5), (2, 3), (6, 7))):
+        out[:, i, 0] = ym[:, cx]
+        out[:, i, 1] = ym[:, cy]
+        out[:, i, 2] = arrs['likes'][:, i]
+        out[:, i, 3] = arrs['preds'][:, cx]
+        out[:, i, 4] = arrs['preds'][:, cy]
+        out[:, i, 5] = arrs['ensemble_vars'][:, cx]
+        out[:, i, 6] = arrs['ensemble_vars'][:, cy]
+        out[:, i, 7] = yv[:, i, i]
+        out[:, i, 8] = yv[:, i + 1, i + 1]
+    return out.reshape(T, 36)

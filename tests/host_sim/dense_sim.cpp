@@ -1,0 +1,70 @@
+// Host-side simulator of the general (D, O) lane bodies.  TEST INFRASTRUCTURE ONLY: it calls the
+// same headers the gfx950 kernels include (eks_amd/csrc/eks_dense_lane.hpp) from plain loops, so
+// the chunked element algebra and the dual-number sensitivities of the AR(1) loss can be compared
+// with the float64 oracle on a CPU-only box.  It is not a fallback: nothing under eks_amd/ loads it.
+#include <algorithm>
+#include <vector>
+
+#include "eks_dense_lane.hpp"
+
+using namespace eks;
+
+// nll and (n_tan > 0) dnll[i] along the tangents (da[i], dq[i]) of one chain, chunks of B frames:
+// what ar1_chunks_kernel + ar1_reduce_kernel compute (eks_dense.hip); tree = 0 applies the chunk
+// elements one after the other instead of composing them first
+template <typename S, int D>
+static S ar1_ll(int T, int O, int B, bool tree, const float* y, const float* var, const DenseModelPtrs& M,
+                const double* a, const double* q, const double* da, const double* dq) {
+  Vec<S, D> av, qv;
+  load_ar1_dynamics<S, D>(a, q, da, dq, 0, av, qv);
+  Vec<double, D> m0;
+  Mat<double, D> P0;
+  load_prior<D>(M, 0, m0, P0);
+  Vec<S, D> m;
+  Mat<S, D> P;
+  for (int i = 0; i < D; ++i) {
+    m.a[i] = S(m0.a[i]);
+    for (int j = 0; j < D; ++j) P.a[i][j] = S(P0.a[i][j]);
+  }
+  S ll = ar1_first_frame<S, D>(y, var, 1, O, 0, M, m, P);
+  if (T == 1) return ll;
+  std::vector<DElem<S, D>> el;
+  for (int t0 = 1; t0 < T; t0 += B) {
+    const DElem<S, D> e = ar1_summarize_chunk<S, D>(y, var, 1, O, 0, t0, std::min(B, T - t0), M, av, qv);
+    if (tree)
+      el.push_back(e);
+    else
+      ll = ll + delem_apply(e, m, P);
+  }
+  if (!tree) return ll;
+  // the kernels' order of composition: groups of 64, pairwise doubling inside a group (A1/A2)
+  while (el.size() > 1) {
+    std::vector<DElem<S, D>> next;
+    for (size_t j0 = 0; j0 < el.size(); j0 += 64) {
+      const size_t n = std::min<size_t>(64, el.size() - j0);
+      for (size_t half = 1; half < n; half <<= 1)
+        for (size_t i = 0; i + half < n; i += 2 * half) el[j0 + i] = delem_combine(el[j0 + i], el[j0 + i + half]);
+      next.push_back(el[j0]);
+    }
+    el.swap(next);
+  }
+  return ll + delem_apply(el[0], m, P);
+}
+
+extern "C" int sim_ar1_nll(int T, int D, int O, int B, int tree, const float* y, const float* var,
+                           const double* m0, const double* S0, const double* C, const double* a,
+                           const double* q, const double* da, const double* dq, int n_tan,
+                           double* nll, double* dnll) {
+  if (D != 3) return -3;
+  const DenseModelPtrs M{m0, S0, nullptr, C, nullptr};
+  if (n_tan == 0) {
+    *nll = -ar1_ll<double, 3>(T, O, B, tree != 0, y, var, M, a, q, nullptr, nullptr);
+    return 0;
+  }
+  for (int i = 0; i < n_tan; ++i) {
+    const DualD ll = ar1_ll<DualD, 3>(T, O, B, tree != 0, y, var, M, a, q, da + i * D, dq + i * D);
+    *nll = -ll.v;
+    dnll[i] = -ll.d;
+  }
+  return 0;
+}

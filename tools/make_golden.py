@@ -41,8 +41,44 @@ def pack(full):
                 colabs=np.abs(full).sum(axis=0))
 
 
+def pupil():
+    """ibl-pupil through the pupil smoother (the reference's tests/integration/test_ibl_pupil.py:
+    defaults and smooth_params=[0.99, 0.99]).  The marker array is the one already stored in
+    ibl_pupil_singlecam.npz, re-ordered to (top, bottom, right, left)."""
+    g = np.load(os.path.join(OUT, 'ibl_pupil_singlecam.npz'))
+    order = [list(g['keypoints']).index(k) for k in orc.PUPIL_KEYPOINTS]
+    mk = g['markers'][:, :, :, order]
+    arrs = orc.pupil_arrays(mk)
+    out = dict(order=np.array(order), keep_idx=keep_idx(mk.shape[2]), m0=arrs['m0'], S0=arrs['S0'],
+               latent_vars=arrs['latent_vars'], means=np.array([arrs['mean_x'], arrs['mean_y']]))
+    args = (arrs['ys'], arrs['m0'], arrs['S0'], arrs['C'], arrs['ensemble_vars'], arrs['latent_vars'])
+    s, ms, Vs, info = orc.run_pupil_kalman_smoother(*args, smooth_params=[0.99, 0.99])
+    out['fixed_s'] = np.array(s)
+    out['fixed_nll'] = info['nll']
+    for k, v in pack(orc.pupil_outputs(arrs, ms, Vs)).items():
+        out[f'fixed_{k}'] = v
+    for k, v in pack(np.concatenate([ms, Vs.reshape(len(ms), 9)], axis=1)).items():
+        out[f'fixed_state_{k}'] = v
+    s, ms, Vs, info = orc.run_pupil_kalman_smoother(*args)
+    out['adam_s'] = np.array(s)
+    out['adam_iters'] = info['iters']
+    out['adam_last_loss'] = info['last_loss']
+    for k, v in pack(orc.pupil_outputs(arrs, ms, Vs)).items():
+        out[f'adam_{k}'] = v
+    # the loss and its gradient at a few points of the (u_diam, u_com) plane
+    us = np.array([[4.59511985, 3.8918203], [2.0, 2.0], [6.0, 1.0], [0.0, 5.0], [-2.0, 7.0]])
+    lg = [orc.pupil_nll_and_grad(u, *args, use_c=False) for u in us]
+    out['probe_u'] = us
+    out['probe_nll'] = np.array([v[0] for v in lg])
+    out['probe_grad'] = np.array([v[1] for v in lg])
+    np.savez_compressed(os.path.join(OUT, 'ibl_pupil_pupil.npz'), **out)
+    print('ibl-pupil (pupil smoother): s_adam', s, 'iters', info['iters'], 'loss', info['last_loss'])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ['pupil']:
+        return pupil()
     # ---------------- ibl-pupil: singlecam, 5 models x 2000 frames x 4 keypoints
     dfs = read_dir(os.path.join(REF, 'ibl-pupil'))
     kps = dfs[0].columns[dfs[0].columns.get_level_values('coords') == 'x'].get_level_values('bodyparts').tolist()
@@ -135,6 +171,7 @@ def main():
             out[f'infl_s10_cam{c}_{k}'] = v
     np.savez_compressed(os.path.join(OUT, 'mirror_mouse_multicam.npz'), **out)
     print('mirror-mouse: s_adam', s_a, 'iters', out['adam_iters'])
+    pupil()
 
 
 if __name__ == '__main__':
