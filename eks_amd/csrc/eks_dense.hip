@@ -30,7 +30,8 @@ __global__ __launch_bounds__(64) void dense_summarize_kernel(DenseGeom G, DenseM
                                                             const double* __restrict__ s,
                                                             const float* __restrict__ y,
                                                             const float* __restrict__ var,
-                                                            double* __restrict__ elems) {
+                                                            double* __restrict__ elems,
+                                                            double* __restrict__ first) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= G.K * G.nc) return;
   const int k = idx % G.K, j = idx / G.K;
@@ -38,9 +39,21 @@ __global__ __launch_bounds__(64) void dense_summarize_kernel(DenseGeom G, DenseM
   bool fid;
   load_dynamics<double, D>(M, k, s[k], F, sQ, fid);
   const int t0 = j * G.B, len = min(G.B, G.T - t0);
-  const DElem<double, D> e =
-      dense_summarize_chunk<double, D, false>(y, var, nullptr, G.K, G.O, k, t0, len, M, F, sQ, fid);
+  const DElem<double, D> e = dense_smooth_element<D>(y, var, G.K, G.O, k, t0, len, M, F, sQ, fid);
   store_delem<double, D>(elems + (size_t)idx * delem_doubles<D>(), e);
+  if (j == 0) {   // the belief the scan starts from: the prior updated with frame 0
+    Vec<double, D> m;
+    Mat<double, D> P;
+    load_prior<D>(M, k, m, P);
+    belief_update_frame<D>(y, var, G.K, G.O, k, 0, M, m, P);
+    double* r = first + (size_t)k * (D + D * D);
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      r[a] = m.a[a];
+#pragma unroll
+      for (int b = 0; b < D; ++b) r[D + a * D + b] = P.a[a][b];
+    }
+  }
 }
 
 // ---- scan of the chunk elements, block-parallel like the scalar path (eks_diag.hip K2):
@@ -74,7 +87,8 @@ __global__ __launch_bounds__(kDenseCB) void dense_scan_reduce_kernel(DenseGeom G
 }
 
 template <int D>
-__global__ __launch_bounds__(64) void dense_scan_blocks_kernel(DenseGeom G, DenseModelPtrs M, int nblk,
+__global__ __launch_bounds__(64) void dense_scan_blocks_kernel(DenseGeom G, int nblk,
+                                                              const double* __restrict__ first,
                                                               const double* __restrict__ agg,
                                                               double* __restrict__ bprior,
                                                               double* __restrict__ bsuffix) {
@@ -86,7 +100,13 @@ __global__ __launch_bounds__(64) void dense_scan_blocks_kernel(DenseGeom G, Dens
   if (idx < G.K) {
     Vec<double, D> m;
     Mat<double, D> P;
-    load_prior<D>(M, k, m, P);
+    const double* f0 = first + (size_t)k * REC;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      m.a[a] = f0[a];
+#pragma unroll
+      for (int b = 0; b < D; ++b) P.a[a][b] = f0[D + a * D + b];
+    }
     for (int q = 0; q < nblk; ++q) {
       double* r = bprior + ((size_t)q * G.K + k) * REC;
 #pragma unroll
@@ -226,6 +246,7 @@ __global__ __launch_bounds__(64) void dense_replay_kernel(DenseGeom G, DenseMode
       J.a[a][b] = rs[D + a * D + b];
     }
   }
+  if (j == 0) load_prior<D>(M, k, m, P);   // chunk 0 replays frame 0's update of the prior itself
   const int t0 = j * G.B, len = min(G.B, G.T - t0);
   dense_replay_chunk<D>(y, var, G.K, G.O, k, t0, len, M, F, sQ, fid, m, P, eta, J,
                         filt + ((size_t)k * G.T + t0) * REC, ms, Vs, vs_diag != 0);
@@ -400,7 +421,7 @@ size_t dense_smooth_workspace_bytes(int T, int K, int D, int O) {
   const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
   return align_up((size_t)nc * K * nv * 8, 256) + 2 * align_up((size_t)nc * K * rec * 8, 256) +
          align_up((size_t)nblk * K * nv * 8, 256) + 2 * align_up((size_t)nblk * K * rec * 8, 256) +
-         align_up((size_t)T * K * rec * 8, 256);
+         align_up((size_t)T * K * rec * 8, 256) + align_up((size_t)K * rec * 8, 256);
 }
 
 size_t dense_nll_workspace_bytes(int T, int K, int D, int O, int n_cand) {
@@ -445,20 +466,22 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
   double* bsuffix = reinterpret_cast<double*>(p);
   p += align_up((size_t)nblk * K * rec * 8, 256);
   double* filt = reinterpret_cast<double*>(p);
+  p += align_up((size_t)T * K * rec * 8, 256);
+  double* first = reinterpret_cast<double*>(p);
   const int lanes = K * G.nc;
   const int vs_diag = (d.flags & EKS_FLAG_VS_DIAG) ? 1 : 0;
   EKS_DISPATCH_D(D, {
     {
       ProfScope ps("dense_summarize", st);
       hipLaunchKernelGGL(dense_summarize_kernel<DD>, dim3((lanes + 63) / 64), dim3(64), 0, st, G, M,
-                         Mm.s, y, var, elems);
+                         Mm.s, y, var, elems, first);
     }
     {
       ProfScope ps("dense_scan", st);
       const dim3 sgrid(K, nblk);
       hipLaunchKernelGGL(dense_scan_reduce_kernel<DD>, sgrid, dim3(kDenseCB), 0, st, G, elems, agg);
-      hipLaunchKernelGGL(dense_scan_blocks_kernel<DD>, dim3((2 * K + 63) / 64), dim3(64), 0, st, G, M,
-                         nblk, agg, bprior, bsuffix);
+      hipLaunchKernelGGL(dense_scan_blocks_kernel<DD>, dim3((2 * K + 63) / 64), dim3(64), 0, st, G, nblk,
+                         first, agg, bprior, bsuffix);
       hipLaunchKernelGGL(dense_scan_local_kernel<DD>, sgrid, dim3(kDenseCB), 0, st, G, elems, bprior,
                          bsuffix, prior, suffix);
     }

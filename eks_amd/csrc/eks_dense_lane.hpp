@@ -149,9 +149,58 @@ EKS_HD S ar1_first_frame(const float* __restrict__ y, const float* __restrict__ 
   return ll;
 }
 
-// K3: exact replay.  (m, P): predicted belief entering the chunk; (eta_s, J_s): information about
-// the state at the first frame after the chunk.  `filt` is this lane's scratch: len records of
-// D + D*D doubles (filtered mean and covariance), written forwards and read backwards.
+// Measurement update of the belief N(m, P) with frame t of keypoint k, one scalar observation at
+// a time (R_t diagonal).
+template <int D>
+EKS_HD void belief_update_frame(const float* __restrict__ y, const float* __restrict__ var, int K,
+                                int O, int k, int t, const DenseModelPtrs& M, Vec<double, D>& m,
+                                Mat<double, D>& P) {
+  const size_t row = ((size_t)t * K + k) * O;
+  for (int o = 0; o < O; ++o) {
+    const Vec<double, D> h = load_obs_row<double, D>(M, k, O, o);
+    const float v = var[row + o];
+    const double r = v > kVarFloor ? (double)v : (double)kVarFloor;
+    const Vec<double, D> u = mat_vec(P, h);
+    const double g = 1.0 / (r + dot(h, u));
+    const double gd = g * ((double)y[row + o] - dot(h, m));
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      m.a[a] += u.a[a] * gd;
+#pragma unroll
+      for (int b = 0; b < D; ++b) P.a[a][b] -= u.a[a] * u.a[b] * g;
+    }
+  }
+}
+
+// Smoother element of frames [t0, t0+len) of keypoint k: each frame enters as the pair (predict
+// into t, observe t); frame 0 of the sequence is left out (it updates the prior directly, see
+// dense_replay_chunk).  The boundary state between two chunks is therefore the FILTERED state of
+// the earlier chunk's last frame, and what an element knows about its entry state is bounded by
+// the process noise: (eta, J) stay moderate even when an ensemble variance sits at the 1e-12
+// clip.  (An element that opens with such an observation carries J ~ 1e12 and the boundary
+// algebra cancels catastrophically - measured: smoothed means off by 1e7.)
+template <int D>
+EKS_HD DElem<double, D> dense_smooth_element(const float* __restrict__ y, const float* __restrict__ var,
+                                             int K, int O, int k, int t0, int len,
+                                             const DenseModelPtrs& M, const Mat<double, D>& F,
+                                             const Mat<double, D>& sQ, bool f_identity) {
+  DElem<double, D> e = delem_identity<double, D>();
+  for (int t = t0 > 0 ? t0 : 1; t < t0 + len; ++t) {
+    delem_predict(e, F, sQ, f_identity);
+    const size_t row = ((size_t)t * K + k) * O;
+    for (int o = 0; o < O; ++o) {
+      const float v = var[row + o];
+      const double r = v > kVarFloor ? (double)v : (double)kVarFloor;
+      delem_observe(e, load_obs_row<double, D>(M, k, O, o), (double)y[row + o], r, false);
+    }
+  }
+  return e;
+}
+
+// K3: exact replay of frames [t0, t0+len).  (m, P): the filtered belief of frame t0-1 (the prior
+// itself when t0 == 0); (eta_s, J_s): what all later frames say about the state at the chunk's
+// last frame.  `filt` is this lane's scratch: len records of D + D*D doubles (filtered mean and
+// covariance), written forwards and read backwards.
 template <int D>
 EKS_HD void dense_replay_chunk(const float* __restrict__ y, const float* __restrict__ var, int K,
                                int O, int k, int t0, int len, const DenseModelPtrs& M,
@@ -162,21 +211,14 @@ EKS_HD void dense_replay_chunk(const float* __restrict__ y, const float* __restr
   constexpr int REC = D + D * D;
   for (int i = 0; i < len; ++i) {
     const int t = t0 + i;
-    const size_t row = ((size_t)t * K + k) * O;
-    for (int o = 0; o < O; ++o) {
-      const Vec<double, D> h = load_obs_row<double, D>(M, k, O, o);
-      const float v = var[row + o];
-      const double r = v > kVarFloor ? (double)v : (double)kVarFloor;
-      const Vec<double, D> u = mat_vec(P, h);
-      const double g = 1.0 / (r + dot(h, u));
-      const double gd = g * ((double)y[row + o] - dot(h, m));
-#pragma unroll
-      for (int a = 0; a < D; ++a) {
-        m.a[a] += u.a[a] * gd;
-#pragma unroll
-        for (int b = 0; b < D; ++b) P.a[a][b] -= u.a[a] * u.a[b] * g;
+    if (t > 0) {
+      if (!f_identity) {
+        m = mat_vec(F, m);
+        P = mat_mul_nt(mat_mul(F, P), F);
       }
+      P = mat_add(P, sQ);
     }
+    belief_update_frame<D>(y, var, K, O, k, t, M, m, P);
     double* rec = filt + (size_t)i * REC;
 #pragma unroll
     for (int a = 0; a < D; ++a) {
@@ -184,17 +226,27 @@ EKS_HD void dense_replay_chunk(const float* __restrict__ y, const float* __restr
 #pragma unroll
       for (int b = 0; b < D; ++b) rec[D + a * D + b] = P.a[a][b];
     }
-    if (!f_identity) {
-      m = mat_vec(F, m);
-      P = mat_mul_nt(mat_mul(F, P), F);
-    }
-    P = mat_add(P, sQ);
   }
+  auto emit = [&](int i, const Vec<double, D>& mo, const Mat<double, D>& Po) {
+    const size_t ko = (size_t)(t0 + i) * K + k;
+#pragma unroll
+    for (int a = 0; a < D; ++a) ms[ko * D + a] = (float)mo.a[a];
+    if (vs_diag) {
+#pragma unroll
+      for (int a = 0; a < D; ++a) Vs[ko * D + a] = (float)Po.a[a][a];
+    } else {
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) Vs[(ko * D + a) * D + b] = (float)Po.a[a][b];
+    }
+  };
   Vec<double, D> m_s;
   Mat<double, D> P_s;
   double logdet;
-  condition_on_info(m, P, eta_s, J_s, m_s, P_s, logdet);
-  for (int i = len - 1; i >= 0; --i) {
+  condition_on_info(m, P, eta_s, J_s, m_s, P_s, logdet);      // smoothed last frame of the chunk
+  emit(len - 1, m_s, P_s);
+  for (int i = len - 2; i >= 0; --i) {
     const double* rec = filt + (size_t)i * REC;
     Vec<double, D> mf;
     Mat<double, D> Pf;
@@ -218,18 +270,7 @@ EKS_HD void dense_replay_chunk(const float* __restrict__ y, const float* __restr
     // P_s = Pf + G (P_s - Pp) G^T,  G = Z^T
     const Mat<double, D> dP = mat_sub(P_s, Pp);
     P_s = mat_symmetrize(mat_add(Pf, mat_mul(mat_mul_tn(Z, dP), Z)));
-    const size_t ko = (size_t)(t0 + i) * K + k;
-#pragma unroll
-    for (int a = 0; a < D; ++a) ms[ko * D + a] = (float)m_s.a[a];
-    if (vs_diag) {
-#pragma unroll
-      for (int a = 0; a < D; ++a) Vs[ko * D + a] = (float)P_s.a[a][a];
-    } else {
-#pragma unroll
-      for (int a = 0; a < D; ++a)
-#pragma unroll
-        for (int b = 0; b < D; ++b) Vs[(ko * D + a) * D + b] = (float)P_s.a[a][b];
-    }
+    emit(i, m_s, P_s);
   }
 }
 

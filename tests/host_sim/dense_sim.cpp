@@ -68,3 +68,57 @@ extern "C" int sim_ar1_nll(int T, int D, int O, int B, int tree, const float* y,
   }
   return 0;
 }
+
+// The general (D, O) smoother as eks_dense.hip arranges it, from plain loops: chunk elements
+// (dense_smooth_element), the scan as sequential applies / pull-backs over the chunk elements,
+// then the exact replay of every chunk (dense_replay_chunk).  ms [T][K][D], Vs [T][K][D][D].
+template <int D>
+static void dense_smooth_sim(int T, int K, int O, int B, const float* y, const float* var,
+                             const DenseModelPtrs& M, const double* s, float* ms, float* Vs) {
+  constexpr int REC = D + D * D;
+  const int nc = (T + B - 1) / B;
+  std::vector<double> filt((size_t)B * REC);
+  for (int k = 0; k < K; ++k) {
+    Mat<double, D> F, sQ;
+    bool fid;
+    load_dynamics<double, D>(M, k, s[k], F, sQ, fid);
+    std::vector<DElem<double, D>> el(nc);
+    for (int j = 0; j < nc; ++j)
+      el[j] = dense_smooth_element<D>(y, var, K, O, k, j * B, std::min(B, T - j * B), M, F, sQ, fid);
+    std::vector<Vec<double, D>> pm(nc), se(nc);
+    std::vector<Mat<double, D>> pP(nc), sJ(nc);
+    Vec<double, D> m;
+    Mat<double, D> P;
+    load_prior<D>(M, k, m, P);
+    belief_update_frame<D>(y, var, K, O, k, 0, M, m, P);
+    for (int j = 0; j < nc; ++j) {
+      pm[j] = m;
+      pP[j] = P;
+      delem_apply(el[j], m, P);
+    }
+    Vec<double, D> eta = vec_zero<double, D>();
+    Mat<double, D> J = mat_zero<double, D>();
+    for (int j = nc - 1; j >= 0; --j) {
+      se[j] = eta;
+      sJ[j] = J;
+      delem_back(el[j], eta, J);
+    }
+    for (int j = 0; j < nc; ++j) {
+      if (j == 0) load_prior<D>(M, k, pm[0], pP[0]);
+      dense_replay_chunk<D>(y, var, K, O, k, j * B, std::min(B, T - j * B), M, F, sQ, fid, pm[j], pP[j],
+                            se[j], sJ[j], filt.data(), ms, Vs, false);
+    }
+  }
+}
+
+extern "C" int sim_dense_smooth(int T, int K, int D, int O, int B, const float* y, const float* var,
+                                const double* m0, const double* S0, const double* A, const double* C,
+                                const double* Q, const double* s, float* ms, float* Vs) {
+  const DenseModelPtrs M{m0, S0, A, C, Q};
+  switch (D) {
+    case 2: dense_smooth_sim<2>(T, K, O, B, y, var, M, s, ms, Vs); return 0;
+    case 3: dense_smooth_sim<3>(T, K, O, B, y, var, M, s, ms, Vs); return 0;
+    case 4: dense_smooth_sim<4>(T, K, O, B, y, var, M, s, ms, Vs); return 0;
+    default: return -3;
+  }
+}

@@ -82,6 +82,33 @@ def test_smooth_diag_matches_oracle(T, K, unit, vs_diag):
         Vd_o = np.diagonal(Vs_o, axis1=2, axis2=3)
         assert (np.abs(Vd - Vd_o) / Vd_o).max() < 1e-5
 
+@pytest.mark.parametrize('sval', [np.exp(-8.0), 0.3, 2980.0])
+def test_smooth_diag_with_variances_at_the_clip(sval):
+    """Ensemble variance 0 -> 1e-12 (eks/utils.py:373) on the scalar-chain path: whole frames,
+    single coordinates and runs of frames at the clip; posterior variances compared ELEMENTWISE
+    (they span 12 decades along time)."""
+    from eks_amd import hip_ops
+    T, K = 2500, 6
+    arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=91, unit=True)
+    var_tk = var_tk.copy()
+    var_tk[::7, :, 0] = 0.0
+    var_tk[3::11] = 1e-9
+    var_tk[1000:1040, 2] = 0.0
+    arrs['ensemble_vars'] = var_tk.astype(np.float64)
+    s = np.full(K, sval)
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    ms, Vs = hip_ops.smooth(_dev(y_tk), _dev(var_tk), *_params_dev(arrs), _dev(s), flags=flags, vs_diag=True)
+    ms = np.transpose(ms.cpu().numpy().astype(np.float64), (1, 0, 2))
+    Vs = np.transpose(Vs.cpu().numpy().astype(np.float64), (1, 0, 2))
+    # information-form oracle: the covariance-form P - K S K' cannot resolve a 1e-12 posterior
+    # variance under a 1e4 prior (its own rounding is 100 % of the result there)
+    Rd = np.maximum(np.swapaxes(arrs['ensemble_vars'], 0, 1), 1e-12)
+    ms_o, Vs_o = orc.info_form_smoother(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'],
+                                        arrs['Qs'], s, Rd)[:2]
+    assert _rel(ms, ms_o, axis_scale=(1, 2)) < 1e-5
+    Vd_o = np.diagonal(Vs_o, axis1=2, axis2=3)
+    assert (np.abs(Vs - Vd_o) / Vd_o).max() < 1e-5
+
 
 def _dense_problem(T, K, D, O, seed):
     rng = np.random.default_rng(seed)
@@ -132,6 +159,39 @@ def test_smooth_dense_matches_oracle(T, K, D, O, general_A):
             Vk = np.transpose(Vs, (1, 0, 2, 3))
             ref = Vs_o
         assert _rel(Vk, ref, axis_scale=tuple(range(1, ref.ndim))) < 1e-5
+
+@pytest.mark.parametrize('case', ['all_clipped', 'tiny', 'one_clipped'])
+@pytest.mark.parametrize('sval', [10.0, 1e-3])
+def test_smooth_dense_with_variances_at_the_clip(case, sval):
+    """Ensemble variance 0 (identical members) is clipped to 1e-12 upstream (eks/utils.py:373).
+    Whole frames at the clip / at 1e-8 are compared with the information-form oracle (the
+    covariance-form recursion itself loses 1e-2 there: cond(S) ~ 1e9 with O > D); a single
+    clipped coordinate among ordinary ones with the covariance form (the information form is the
+    inaccurate one when scales are mixed inside a frame)."""
+    from eks_amd import hip_ops
+    T, K, D, O = 1500, 3, 3, 4
+    arrs, y, var = _dense_problem(T, K, D, O, seed=77)
+    arrs['Cs'] = np.ascontiguousarray(np.linalg.qr(arrs['Cs'])[0])
+    if case == 'all_clipped':
+        var[2::9] = 0.0
+    elif case == 'tiny':
+        var[::5] = 1e-8
+    else:
+        var[::7, :, 1] = 0.0
+    rng = np.random.default_rng(5)
+    x = np.cumsum(rng.standard_normal((K, T, D)) * 0.5, axis=1)
+    y = (np.einsum('kod,ktd->tko', arrs['Cs'], x)
+         + rng.standard_normal((T, K, O)) * np.sqrt(np.maximum(var, 1e-12))).astype(np.float32)
+    arrs['ys'] = np.transpose(y, (1, 0, 2)).astype(np.float64)
+    s = np.full(K, sval)
+    ms, Vs = hip_ops.smooth(_dev(y), _dev(var), *_params_dev(arrs), _dev(s), flags=0)
+    ms = np.transpose(ms.cpu().numpy().astype(np.float64), (1, 0, 2))
+    Vs = np.transpose(Vs.cpu().numpy().astype(np.float64), (1, 0, 2, 3))
+    Rd = np.maximum(np.swapaxes(var.astype(np.float64), 0, 1), 1e-12)
+    args = (arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], s, Rd)
+    ms_o, Vs_o = orc.kalman_smoother(*args)[:2] if case == 'one_clipped' else orc.info_form_smoother(*args)[:2]
+    assert _rel(ms, ms_o, axis_scale=(1, 2)) < 1e-5
+    assert (np.abs(Vs - Vs_o) / np.abs(Vs_o).max(axis=1, keepdims=True)).max() < 1e-5
 
 
 @pytest.mark.parametrize('T,N', [(2001, 7), (2000, 70), (1, 3), (2, 5), (300, 130), (1024, 5), (1025, 66),

@@ -82,3 +82,56 @@ def test_float32_three_regime_nll_and_dual_gradient(sim, T, BN):
         np.testing.assert_array_equal(nll.argmin(axis=1), ref_nll.argmin(axis=1))
         if grad:
             assert (np.abs(dn - ref_g) / np.abs(ref_g).max(axis=1, keepdims=True)).max() < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# general (D, O) smoother: chunk elements -> scan -> exact replay, from the kernels' own headers
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def dense_sim():
+    src = os.path.join(ROOT, 'tests', 'host_sim', 'dense_sim.cpp')
+    lib = os.path.join(ROOT, 'tests', 'host_sim', 'libdense_sim.so')
+    subprocess.run(['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-I', os.path.join(ROOT, 'eks_amd', 'csrc'),
+                    src, '-o', lib], check=True)
+    return ctypes.CDLL(lib)
+
+
+@pytest.mark.parametrize('case', ['plain', 'all_clipped', 'tiny', 'one_clipped'])
+@pytest.mark.parametrize('sval', [10.0, 1e-3])
+def test_dense_chunked_smoother_matches_oracle_also_at_the_variance_clip(dense_sim, case, sval):
+    """Predict-first chunk elements keep the boundary algebra well-scaled when an ensemble variance
+    sits at the 1e-12 clip (an element that opened with such an observation gave smoothed means
+    off by 1e7).  Frames entirely at tiny variances are checked against the information-form
+    oracle: the covariance-form recursion itself is only good to 1e-2 there (cond(S) ~ 1e9)."""
+    rng = np.random.default_rng(11)
+    T, K, D, O, B = 700, 2, 3, 4, 32
+    x = np.cumsum(rng.standard_normal((K, T, D)) * 0.7, axis=1)
+    C = np.ascontiguousarray(np.linalg.qr(rng.standard_normal((K, O, D)))[0])
+    var = (0.25 * rng.gamma(2.0, 1.0, (T, K, O))).clip(1e-3).astype(np.float32)
+    if case == 'all_clipped':
+        var[2::9] = 0.0
+    elif case == 'tiny':
+        var[::5] = 1e-8
+    elif case == 'one_clipped':
+        var[::7, :, 1] = 0.0
+    y = (np.einsum('kod,ktd->tko', C, x) + rng.standard_normal((T, K, O)) * np.sqrt(np.maximum(var, 1e-12))
+         ).astype(np.float32)
+    L = rng.standard_normal((K, D, D)) * 0.3
+    Q = L @ np.swapaxes(L, 1, 2) + 0.2 * np.eye(D)
+    m0, S0, A = np.zeros((K, D)), np.tile(4 * np.eye(D), (K, 1, 1)), np.tile(np.eye(D), (K, 1, 1))
+    s = np.full(K, sval)
+    ms = np.zeros((T, K, D), np.float32)
+    Vs = np.zeros((T, K, D, D), np.float32)
+    v = ctypes.c_void_p
+    p = lambda a: a.ctypes.data_as(v)      # noqa: E731
+    assert dense_sim.sim_dense_smooth(T, K, D, O, B, p(y), p(var), p(m0), p(S0), p(A), p(C), p(Q), p(s),
+                                      p(ms), p(Vs)) == 0
+    ys = np.swapaxes(y, 0, 1).astype(np.float64)
+    Rd = np.maximum(np.swapaxes(var.astype(np.float64), 0, 1), 1e-12)
+    if case in ('plain', 'one_clipped'):
+        ms_o, Vs_o = orc.kalman_smoother(ys, m0, S0, A, C, Q, s, Rd)[:2]
+    else:
+        ms_o, Vs_o = orc.info_form_smoother(ys, m0, S0, A, C, Q, s, Rd)[:2]
+    ms_k, Vs_k = np.swapaxes(ms, 0, 1), np.swapaxes(Vs, 0, 1)
+    assert (np.abs(ms_k - ms_o) / np.abs(ms_o).max(axis=(1, 2), keepdims=True)).max() < 1e-6
+    assert (np.abs(Vs_k - Vs_o) / np.abs(Vs_o).max(axis=1, keepdims=True)).max() < 1e-6
