@@ -38,6 +38,13 @@ SIGNATURES = {
     'eks_adam_step': (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_double,
                                      c_double, c_double, c_double, c_int32, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
+    'eks_adam_run': (ctypes.c_int, [POINTER(EksDims)] + [c_void_p] * 7 + [c_int32, c_void_p, c_void_p,
+                                                                         c_double, c_double, c_double, c_double,
+                                                                         c_int32, c_int32] + [c_void_p] * 6
+                     + [c_size_t, c_void_p]),
+    'eks_pupil_adam_run': (ctypes.c_int, [POINTER(EksDims)] + [c_void_p] * 6 + [c_double, c_double, c_int32,
+                                                                               c_int32] + [c_void_p] * 9
+                           + [c_size_t, c_void_p]),
     'eks_ar1_nll_workspace_bytes': (c_size_t, [POINTER(EksDims), c_int32]),
     'eks_ar1_nll': (ctypes.c_int, [POINTER(EksDims)] + [c_void_p] * 9 + [c_int32, c_void_p, c_void_p,
                                                                         c_void_p, c_size_t, c_void_p]),

@@ -126,7 +126,7 @@ def _block_csr(blocks, K):
 
 
 def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, s_bounds_log, tol,
-                        safety_cap, min_R_var, s_mode, n_grid):
+                        safety_cap, min_R_var, s_mode, n_grid, sync_every: int = 16):
     """Returns (s per keypoint as a device float64 tensor, info dict)."""
     torch = _torch()
     y_c, var_c = P.cropped(s_frames)
@@ -155,14 +155,16 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
     offs_d = torch.as_tensor(offs, device=P.dev)
     mem_d = torch.as_tensor(members, device=P.dev)
     s_kp = torch.as_tensor(np.exp(np.clip(u0, lo, hi))[of_kp], device=P.dev)
-    n_active = torch.zeros(1, dtype=torch.int32, device=P.dev)
-    iters = 0
-    for iters in range(1, int(safety_cap) + 1):
-        nll, g = hip_ops.nll(y_c, rconst, *P.params, s_kp[:, None].contiguous(), per_keypoint=True,
-                             want_grad=True, flags=P.flags)
-        hip_ops.adam_step(offs_d, mem_d, nll[:, 0].contiguous(), g[:, 0].contiguous(), state, s_kp,
-                          n_active, lr, lo, hi, tol, safety_cap)
-        if int(n_active.item()) == 0:
+    loop = hip_ops.AdamLoop(y_c, rconst, *P.params, offs_d, mem_d, state, s_kp, lr, lo, hi, tol,
+                            safety_cap, flags=P.flags)
+    iters, cap = 0, int(safety_cap)
+    while iters < cap:
+        # several iterations per host round trip: a step enqueued after a block has stopped (or
+        # reached the cap) leaves that block untouched, so over-issuing changes nothing
+        n = min(sync_every, cap - iters)
+        loop.run(n)
+        iters += n
+        if int(loop.n_active.item()) == 0:
             break
     return s_kp, dict(mode='adam', state=state, launches=iters)
 

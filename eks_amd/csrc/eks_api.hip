@@ -148,6 +148,45 @@ int eks_pupil_adam_step(int32_t n_chains, const double* latent_var, const double
                          n_active, reinterpret_cast<hipStream_t>(stream));
 }
 
+int eks_adam_run(const eks_dims_t* d, const float* y, const double* rconst, const double* m0,
+                 const double* S0, const double* A, const double* C, const double* Q,
+                 int32_t n_blocks, const int32_t* block_offsets, const int32_t* block_members,
+                 double lr, double lo, double hi, double tol, int32_t safety_cap, int32_t n_iters,
+                 double* state, double* s_keypoint, double* nll, double* dnll, int32_t* n_active,
+                 void* workspace, size_t workspace_bytes, eks_stream_t stream) {
+  if (n_iters < 0) return EKS_ERR_SHAPE;
+  if (!dnll) return EKS_ERR_NULL;
+  for (int it = 0; it < n_iters; ++it) {
+    int rc = eks_nll(d, y, rconst, m0, S0, A, C, Q, s_keypoint, 1, 1, nll, dnll, workspace,
+                     workspace_bytes, stream);
+    if (rc != EKS_OK) return rc;
+    rc = eks_adam_step(n_blocks, block_offsets, block_members, nll, dnll, lr, lo, hi, tol, safety_cap,
+                       state, s_keypoint, n_active, stream);
+    if (rc != EKS_OK) return rc;
+  }
+  return EKS_OK;
+}
+
+int eks_pupil_adam_run(const eks_dims_t* d, const float* y, const float* var, const double* m0,
+                       const double* S0, const double* C, const double* latent_var, double lr,
+                       double tol, int32_t safety_cap, int32_t n_iters, double* state, double* a,
+                       double* q, double* da, double* dq, double* nll, double* dnll,
+                       int32_t* n_active, void* workspace, size_t workspace_bytes,
+                       eks_stream_t stream) {
+  if (n_iters < 0) return EKS_ERR_SHAPE;
+  if (d && d->state_dim != 3) return EKS_ERR_SHAPE;   // (diameter, com_x, com_y)
+  if (!nll || !dnll) return EKS_ERR_NULL;
+  for (int it = 0; it < n_iters; ++it) {
+    int rc = eks_ar1_nll(d, y, var, m0, S0, C, a, q, da, dq, 2, nll, dnll, workspace, workspace_bytes,
+                         stream);
+    if (rc != EKS_OK) return rc;
+    rc = eks_pupil_adam_step(d->n_keypoints, latent_var, nll, dnll, lr, tol, safety_cap, state, a, q,
+                             da, dq, n_active, stream);
+    if (rc != EKS_OK) return rc;
+  }
+  return EKS_OK;
+}
+
 int eks_ensemble(int32_t n_models, int32_t n_cameras, int32_t n_frames, int32_t n_keypoints,
                  const float* markers, int32_t avg_mode, int32_t var_mode, float nan_replacement,
                  float* stats, eks_stream_t stream) {

@@ -13,7 +13,9 @@
 //                           (Tried and dropped, round 1: packed fp32, a transient/steady kernel
 //                           split with LDS-staged tiles - see DESIGN.md.)
 //   N2 diag_nll_assemble  : thread = (keypoint, candidate): walks the chunk summaries in time
-//                           order in float64 and writes nll[K][n_cand] (and dnll).
+//                           order in float64 and writes nll[K][n_cand] (and dnll); with few
+//                           (keypoint, candidate) pairs - the Adam loop - a tree variant composes
+//                           the summaries in log depth instead.
 // y is read once from HBM: 4 B per chain-frame regardless of the candidate count.
 #include <hip/hip_runtime.h>
 
@@ -135,6 +137,122 @@ __global__ __launch_bounds__(256) void diag_nll_assemble_kernel(NllGeom G, DiagM
   if constexpr (GRAD) dnll[(size_t)k * G.n_cand + ci] = fin ? -der(tot) : 0.0;
 }
 
+// N2' tree variant for few chain-streams (the Adam loop: one candidate per keypoint, ~200 chunk
+// summaries per chain): block = (64 lanes, D chains of one (keypoint, candidate)).  Each lane
+// composes a contiguous run of chunk elements, the 64 partial elements are composed in time order
+// by a 6-level tree through LDS, lane 0 pushes the prior through the result; the D chain
+// log-likelihoods are summed through LDS.  Depth ~ ncn/64 + 6 compositions instead of ncn.
+template <typename RD>
+struct NllAcc {
+  Elem<RD> e;
+  RD ell;
+};
+
+template <typename RD>
+__device__ inline NllAcc<RD> nll_acc_combine(const NllAcc<RD>& i, const NllAcc<RD>& j) {
+  const RD den = RD(1.0) + i.e.C * j.e.J;
+  const RD inv = rcp(den);
+  NllAcc<RD> o;
+  o.ell = i.ell + j.ell - RD(0.5) * log_with_rcp(den, inv) +
+          (j.e.eta * i.e.b + RD(0.5) * j.e.eta * j.e.eta * i.e.C - RD(0.5) * j.e.J * i.e.b * i.e.b) * inv;
+  o.e = elem_combine(i.e, j.e);
+  return o;
+}
+
+constexpr int kAsmLanes = 64;
+
+template <bool GRAD>
+__global__ void diag_nll_assemble_tree_kernel(NllGeom G, DiagModel M, NllWs W, int K,
+                                              double* __restrict__ nll, double* __restrict__ dnll) {
+  using RD = typename std::conditional<GRAD, DualD, double>::type;
+  constexpr int NF = GRAD ? 12 : 6;
+  extern __shared__ double lds[];                 // [D][NF][64] + [D][2]
+  const int i = threadIdx.x, d = threadIdx.y;
+  const int k = blockIdx.x % K, ci = blockIdx.x / K;
+  const int n = k * G.D + d;
+  double* my = lds + (size_t)d * NF * kAsmLanes;
+  auto get = [&](int j) {
+    const size_t o = ((size_t)j * W.ncp + ci) * G.N + n;
+    NllAcc<RD> a;
+    if constexpr (GRAD) {
+      a.e.A = DualD(W.A[o], W.dA[o]);
+      a.e.b = DualD(W.b[o], W.db[o]);
+      a.e.C = DualD(W.C[o], W.dC[o]);
+      a.e.eta = DualD(W.eta[o], W.deta[o]);
+      a.e.J = DualD(W.J[o], W.dJ[o]);
+      a.ell = DualD(W.ell[o], W.dell[o]);
+    } else {
+      a.e.A = W.A[o];
+      a.e.b = W.b[o];
+      a.e.C = W.C[o];
+      a.e.eta = W.eta[o];
+      a.e.J = W.J[o];
+      a.ell = W.ell[o];
+    }
+    return a;
+  };
+  auto put = [&](int slot, const NllAcc<RD>& a) {
+    const RD f[6] = {a.e.A, a.e.b, a.e.C, a.e.eta, a.e.J, a.ell};
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      my[q * kAsmLanes + slot] = val(f[q]);
+      if constexpr (GRAD) my[(6 + q) * kAsmLanes + slot] = der(f[q]);
+    }
+  };
+  auto take = [&](int slot) {
+    RD f[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      if constexpr (GRAD)
+        f[q] = DualD(my[q * kAsmLanes + slot], my[(6 + q) * kAsmLanes + slot]);
+      else
+        f[q] = my[q * kAsmLanes + slot];
+    }
+    NllAcc<RD> a;
+    a.e.A = f[0]; a.e.b = f[1]; a.e.C = f[2]; a.e.eta = f[3]; a.e.J = f[4]; a.ell = f[5];
+    return a;
+  };
+  const int per = (G.ncn + kAsmLanes - 1) / kAsmLanes;
+  const int j0 = i * per, j1 = min(G.ncn, j0 + per);
+  const int nlive = (G.ncn + per - 1) / per;      // lanes that own at least one chunk
+  NllAcc<RD> acc;
+  if (j0 < j1) {
+    acc = get(j0);
+    for (int j = j0 + 1; j < j1; ++j) acc = nll_acc_combine(acc, get(j));
+  }
+  for (int half = 1; half < nlive; half <<= 1) {
+    const int span = half << 1;
+    const bool send = (i & (span - 1)) == half && i < nlive;
+    const bool recv = (i & (span - 1)) == 0 && i + half < nlive;
+    if (send) put(i, acc);
+    __syncthreads();
+    if (recv) acc = nll_acc_combine(acc, take(i + half));
+  }
+  double* tot = lds + (size_t)G.D * NF * kAsmLanes;
+  if (i == 0) {
+    const size_t dd = (size_t)k * G.D * G.D + (size_t)d * (G.D + 1);
+    const RD m = RD(M.m0[(size_t)k * G.D + d]), P = RD(M.S0[dd]);
+    const RD den = RD(1.0) + acc.e.J * P;
+    const RD inv = rcp(den);
+    const RD ll = acc.ell - RD(0.5) * log_with_rcp(den, inv) +
+                  (acc.e.eta * m + RD(0.5) * acc.e.eta * acc.e.eta * P - RD(0.5) * acc.e.J * m * m) * inv;
+    tot[2 * d] = val(ll);
+    tot[2 * d + 1] = der(ll);
+  }
+  __syncthreads();
+  if (i == 0 && d == 0) {
+    double v = 0.0, g = 0.0;
+    for (int q = 0; q < G.D; ++q) {
+      v += tot[2 * q];
+      g += tot[2 * q + 1];
+    }
+    v = -v;
+    const bool fin = isfinite(v);              // eks/core.py:650
+    nll[(size_t)k * G.n_cand + ci] = fin ? v : 1e12;
+    if constexpr (GRAD) dnll[(size_t)k * G.n_cand + ci] = fin ? -g : 0.0;
+  }
+}
+
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
@@ -250,6 +368,18 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
 #undef EKS_NLL_LAUNCH
   const int total = K * n_cand;
   ProfScope ps2("diag_nll_assemble", st);
+  // few (keypoint, candidate) pairs and many chunks: compose the chunk summaries by a tree
+  if ((long)total * D <= 8192 && G.ncn >= 8 && D <= 16 && !env_int("EKS_NLL_ASSEMBLE_SEQ", 0)) {
+    const dim3 tb(kAsmLanes, D);
+    const size_t shm = ((size_t)D * (grad ? 12 : 6) * kAsmLanes + 2 * D) * sizeof(double);
+    if (grad)
+      hipLaunchKernelGGL(diag_nll_assemble_tree_kernel<true>, dim3(total), tb, shm, st, G, M, W, K, nll,
+                         dnll);
+    else
+      hipLaunchKernelGGL(diag_nll_assemble_tree_kernel<false>, dim3(total), tb, shm, st, G, M, W, K,
+                         nll, dnll);
+    return hip_status(hipGetLastError());
+  }
   if (grad)
     hipLaunchKernelGGL(diag_nll_assemble_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, st, G,
                        M, W, K, nll, dnll);

@@ -162,6 +162,41 @@ def adam_step(block_offsets, block_members, nll_k, dnll_k, state, s_keypoint, n_
     _lib.check(rc, 'eks_adam_step')
 
 
+class AdamLoop:
+    """eks_adam_run with every buffer allocated once (reference eks/core.py:654-681 / :520-549):
+    `run(n)` enqueues n iterations of loss + gradient + Adam step without touching the host."""
+
+    def __init__(self, y, rconst, m0, S0, A, C, Q, block_offsets, block_members, state, s_keypoint, lr,
+                 lo, hi, tol, safety_cap, flags: int = 0):
+        self.lib = _lib.load()
+        T, K, O = y.shape
+        D = m0.shape[-1]
+        self.bufs = [_chk(y, torch.float32, 'y'), _chk(rconst, torch.float64, 'rconst', (K, O)),
+                     _chk(m0, torch.float64, 'm0', (K, D)), _chk(S0, torch.float64, 'S0', (K, D, D)),
+                     _chk(A, torch.float64, 'A', (K, D, D)), _chk(C, torch.float64, 'C', (K, O, D)),
+                     _chk(Q, torch.float64, 'Q', (K, D, D))]
+        self.offs = _chk(block_offsets, torch.int32, 'block_offsets')
+        self.members = _chk(block_members, torch.int32, 'block_members', (K,))
+        self.nb = self.offs.numel() - 1
+        self.state = _chk(state, torch.float64, 'state', (self.nb, 6))
+        self.s_keypoint = _chk(s_keypoint, torch.float64, 's_keypoint', (K,))
+        self.opt = (float(lr), float(lo), float(hi), float(tol), int(safety_cap))
+        dev = y.device
+        self.nll = torch.empty(K, dtype=torch.float64, device=dev)
+        self.dnll = torch.empty(K, dtype=torch.float64, device=dev)
+        self.n_active = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.dims = _dims(K, T, D, O, flags)
+        self.ws = _workspace(self.lib.eks_nll_workspace_bytes(ctypes.byref(self.dims), 1), dev)
+
+    def run(self, n_iters: int) -> None:
+        rc = self.lib.eks_adam_run(ctypes.byref(self.dims), *[_ptr(b) for b in self.bufs], self.nb,
+                                   _ptr(self.offs), _ptr(self.members), *self.opt, int(n_iters),
+                                   _ptr(self.state), _ptr(self.s_keypoint), _ptr(self.nll),
+                                   _ptr(self.dnll), _ptr(self.n_active), _ptr(self.ws), self.ws.numel(),
+                                   _stream())
+        _lib.check(rc, 'eks_adam_run')
+
+
 def ensemble(markers, avg_mode: str = 'median', var_mode: str = 'confidence_weighted_var',
              nan_replacement: float = 1000.0):
     """eks_ensemble: (M, V, T, K, 3) float32 -> (V, T, K, 5) float32."""
@@ -229,3 +264,13 @@ def pupil_adam_step(loss: Ar1Loss, latent_var, state, n_active, lr, tol, safety_
                                       int(safety_cap), _ptr(state), _ptr(loss.a), _ptr(loss.q),
                                       _ptr(loss.da), _ptr(loss.dq), _ptr(n_active), _stream())
     _lib.check(rc, 'eks_pupil_adam_step')
+
+
+def pupil_adam_run(loss: Ar1Loss, latent_var, state, n_active, lr, tol, safety_cap, n_iters: int):
+    """eks_pupil_adam_run: n_iters x (loss + 2 sensitivities + Adam step) in one call."""
+    rc = loss.lib.eks_pupil_adam_run(ctypes.byref(loss.dims), _ptr(loss.y), _ptr(loss.var), _ptr(loss.m0),
+                                     _ptr(loss.S0), _ptr(loss.C), _ptr(latent_var), float(lr), float(tol),
+                                     int(safety_cap), int(n_iters), _ptr(state), _ptr(loss.a), _ptr(loss.q),
+                                     _ptr(loss.da), _ptr(loss.dq), _ptr(loss.nll), _ptr(loss.dnll),
+                                     _ptr(n_active), _ptr(loss.ws), loss.ws.numel(), _stream())
+    _lib.check(rc, 'eks_pupil_adam_run')

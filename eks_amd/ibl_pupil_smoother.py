@@ -212,8 +212,8 @@ def _to_stable_s(u, eps: float = 1e-3):
 
 def _optimize_on_device(P: _PupilProblem, s_frames, lr, tol, safety_cap, sync_every: int = 32):
     """Adam on u = logit-like reparametrisation of (s_diam, s_com), entirely on the device:
-    eks_ar1_nll (loss + 2 sensitivities) -> eks_pupil_adam_step, `sync_every` iterations per
-    host round trip (steps enqueued after convergence leave the state untouched).
+    eks_pupil_adam_run = { eks_ar1_nll (loss + 2 sensitivities) -> eks_pupil_adam_step } x
+    `sync_every` per host round trip (steps enqueued after convergence leave the state untouched).
     Returns (s_d, s_c, info)."""
     torch = _torch()
     y_c, var_c = P.cropped(s_frames)
@@ -228,10 +228,9 @@ def _optimize_on_device(P: _PupilProblem, s_frames, lr, tol, safety_cap, sync_ev
     hip_ops.pupil_adam_step(loss, latent, state, n_active, lr, tol, safety_cap, init=True)
     launched = 0
     while launched < int(safety_cap):
-        for _ in range(min(sync_every, int(safety_cap) - launched)):
-            loss.evaluate()
-            hip_ops.pupil_adam_step(loss, latent, state, n_active, lr, tol, safety_cap)
-            launched += 1
+        n = min(sync_every, int(safety_cap) - launched)
+        hip_ops.pupil_adam_run(loss, latent, state, n_active, lr, tol, safety_cap, n)
+        launched += n
         if int(n_active.item()) == 0:
             break
     st = state.cpu().numpy()[0]

@@ -103,6 +103,19 @@ int eks_adam_step(int32_t n_blocks, const int32_t* block_offsets, const int32_t*
                   double tol, int32_t safety_cap, double* state, double* s_keypoint,
                   int32_t* n_active, eks_stream_t stream);
 
+/* ---- n_iters iterations of { eks_nll (one s per keypoint, with dnll) -> eks_adam_step } enqueued
+ * back to back: the body of the lax.while_loop of eks/core.py:654-681 (:520-549 for blocks) without
+ * a host round trip per iteration.  Arguments as in eks_nll / eks_adam_step; s_keypoint [K] is
+ * both the evaluation point and the step's output; nll, dnll [K] hold the last evaluation.
+ * Iterations enqueued after a block has stopped leave it untouched, so the caller may issue
+ * n_iters at a time and read *n_active in between.  workspace: eks_nll_workspace_bytes(dims, 1). */
+int eks_adam_run(const eks_dims_t* dims, const float* y, const double* rconst, const double* m0,
+                 const double* S0, const double* A, const double* C, const double* Q,
+                 int32_t n_blocks, const int32_t* block_offsets, const int32_t* block_members,
+                 double lr, double lo, double hi, double tol, int32_t safety_cap, int32_t n_iters,
+                 double* state, double* s_keypoint, double* nll, double* dnll, int32_t* n_active,
+                 void* workspace, size_t workspace_bytes, eks_stream_t stream);
+
 /* ---- IBL pupil smoother, eks/ibl_pupil_smoother.py:363-607.
  * Independent chains k < n_keypoints (one per session), AR(1) dynamics A_k = diag(a[k][:]),
  * process noise diag(q[k][:]), observation matrix C [K][O][D], TIME-VARYING R_t = diag(max(var,
@@ -129,6 +142,17 @@ int eks_pupil_adam_step(int32_t n_chains, const double* latent_var, const double
                         const double* dnll, double lr, double tol, int32_t safety_cap,
                         double* state, double* a, double* q, double* da, double* dq,
                         int32_t* n_active, eks_stream_t stream);
+
+/* ---- n_iters iterations of { eks_ar1_nll (2 tangents) -> eks_pupil_adam_step } enqueued back to
+ * back (the while_loop of :571-594).  a, q, da, dq must have been initialised by
+ * eks_pupil_adam_step(nll = NULL).  nll [n], dnll [2][n] hold the last evaluation.
+ * workspace: eks_ar1_nll_workspace_bytes(dims, 2). ------------------------------------------ */
+int eks_pupil_adam_run(const eks_dims_t* dims, const float* y, const float* var, const double* m0,
+                       const double* S0, const double* C, const double* latent_var, double lr,
+                       double tol, int32_t safety_cap, int32_t n_iters, double* state, double* a,
+                       double* q, double* da, double* dq, double* nll, double* dnll,
+                       int32_t* n_active, void* workspace, size_t workspace_bytes,
+                       eks_stream_t stream);
 
 /* ---- ensemble statistics, eks/core.py:25-101: markers float32 [M][V][T][K][3] (x,y,likelihood)
  * -> stats float32 [V][T][K][5] (x, y, var_x, var_y, likelihood).  avg_mode 0 median / 1 mean,

@@ -1,5 +1,5 @@
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eks_amd import synth, hip_ops, _lib
 from eks_amd.core import _DeviceProblem, _optimize_on_device
 dev = torch.device('cuda', 0)
