@@ -30,6 +30,8 @@ constexpr int kNllChunk = 4096;      // frames per lane, grid mode (measured bes
 constexpr int kNllChunkGrad = 512;   // frames per lane, Adam mode (one candidate: needs more lanes)
 constexpr int kNclGrid = 8;
 constexpr int kNllChunkMin = 2048;
+constexpr int kNllChunk0 = 1024;     // frames in chunk 0, grid mode (C3: 768 0.253 ms, 1024 0.267, 1536 0.287,
+                                     // 3200 0.341; 512 0.342 - chunk 1 then starts before the variance converged)
 
 struct NllWs {
   // planes indexed [(j * ncp + c) * N + n]
@@ -41,7 +43,9 @@ struct NllWs {
 
 struct NllGeom {
   int N, T, D, ncn, BN;
+  int B0;                // frames in chunk 0 (chunk j >= 1 covers [B0 + (j-1) BN, B0 + j BN))
   int nt_log2, ntile, ngrp, n_cand, per_keypoint;
+  int converged_entry;   // chunks j >= 1 may assume the filter variance has converged (float path)
 };
 
 template <typename R, int NCL, bool UNIT>
@@ -71,10 +75,11 @@ __global__ __launch_bounds__(512) void diag_nll_summarize_kernel(NllGeom G, Diag
     const double s = G.per_keypoint ? s_cand[(size_t)k * G.n_cand + ci] : s_cand[ci];
     sq[c] = s * q;
   }
-  const int t0 = j * G.BN;
-  const int len = min(G.BN, G.T - t0);
+  const int t0 = j == 0 ? 0 : G.B0 + (j - 1) * G.BN;
+  const int len = j == 0 ? min(G.B0, G.T) : min(G.BN, G.T - t0);
   NllElem<R> out[NCL];
-  nll_summarize_chunk<R, NCL, UNIT>(y, G.N, n, t0, len, rconst[n], M.A[dd], M.C[dd], sq, out);
+  nll_summarize_chunk<R, NCL, UNIT>(y, G.N, n, t0, len, rconst[n], M.A[dd], M.C[dd], sq, out,
+                                    G.converged_entry != 0);
 #pragma unroll
   for (int c = 0; c < NCL; ++c) {
     const int ci = g * NCL + c;
@@ -264,9 +269,10 @@ static NllGeom make_geom(int T, int N, int D, int n_cand, int per_keypoint, bool
   G.T = T;
   G.D = D;
   G.BN = grad ? kNllChunkGrad : kNllChunk;
+  G.B0 = G.BN;
   if (!grad) {
     // one block per (64-chain tile, chunk): pick the chunk length so that the grid is a whole
-    // number of 256-CU rounds (C3: 8 tiles x 32 chunks of 3136 frames = 256 blocks)
+    // number of 256-CU rounds (C3: 8 tiles x 32 chunks = 256 blocks)
     const int ntile64 = (N + 63) / 64;
     long rounds = ((long)T * ntile64 + 128L * kNllChunk) / (256L * kNllChunk);
     if (rounds < 1) rounds = 1;
@@ -278,8 +284,20 @@ static NllGeom make_geom(int T, int N, int D, int n_cand, int per_keypoint, bool
                                                 // per chunk) and transient work
     G.BN = env_int("EKS_NLL_CHUNK", bn);
     if (G.BN < kNllChunkGrad) G.BN = kNllChunkGrad;
+    G.B0 = G.BN;
+    // Chunk 0 is the only one that always pays the start-up transient (its element starts from a
+    // known state; later chunks enter with the converged variance, nll_summarize_chunk), so it is
+    // kept shorter than the others - its block must not be the one every other block waits for -
+    // and the other chunks share the remaining frames so that the block count is unchanged.
+    const long nch = (T + G.BN - 1) / G.BN;
+    const int b0 = env_int("EKS_NLL_CHUNK0", kNllChunk0);
+    if (nch >= 3 && b0 < G.BN && !getenv("EKS_NLL_CHUNK")) {
+      G.B0 = b0;
+      G.BN = (int)((T - b0 + nch - 2) / (nch - 1));
+      G.BN = (G.BN + 63) / 64 * 64;
+    }
   }
-  G.ncn = (T + G.BN - 1) / G.BN;
+  G.ncn = T <= G.B0 ? 1 : 1 + (T - G.B0 + G.BN - 1) / G.BN;
   int nt_log2 = 0;
   while ((1 << nt_log2) < N && nt_log2 < 6) ++nt_log2;
   G.nt_log2 = nt_log2;
@@ -287,6 +305,7 @@ static NllGeom make_geom(int T, int N, int D, int n_cand, int per_keypoint, bool
   G.n_cand = n_cand;
   G.ngrp = (n_cand + ncl - 1) / ncl;
   G.per_keypoint = per_keypoint;
+  G.converged_entry = 0;
   return G;
 }
 
@@ -302,7 +321,7 @@ static inline int pick_ncl(int n_cand, bool grad) {
 
 size_t diag_nll_workspace_bytes(int T, int N, int n_cand) {
   // sized for the larger of the two modes (grad planes + smaller chunks)
-  const int ncn = (T + kNllChunkGrad - 1) / kNllChunkGrad;
+  const int ncn = (T + kNllChunkGrad - 1) / kNllChunkGrad + 1;
   const size_t ncp = align_up((size_t)n_cand, kNclGrid);
   const size_t fl = align_up((size_t)ncn * ncp * N * sizeof(float), 256);
   const size_t db = align_up((size_t)ncn * ncp * N * sizeof(double), 256);
@@ -316,7 +335,12 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
   if (ws_bytes < diag_nll_workspace_bytes(T, N, n_cand)) return EKS_ERR_WORKSPACE;
   const bool grad = dnll != nullptr;
   const int ncl = pick_ncl(n_cand, grad);
-  const NllGeom G = make_geom(T, N, D, n_cand, per_keypoint, grad, ncl);
+  NllGeom G = make_geom(T, N, D, n_cand, per_keypoint, grad, ncl);
+  // few (keypoint, candidate) pairs and many chunks: the chunk summaries are composed by a tree
+  // (which cannot take converged-entry summaries: they are only valid in sequential order)
+  const bool tree = (long)K * n_cand * D <= 8192 && G.ncn >= 8 && D <= 16 &&
+                    !env_int("EKS_NLL_ASSEMBLE_SEQ", 0);
+  G.converged_entry = !grad && !tree && !env_int("EKS_NLL_EXACT_ENTRY", 0);
   NllWs W;
   W.ncp = G.ngrp * ncl;
   const size_t fl = align_up((size_t)G.ncn * W.ncp * N * sizeof(float), 256);
@@ -368,8 +392,7 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
 #undef EKS_NLL_LAUNCH
   const int total = K * n_cand;
   ProfScope ps2("diag_nll_assemble", st);
-  // few (keypoint, candidate) pairs and many chunks: compose the chunk summaries by a tree
-  if ((long)total * D <= 8192 && G.ncn >= 8 && D <= 16 && !env_int("EKS_NLL_ASSEMBLE_SEQ", 0)) {
+  if (tree) {
     const dim3 tb(kAsmLanes, D);
     const size_t shm = ((size_t)D * (grad ? 12 : 6) * kAsmLanes + 2 * D) * sizeof(double);
     if (grad)

@@ -262,10 +262,21 @@ EKS_HD void nll_lane_finish(NllLane<R, NCL, UNIT>& L, int len, NllElem<R>* out) 
 
 // One lane: chunk [t0, t0+len) of chain n for NCL candidates.  y: [T][N] float.
 // sq[c] = s_c * q of the chain (value; its derivative w.r.t. log s is itself).
+//
+// allow_converged_entry: for a chunk that starts deep enough into the sequence (t0 frames in) the
+// TRUE filter's predicted variance has long reached the Riccati fixed point P_inf - with constant
+// R it does not depend on the data - so the chunk can be summarised for an entering belief
+// N(m_in, P_inf) instead of a known x_in: the gains are the steady ones from the first frame, the
+// innovations are d_t = d0_t - c m_in rho^t with d0 the zero-start sequence, and
+//   sum d_t^2 = S0 - 2 c m_in S1 + c^2 m_in^2 S2,   S1 = sum d0_t rho^t,  S2 = sum rho^2t.
+// No transient regimes at all: four FMAs per frame and candidate while rho^t is alive, two after.
+// Such a summary is marked by C = -1 and carries eta = c S1 / S_inf, J = c^2 S2 / S_inf; it is
+// only valid in a strictly sequential assembly (nll_assemble), where P is P_inf when it is used.
+// Taken only when every lane of the wave has rho^(2 t0) < 1e-20 and rho^t dies inside the chunk.
 template <typename R, int NCL, bool UNIT>
 EKS_HD void nll_summarize_chunk(const float* __restrict__ y, int N, int n, int t0, int len,
                                 double r_d, double a_d, double c_d, const double* sq_d,
-                                NllElem<R>* out) {
+                                NllElem<R>* out, bool allow_converged_entry = false) {
   NllLane<R, NCL, UNIT> L;
   nll_lane_init<R, NCL, UNIT>(L, r_d, a_d, c_d, sq_d);
   const float af = (float)a_d;
@@ -273,8 +284,95 @@ EKS_HD void nll_summarize_chunk(const float* __restrict__ y, int N, int n, int t
   const size_t rs = (size_t)N;
   const int nfull = len / 8;
   int blk = 0;
-  // ---- transient: 8-frame blocks with per-candidate regimes until every candidate is steady
   bool steady = false;
+  if constexpr (sizeof(R) == sizeof(float)) {
+    bool ok = allow_converged_entry && t0 > 0;
+    float rho[NCL];
+#pragma unroll
+    for (int k = 0; k < NCL; ++k) {
+      rho[k] = UNIT ? (1.f - L.tI[k]) : L.pc[k].a * (1.f - L.pc[k].c * L.tI[k]);
+      const float nl = -logf(fmaxf(fabsf(rho[k]), 1e-30f));         // -ln |rho| > 0
+      // rho^(2 t0) < 1e-20, and rho^t < kDeadA well inside the whole 8-frame blocks of the chunk
+      ok = ok && fabsf(rho[k]) < 1.f && 2.f * (float)t0 * nl > 46.f &&
+           18.5f / nl + 48.f < (float)(nfull * 8);
+    }
+    if (EKS_WAVE_ALL(ok)) {
+      float dk[NCL], w[NCL];
+      double s1acc[NCL];
+#pragma unroll
+      for (int k = 0; k < NCL; ++k) {
+        dk[k] = 0.f;
+        w[k] = 1.f;
+        s1acc[k] = 0.0;
+      }
+      float yprev = 0.f;            // d0_0 = y_0: the zero-start prediction of frame 0 is 0
+      float s1[NCL], s2[NCL];
+#pragma unroll
+      for (int k = 0; k < NCL; ++k) s1[k] = s2[k] = 0.f;
+      auto eat4 = [&](const float (&yy)[8]) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float dy = UNIT ? (yy[q] - yprev) : (yy[q] - af * yprev);
+          yprev = yy[q];
+#pragma unroll
+          for (int k = 0; k < NCL; ++k) {
+            dk[k] = rho[k] * dk[k] + dy;
+            s2[k] += dk[k] * dk[k];
+            s1[k] += dk[k] * w[k];
+            w[k] *= rho[k];
+          }
+        }
+      };
+      // pairs of 8-frame blocks, the second in flight while the first is consumed; partial sums
+      // go to float64 and the rho^t trackers are examined every 32 frames
+      float ya[8], yb[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) ya[q] = yp[(size_t)q * rs];
+      bool alive = true;
+      while (alive && blk + 2 <= nfull) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) yb[q] = yp[(size_t)((blk + 1) * 8 + q) * rs];
+        eat4(ya);
+        if (blk + 2 < nfull) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) ya[q] = yp[(size_t)((blk + 2) * 8 + q) * rs];
+        }
+        eat4(yb);
+        blk += 2;
+        if ((blk & 2) == 0 || blk + 2 > nfull) {
+          bool dead = true;
+#pragma unroll
+          for (int k = 0; k < NCL; ++k) {
+            L.acc2[k].add(s2[k]);
+            s1acc[k] += (double)s1[k];
+            s1[k] = s2[k] = 0.f;
+            dead = dead && fabsf(w[k]) < L.kDeadA;
+          }
+          alive = !EKS_WAVE_ALL(dead);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NCL; ++k) {
+        L.phase[k] = 2;
+        L.n_post[k] = blk * 8;
+        L.dl[k] = dk[k];
+        L.e[k].A = 0.f;
+        L.e[k].C = -1.f;                                           // converged-entry marker
+        L.e[k].eta = (float)(s1acc[k] * (double)L.cgI[k]);
+        const float c_cg = UNIT ? L.cgI[k] : L.pc[k].c * L.cgI[k];
+        L.e[k].J = c_cg / (1.f - rho[k] * rho[k]);
+        if (UNIT) {
+          L.e[k].b = yprev - rho[k] * dk[k];
+        } else {
+          const float bprev = (yprev - dk[k]) / L.pc[k].c;
+          L.e[k].b = L.pc[k].a * (bprev + L.tI[k] * dk[k]);
+        }
+      }
+      L.y_last = yprev;
+      steady = true;
+    }
+  }
+  // ---- transient: 8-frame blocks with per-candidate regimes until every candidate is steady
   while (blk < nfull && !steady) {
     float yb[8];
 #pragma unroll
@@ -370,6 +468,11 @@ EKS_HD RD nll_assemble(int nchunks, double m0, double S0, Getter get) {
     Elem<RD> e;
     RD ell;
     get(j, e, ell);
+    if (val(e.C) < 0.0) {     // converged-entry summary (nll_summarize_chunk): P is P_inf here
+      ll = ll + ell + e.eta * m - RD(0.5) * e.J * m * m;
+      m = e.A * m + e.b;
+      continue;
+    }
     const RD den = RD(1.0) + e.J * P;
     const RD inv = rcp(den);
     ll = ll + ell - RD(0.5) * log_with_rcp(den, inv) +

@@ -70,7 +70,7 @@ extern "C" int sim_diag_smooth(int T, int N, int D, int B, int unit, const float
 #include "eks_nll_lane.hpp"
 
 template <typename R, typename RD, int NCL>
-static void run_nll(int T, int N, int D, int BN, bool unit, const float* y, const double* rconst,
+static void run_nll(int T, int N, int D, int BN, bool unit, bool conv, const float* y, const double* rconst,
                     const DiagModel& M, const double* s_cand, int n_cand, int per_kp, double* nll,
                     double* dnll) {
   const int K = N / D;
@@ -91,9 +91,9 @@ static void run_nll(int T, int N, int D, int BN, bool unit, const float* y, cons
         const int t0 = j * BN, len = std::min(BN, T - t0);
         NllElem<R>* o = &el[(((size_t)j * N + n) * ngrp + g) * NCL];
         if (unit)
-          nll_summarize_chunk<R, NCL, true>(y, N, n, t0, len, rconst[n], M.A[dd], M.C[dd], sq, o);
+          nll_summarize_chunk<R, NCL, true>(y, N, n, t0, len, rconst[n], M.A[dd], M.C[dd], sq, o, conv);
         else
-          nll_summarize_chunk<R, NCL, false>(y, N, n, t0, len, rconst[n], M.A[dd], M.C[dd], sq, o);
+          nll_summarize_chunk<R, NCL, false>(y, N, n, t0, len, rconst[n], M.A[dd], M.C[dd], sq, o, conv);
       }
   for (int k = 0; k < K; ++k)
     for (int ci = 0; ci < n_cand; ++ci) {
@@ -117,18 +117,20 @@ static void run_nll(int T, int N, int D, int BN, bool unit, const float* y, cons
     }
 }
 
+// grad: 0 value only (float lanes; the converged-entry summaries of chunks j >= 1 allowed, as in
+// diag_nll with the sequential assembly), 1 dual numbers, 2 value only with exact-entry summaries
 extern "C" int sim_diag_nll(int T, int N, int D, int BN, int unit, int grad, const float* y,
                             const double* rconst, const double* m0, const double* S0,
                             const double* A, const double* C, const double* Q,
                             const double* s_cand, int n_cand, int per_kp, double* nll,
                             double* dnll) {
   DiagModel M{m0, S0, A, C, Q, nullptr, D};
-  if (grad) {
-    if (n_cand >= 8) run_nll<Dual, DualD, 8>(T, N, D, BN, unit, y, rconst, M, s_cand, n_cand, per_kp, nll, dnll);
-    else run_nll<Dual, DualD, 1>(T, N, D, BN, unit, y, rconst, M, s_cand, n_cand, per_kp, nll, dnll);
+  if (grad == 1) {
+    if (n_cand >= 8) run_nll<Dual, DualD, 8>(T, N, D, BN, unit, false, y, rconst, M, s_cand, n_cand, per_kp, nll, dnll);
+    else run_nll<Dual, DualD, 1>(T, N, D, BN, unit, false, y, rconst, M, s_cand, n_cand, per_kp, nll, dnll);
   } else {
-    if (n_cand >= 8) run_nll<float, double, 8>(T, N, D, BN, unit, y, rconst, M, s_cand, n_cand, per_kp, nll, nullptr);
-    else run_nll<float, double, 1>(T, N, D, BN, unit, y, rconst, M, s_cand, n_cand, per_kp, nll, nullptr);
+    if (n_cand >= 8) run_nll<float, double, 8>(T, N, D, BN, unit, grad == 0, y, rconst, M, s_cand, n_cand, per_kp, nll, nullptr);
+    else run_nll<float, double, 1>(T, N, D, BN, unit, grad == 0, y, rconst, M, s_cand, n_cand, per_kp, nll, nullptr);
   }
   return 0;
 }

@@ -1,0 +1,29 @@
+"""How much of diag_nll_summarize is transient work?  Times eks_nll on the C3 shape for candidate
+grids that are all fast (large s), all slow (small s) and the real 64-point grid."""
+import os, sys, ctypes
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from eks_amd import synth, hip_ops, _lib
+dev = torch.device('cuda', 0)
+T, K = 100000, 256
+y, var = synth.singlecam_observations_torch(T, K, seed=3, device=dev)
+eye = torch.eye(2, dtype=torch.float64, device=dev).expand(K, 2, 2).contiguous()
+m0 = torch.zeros(K, 2, dtype=torch.float64, device=dev)
+S0 = torch.diag_embed(y.double().var(dim=0, unbiased=False)).contiguous()
+flags = _lib.FLAG_DIAG_MODEL | _lib.FLAG_UNIT_AC
+rc = hip_ops.const_r(var, 1e-4)
+lib = _lib.load()
+def drain():
+    buf = ctypes.create_string_buffer(1 << 16); ms = (ctypes.c_float * 4096)()
+    n = lib.eks_profile_drain(buf, len(buf), ms, 4096)
+    names = buf.raw.split(b'\0')[:n]; out = {}
+    for nm, t in zip(names, list(ms)[:n]): out.setdefault(nm.decode(), []).append(float(t))
+    return {k: float(np.mean(v)) for k, v in out.items()}
+for name, lo, hi in (('real grid -8..8', -8, 8), ('fast 2..8', 2, 8), ('mid -2..2', -2, 2), ('slow -8..-6', -8, -6),
+                     ('slowest -8', -8, -8), ('-4', -4, -4), ('0', 0, 0)):
+    cand = torch.exp(torch.linspace(lo, hi, 64, dtype=torch.float64, device=dev))
+    for _ in range(3): hip_ops.nll(y, rc, m0, S0, eye, eye, eye, cand, flags=flags)
+    torch.cuda.synchronize(); drain(); lib.eks_profile_enable(1)
+    for _ in range(10): hip_ops.nll(y, rc, m0, S0, eye, eye, eye, cand, flags=flags)
+    torch.cuda.synchronize(); lib.eks_profile_enable(0)
+    print(name, drain(), flush=True)
