@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cstdlib>
 
 #include "eks_internal.hpp"
 
@@ -12,7 +13,6 @@ namespace eks {
 // constant R: rconst[n] = max(nanmedian_t max(var[t][n], 1e-12), min_var)     (eks/core.py:702-709)
 // Exact selection on the float bit patterns (positive floats order like their bits).
 // ==========================================================================================
-constexpr int kMedWaves = 16;  // waves per block of the two full passes
 
 __device__ __forceinline__ uint32_t var_key(float v, bool& valid) {
   valid = !(v != v);
@@ -21,31 +21,39 @@ __device__ __forceinline__ uint32_t var_key(float v, bool& valid) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Fast path (T > kMedCap): two full passes instead of five.
-//   B0 sample   : 256 evenly spaced rows per chain; the sample's order statistics 4 sigma either
-//                 side of its median bracket the true median: [lo, hi] holds ~25 % of the frames.
-//   B1 hist     : full pass; frames below lo are counted, frames inside [lo, hi] go to 256 linear
-//                 bins of the KEY range (LDS histograms as above).
-//   B2 narrow   : per chain, the bin(s) holding the two middle ranks -> [lo2, hi2] (~100 frames).
-//   B3 collect  : full pass; frames inside [lo2, hi2] are appended to a per-chain list.
-//   B4 finish   : exact selection of the middle ranks inside the list (rank by counting in LDS).
-// A chain whose bracket misses the median, or whose bin holds more than kMedCap frames (heavy
-// duplicates), is flagged and served by median_column_kernel: one block per flagged chain, an
-// MSB-first radix select (4 x 8 bits + one sweep for the upper middle of even counts) over the
+// Fast path (T > kMedSmall): ONE full pass over var.
+//   S1 sample  : ~4096 evenly spaced rows, transposed through LDS into per-chain sample columns
+//                (coalesced both ways; 4 % of the data).
+//   S2 bracket : per chain, the sample's order statistics 4.5 sigma either side of its median
+//                (radix select in LDS) bracket the true median: [lo, hi] holds ~6 % of the frames.
+//   S3 collect : the full pass.  Lanes = chains, 128 rows per wave with 32 loads in flight per
+//                lane; frames below lo and valid frames are counted in registers, frames inside
+//                [lo, hi] are staged per chain in LDS by the 8 waves of a block and appended to
+//                the chain's list as one contiguous run (one global atomic per chain and block).
+//   S4 finish  : per chain, exact selection of the two middle ranks inside the list (radix select
+//                in LDS).
+// A chain whose bracket misses the median, or whose bracket holds more than kMedList frames
+// (heavy duplicates), is flagged and served by median_column_kernel: one block per flagged chain,
+// an MSB-first radix select (4 x 8 bits + one sweep for the upper middle of even counts) over the
 // chain's column - five strided sweeps, slow but exact, and a single (normally empty) launch.
-// Short sequences (T <= kMedCap) are selected directly from the whole column.
+// Short sequences (T <= kMedSmall) are selected directly from the whole column.
+// (Round-1 history: 5 radix passes 1.40 ms -> sample / histogram / collect, two full passes,
+//  0.20 ms -> this.)
 // ------------------------------------------------------------------------------------------
-constexpr int kMedCap = 1024;
-constexpr int kMedFlight = 16;   // rows in flight per lane in the two full passes (measured best with 256 blocks)
-constexpr int kMedSamples = 256;
+constexpr int kMedSmall = 1024;      // T up to here: one block per chain selects from the column
+constexpr int kMedSamples = 4096;    // sample rows per chain (fewer for short sequences)
+constexpr int kMedList = 16384;      // capacity of a chain's in-bracket list
+constexpr int kColRows = 128;        // rows per wave in the full pass
+constexpr int kColFlight = 32;       // loads in flight per lane
+constexpr int kColWaves = 8;         // waves per block of the full pass (same 64 chains)
+constexpr int kColStage = 160;      // per-chain LDS staging slots per block (expected ~75 in-bracket keys)
 
 struct BracketWs {
-  uint32_t *lo, *hi, *less, *valid;     // [N]
-  uint32_t* hist;                        // [256][N]
-  uint32_t *lo2, *hi2, *less2, *cnt2;    // [N]
-  uint32_t* list;                        // [N][kMedCap]
-  uint32_t* fallback;                    // [N] 1 -> use the radix path for this chain
-  uint32_t* any_fallback;                // [1]
+  uint32_t *lo, *hi, *less, *valid, *cnt;   // [N]
+  uint32_t* smp;                             // [N][S]
+  uint32_t* list;                            // [N][kMedList]
+  uint32_t* fallback;                        // [N] 1 -> use the radix path for this chain
+  uint32_t* any_fallback;                    // [1]
 };
 
 // exact middle-rank selection inside `vals[0..L)` (LDS), ranks a <= b, by counting
@@ -66,7 +74,7 @@ __device__ __forceinline__ void select_two(const uint32_t* vals, int L, uint32_t
 
 __global__ __launch_bounds__(256) void median_small_kernel(int T, int N, const float* __restrict__ var,
                                                           double min_var, double* __restrict__ rconst) {
-  __shared__ uint32_t vals[kMedCap];
+  __shared__ uint32_t vals[kMedSmall];
   __shared__ uint32_t cnt, v_lo, v_hi;
   const int n = blockIdx.x;
   if (threadIdx.x == 0) cnt = 0;
@@ -86,190 +94,262 @@ __global__ __launch_bounds__(256) void median_small_kernel(int T, int N, const f
   }
 }
 
-__global__ __launch_bounds__(kMedSamples) void bracket_sample_kernel(int T, int N,
-                                                                    const float* __restrict__ var,
-                                                                    BracketWs B) {
-  __shared__ uint32_t smp[kMedSamples];
-  __shared__ uint32_t nvalid;
-  const int n = blockIdx.x, i = threadIdx.x;
-  if (i == 0) nvalid = 0;
+
+// k-th smallest (0-based) of vals[0..L) in LDS by MSB-first radix select; the whole block (256
+// threads) takes part.  Keys are first mapped to (key - base) << lsh so that the 8 bits of the
+// first pass spread the keys over all 256 bins (the keys of one chain share their top bits, and
+// same-address LDS atomics serialise); 0xFFFFFFFF (invalid) stays last.  hist: 256 counters,
+// sh: 2 words of LDS scratch.
+__device__ __forceinline__ uint32_t radix_norm(uint32_t key, uint32_t base, int lsh) {
+  return key == 0xFFFFFFFFu ? key : (key - base) << lsh;
+}
+
+__device__ uint32_t lds_radix_select(const uint32_t* vals, int L, uint32_t rank, uint32_t base, int lsh,
+                                     uint32_t* hist, uint32_t* sh) {
+  uint32_t prefix = 0;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    hist[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int i = threadIdx.x; i < L; i += 256) {
+      const uint32_t key = radix_norm(vals[i], base, lsh);
+      if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {       // wave 0: lane l owns bins 4l..4l+3, exclusive scan of lane sums
+      const int lane = threadIdx.x;
+      uint32_t c[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c[q] = hist[4 * lane + q];
+      const uint32_t mine = c[0] + c[1] + c[2] + c[3];
+      uint32_t incl = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+      }
+      uint32_t cum = incl - mine;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (rank >= cum && rank < cum + c[q]) {
+          sh[0] = (prefix << 8) | (uint32_t)(4 * lane + q);
+          sh[1] = rank - cum;
+        }
+        cum += c[q];
+      }
+    }
+    __syncthreads();
+    prefix = sh[0];
+    rank = sh[1];
+    __syncthreads();
+  }
+  return (prefix >> lsh) + base;
+}
+
+// min / max over the valid keys of vals[0..L) (block-wide, through LDS scratch mm[2])
+__device__ void lds_key_range(const uint32_t* vals, int L, uint32_t* mm, uint32_t& lo, uint32_t& hi) {
+  if (threadIdx.x == 0) {
+    mm[0] = 0xFFFFFFFFu;
+    mm[1] = 0u;
+  }
   __syncthreads();
-  bool valid;
-  const uint32_t key = var_key(var[(size_t)(((long)i * T) / kMedSamples) * N + n], valid);
-  smp[i] = valid ? key : 0xFFFFFFFFu;                      // NaNs sort last
-  if (valid) atomicAdd(&nvalid, 1u);
+  uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+  for (int i = threadIdx.x; i < L; i += 256) {
+    const uint32_t k = vals[i];
+    if (k != 0xFFFFFFFFu) {
+      mn = min(mn, k);
+      mx = max(mx, k);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&mm[0], mn);
+    atomicMax(&mm[1], mx);
+  }
+  __syncthreads();
+  lo = mm[0];
+  hi = mm[1];
+  __syncthreads();
+}
+
+static inline int sample_count(int T) { return T / 2 < kMedSamples ? T / 2 : kMedSamples; }
+
+// S1: sample rows i -> floor(i T / S), 64 chains x 64 samples per block, transposed through LDS
+__global__ __launch_bounds__(256) void sample_transpose_kernel(int T, int N, int S,
+                                                              const float* __restrict__ var,
+                                                              BracketWs B) {
+  __shared__ uint32_t tile[64][65];
+  const int n0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int r = w; r < 64; r += 4) {
+    const int i = i0 + r, n = n0 + lane;
+    uint32_t key = 0xFFFFFFFFu;                            // NaNs (and padding) sort last
+    if (i < S && n < N) {
+      bool valid;
+      const uint32_t k = var_key(var[(size_t)(((long)i * T) / S) * N + n], valid);
+      if (valid) key = k;
+    }
+    tile[r][lane] = key;
+  }
+  __syncthreads();
+  for (int c = w; c < 64; c += 4) {
+    const int n = n0 + c, i = i0 + lane;
+    if (n < N && i < S) B.smp[(size_t)n * S + i] = tile[lane][c];
+  }
+}
+
+// S2: one block per chain
+__global__ __launch_bounds__(256) void sample_bracket_kernel(int N, int S, BracketWs B) {
+  __shared__ uint32_t vals[kMedSamples];
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sh[2], nvalid;
+  const int n = blockIdx.x;
+  if (threadIdx.x == 0) nvalid = 0;
+  __syncthreads();
+  uint32_t mine = 0;
+  for (int i = threadIdx.x; i < S; i += 256) {
+    const uint32_t k = B.smp[(size_t)n * S + i];
+    vals[i] = k;
+    mine += k != 0xFFFFFFFFu;
+  }
+  if (mine) atomicAdd(&nvalid, mine);
   __syncthreads();
   const uint32_t nv = nvalid;
-  if (i == 0) {
-    B.less[n] = 0; B.valid[n] = 0; B.cnt2[n] = 0;
+  if (threadIdx.x == 0) {
+    B.less[n] = 0; B.valid[n] = 0; B.cnt[n] = 0;
     B.fallback[n] = nv < 64 ? 1u : 0u;
     if (nv < 64) atomicOr(B.any_fallback, 1u);
   }
   if (nv < 64) return;
-  // rank of my sample (stable for ties), then the bracket ranks 4 sigma (sigma = sqrt(nv)/2) out
-  uint32_t rank = 0;
-  for (int jj = 0; jj < kMedSamples; ++jj) rank += (smp[jj] < smp[i]) || (smp[jj] == smp[i] && jj < i);
-  const int delta = (int)(2.0f * sqrtf((float)nv)) + 1;
+  // bracket ranks 4.5 sigma out (sigma of the sample median's rank = sqrt(nv) / 2)
+  const int delta = (int)(2.25f * sqrtf((float)nv)) + 1;
   const int mid = ((int)nv - 1) / 2;
   const int r_lo = max(0, mid - delta), r_hi = min((int)nv - 1, mid + 1 + delta);
-  if ((int)rank == r_lo) B.lo[n] = smp[i];
-  if ((int)rank == r_hi) B.hi[n] = smp[i];
+  uint32_t kmin, kmax;
+  lds_key_range(vals, S, sh, kmin, kmax);
+  const int lsh = kmax > kmin ? __clz((int)(kmax - kmin)) : 0;
+  const uint32_t lo = lds_radix_select(vals, S, (uint32_t)r_lo, kmin, lsh, hist, sh);
+  const uint32_t hi = lds_radix_select(vals, S, (uint32_t)r_hi, kmin, lsh, hist, sh);
+  if (threadIdx.x == 0) {
+    B.lo[n] = lo;
+    B.hi[n] = hi;
+  }
 }
 
-__global__ __launch_bounds__(64 * kMedWaves) void bracket_hist_kernel(int T, int N, int rows_per_block,
-                                                                     const float* __restrict__ var,
-                                                                     BracketWs B) {
-  __shared__ uint32_t h[256][64];
-  for (int i = threadIdx.x; i < 256 * 64; i += 64 * kMedWaves) (&h[0][0])[i] = 0u;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// S3: the full pass.  Block = 8 waves over the SAME 64 chains (8 consecutive 128-row slabs);
+// in-bracket keys are staged per chain in LDS and written out as whole runs, one global atomic
+// per chain and block.
+__global__ __launch_bounds__(64 * kColWaves) void bracket_collect_kernel(int T, int N,
+                                                                        const float* __restrict__ var,
+                                                                        BracketWs B) {
+  __shared__ uint32_t stage[kColStage][65];      // [slot][chain], padded: both phases conflict-free
+  __shared__ uint32_t staged[64], base[64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int ntile = (N + 63) / 64;
   const int tile = blockIdx.x % ntile, slab = blockIdx.x / ntile;
   const int n = tile * 64 + lane;
-  const int t_begin = slab * rows_per_block;
-  const int t_end = min(T, t_begin + rows_per_block);
+  if (w == 0) staged[lane] = 0u;
+  __syncthreads();
+  const bool live = n < N && !B.fallback[n];
+  const int t_begin = (slab * kColWaves + w) * kColRows;
+  const int t_end = min(T, t_begin + kColRows);
   uint32_t less = 0, nvalid = 0;
-  if (n < N && !B.fallback[n]) {
+  if (live && t_begin < T) {
     const uint32_t lo = B.lo[n], hi = B.hi[n];
-    const unsigned long long width = (unsigned long long)(hi - lo) + 1ull;
-    for (int t = t_begin + wave; t < t_end; t += kMedFlight * kMedWaves) {
-      float v[kMedFlight];
+    for (int t = t_begin; t < t_end; t += kColFlight) {
+      float v[kColFlight];
 #pragma unroll
-      for (int u = 0; u < kMedFlight; ++u) {
-        const int tt = t + kMedWaves * u;
-        v[u] = tt < t_end ? var[(size_t)tt * N + n] : __uint_as_float(0x7FC00000u);
-      }
+      for (int u = 0; u < kColFlight; ++u)
+        v[u] = t + u < t_end ? var[(size_t)(t + u) * N + n] : __uint_as_float(0x7FC00000u);
 #pragma unroll
-      for (int u = 0; u < kMedFlight; ++u) {
+      for (int u = 0; u < kColFlight; ++u) {
         bool valid;
         const uint32_t key = var_key(v[u], valid);
-        if (!valid) continue;
-        ++nvalid;
-        if (key < lo) {
-          ++less;
-        } else if (key <= hi) {
-          const uint32_t bin = (uint32_t)(((unsigned long long)(key - lo) * 256ull) / width);
-          atomicAdd(&h[bin][lane], 1u);
+        nvalid += valid;
+        less += valid && key < lo;
+        if (valid && key >= lo && key <= hi) {
+          const uint32_t pos = atomicAdd(&staged[lane], 1u);
+          if (pos < (uint32_t)kColStage) {
+            stage[pos][lane] = key;
+          } else {                                    // staging full (heavy duplicates): go direct
+            const uint32_t g = atomicAdd(&B.cnt[n], 1u);
+            if (g < (uint32_t)kMedList) B.list[(size_t)n * kMedList + g] = key;
+          }
         }
       }
-    }
-  }
-  __syncthreads();
-  if (n < N && !B.fallback[n]) {
-    for (int b = wave; b < 256; b += kMedWaves) {
-      const uint32_t c = h[b][lane];
-      if (c) atomicAdd(&B.hist[(size_t)b * N + n], c);
     }
     if (less) atomicAdd(&B.less[n], less);
     if (nvalid) atomicAdd(&B.valid[n], nvalid);
   }
-}
-
-// one wave per chain: lane l owns bins 4l .. 4l+3, wave-level exclusive scan of the lane sums
-__global__ __launch_bounds__(256) void bracket_narrow_kernel(int N, BracketWs B) {
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (n >= N || B.fallback[n]) return;                  // wave-uniform
-  const uint32_t cnt = B.valid[n], less = B.less[n];
-  const uint32_t lo = B.lo[n], hi = B.hi[n];
-  const unsigned long long width = (unsigned long long)(hi - lo) + 1ull;
-  const uint32_t r_lo = cnt ? (cnt - 1) / 2 : 0, r_hi = cnt / 2;
-  uint32_t c[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) c[i] = B.hist[(size_t)(4 * lane + i) * N + n];
-  const uint32_t mine = c[0] + c[1] + c[2] + c[3];
-  uint32_t incl = mine;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t up = __shfl_up(incl, off);
-    if (lane >= off) incl += up;
+  __syncthreads();
+  if (w == 0 && live) {
+    const uint32_t c = min(staged[lane], (uint32_t)kColStage);
+    staged[lane] = c;
+    base[lane] = c ? atomicAdd(&B.cnt[n], c) : 0u;
   }
-  uint32_t cum = less + incl - mine;                    // frames below my first bin
-  int b_lo = -1, b_hi = -1;
-  uint32_t less2 = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (r_lo >= cum && r_lo < cum + c[i]) {
-      b_lo = 4 * lane + i;
-      less2 = cum;
-    }
-    if (r_hi >= cum && r_hi < cum + c[i]) b_hi = 4 * lane + i;
-    cum += c[i];
-  }
-  // at most one lane holds each of b_lo / b_hi: broadcast them
-  const unsigned long long m_lo = __ballot(b_lo >= 0), m_hi = __ballot(b_hi >= 0);
-  const bool ok = cnt != 0 && m_lo != 0 && m_hi != 0;
-  int g_lo = 0, g_hi = 0;
-  uint32_t g_less2 = 0;
-  if (ok) {
-    const int l_lo = __ffsll((long long)m_lo) - 1, l_hi = __ffsll((long long)m_hi) - 1;
-    g_lo = __shfl(b_lo, l_lo);
-    g_less2 = __shfl(less2, l_lo);
-    g_hi = __shfl(b_hi, l_hi);
-  }
-  uint32_t inside = 0;                                  // frames inside bins g_lo .. g_hi
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int bb = 4 * lane + i;
-    if (ok && bb >= g_lo && bb <= g_hi) inside += c[i];
-  }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) inside += __shfl_xor(inside, off);
-  if (lane != 0) return;
-  if (!ok || inside > (uint32_t)kMedCap) {
-    B.fallback[n] = 1u;                                 // bracket missed the median / heavy duplicates
-    atomicOr(B.any_fallback, 1u);
-    return;
-  }
-  // key range of bins g_lo .. g_hi: bin b starts at lo + ceil(b * width / 256)
-  B.lo2[n] = lo + (uint32_t)(((unsigned long long)g_lo * width + 255ull) / 256ull);
-  B.hi2[n] = lo + (uint32_t)(((unsigned long long)(g_hi + 1) * width + 255ull) / 256ull) - 1u;
-  B.less2[n] = g_less2;
-}
-
-__global__ __launch_bounds__(64 * kMedWaves) void bracket_collect_kernel(int T, int N, int rows_per_block,
-                                                                        const float* __restrict__ var,
-                                                                        BracketWs B) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ntile = (N + 63) / 64;
-  const int tile = blockIdx.x % ntile, slab = blockIdx.x / ntile;
-  const int n = tile * 64 + lane;
-  if (n >= N || B.fallback[n]) return;
-  const int t_begin = slab * rows_per_block;
-  const int t_end = min(T, t_begin + rows_per_block);
-  const uint32_t lo2 = B.lo2[n], hi2 = B.hi2[n];
-  uint32_t* list = B.list + (size_t)n * kMedCap;
-  for (int t = t_begin + wave; t < t_end; t += kMedFlight * kMedWaves) {
-    float v[kMedFlight];
-#pragma unroll
-    for (int u = 0; u < kMedFlight; ++u) {
-      const int tt = t + kMedWaves * u;
-      v[u] = tt < t_end ? var[(size_t)tt * N + n] : __uint_as_float(0x7FC00000u);
-    }
-#pragma unroll
-    for (int u = 0; u < kMedFlight; ++u) {
-      bool valid;
-      const uint32_t key = var_key(v[u], valid);
-      if (valid && key >= lo2 && key <= hi2) {
-        const uint32_t pos = atomicAdd(&B.cnt2[n], 1u);
-        if (pos < (uint32_t)kMedCap) list[pos] = key;
-      }
-    }
+  __syncthreads();
+  // wave w writes the runs of chains w, w + 8, ...: lanes along the run (contiguous in memory)
+  for (int c = w; c < 64; c += kColWaves) {
+    const int nn = tile * 64 + c;
+    if (nn >= N) break;
+    const uint32_t cnt = staged[c], b = base[c];
+    for (uint32_t q = lane; q < cnt; q += 64)
+      if (b + q < (uint32_t)kMedList) B.list[(size_t)nn * kMedList + b + q] = stage[q][c];
   }
 }
 
+// S4: one block per chain
 __global__ __launch_bounds__(256) void bracket_finish_kernel(int N, double min_var, BracketWs B,
                                                             double* __restrict__ rconst) {
-  __shared__ uint32_t vals[kMedCap];
-  __shared__ uint32_t v_lo, v_hi;
+  __shared__ uint32_t vals[kMedList];
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sh[2];
   const int n = blockIdx.x;
   if (B.fallback[n]) return;                            // the radix path writes this chain
-  const uint32_t L = min(B.cnt2[n], (uint32_t)kMedCap);
-  for (int i = threadIdx.x; i < (int)L; i += blockDim.x) vals[i] = B.list[(size_t)n * kMedCap + i];
+  const uint32_t cnt = B.valid[n], less = B.less[n], inside = B.cnt[n];
+  const uint32_t r_lo = cnt ? (cnt - 1) / 2 : 0, r_hi = cnt / 2;
+  if (cnt == 0 || inside > (uint32_t)kMedList || r_lo < less || r_hi >= less + inside) {
+    if (threadIdx.x == 0) {                             // bracket missed the median / heavy duplicates
+      B.fallback[n] = 1u;
+      atomicOr(B.any_fallback, 1u);
+    }
+    return;
+  }
+  for (int i = threadIdx.x; i < (int)inside; i += 256) vals[i] = B.list[(size_t)n * kMedList + i];
   __syncthreads();
-  const uint32_t cnt = B.valid[n];
-  select_two(vals, (int)L, (cnt - 1) / 2 - B.less2[n], cnt / 2 - B.less2[n], &v_lo, &v_hi);
-  __syncthreads();
+  const uint32_t blo = B.lo[n], bhi = B.hi[n];          // every listed key lies in [blo, bhi]
+  const int lsh = bhi > blo ? __clz((int)(bhi - blo)) : 0;
+  const uint32_t v_lo = lds_radix_select(vals, (int)inside, r_lo - less, blo, lsh, hist, sh);
+  uint32_t v_hi = v_lo;
+  if (r_hi != r_lo) {
+    // the upper middle rank is v_lo again if enough keys are <= v_lo, else the next larger key
+    if (threadIdx.x == 0) {
+      sh[0] = 0u;
+      sh[1] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    uint32_t le = 0, nxt = 0xFFFFFFFFu;
+    for (int i = threadIdx.x; i < (int)inside; i += 256) {
+      const uint32_t k = vals[i];
+      le += k <= v_lo;
+      if (k > v_lo) nxt = min(nxt, k);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      le += __shfl_xor((int)le, off);
+      nxt = min(nxt, (uint32_t)__shfl_xor((int)nxt, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&sh[0], le);
+      atomicMin(&sh[1], nxt);
+    }
+    __syncthreads();
+    v_hi = (r_hi - less) < sh[0] ? v_lo : sh[1];
+  }
   if (threadIdx.x == 0) {
     const double med = 0.5 * (double)__uint_as_float(v_lo) + 0.5 * (double)__uint_as_float(v_hi);
     rconst[n] = med > min_var ? med : min_var;
@@ -284,18 +364,34 @@ __global__ __launch_bounds__(256) void median_column_kernel(int T, int N, const 
   __shared__ uint32_t sh_prefix, sh_rank, sh_cnt, sh_less, sh_eq, sh_next;
   const int n = blockIdx.x;
   if (*B.any_fallback == 0u || B.fallback[n] == 0u) return;
+  // one strided sweep over the column, 16 loads in flight per thread (a lone block is otherwise
+  // bound by T / 256 dependent memory latencies per sweep)
+  auto sweep = [&](auto&& f) {
+    constexpr int kU = 16;
+    for (int t0 = threadIdx.x; t0 < T; t0 += 256 * kU) {
+      float v[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int t = t0 + 256 * u;
+        v[u] = t < T ? var[(size_t)t * N + n] : __uint_as_float(0x7FC00000u);
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        bool valid;
+        const uint32_t key = var_key(v[u], valid);
+        if (valid) f(key);
+      }
+    }
+  };
   uint32_t prefix = 0, rank = 0, less = 0;
   for (int pass = 0; pass < 4; ++pass) {
     hist[threadIdx.x] = 0u;
     __syncthreads();
     const int shift = 24 - 8 * pass;
-    for (int t = threadIdx.x; t < T; t += blockDim.x) {
-      bool valid;
-      const uint32_t key = var_key(var[(size_t)t * N + n], valid);
-      if (!valid) continue;
-      if (pass > 0 && (key >> (shift + 8)) != prefix) continue;
+    sweep([&](uint32_t key) {
+      if (pass > 0 && (key >> (shift + 8)) != prefix) return;
       atomicAdd(&hist[(key >> shift) & 255u], 1u);
-    }
+    });
     __syncthreads();
     if (threadIdx.x == 0) {
       if (pass == 0) {
@@ -329,11 +425,9 @@ __global__ __launch_bounds__(256) void median_column_kernel(int T, int N, const 
   }
   const uint32_t cnt = sh_cnt, eq = sh_eq, key_lo = prefix;
   uint32_t best = 0xFFFFFFFFu;
-  for (int t = threadIdx.x; t < T; t += blockDim.x) {
-    bool valid;
-    const uint32_t key = var_key(var[(size_t)t * N + n], valid);
-    if (valid && key > key_lo && key < best) best = key;
-  }
+  sweep([&](uint32_t key) {
+    if (key > key_lo && key < best) best = key;
+  });
   if (best != 0xFFFFFFFFu) atomicMin(&sh_next, best);
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -352,43 +446,38 @@ __global__ __launch_bounds__(256) void median_column_kernel(int T, int N, const 
 static inline size_t arr_bytes(size_t n) { return align_up(n * 4, 256); }
 
 size_t const_r_workspace_bytes(int N) {
-  return 10 * arr_bytes(N) + arr_bytes((size_t)256 * N) + arr_bytes((size_t)N * kMedCap) + 256;
+  return 8 * arr_bytes(N) + arr_bytes((size_t)N * kMedSamples) + arr_bytes((size_t)N * kMedList) + 256;
 }
 
 int const_r(int T, int N, const float* var, double min_var, double* rconst, void* ws,
             size_t ws_bytes, hipStream_t st) {
   if (ws_bytes < const_r_workspace_bytes(N)) return EKS_ERR_WORKSPACE;
   ProfScope ps("const_r_select", st);
-  if (T <= kMedCap) {
+  if (T <= kMedSmall) {
     hipLaunchKernelGGL(median_small_kernel, dim3(N), dim3(256), 0, st, T, N, var, min_var, rconst);
     return hip_status(hipGetLastError());
   }
   char* p = static_cast<char*>(ws);
   BracketWs B;
-  uint32_t** arrs[10] = {&B.lo, &B.hi, &B.less, &B.valid, &B.lo2, &B.hi2, &B.less2, &B.cnt2,
-                         &B.fallback, &B.any_fallback};
-  for (int i = 0; i < 10; ++i) {
+  uint32_t** arrs[7] = {&B.lo, &B.hi, &B.less, &B.valid, &B.cnt, &B.fallback, &B.any_fallback};
+  for (int i = 0; i < 7; ++i) {
     *arrs[i] = reinterpret_cast<uint32_t*>(p);
     p += arr_bytes(N);
   }
-  B.hist = reinterpret_cast<uint32_t*>(p);
-  p += arr_bytes((size_t)256 * N);
+  B.smp = reinterpret_cast<uint32_t*>(p);
+  p += arr_bytes((size_t)N * kMedSamples);
   B.list = reinterpret_cast<uint32_t*>(p);
 
-  hipError_t e = hipMemsetAsync(B.hist, 0, arr_bytes((size_t)256 * N), st);
-  if (e == hipSuccess) e = hipMemsetAsync(B.any_fallback, 0, 4, st);
+  hipError_t e = hipMemsetAsync(B.any_fallback, 0, 4, st);
   if (e != hipSuccess) return hip_status(e);
+  const int S = sample_count(T);
   const int ntile = (N + 63) / 64;
-  // one 16-wave block per CU, each long enough to amortise its LDS flush
-  int rows = (int)(((long)T * ntile + 255) / 256);
-  if (rows < kMedFlight * kMedWaves) rows = kMedFlight * kMedWaves;
-  rows = (rows + kMedWaves - 1) / kMedWaves * kMedWaves;
-  const int nslab = (T + rows - 1) / rows;
-  const dim3 grid(ntile * nslab), big(64 * kMedWaves);
-  hipLaunchKernelGGL(bracket_sample_kernel, dim3(N), dim3(kMedSamples), 0, st, T, N, var, B);
-  hipLaunchKernelGGL(bracket_hist_kernel, grid, big, 0, st, T, N, rows, var, B);
-  hipLaunchKernelGGL(bracket_narrow_kernel, dim3((N + 3) / 4), dim3(256), 0, st, N, B);
-  hipLaunchKernelGGL(bracket_collect_kernel, grid, big, 0, st, T, N, rows, var, B);
+  hipLaunchKernelGGL(sample_transpose_kernel, dim3(ntile, (S + 63) / 64), dim3(256), 0, st, T, N, S,
+                     var, B);
+  hipLaunchKernelGGL(sample_bracket_kernel, dim3(N), dim3(256), 0, st, N, S, B);
+  const int nslab = (T + kColRows * kColWaves - 1) / (kColRows * kColWaves);
+  hipLaunchKernelGGL(bracket_collect_kernel, dim3((unsigned)(ntile * nslab)), dim3(64 * kColWaves), 0, st,
+                     T, N, var, B);
   hipLaunchKernelGGL(bracket_finish_kernel, dim3(N), dim3(256), 0, st, N, min_var, B, rconst);
   hipLaunchKernelGGL(median_column_kernel, dim3(N), dim3(256), 0, st, T, N, var, min_var, B, rconst);
   return hip_status(hipGetLastError());
