@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void diag_summarize_kernel(LaneMap L, DiagMode
                                                             const float* __restrict__ var) {
   int n, j;
   if (!lane_coords(L, n, j)) return;
+  if (L.reverse) j = L.nc - 1 - j;
   const ChainParams<float> p = load_chain_params(M, n);
   const int t0 = j * B;
   const int len = min(B, L.T - t0);
@@ -292,8 +293,15 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
   const long waves = (long)L.ntile * ((L.nc + cpw - 1) / cpw);
   const dim3 grid((unsigned)((waves + 3) / 4));
   const bool unit = d.flags & EKS_FLAG_UNIT_AC;
+  // K1 and K3 walk the chunks in opposite directions: the tail of one stream of y, var is the
+  // head of the next and can be served from the 256 MiB Infinity Cache.  EKS_SUMMARIZE_REVERSE
+  // picks which of the two runs backwards (A/B knob).
+  const char* k1r = getenv("EKS_SUMMARIZE_REVERSE");
+  const int k1_reverse = (k1r && k1r[0] == '1') ? 1 : 0;
   {
     ProfScope ps("diag_summarize", st);
+    LaneMap L = Lf;
+    L.reverse = k1_reverse;
     if (unit)
       hipLaunchKernelGGL((diag_summarize_kernel<kChunk, true>), grid, dim3(256), 0, st, L, M, W, y, var);
     else
@@ -311,7 +319,7 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
     ProfScope ps("diag_replay", st);
     LaneMap L = Lf;
     const char* fwd = getenv("EKS_REPLAY_FORWARD");
-    L.reverse = (fwd && fwd[0] == '1') ? 0 : 1;
+    L.reverse = (fwd && fwd[0] == '1') ? 0 : (fwd && fwd[0] == '0') ? 1 : !k1_reverse;
     if (unit)
       launch_replay<true>(vs_row, grid, st, L, M, W, y, var, ms, Vs);
     else

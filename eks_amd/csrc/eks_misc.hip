@@ -33,9 +33,9 @@ __device__ __forceinline__ uint32_t var_key(float v, bool& valid) {
 //   S4 finish  : per chain, exact selection of the two middle ranks inside the list (radix select
 //                in LDS).
 // A chain whose bracket misses the median, or whose bracket holds more than kMedList frames
-// (heavy duplicates), is flagged and served by median_column_kernel: one block per flagged chain,
-// an MSB-first radix select (4 x 8 bits + one sweep for the upper middle of even counts) over the
-// chain's column - five strided sweeps, slow but exact, and a single (normally empty) launch.
+// (heavy duplicates), is served by its S4 block from the whole column instead (median_column:
+// MSB-first radix select, 4 x 8 bits + one sweep for the upper middle of even counts - five
+// strided sweeps, slow but exact and rare).
 // Short sequences (T <= kMedSmall) are selected directly from the whole column.
 // (Round-1 history: 5 radix passes 1.40 ms -> sample / histogram / collect, two full passes,
 //  0.20 ms -> this.)
@@ -52,8 +52,7 @@ struct BracketWs {
   uint32_t *lo, *hi, *less, *valid, *cnt;   // [N]
   uint32_t* smp;                             // [N][S]
   uint32_t* list;                            // [N][kMedList]
-  uint32_t* fallback;                        // [N] 1 -> use the radix path for this chain
-  uint32_t* any_fallback;                    // [1]
+  uint32_t* fallback;                        // [N] 1 -> too few valid samples: select from the column
 };
 
 // exact middle-rank selection inside `vals[0..L)` (LDS), ranks a <= b, by counting
@@ -222,7 +221,6 @@ __global__ __launch_bounds__(256) void sample_bracket_kernel(int N, int S, Brack
   if (threadIdx.x == 0) {
     B.less[n] = 0; B.valid[n] = 0; B.cnt[n] = 0;
     B.fallback[n] = nv < 64 ? 1u : 0u;
-    if (nv < 64) atomicOr(B.any_fallback, 1u);
   }
   if (nv < 64) return;
   // bracket ranks 4.5 sigma out (sigma of the sample median's rank = sqrt(nv) / 2)
@@ -302,68 +300,12 @@ __global__ __launch_bounds__(64 * kColWaves) void bracket_collect_kernel(int T, 
   }
 }
 
-// S4: one block per chain
-__global__ __launch_bounds__(256) void bracket_finish_kernel(int N, double min_var, BracketWs B,
-                                                            double* __restrict__ rconst) {
-  __shared__ uint32_t vals[kMedList];
-  __shared__ uint32_t hist[256];
-  __shared__ uint32_t sh[2];
-  const int n = blockIdx.x;
-  if (B.fallback[n]) return;                            // the radix path writes this chain
-  const uint32_t cnt = B.valid[n], less = B.less[n], inside = B.cnt[n];
-  const uint32_t r_lo = cnt ? (cnt - 1) / 2 : 0, r_hi = cnt / 2;
-  if (cnt == 0 || inside > (uint32_t)kMedList || r_lo < less || r_hi >= less + inside) {
-    if (threadIdx.x == 0) {                             // bracket missed the median / heavy duplicates
-      B.fallback[n] = 1u;
-      atomicOr(B.any_fallback, 1u);
-    }
-    return;
-  }
-  for (int i = threadIdx.x; i < (int)inside; i += 256) vals[i] = B.list[(size_t)n * kMedList + i];
-  __syncthreads();
-  const uint32_t blo = B.lo[n], bhi = B.hi[n];          // every listed key lies in [blo, bhi]
-  const int lsh = bhi > blo ? __clz((int)(bhi - blo)) : 0;
-  const uint32_t v_lo = lds_radix_select(vals, (int)inside, r_lo - less, blo, lsh, hist, sh);
-  uint32_t v_hi = v_lo;
-  if (r_hi != r_lo) {
-    // the upper middle rank is v_lo again if enough keys are <= v_lo, else the next larger key
-    if (threadIdx.x == 0) {
-      sh[0] = 0u;
-      sh[1] = 0xFFFFFFFFu;
-    }
-    __syncthreads();
-    uint32_t le = 0, nxt = 0xFFFFFFFFu;
-    for (int i = threadIdx.x; i < (int)inside; i += 256) {
-      const uint32_t k = vals[i];
-      le += k <= v_lo;
-      if (k > v_lo) nxt = min(nxt, k);
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      le += __shfl_xor((int)le, off);
-      nxt = min(nxt, (uint32_t)__shfl_xor((int)nxt, off));
-    }
-    if ((threadIdx.x & 63) == 0) {
-      atomicAdd(&sh[0], le);
-      atomicMin(&sh[1], nxt);
-    }
-    __syncthreads();
-    v_hi = (r_hi - less) < sh[0] ? v_lo : sh[1];
-  }
-  if (threadIdx.x == 0) {
-    const double med = 0.5 * (double)__uint_as_float(v_lo) + 0.5 * (double)__uint_as_float(v_hi);
-    rconst[n] = med > min_var ? med : min_var;
-  }
-}
-
 // exact median of one chain's column by radix select inside one block (fallback path)
-__global__ __launch_bounds__(256) void median_column_kernel(int T, int N, const float* __restrict__ var,
-                                                           double min_var, BracketWs B,
-                                                           double* __restrict__ rconst) {
-  __shared__ uint32_t hist[256];
-  __shared__ uint32_t sh_prefix, sh_rank, sh_cnt, sh_less, sh_eq, sh_next;
-  const int n = blockIdx.x;
-  if (*B.any_fallback == 0u || B.fallback[n] == 0u) return;
+// (called by the whole 256-thread block of bracket_finish_kernel; hist: 256 counters, sc: 6 words)
+__device__ void median_column(int T, int N, const float* __restrict__ var, double min_var, int n,
+                              double* __restrict__ rconst, uint32_t* hist, uint32_t* sc) {
+  uint32_t &sh_prefix = sc[0], &sh_rank = sc[1], &sh_cnt = sc[2], &sh_less = sc[3], &sh_eq = sc[4],
+           &sh_next = sc[5];
   // one strided sweep over the column, 16 loads in flight per thread (a lone block is otherwise
   // bound by T / 256 dependent memory latencies per sweep)
   auto sweep = [&](auto&& f) {
@@ -443,6 +385,60 @@ __global__ __launch_bounds__(256) void median_column_kernel(int T, int N, const 
   }
 }
 
+// S4: one block per chain
+__global__ __launch_bounds__(256) void bracket_finish_kernel(int T, int N, const float* __restrict__ var,
+                                                            double min_var, BracketWs B,
+                                                            double* __restrict__ rconst) {
+  __shared__ uint32_t vals[kMedList];
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sh[2], sc[6];
+  const int n = blockIdx.x;
+  const uint32_t cnt = B.valid[n], less = B.less[n], inside = B.cnt[n];
+  const uint32_t r_lo = cnt ? (cnt - 1) / 2 : 0, r_hi = cnt / 2;
+  // too few valid samples, the bracket missed the median, or heavy duplicates overflowed the
+  // list: this block selects from the chain's whole column instead (block-uniform branch)
+  if (B.fallback[n] || cnt == 0 || inside > (uint32_t)kMedList || r_lo < less ||
+      r_hi >= less + inside) {
+    median_column(T, N, var, min_var, n, rconst, hist, sc);
+    return;
+  }
+  for (int i = threadIdx.x; i < (int)inside; i += 256) vals[i] = B.list[(size_t)n * kMedList + i];
+  __syncthreads();
+  const uint32_t blo = B.lo[n], bhi = B.hi[n];          // every listed key lies in [blo, bhi]
+  const int lsh = bhi > blo ? __clz((int)(bhi - blo)) : 0;
+  const uint32_t v_lo = lds_radix_select(vals, (int)inside, r_lo - less, blo, lsh, hist, sh);
+  uint32_t v_hi = v_lo;
+  if (r_hi != r_lo) {
+    // the upper middle rank is v_lo again if enough keys are <= v_lo, else the next larger key
+    if (threadIdx.x == 0) {
+      sh[0] = 0u;
+      sh[1] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    uint32_t le = 0, nxt = 0xFFFFFFFFu;
+    for (int i = threadIdx.x; i < (int)inside; i += 256) {
+      const uint32_t k = vals[i];
+      le += k <= v_lo;
+      if (k > v_lo) nxt = min(nxt, k);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      le += __shfl_xor((int)le, off);
+      nxt = min(nxt, (uint32_t)__shfl_xor((int)nxt, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&sh[0], le);
+      atomicMin(&sh[1], nxt);
+    }
+    __syncthreads();
+    v_hi = (r_hi - less) < sh[0] ? v_lo : sh[1];
+  }
+  if (threadIdx.x == 0) {
+    const double med = 0.5 * (double)__uint_as_float(v_lo) + 0.5 * (double)__uint_as_float(v_hi);
+    rconst[n] = med > min_var ? med : min_var;
+  }
+}
+
 static inline size_t arr_bytes(size_t n) { return align_up(n * 4, 256); }
 
 size_t const_r_workspace_bytes(int N) {
@@ -459,8 +455,8 @@ int const_r(int T, int N, const float* var, double min_var, double* rconst, void
   }
   char* p = static_cast<char*>(ws);
   BracketWs B;
-  uint32_t** arrs[7] = {&B.lo, &B.hi, &B.less, &B.valid, &B.cnt, &B.fallback, &B.any_fallback};
-  for (int i = 0; i < 7; ++i) {
+  uint32_t** arrs[6] = {&B.lo, &B.hi, &B.less, &B.valid, &B.cnt, &B.fallback};
+  for (int i = 0; i < 6; ++i) {
     *arrs[i] = reinterpret_cast<uint32_t*>(p);
     p += arr_bytes(N);
   }
@@ -468,8 +464,6 @@ int const_r(int T, int N, const float* var, double min_var, double* rconst, void
   p += arr_bytes((size_t)N * kMedSamples);
   B.list = reinterpret_cast<uint32_t*>(p);
 
-  hipError_t e = hipMemsetAsync(B.any_fallback, 0, 4, st);
-  if (e != hipSuccess) return hip_status(e);
   const int S = sample_count(T);
   const int ntile = (N + 63) / 64;
   hipLaunchKernelGGL(sample_transpose_kernel, dim3(ntile, (S + 63) / 64), dim3(256), 0, st, T, N, S,
@@ -478,8 +472,7 @@ int const_r(int T, int N, const float* var, double min_var, double* rconst, void
   const int nslab = (T + kColRows * kColWaves - 1) / (kColRows * kColWaves);
   hipLaunchKernelGGL(bracket_collect_kernel, dim3((unsigned)(ntile * nslab)), dim3(64 * kColWaves), 0, st,
                      T, N, var, B);
-  hipLaunchKernelGGL(bracket_finish_kernel, dim3(N), dim3(256), 0, st, N, min_var, B, rconst);
-  hipLaunchKernelGGL(median_column_kernel, dim3(N), dim3(256), 0, st, T, N, var, min_var, B, rconst);
+  hipLaunchKernelGGL(bracket_finish_kernel, dim3(N), dim3(256), 0, st, T, N, var, min_var, B, rconst);
   return hip_status(hipGetLastError());
 }
 
