@@ -1,0 +1,27 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun): tests, bench lines, rocprofv3 kernel stats and PMC passes for the
+# C3 workload.  Everything lands under gpurun_out/evidence/; tools/make_profiles.py (run afterwards in
+# the build container) turns it into profiles/<tag>_*.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/evidence
+rm -rf $O; mkdir -p $O
+cd $R
+python -m pytest tests -q -m gpu 2>&1 | tail -2 > $O/pytest_gpu.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
+python bench.py > $O/bench_c3.json 2> $O/bench_c3.err
+python bench.py --workload c4 --no-cpu-baseline > $O/bench_c4.json 2>/dev/null
+python bench.py --workload c5 --no-cpu-baseline > $O/bench_c5.json 2>/dev/null
+python bench.py --workload c2 --no-cpu-baseline > $O/bench_c2.json 2>/dev/null
+python bench.py --workload pupil > $O/bench_pupil.json 2>/dev/null
+python tools/adam_time.py > $O/adam_time.txt 2>&1
+cd /tmp; export TMPDIR=/tmp
+B="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-events"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > /dev/null 2>&1
+B3="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- $B3 > /dev/null 2>&1
+# keep only the summaries (the traces are large)
+find $O -name "*_kernel_trace.csv" -delete; find $O -name "*_agent_info.csv" -delete
+ls -R $O | head -40

@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Turn gpurun_out/evidence/ (written by tools/collect_evidence.sh on the GPU box) into the committed
+summaries profiles/<tag>_kernel_stats.txt, <tag>_pmc_summary.txt, <tag>_bench*.json and
+profiles/r01_traffic.json.  Usage: python tools/make_profiles.py r01_f"""
+import collections, csv, glob, json, os, shutil, sys
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ev = os.path.join(root, 'gpurun_out', 'evidence')
+prof = os.path.join(root, 'profiles')
+b = json.load(open(os.path.join(ev, 'bench_c3.json')))
+rows = list(csv.DictReader(open(glob.glob(os.path.join(ev, 'stats', '*', '*_kernel_stats.csv'))[0])))
+out = [f'# {tag}: rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 '
+       '--no-cpu-baseline --no-kernel-events',
+       '# C3 workload: singlecam T=100000 x K=256, 64-candidate NLL grid + smooth (23 steps incl. warm-up).',
+       f"{'kernel':92s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>7s}"]
+tot = 0.0
+for r in rows:
+    if 'eks::' in r['Name']:
+        out.append(f"{r['Name'][:92]:92s} {r['Calls']:>6s} {float(r['AverageNs'])/1e3:10.1f} "
+                   f"{float(r['MinNs'])/1e3:10.1f} {float(r['MaxNs'])/1e3:10.1f} {float(r['Percentage']):7.2f}")
+        tot += float(r['AverageNs']) / 1e3
+out.append(f"# sum of per-kernel averages = {tot:.1f} us per step (bench.py wall clock: {b['ms_per_step']*1e3:.1f} us per step)")
+open(os.path.join(prof, f'{tag}_kernel_stats.txt'), 'w').write('\n'.join(out) + '\n')
+
+
+def load(d):
+    return list(csv.DictReader(open(glob.glob(os.path.join(ev, d, '*', '*_counter_collection.csv'))[0])))
+
+
+lines = [f'# {tag}: PMC counters from separate rocprofv3 --pmc passes of: python3 bench.py --steps 3 --warmup 1 '
+         '--no-cpu-baseline --no-kernel-events',
+         '# averages per dispatch.  FETCH_SIZE / WRITE_SIZE in KiB as reported; gfx950 correction: '
+         'read bytes = 2 * FETCH_SIZE * 1024']
+agg_all = {}
+for d in ('pmc_sq', 'pmc_fetch', 'pmc_write'):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in load(d):
+        if 'eks::' in r['Kernel_Name']:
+            nm = r['Kernel_Name'].split('(')[0].replace('void ', '')
+            agg[nm][r['Counter_Name']].append(float(r['Counter_Value']))
+    agg_all[d] = agg
+    lines.append(f'== {d}')
+    for k, v in sorted(agg.items()):
+        lines.append(f"{k[:70]:70s} " + ' '.join(f'{c}={sum(x)/len(x):.4g}' for c, x in sorted(v.items())))
+open(os.path.join(prof, f'{tag}_pmc_summary.txt'), 'w').write('\n'.join(lines) + '\n')
+traffic = {}
+for k in agg_all['pmc_fetch']:
+    f = agg_all['pmc_fetch'][k]['FETCH_SIZE']
+    w = agg_all['pmc_write'].get(k, {}).get('WRITE_SIZE', [0])
+    traffic[k.replace('eks::', '').split('<')[0]] = int((2 * sum(f) / len(f) + sum(w) / len(w)) * 1024)
+json.dump({'source': f'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 '
+                     f'--warmup 1 --no-cpu-baseline --no-kernel-events; see {tag}_pmc_summary.txt',
+           'correction': 'hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reads half of a '
+                         'coalesced stream, MI355X_MICROARCH.md HBM section)',
+           'hbm_bytes_per_launch': traffic}, open(os.path.join(prof, 'r01_traffic.json'), 'w'), indent=1)
+for name in ('c3', 'c4', 'c5', 'c2', 'pupil'):
+    src = os.path.join(ev, f'bench_{name}.json')
+    if os.path.exists(src) and os.path.getsize(src):
+        shutil.copy(src, os.path.join(prof, f'{tag}_bench_{name}.json'))
+for name in ('pytest_gpu.txt', 'smoke.txt', 'adam_time.txt'):
+    src = os.path.join(ev, name)
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(prof, f'{tag}_{name}'))
+print(b['ms_per_step'], b['value'], b['roofline']['frac'], b['roofline']['stage_avg_ms'])
+print(open(os.path.join(prof, f'{tag}_kernel_stats.txt')).read())
