@@ -7,7 +7,7 @@
 //   D3 dense_replay    : lane = (keypoint, chunk): exact filter, fuse, RTS; filtered beliefs go
 //                        through a per-lane scratch record stream (these problems are tiny:
 //                        BASELINE config 4 is 4 keypoints x 50k frames, latency- not HBM-bound)
-//   D4 dense_nll_assemble : lane = (keypoint, candidate): marginal log-likelihood (and d/dlog s)
+//   losses                : eks_nll / eks_ar1_nll, tree-composed chunk elements (below)
 #include <hip/hip_runtime.h>
 
 #include "eks_dense_lane.hpp"
@@ -252,162 +252,138 @@ __global__ __launch_bounds__(64) void dense_replay_kernel(DenseGeom G, DenseMode
                         filt + ((size_t)k * G.T + t0) * REC, ms, Vs, vs_diag != 0);
 }
 
-template <typename S, int D>
-__global__ __launch_bounds__(64) void dense_nll_summarize_kernel(DenseGeom G, DenseModelPtrs M,
-                                                                const double* __restrict__ s_cand,
-                                                                const float* __restrict__ y,
-                                                                const double* __restrict__ rconst,
-                                                                double* __restrict__ elems) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= G.K * G.nc * G.n_cand) return;
-  const int k = idx % G.K, rest = idx / G.K, c = rest % G.n_cand, j = rest / G.n_cand;
-  const double sv = G.per_keypoint ? s_cand[(size_t)k * G.n_cand + c] : s_cand[c];
-  Mat<S, D> F, sQ;
-  bool fid;
-  load_dynamics<S, D>(M, k, make_real(S(), sv, sv), F, sQ, fid);
-  const int t0 = j * G.B, len = min(G.B, G.T - t0);
-  const DElem<S, D> e =
-      dense_summarize_chunk<S, D, true>(y, nullptr, rconst, G.K, G.O, k, t0, len, M, F, sQ, fid);
-  constexpr int NREC = delem_doubles<D>() * (sizeof(S) > sizeof(double) ? 2 : 1);
-  store_delem<S, D>(elems + (size_t)idx * NREC, e);
-}
+// ---- filter losses: eks_nll on the general (D, O) path (constant R, candidates s, d/dlog s) and
+// eks_ar1_nll (pupil: AR(1) dynamics with explicit tangents, time-varying R_t).  Few chains,
+// evaluated hundreds to thousands of times per session: everything is arranged for depth.  A
+// "stream" is one (chain, candidate-or-tangent) pair.
+//   L1 loss_chunks : workgroup = 64 consecutive chunks of one stream (frames 1..T-1 as predict-
+//                    then-observe pairs, eks_dense_lane.hpp); each lane summarises its chunk
+//                    (loss_summarize_chunk), then the 64 elements are composed in time order
+//                    by a 6-level tree through LDS (delem_combine carries the log-likelihood)
+//   L2 loss_reduce : the same tree over the previous level's aggregates, repeated until one
+//                    element per stream remains; that launch updates the prior belief with frame
+//                    0, applies the element and writes nll / dnll.
+// Sensitivities are dual numbers: MODE 0 (AR(1)) stream c differentiates along (da[c], dq[c]);
+// MODE 1 (scaled process noise s Q) differentiates with respect to log s.
+constexpr int kLossCB = 64;
 
-// marginal log-likelihood of chain k through record stream c (candidate or tangent): the chunk
-// elements applied in time order to the prior belief
+struct LossGeom {
+  int K, T, O, B, nc, ns;   // ns = streams per chain
+};
+
+struct LossSpec {
+  const double *a, *q, *da, *dq;   // MODE 0: [K][D] and tangents [ns][K][D]
+  const double* s_cand;            // MODE 1: [ns] shared or [K][ns] per keypoint
+  int per_keypoint;
+  ObsNoise R;
+};
+
+template <typename S, int D, int MODE>
+struct LossDyn;
 template <typename S, int D>
-__device__ S dense_assemble_ll(const DenseGeom& G, const DenseModelPtrs& M,
-                               const double* __restrict__ elems, int k, int c) {
-  constexpr int NREC = delem_doubles<D>() * (sizeof(S) > sizeof(double) ? 2 : 1);
-  Vec<double, D> m0;
-  Mat<double, D> P0;
-  load_prior<D>(M, k, m0, P0);
-  Vec<S, D> m;
-  Mat<S, D> P;
-#pragma unroll
-  for (int a = 0; a < D; ++a) {
-    m.a[a] = S(m0.a[a]);
-#pragma unroll
-    for (int b = 0; b < D; ++b) P.a[a][b] = S(P0.a[a][b]);
+struct LossDyn<S, D, 0> {
+  using type = DynDiag<S, D>;
+  static __device__ type load(const LossGeom& G, const DenseModelPtrs&, const LossSpec& P, int k, int c) {
+    type dyn;
+    const size_t toff = (size_t)c * G.K * D;
+    load_ar1_dynamics<S, D>(P.a, P.q, P.da ? P.da + toff : nullptr, P.dq ? P.dq + toff : nullptr, k,
+                            dyn.a, dyn.q);
+    return dyn;
   }
-  S ll = S(0.0);
-  for (int j = 0; j < G.nc; ++j) {
-    const size_t rec = ((size_t)j * G.n_cand + c) * G.K + k;
-    const DElem<S, D> e = load_delem<S, D>(elems + rec * NREC);
-    ll = ll + delem_apply(e, m, P);
-  }
-  return ll;
-}
-
+};
 template <typename S, int D>
-__global__ __launch_bounds__(64) void dense_nll_assemble_kernel(DenseGeom G, DenseModelPtrs M,
-                                                               const double* __restrict__ elems,
-                                                               double* __restrict__ nll,
-                                                               double* __restrict__ dnll) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= G.K * G.n_cand) return;
-  const int k = idx % G.K, c = idx / G.K;
-  const S ll = dense_assemble_ll<S, D>(G, M, elems, k, c);
-  const double v = -val(ll);
-  const bool fin = isfinite(v);
-  nll[(size_t)k * G.n_cand + c] = fin ? v : 1e12;  // eks/core.py:650
-  if (dnll) dnll[(size_t)k * G.n_cand + c] = fin ? -der(ll) : 0.0;
-}
-
-// ---- AR(1) loss with the time-varying R_t (pupil smoother, eks/ibl_pupil_smoother.py:540-552).
-// One or a few chains, evaluated thousands of times per session: everything is arranged for
-// depth, not throughput.  A "stream" is one (chain, tangent) pair; tangent i differentiates along
-// (da[i], dq[i]) with dual numbers.
-//   A1 ar1_chunks : workgroup = 64 consecutive chunks of one stream (frames 1..T-1 as predict-
-//                   then-observe pairs, eks_dense_lane.hpp); each lane summarises its chunk
-//                   (ar1_summarize_chunk), then the 64 elements are composed in time order
-//                   by a 6-level tree through LDS (delem_combine carries the log-likelihood)
-//   A2 ar1_reduce : the same tree over the previous level's aggregates, repeated until one
-//                   element per stream remains; that launch updates the prior belief with frame
-//                   0, applies the element and writes nll / dnll.
-constexpr int kAr1CB = 64;
-
-struct Ar1Geom {
-  int K, T, O, B, nc, ns;   // ns = record streams per chain = max(n_tan, 1)
+struct LossDyn<S, D, 1> {
+  using type = DynFull<S, D>;
+  static __device__ type load(const LossGeom& G, const DenseModelPtrs& M, const LossSpec& P, int k, int c) {
+    type dyn;
+    const double sv = P.per_keypoint ? P.s_cand[(size_t)k * G.ns + c] : P.s_cand[c];
+    load_dynamics<S, D>(M, k, make_real(S(), sv, sv), dyn.F, dyn.sQ, dyn.f_identity);
+    return dyn;
+  }
 };
 
 // Ordered tree reduction of the workgroup's elements (lane i holds element i of n); the result
-// is in lane 0.  lds: kAr1CB * NREC doubles, field-major.
+// is in lane 0.  lds: kLossCB * NREC doubles, field-major.
 template <typename S, int D>
-__device__ void ar1_tree_reduce(DElem<S, D>& e, int i, int n, double* lds) {
+__device__ void loss_tree_reduce(DElem<S, D>& e, int i, int n, double* lds) {
   for (int half = 1; half < n; half <<= 1) {
     const int span = half << 1;
     const bool send = (i & (span - 1)) == half, recv = (i & (span - 1)) == 0 && i + half < n;
-    if (send && i < n) store_delem<S, D>(lds + i, e, kAr1CB);
+    if (send && i < n) store_delem<S, D>(lds + i, e, kLossCB);
     __syncthreads();
-    if (recv) e = delem_combine(e, load_delem<S, D>(lds + i + half, kAr1CB));
+    if (recv) e = delem_combine(e, load_delem<S, D>(lds + i + half, kLossCB));
   }
 }
 
-template <typename S, int D>
-__device__ void ar1_finish(const Ar1Geom& G, const DenseModelPtrs& M, const float* __restrict__ y,
-                           const float* __restrict__ var, const DElem<S, D>& e, int k, int c,
-                           double* __restrict__ nll, double* __restrict__ dnll) {
+template <typename S, int D, int MODE>
+__device__ void loss_finish(const LossGeom& G, const DenseModelPtrs& M, const LossSpec& P,
+                            const float* __restrict__ y, const DElem<S, D>& e, int k, int c,
+                            double* __restrict__ nll, double* __restrict__ dnll) {
   Vec<double, D> m0;
   Mat<double, D> P0;
   load_prior<D>(M, k, m0, P0);
   Vec<S, D> m;
-  Mat<S, D> P;
+  Mat<S, D> Pm;
 #pragma unroll
   for (int a = 0; a < D; ++a) {
     m.a[a] = S(m0.a[a]);
 #pragma unroll
-    for (int b = 0; b < D; ++b) P.a[a][b] = S(P0.a[a][b]);
+    for (int b = 0; b < D; ++b) Pm.a[a][b] = S(P0.a[a][b]);
   }
-  S ll = ar1_first_frame<S, D>(y, var, G.K, G.O, k, M, m, P);
-  if (G.T > 1) ll = ll + delem_apply(e, m, P);
-  if (c == 0) nll[k] = -val(ll);   // no 1e12 substitution in this loss (:551-552)
-  if (dnll) dnll[(size_t)c * G.K + k] = -der(ll);
+  S ll = loss_first_frame<S, D>(y, P.R, G.K, G.O, k, M, m, Pm);
+  if (G.T > 1) ll = ll + delem_apply(e, m, Pm);
+  if (MODE == 0) {
+    if (c == 0) nll[k] = -val(ll);   // no 1e12 substitution in the pupil loss (:551-552)
+    if (dnll) dnll[(size_t)c * G.K + k] = -der(ll);
+  } else {
+    const double v = -val(ll);
+    const bool fin = isfinite(v);
+    nll[(size_t)k * G.ns + c] = fin ? v : 1e12;  // eks/core.py:650
+    if (dnll) dnll[(size_t)k * G.ns + c] = fin ? -der(ll) : 0.0;
+  }
 }
 
-template <typename S, int D>
-__global__ __launch_bounds__(kAr1CB) void ar1_chunks_kernel(
-    Ar1Geom G, DenseModelPtrs M, const double* __restrict__ a, const double* __restrict__ q,
-    const double* __restrict__ da, const double* __restrict__ dq, const float* __restrict__ y,
-    const float* __restrict__ var, double* __restrict__ out, double* __restrict__ nll,
-    double* __restrict__ dnll) {
+template <typename S, int D, int MODE>
+__global__ __launch_bounds__(kLossCB) void loss_chunks_kernel(LossGeom G, DenseModelPtrs M, LossSpec P,
+                                                             const float* __restrict__ y,
+                                                             double* __restrict__ out,
+                                                             double* __restrict__ nll,
+                                                             double* __restrict__ dnll) {
   constexpr int NREC = delem_doubles<D>() * (sizeof(S) > sizeof(double) ? 2 : 1);
-  __shared__ double lds[kAr1CB * NREC];
+  __shared__ double lds[kLossCB * NREC];
   const int i = threadIdx.x, stream = blockIdx.y, k = stream % G.K, c = stream / G.K;
-  const int j0 = blockIdx.x * kAr1CB, n = min(kAr1CB, G.nc - j0), j = j0 + i;
+  const int j0 = blockIdx.x * kLossCB, n = min(kLossCB, G.nc - j0), j = j0 + i;
   DElem<S, D> e;
   if (i < n) {
-    Vec<S, D> av, qv;
-    const size_t toff = (size_t)c * G.K * D;
-    load_ar1_dynamics<S, D>(a, q, da ? da + toff : nullptr, dq ? dq + toff : nullptr, k, av, qv);
+    const typename LossDyn<S, D, MODE>::type dyn = LossDyn<S, D, MODE>::load(G, M, P, k, c);
     const int t0 = 1 + j * G.B;
-    e = ar1_summarize_chunk<S, D>(y, var, G.K, G.O, k, t0, min(G.B, G.T - t0), M, av, qv);
+    e = loss_summarize_chunk<S, D>(y, P.R, G.K, G.O, k, t0, min(G.B, G.T - t0), M, dyn);
   }
-  ar1_tree_reduce<S, D>(e, i, n, lds);
+  loss_tree_reduce<S, D>(e, i, n, lds);
   if (i != 0) return;
   if (gridDim.x == 1)
-    ar1_finish<S, D>(G, M, y, var, e, k, c, nll, dnll);
+    loss_finish<S, D, MODE>(G, M, P, y, e, k, c, nll, dnll);
   else
     store_delem<S, D>(out + ((size_t)stream * gridDim.x + blockIdx.x) * NREC, e);
 }
 
-template <typename S, int D>
-__global__ __launch_bounds__(kAr1CB) void ar1_reduce_kernel(Ar1Geom G, DenseModelPtrs M,
-                                                           const float* __restrict__ y,
-                                                           const float* __restrict__ var, int n_in,
-                                                           const double* __restrict__ in,
-                                                           double* __restrict__ out,
-                                                           double* __restrict__ nll,
-                                                           double* __restrict__ dnll) {
+template <typename S, int D, int MODE>
+__global__ __launch_bounds__(kLossCB) void loss_reduce_kernel(LossGeom G, DenseModelPtrs M, LossSpec P,
+                                                             const float* __restrict__ y, int n_in,
+                                                             const double* __restrict__ in,
+                                                             double* __restrict__ out,
+                                                             double* __restrict__ nll,
+                                                             double* __restrict__ dnll) {
   constexpr int NREC = delem_doubles<D>() * (sizeof(S) > sizeof(double) ? 2 : 1);
-  __shared__ double lds[kAr1CB * NREC];
+  __shared__ double lds[kLossCB * NREC];
   const int i = threadIdx.x, stream = blockIdx.y, k = stream % G.K, c = stream / G.K;
-  const int j0 = blockIdx.x * kAr1CB, n = min(kAr1CB, n_in - j0);
+  const int j0 = blockIdx.x * kLossCB, n = min(kLossCB, n_in - j0);
   DElem<S, D> e;
   if (i < n) e = load_delem<S, D>(in + ((size_t)stream * n_in + j0 + i) * NREC);
-  ar1_tree_reduce<S, D>(e, i, n, lds);
+  loss_tree_reduce<S, D>(e, i, n, lds);
   if (i != 0) return;
   if (gridDim.x == 1)
-    ar1_finish<S, D>(G, M, y, var, e, k, c, nll, dnll);
+    loss_finish<S, D, MODE>(G, M, P, y, e, k, c, nll, dnll);
   else
     store_delem<S, D>(out + ((size_t)stream * gridDim.x + blockIdx.x) * NREC, e);
 }
@@ -422,13 +398,6 @@ size_t dense_smooth_workspace_bytes(int T, int K, int D, int O) {
   return align_up((size_t)nc * K * nv * 8, 256) + 2 * align_up((size_t)nc * K * rec * 8, 256) +
          align_up((size_t)nblk * K * nv * 8, 256) + 2 * align_up((size_t)nblk * K * rec * 8, 256) +
          align_up((size_t)T * K * rec * 8, 256) + align_up((size_t)K * rec * 8, 256);
-}
-
-size_t dense_nll_workspace_bytes(int T, int K, int D, int O, int n_cand) {
-  (void)O;
-  const int B = dense_chunk(T), nc = (T + B - 1) / B;
-  const size_t nv = 3 * D * D + 2 * D + 1;
-  return align_up((size_t)nc * K * n_cand * nv * 2 * 8, 256);
 }
 
 #define EKS_DISPATCH_D(D_, BODY) \
@@ -494,39 +463,10 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
   return hip_status(hipGetLastError());
 }
 
-int dense_nll(const eks_dims_t& d, const float* y, const double* rconst, const DenseModel& Mm,
-              const double* s_cand, int n_cand, int per_keypoint, double* nll, double* dnll,
-              void* ws, size_t ws_bytes, hipStream_t st) {
-  const int T = d.n_frames, K = d.n_keypoints, D = d.state_dim, O = d.obs_dim;
-  if (D < 1 || D > 6 || O < 1 || O > 64) return EKS_ERR_UNSUPPORTED;
-  if (ws_bytes < dense_nll_workspace_bytes(T, K, D, O, n_cand)) return EKS_ERR_WORKSPACE;
-  DenseGeom G{K, T, O, dense_chunk(T), 0, n_cand, per_keypoint};
-  G.nc = (T + G.B - 1) / G.B;
-  const DenseModelPtrs M{Mm.m0, Mm.S0, Mm.A, Mm.C, Mm.Q};
-  double* elems = static_cast<double*>(ws);
-  const int lanes = K * G.nc * n_cand, lanes2 = K * n_cand;
-  if (dnll) {
-    EKS_DISPATCH_D(D, {
-      hipLaunchKernelGGL((dense_nll_summarize_kernel<DualD, DD>), dim3((lanes + 63) / 64), dim3(64), 0,
-                         st, G, M, s_cand, y, rconst, elems);
-      hipLaunchKernelGGL((dense_nll_assemble_kernel<DualD, DD>), dim3((lanes2 + 63) / 64), dim3(64), 0,
-                         st, G, M, elems, nll, dnll);
-    })
-  } else {
-    EKS_DISPATCH_D(D, {
-      hipLaunchKernelGGL((dense_nll_summarize_kernel<double, DD>), dim3((lanes + 63) / 64), dim3(64),
-                         0, st, G, M, s_cand, y, rconst, elems);
-      hipLaunchKernelGGL((dense_nll_assemble_kernel<double, DD>), dim3((lanes2 + 63) / 64), dim3(64),
-                         0, st, G, M, elems, nll, dnll);
-    })
-  }
-  return hip_status(hipGetLastError());
-}
-
 // frames per lane: short chunks keep the per-lane recursion short (a frame costs about a fifth
 // of an element composition, and the tree adds one composition per doubling of the chunk
 // count); they grow only when the launch would exceed a few waves per SIMD
-static int ar1_chunk(int T, int streams) {
+static int loss_chunk(int T, int streams) {
   int b = 8;
   while ((long)((T + b - 1) / b) * streams > (1L << 18)) b <<= 1;
   return b;
@@ -534,38 +474,66 @@ static int ar1_chunk(int T, int streams) {
 
 // chunks cover frames 1..T-1 (frame 0 updates the prior in the finishing launch); at least one
 // (possibly empty) chunk so that a launch exists to finish
-static int ar1_chunks(int T, int B) { return T > 1 ? (T - 1 + B - 1) / B : 1; }
+static int loss_chunks(int T, int B) { return T > 1 ? (T - 1 + B - 1) / B : 1; }
 
-size_t ar1_nll_workspace_bytes(int T, int K, int D, int n_tan) {
-  const int ns = n_tan > 0 ? n_tan : 1, B = ar1_chunk(T, K * ns), nc = ar1_chunks(T, B);
+static size_t loss_workspace_bytes(int T, int K, int D, int ns) {
+  const int B = loss_chunk(T, K * ns), nc = loss_chunks(T, B);
   const size_t nv = 3 * D * D + 2 * D + 1;
   size_t total = 0;
-  for (int n = (nc + kAr1CB - 1) / kAr1CB; n > 1; n = (n + kAr1CB - 1) / kAr1CB) {
+  for (int n = (nc + kLossCB - 1) / kLossCB; n > 1; n = (n + kLossCB - 1) / kLossCB) {
     total += align_up((size_t)n * K * ns * nv * 2 * 8, 256);
-    if (n <= kAr1CB) break;
+    if (n <= kLossCB) break;
   }
   return total + 256;
 }
 
-template <typename S, int DD>
-static void ar1_launch(const Ar1Geom& G, const DenseModelPtrs& M, const double* a, const double* q,
-                       const double* da, const double* dq, const float* y, const float* var,
-                       double* nll, double* dnll, char* ws, hipStream_t st) {
+template <typename S, int DD, int MODE>
+static void loss_launch(const LossGeom& G, const DenseModelPtrs& M, const LossSpec& P, const float* y,
+                        double* nll, double* dnll, char* ws, hipStream_t st) {
   constexpr size_t rec_bytes = (3 * DD * DD + 2 * DD + 1) * (sizeof(S) > sizeof(double) ? 2 : 1) * 8;
   const int streams = G.K * G.ns;
-  int n = (G.nc + kAr1CB - 1) / kAr1CB;
+  int n = (G.nc + kLossCB - 1) / kLossCB;
   double* out = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL((ar1_chunks_kernel<S, DD>), dim3(n, streams), dim3(kAr1CB), 0, st, G, M, a, q, da,
-                     dq, y, var, out, nll, dnll);
+  hipLaunchKernelGGL((loss_chunks_kernel<S, DD, MODE>), dim3(n, streams), dim3(kLossCB), 0, st, G, M, P, y,
+                     out, nll, dnll);
   while (n > 1) {
-    const int n_out = (n + kAr1CB - 1) / kAr1CB;
+    const int n_out = (n + kLossCB - 1) / kLossCB;
     double* in = out;
     out = reinterpret_cast<double*>(reinterpret_cast<char*>(in) +
                                     align_up((size_t)n * streams * rec_bytes, 256));
-    hipLaunchKernelGGL((ar1_reduce_kernel<S, DD>), dim3(n_out, streams), dim3(kAr1CB), 0, st, G, M, y,
-                       var, n, in, out, nll, dnll);
+    hipLaunchKernelGGL((loss_reduce_kernel<S, DD, MODE>), dim3(n_out, streams), dim3(kLossCB), 0, st, G, M,
+                       P, y, n, in, out, nll, dnll);
     n = n_out;
   }
+}
+
+size_t dense_nll_workspace_bytes(int T, int K, int D, int O, int n_cand) {
+  (void)O;
+  return loss_workspace_bytes(T, K, D, n_cand);
+}
+
+int dense_nll(const eks_dims_t& d, const float* y, const double* rconst, const DenseModel& Mm,
+              const double* s_cand, int n_cand, int per_keypoint, double* nll, double* dnll,
+              void* ws, size_t ws_bytes, hipStream_t st) {
+  const int T = d.n_frames, K = d.n_keypoints, D = d.state_dim, O = d.obs_dim;
+  if (D < 1 || D > 6 || O < 1 || O > 64) return EKS_ERR_UNSUPPORTED;
+  if ((long)K * n_cand > 65535) return EKS_ERR_UNSUPPORTED;
+  if (ws_bytes < dense_nll_workspace_bytes(T, K, D, O, n_cand)) return EKS_ERR_WORKSPACE;
+  LossGeom G{K, T, O, loss_chunk(T, K * n_cand), 0, n_cand};
+  G.nc = loss_chunks(T, G.B);
+  const DenseModelPtrs M{Mm.m0, Mm.S0, Mm.A, Mm.C, Mm.Q};
+  const LossSpec P{nullptr, nullptr, nullptr, nullptr, s_cand, per_keypoint, ObsNoise{nullptr, rconst}};
+  ProfScope ps("dense_nll", st);
+  if (dnll) {
+    EKS_DISPATCH_D(D, (loss_launch<DualD, DD, 1>(G, M, P, y, nll, dnll, static_cast<char*>(ws), st)))
+  } else {
+    EKS_DISPATCH_D(D, (loss_launch<double, DD, 1>(G, M, P, y, nll, nullptr, static_cast<char*>(ws), st)))
+  }
+  return hip_status(hipGetLastError());
+}
+
+size_t ar1_nll_workspace_bytes(int T, int K, int D, int n_tan) {
+  return loss_workspace_bytes(T, K, D, n_tan > 0 ? n_tan : 1);
 }
 
 int ar1_nll(const eks_dims_t& d, const float* y, const float* var, const double* m0,
@@ -576,16 +544,17 @@ int ar1_nll(const eks_dims_t& d, const float* y, const float* var, const double*
   if (D < 1 || D > 6 || O < 1 || O > 64) return EKS_ERR_UNSUPPORTED;
   if (ws_bytes < ar1_nll_workspace_bytes(T, K, D, n_tan)) return EKS_ERR_WORKSPACE;
   const int ns = n_tan > 0 ? n_tan : 1;
-  Ar1Geom G{K, T, O, ar1_chunk(T, K * ns), 0, ns};
-  G.nc = ar1_chunks(T, G.B);
+  if ((long)K * ns > 65535) return EKS_ERR_UNSUPPORTED;
+  LossGeom G{K, T, O, loss_chunk(T, K * ns), 0, ns};
+  G.nc = loss_chunks(T, G.B);
   const DenseModelPtrs M{m0, S0, nullptr, C, nullptr};
   ProfScope ps("ar1_nll", st);
   if (n_tan > 0) {
-    EKS_DISPATCH_D(D, (ar1_launch<DualD, DD>(G, M, a, q, da, dq, y, var, nll, dnll,
-                                             static_cast<char*>(ws), st)))
+    const LossSpec P{a, q, da, dq, nullptr, 0, ObsNoise{var, nullptr}};
+    EKS_DISPATCH_D(D, (loss_launch<DualD, DD, 0>(G, M, P, y, nll, dnll, static_cast<char*>(ws), st)))
   } else {
-    EKS_DISPATCH_D(D, (ar1_launch<double, DD>(G, M, a, q, nullptr, nullptr, y, var, nll, nullptr,
-                                              static_cast<char*>(ws), st)))
+    const LossSpec P{a, q, nullptr, nullptr, nullptr, 0, ObsNoise{var, nullptr}};
+    EKS_DISPATCH_D(D, (loss_launch<double, DD, 0>(G, M, P, y, nll, nullptr, static_cast<char*>(ws), st)))
   }
   return hip_status(hipGetLastError());
 }

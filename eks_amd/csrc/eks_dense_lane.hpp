@@ -46,60 +46,56 @@ EKS_HD Vec<S, D> load_obs_row(const DenseModelPtrs& M, int k, int O, int o) {
   return h;
 }
 
-// K1: element of frames [t0, t0+len) of keypoint k.  CONST_R: constant observation variances
-// rconst[k][o] (the loss, eks/core.py:602); otherwise R_t from var.  WANT_ELL accumulates the
-// log-likelihood part (the losses; the pupil loss keeps the time-varying R_t,
-// eks/ibl_pupil_smoother.py:514-518).
-template <typename S, int D, bool CONST_R, bool WANT_ELL = CONST_R>
-EKS_HD DElem<S, D> dense_summarize_chunk(const float* __restrict__ y, const float* __restrict__ var,
-                                         const double* __restrict__ rconst, int K, int O, int k,
-                                         int t0, int len, const DenseModelPtrs& M,
-                                         const Mat<S, D>& F, const Mat<S, D>& sQ, bool f_identity) {
-  DElem<S, D> e = delem_identity<S, D>();
-  for (int t = t0; t < t0 + len; ++t) {
-    const size_t row = ((size_t)t * K + k) * O;
-    for (int o = 0; o < O; ++o) {
-      double r;
-      if (CONST_R) {
-        r = rconst[(size_t)k * O + o];
-      } else {
-        const float v = var[row + o];
-        r = v > kVarFloor ? (double)v : (double)kVarFloor;
-      }
-      delem_observe(e, load_obs_row<S, D>(M, k, O, o), S((double)y[row + o]), S(r), WANT_ELL);
-    }
-    delem_predict(e, F, sQ, f_identity);
-  }
-  return e;
-}
-
-// AR(1) loss with the time-varying R_t (eks/ibl_pupil_smoother.py:514-518, :540-552).
+// ---- filter losses (marginal log-likelihood and its forward sensitivities) --------------------
+// Two users: the smoothing-parameter loss of eks/core.py:640-650 on the general (D, O) path
+// (dynamics A, s Q with d/dlog s; CONSTANT R) and the pupil loss of eks/ibl_pupil_smoother.py:
+// 540-552 (AR(1) dynamics diag(a), diag(q) with explicit tangents; TIME-VARYING R_t, :514-518).
 //
-// Frame 0 updates the prior belief directly (ar1_first_frame); every later frame t enters a chunk
+// Frame 0 updates the prior belief directly (loss_first_frame); every later frame t enters a chunk
 // element as the pair (predict into t, observe t).  With the predict FIRST the element's
 // information about its entry state is bounded by the process noise, so its (eta, J, ell) stay
-// moderate even when an ensemble variance sits at the 1e-12 clip - an element that opened with an
+// moderate even when a variance sits at the 1e-12 clip - an element that opened with an
 // observation would carry y^2 / r ~ 1e14 terms that only cancel in the final assembly.
 //
 // Per frame the O observations are folded into information form in plain doubles (they do not
 // depend on the parameters) and absorbed as D pseudo-observations (delem_observe_info).  A frame
 // whose variances span more than 8 decades is absorbed observation by observation instead (the
 // information matrix would lose the large-variance rows to rounding).
+struct ObsNoise {
+  const float* var;       // [T][K][O] time-varying ensemble variances, or
+  const double* rconst;   // [K][O] constant variances (exactly one of the two is non-null)
+  EKS_HD double at(size_t row, int k, int O, int o) const {
+    if (rconst) return rconst[(size_t)k * O + o];
+    const float v = var[row + o];
+    return v > kVarFloor ? (double)v : (double)kVarFloor;
+  }
+};
+
 template <typename S, int D>
-EKS_HD DElem<S, D> ar1_summarize_chunk(const float* __restrict__ y, const float* __restrict__ var,
-                                       int K, int O, int k, int t0, int len,
-                                       const DenseModelPtrs& M, const Vec<S, D>& av,
-                                       const Vec<S, D>& qv) {
+struct DynDiag {            // x' = diag(a) x + N(0, diag(q))
+  Vec<S, D> a, q;
+  EKS_HD void predict(DElem<S, D>& e) const { delem_predict_diag(e, a, q); }
+};
+template <typename S, int D>
+struct DynFull {            // x' = F x + N(0, sQ)
+  Mat<S, D> F, sQ;
+  bool f_identity;
+  EKS_HD void predict(DElem<S, D>& e) const { delem_predict(e, F, sQ, f_identity); }
+};
+
+template <typename S, int D, typename Dyn>
+EKS_HD DElem<S, D> loss_summarize_chunk(const float* __restrict__ y, const ObsNoise& R, int K, int O,
+                                        int k, int t0, int len, const DenseModelPtrs& M,
+                                        const Dyn& dyn) {
   DElem<S, D> e = delem_identity<S, D>();
   for (int t = t0; t < t0 + len; ++t) {
-    delem_predict_diag(e, av, qv);
+    dyn.predict(e);
     const size_t row = ((size_t)t * K + k) * O;
     Mat<double, D> Lam = mat_zero<double, D>();
     Vec<double, D> nu = vec_zero<double, D>();
     double c = O * kLog2Pi, rmin = 1e300, rmax = 0.0;
     for (int o = 0; o < O; ++o) {
-      const float v = var[row + o];
-      const double r = v > kVarFloor ? (double)v : (double)kVarFloor;
+      const double r = R.at(row, k, O, o);
       const double yo = (double)y[row + o], w = 1.0 / r;
       rmin = fmin(rmin, r);
       rmax = fmax(rmax, r);
@@ -115,11 +111,9 @@ EKS_HD DElem<S, D> ar1_summarize_chunk(const float* __restrict__ y, const float*
     if (rmax <= 1e8 * rmin) {
       delem_observe_info(e, Lam, nu, c);
     } else {
-      for (int o = 0; o < O; ++o) {
-        const float v = var[row + o];
-        const double r = v > kVarFloor ? (double)v : (double)kVarFloor;
-        delem_observe(e, load_obs_row<S, D>(M, k, O, o), S((double)y[row + o]), S(r), true);
-      }
+      for (int o = 0; o < O; ++o)
+        delem_observe(e, load_obs_row<S, D>(M, k, O, o), S((double)y[row + o]), S(R.at(row, k, O, o)),
+                      true);
     }
   }
   return e;
@@ -128,14 +122,13 @@ EKS_HD DElem<S, D> ar1_summarize_chunk(const float* __restrict__ y, const float*
 // Measurement update of the belief N(m, P) with frame 0 (scalar observation at a time); returns
 // the frame's log-likelihood.
 template <typename S, int D>
-EKS_HD S ar1_first_frame(const float* __restrict__ y, const float* __restrict__ var, int K, int O,
-                         int k, const DenseModelPtrs& M, Vec<S, D>& m, Mat<S, D>& P) {
+EKS_HD S loss_first_frame(const float* __restrict__ y, const ObsNoise& R, int K, int O, int k,
+                          const DenseModelPtrs& M, Vec<S, D>& m, Mat<S, D>& P) {
   S ll = S(0.0);
   const size_t row = (size_t)k * O;
   for (int o = 0; o < O; ++o) {
     const Vec<S, D> h = load_obs_row<S, D>(M, k, O, o);
-    const float v = var[row + o];
-    const S r = S(v > kVarFloor ? (double)v : (double)kVarFloor);
+    const S r = S(R.at(row, k, O, o));
     const Vec<S, D> u = mat_vec(P, h);
     const S sigma = r + dot(h, u), g = rcp(sigma), d = S((double)y[row + o]) - dot(h, m), gd = g * d;
     ll = ll - S(0.5) * (S(kLog2Pi) + log_s(sigma) + d * gd);

@@ -10,13 +10,14 @@
 using namespace eks;
 
 // nll and (n_tan > 0) dnll[i] along the tangents (da[i], dq[i]) of one chain, chunks of B frames:
-// what ar1_chunks_kernel + ar1_reduce_kernel compute (eks_dense.hip); tree = 0 applies the chunk
+// what loss_chunks_kernel + loss_reduce_kernel compute (eks_dense.hip); tree = 0 applies the chunk
 // elements one after the other instead of composing them first
 template <typename S, int D>
 static S ar1_ll(int T, int O, int B, bool tree, const float* y, const float* var, const DenseModelPtrs& M,
                 const double* a, const double* q, const double* da, const double* dq) {
-  Vec<S, D> av, qv;
-  load_ar1_dynamics<S, D>(a, q, da, dq, 0, av, qv);
+  DynDiag<S, D> dyn;
+  load_ar1_dynamics<S, D>(a, q, da, dq, 0, dyn.a, dyn.q);
+  const ObsNoise R{var, nullptr};
   Vec<double, D> m0;
   Mat<double, D> P0;
   load_prior<D>(M, 0, m0, P0);
@@ -26,11 +27,11 @@ static S ar1_ll(int T, int O, int B, bool tree, const float* y, const float* var
     m.a[i] = S(m0.a[i]);
     for (int j = 0; j < D; ++j) P.a[i][j] = S(P0.a[i][j]);
   }
-  S ll = ar1_first_frame<S, D>(y, var, 1, O, 0, M, m, P);
+  S ll = loss_first_frame<S, D>(y, R, 1, O, 0, M, m, P);
   if (T == 1) return ll;
   std::vector<DElem<S, D>> el;
   for (int t0 = 1; t0 < T; t0 += B) {
-    const DElem<S, D> e = ar1_summarize_chunk<S, D>(y, var, 1, O, 0, t0, std::min(B, T - t0), M, av, qv);
+    const DElem<S, D> e = loss_summarize_chunk<S, D>(y, R, 1, O, 0, t0, std::min(B, T - t0), M, dyn);
     if (tree)
       el.push_back(e);
     else
@@ -121,4 +122,57 @@ extern "C" int sim_dense_smooth(int T, int K, int D, int O, int B, const float* 
     case 4: dense_smooth_sim<4>(T, K, O, B, y, var, M, s, ms, Vs); return 0;
     default: return -3;
   }
+}
+
+// eks_nll on the general (D, O) path: constant R, process noise s Q, d nll / d log s by dual
+// numbers; chunk elements composed in the kernels' tree order (loss_chunks / loss_reduce, MODE 1).
+template <typename S, int D>
+static S scaled_ll(int T, int K, int O, int B, int k, const float* y, const double* rconst,
+                   const DenseModelPtrs& M, double s) {
+  DynFull<S, D> dyn;
+  load_dynamics<S, D>(M, k, make_real(S(), s, s), dyn.F, dyn.sQ, dyn.f_identity);
+  const ObsNoise R{nullptr, rconst};
+  Vec<double, D> m0;
+  Mat<double, D> P0;
+  load_prior<D>(M, k, m0, P0);
+  Vec<S, D> m;
+  Mat<S, D> P;
+  for (int i = 0; i < D; ++i) {
+    m.a[i] = S(m0.a[i]);
+    for (int j = 0; j < D; ++j) P.a[i][j] = S(P0.a[i][j]);
+  }
+  S ll = loss_first_frame<S, D>(y, R, K, O, k, M, m, P);
+  if (T == 1) return ll;
+  std::vector<DElem<S, D>> el;
+  for (int t0 = 1; t0 < T; t0 += B)
+    el.push_back(loss_summarize_chunk<S, D>(y, R, K, O, k, t0, std::min(B, T - t0), M, dyn));
+  while (el.size() > 1) {
+    std::vector<DElem<S, D>> next;
+    for (size_t j0 = 0; j0 < el.size(); j0 += 64) {
+      const size_t n = std::min<size_t>(64, el.size() - j0);
+      for (size_t half = 1; half < n; half <<= 1)
+        for (size_t i = 0; i + half < n; i += 2 * half) el[j0 + i] = delem_combine(el[j0 + i], el[j0 + i + half]);
+      next.push_back(el[j0]);
+    }
+    el.swap(next);
+  }
+  return ll + delem_apply(el[0], m, P);
+}
+
+extern "C" int sim_dense_nll(int T, int K, int D, int O, int B, const float* y, const double* rconst,
+                             const double* m0, const double* S0, const double* A, const double* C,
+                             const double* Q, const double* s, double* nll, double* dnll) {
+  const DenseModelPtrs M{m0, S0, A, C, Q};
+  for (int k = 0; k < K; ++k) {
+    DualD ll;
+    switch (D) {
+      case 2: ll = scaled_ll<DualD, 2>(T, K, O, B, k, y, rconst, M, s[k]); break;
+      case 3: ll = scaled_ll<DualD, 3>(T, K, O, B, k, y, rconst, M, s[k]); break;
+      case 4: ll = scaled_ll<DualD, 4>(T, K, O, B, k, y, rconst, M, s[k]); break;
+      default: return -3;
+    }
+    nll[k] = -ll.v;
+    dnll[k] = -ll.d;
+  }
+  return 0;
 }

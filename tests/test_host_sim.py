@@ -135,3 +135,29 @@ def test_dense_chunked_smoother_matches_oracle_also_at_the_variance_clip(dense_s
     ms_k, Vs_k = np.swapaxes(ms, 0, 1), np.swapaxes(Vs, 0, 1)
     assert (np.abs(ms_k - ms_o) / np.abs(ms_o).max(axis=(1, 2), keepdims=True)).max() < 1e-6
     assert (np.abs(Vs_k - Vs_o) / np.abs(Vs_o).max(axis=1, keepdims=True)).max() < 1e-6
+
+
+@pytest.mark.parametrize('D,O,general_A', [(3, 4, False), (2, 2, True), (4, 8, False)])
+def test_dense_loss_and_log_s_sensitivity_match_oracle(dense_sim, D, O, general_A):
+    """eks_nll on the general path: predict-first chunk elements, D pseudo-observations per frame,
+    tree composition, dual-number d/dlog s - against the oracle's filter and forward sensitivity."""
+    rng = np.random.default_rng(D * 10 + O)
+    T, K, B = 900, 3, 8
+    x = np.cumsum(rng.standard_normal((K, T, D)) * 0.5, axis=1)
+    C = rng.standard_normal((K, O, D))
+    y = (np.einsum('kod,ktd->tko', C, x) + rng.standard_normal((T, K, O)) * 0.7).astype(np.float32)
+    L = rng.standard_normal((K, D, D)) * 0.3
+    Q = L @ np.swapaxes(L, 1, 2) + 0.2 * np.eye(D)
+    A = np.tile(np.eye(D), (K, 1, 1))
+    if general_A:
+        A = A * 0.97 + 0.02 * rng.standard_normal((K, D, D))
+    m0, S0 = rng.standard_normal((K, D)), np.tile(3.0 * np.eye(D), (K, 1, 1))
+    rconst = rng.uniform(0.2, 1.5, (K, O))
+    s = np.exp(rng.uniform(-4, 3, K))
+    nll, dn = np.zeros(K), np.zeros(K)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)      # noqa: E731
+    assert dense_sim.sim_dense_nll(T, K, D, O, B, p(y), p(rconst), p(m0), p(S0), p(A), p(C), p(Q), p(s),
+                                   p(nll), p(dn)) == 0
+    ref, g = orc.filter_nll(np.swapaxes(y, 0, 1).astype(np.float64), m0, S0, A, C, Q, s, rconst, want_grad=True)
+    np.testing.assert_allclose(nll, ref, rtol=1e-10)
+    np.testing.assert_allclose(dn, g, rtol=1e-8, atol=1e-9 * np.abs(g).max())
