@@ -16,14 +16,8 @@
 namespace eks {
 
 struct DenseGeom {
-  int K, T, O, B, nc, n_cand, per_keypoint;
+  int K, T, O, B, nc;
 };
-
-static int dense_chunk(int T) {
-  int b = 16;
-  while (b < 512 && (long)b * b < T) b <<= 1;
-  return b;
-}
 
 template <int D>
 __global__ __launch_bounds__(64) void dense_summarize_kernel(DenseGeom G, DenseModelPtrs M,
@@ -416,7 +410,7 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
   const int T = d.n_frames, K = d.n_keypoints, D = d.state_dim, O = d.obs_dim;
   if (D < 1 || D > 6 || O < 1 || O > 64) return EKS_ERR_UNSUPPORTED;
   if (ws_bytes < dense_smooth_workspace_bytes(T, K, D, O)) return EKS_ERR_WORKSPACE;
-  DenseGeom G{K, T, O, kDenseSmoothChunk, 0, 1, 0};
+  DenseGeom G{K, T, O, kDenseSmoothChunk, 0};
   G.nc = (T + G.B - 1) / G.B;
   const int nblk = (G.nc + kDenseCB - 1) / kDenseCB;
   const DenseModelPtrs M{Mm.m0, Mm.S0, Mm.A, Mm.C, Mm.Q};
