@@ -48,12 +48,16 @@ struct NllGeom {
   int converged_entry;   // chunks j >= 1 may assume the filter variance has converged (float path)
 };
 
-template <typename R, int NCL, bool UNIT>
+template <typename R, int NCL, bool UNIT, bool TILE64>
 __global__ __launch_bounds__(512) void diag_nll_summarize_kernel(NllGeom G, DiagModel M, NllWs W,
                                           const float* __restrict__ y,
                                           const double* __restrict__ rconst,
                                           const double* __restrict__ s_cand) {
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // TILE64: a wave holds 64 chains of ONE chunk and one candidate group, so everything derived
+  // from the wave index is scalar (readfirstlane tells the compiler): chunk bounds, loop trip
+  // counts and the row addresses of y (SGPR base + per-lane offset, no VALU address arithmetic)
+  int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (TILE64) wave = __builtin_amdgcn_readfirstlane(wave);
   const int lane = threadIdx.x & 63;
   const int g = wave % G.ngrp;
   const int rest = wave / G.ngrp;
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(512) void diag_nll_summarize_kernel(NllGeom G, Diag
   const int cg = rest / G.ntile;
   const int nt = 1 << G.nt_log2;
   const int n = tile * nt + (lane & (nt - 1));
-  const int j = cg * (64 >> G.nt_log2) + (lane >> G.nt_log2);
+  const int j = TILE64 ? cg : cg * (64 >> G.nt_log2) + (lane >> G.nt_log2);
   if (n >= G.N || j >= G.ncn) return;
   const int k = n / G.D, d = n - k * G.D;
   const size_t dd = (size_t)k * G.D * G.D + (size_t)d * (G.D + 1);
@@ -78,7 +82,8 @@ __global__ __launch_bounds__(512) void diag_nll_summarize_kernel(NllGeom G, Diag
   const int t0 = j == 0 ? 0 : G.B0 + (j - 1) * G.BN;
   const int len = j == 0 ? min(G.B0, G.T) : min(G.BN, G.T - t0);
   NllElem<R> out[NCL];
-  nll_summarize_chunk<R, NCL, UNIT>(y, G.N, n, t0, len, rconst[n], M.A[dd], M.C[dd], sq, out,
+  const float* y_chunk = y + (size_t)t0 * G.N;
+  nll_summarize_chunk<R, NCL, UNIT>(y_chunk, G.N, n, t0, len, rconst[n], M.A[dd], M.C[dd], sq, out,
                                     G.converged_entry != 0);
 #pragma unroll
   for (int c = 0; c < NCL; ++c) {
@@ -366,14 +371,20 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
   }
   const dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
   const bool unit = d.flags & EKS_FLAG_UNIT_AC;
-#define EKS_NLL_LAUNCH(RT, NCL)                                                                  \
-  do {                                                                                           \
-    if (unit)                                                                                    \
-      hipLaunchKernelGGL((diag_nll_summarize_kernel<RT, NCL, true>), grid, block, 0, st, G, M, W, \
-                         y, rconst, s_cand);                                                     \
-    else                                                                                         \
-      hipLaunchKernelGGL((diag_nll_summarize_kernel<RT, NCL, false>), grid, block, 0, st, G, M,  \
-                         W, y, rconst, s_cand);                                                  \
+  const bool tile64 = G.nt_log2 == 6;
+#define EKS_NLL_LAUNCH2(RT, NCL, UN, T64)                                                          \
+  hipLaunchKernelGGL((diag_nll_summarize_kernel<RT, NCL, UN, T64>), grid, block, 0, st, G, M, W, y, \
+                     rconst, s_cand)
+#define EKS_NLL_LAUNCH(RT, NCL)                          \
+  do {                                                   \
+    if (unit && tile64)                                  \
+      EKS_NLL_LAUNCH2(RT, NCL, true, true);              \
+    else if (unit)                                       \
+      EKS_NLL_LAUNCH2(RT, NCL, true, false);             \
+    else if (tile64)                                     \
+      EKS_NLL_LAUNCH2(RT, NCL, false, true);             \
+    else                                                 \
+      EKS_NLL_LAUNCH2(RT, NCL, false, false);            \
   } while (0)
   {
     ProfScope ps("diag_nll_summarize", st);
@@ -390,6 +401,7 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
     }
   }
 #undef EKS_NLL_LAUNCH
+#undef EKS_NLL_LAUNCH2
   const int total = K * n_cand;
   ProfScope ps2("diag_nll_assemble", st);
   if (tree) {

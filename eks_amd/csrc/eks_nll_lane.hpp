@@ -274,13 +274,17 @@ EKS_HD void nll_lane_finish(NllLane<R, NCL, UNIT>& L, int len, NllElem<R>* out) 
 // only valid in a strictly sequential assembly (nll_assemble), where P is P_inf when it is used.
 // Taken only when every lane of the wave has rho^(2 t0) < 1e-20 and rho^t dies inside the chunk.
 template <typename R, int NCL, bool UNIT>
-EKS_HD void nll_summarize_chunk(const float* __restrict__ y, int N, int n, int t0, int len,
+EKS_HD void nll_summarize_chunk(const float* __restrict__ y_chunk, int N, int n, int t0, int len,
                                 double r_d, double a_d, double c_d, const double* sq_d,
                                 NllElem<R>* out, bool allow_converged_entry = false) {
   NllLane<R, NCL, UNIT> L;
   nll_lane_init<R, NCL, UNIT>(L, r_d, a_d, c_d, sq_d);
   const float af = (float)a_d;
-  const float* yp = y + (size_t)t0 * N + n;
+  // `y_chunk` = y + t0 * N: the kernels make it wave-uniform when a wave holds 64 chains of ONE
+  // chunk, so that the row addresses are scalar arithmetic (SGPR base + per-lane offset n) and
+  // the load costs no VALU instruction
+  const float* yrow = y_chunk;
+  const unsigned un = (unsigned)n;
   const size_t rs = (size_t)N;
   const int nfull = len / 8;
   int blk = 0;
@@ -327,15 +331,15 @@ EKS_HD void nll_summarize_chunk(const float* __restrict__ y, int N, int n, int t
       // go to float64 and the rho^t trackers are examined every 32 frames
       float ya[8], yb[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) ya[q] = yp[(size_t)q * rs];
+      for (int q = 0; q < 8; ++q) ya[q] = (yrow + (size_t)q * rs)[un];
       bool alive = true;
       while (alive && blk + 2 <= nfull) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) yb[q] = yp[(size_t)((blk + 1) * 8 + q) * rs];
+        for (int q = 0; q < 8; ++q) yb[q] = (yrow + (size_t)((blk + 1) * 8 + q) * rs)[un];
         eat4(ya);
         if (blk + 2 < nfull) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) ya[q] = yp[(size_t)((blk + 2) * 8 + q) * rs];
+          for (int q = 0; q < 8; ++q) ya[q] = (yrow + (size_t)((blk + 2) * 8 + q) * rs)[un];
         }
         eat4(yb);
         blk += 2;
@@ -376,7 +380,7 @@ EKS_HD void nll_summarize_chunk(const float* __restrict__ y, int N, int n, int t
   while (blk < nfull && !steady) {
     float yb[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) yb[q] = yp[(size_t)(blk * 8 + q) * rs];
+    for (int q = 0; q < 8; ++q) yb[q] = (yrow + (size_t)(blk * 8 + q) * rs)[un];
     L.template consume<8>(yb);
     ++blk;
     steady = L.all_steady();
@@ -396,7 +400,7 @@ EKS_HD void nll_summarize_chunk(const float* __restrict__ y, int N, int n, int t
     float yprev = L.y_last;
     float ya[8], yb[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) ya[q] = yp[(size_t)(blk * 8 + q) * rs];
+    for (int q = 0; q < 8; ++q) ya[q] = (yrow + (size_t)(blk * 8 + q) * rs)[un];
     const int first = blk;
     auto eat = [&](const float (&yy)[8]) {
 #pragma unroll
@@ -419,11 +423,11 @@ EKS_HD void nll_summarize_chunk(const float* __restrict__ y, int N, int n, int t
     };
     for (; blk + 2 <= nfull; blk += 2) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) yb[q] = yp[(size_t)((blk + 1) * 8 + q) * rs];
+      for (int q = 0; q < 8; ++q) yb[q] = (yrow + (size_t)((blk + 1) * 8 + q) * rs)[un];
       eat(ya);
       if (blk + 2 < nfull) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) ya[q] = yp[(size_t)((blk + 2) * 8 + q) * rs];
+        for (int q = 0; q < 8; ++q) ya[q] = (yrow + (size_t)((blk + 2) * 8 + q) * rs)[un];
       }
       eat(yb);
       if ((blk & 2) != 0) flush();          // float32 partial sums span at most 32 frames
@@ -450,7 +454,7 @@ EKS_HD void nll_summarize_chunk(const float* __restrict__ y, int N, int n, int t
   }
   for (int i = blk * 8; i < len; ++i) {        // ragged tail (or a chunk shorter than 8 frames)
     float y1[8];
-    y1[0] = yp[(size_t)i * rs];
+    y1[0] = (yrow + (size_t)i * rs)[un];
     L.template consume<1>(y1);
   }
   nll_lane_finish<R, NCL, UNIT>(L, len, out);
