@@ -48,6 +48,17 @@ struct NllGeom {
   int converged_entry;   // chunks j >= 1 may assume the filter variance has converged (float path)
 };
 
+// Row loads of y through a buffer resource (gfx950 `buffer_load_dword v, v_off, s[rsrc], s_row offen`):
+// the row offset lives in an SGPR, so the 16 loads per 16 frames of the steady loop cost no VALU
+// address arithmetic.  Offsets are 32-bit: used when a chunk spans < 2 GiB (launch code).
+struct BufferRows {
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned voff, row_bytes;
+  __device__ __forceinline__ float operator()(int i) const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (unsigned)i * row_bytes, 0));
+  }
+};
+
 template <typename R, int NCL, bool UNIT, bool TILE64>
 __global__ __launch_bounds__(512) void diag_nll_summarize_kernel(NllGeom G, DiagModel M, NllWs W,
                                           const float* __restrict__ y,
@@ -82,9 +93,19 @@ __global__ __launch_bounds__(512) void diag_nll_summarize_kernel(NllGeom G, Diag
   const int t0 = j == 0 ? 0 : G.B0 + (j - 1) * G.BN;
   const int len = j == 0 ? min(G.B0, G.T) : min(G.BN, G.T - t0);
   NllElem<R> out[NCL];
-  const float* y_chunk = y + (size_t)t0 * G.N;
-  nll_summarize_chunk<R, NCL, UNIT>(y_chunk, G.N, n, t0, len, rconst[n], M.A[dd], M.C[dd], sq, out,
-                                    G.converged_entry != 0);
+  if constexpr (TILE64) {
+    // buffer loads: resource based at the chunk's first row (scalar), per-lane byte offset 4 n,
+    // row offset i * 4 N in an SGPR - a load costs no VALU address arithmetic
+    const BufferRows ld{__builtin_amdgcn_make_buffer_rsrc(
+                            const_cast<float*>(y + (size_t)t0 * G.N + tile * 64), 0, 0x7FFFFFFF, 0x00020000),
+                        (unsigned)(lane * 4), (unsigned)(G.N * 4)};
+    nll_summarize_chunk<R, NCL, UNIT>(ld, t0, len, rconst[n], M.A[dd], M.C[dd], sq, out,
+                                      G.converged_entry != 0);
+  } else {
+    const RowsByPointer ld{y + (size_t)t0 * G.N + n, (size_t)G.N};
+    nll_summarize_chunk<R, NCL, UNIT>(ld, t0, len, rconst[n], M.A[dd], M.C[dd], sq, out,
+                                      G.converged_entry != 0);
+  }
 #pragma unroll
   for (int c = 0; c < NCL; ++c) {
     const int ci = g * NCL + c;
@@ -371,7 +392,7 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
   }
   const dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
   const bool unit = d.flags & EKS_FLAG_UNIT_AC;
-  const bool tile64 = G.nt_log2 == 6;
+  const bool tile64 = G.nt_log2 == 6 && (long)(G.BN > G.B0 ? G.BN : G.B0) * N * 4 < (1L << 31);
 #define EKS_NLL_LAUNCH2(RT, NCL, UN, T64)                                                          \
   hipLaunchKernelGGL((diag_nll_summarize_kernel<RT, NCL, UN, T64>), grid, block, 0, st, G, M, W, y, \
                      rconst, s_cand)

@@ -273,19 +273,21 @@ EKS_HD void nll_lane_finish(NllLane<R, NCL, UNIT>& L, int len, NllElem<R>* out) 
 // Such a summary is marked by C = -1 and carries eta = c S1 / S_inf, J = c^2 S2 / S_inf; it is
 // only valid in a strictly sequential assembly (nll_assemble), where P is P_inf when it is used.
 // Taken only when every lane of the wave has rho^(2 t0) < 1e-20 and rho^t dies inside the chunk.
-template <typename R, int NCL, bool UNIT>
-EKS_HD void nll_summarize_chunk(const float* __restrict__ y_chunk, int N, int n, int t0, int len,
-                                double r_d, double a_d, double c_d, const double* sq_d,
-                                NllElem<R>* out, bool allow_converged_entry = false) {
+// `ld(i)` returns the observation of the lane's chain at frame t0 + i (RowsByPointer below; the
+// gfx950 kernels pass a buffer-load functor whose row address is scalar arithmetic).
+struct RowsByPointer {
+  const float* p;      // y + t0 * N + n
+  size_t rs;           // N
+  EKS_HD float operator()(int i) const { return p[(size_t)i * rs]; }
+};
+
+template <typename R, int NCL, bool UNIT, typename LD>
+EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, double a_d, double c_d,
+                                const double* sq_d, NllElem<R>* out,
+                                bool allow_converged_entry = false) {
   NllLane<R, NCL, UNIT> L;
   nll_lane_init<R, NCL, UNIT>(L, r_d, a_d, c_d, sq_d);
   const float af = (float)a_d;
-  // `y_chunk` = y + t0 * N: the kernels make it wave-uniform when a wave holds 64 chains of ONE
-  // chunk, so that the row addresses are scalar arithmetic (SGPR base + per-lane offset n) and
-  // the load costs no VALU instruction
-  const float* yrow = y_chunk;
-  const unsigned un = (unsigned)n;
-  const size_t rs = (size_t)N;
   const int nfull = len / 8;
   int blk = 0;
   bool steady = false;
@@ -331,15 +333,15 @@ EKS_HD void nll_summarize_chunk(const float* __restrict__ y_chunk, int N, int n,
       // go to float64 and the rho^t trackers are examined every 32 frames
       float ya[8], yb[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) ya[q] = (yrow + (size_t)q * rs)[un];
+      for (int q = 0; q < 8; ++q) ya[q] = ld(q);
       bool alive = true;
       while (alive && blk + 2 <= nfull) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) yb[q] = (yrow + (size_t)((blk + 1) * 8 + q) * rs)[un];
+        for (int q = 0; q < 8; ++q) yb[q] = ld(((blk + 1) * 8 + q));
         eat4(ya);
         if (blk + 2 < nfull) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) ya[q] = (yrow + (size_t)((blk + 2) * 8 + q) * rs)[un];
+          for (int q = 0; q < 8; ++q) ya[q] = ld(((blk + 2) * 8 + q));
         }
         eat4(yb);
         blk += 2;
@@ -380,7 +382,7 @@ EKS_HD void nll_summarize_chunk(const float* __restrict__ y_chunk, int N, int n,
   while (blk < nfull && !steady) {
     float yb[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) yb[q] = (yrow + (size_t)(blk * 8 + q) * rs)[un];
+    for (int q = 0; q < 8; ++q) yb[q] = ld((blk * 8 + q));
     L.template consume<8>(yb);
     ++blk;
     steady = L.all_steady();
@@ -400,7 +402,7 @@ EKS_HD void nll_summarize_chunk(const float* __restrict__ y_chunk, int N, int n,
     float yprev = L.y_last;
     float ya[8], yb[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) ya[q] = (yrow + (size_t)(blk * 8 + q) * rs)[un];
+    for (int q = 0; q < 8; ++q) ya[q] = ld((blk * 8 + q));
     const int first = blk;
     auto eat = [&](const float (&yy)[8]) {
 #pragma unroll
@@ -423,11 +425,11 @@ EKS_HD void nll_summarize_chunk(const float* __restrict__ y_chunk, int N, int n,
     };
     for (; blk + 2 <= nfull; blk += 2) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) yb[q] = (yrow + (size_t)((blk + 1) * 8 + q) * rs)[un];
+      for (int q = 0; q < 8; ++q) yb[q] = ld(((blk + 1) * 8 + q));
       eat(ya);
       if (blk + 2 < nfull) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) ya[q] = (yrow + (size_t)((blk + 2) * 8 + q) * rs)[un];
+        for (int q = 0; q < 8; ++q) ya[q] = ld(((blk + 2) * 8 + q));
       }
       eat(yb);
       if ((blk & 2) != 0) flush();          // float32 partial sums span at most 32 frames
@@ -454,7 +456,7 @@ EKS_HD void nll_summarize_chunk(const float* __restrict__ y_chunk, int N, int n,
   }
   for (int i = blk * 8; i < len; ++i) {        // ragged tail (or a chunk shorter than 8 frames)
     float y1[8];
-    y1[0] = (yrow + (size_t)i * rs)[un];
+    y1[0] = ld(i);
     L.template consume<1>(y1);
   }
   nll_lane_finish<R, NCL, UNIT>(L, len, out);

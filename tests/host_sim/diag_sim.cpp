@@ -91,9 +91,9 @@ static void run_nll(int T, int N, int D, int BN, bool unit, bool conv, const flo
         const int t0 = j * BN, len = std::min(BN, T - t0);
         NllElem<R>* o = &el[(((size_t)j * N + n) * ngrp + g) * NCL];
         if (unit)
-          nll_summarize_chunk<R, NCL, true>(y + (size_t)t0 * N, N, n, t0, len, rconst[n], M.A[dd], M.C[dd], sq, o, conv);
+          nll_summarize_chunk<R, NCL, true>(RowsByPointer{y + (size_t)t0 * N + n, (size_t)N}, t0, len, rconst[n], M.A[dd], M.C[dd], sq, o, conv);
         else
-          nll_summarize_chunk<R, NCL, false>(y + (size_t)t0 * N, N, n, t0, len, rconst[n], M.A[dd], M.C[dd], sq, o, conv);
+          nll_summarize_chunk<R, NCL, false>(RowsByPointer{y + (size_t)t0 * N + n, (size_t)N}, t0, len, rconst[n], M.A[dd], M.C[dd], sq, o, conv);
       }
   for (int k = 0; k < K; ++k)
     for (int ci = 0; ci < n_cand; ++ci) {
