@@ -200,7 +200,7 @@ def bench_pupil(args, T, dev, lib):
            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
            'config': {'workload': f'pupil AR(1) T={T} frames, one chain; step = loss + 2 sensitivities + Adam'},
-           'roofline': {'bound': 'hbm', 'kernel': 'ar1_chunks_kernel + ar1_reduce_kernel', 'unit': 'GB/s',
+           'roofline': {'bound': 'hbm', 'kernel': 'loss_chunks_kernel + loss_reduce_kernel', 'unit': 'GB/s',
                         'peak': HBM_PEAK_GBS, 'achieved': 64 * T / (nll_ms * 1e-3) / 1e9,
                         'frac': 64 * T / (nll_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
                         'stage_avg_ms': prof,
