@@ -2,6 +2,8 @@
 // pair of hipEvents recorded on the caller's stream (no synchronisation at record time).
 // eks_profile_drain() synchronises on the recorded events and returns (name, milliseconds) pairs.
 // Used by bench.py for the `roofline` object; off by default and then costs one branch per launch.
+// Level 2 brackets only the smoother's replay kernels (the HBM-roofline kernels): two event
+// records per step instead of twelve inside bench.py's timed region.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -16,14 +18,34 @@ struct ProfEntry {
   const char* name;
   hipEvent_t a, b;
 };
-static bool g_prof_on = false;
+static int g_prof_level = 0;          // 0 off, 1 every scope, 2 only the *_replay scopes
 static std::vector<ProfEntry> g_prof;
+static std::vector<hipEvent_t> g_pool;  // events are reused: creating one costs microseconds
 static std::mutex g_prof_mu;
 
-ProfScope::ProfScope(const char* name, hipStream_t st) : name_(name), st_(st), live_(g_prof_on) {
+static hipEvent_t take_event() {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_pool.empty()) {
+    hipEvent_t e = g_pool.back();
+    g_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+static bool scope_live(const char* name) {
+  if (g_prof_level == 1) return true;
+  if (g_prof_level != 2) return false;
+  const size_t n = strlen(name);
+  return n >= 7 && strcmp(name + n - 7, "_replay") == 0;
+}
+
+ProfScope::ProfScope(const char* name, hipStream_t st) : name_(name), st_(st), live_(scope_live(name)) {
   if (!live_) return;
-  hipEventCreate(&a_);
-  hipEventCreate(&b_);
+  a_ = take_event();
+  b_ = take_event();
   hipEventRecord(a_, st_);
 }
 ProfScope::~ProfScope() {
@@ -38,7 +60,7 @@ ProfScope::~ProfScope() {
 extern "C" {
 
 int eks_profile_enable(int on) {
-  eks::g_prof_on = on != 0;
+  eks::g_prof_level = on < 0 ? 0 : on > 2 ? 1 : on;
   return EKS_OK;
 }
 
@@ -50,8 +72,8 @@ int eks_profile_drain(char* names, size_t names_bytes, float* ms, int32_t max_n)
     hipEventSynchronize(e.b);
     float t = 0.f;
     hipEventElapsedTime(&t, e.a, e.b);
-    hipEventDestroy(e.a);
-    hipEventDestroy(e.b);
+    eks::g_pool.push_back(e.a);
+    eks::g_pool.push_back(e.b);
     const size_t len = strlen(e.name) + 1;
     if (n < max_n && names && ms && off + len <= names_bytes) {
       memcpy(names + off, e.name, len);

@@ -161,8 +161,9 @@ int eks_ensemble(int32_t n_models, int32_t n_cameras, int32_t n_frames, int32_t 
                  const float* markers, int32_t avg_mode, int32_t var_mode, float nan_replacement,
                  float* stats, eks_stream_t stream);
 
-/* ---- optional per-kernel timing (used by bench.py's roofline object).  When enabled, each
- * kernel launch is bracketed by hipEvents on the caller's stream; eks_profile_drain waits for the
+/* ---- optional per-kernel timing (used by bench.py's roofline object).  on = 1: each kernel launch
+ * (stage) is bracketed by hipEvents on the caller's stream; on = 2: only the smoother's replay
+ * kernels (the HBM-roofline kernels); 0: off. eks_profile_drain waits for the
  * recorded events, writes up to max_n NUL-terminated kernel names back to back into `names` and
  * their durations in milliseconds into `ms`, clears the record and returns the count. -------- */
 int eks_profile_enable(int on);
