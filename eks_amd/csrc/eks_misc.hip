@@ -25,7 +25,7 @@ __device__ __forceinline__ uint32_t var_key(float v, bool& valid) {
 //   S1 sample  : ~4096 evenly spaced rows, transposed through LDS into per-chain sample columns
 //                (coalesced both ways; 4 % of the data).
 //   S2 bracket : per chain, the sample's order statistics 4.5 sigma either side of its median
-//                (radix select in LDS) bracket the true median: [lo, hi] holds ~6 % of the frames.
+//                (two histogram passes in LDS) bracket the true median: [lo, hi] holds ~6 % of the frames.
 //   S3 collect : the full pass.  Lanes = chains, 128 rows per wave with 32 loads in flight per
 //                lane; frames below lo and valid frames are counted in registers, frames inside
 //                [lo, hi] are staged per chain in LDS by the 8 waves of a block and appended to
@@ -145,6 +145,63 @@ __device__ uint32_t lds_radix_select(const uint32_t* vals, int L, uint32_t rank,
   return (prefix >> lsh) + base;
 }
 
+// Bracket two ranks r_lo <= r_hi of vals[0..L) at 16-bit resolution of the normalised keys: two
+// histogram passes (the second one refines the two first-pass bins at once) instead of two exact
+// radix selects.  Returns the low edge of r_lo's cell and the high edge of r_hi's: every key of
+// rank r_lo..r_hi lies inside.  hist: 512 counters, sh: 4 words.
+__device__ void lds_bracket(const uint32_t* vals, int L, uint32_t r_lo, uint32_t r_hi, uint32_t base,
+                            int lsh, uint32_t* hist, uint32_t* sh, uint32_t& lo, uint32_t& hi) {
+  // wave 0 / wave 1 locate rank r in hist[off .. off + 256): bin -> sh[slot], rank inside -> sh[slot + 1]
+  auto find = [&](uint32_t rank, int off, int slot) {
+    const int lane = threadIdx.x & 63;
+    uint32_t c[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c[q] = hist[off + 4 * lane + q];
+    const uint32_t mine = c[0] + c[1] + c[2] + c[3];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(incl, o);
+      if (lane >= o) incl += up;
+    }
+    uint32_t cum = incl - mine;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (rank >= cum && rank < cum + c[q]) {
+        sh[slot] = (uint32_t)(4 * lane + q);
+        sh[slot + 1] = rank - cum;
+      }
+      cum += c[q];
+    }
+  };
+  hist[threadIdx.x] = 0u;
+  hist[256 + threadIdx.x] = 0u;
+  __syncthreads();
+  for (int i = threadIdx.x; i < L; i += 256) atomicAdd(&hist[radix_norm(vals[i], base, lsh) >> 24], 1u);
+  __syncthreads();
+  if (threadIdx.x < 64) find(r_lo, 0, 0);
+  else if (threadIdx.x < 128) find(r_hi, 0, 2);
+  __syncthreads();
+  const uint32_t b_lo = sh[0], q_lo = sh[1], b_hi = sh[2], q_hi = sh[3];
+  __syncthreads();
+  hist[threadIdx.x] = 0u;
+  hist[256 + threadIdx.x] = 0u;
+  __syncthreads();
+  for (int i = threadIdx.x; i < L; i += 256) {
+    const uint32_t k = radix_norm(vals[i], base, lsh);
+    if ((k >> 24) == b_lo) atomicAdd(&hist[(k >> 16) & 255u], 1u);
+    if ((k >> 24) == b_hi) atomicAdd(&hist[256 + ((k >> 16) & 255u)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) find(q_lo, 0, 0);
+  else if (threadIdx.x < 128) find(q_hi, 256, 2);
+  __syncthreads();
+  const uint32_t c_lo = (b_lo << 8) | sh[0], c_hi = (b_hi << 8) | sh[2];   // 16-bit cells
+  lo = ((c_lo << 16) >> lsh) + base;
+  hi = (((c_hi << 16) | 0xFFFFu) >> lsh) + base;
+  __syncthreads();
+}
+
 // min / max over the valid keys of vals[0..L) (block-wide, through LDS scratch mm[2])
 __device__ void lds_key_range(const uint32_t* vals, int L, uint32_t* mm, uint32_t& lo, uint32_t& hi) {
   if (threadIdx.x == 0) {
@@ -204,8 +261,8 @@ __global__ __launch_bounds__(256) void sample_transpose_kernel(int T, int N, int
 // S2: one block per chain
 __global__ __launch_bounds__(256) void sample_bracket_kernel(int N, int S, BracketWs B) {
   __shared__ uint32_t vals[kMedSamples];
-  __shared__ uint32_t hist[256];
-  __shared__ uint32_t sh[2], nvalid;
+  __shared__ uint32_t hist[512];
+  __shared__ uint32_t sh[4], nvalid;
   const int n = blockIdx.x;
   if (threadIdx.x == 0) nvalid = 0;
   __syncthreads();
@@ -230,11 +287,13 @@ __global__ __launch_bounds__(256) void sample_bracket_kernel(int N, int S, Brack
   uint32_t kmin, kmax;
   lds_key_range(vals, S, sh, kmin, kmax);
   const int lsh = kmax > kmin ? __clz((int)(kmax - kmin)) : 0;
-  const uint32_t lo = lds_radix_select(vals, S, (uint32_t)r_lo, kmin, lsh, hist, sh);
-  const uint32_t hi = lds_radix_select(vals, S, (uint32_t)r_hi, kmin, lsh, hist, sh);
+  // the bracket only has to CONTAIN the sample's order statistics r_lo .. r_hi: 1/65536 of the
+  // sample's key range is resolution enough (the exact selection happens in S4)
+  uint32_t lo, hi;
+  lds_bracket(vals, S, (uint32_t)r_lo, (uint32_t)r_hi, kmin, lsh, hist, sh, lo, hi);
   if (threadIdx.x == 0) {
     B.lo[n] = lo;
-    B.hi[n] = hi;
+    B.hi[n] = min(hi, kmax);
   }
 }
 
