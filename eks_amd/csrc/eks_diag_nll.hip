@@ -168,6 +168,50 @@ __global__ __launch_bounds__(256) void diag_nll_assemble_kernel(NllGeom G, DiagM
   if constexpr (GRAD) dnll[(size_t)k * G.n_cand + ci] = fin ? -der(tot) : 0.0;
 }
 
+// N2 for D a power of two (the usual D = 2): thread = (chain, candidate) with the chain index
+// fastest - coalesced plane reads, half the sequential depth - and the D chain log-likelihoods of
+// a keypoint, which sit in adjacent lanes, are summed with wave shuffles.
+template <bool GRAD>
+__global__ __launch_bounds__(256) void diag_nll_assemble_chain_kernel(NllGeom G, DiagModel M, NllWs W,
+                                                                     double* __restrict__ nll,
+                                                                     double* __restrict__ dnll) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= G.N * G.n_cand) return;         // whole groups of D lanes leave together
+  const int n = idx % G.N, ci = idx / G.N;
+  const int k = n / G.D, d = n - k * G.D;
+  using RD = typename std::conditional<GRAD, DualD, double>::type;
+  const size_t dd = (size_t)k * G.D * G.D + (size_t)d * (G.D + 1);
+  auto get = [&](int j, Elem<RD>& e, RD& ell) {
+    const size_t o = ((size_t)j * W.ncp + ci) * G.N + n;
+    if constexpr (GRAD) {
+      e.A = DualD(W.A[o], W.dA[o]);
+      e.b = DualD(W.b[o], W.db[o]);
+      e.C = DualD(W.C[o], W.dC[o]);
+      e.eta = DualD(W.eta[o], W.deta[o]);
+      e.J = DualD(W.J[o], W.dJ[o]);
+      ell = DualD(W.ell[o], W.dell[o]);
+    } else {
+      e.A = W.A[o];
+      e.b = W.b[o];
+      e.C = W.C[o];
+      e.eta = W.eta[o];
+      e.J = W.J[o];
+      ell = W.ell[o];
+    }
+  };
+  const RD tot = nll_assemble<RD>(G.ncn, M.m0[(size_t)k * G.D + d], M.S0[dd], get);
+  double v = val(tot), g = der(tot);
+  for (int off = 1; off < G.D; off <<= 1) {
+    v += __shfl_xor(v, off);
+    g += __shfl_xor(g, off);
+  }
+  if (d != 0) return;
+  v = -v;
+  const bool fin = isfinite(v);              // eks/core.py:650
+  nll[(size_t)k * G.n_cand + ci] = fin ? v : 1e12;
+  if constexpr (GRAD) dnll[(size_t)k * G.n_cand + ci] = fin ? -g : 0.0;
+}
+
 // N2' tree variant for few chain-streams (the Adam loop: one candidate per keypoint, ~200 chunk
 // summaries per chain): block = (64 lanes, D chains of one (keypoint, candidate)).  Each lane
 // composes a contiguous run of chunk elements, the 64 partial elements are composed in time order
@@ -434,6 +478,16 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
     else
       hipLaunchKernelGGL(diag_nll_assemble_tree_kernel<false>, dim3(total), tb, shm, st, G, M, W, K,
                          nll, dnll);
+    return hip_status(hipGetLastError());
+  }
+  if ((D & (D - 1)) == 0 && D <= 64) {       // chains of a keypoint in adjacent lanes
+    const long lanes = (long)N * n_cand;
+    if (grad)
+      hipLaunchKernelGGL(diag_nll_assemble_chain_kernel<true>, dim3((unsigned)((lanes + 255) / 256)),
+                         dim3(256), 0, st, G, M, W, nll, dnll);
+    else
+      hipLaunchKernelGGL(diag_nll_assemble_chain_kernel<false>, dim3((unsigned)((lanes + 255) / 256)),
+                         dim3(256), 0, st, G, M, W, nll, dnll);
     return hip_status(hipGetLastError());
   }
   if (grad)

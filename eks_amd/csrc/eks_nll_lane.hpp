@@ -470,10 +470,13 @@ template <typename RD, typename Getter>
 EKS_HD RD nll_assemble(int nchunks, double m0, double S0, Getter get) {
   RD m = RD(m0), P = RD(S0);
   RD ll = RD(0.0);
+  Elem<RD> e_next;
+  RD ell_next;
+  get(0, e_next, ell_next);
   for (int j = 0; j < nchunks; ++j) {
-    Elem<RD> e;
-    RD ell;
-    get(j, e, ell);
+    const Elem<RD> e = e_next;
+    const RD ell = ell_next;
+    if (j + 1 < nchunks) get(j + 1, e_next, ell_next);   // in flight while chunk j is applied
     if (val(e.C) < 0.0) {     // converged-entry summary (nll_summarize_chunk): P is P_inf here
       ll = ll + ell + e.eta * m - RD(0.5) * e.J * m * m;
       m = e.A * m + e.b;
