@@ -38,6 +38,7 @@ struct NllWs {
   float *A, *b, *C, *eta, *J;            // values
   float *dA, *db, *dC, *deta, *dJ;       // derivatives (grad mode only)
   double *ell, *dell;
+  float* xr;                             // chunk reference states [ncn][N] (candidate-independent)
   int ncp;                               // padded candidate count
 };
 
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(512) void diag_nll_summarize_kernel(NllGeom G, Diag
     nll_summarize_chunk<R, NCL, UNIT>(ld, t0, len, rconst[n], M.A[dd], M.C[dd], sq, out,
                                       G.converged_entry != 0);
   }
+  if (g == 0) W.xr[(size_t)j * G.N + n] = out[0].xref;
 #pragma unroll
   for (int c = 0; c < NCL; ++c) {
     const int ci = g * NCL + c;
@@ -141,8 +143,9 @@ __global__ __launch_bounds__(256) void diag_nll_assemble_kernel(NllGeom G, DiagM
   for (int d = 0; d < G.D; ++d) {
     const int n = k * G.D + d;
     const size_t dd = (size_t)k * G.D * G.D + (size_t)d * (G.D + 1);
-    auto get = [&](int j, Elem<RD>& e, RD& ell) {
+    auto get = [&](int j, Elem<RD>& e, RD& ell, double& xr) {
       const size_t o = ((size_t)j * W.ncp + ci) * G.N + n;
+      xr = (double)W.xr[(size_t)j * G.N + n];
       if constexpr (GRAD) {
         e.A = DualD(W.A[o], W.dA[o]);
         e.b = DualD(W.b[o], W.db[o]);
@@ -181,8 +184,9 @@ __global__ __launch_bounds__(256) void diag_nll_assemble_chain_kernel(NllGeom G,
   const int k = n / G.D, d = n - k * G.D;
   using RD = typename std::conditional<GRAD, DualD, double>::type;
   const size_t dd = (size_t)k * G.D * G.D + (size_t)d * (G.D + 1);
-  auto get = [&](int j, Elem<RD>& e, RD& ell) {
+  auto get = [&](int j, Elem<RD>& e, RD& ell, double& xr) {
     const size_t o = ((size_t)j * W.ncp + ci) * G.N + n;
+    xr = (double)W.xr[(size_t)j * G.N + n];
     if constexpr (GRAD) {
       e.A = DualD(W.A[o], W.dA[o]);
       e.b = DualD(W.b[o], W.db[o]);
@@ -221,16 +225,21 @@ template <typename RD>
 struct NllAcc {
   Elem<RD> e;
   RD ell;
+  double xr;   // reference of the run's FIRST chunk: the run is a function of (x_in - xr)
 };
 
 template <typename RD>
 __device__ inline NllAcc<RD> nll_acc_combine(const NllAcc<RD>& i, const NllAcc<RD>& j) {
-  const RD den = RD(1.0) + i.e.C * j.e.J;
+  // run i hands its (absolute) outgoing mean to run j, which wants it relative to ITS reference
+  Elem<RD> ie = i.e;
+  ie.b = i.e.b - RD(j.xr);
+  const RD den = RD(1.0) + ie.C * j.e.J;
   const RD inv = rcp(den);
   NllAcc<RD> o;
   o.ell = i.ell + j.ell - RD(0.5) * log_with_rcp(den, inv) +
-          (j.e.eta * i.e.b + RD(0.5) * j.e.eta * j.e.eta * i.e.C - RD(0.5) * j.e.J * i.e.b * i.e.b) * inv;
-  o.e = elem_combine(i.e, j.e);
+          (j.e.eta * ie.b + RD(0.5) * j.e.eta * j.e.eta * ie.C - RD(0.5) * j.e.J * ie.b * ie.b) * inv;
+  o.e = elem_combine(ie, j.e);
+  o.xr = i.xr;
   return o;
 }
 
@@ -240,7 +249,7 @@ template <bool GRAD>
 __global__ void diag_nll_assemble_tree_kernel(NllGeom G, DiagModel M, NllWs W, int K,
                                               double* __restrict__ nll, double* __restrict__ dnll) {
   using RD = typename std::conditional<GRAD, DualD, double>::type;
-  constexpr int NF = GRAD ? 12 : 6;
+  constexpr int NF = GRAD ? 13 : 7;               // 6 element fields (+ derivatives) + reference
   extern __shared__ double lds[];                 // [D][NF][64] + [D][2]
   const int i = threadIdx.x, d = threadIdx.y;
   const int k = blockIdx.x % K, ci = blockIdx.x / K;
@@ -249,6 +258,7 @@ __global__ void diag_nll_assemble_tree_kernel(NllGeom G, DiagModel M, NllWs W, i
   auto get = [&](int j) {
     const size_t o = ((size_t)j * W.ncp + ci) * G.N + n;
     NllAcc<RD> a;
+    a.xr = (double)W.xr[(size_t)j * G.N + n];
     if constexpr (GRAD) {
       a.e.A = DualD(W.A[o], W.dA[o]);
       a.e.b = DualD(W.b[o], W.db[o]);
@@ -273,6 +283,7 @@ __global__ void diag_nll_assemble_tree_kernel(NllGeom G, DiagModel M, NllWs W, i
       my[q * kAsmLanes + slot] = val(f[q]);
       if constexpr (GRAD) my[(6 + q) * kAsmLanes + slot] = der(f[q]);
     }
+    my[(NF - 1) * kAsmLanes + slot] = a.xr;
   };
   auto take = [&](int slot) {
     RD f[6];
@@ -285,6 +296,7 @@ __global__ void diag_nll_assemble_tree_kernel(NllGeom G, DiagModel M, NllWs W, i
     }
     NllAcc<RD> a;
     a.e.A = f[0]; a.e.b = f[1]; a.e.C = f[2]; a.e.eta = f[3]; a.e.J = f[4]; a.ell = f[5];
+    a.xr = my[(NF - 1) * kAsmLanes + slot];
     return a;
   };
   const int per = (G.ncn + kAsmLanes - 1) / kAsmLanes;
@@ -306,7 +318,7 @@ __global__ void diag_nll_assemble_tree_kernel(NllGeom G, DiagModel M, NllWs W, i
   double* tot = lds + (size_t)G.D * NF * kAsmLanes;
   if (i == 0) {
     const size_t dd = (size_t)k * G.D * G.D + (size_t)d * (G.D + 1);
-    const RD m = RD(M.m0[(size_t)k * G.D + d]), P = RD(M.S0[dd]);
+    const RD m = RD(M.m0[(size_t)k * G.D + d] - acc.xr), P = RD(M.S0[dd]);   // relative to the reference
     const RD den = RD(1.0) + acc.e.J * P;
     const RD inv = rcp(den);
     const RD ll = acc.ell - RD(0.5) * log_with_rcp(den, inv) +
@@ -395,7 +407,7 @@ size_t diag_nll_workspace_bytes(int T, int N, int n_cand) {
   const size_t ncp = align_up((size_t)n_cand, kNclGrid);
   const size_t fl = align_up((size_t)ncn * ncp * N * sizeof(float), 256);
   const size_t db = align_up((size_t)ncn * ncp * N * sizeof(double), 256);
-  return 10 * fl + 2 * db;
+  return 11 * fl + 2 * db;   // 10 element planes + the chunk references (one candidate's worth is used)
 }
 
 int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M,
@@ -419,8 +431,8 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
   W.ell = reinterpret_cast<double*>(p);
   W.dell = reinterpret_cast<double*>(p + db);
   p += 2 * db;
-  float** planes[10] = {&W.A, &W.b, &W.C, &W.eta, &W.J, &W.dA, &W.db, &W.dC, &W.deta, &W.dJ};
-  for (int i = 0; i < 10; ++i) *planes[i] = reinterpret_cast<float*>(p + i * fl);
+  float** planes[11] = {&W.A, &W.b, &W.C, &W.eta, &W.J, &W.dA, &W.db, &W.dC, &W.deta, &W.dJ, &W.xr};
+  for (int i = 0; i < 11; ++i) *planes[i] = reinterpret_cast<float*>(p + i * fl);
 
   const int cpw = 64 >> G.nt_log2;
   const long waves = (long)G.ngrp * G.ntile * ((G.ncn + cpw - 1) / cpw);
@@ -471,7 +483,7 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
   ProfScope ps2("diag_nll_assemble", st);
   if (tree) {
     const dim3 tb(kAsmLanes, D);
-    const size_t shm = ((size_t)D * (grad ? 12 : 6) * kAsmLanes + 2 * D) * sizeof(double);
+    const size_t shm = ((size_t)D * (grad ? 13 : 7) * kAsmLanes + 2 * D) * sizeof(double);
     if (grad)
       hipLaunchKernelGGL(diag_nll_assemble_tree_kernel<true>, dim3(total), tb, shm, st, G, M, W, K, nll,
                          dnll);

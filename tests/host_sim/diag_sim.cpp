@@ -101,8 +101,9 @@ static void run_nll(int T, int N, int D, int BN, bool unit, bool conv, const flo
       for (int d = 0; d < D; ++d) {
         const int n = k * D + d;
         const size_t dd = (size_t)k * D * D + (size_t)d * (D + 1);
-        auto get = [&](int j, Elem<RD>& e, RD& ell) {
+        auto get = [&](int j, Elem<RD>& e, RD& ell, double& xr) {
           const NllElem<R>& s = el[(((size_t)j * N + n) * ngrp + ci / NCL) * NCL + ci % NCL];
+          xr = (double)s.xref;
           e.A = make_real(RD(), (double)val(s.e.A), (double)der(s.e.A));
           e.b = make_real(RD(), (double)val(s.e.b), (double)der(s.e.b));
           e.C = make_real(RD(), (double)val(s.e.C), (double)der(s.e.C));

@@ -264,6 +264,29 @@ def test_nll_grid_staged_kernel_matches_c_oracle(T, K, unit):
     np.testing.assert_array_equal(nll.argmin(axis=1)[clear], ref.argmin(axis=1)[clear])
     assert clear.mean() > 0.9
 
+@pytest.mark.parametrize('T,K,unit,var_scale', [(40000, 32, True, 1.0), (26001, 40, False, 1.0),
+                                                (40000, 32, True, 60.0), (9000, 70, True, 0.05)])
+def test_nll_grid_converged_entry_chunks_match_c_oracle(T, K, unit, var_scale):
+    """Long sequences: chunks after the first are summarised for an entering belief N(m, P_inf)
+    (no start-up transient), the first chunk is short, rows are read through buffer resources.
+    var_scale moves the candidates' closed-loop poles: large R makes the slow candidates fall back
+    to exact-entry summaries in the early chunks, small R makes every candidate fast."""
+    from eks_amd import hip_ops
+    from oracle import c_oracle
+    arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=5 + T, unit=unit)
+    var_tk = (var_tk * var_scale).astype(np.float32)
+    cand = np.exp(np.linspace(-8, 8, 64))
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    rconst = hip_ops.const_r(_dev(var_tk), 1e-4)
+    nll = hip_ops.nll(_dev(y_tk), rconst, *_params_dev(arrs), _dev(cand), flags=flags).cpu().numpy()
+    ref = c_oracle.nll_grid(arrs['ys'], rconst.cpu().numpy(), arrs['m0s'], arrs['S0s'], arrs['As'],
+                            arrs['Cs'], arrs['Qs'], cand)
+    assert (np.abs(nll - ref) / np.abs(ref)).max() < 1e-5
+    srt = np.sort(ref, axis=1)
+    clear = (srt[:, 1] - srt[:, 0]) > 2e-5 * np.abs(srt[:, 0])
+    np.testing.assert_array_equal(nll.argmin(axis=1)[clear], ref.argmin(axis=1)[clear])
+    assert clear.mean() > 0.9
+
 
 @pytest.mark.parametrize('T,K,unit', [(3000, 5, True), (1500, 3, False)])
 def test_nll_grad_diag_matches_oracle(T, K, unit):
