@@ -137,8 +137,10 @@ struct NllLane {
   int phase[NCL], n_post[NCL];
   float tolC[NCL];
   R rR;
-  // |A| below this no longer moves eta / J at float32 resolution of the assembled NLL
-  static constexpr float kDeadA = sizeof(R) == sizeof(float) ? 1e-8f : 1e-12f;
+  // |A| (= rho^t) below this no longer matters: A only ever multiplies x_in - xref, a few pixels
+  // now that summaries are relative to the chunk's reference state, so what is dropped is
+  // ~1e-5 px in the mean and ~1e-9 of the NLL (with the reference at the origin it had to be 1e-8)
+  static constexpr float kDeadA = sizeof(R) == sizeof(float) ? 1e-5f : 1e-9f;
 
   // Transient code: consume NB (<= 8) frames with per-candidate regimes (wave-uniform).
   //
@@ -353,9 +355,9 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
     for (int k = 0; k < NCL; ++k) {
       rho[k] = UNIT ? (1.f - L.tI[k]) : L.pc[k].a * (1.f - L.pc[k].c * L.tI[k]);
       const float nl = -logf(fmaxf(fabsf(rho[k]), 1e-30f));         // -ln |rho| > 0
-      // rho^(2 t0) < 1e-20, and rho^t < kDeadA well inside the whole 8-frame blocks of the chunk
+      // rho^(2 t0) < 1e-20, and rho^t < kDeadA (ln 1e5 = 11.5) well inside the chunk's whole blocks
       ok = ok && fabsf(rho[k]) < 1.f && 2.f * (float)t0 * nl > 46.f &&
-           18.5f / nl + 48.f < (float)(nfull * 8);
+           11.6f / nl + 48.f < (float)(nfull * 8);
     }
     if (EKS_WAVE_ALL(ok)) {
       float dk[NCL], w[NCL];
