@@ -104,12 +104,13 @@ def cpu_baseline(y_dev, var_dev, T, n_cand, budget_s):
         s = cand[np.argmin(nll, axis=1)]
     else:
         s = np.full(Kc, 10.0)
-    c_oracle.smooth(y, Rd, m0, S0, eye, eye, eye, s, nthreads=cores)
+    ms_cpu, Vs_cpu, _ = c_oracle.smooth(y, Rd, m0, S0, eye, eye, eye, s, nthreads=cores)
     dt = time.perf_counter() - t0
+    ref = dict(nll=nll if n_cand else None, ms=ms_cpu, Vs=Vs_cpu)
     return dict(value=T * Kc / dt, unit='frames*keypoints/s', cores=cores, kind='port',
                 sample=f'first {Kc} of the keypoints x all {T} frames of the same workload '
                        f'({n_cand}-candidate NLL grid + smooth), float64 C port of the reference '
-                       f'recursion (oracle/eks_oracle.c), OpenMP over keypoints, {dt:.1f} s'), s
+                       f'recursion (oracle/eks_oracle.c), OpenMP over keypoints, {dt:.1f} s'), s, ref
 
 
 def bench_dense(args, T, K, dev, rank, world, lib):
@@ -352,7 +353,7 @@ def main():
             }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                cb, s_cpu = cpu_baseline(y, var, T, n_cand, args.cpu_seconds)
+                cb, s_cpu, ref = cpu_baseline(y, var, T, n_cand, args.cpu_seconds)
                 out['cpu_baseline'] = cb
                 out['gpu_over_cpu'] = value / cb['value']
                 if n_cand:
@@ -363,6 +364,25 @@ def main():
                     i_gpu = np.abs(np.log(s_gpu)[:, None] - np.log(cand_np)[None]).argmin(1)
                     i_cpu = np.abs(np.log(s_cpu)[:, None] - np.log(cand_np)[None]).argmin(1)
                     out['cpu_baseline']['argmin_index_agreement'] = float(np.mean(i_gpu == i_cpu))
+                    same = i_gpu == i_cpu
+                else:
+                    same = np.ones(len(s_cpu), dtype=bool)
+                # parity of the timed path's own outputs against the float64 port, on the sample
+                # (untimed): relative to the keypoint's magnitude, BASELINE.json's 1e-5 bar
+                Kc = len(s_cpu)
+                par = {}
+                if n_cand:
+                    nll_gpu = hip_ops.nll(y, hip_ops.const_r(var, 1e-4), m0, S0, eye, eye, eye, cand,
+                                          flags=flags)[:Kc].cpu().numpy()
+                    par['nll_max_rel_err'] = float((np.abs(nll_gpu - ref['nll']) / np.abs(ref['nll'])).max())
+                ms_g = np.transpose(ms[:, :Kc].cpu().numpy().astype(np.float64), (1, 0, 2))[same]
+                Vs_g = np.transpose(Vs[:, :Kc].cpu().numpy().astype(np.float64), (1, 0, 2, 3))[same]
+                ms_c, Vs_c = ref['ms'][same], ref['Vs'][same]
+                par['ms_max_rel_err'] = float((np.abs(ms_g - ms_c) / np.abs(ms_c).max(axis=(1, 2), keepdims=True)).max())
+                Vd_g, Vd_c = np.diagonal(Vs_g, axis1=2, axis2=3), np.diagonal(Vs_c, axis1=2, axis2=3)
+                par['Vs_max_rel_err'] = float((np.abs(Vd_g - Vd_c) / Vd_c).max())
+                par['keypoints_compared'] = int(same.sum())
+                out['parity_vs_cpu_port'] = par
             except Exception as e:                      # the baseline must never sink the bench line
                 out['cpu_baseline'] = {'value': None, 'unit': 'frames*keypoints/s', 'cores': 0,
                                        'kind': 'port', 'sample': f'failed: {e!r}'}
