@@ -222,11 +222,12 @@ def test_const_r_all_nan_column():
     assert np.isnan(got[0, 0]) and got[1, 0] == 2.0
 
 
-@pytest.mark.parametrize('T,K,unit', [(5000, 6, True), (2500, 3, False), (100, 2, True)])
-def test_nll_grid_diag_matches_oracle(T, K, unit):
+@pytest.mark.parametrize('T,K,unit,n_cand', [(5000, 6, True, 64), (2500, 3, False, 64), (100, 2, True, 64),
+                                             (3000, 40, True, 10), (1200, 4, False, 3)])
+def test_nll_grid_diag_matches_oracle(T, K, unit, n_cand):
     from eks_amd import hip_ops
     arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=7 + T, unit=unit)
-    cand = np.exp(np.linspace(-8, 8, 64))
+    cand = np.exp(np.linspace(-8, 8, n_cand))
     flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
     rconst = hip_ops.const_r(_dev(var_tk), 1e-4)
     Rc = orc.constant_R_from_timevarying(orc.build_R_from_vars(np.swapaxes(arrs['ensemble_vars'], 0, 1)))
