@@ -275,13 +275,20 @@ def main():
             s = s_fixed
         hip_ops.smooth(y, var, m0, S0, eye, eye, eye, s, flags=flags, out=(ms, Vs))
         if world > 1:
+            # the per-session gather of s_finals (K float64 per rank) is asynchronous: it runs on
+            # the collective stream while this rank's next session is being smoothed, and is waited
+            # for before the timed region closes
             if backend == 'nccl':
-                dist.all_gather(gathered, s)
+                pending.append(dist.all_gather(gathered, s, async_op=True))
             else:
-                dist.all_gather(gathered_host, s.cpu())
+                pending.append(dist.all_gather(gathered_host, s.cpu(), async_op=True))
         return s
 
+    pending = []
+
     def sync():
+        while pending:
+            pending.pop(0).wait()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
