@@ -12,8 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libeks_hip.so')
-SOURCES = ['eks_api.hip', 'eks_diag.hip', 'eks_diag_nll.hip', 'eks_dense.hip', 'eks_misc.hip',
-           'eks_profile.hip']
+SOURCES = ['eks_api.hip', 'eks_diag.hip', 'eks_diag_nll.hip', 'eks_dense.hip', 'eks_loss.hip',
+           'eks_loss_ar1.hip', 'eks_misc.hip', 'eks_profile.hip']
 ARCH = 'gfx950'
 
 
@@ -62,7 +62,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f'hipcc failed: {" ".join(cmd)}\n{r.stdout}\n{r.stderr}')
         return r
 
-    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(7, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if jobs or force or not _newer(LIB, objs):
         run([cc, '-shared', '-fPIC', f'--offload-arch={ARCH}', *objs, '-o', LIB])

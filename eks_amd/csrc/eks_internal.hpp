@@ -69,4 +69,16 @@ int pupil_adam_step(int n, const double* latent_var, const double* nll, const do
 int ensemble_stats(int M, int V, int T, int K, const float* markers, int avg_mode, int var_mode,
                    float nan_replacement, float* stats, hipStream_t st);
 
+// dispatch on the state dimension of the general path (D = 1 .. 6 are instantiated)
+#define EKS_DISPATCH_D(D_, BODY) \
+  switch (D_) {                  \
+    case 1: { constexpr int DD = 1; BODY; } break; \
+    case 2: { constexpr int DD = 2; BODY; } break; \
+    case 3: { constexpr int DD = 3; BODY; } break; \
+    case 4: { constexpr int DD = 4; BODY; } break; \
+    case 5: { constexpr int DD = 5; BODY; } break; \
+    case 6: { constexpr int DD = 6; BODY; } break; \
+    default: return EKS_ERR_UNSUPPORTED;           \
+  }
+
 }  // namespace eks
