@@ -90,13 +90,16 @@ class _DeviceProblem:
         if hasattr(ys, 'detach'):
             y = ys.to(self.dev, dtype=torch.float32).transpose(0, 1).contiguous()
         else:
-            y = torch.as_tensor(np.ascontiguousarray(np.swapaxes(_to_numpy(ys), 0, 1),
-                                                     dtype=np.float32), device=self.dev)
+            # upload in the caller's (K,T,O) layout and dtype; the float32 conversion and the
+            # transposition to frame-major happen on the device (a host-side transpose of a few
+            # hundred MB costs more than everything the GPU does)
+            y = torch.as_tensor(np.ascontiguousarray(_to_numpy(ys)), device=self.dev).to(torch.float32)
+            y = y.transpose(0, 1).contiguous()
         if hasattr(ensemble_vars, 'detach'):
             var = ensemble_vars.to(self.dev, dtype=torch.float32).contiguous()
         else:
-            var = torch.as_tensor(np.ascontiguousarray(_to_numpy(ensemble_vars), dtype=np.float32),
-                                  device=self.dev)
+            var = torch.as_tensor(np.ascontiguousarray(_to_numpy(ensemble_vars)), device=self.dev)
+            var = var.to(torch.float32).contiguous()
         self.T = y.shape[0]
         if tuple(y.shape) != (self.T, self.K, self.O) or tuple(var.shape) != (self.T, self.K, self.O):
             raise ValueError(f'ys must be (K,T,O) and ensemble_vars (T,K,O); got {tuple(ys.shape)} '
@@ -239,12 +242,13 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
         s_dev = torch.as_tensor(s_finals, device=P.dev)
     else:
         t1 = time.perf_counter()
-        ev_host = _to_numpy(ensemble_vars)[:2000] if not hasattr(ensemble_vars, 'detach') \
-            else ensemble_vars[:2000].detach().cpu().numpy()
-        guesses = np.empty(K)
-        for k in range(K):
-            g = float(compute_initial_guesses(ev_host[:, k, :]) or 2.0)
-            guesses[k] = g if (np.isfinite(g) and g > 0.0) else 2.0
+        guesses = np.full(K, 2.0)
+        if s_mode == 'adam':            # the starting point of the optimiser (reference :233-236)
+            ev_host = _to_numpy(ensemble_vars)[:2000] if not hasattr(ensemble_vars, 'detach') \
+                else ensemble_vars[:2000].detach().cpu().numpy()
+            for k in range(K):
+                g = float(compute_initial_guesses(ev_host[:, k, :]) or 2.0)
+                guesses[k] = g if (np.isfinite(g) and g > 0.0) else 2.0
         s_dev, info = _optimize_on_device(P, blocks, s_frames, guesses, lr, s_bounds_log, tol,
                                           safety_cap, 1e-4, s_mode, n_grid)
         s_finals[:] = s_dev.cpu().numpy()
