@@ -175,13 +175,18 @@ def center_predictions(ensemble_marker_array: MarkerArray, quantile_keep_pca: fl
     # SURVEY.md A.4); the means feed every output column, so the extra digits are kept
     preds = np.asarray(ensemble_marker_array.slice_fields('x', 'y').array, dtype=np.float64)
     vars_ = np.asarray(ensemble_marker_array.slice_fields('var_x', 'var_y').array)
-    worst = vars_.max(axis=(0, 1, 4))                                   # (T, K)
-    mask = worst <= np.percentile(worst, quantile_keep_pca, axis=0)
-    n_good = int(mask.sum(axis=0).min())
-    # first n_good kept frames of every keypoint (the reference truncates to the shortest list)
-    order = np.argsort(~mask, axis=0, kind='stable')[:n_good]           # (n_good, K) frame indices
-    kk = np.arange(K)[None, :]
-    good = preds[:, :, order, kk, :]                                    # (1, V, n_good, K, 2)
+    if quantile_keep_pca >= 100 and not np.isnan(vars_).any():
+        # every frame is kept (the single-camera drivers): no percentile, no ordering
+        mask = np.ones((T, K), dtype=bool)
+        good = preds
+    else:
+        worst = vars_.max(axis=(0, 1, 4))                               # (T, K)
+        mask = worst <= np.percentile(worst, quantile_keep_pca, axis=0)
+        n_good = int(mask.sum(axis=0).min())
+        # first n_good kept frames of every keypoint (the reference truncates to the shortest list)
+        order = np.argsort(~mask, axis=0, kind='stable')[:n_good]       # (n_good, K) frame indices
+        kk = np.arange(K)[None, :]
+        good = preds[:, :, order, kk, :]                                # (1, V, n_good, K, 2)
     means = good.mean(axis=2, keepdims=True)                            # (1, V, 1, K, 2)
     centered = preds - means
     fields = ['x', 'y']
