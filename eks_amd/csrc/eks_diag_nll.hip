@@ -5,17 +5,20 @@
 //
 //   N1 diag_nll_summarize : wave = (64-chain tile, time chunk, group of NCL candidates); the waves of
 //                           a block are the candidate groups of ONE (tile, chunk).  Each lane keeps
-//                           NCL candidate filters in registers; once every candidate of the lane
-//                           is steady the work is two FMAs per frame and candidate, the
-//                           candidates interleaved in the frame loop (independent chains issue
-//                           back to back), loads double-buffered 8 frames ahead.  The chunk
-//                           length is chosen so that the grid is a whole number of 256-CU rounds.
+//                           NCL candidate filters in registers.  Chunk 0 (short) starts from a
+//                           known state and passes through the transient regimes; every later
+//                           chunk enters with the converged filter variance (eks_nll_lane.hpp):
+//                           two FMAs per frame and candidate (four while rho^t is alive), the
+//                           candidates interleaved in the frame loop, rows of y loaded through a
+//                           buffer resource (scalar row offsets) 8 frames ahead.  Summaries are
+//                           relative to the chunk's reference state y_0 / c.  The chunk length
+//                           is chosen so that the grid is a whole number of 256-CU rounds.
 //                           (Tried and dropped, round 1: packed fp32, a transient/steady kernel
-//                           split with LDS-staged tiles - see DESIGN.md.)
-//   N2 diag_nll_assemble  : thread = (keypoint, candidate): walks the chunk summaries in time
-//                           order in float64 and writes nll[K][n_cand] (and dnll); with few
-//                           (keypoint, candidate) pairs - the Adam loop - a tree variant composes
-//                           the summaries in log depth instead.
+//                           split with LDS-staged tiles, deeper load rings - see DESIGN.md.)
+//   N2 diag_nll_assemble  : thread = (chain, candidate): walks the chunk summaries in time order
+//                           in float64, the chains of a keypoint are summed by wave shuffles
+//                           -> nll[K][n_cand] (and dnll); with few (keypoint, candidate) pairs -
+//                           the Adam loop - a tree variant composes the summaries in log depth.
 // y is read once from HBM: 4 B per chain-frame regardless of the candidate count.
 #include <hip/hip_runtime.h>
 
@@ -30,8 +33,9 @@ constexpr int kNllChunk = 4096;      // frames per lane, grid mode (measured bes
 constexpr int kNllChunkGrad = 512;   // frames per lane, Adam mode (one candidate: needs more lanes)
 constexpr int kNclGrid = 8;
 constexpr int kNllChunkMin = 2048;
-constexpr int kNllChunk0 = 1024;     // frames in chunk 0, grid mode (C3: 768 0.253 ms, 1024 0.267, 1536 0.287,
-                                     // 3200 0.341; 512 0.342 - chunk 1 then starts before the variance converged)
+constexpr int kNllChunk0 = 1024;     // frames in chunk 0, grid mode (C3 at the time: 768 0.253 ms, 1024 0.267,
+                                     // 1536 0.287, 3200 0.341; 512 0.342 - chunk 1 then starts before the
+                                     // variance has converged and falls back to the exact-entry summary)
 
 struct NllWs {
   // planes indexed [(j * ncp + c) * N + n]

@@ -3,17 +3,22 @@
 // extended_kalman_filter with R = diag(max(nanmedian_t var, 1e-4)), :602, :702-709).
 //
 // Time-parallel form: a lane owns (chain, time chunk, group of NCL candidate s values) and builds,
-// per candidate, the chunk's element (A, b, C, eta, J) plus `ell`, the chunk's log-likelihood under
-// x_in = 0 ("run-local filter").  A second, tiny kernel walks the chunks of a chain in order and
-// assembles the exact marginal log-likelihood (nll_assemble below).
+// per candidate, the chunk's summary: element (A, b, C, eta, J) plus `ell`, the chunk's
+// log-likelihood for a reference entry state ("run-local filter").  A second, tiny kernel walks
+// the chunks of a chain in order and assembles the exact marginal log-likelihood (nll_assemble).
 //
 // With R constant the run-local variance C converges geometrically to the Riccati fixed point, so
-// the chunk is processed in three wave-uniform regimes of decreasing cost:
+// an exact-entry chunk (known x_in; always chunk 0) is processed in three wave-uniform regimes of
+// decreasing cost:
 //   0  full recursion (rcp + log per frame) until C is within ~1e-6 (plus the float32 stall
 //      distance ulp / (1 - rho)) of the closed-form fixed point, then C is snapped onto it,
 //   1  C frozen: gains are constants; A (memory of x_in) still decays, eta/J still accumulate,
-//   2  A < 1e-12: only the innovation d' = rho d + (y' - a y) and the sum of its squares advance:
+//   2  A dead: only the innovation d' = rho d + (y' - a y) and the sum of its squares advance:
 //      two FMAs per frame and candidate, fused over the lane's candidates.
+// A chunk deep enough into the sequence skips the regimes altogether (converged entry, see
+// nll_summarize_chunk).  All regimes advance the innovation, never the run-local mean, and every
+// summary is relative to the chunk's reference state y_0 / c (float32 would otherwise lose the
+// NLL's low digits to terms that grow like y^2 and cancel in the assembly).
 // d nll / d log s comes from running the same code on dual numbers (forward-mode AD; replaces
 // jax.value_and_grad at eks/core.py:652).
 #pragma once
