@@ -1,13 +1,15 @@
-// gfx950 kernels for the general (D, O) smoother and loss: multicam linear path,
-// D = n_latent (3..6), O = 2 * n_cameras (reference eks/multicam_smoother.py:409-443).  Same
-// three-phase chunked scan as the scalar-chain path, with float64 small matrices in registers:
-//   D1 dense_summarize : lane = (keypoint, chunk [, candidate]) -> element (A, b, C, eta, J [, ell])
+// gfx950 kernels for the general (D, O) smoother: multicam linear path, D = n_latent (3..6),
+// O = 2 * n_cameras (reference eks/multicam_smoother.py:409-443), and the pupil smoother's final
+// pass (D = 3, O = 8).  Same three-phase chunked scan as the scalar-chain path, with float64 small
+// matrices in registers; chunk elements are built predict-first (eks_dense_lane.hpp):
+//   D1 dense_summarize : lane = (keypoint, chunk) -> element (A, b, C, eta, J); chunk 0's lane also
+//                        updates the prior with frame 0 (the belief the scan starts from)
 //   D2 dense_scan_*    : block-parallel scan of the chunk elements (general element composition
 //                        through Cholesky / Woodbury forms, eks_dense_math.hpp delem_combine)
 //   D3 dense_replay    : lane = (keypoint, chunk): exact filter, fuse, RTS; filtered beliefs go
 //                        through a per-lane scratch record stream (these problems are tiny:
 //                        BASELINE config 4 is 4 keypoints x 50k frames, latency- not HBM-bound)
-//   losses                : eks_nll / eks_ar1_nll, tree-composed chunk elements (below)
+// The losses of this path (eks_nll, eks_ar1_nll) live in eks_loss_kernels.hpp.
 #include <hip/hip_runtime.h>
 
 #include "eks_dense_lane.hpp"

@@ -5,8 +5,9 @@
 // the same code yields d/dlog s.  All loops have compile-time bounds: matrices live in VGPRs.
 //
 // R_t is diagonal on this path (eks/utils.py:368-377), so a frame's O observations are absorbed
-// one scalar at a time (rank-1 updates): exact, and no O x O or D x D inverse is ever formed in
-// the per-frame code.
+// one scalar at a time (rank-1 updates) - or, in the losses, as D pseudo-observations after
+// folding the frame into information form (delem_observe_info): exact, and no O x O inverse is
+// ever formed in the per-frame code.
 #pragma once
 #include "eks_nll_lane.hpp"
 
