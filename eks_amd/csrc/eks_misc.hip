@@ -317,11 +317,20 @@ __global__ __launch_bounds__(64 * kColWaves) void bracket_collect_kernel(int T, 
   uint32_t less = 0, nvalid = 0;
   if (live && t_begin < T) {
     const uint32_t lo = B.lo[n], hi = B.hi[n];
-    for (int t = t_begin; t < t_end; t += kColFlight) {
+    // rows through a buffer resource based at this wave's first row and tile: the row offset is
+    // scalar arithmetic, rows past t_end fall outside num_records and read 0 -> replaced by NaN
+    const int t_beg_u = __builtin_amdgcn_readfirstlane(t_begin);
+    const int rows = __builtin_amdgcn_readfirstlane(t_end - t_begin);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(var + (size_t)t_beg_u * N + tile * 64), 0, 0x7FFFFFFF, 0x00020000);
+    const unsigned voff = (unsigned)lane * 4u, row_bytes = (unsigned)N * 4u;
+    for (int t = 0; t < rows; t += kColFlight) {
       float v[kColFlight];
 #pragma unroll
       for (int u = 0; u < kColFlight; ++u)
-        v[u] = t + u < t_end ? var[(size_t)(t + u) * N + n] : __uint_as_float(0x7FC00000u);
+        v[u] = t + u < rows ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                  rsrc, voff, (unsigned)(t + u) * row_bytes, 0))
+                            : __uint_as_float(0x7FC00000u);
 #pragma unroll
       for (int u = 0; u < kColFlight; ++u) {
         bool valid;
