@@ -9,7 +9,12 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ev = os.path.join(root, 'gpurun_out', 'evidence')
 prof = os.path.join(root, 'profiles')
 b = json.load(open(os.path.join(ev, 'bench_c3.json')))
-rows = list(csv.DictReader(open(glob.glob(os.path.join(ev, 'stats', '*', '*_kernel_stats.csv'))[0])))
+def newest(pattern):
+    """gpurun merges into gpurun_out/: earlier runs' pid-prefixed files may still be there"""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+rows = list(csv.DictReader(open(newest(os.path.join(ev, 'stats', '*', '*_kernel_stats.csv')))))
 out = [f'# {tag}: rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 '
        '--no-cpu-baseline --no-kernel-events',
        '# C3 workload: singlecam T=100000 x K=256, 64-candidate NLL grid + smooth (23 steps incl. warm-up).',
@@ -25,7 +30,7 @@ open(os.path.join(prof, f'{tag}_kernel_stats.txt'), 'w').write('\n'.join(out) + 
 
 
 def load(d):
-    return list(csv.DictReader(open(glob.glob(os.path.join(ev, d, '*', '*_counter_collection.csv'))[0])))
+    return list(csv.DictReader(open(newest(os.path.join(ev, d, '*', '*_counter_collection.csv')))))
 
 
 lines = [f'# {tag}: PMC counters from separate rocprofv3 --pmc passes of: python3 bench.py --steps 3 --warmup 1 '
