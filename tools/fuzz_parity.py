@@ -1,0 +1,56 @@
+"""Randomised parity sweep of the scalar-chain kernels against the C oracle: random T, K, model
+(unit / general diagonal), variance scales (incl. clipped zeros), smoothing parameters.
+Usage: python tools/fuzz_parity.py [n_cases] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import numpy as np
+from oracle import c_oracle, eks_oracle as orc
+import test_gpu_kernels as tg
+from eks_amd import hip_ops
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+worst = dict(ms=0.0, Vs=0.0, nll=0.0, med=0.0)
+for case in range(n_cases):
+    T = int(rng.choice([1, 2, 3, 7, 31, 32, 33, 64, 257, 1000, 1024, 1025, 2049, 4097, 9000, 20011]))
+    K = int(rng.choice([1, 2, 3, 5, 17, 31, 32, 33, 70]))
+    unit = bool(rng.integers(0, 2))
+    arrs, y_tk, var_tk = tg._singlecam_problem(max(T, 2), K, seed=int(rng.integers(1 << 30)), unit=unit)
+    y_tk, var_tk = y_tk[:T].copy(), var_tk[:T].copy()
+    arrs['ys'] = arrs['ys'][:, :T]; arrs['ensemble_vars'] = arrs['ensemble_vars'][:T]
+    scale = float(np.exp(rng.uniform(-4, 4)))
+    var_tk = (var_tk * scale).astype(np.float32)
+    if rng.random() < 0.4:
+        var_tk[rng.random(var_tk.shape) < 0.1] = 0.0
+    y_tk = (y_tk * float(np.exp(rng.uniform(-1, 2)))).astype(np.float32)
+    arrs['ys'] = np.transpose(y_tk, (1, 0, 2)).astype(np.float64); arrs['ensemble_vars'] = var_tk.astype(np.float64)
+    if T < 3:
+        arrs['S0s'] = np.tile(np.eye(2) * 3.0, (K, 1, 1))
+    else:
+        arrs['S0s'] = np.eye(2) * np.maximum(np.var(arrs['ys'], axis=1), 1e-3)[:, :, None]
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    Rd = np.maximum(np.swapaxes(arrs['ensemble_vars'], 0, 1), 1e-12)
+    # constant R (exact median)
+    rc = hip_ops.const_r(tg._dev(var_tk), 1e-4).cpu().numpy()
+    ref_rc = orc.constant_R_from_timevarying(Rd)
+    worst['med'] = max(worst['med'], float(np.abs(rc - ref_rc).max() / np.abs(ref_rc).max()))
+    assert np.array_equal(rc, ref_rc), (case, T, K, 'median mismatch')
+    # NLL grid
+    n_cand = int(rng.choice([1, 5, 16, 64]))
+    cand = np.exp(np.sort(rng.uniform(-8, 8, n_cand)))
+    nll = hip_ops.nll(tg._dev(y_tk), tg._dev(rc), *tg._params_dev(arrs), tg._dev(cand), flags=flags).cpu().numpy()
+    ref = c_oracle.nll_grid(arrs['ys'], rc, arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], cand)
+    e_nll = float((np.abs(nll - ref) / np.maximum(np.abs(ref), 1.0)).max())
+    # smoother
+    s = np.exp(rng.uniform(-8, 8, K))
+    ms, Vs = hip_ops.smooth(tg._dev(y_tk), tg._dev(var_tk), *tg._params_dev(arrs), tg._dev(s), flags=flags, vs_diag=True)
+    ms = np.transpose(ms.cpu().numpy().astype(np.float64), (1, 0, 2)); Vs = np.transpose(Vs.cpu().numpy().astype(np.float64), (1, 0, 2))
+    mo, Vo = orc.info_form_smoother(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], s, Rd)[:2]
+    e_ms = float((np.abs(ms - mo) / np.maximum(np.abs(mo).max(axis=(1, 2), keepdims=True), 1e-3)).max())
+    Vd = np.diagonal(Vo, axis1=2, axis2=3)
+    e_Vs = float((np.abs(Vs - Vd) / Vd).max())
+    worst['nll'] = max(worst['nll'], e_nll); worst['ms'] = max(worst['ms'], e_ms); worst['Vs'] = max(worst['Vs'], e_Vs)
+    flag = '' if max(e_nll, e_ms, e_Vs) < 1e-5 else '   <-- above 1e-5'
+    print(f'case {case}: T={T} K={K} unit={unit} var x{scale:.3g} n_cand={n_cand}: nll {e_nll:.1e} ms {e_ms:.1e} Vs {e_Vs:.1e}{flag}', flush=True)
+print('worst', worst)
