@@ -340,6 +340,13 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
                                 bool allow_converged_entry = false) {
   NllLane<R, NCL, UNIT> L;
   nll_lane_init<R, NCL, UNIT>(L, r_d, a_d, c_d, sq_d);
+  // Snapping C onto the fixed point costs a one-off ~1e-5 of a frame's terms: nothing against a
+  // chunk of thousands of frames, the whole error budget of a sequence of three.  Short chunks
+  // stay in the full recursion.
+  if (len < 256) {
+#pragma unroll
+    for (int k = 0; k < NCL; ++k) L.tolC[k] = -1.f;
+  }
   const float af = (float)a_d;
   // Reference state: the chunk is summarised as a function of x_in - xref with xref = y_0 / c,
   // the state its own first observation points at.  With xref = 0 the zero-start innovations
