@@ -14,7 +14,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 worst = dict(ms=0.0, Vs=0.0, nll=0.0, med=0.0)
 for case in range(n_cases):
     T = int(rng.choice([1, 2, 3, 7, 31, 32, 33, 64, 257, 1000, 1024, 1025, 2049, 4097, 9000, 20011]))
-    K = int(rng.choice([1, 2, 3, 5, 17, 31, 32, 33, 70]))
+    K = int(rng.choice([1, 2, 3, 5, 17, 31, 32, 33, 70, 700]))
     unit = bool(rng.integers(0, 2))
     arrs, y_tk, var_tk = tg._singlecam_problem(max(T, 2), K, seed=int(rng.integers(1 << 30)), unit=unit)
     y_tk, var_tk = y_tk[:T].copy(), var_tk[:T].copy()
@@ -37,7 +37,7 @@ for case in range(n_cases):
     worst['med'] = max(worst['med'], float(np.abs(rc - ref_rc).max() / np.abs(ref_rc).max()))
     assert np.array_equal(rc, ref_rc), (case, T, K, 'median mismatch')
     # NLL grid
-    n_cand = int(rng.choice([1, 5, 16, 64]))
+    n_cand = int(rng.choice([1, 5, 16, 64, 129, 200]))
     cand = np.exp(np.sort(rng.uniform(-8, 8, n_cand)))
     nll = hip_ops.nll(tg._dev(y_tk), tg._dev(rc), *tg._params_dev(arrs), tg._dev(cand), flags=flags).cpu().numpy()
     ref = c_oracle.nll_grid(arrs['ys'], rc, arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], cand)
