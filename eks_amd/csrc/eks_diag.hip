@@ -168,27 +168,62 @@ __global__ __launch_bounds__(kScanCH* kScanCB) void diag_scan_reduce_kernel(int 
   }
 }
 
-__global__ __launch_bounds__(64) void diag_scan_blocks_kernel(int N, DiagModel M, ScanWs S) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= 2 * N) return;
-  const int n = idx % N;
-  if (idx < N) {
-    float m, P;
-    load_chain_prior(M, n, m, P);
-    for (int q = 0; q < S.nblk; ++q) {
-      const size_t o = (size_t)q * N + n;
-      S.bm[o] = m;
-      S.bP[o] = P;
-      elem_apply(Elem<float>{S.gA[o], S.gb[o], S.gC[o], S.gEta[o], S.gJ[o]}, m, P);
+// S2: one wave per chain, lanes along the block aggregates (64 per pass): inclusive forward /
+// reverse compositions by shuffles; the exclusive prefix pushed through the chain's running belief
+// gives the belief entering each block, the exclusive suffix pulled back from the running
+// information gives what leaves it.  (The first version walked the aggregates one by one.)
+__global__ __launch_bounds__(256) void diag_scan_blocks_kernel(int N, DiagModel M, ScanWs S) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;                                       // wave-uniform
+  auto agg = [&](int q) {
+    const size_t o = (size_t)q * N + n;
+    return q < S.nblk ? Elem<float>{S.gA[o], S.gb[o], S.gC[o], S.gEta[o], S.gJ[o]} : elem_identity<float>();
+  };
+  float m, P;
+  load_chain_prior(M, n, m, P);
+  for (int q0 = 0; q0 < S.nblk; q0 += 64) {                 // forward: belief entering block q0 + lane
+    const Elem<float> own = agg(q0 + lane);
+    Elem<float> f = own;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const Elem<float> up = shfl_up_elem(f, off);
+      if (lane >= off) f = elem_combine(up, f);
     }
-  } else {
-    float eta = 0.f, J = 0.f;
-    for (int q = S.nblk - 1; q >= 0; --q) {
-      const size_t o = (size_t)q * N + n;
-      S.bEta[o] = eta;
-      S.bJ[o] = J;
-      elem_back(Elem<float>{S.gA[o], S.gb[o], S.gC[o], S.gEta[o], S.gJ[o]}, eta, J);
+    Elem<float> excl = shfl_up_elem(f, 1);
+    if (lane == 0) excl = elem_identity<float>();
+    float mq = m, Pq = P;
+    elem_apply(excl, mq, Pq);
+    if (q0 + lane < S.nblk) {
+      const size_t o = (size_t)(q0 + lane) * N + n;
+      S.bm[o] = mq;
+      S.bP[o] = Pq;
     }
+    // carry the belief past these 64 aggregates (lane 63 holds their whole composition)
+    const Elem<float> all{__shfl(f.A, 63), __shfl(f.b, 63), __shfl(f.C, 63), __shfl(f.eta, 63), __shfl(f.J, 63)};
+    elem_apply(all, m, P);
+  }
+  float eta = 0.f, J = 0.f;
+  const int npass = (S.nblk + 63) / 64;
+  for (int pass = npass - 1; pass >= 0; --pass) {           // backward: information leaving each block
+    const int q0 = pass * 64;
+    const Elem<float> own = agg(q0 + lane);
+    Elem<float> r = own;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const Elem<float> dn = shfl_down_elem(r, off);
+      if (lane + off < 64) r = elem_combine(r, dn);
+    }
+    Elem<float> after = shfl_down_elem(r, 1);
+    if (lane == 63) after = elem_identity<float>();
+    float eq = eta, Jq = J;
+    elem_back(after, eq, Jq);
+    if (q0 + lane < S.nblk) {
+      const size_t o = (size_t)(q0 + lane) * N + n;
+      S.bEta[o] = eq;
+      S.bJ[o] = Jq;
+    }
+    const Elem<float> all{__shfl(r.A, 0), __shfl(r.b, 0), __shfl(r.C, 0), __shfl(r.eta, 0), __shfl(r.J, 0)};
+    elem_back(all, eta, J);
   }
 }
 
@@ -327,7 +362,7 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
     ProfScope ps("diag_scan", st);
     const dim3 sgrid((N + kScanCH - 1) / kScanCH, S.nblk), sblock(kScanCH * kScanCB);
     hipLaunchKernelGGL(diag_scan_reduce_kernel, sgrid, sblock, 0, st, N, L.nc, W, S);
-    hipLaunchKernelGGL(diag_scan_blocks_kernel, dim3((2 * N + 63) / 64), dim3(64), 0, st, N, M, S);
+    hipLaunchKernelGGL(diag_scan_blocks_kernel, dim3((N + 3) / 4), dim3(256), 0, st, N, M, S);
     hipLaunchKernelGGL(diag_scan_local_kernel, sgrid, sblock, 0, st, N, L.nc, W, S);
   }
   const int vs_row = vs_diag ? 0 : D;

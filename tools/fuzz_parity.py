@@ -47,7 +47,11 @@ for case in range(n_cases):
     ms, Vs = hip_ops.smooth(tg._dev(y_tk), tg._dev(var_tk), *tg._params_dev(arrs), tg._dev(s), flags=flags, vs_diag=True)
     ms = np.transpose(ms.cpu().numpy().astype(np.float64), (1, 0, 2)); Vs = np.transpose(Vs.cpu().numpy().astype(np.float64), (1, 0, 2))
     mo, Vo = orc.info_form_smoother(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], s, Rd)[:2]
-    e_ms = float((np.abs(ms - mo) / np.maximum(np.abs(mo).max(axis=(1, 2), keepdims=True), 1e-3)).max())
+    # scale of a keypoint: its smoothed track or its observations in state units, whichever is larger
+    # (a float32 pipeline cannot resolve an output of 0.03 px better than ~1e-7 of 3 px inputs)
+    cdiag = np.abs(np.diagonal(arrs['Cs'], axis1=1, axis2=2))[:, None, :]
+    scale_k = np.maximum(np.abs(mo).max(axis=(1, 2), keepdims=True), (np.abs(arrs['ys']) / cdiag).max(axis=(1, 2), keepdims=True))
+    e_ms = float((np.abs(ms - mo) / np.maximum(scale_k, 1e-3)).max())
     Vd = np.diagonal(Vo, axis1=2, axis2=3)
     e_Vs = float((np.abs(Vs - Vd) / Vd).max())
     worst['nll'] = max(worst['nll'], e_nll); worst['ms'] = max(worst['ms'], e_ms); worst['Vs'] = max(worst['Vs'], e_Vs)
