@@ -138,6 +138,10 @@ struct NllLane {
   R rg_last[NCL];     // r g = 1 - c K of the last consumed frame
   float y_last;       // last consumed observation
   bool any_frame;
+  // y' - a y is formed with a in float64: rounding a to float32 (6e-8) shifts every prediction
+  // by 6e-8 |y|, a perturbation of the MODEL that slow candidates integrate (measured 1e-5 on the
+  // NLL at |y| ~ 1000); one float64 FMA per frame and lane, shared by the lane's candidates
+  double a_dbl;
   Acc64<R> quad[NCL], logacc[NCL], acc2[NCL];
   int phase[NCL], n_post[NCL];
   float tolC[NCL];
@@ -165,7 +169,7 @@ struct NllLane {
         R s2 = R(0.f), d = dl[k];
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
-          const float dy = UNIT ? (yb[q] - yp) : (yb[q] - val(pc[k].a) * yp);
+          const float dy = UNIT ? (yb[q] - yp) : (float)((double)yb[q] - a_dbl * (double)yp);
           yp = yb[q];
           d = rho * d + R(dy);
           s2 = s2 + d * d;
@@ -179,7 +183,7 @@ struct NllLane {
         R s2 = R(0.f), d = dl[k];
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
-          const float dy = UNIT ? (yb[q] - yp) : (yb[q] - val(pc[k].a) * yp);
+          const float dy = UNIT ? (yb[q] - yp) : (float)((double)yb[q] - a_dbl * (double)yp);
           yp = yb[q];
           d = rho * d + R(dy);
           s2 = s2 + d * d;
@@ -202,7 +206,7 @@ struct NllLane {
         R qs = R(0.f), ls = R(0.f), d = dl[k], rg = rg_last[k];
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
-          const float dy = UNIT ? (yb[q] - yp) : (yb[q] - val(pc[k].a) * yp);
+          const float dy = UNIT ? (yb[q] - yp) : (float)((double)yb[q] - a_dbl * (double)yp);
           yp = yb[q];
           d = (UNIT ? rg : a * rg) * d + R(dy);        // gain of the PREVIOUS frame carries d over
           const R S = UNIT ? (rR + e[k].C) : (rR + e[k].C * c * c);
@@ -264,6 +268,7 @@ EKS_HD void nll_lane_init(NllLane<R, NCL, UNIT>& L, double r_d, double a_d, doub
   L.rR = R(r);
   L.y_last = 0.f;
   L.any_frame = false;
+  L.a_dbl = a_d;
   const float af = (float)a_d, cf = (float)c_d;
 #pragma unroll
   for (int k = 0; k < NCL; ++k) {
@@ -387,7 +392,7 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
       auto eat4 = [&](const float (&yy)[8]) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          const float dy = UNIT ? (yy[q] - yprev) : (yy[q] - af * yprev);
+          const float dy = UNIT ? (yy[q] - yprev) : (float)((double)yy[q] - a_d * (double)yprev);
           yprev = yy[q];
 #pragma unroll
           for (int k = 0; k < NCL; ++k) {
@@ -472,7 +477,7 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
     auto eat = [&](const float (&yy)[8]) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const float dy = UNIT ? (yy[q] - yprev) : (yy[q] - af * yprev);
+        const float dy = UNIT ? (yy[q] - yprev) : (float)((double)yy[q] - a_d * (double)yprev);
         yprev = yy[q];
 #pragma unroll
         for (int k = 0; k < NCL; ++k) {
