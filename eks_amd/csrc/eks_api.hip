@@ -187,6 +187,27 @@ int eks_pupil_adam_run(const eks_dims_t* d, const float* y, const float* var, co
   return EKS_OK;
 }
 
+size_t eks_ekf_smooth_workspace_bytes(const eks_dims_t* d, int32_t want_smoother) {
+  if (check_dims(d) != EKS_OK) return 0;
+  return ekf_smooth_workspace_bytes(d->n_frames, d->n_keypoints, want_smoother);
+}
+
+int eks_ekf_smooth(const eks_dims_t* d, int32_t n_data_keypoints, const float* y, const float* var,
+                   const double* rconst, const double* m0, const double* S0, const double* A,
+                   const double* Q, const double* s, const double* cams, int32_t n_cams,
+                   double* xlin, int32_t max_sweeps, double tol, float* ms, float* Vs, double* nll,
+                   double* info, void* workspace, size_t workspace_bytes, eks_stream_t stream) {
+  const int rc = check_dims(d);
+  if (rc != EKS_OK) return rc;
+  if (!y || !m0 || !S0 || !A || !Q || !s || !cams || !xlin) return EKS_ERR_NULL;
+  if (!var && !rconst) return EKS_ERR_NULL;
+  if (ms && !Vs) return EKS_ERR_NULL;
+  if (!workspace) return EKS_ERR_WORKSPACE;
+  const DenseModel M{m0, S0, A, nullptr, Q, s};
+  return ekf_smooth(*d, n_data_keypoints, y, var, rconst, M, cams, n_cams, xlin, max_sweeps, tol, ms,
+                    Vs, nll, info, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
 int eks_ensemble(int32_t n_models, int32_t n_cameras, int32_t n_frames, int32_t n_keypoints,
                  const float* markers, int32_t avg_mode, int32_t var_mode, float nan_replacement,
                  float* stats, eks_stream_t stream) {

@@ -21,27 +21,36 @@ struct DenseGeom {
   int K, T, O, B, nc;
 };
 
-template <int D>
+// Sweeps of the extended filter (eks_ekf_smooth) are enqueued without host round trips: a sweep's
+// kernels return at once when the previous sweep already met the tolerance.
+struct Gate {
+  const double* resid;   // largest change of a linearisation point in the previous sweep, or null
+  double tol;
+  __device__ bool closed() const { return resid != nullptr && *resid <= tol; }
+};
+
+template <int D, typename Obs>
 __global__ __launch_bounds__(64) void dense_summarize_kernel(DenseGeom G, DenseModelPtrs M,
-                                                            const double* __restrict__ s,
-                                                            const float* __restrict__ y,
-                                                            const float* __restrict__ var,
+                                                            const double* __restrict__ s, Obs obs,
                                                             double* __restrict__ elems,
-                                                            double* __restrict__ first) {
+                                                            double* __restrict__ first, Gate gate) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= G.K * G.nc) return;
+  if (idx >= G.K * G.nc || gate.closed()) return;
   const int k = idx % G.K, j = idx / G.K;
   Mat<double, D> F, sQ;
   bool fid;
   load_dynamics<double, D>(M, k, s[k], F, sQ, fid);
   const int t0 = j * G.B, len = min(G.B, G.T - t0);
-  const DElem<double, D> e = dense_smooth_element<D>(y, var, G.K, G.O, k, t0, len, M, F, sQ, fid);
+  const DElem<double, D> e = dense_smooth_element_obs<D>(obs, k, t0, len, F, sQ, fid);
   store_delem<double, D>(elems + (size_t)idx * delem_doubles<D>(), e);
   if (j == 0) {   // the belief the scan starts from: the prior updated with frame 0
     Vec<double, D> m;
     Mat<double, D> P;
     load_prior<D>(M, k, m, P);
-    belief_update_frame<D>(y, var, G.K, G.O, k, 0, M, m, P);
+    double xl[D];   // the extended filter linearises frame 0 at the prior mean
+#pragma unroll
+    for (int a = 0; a < D; ++a) xl[a] = m.a[a];
+    belief_update_obs<D>(obs, k, 0, xl, m, P);
     double* r = first + (size_t)k * (D + D * D);
 #pragma unroll
     for (int a = 0; a < D; ++a) {
@@ -63,9 +72,11 @@ constexpr int kDenseCB = 64;
 template <int D>
 __global__ __launch_bounds__(kDenseCB) void dense_scan_reduce_kernel(DenseGeom G,
                                                                     const double* __restrict__ elems,
-                                                                    double* __restrict__ agg) {
+                                                                    double* __restrict__ agg,
+                                                                    Gate gate) {
   constexpr int NV = delem_doubles<D>();
   __shared__ double lds[kDenseCB * NV];
+  if (gate.closed()) return;
   const int k = blockIdx.x, blk = blockIdx.y, i = threadIdx.x;
   const int j = blk * kDenseCB + i;
   DElem<double, D> e = j < G.nc ? load_delem<double, D>(elems + ((size_t)j * G.K + k) * NV)
@@ -87,9 +98,10 @@ __global__ __launch_bounds__(64) void dense_scan_blocks_kernel(DenseGeom G, int 
                                                               const double* __restrict__ first,
                                                               const double* __restrict__ agg,
                                                               double* __restrict__ bprior,
-                                                              double* __restrict__ bsuffix) {
+                                                              double* __restrict__ bsuffix,
+                                                              Gate gate) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= 2 * G.K) return;
+  if (idx >= 2 * G.K || gate.closed()) return;
   constexpr int REC = D + D * D;
   constexpr int NV = delem_doubles<D>();
   const int k = idx % G.K;
@@ -135,10 +147,12 @@ __global__ __launch_bounds__(kDenseCB) void dense_scan_local_kernel(DenseGeom G,
                                                                    const double* __restrict__ bprior,
                                                                    const double* __restrict__ bsuffix,
                                                                    double* __restrict__ prior,
-                                                                   double* __restrict__ suffix) {
+                                                                   double* __restrict__ suffix,
+                                                                   Gate gate) {
   constexpr int NV = delem_doubles<D>();
   constexpr int REC = D + D * D;
   __shared__ double lds[kDenseCB * NV];
+  if (gate.closed()) return;
   const int k = blockIdx.x, blk = blockIdx.y, i = threadIdx.x;
   const int j = blk * kDenseCB + i;
   const bool live = j < G.nc;
@@ -211,18 +225,19 @@ __global__ __launch_bounds__(kDenseCB) void dense_scan_local_kernel(DenseGeom G,
   }
 }
 
-template <int D>
+template <int D, bool EKF, typename Obs>
 __global__ __launch_bounds__(64) void dense_replay_kernel(DenseGeom G, DenseModelPtrs M,
-                                                         const double* __restrict__ s,
-                                                         const float* __restrict__ y,
-                                                         const float* __restrict__ var,
+                                                         const double* __restrict__ s, Obs obs,
                                                          const double* __restrict__ prior,
                                                          const double* __restrict__ suffix,
                                                          double* __restrict__ filt,
                                                          float* __restrict__ ms,
-                                                         float* __restrict__ Vs, int vs_diag) {
+                                                         float* __restrict__ Vs, int vs_diag,
+                                                         double* __restrict__ xlin,
+                                                         double* __restrict__ ll_chunk,
+                                                         double* __restrict__ resid, Gate gate) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= G.K * G.nc) return;
+  if (idx >= G.K * G.nc || gate.closed()) return;
   constexpr int REC = D + D * D;
   const int k = idx % G.K, j = idx / G.K;
   Mat<double, D> F, sQ;
@@ -244,8 +259,18 @@ __global__ __launch_bounds__(64) void dense_replay_kernel(DenseGeom G, DenseMode
   }
   if (j == 0) load_prior<D>(M, k, m, P);   // chunk 0 replays frame 0's update of the prior itself
   const int t0 = j * G.B, len = min(G.B, G.T - t0);
-  dense_replay_chunk<D>(y, var, G.K, G.O, k, t0, len, M, F, sQ, fid, m, P, eta, J,
-                        filt + ((size_t)k * G.T + t0) * REC, ms, Vs, vs_diag != 0);
+  double ll = 0.0, ch = 0.0;
+  dense_replay_chunk_obs<D, EKF>(obs, G.K, k, t0, len, F, sQ, fid, m, P, eta, J,
+                                 filt ? filt + ((size_t)k * G.T + t0) * REC : nullptr, ms, Vs,
+                                 vs_diag != 0, EKF ? xlin + ((size_t)k * G.T + t0) * D : nullptr, &ll,
+                                 &ch);
+  if constexpr (EKF) {
+    ll_chunk[idx] = ll;
+    // non-negative doubles order like their bit patterns; a NaN (diverged linearisation) has the
+    // largest pattern and keeps the following sweeps open
+    atomicMax(reinterpret_cast<unsigned long long*>(resid),
+              (unsigned long long)__double_as_longlong(ch != ch ? 1e300 : ch));
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -288,27 +313,137 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
   double* first = reinterpret_cast<double*>(p);
   const int lanes = K * G.nc;
   const int vs_diag = (d.flags & EKS_FLAG_VS_DIAG) ? 1 : 0;
+  const Gate open{nullptr, 0.0};
   EKS_DISPATCH_D(D, {
+    const LinearObs<DD> obs = make_linear_obs<DD>(y, var, K, O, M);
     {
       ProfScope ps("dense_summarize", st);
-      hipLaunchKernelGGL(dense_summarize_kernel<DD>, dim3((lanes + 63) / 64), dim3(64), 0, st, G, M,
-                         Mm.s, y, var, elems, first);
+      hipLaunchKernelGGL((dense_summarize_kernel<DD, LinearObs<DD>>), dim3((lanes + 63) / 64),
+                         dim3(64), 0, st, G, M, Mm.s, obs, elems, first, open);
     }
     {
       ProfScope ps("dense_scan", st);
       const dim3 sgrid(K, nblk);
-      hipLaunchKernelGGL(dense_scan_reduce_kernel<DD>, sgrid, dim3(kDenseCB), 0, st, G, elems, agg);
+      hipLaunchKernelGGL(dense_scan_reduce_kernel<DD>, sgrid, dim3(kDenseCB), 0, st, G, elems, agg,
+                         open);
       hipLaunchKernelGGL(dense_scan_blocks_kernel<DD>, dim3((2 * K + 63) / 64), dim3(64), 0, st, G, nblk,
-                         first, agg, bprior, bsuffix);
+                         first, agg, bprior, bsuffix, open);
       hipLaunchKernelGGL(dense_scan_local_kernel<DD>, sgrid, dim3(kDenseCB), 0, st, G, elems, bprior,
-                         bsuffix, prior, suffix);
+                         bsuffix, prior, suffix, open);
     }
     {
       ProfScope ps("dense_replay", st);
-      hipLaunchKernelGGL(dense_replay_kernel<DD>, dim3((lanes + 63) / 64), dim3(64), 0, st, G, M,
-                         Mm.s, y, var, prior, suffix, filt, ms, Vs, vs_diag);
+      hipLaunchKernelGGL((dense_replay_kernel<DD, false, LinearObs<DD>>), dim3((lanes + 63) / 64),
+                         dim3(64), 0, st, G, M, Mm.s, obs, prior, suffix, filt, ms, Vs, vs_diag,
+                         nullptr, nullptr, nullptr, open);
     }
   })
+  return hip_status(hipGetLastError());
+}
+
+// ---- extended Kalman filter / smoother with calibrated pinhole cameras ------------------------
+// Reference: run_kalman_smoother(h_fn=...) (eks/core.py:188-190, :274-295) as driven by the
+// calibrated branch of eks/multicam_smoother.py:369-407; D = 3, O = 2 * n_cams.
+//
+// The extended filter linearises frame t at its own predicted mean, which makes the recursion
+// sequential in the reference.  Here it is solved as a fixed point instead: with linearisation
+// points X fixed the model is a linear one with time-varying observation rows, which the chunked
+// scan handles in parallel over (chain, chunk); the replay then runs the TRUE extended filter
+// inside each chunk from the chunk's entry belief and writes its predicted means back as the new
+// X.  At the fixed point (entry beliefs consistent with X) the result IS the sequential extended
+// filter; every sweep makes at least one more chunk exact, in practice 2-4 sweeps reach 1e-10
+// because the filter forgets its entry belief within a few frames.  Sweeps are gated on the
+// device (Gate), so the whole solve is one enqueue without host round trips.
+constexpr int kEkfMaxSweeps = 64;
+
+__global__ __launch_bounds__(64) void ekf_finish_kernel(int K, int nc, int n_sweeps, double tol,
+                                                       const double* __restrict__ ll_chunk,
+                                                       const double* __restrict__ resid,
+                                                       double* __restrict__ nll,
+                                                       double* __restrict__ info) {
+  const int k = blockIdx.x, i = threadIdx.x;
+  double acc = 0.0;
+  for (int j = i; j < nc; j += 64) acc += ll_chunk[(size_t)j * K + k];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (i == 0) {
+    if (nll) nll[k] = -acc;
+    if (k == 0 && info) {
+      int ran = 1;
+      while (ran < n_sweeps && !(resid[ran - 1] <= tol)) ++ran;
+      info[0] = (double)ran;          // filter sweeps executed
+      info[1] = resid[ran - 1];       // largest relative change of a linearisation point in the last
+    }
+  }
+}
+
+static size_t ekf_ws_layout(int T, int K, bool smooth, double** ptrs, char* base) {
+  constexpr int D = 3;
+  const int B = kDenseSmoothChunk, nc = (T + B - 1) / B, nblk = (nc + kDenseCB - 1) / kDenseCB;
+  const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
+  const size_t sizes[10] = {(size_t)nc * K * nv * 8,   (size_t)nc * K * rec * 8,
+                            (size_t)nc * K * rec * 8,  (size_t)nblk * K * nv * 8,
+                            (size_t)nblk * K * rec * 8, (size_t)nblk * K * rec * 8,
+                            smooth ? (size_t)T * K * rec * 8 : 0, (size_t)K * rec * 8,
+                            (size_t)nc * K * 8,         (size_t)(kEkfMaxSweeps + 2) * 8};
+  size_t off = 0;
+  for (int i = 0; i < 10; ++i) {
+    if (ptrs) ptrs[i] = reinterpret_cast<double*>(base + off);
+    off += align_up(sizes[i], 256);
+  }
+  return off;
+}
+
+size_t ekf_smooth_workspace_bytes(int T, int K, int smooth) {
+  return ekf_ws_layout(T, K, smooth != 0, nullptr, nullptr);
+}
+
+int ekf_smooth(const eks_dims_t& d, int n_data_keypoints, const float* y, const float* var,
+               const double* rconst, const DenseModel& Mm, const double* cams, int n_cams,
+               double* xlin, int max_sweeps, double tol, float* ms, float* Vs, double* nll,
+               double* info, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int T = d.n_frames, K = d.n_keypoints, D = d.state_dim, O = d.obs_dim, Kd = n_data_keypoints;
+  if (D != 3 || n_cams < 1 || O != 2 * n_cams || Kd < 1 || K % Kd != 0) return EKS_ERR_UNSUPPORTED;
+  if (max_sweeps < 1 || max_sweeps > kEkfMaxSweeps) return EKS_ERR_SHAPE;
+  if ((var == nullptr) == (rconst == nullptr)) return EKS_ERR_SHAPE;
+  const bool smooth = ms != nullptr;
+  if (ws_bytes < ekf_smooth_workspace_bytes(T, K, smooth)) return EKS_ERR_WORKSPACE;
+  double* w[10];
+  ekf_ws_layout(T, K, smooth, w, static_cast<char*>(ws));
+  double *elems = w[0], *prior = w[1], *suffix = w[2], *agg = w[3], *bprior = w[4], *bsuffix = w[5],
+         *filt = w[6], *first = w[7], *ll_chunk = w[8], *resid = w[9];
+  DenseGeom G{K, T, O, kDenseSmoothChunk, 0};
+  G.nc = (T + G.B - 1) / G.B;
+  const int nblk = (G.nc + kDenseCB - 1) / kDenseCB, lanes = K * G.nc;
+  const DenseModelPtrs M{Mm.m0, Mm.S0, Mm.A, nullptr, Mm.Q};
+  const PinholeObs obs{y, ObsNoise{var, rconst}, Kd, O, T, cams, xlin};
+  const int vs_diag = (d.flags & EKS_FLAG_VS_DIAG) ? 1 : 0;
+  const dim3 sgrid(K, nblk);
+  hipError_t e = hipMemsetAsync(resid, 0, (kEkfMaxSweeps + 2) * 8, st);
+  if (e != hipSuccess) return hip_status(e);
+  auto sweep = [&](const Gate& gate, double* resid_out, bool with_smoother) {
+    hipLaunchKernelGGL((dense_summarize_kernel<3, PinholeObs>), dim3((lanes + 63) / 64), dim3(64), 0,
+                       st, G, M, Mm.s, obs, elems, first, gate);
+    hipLaunchKernelGGL(dense_scan_reduce_kernel<3>, sgrid, dim3(kDenseCB), 0, st, G, elems, agg, gate);
+    hipLaunchKernelGGL(dense_scan_blocks_kernel<3>, dim3((2 * K + 63) / 64), dim3(64), 0, st, G, nblk,
+                       first, agg, bprior, bsuffix, gate);
+    hipLaunchKernelGGL(dense_scan_local_kernel<3>, sgrid, dim3(kDenseCB), 0, st, G, elems, bprior,
+                       bsuffix, prior, suffix, gate);
+    hipLaunchKernelGGL((dense_replay_kernel<3, true, PinholeObs>), dim3((lanes + 63) / 64), dim3(64),
+                       0, st, G, M, Mm.s, obs, prior, suffix, with_smoother ? filt : nullptr,
+                       with_smoother ? ms : nullptr, Vs, vs_diag, xlin, ll_chunk, resid_out, gate);
+  };
+  {
+    ProfScope ps("ekf_filter_sweeps", st);
+    for (int i = 0; i < max_sweeps; ++i)
+      sweep(Gate{i > 0 ? resid + i - 1 : nullptr, tol}, resid + i, false);
+  }
+  if (smooth) {
+    ProfScope ps("ekf_smooth_sweep", st);
+    sweep(Gate{nullptr, 0.0}, resid + kEkfMaxSweeps, true);
+  }
+  hipLaunchKernelGGL(ekf_finish_kernel, dim3(K), dim3(64), 0, st, K, G.nc, max_sweeps, tol, ll_chunk,
+                     resid, nll, info);
   return hip_status(hipGetLastError());
 }
 

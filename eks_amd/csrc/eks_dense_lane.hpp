@@ -2,6 +2,7 @@
 // One lane owns one keypoint over one chunk of frames.  y, var: float [T][K][O].
 #pragma once
 #include "eks_dense_math.hpp"
+#include "eks_pinhole.hpp"
 
 namespace eks {
 
@@ -142,27 +143,91 @@ EKS_HD S loss_first_frame(const float* __restrict__ y, const ObsNoise& R, int K,
   return ll;
 }
 
-// Measurement update of the belief N(m, P) with frame t of keypoint k, one scalar observation at
-// a time (R_t diagonal).
+// ---- observation sources of the smoother ---------------------------------------------------------
+// visit(t, k, xl, fn) calls fn(h, y_eff, r) for each scalar observation of frame t of chain k:
+// observation row h, effective observation and its variance.
+//   LinearObs  : y = C x + v (reference eks/core.py:182-186): h = C[o], y_eff = y.
+//   PinholeObs : y = h(x) + v with h the calibrated multi-camera projection (reference
+//                eks/core.py:188-190, eks/multicam_smoother.py:871-898), linearised at xl (or, when
+//                xl is null, at the stored linearisation point of the frame):
+//                h = J_o(xl), y_eff = y - h_o(xl) + J_o(xl) xl - what the extended Kalman filter's
+//                update does when xl is the predicted mean.
 template <int D>
-EKS_HD void belief_update_frame(const float* __restrict__ y, const float* __restrict__ var, int K,
-                                int O, int k, int t, const DenseModelPtrs& M, Vec<double, D>& m,
+struct LinearObs {
+  const float *y, *var;     // [T][K][O]
+  int K, O;
+  DenseModelPtrs M;
+  template <typename Fn>
+  EKS_HD void visit(int t, int k, const double* /*xl*/, Fn&& fn) const {
+    const size_t row = ((size_t)t * K + k) * O;
+    for (int o = 0; o < O; ++o) {
+      const float v = var[row + o];
+      fn(load_obs_row<double, D>(M, k, O, o), (double)y[row + o],
+         v > kVarFloor ? (double)v : (double)kVarFloor);
+    }
+  }
+};
+
+template <int D>
+EKS_HD LinearObs<D> make_linear_obs(const float* y, const float* var, int K, int O,
+                                    const DenseModelPtrs& M) {
+  return LinearObs<D>{y, var, K, O, M};
+}
+
+struct PinholeObs {
+  const float* y;           // [T][Kd][O], O = 2 * n_cams: (u, v) per camera
+  ObsNoise R;               // [T][Kd][O] or constant [Kd][O]
+  int Kd, O, T;             // chain k reads the data of keypoint k % Kd
+  const double* cams;       // [n_cams][kCamDoubles]
+  double* xlin;             // [K][T][3] linearisation points (predicted means of the last sweep)
+  template <typename Fn>
+  EKS_HD void visit(int t, int k, const double* xl, Fn&& fn) const {
+    const int kd = k % Kd;
+    const size_t row = ((size_t)t * Kd + kd) * O;
+    double X[3];
+    const double* src = xl ? xl : xlin + ((size_t)k * T + t) * 3;
+    X[0] = src[0]; X[1] = src[1]; X[2] = src[2];
+    for (int c = 0; 2 * c < O; ++c) {
+      double uv[2], J[2][3];
+      pinhole_project_jac(cams + (size_t)c * kCamDoubles, X, uv, J);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        Vec<double, 3> h;
+        h.a[0] = J[a][0]; h.a[1] = J[a][1]; h.a[2] = J[a][2];
+        const double lin = h.a[0] * X[0] + h.a[1] * X[1] + h.a[2] * X[2];
+        fn(h, (double)y[row + 2 * c + a] - uv[a] + lin, R.at(row, kd, O, 2 * c + a));
+      }
+    }
+  }
+};
+
+// Measurement update of the belief N(m, P) with frame t of keypoint k, one scalar observation at
+// a time (R_t diagonal).  Returns the frame's log-likelihood when LL is set.
+template <int D, bool LL = false, typename Obs>
+EKS_HD double belief_update_obs(const Obs& obs, int k, int t, const double* xl, Vec<double, D>& m,
                                 Mat<double, D>& P) {
-  const size_t row = ((size_t)t * K + k) * O;
-  for (int o = 0; o < O; ++o) {
-    const Vec<double, D> h = load_obs_row<double, D>(M, k, O, o);
-    const float v = var[row + o];
-    const double r = v > kVarFloor ? (double)v : (double)kVarFloor;
+  double ll = 0.0;
+  obs.visit(t, k, xl, [&](const Vec<double, D>& h, double yv, double r) {
     const Vec<double, D> u = mat_vec(P, h);
-    const double g = 1.0 / (r + dot(h, u));
-    const double gd = g * ((double)y[row + o] - dot(h, m));
+    const double sigma = r + dot(h, u);
+    const double g = 1.0 / sigma;
+    const double d = yv - dot(h, m), gd = g * d;
+    if (LL) ll -= 0.5 * (kLog2Pi + log(sigma) + d * gd);
 #pragma unroll
     for (int a = 0; a < D; ++a) {
       m.a[a] += u.a[a] * gd;
 #pragma unroll
       for (int b = 0; b < D; ++b) P.a[a][b] -= u.a[a] * u.a[b] * g;
     }
-  }
+  });
+  return ll;
+}
+
+template <int D>
+EKS_HD void belief_update_frame(const float* __restrict__ y, const float* __restrict__ var, int K,
+                                int O, int k, int t, const DenseModelPtrs& M, Vec<double, D>& m,
+                                Mat<double, D>& P) {
+  belief_update_obs<D>(LinearObs<D>{y, var, K, O, M}, k, t, nullptr, m, P);
 }
 
 // Smoother element of frames [t0, t0+len) of keypoint k: each frame enters as the pair (predict
@@ -172,36 +237,47 @@ EKS_HD void belief_update_frame(const float* __restrict__ y, const float* __rest
 // the process noise: (eta, J) stay moderate even when an ensemble variance sits at the 1e-12
 // clip.  (An element that opens with such an observation carries J ~ 1e12 and the boundary
 // algebra cancels catastrophically - measured: smoothed means off by 1e7.)
+template <int D, typename Obs>
+EKS_HD DElem<double, D> dense_smooth_element_obs(const Obs& obs, int k, int t0, int len,
+                                                 const Mat<double, D>& F, const Mat<double, D>& sQ,
+                                                 bool f_identity) {
+  DElem<double, D> e = delem_identity<double, D>();
+  for (int t = t0 > 0 ? t0 : 1; t < t0 + len; ++t) {
+    delem_predict(e, F, sQ, f_identity);
+    obs.visit(t, k, nullptr, [&](const Vec<double, D>& h, double yv, double r) {
+      delem_observe(e, h, yv, r, false);
+    });
+  }
+  return e;
+}
+
 template <int D>
 EKS_HD DElem<double, D> dense_smooth_element(const float* __restrict__ y, const float* __restrict__ var,
                                              int K, int O, int k, int t0, int len,
                                              const DenseModelPtrs& M, const Mat<double, D>& F,
                                              const Mat<double, D>& sQ, bool f_identity) {
-  DElem<double, D> e = delem_identity<double, D>();
-  for (int t = t0 > 0 ? t0 : 1; t < t0 + len; ++t) {
-    delem_predict(e, F, sQ, f_identity);
-    const size_t row = ((size_t)t * K + k) * O;
-    for (int o = 0; o < O; ++o) {
-      const float v = var[row + o];
-      const double r = v > kVarFloor ? (double)v : (double)kVarFloor;
-      delem_observe(e, load_obs_row<double, D>(M, k, O, o), (double)y[row + o], r, false);
-    }
-  }
-  return e;
+  return dense_smooth_element_obs<D>(LinearObs<D>{y, var, K, O, M}, k, t0, len, F, sQ, f_identity);
 }
 
 // K3: exact replay of frames [t0, t0+len).  (m, P): the filtered belief of frame t0-1 (the prior
 // itself when t0 == 0); (eta_s, J_s): what all later frames say about the state at the chunk's
 // last frame.  `filt` is this lane's scratch: len records of D + D*D doubles (filtered mean and
 // covariance), written forwards and read backwards.
-template <int D>
-EKS_HD void dense_replay_chunk(const float* __restrict__ y, const float* __restrict__ var, int K,
-                               int O, int k, int t0, int len, const DenseModelPtrs& M,
-                               const Mat<double, D>& F, const Mat<double, D>& sQ, bool f_identity,
-                               Vec<double, D> m, Mat<double, D> P, const Vec<double, D>& eta_s,
-                               const Mat<double, D>& J_s, double* __restrict__ filt,
-                               float* __restrict__ ms, float* __restrict__ Vs, bool vs_diag) {
+//
+// EKF (extended filter, PinholeObs): every frame is linearised at the lane's own predicted mean
+// (what the reference's dynamax filter does), the predicted mean replaces the
+// stored linearisation point and the largest change is returned through `resid`; `ll` receives
+// the chunk's log-likelihood.  ms == nullptr: filter only (no records, no backward pass).
+template <int D, bool EKF, typename Obs>
+EKS_HD void dense_replay_chunk_obs(const Obs& obs, int K, int k, int t0, int len,
+                                   const Mat<double, D>& F, const Mat<double, D>& sQ,
+                                   bool f_identity, Vec<double, D> m, Mat<double, D> P,
+                                   const Vec<double, D>& eta_s, const Mat<double, D>& J_s,
+                                   double* __restrict__ filt, float* __restrict__ ms,
+                                   float* __restrict__ Vs, bool vs_diag, double* __restrict__ xlin,
+                                   double* ll_out, double* resid_out) {
   constexpr int REC = D + D * D;
+  double ll = 0.0, resid = 0.0;
   for (int i = 0; i < len; ++i) {
     const int t = t0 + i;
     if (t > 0) {
@@ -211,7 +287,22 @@ EKS_HD void dense_replay_chunk(const float* __restrict__ y, const float* __restr
       }
       P = mat_add(P, sQ);
     }
-    belief_update_frame<D>(y, var, K, O, k, t, M, m, P);
+    if constexpr (EKF) {
+      double xl[D];
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        xl[a] = m.a[a];
+        const double old = xlin[a + (size_t)i * D];
+        const double scale = fabs(old) > 1.0 ? fabs(old) : 1.0;
+        const double ch = fabs(xl[a] - old) / scale;
+        resid = (ch > resid || ch != ch) ? ch : resid;     // a NaN sticks
+        xlin[a + (size_t)i * D] = xl[a];
+      }
+      ll += belief_update_obs<D, true>(obs, k, t, xl, m, P);
+    } else {
+      belief_update_obs<D>(obs, k, t, nullptr, m, P);
+    }
+    if (ms == nullptr) continue;
     double* rec = filt + (size_t)i * REC;
 #pragma unroll
     for (int a = 0; a < D; ++a) {
@@ -220,6 +311,11 @@ EKS_HD void dense_replay_chunk(const float* __restrict__ y, const float* __restr
       for (int b = 0; b < D; ++b) rec[D + a * D + b] = P.a[a][b];
     }
   }
+  if constexpr (EKF) {
+    *ll_out = ll;
+    *resid_out = resid;
+  }
+  if (ms == nullptr) return;
   auto emit = [&](int i, const Vec<double, D>& mo, const Mat<double, D>& Po) {
     const size_t ko = (size_t)(t0 + i) * K + k;
 #pragma unroll
@@ -265,6 +361,18 @@ EKS_HD void dense_replay_chunk(const float* __restrict__ y, const float* __restr
     P_s = mat_symmetrize(mat_add(Pf, mat_mul(mat_mul_tn(Z, dP), Z)));
     emit(i, m_s, P_s);
   }
+}
+
+template <int D>
+EKS_HD void dense_replay_chunk(const float* __restrict__ y, const float* __restrict__ var, int K,
+                               int O, int k, int t0, int len, const DenseModelPtrs& M,
+                               const Mat<double, D>& F, const Mat<double, D>& sQ, bool f_identity,
+                               Vec<double, D> m, Mat<double, D> P, const Vec<double, D>& eta_s,
+                               const Mat<double, D>& J_s, double* __restrict__ filt,
+                               float* __restrict__ ms, float* __restrict__ Vs, bool vs_diag) {
+  dense_replay_chunk_obs<D, false>(LinearObs<D>{y, var, K, O, M}, K, k, t0, len, F, sQ, f_identity,
+                                   m, P, eta_s, J_s, filt, ms, Vs, vs_diag, nullptr, nullptr,
+                                   nullptr);
 }
 
 // ---- element records in the workspace: doubles, value parts then (dual only) derivative parts

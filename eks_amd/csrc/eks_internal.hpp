@@ -48,6 +48,12 @@ int dense_nll(const eks_dims_t& d, const float* y, const double* rconst, const D
               const double* s_cand, int n_cand, int per_keypoint, double* nll, double* dnll,
               void* ws, size_t ws_bytes, hipStream_t st);
 
+size_t ekf_smooth_workspace_bytes(int T, int K, int smooth);
+int ekf_smooth(const eks_dims_t& d, int n_data_keypoints, const float* y, const float* var,
+               const double* rconst, const DenseModel& M, const double* cams, int n_cams,
+               double* xlin, int max_sweeps, double tol, float* ms, float* Vs, double* nll,
+               double* info, void* ws, size_t ws_bytes, hipStream_t st);
+
 size_t ar1_nll_workspace_bytes(int T, int K, int D, int n_tan);
 int ar1_nll(const eks_dims_t& d, const float* y, const float* var, const double* m0,
             const double* S0, const double* C, const double* a, const double* q, const double* da,

@@ -274,3 +274,48 @@ def pupil_adam_run(loss: Ar1Loss, latent_var, state, n_active, lr, tol, safety_c
                                      _ptr(loss.da), _ptr(loss.dq), _ptr(loss.nll), _ptr(loss.dnll),
                                      _ptr(n_active), _ptr(loss.ws), loss.ws.numel(), _stream())
     _lib.check(rc, 'eks_pupil_adam_run')
+
+
+def ekf_smooth(y, var, rconst, m0, S0, A, Q, s, cams, xlin, max_sweeps: int = 16, tol: float = 1e-9,
+               want_smoother: bool = True, vs_diag: bool = False):
+    """eks_ekf_smooth: extended Kalman filter (+ RTS smoother) with calibrated pinhole cameras.
+
+    y (T, Kd, O) float32; exactly one of var (T, Kd, O) float32 / rconst (Kd, O) float64; m0 (K, 3),
+    S0, A, Q (K, 3, 3), s (K,) float64 per CHAIN (K a multiple of Kd; chain k reads keypoint
+    k % Kd); cams (V, 32) float64 (see include/eks_hip.h), O = 2 V; xlin (K, T, 3) float64 in/out.
+    Returns (ms, Vs, nll, info): ms / Vs are None when want_smoother is False; info is a device
+    tensor (sweeps executed, last relative change of a linearisation point)."""
+    lib = _lib.load()
+    T, Kd, O = y.shape
+    K = m0.shape[0]
+    V = cams.shape[0]
+    y = _chk(y, torch.float32, 'y')
+    if (var is None) == (rconst is None):
+        raise ValueError('pass exactly one of var and rconst')
+    if var is not None:
+        var = _chk(var, torch.float32, 'var', (T, Kd, O))
+    else:
+        rconst = _chk(rconst, torch.float64, 'rconst', (Kd, O))
+    m0 = _chk(m0, torch.float64, 'm0', (K, 3))
+    S0 = _chk(S0, torch.float64, 'S0', (K, 3, 3))
+    A = _chk(A, torch.float64, 'A', (K, 3, 3))
+    Q = _chk(Q, torch.float64, 'Q', (K, 3, 3))
+    s = _chk(s, torch.float64, 's', (K,))
+    cams = _chk(cams, torch.float64, 'cams', (V, 32))
+    if not xlin.is_contiguous():
+        raise ValueError('xlin must be contiguous (it is updated in place)')
+    _chk(xlin, torch.float64, 'xlin', (K, T, 3))
+    d = _dims(K, T, 3, O, FLAG_VS_DIAG if vs_diag else 0)
+    ms = Vs = None
+    if want_smoother:
+        ms = torch.empty((T, K, 3), dtype=torch.float32, device=y.device)
+        Vs = torch.empty((T, K, 3) if vs_diag else (T, K, 3, 3), dtype=torch.float32, device=y.device)
+    nll_k = torch.empty((K,), dtype=torch.float64, device=y.device)
+    info = torch.zeros((2,), dtype=torch.float64, device=y.device)
+    ws = _workspace(lib.eks_ekf_smooth_workspace_bytes(ctypes.byref(d), int(want_smoother)), y.device)
+    rc = lib.eks_ekf_smooth(ctypes.byref(d), int(Kd), _ptr(y), _ptr(var), _ptr(rconst), _ptr(m0),
+                            _ptr(S0), _ptr(A), _ptr(Q), _ptr(s), _ptr(cams), int(V), _ptr(xlin),
+                            int(max_sweeps), float(tol), _ptr(ms), _ptr(Vs), _ptr(nll_k), _ptr(info),
+                            _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, 'eks_ekf_smooth')
+    return ms, Vs, nll_k, info

@@ -109,3 +109,61 @@ def pupil_observations(T: int, seed: int, noise: float = 0.6):
     ys = (lat @ C.T + rng.normal(size=(T, 8)) * np.sqrt(ev)).astype(np.float32).astype(np.float64)
     lv = lat.var(axis=0)
     return ys, ev, np.array([lat[:, 0].mean(), 0.0, 0.0]), np.diag(lv), lv
+
+
+def ring_cameras(V: int, seed: int = 0) -> list[dict]:
+    """V calibrated cameras on a ring of radius ~1 m looking at the origin, with mild radial /
+    tangential / thin-prism distortion and a little skew: dicts(rot (3,3), tvec, K, dist)."""
+    rng = np.random.default_rng(1000 + seed)
+    cams = []
+    for v in range(V):
+        ang = 2.0 * np.pi * v / V + 0.3
+        pos = np.array([1000.0 * np.cos(ang), 1000.0 * np.sin(ang), 300.0 + 60.0 * v])
+        z = -pos / np.linalg.norm(pos)
+        x = np.cross([0.0, 0.0, 1.0], z)
+        x /= np.linalg.norm(x)
+        R = np.stack([x, np.cross(z, x), z])
+        Kmat = np.array([[900.0 + 25.0 * v, 0.4 * v, 320.0], [0.0, 880.0 + 10.0 * v, 240.0],
+                         [0.0, 0.0, 1.0]])
+        dist = np.array([-0.15, 0.06, 1e-3, -6e-4, 0.012, 0.0, 0.0, 0.0, 3e-4, 0.0, -2e-4, 0.0])
+        dist[:2] += rng.normal(0.0, 0.01, 2)
+        cams.append(dict(rot=R, tvec=-R @ pos, K=Kmat, dist=dist))
+    return cams
+
+
+def calibrated_multicam(T: int, K: int, V: int = 3, M: int = 5, seed: int = 0) -> dict:
+    """Calibrated multi-camera problem: K keypoints follow 3-D
+    random walks inside a ~40 cm volume, seen by `ring_cameras(V)`; ensemble noise as in
+    `singlecam_markers`.  Returns the markers (M, V, T, K, 3) float32 AND a ready filter problem:
+    y_tko / var_tko (T, K, 2V) (ensemble median / variance), m0s, S0s, As, Qs, a smoothing
+    parameter per keypoint, the cameras (dicts) and `cams_packed` (V, 32)."""
+    from .calibration import pack_camera, project
+    rng = np.random.default_rng(seed)
+    cams = ring_cameras(V, seed)
+    packed = np.stack([pack_camera(c['rot'], c['tvec'], c['K'], c['dist']) for c in cams])
+    q = np.exp(rng.uniform(np.log(0.5), np.log(8.0), size=(K, 1)))
+    steps = rng.standard_normal((T, K, 3)) * np.sqrt(q)[None]
+    steps[0] = 0.0
+    lat = rng.uniform(-150.0, 150.0, size=(1, K, 3)) + np.cumsum(steps, axis=0)
+    lat = np.clip(lat, -400.0, 400.0)                                     # stay in front of the cameras
+    sig2 = 0.25 * rng.gamma(2.0, 1.0, size=(V, T, K))
+    occ = rng.random((V, T, K)) < 0.02
+    sig2 = np.where(occ, sig2 * 100.0, sig2)
+    markers = np.empty((M, V, T, K, 3), dtype=np.float32)
+    for v in range(V):
+        uv = project(packed[v], lat)                                      # (T,K,2)
+        for m in range(M):
+            markers[m, v, :, :, 0:2] = uv + rng.standard_normal((T, K, 2)) * np.sqrt(sig2[v])[..., None]
+            markers[m, v, :, :, 2] = np.where(occ[v], rng.uniform(0.05, 0.5, size=(T, K)),
+                                              rng.beta(50.0, 1.0, size=(T, K)))
+    xy = markers[..., :2].astype(np.float64)
+    med = np.median(xy, axis=0)                                           # (V,T,K,2)
+    var = np.var(xy, axis=0) + 1e-3
+    y_tko = np.transpose(med, (1, 2, 0, 3)).reshape(T, K, 2 * V)
+    var_tko = np.transpose(var, (1, 2, 0, 3)).reshape(T, K, 2 * V)
+    m0s = lat[:10].mean(axis=0) + rng.normal(0.0, 3.0, size=(K, 3))
+    S0s = np.stack([np.diag(lat[:, k].var(axis=0) + 1e-4) for k in range(K)])
+    Qs = np.stack([np.diag(np.full(3, 1.0) * (0.5 + rng.random(3))) for _ in range(K)])
+    return dict(markers=markers, latent=lat, cams=cams, cams_packed=packed, y_tko=y_tko,
+                var_tko=var_tko, m0s=m0s, S0s=S0s, As=np.tile(np.eye(3), (K, 1, 1)), Qs=Qs,
+                s=np.exp(rng.uniform(np.log(0.05), np.log(20.0), size=K)))

@@ -154,6 +154,35 @@ int eks_pupil_adam_run(const eks_dims_t* dims, const float* y, const float* var,
                        int32_t* n_active, void* workspace, size_t workspace_bytes,
                        eks_stream_t stream);
 
+/* ---- extended Kalman filter / smoother with calibrated pinhole cameras (SURVEY.md section 8(f)
+ * rank 3): run_kalman_smoother(h_fn = multi-camera projection), eks/core.py:188-190, :274-295, as
+ * called from eks/multicam_smoother.py:369-407; the projection is make_jax_projection_fn (:814-868)
+ * with its analytic Jacobian in place of jax.jacfwd.  State dim 3, obs dim 2 * n_cams (u, v per
+ * camera).
+ *   dims.n_keypoints = number of CHAINS K; chain k reads the observations of keypoint
+ *   k % n_data_keypoints (several chains per keypoint = several values of s over the same data,
+ *   which is how the optimiser takes central differences in log s).
+ *   y [T][Kd][O] float32; exactly one of var [T][Kd][O] float32 (time-varying R_t = diag(max(var,
+ *   1e-12)), final pass) and rconst [Kd][O] float64 (constant R, the loss of :640-650) is non-NULL.
+ *   m0 [K][3], S0, A, Q [K][3][3], s [K] per chain.  cams [n_cams][32] float64: R row-major (9),
+ *   t (3), fx, fy, cx, cy, skew, then the 14 OpenCV-ordered distortion coefficients k1 k2 p1 p2 k3
+ *   k4 k5 k6 s1 s2 s3 s4 tx ty (radial POLYNOMIAL in r^2 as in the reference; tx, ty ignored), pad.
+ *   xlin [K][T][3] float64, in/out: the linearisation points (predicted means).  On entry any
+ *   finite guess (the prior mean, a triangulation, the previous call's result); on return the
+ *   extended filter's predicted means.  The filter is solved as a fixed point over xlin by at
+ *   most max_sweeps (<= 64) gated scan sweeps, stopping once no point moves by more than tol
+ *   (relative to max(1, |x|)); info[0] = sweeps executed, info[1] = last such change (the result
+ *   equals the sequential extended filter's when info[1] <= tol).
+ *   ms [T][K][3], Vs [T][K][3][3] (or [T][K][3] with EKS_FLAG_VS_DIAG) float32 smoothed outputs;
+ *   ms == NULL: filter only.  nll [K] = -marginal log-likelihood (may be NULL). -------------- */
+size_t eks_ekf_smooth_workspace_bytes(const eks_dims_t* dims, int32_t want_smoother);
+int eks_ekf_smooth(const eks_dims_t* dims, int32_t n_data_keypoints, const float* y,
+                   const float* var, const double* rconst, const double* m0, const double* S0,
+                   const double* A, const double* Q, const double* s, const double* cams,
+                   int32_t n_cams, double* xlin, int32_t max_sweeps, double tol, float* ms,
+                   float* Vs, double* nll, double* info, void* workspace, size_t workspace_bytes,
+                   eks_stream_t stream);
+
 /* ---- ensemble statistics, eks/core.py:25-101: markers float32 [M][V][T][K][3] (x,y,likelihood)
  * -> stats float32 [V][T][K][5] (x, y, var_x, var_y, likelihood).  avg_mode 0 median / 1 mean,
  * var_mode 0 confidence_weighted_var / 1 var. ------------------------------------------------ */

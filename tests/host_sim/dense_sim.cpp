@@ -176,3 +176,74 @@ extern "C" int sim_dense_nll(int T, int K, int D, int O, int B, const float* y, 
   }
   return 0;
 }
+
+// ---- extended filter with pinhole cameras (eks_ekf_smooth) from plain loops ------------------
+extern "C" void sim_pinhole(const double* cam, const double* X, double* uv, double* J) {
+  double Jm[2][3];
+  pinhole_project_jac(cam, X, uv, Jm);
+  for (int a = 0; a < 2; ++a)
+    for (int i = 0; i < 3; ++i) J[a * 3 + i] = Jm[a][i];
+}
+
+// One chain per data keypoint.  Filter sweeps (scan over elements linearised at xlin, then the
+// per-chunk extended replay that rewrites xlin) until no linearisation point moves by more than
+// tol, then one sweep with the backward pass.  Returns the number of filter sweeps.
+extern "C" int sim_ekf_smooth(int T, int K, int n_cams, int B, const float* y, const float* var,
+                              const double* rconst, const double* m0, const double* S0,
+                              const double* A, const double* Q, const double* s, const double* cams,
+                              double* xlin, int max_sweeps, double tol, float* ms, float* Vs,
+                              double* nll, double* last_resid) {
+  constexpr int D = 3, REC = D + D * D;
+  const int O = 2 * n_cams, nc = (T + B - 1) / B;
+  const DenseModelPtrs M{m0, S0, A, nullptr, Q};
+  const PinholeObs obs{y, ObsNoise{var, rconst}, K, O, T, cams, xlin};
+  std::vector<double> filt((size_t)B * REC);
+  int sweeps = 0;
+  double worst = 0.0;
+  for (int pass = 0; pass <= max_sweeps; ++pass) {
+    const bool final_pass = pass == max_sweeps || (pass > 0 && worst <= tol);
+    worst = 0.0;
+    for (int k = 0; k < K; ++k) {
+      Mat<double, D> F, sQ;
+      bool fid;
+      load_dynamics<double, D>(M, k, s[k], F, sQ, fid);
+      std::vector<DElem<double, D>> el(nc);
+      for (int j = 0; j < nc; ++j)
+        el[j] = dense_smooth_element_obs<D>(obs, k, j * B, std::min(B, T - j * B), F, sQ, fid);
+      std::vector<Vec<double, D>> pm(nc), se(nc);
+      std::vector<Mat<double, D>> pP(nc), sJ(nc);
+      Vec<double, D> m;
+      Mat<double, D> P;
+      load_prior<D>(M, k, m, P);
+      double xl[D] = {m.a[0], m.a[1], m.a[2]};
+      belief_update_obs<D>(obs, k, 0, xl, m, P);
+      for (int j = 0; j < nc; ++j) {
+        pm[j] = m;
+        pP[j] = P;
+        delem_apply(el[j], m, P);
+      }
+      Vec<double, D> eta = vec_zero<double, D>();
+      Mat<double, D> J = mat_zero<double, D>();
+      for (int j = nc - 1; j >= 0; --j) {
+        se[j] = eta;
+        sJ[j] = J;
+        delem_back(el[j], eta, J);
+      }
+      double ll_k = 0.0;
+      for (int j = 0; j < nc; ++j) {
+        if (j == 0) load_prior<D>(M, k, pm[0], pP[0]);
+        double ll = 0.0, ch = 0.0;
+        dense_replay_chunk_obs<D, true>(obs, K, k, j * B, std::min(B, T - j * B), F, sQ, fid, pm[j],
+                                        pP[j], se[j], sJ[j], filt.data(), final_pass ? ms : nullptr,
+                                        Vs, false, xlin + ((size_t)k * T + (size_t)j * B) * D, &ll, &ch);
+        ll_k += ll;
+        worst = std::max(worst, ch);
+      }
+      nll[k] = -ll_k;
+    }
+    if (final_pass) break;
+    ++sweeps;
+  }
+  *last_resid = worst;
+  return sweeps;
+}
