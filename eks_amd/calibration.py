@@ -226,5 +226,47 @@ class CameraGroup:
     def __init__(self, cameras: Sequence[Camera]):
         self.cameras = list(cameras)
 
+    @classmethod
+    def load(cls, path: str) -> 'CameraGroup':
+        """Read an aniposelib calibration TOML: one `[cam_N]` table per camera with `name`,
+        `matrix` (3x3), `distortions`, `rotation` (rotation vector), `translation`; other tables
+        (`[metadata]`) are ignored.  (aniposelib's CameraGroup.load, used at reference
+        eks/multicam_smoother.py:232; neither aniposelib nor a TOML module is in this image, so
+        the flat key = value subset those files use is parsed here.)"""
+        tables = _read_flat_toml(path)
+        cams = []
+        for key in sorted((k for k in tables if k.startswith('cam_')),
+                          key=lambda k: int(k.split('_')[1])):
+            t = tables[key]
+            cams.append(Camera(np.asarray(t['rotation'], float), t['translation'], t['matrix'],
+                               t.get('distortions', ()), name=str(t.get('name', key))))
+        if not cams:
+            raise ValueError(f'no [cam_N] tables in {path}')
+        return cls(cams)
+
     def triangulate(self, xy_views, **_):
         return triangulate(cameras_of(self), xy_views)
+
+
+def _read_flat_toml(path: str) -> dict:
+    import ast
+    tables: dict = {}
+    cur = tables.setdefault('', {})
+    pending = ''
+    with open(path) as f:
+        for raw in f:
+            line = raw.split('#', 1)[0].strip() if '"' not in raw else raw.strip()
+            if not line:
+                continue
+            if not pending and line.startswith('[') and line.endswith(']') and '=' not in line:
+                cur = tables.setdefault(line[1:-1].strip(), {})
+                continue
+            pending = f'{pending} {line}' if pending else line
+            if pending.count('[') != pending.count(']'):
+                continue                                  # array continues on the next line
+            key, _, val = pending.partition('=')
+            val = val.strip()
+            val = {'true': 'True', 'false': 'False'}.get(val, val)
+            cur[key.strip()] = ast.literal_eval(val)
+            pending = ''
+    return tables

@@ -192,6 +192,138 @@ def optimize_smooth_param(ys, m0s, S0s, As, Cs, Qs, Rs, blocks, s_finals, s_fram
     _log_opt(blocks, s_finals, info)
 
 
+def _run_kalman_smoother_pinhole(ys, m0s, S0s, As, Qs, ensemble_vars, h_fn, s_frames, smooth_param,
+                                 blocks, lr, s_bounds_log, tol, safety_cap, s_mode, n_grid, vs_diag,
+                                 return_device, x_init, fd_step: float = 1e-3,
+                                 lin_tol: float = 1e-10, max_sweeps: int = 16):
+    """run_kalman_smoother with the calibrated multi-camera projection (reference eks/core.py:
+    159-302 with h_fn; optimiser :562-699 / :306-559).  Extended filter = eks_ekf_smooth.  The
+    reference differentiates the loss through the filter (jax.value_and_grad); here d NLL / d log s
+    is a central difference over three chains per keypoint (u, u + h, u - h) that share the data,
+    so one launch evaluates loss and gradient; each chain keeps its own linearisation points
+    between iterations (warm start: 1-2 sweeps per iteration)."""
+    from .calibration import PinholeProjection
+    if not isinstance(h_fn, PinholeProjection):
+        raise NotImplementedError(
+            'h_fn must be an eks_amd.calibration.PinholeProjection (make_projection_from_camgroup): '
+            'the HIP kernels cannot call a Python emission function')
+    torch = _torch()
+    dev = hip_ops.require_gpu()
+    f64 = lambda a: torch.as_tensor(np.ascontiguousarray(_to_numpy(a, np.float64)), device=dev)
+    m0, S0, A, Q = f64(m0s), f64(S0s), f64(As), f64(Qs)
+    K = m0.shape[0]
+    if m0.shape[1] != 3:
+        raise ValueError('the calibrated path has a 3-D latent state')
+    cams = torch.as_tensor(h_fn.cams, device=dev)
+    if hasattr(ys, 'detach'):
+        y = ys.to(dev, dtype=torch.float32).transpose(0, 1).contiguous()
+        var = ensemble_vars.to(dev, dtype=torch.float32).contiguous()
+    else:
+        y = torch.as_tensor(np.ascontiguousarray(_to_numpy(ys)), device=dev).to(torch.float32)
+        y = y.transpose(0, 1).contiguous()
+        var = torch.as_tensor(np.ascontiguousarray(_to_numpy(ensemble_vars)), device=dev)
+        var = var.to(torch.float32).contiguous()
+    T, O = y.shape[0], y.shape[2]
+    if tuple(y.shape) != (T, K, O) or tuple(var.shape) != (T, K, O) or O != 2 * h_fn.n_cameras:
+        raise ValueError(f'ys must be (K,T,2V) and ensemble_vars (T,K,2V); got {tuple(y.shape)} '
+                         f'(frame-major) and {tuple(var.shape)} for {h_fn.n_cameras} cameras')
+    if not blocks:
+        blocks = [[k] for k in range(K)]
+    if x_init is None:
+        xlin = m0[:, None, :].expand(K, T, 3).contiguous()
+    else:
+        xlin = f64(x_init).reshape(K, T, 3).contiguous()
+    worst = torch.zeros((), dtype=torch.float64, device=dev)
+
+    def crop(a):
+        if not s_frames or (len(s_frames) == 1 and s_frames[0] == (None, None)):
+            return a, None
+        if not isinstance(s_frames, list):
+            raise TypeError('s_frames must be a list of (start, end) tuples or None.')
+        idx = torch.cat([torch.arange(a0, b0, device=dev) for a0, b0 in frame_spans(T, s_frames)])
+        return a.index_select(0, idx).contiguous(), idx
+
+    s_finals = np.empty(K, dtype=float)
+    info = {}
+    if smooth_param is not None:
+        s_finals[:] = float(smooth_param) if isinstance(smooth_param, (int, float)) \
+            else np.asarray(smooth_param, dtype=float)
+        s_dev = torch.as_tensor(s_finals, device=dev)
+    else:
+        y_c, idx = crop(y)
+        var_c = var if idx is None else var.index_select(0, idx).contiguous()
+        x_c = xlin if idx is None else xlin.index_select(1, idx).contiguous()
+        rconst = hip_ops.const_r(var_c, 1e-4)
+        lo, hi = float(s_bounds_log[0]), float(s_bounds_log[1])
+        offs, members, of_kp = _block_csr(blocks, K)
+        nb = len(blocks)
+        if s_mode == 'grid':
+            cand = torch.exp(torch.linspace(lo, hi, n_grid, dtype=torch.float64, device=dev))
+            rep = lambda a: a.repeat((n_grid,) + (1,) * (a.dim() - 1))
+            xg = x_c.repeat(n_grid, 1, 1)
+            _, _, nll, inf = hip_ops.ekf_smooth(y_c, None, rconst, rep(m0), rep(S0), rep(A), rep(Q),
+                                                cand.repeat_interleave(K), cams, xg, max_sweeps,
+                                                lin_tol, want_smoother=False)
+            worst = torch.maximum(worst, inf[1])
+            nll = nll.view(n_grid, K).transpose(0, 1).contiguous()
+            blk = torch.zeros((nb, n_grid), dtype=torch.float64, device=dev)
+            blk.index_add_(0, torch.as_tensor(of_kp, device=dev), nll)
+            s_blk, amin = hip_ops.argmin_s(blk, cand)
+            s_dev = s_blk[torch.as_tensor(of_kp, device=dev)].contiguous()
+            info = dict(mode='grid', nll=nll, argmin=amin, candidates=cand)
+        else:
+            ev_host = _to_numpy(ensemble_vars)[:2000] if not hasattr(ensemble_vars, 'detach') \
+                else ensemble_vars[:2000].detach().cpu().numpy()
+            guesses = np.full(K, 2.0)
+            for k in range(K):
+                g = float(compute_initial_guesses(ev_host[:, k, :]) or 2.0)
+                guesses[k] = g if (np.isfinite(g) and g > 0.0) else 2.0
+            u0 = np.array([np.float32(np.log(np.clip(np.mean([guesses[k] for k in b]), 1e-6, 1e3)))
+                           for b in blocks], dtype=np.float64)
+            state = np.zeros((nb, 6))
+            state[:, 0] = u0
+            state[:, 3] = np.inf
+            state = torch.as_tensor(state, device=dev)
+            offs_d, mem_d = torch.as_tensor(offs, device=dev), torch.as_tensor(members, device=dev)
+            s_kp = torch.as_tensor(np.exp(np.clip(u0, lo, hi))[of_kp], device=dev)
+            n_active = torch.zeros(1, dtype=torch.int32, device=dev)
+            rep3 = lambda a: a.repeat((3,) + (1,) * (a.dim() - 1))
+            m3, S3, A3, Q3 = rep3(m0), rep3(S0), rep3(A), rep3(Q)
+            x3 = x_c.repeat(3, 1, 1)
+            step = torch.tensor([1.0, np.exp(fd_step), np.exp(-fd_step)], dtype=torch.float64,
+                                device=dev)
+            iters, cap = 0, int(safety_cap)
+            while iters < cap:
+                for _ in range(min(8, cap - iters)):
+                    s3 = (step[:, None] * s_kp[None, :]).reshape(-1).contiguous()
+                    _, _, nll3, inf = hip_ops.ekf_smooth(y_c, None, rconst, m3, S3, A3, Q3, s3, cams, x3,
+                                                         max_sweeps, lin_tol, want_smoother=False)
+                    worst = torch.maximum(worst, inf[1])
+                    nll3 = nll3.view(3, K)
+                    dnll = ((nll3[1] - nll3[2]) / (2.0 * fd_step)).contiguous()
+                    hip_ops.adam_step(offs_d, mem_d, nll3[0].contiguous(), dnll, state, s_kp, n_active,
+                                      lr, lo, hi, tol, cap)
+                    iters += 1
+                if int(n_active.item()) == 0:
+                    break
+            s_dev = s_kp
+            info = dict(mode='adam', state=state, launches=iters)
+            if idx is None:
+                xlin = x3[:K].contiguous()          # warm start of the final pass
+        s_finals[:] = s_dev.cpu().numpy()
+        _log_opt(blocks, s_finals, info)
+    ms, Vs, _, inf = hip_ops.ekf_smooth(y, var, None, m0, S0, A, Q, s_dev.contiguous(), cams, xlin,
+                                        max_sweeps, lin_tol, want_smoother=True, vs_diag=vs_diag)
+    worst = float(torch.maximum(worst, inf[1]).item())
+    if not worst <= lin_tol:
+        logger.warning(f'extended filter: linearisation points still moving by {worst:.2e} after '
+                       f'{max_sweeps} sweeps (tolerance {lin_tol:.0e}); the result may differ from '
+                       'the sequential extended Kalman filter')
+    if return_device:
+        return s_finals, ms.transpose(0, 1), Vs.transpose(0, 1)
+    return s_finals, np.swapaxes(ms.cpu().numpy(), 0, 1), np.swapaxes(Vs.cpu().numpy(), 0, 1)
+
+
 def _log_opt(blocks, s_finals, info) -> None:
     if not logger.isEnabledFor(logging.DEBUG) or info.get('mode') != 'adam':
         return
@@ -206,7 +338,7 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
                         blocks: list[list[int]] | None = None, lr: float = 0.25,
                         s_bounds_log: tuple = (-8.0, 8.0), tol: float = 1e-2, safety_cap: int = 300,
                         h_fn: Callable | None = None, *, s_mode: str = 'adam', n_grid: int = 64,
-                        vs_diag: bool = False, return_device: bool = False):
+                        vs_diag: bool = False, return_device: bool = False, x_init=None):
     """Choose (or optimise) the process-noise scale s per keypoint, then run the Kalman filter +
     RTS smoother.  Drop-in for the reference's eks/core.py:159-302.
 
@@ -218,12 +350,20 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
     Extensions (keyword-only, not in the reference): s_mode 'adam' (reference behaviour) or 'grid'
     (n_grid candidates exp(linspace(*s_bounds_log)), BASELINE.json config 3); vs_diag returns only
     the diagonal of Vs as (K,T,D); return_device keeps ms / Vs as device tensors.
+
+    h_fn: the nonlinear observation model y_t = h_fn(x_t) + v_t (reference :188-190).  The
+    accelerated path takes a `calibration.PinholeProjection` (what
+    `make_projection_from_camgroup` returns - the only h_fn the reference itself constructs);
+    the kernels cannot call back into Python, so any other callable raises NotImplementedError.
+    `Cs` is ignored then, D must be 3 and O = 2 * n_cameras.  x_init (K,T,3), optional: a first
+    guess of the states (e.g. the triangulated points) that the linearisation starts from.
     """
-    if h_fn is not None:
-        raise NotImplementedError('nonlinear emission functions (calibrated multicam, reference '
-                                  'eks/multicam_smoother.py:369-407) are outside the accelerated path')
     if s_mode not in ('adam', 'grid'):
         raise ValueError("s_mode must be 'adam' or 'grid'")
+    if h_fn is not None:
+        return _run_kalman_smoother_pinhole(ys, m0s, S0s, As, Qs, ensemble_vars, h_fn, s_frames,
+                                            smooth_param, blocks, lr, s_bounds_log, tol, safety_cap,
+                                            s_mode, n_grid, vs_diag, return_device, x_init)
     torch = _torch()
     t0 = time.perf_counter()
     P = _DeviceProblem(ys, m0s, S0s, As, Cs, Qs, ensemble_vars)

@@ -1,5 +1,5 @@
-"""Multi-camera ensemble Kalman smoother, linear (PCA-subspace) path - mirror of the reference's
-eks/multicam_smoother.py.
+"""Multi-camera ensemble Kalman smoother - mirror of the reference's eks/multicam_smoother.py:
+the linear (PCA-subspace) path and the calibrated nonlinear path (`calibration` / `camgroup`).
 
     fit_eks_mirrored_multicam(...) -> (final_df, s_finals, input_dfs, bodypart_list)
     fit_eks_multicam(...)          -> (camera_dfs, s_finals, input_dfs, bodypart_list, df_3d)
@@ -9,8 +9,7 @@ eks/multicam_smoother.py.
     mA_compute_maha / inflate_variance: Mahalanobis variance inflation (reference :653-764),
         host-side like upstream but vectorised over frames
 
-Out of scope (raise NotImplementedError): the calibrated nonlinear path (`calibration` /
-`camgroup`, reference :369-407, :771-946) - SURVEY.md section 8(f).
+    initialize_kalman_filter_geometric(ys_3d)  (calibrated path; camera helpers in calibration.py)
 """
 from __future__ import annotations
 
@@ -22,6 +21,8 @@ from typing import Literal
 import numpy as np
 import pandas as pd
 
+from .calibration import (CameraGroup, make_projection_from_camgroup, project_3d_covariance_to_2d,
+                          triangulate_3d_models)
 from .core import ensemble, run_kalman_smoother
 from .marker_array import (MarkerArray, input_dfs_to_markerArray, mA_to_stacked_array,
                            stacked_array_to_mA)
@@ -80,9 +81,14 @@ def fit_eks_multicam(input_source, save_dir: str, bodypart_list: list | None = N
                      inflate_vars: bool = False, n_latent: int = 3, calibration: str | None = None,
                      save_3d_outputs: bool = True) -> tuple:
     """One set of CSVs per camera (reference eks/multicam_smoother.py:156-276)."""
+    camgroup = None
     if calibration is not None:
-        raise NotImplementedError('calibrated (nonlinear) multicam is outside the accelerated path')
-    if camera_names is None:
+        camgroup = CameraGroup.load(calibration)
+        if camera_names is not None:
+            logger.warning('camera_names argument is ignored when calibration is provided; '
+                           'camera names will be read from the calibration file')
+        camera_names = [cam.name for cam in camgroup.cameras]
+    elif camera_names is None:
         raise ValueError('camera_names must be provided when no calibration file is given')
     input_dfs, keypoint_names = format_data(input_source, camera_names=camera_names)
     if bodypart_list is None:
@@ -91,10 +97,13 @@ def fit_eks_multicam(input_source, save_dir: str, bodypart_list: list | None = N
     camera_dfs, s_finals, df_3d = ensemble_kalman_smoother_multicam(
         marker_array=marker_array, keypoint_names=bodypart_list, smooth_param=smooth_param,
         quantile_keep_pca=quantile_keep_pca, camera_names=camera_names, s_frames=s_frames,
-        avg_mode=avg_mode, var_mode=var_mode, inflate_vars=inflate_vars, n_latent=n_latent)
+        avg_mode=avg_mode, var_mode=var_mode, inflate_vars=inflate_vars, n_latent=n_latent,
+        camgroup=camgroup)
     os.makedirs(save_dir, exist_ok=True)
     for cam, df in zip(camera_names, camera_dfs):
         df.to_csv(os.path.join(save_dir, f'multicam_{cam}_results.csv'))
+    if save_3d_outputs and calibration is not None:
+        df_3d.to_csv(os.path.join(save_dir, 'multicam_3d_results.csv'))
     return camera_dfs, s_finals, input_dfs, bodypart_list, df_3d
 
 
@@ -111,8 +120,6 @@ def ensemble_kalman_smoother_multicam(marker_array: MarkerArray, keypoint_names:
     eks/multicam_smoother.py:279-551, linear branch)."""
     if camera_names is None or len(camera_names) == 0:
         raise ValueError('camera_names must be provided')
-    if camgroup is not None:
-        raise NotImplementedError('calibrated (nonlinear) multicam is outside the accelerated path')
     M, V, T, K, _ = marker_array.shape
     t_all = time.perf_counter()
     ens = ensemble(marker_array, avg_mode=avg_mode, var_mode=var_mode)       # (1,V,T,K,5)
@@ -124,6 +131,9 @@ def ensemble_kalman_smoother_multicam(marker_array: MarkerArray, keypoint_names:
             inflate_vars_kwargs['mean'] = np.zeros_like(inflate_vars_kwargs['mean'])
         vars_ma = mA_compute_maha(centered, vars_ma, ens.slice_fields('likelihood'), n_latent,
                                   inflate_vars_kwargs=inflate_vars_kwargs)
+    if camgroup is not None:
+        return _calibrated_branch(marker_array, keypoint_names, camera_names, camgroup, ens, vars_ma,
+                                  smooth_param, s_frames, kalman_kwargs, t_all)
     pcas, good_pcs = compute_pca(valid_mask, centered, good_centered, n_components=n_latent,
                                  pca_object=pca_object)
     m0s, S0s, As, Qs, Cs = initialize_kalman_filter_pca(good_pcs, pcas, n_latent)
@@ -163,6 +173,67 @@ def ensemble_kalman_smoother_multicam(marker_array: MarkerArray, keypoint_names:
     logger.debug(f'[profile] ensemble_kalman_smoother_multicam total: '
                  f'{time.perf_counter() - t_all:.3f}s')
     return camera_dfs, s_finals, df_3d
+
+
+def _calibrated_branch(marker_array, keypoint_names, camera_names, camgroup, ens, vars_ma,
+                       smooth_param, s_frames, kalman_kwargs, t_all) -> tuple:
+    """Nonlinear path (reference eks/multicam_smoother.py:367-407, :450-480): triangulate every
+    ensemble member, average -> 3-D initialisation; latent state = the 3-D point, observation =
+    its projection into every calibrated camera; extended Kalman smoother (eks_ekf_smooth);
+    reprojection of the smoothed points and of their covariances through the projection's
+    Jacobian."""
+    M, V, T, K, _ = marker_array.shape
+    h_fn, h_cams = make_projection_from_camgroup(camgroup)
+    t0 = time.perf_counter()
+    ys_3d = triangulate_3d_models(marker_array, camgroup).mean(axis=0)      # (K,T,3)
+    logger.debug(f'[profile] triangulation: {time.perf_counter() - t0:.3f}s')
+    m0s, S0s, As, Qs, Cs = initialize_kalman_filter_geometric(ys_3d)
+    stats = np.asarray(ens.array)[0]                                         # (V,T,K,5)
+    # the UNCENTRED ensemble averages are the observations here (reference :389-397)
+    ys = np.transpose(stats[..., 0:2], (2, 1, 0, 3)).reshape(K, T, 2 * V)
+    evs = np.stack([mA_to_stacked_array(vars_ma, k) for k in range(K)])      # (K,T,2V), maybe inflated
+    t0 = time.perf_counter()
+    s_finals, ms, Vs = run_kalman_smoother(
+        ys=ys, m0s=m0s, S0s=S0s, As=As, Qs=Qs, Cs=Cs, ensemble_vars=np.swapaxes(evs, 0, 1),
+        s_frames=s_frames, smooth_param=smooth_param, h_fn=h_fn, x_init=ys_3d, **kalman_kwargs)
+    logger.debug(f'[profile] run_kalman_smoother (total): {time.perf_counter() - t0:.3f}s')
+    index = make_dlc_pandas_index(keypoint_names, labels=OUTPUT_LABELS)
+    camera_dfs = []
+    for c in range(V):
+        out = np.empty((T, K, 9))
+        for k in range(K):
+            out[:, k, 0:2] = h_cams[c](ms[k])
+            # like upstream, the ensemble variance added here is columns 0 and 1 of the keypoint's
+            # (T, 2V) array - camera 0's - whatever the camera (reference :466-467, :949-951)
+            out[:, k, 7], out[:, k, 8] = project_3d_covariance_to_2d(ms[k], Vs[k], h_cams[c], evs[k])
+        out[:, :, 2] = stats[c, :, :, 4]
+        out[:, :, 3:5] = stats[c, :, :, 0:2]
+        out[:, :, 5:7] = stats[c, :, :, 2:4]          # the UNinflated ensemble variances (:474-477)
+        camera_dfs.append(pd.DataFrame(out.reshape(T, K * 9), columns=index))
+    lat = np.concatenate([np.swapaxes(ms, 0, 1),
+                          np.swapaxes(np.diagonal(Vs, axis1=2, axis2=3), 0, 1)], axis=2)
+    labels_3d = ['x', 'y', 'z', 'x_posterior_var', 'y_posterior_var', 'z_posterior_var']
+    df_3d = pd.DataFrame(lat.reshape(T, K * 6),
+                         columns=make_dlc_pandas_index(keypoint_names, labels=labels_3d))
+    logger.debug(f'[profile] ensemble_kalman_smoother_multicam total: '
+                 f'{time.perf_counter() - t_all:.3f}s')
+    return camera_dfs, s_finals, df_3d
+
+
+def initialize_kalman_filter_geometric(ys: np.ndarray) -> tuple:
+    """Filter parameters of the 3-D latent from the triangulated points ys (K,T,3): m0 = mean of
+    the first 10 frames, S0 = diag(var + 1e-4), A = C = I, Q = diag of the squared robust (MAD)
+    scale of the frame-to-frame differences (reference eks/multicam_smoother.py:600-650).
+    Returns (m0s, S0s, As, Qs, Cs)."""
+    ys = np.asarray(ys, dtype=np.float64)
+    K, T, D = ys.shape
+    m0s = ys[:, :10].mean(axis=1)
+    S0s = np.stack([np.diag(np.nanvar(ys[k], axis=0) + 1e-4) for k in range(K)])
+    eye = np.tile(np.eye(D), (K, 1, 1))
+    dx = np.diff(ys, axis=1)
+    mad = np.median(np.abs(dx - np.median(dx, axis=1, keepdims=True)), axis=1) + 1e-12
+    Qs = np.stack([np.diag(v) for v in np.maximum((1.4826 * mad) ** 2, 1e-8)])
+    return m0s, S0s, eye, Qs, eye.copy()
 
 
 def mA_compute_maha(centered_emA_preds: MarkerArray, emA_vars: MarkerArray, emA_likes: MarkerArray,

@@ -1,0 +1,194 @@
+"""CPU: the calibrated (nonlinear) multi-camera path - SURVEY.md section 8(f) rank 3.
+
+* the oracle's extended filter (oracle/ekf_oracle.py) reduces to the linear oracle for an affine
+  camera and its complex-step Jacobian agrees with the analytic one of the product
+  (eks_amd/calibration.py) and of the kernels' header (eks_pinhole.hpp, compiled for the host);
+* the kernels' fixed-point formulation (scan sweeps over stored linearisation points + extended
+  replay per chunk), run from plain loops over the SAME lane headers, reproduces the sequential
+  extended filter / smoother;
+* host pieces of the driver: triangulation, geometric initialisation, calibration TOML.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from eks_amd import calibration as cal
+from eks_amd import synth
+from oracle import ekf_oracle as ek
+from oracle import eks_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def dense_sim():
+    src = os.path.join(ROOT, 'tests', 'host_sim', 'dense_sim.cpp')
+    lib = os.path.join(ROOT, 'tests', 'host_sim', 'libdense_sim_ekf.so')
+    subprocess.run(['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-I', os.path.join(ROOT, 'eks_amd', 'csrc'),
+                    src, '-o', lib], check=True)
+    return ctypes.CDLL(lib)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _oracle_h(cams):
+    return ek.combine_projections([ek.make_projection_fn(c['rot'], c['tvec'], c['K'], c['dist'])
+                                   for c in cams])
+
+
+def test_extended_filter_with_an_affine_camera_is_the_linear_filter():
+    rng = np.random.default_rng(0)
+    T, D, O = 200, 3, 4
+    C = rng.normal(size=(O, D))
+    off = rng.normal(size=O) * 10
+    y = rng.normal(size=(T, O)).cumsum(axis=0)
+    Rd = 0.5 + rng.random((T, O))
+    m0, S0 = rng.normal(size=D), np.eye(D) * 4.0
+    A = np.eye(D) + 0.05 * rng.normal(size=(D, D))
+    Q = np.diag([1.0, 2.0, 0.5])
+    ms, Vs, ll = ek.eks_smoother(y, Rd, m0, S0, A, Q, 0.7, lambda x: x @ C.T + off)
+    mo, Vo, llo = orc.kalman_smoother((y - off)[None], m0[None], S0[None], A[None], C[None], Q[None],
+                                      np.array([0.7]), Rd[None])
+    assert np.abs(ms - mo[0]).max() < 1e-9 and np.abs(Vs - Vo[0]).max() < 1e-10
+    assert abs(ll + llo[0]) < 1e-10 * abs(ll)       # third output is the NLL
+
+
+def test_analytic_jacobians_match_complex_step_at_wide_angles(dense_sim):
+    cams = synth.ring_cameras(3, seed=2)
+    rng = np.random.default_rng(1)
+    X = rng.uniform(-350, 350, size=(40, 3))           # up to ~20 degrees off axis: distortion matters
+    for c in cams:
+        packed = cal.pack_camera(c['rot'], c['tvec'], c['K'], c['dist'])
+        packed[22:25] = [0.02, -0.01, 0.005]           # k4..k6
+        packed[26], packed[28] = 1e-4, -5e-5           # s2, s4
+        dist = packed[17:29]
+        h = ek.make_projection_fn(c['rot'], c['tvec'], c['K'], dist)
+        Jref = np.stack([ek.jacobian_cs(h, x) for x in X])
+        assert np.abs(cal.project(packed, X) - h(X)).max() < 1e-10
+        assert np.abs(cal.project_jacobian(packed, X) - Jref).max() < 1e-9 * np.abs(Jref).max()
+        uv, J = np.zeros(2), np.zeros(6)
+        for x, jr in zip(X, Jref):
+            dense_sim.sim_pinhole(_p(packed), _p(x), _p(uv), _p(J))
+            assert np.abs(uv - h(x)).max() < 1e-10
+            assert np.abs(J.reshape(2, 3) - jr).max() < 1e-9 * np.abs(jr).max()
+
+
+def test_rodrigues_small_and_general_angles():
+    assert np.allclose(cal.rodrigues([0, 0, 0]), np.eye(3))
+    R = cal.rodrigues([0.3, -0.2, 0.5])
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-14) and np.isclose(np.linalg.det(R), 1.0)
+    assert np.allclose(R, ek.rodrigues([0.3, -0.2, 0.5]))
+
+
+@pytest.mark.parametrize('init', ['prior', 'triangulated'])
+def test_fixed_point_sweeps_reproduce_the_sequential_extended_smoother(dense_sim, init):
+    T, K, V = 700, 3, 3
+    prob = synth.calibrated_multicam(T, K, V, seed=11)
+    y = prob['y_tko'].astype(np.float32)
+    var = prob['var_tko'].astype(np.float32)
+    var[5, 0, :] = 1e-5                                 # a near-exact frame
+    s = np.array([2.0, 0.01, 300.0])
+    m0, S0, A, Q = prob['m0s'], prob['S0s'], prob['As'], prob['Qs']
+    if init == 'prior':
+        xlin = np.repeat(m0[:, None, :], T, axis=1).copy()
+    else:
+        xy = np.transpose(prob['y_tko'].reshape(T, K, V, 2), (2, 1, 0, 3)).reshape(V, K * T, 2)
+        xlin = cal.triangulate(prob['cams_packed'], xy).reshape(K, T, 3).copy()
+    ms = np.zeros((T, K, 3), np.float32)
+    Vs = np.zeros((T, K, 3, 3), np.float32)
+    nll = np.zeros(K)
+    resid = ctypes.c_double()
+    n = dense_sim.sim_ekf_smooth(T, K, V, 32, _p(y), _p(var), None, _p(m0), _p(S0), _p(A), _p(Q), _p(s),
+                                 _p(prob['cams_packed']), _p(xlin), 40, ctypes.c_double(1e-10), _p(ms),
+                                 _p(Vs), _p(nll), ctypes.byref(resid))
+    assert n <= 8 and resid.value <= 1e-10
+    h = _oracle_h(prob['cams'])
+    for k in range(K):
+        Rk = np.maximum(var[:, k].astype(np.float64), 1e-12)
+        mo, Vo, ll = ek.eks_smoother(y[:, k].astype(np.float64), Rk, m0[k], S0[k], A[k], Q[k], s[k], h)
+        _, _, _, mp = ek.ekf_filter(y[:, k].astype(np.float64), Rk, m0[k], S0[k], A[k], Q[k], s[k], h)
+        assert np.abs(xlin[k] - mp).max() < 1e-7        # linearisation points = predicted means
+        assert np.abs(ms[:, k] - mo).max() < 1e-5 * np.abs(mo).max()
+        assert np.abs(Vs[:, k] - Vo).max() < 1e-5 * np.abs(Vo).max()
+        assert abs(nll[k] + ll) < 1e-10 * abs(ll)
+
+
+def test_constant_r_loss_through_the_sweeps(dense_sim):
+    T, K, V = 400, 2, 2
+    prob = synth.calibrated_multicam(T, K, V, seed=3)
+    y = prob['y_tko'].astype(np.float32)
+    rconst = np.median(prob['var_tko'], axis=0)
+    s = np.array([0.3, 4.0])
+    xlin = np.repeat(prob['m0s'][:, None, :], T, axis=1).copy()
+    nll = np.zeros(K)
+    resid = ctypes.c_double()
+    dense_sim.sim_ekf_smooth(T, K, V, 32, _p(y), None, _p(rconst), _p(prob['m0s']), _p(prob['S0s']),
+                             _p(prob['As']), _p(prob['Qs']), _p(s), _p(prob['cams_packed']), _p(xlin), 40,
+                             ctypes.c_double(1e-10), None, None, _p(nll), ctypes.byref(resid))
+    h = _oracle_h(prob['cams'])
+    for k in range(K):
+        ref = ek.ekf_nll(y[:, k].astype(np.float64), rconst[k], prob['m0s'][k], prob['S0s'][k],
+                         prob['As'][k], prob['Qs'][k], s[k], h)
+        assert abs(nll[k] - ref) < 1e-10 * abs(ref)
+
+
+def test_triangulation_and_geometric_initialisation():
+    prob = synth.calibrated_multicam(300, 2, 4, seed=5)
+    xy = np.stack([cal.project(c, prob['latent'][:, 0]) for c in prob['cams_packed']])
+    tri = cal.triangulate(prob['cams_packed'], xy)
+    assert np.abs(tri - prob['latent'][:, 0]).max() < 1e-6
+    assert np.abs(tri - ek.triangulate_dlt(prob['cams'], xy)).max() < 1e-6
+    from eks_amd.multicam_smoother import initialize_kalman_filter_geometric
+    ys3 = np.swapaxes(prob['latent'], 0, 1)
+    got = initialize_kalman_filter_geometric(ys3)
+    ref = ek.initialize_kalman_filter_geometric(ys3)
+    for g, r in zip(got, ref):
+        assert np.allclose(g, r, rtol=1e-12, atol=0)
+
+
+def test_camera_group_from_calibration_toml(tmp_path):
+    fn = tmp_path / 'calibration.toml'
+    fn.write_text('''[cam_0]
+name = "top"
+size = [ 640, 480,]
+matrix = [ [ 900.0, 0.5, 320.0,], [ 0.0, 880.0, 240.0,], [ 0.0, 0.0, 1.0,],]
+distortions = [ -0.15, 0.06, 0.001, -0.002, 0.01,]
+rotation = [ 0.1, -0.2, 0.3,]
+translation = [ 1.0, 2.0,
+  1000.0,]
+
+[cam_1]
+name = "bot"
+size = [ 640, 480,]
+matrix = [ [ 910.0, 0.0, 320.0,], [ 0.0, 890.0, 240.0,], [ 0.0, 0.0, 1.0,],]
+distortions = [ -0.1, 0.0, 0.0, 0.0, 0.0,]
+rotation = [ 0.0, 0.5, 0.0,]
+translation = [ -10.0, 0.0, 900.0,]
+
+[metadata]
+adjusted = false
+error = 0.52
+''')
+    g = cal.CameraGroup.load(str(fn))
+    assert [c.name for c in g.cameras] == ['top', 'bot']
+    h, heads = cal.make_projection_from_camgroup(g)
+    assert h.n_cameras == 2 and h.cams.shape == (2, 32)
+    ref = ek.make_projection_fn([0.1, -0.2, 0.3], [1.0, 2.0, 1000.0],
+                                np.array([[900.0, 0.5, 320.0], [0, 880.0, 240.0], [0, 0, 1.0]]),
+                                [-0.15, 0.06, 0.001, -0.002, 0.01])
+    x = np.array([20.0, -35.0, 60.0])
+    assert np.allclose(heads[0](x), ref(x), rtol=1e-13)
+    assert np.allclose(h(x)[:2], ref(x), rtol=1e-13) and h(x).shape == (4,)
+
+
+def test_only_calibrated_projections_are_accepted_as_h_fn():
+    from eks_amd.core import run_kalman_smoother
+    z = np.zeros
+    with pytest.raises(NotImplementedError):
+        run_kalman_smoother(z((1, 4, 4)), z((1, 3)), z((1, 3, 3)), z((1, 3, 3)), z((1, 4, 3)),
+                            z((1, 3, 3)), z((4, 1, 4)), smooth_param=1.0, h_fn=lambda x: x)
