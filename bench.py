@@ -37,6 +37,7 @@ WORKLOADS = {
     'c5': (50_000, 128 * 32, 0), # configs[4], one GPU's share: 128 sessions x 32 keypoints batched
     'c4': (50_000, 4, 0),        # configs[3]: mirrored multicam, 2 views x 4 paws, D = 3, O = 4 (dense path)
     'pupil': (100_000, 1, 0),    # IBL pupil AR(1) session, one optimiser iteration per step
+    'ekf': (50_000, 16, 0),      # calibrated multicam, 4 cameras, D = 3, O = 8, fixed s
 }
 SMOOTH_BYTES_PER_UNIT = 40       # y 8 + var 8 in, ms 8 + Vs 16 out  
 NLL_BYTES_PER_UNIT = 8           # y read once regardless of candidate count
@@ -225,6 +226,73 @@ def bench_pupil(args, T, dev, lib):
     print(json.dumps(out), flush=True)
 
 
+def bench_ekf(args, T, K, dev, lib, V=4):
+    """Calibrated multi-camera path (reference eks/core.py:188-190 with the pinhole h_fn of
+    eks/multicam_smoother.py:814-898): one step = eks_ekf_smooth from a cold start (linearisation
+    points = the prior mean) to the smoothed outputs - gated filter sweeps to the fixed point, then
+    the smoothing sweep.  Small and latency-bound (K chains x T/32 chunks of float64 3x3 algebra):
+    reported for the record, not the headline."""
+    import torch
+    from eks_amd import hip_ops, synth
+    prob = synth.calibrated_multicam(T, K, V, seed=4)
+    t = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+    y, var = t(prob['y_tko'], torch.float32), t(prob['var_tko'], torch.float32)
+    m0, S0, A, Q, s = t(prob['m0s']), t(prob['S0s']), t(prob['As']), t(prob['Qs']), t(prob['s'])
+    cams = t(prob['cams_packed'])
+    cold = m0[:, None, :].expand(K, T, 3).contiguous()
+    xlin = cold.clone()
+    info = None
+
+    def step():
+        nonlocal info
+        xlin.copy_(cold)
+        info = hip_ops.ekf_smooth(y, var, None, m0, S0, A, Q, s, cams, xlin, max_sweeps=8, tol=1e-10)[3]
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    lib.eks_profile_drain(None, 0, None, 0)
+    lib.eks_profile_enable(0 if args.no_kernel_events else 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lib.eks_profile_enable(0)
+    prof = {k: float(np.mean(v)) for k, v in drain_profile(lib).items()}
+    O = 2 * V
+    bytes_per_unit = 4 * O * 2 + 4 * 3 + 4 * 9            # y, var in; ms, Vs out (float32)
+    sm = prof.get('ekf_smooth_sweep', float('nan'))
+    out = {'metric': 'frames*keypoints smoothed/s, calibrated multicam extended Kalman smoother '
+                     f'({V} cameras, D=3, O={O})',
+           'value': args.steps * T * K / dt, 'unit': 'frames*keypoints/s', 'n_gpus': 1, 'steps': args.steps,
+           'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+           'config': {'workload': f'calibrated multicam T={T} x K={K} keypoints, {V} pinhole cameras with '
+                                  'distortion, fixed s, cold start (prior-mean linearisation)',
+                      'filter_sweeps': float(info[0].item()), 'last_change': float(info[1].item())},
+           'roofline': {'bound': 'hbm', 'kernel': 'dense_replay_kernel<3, true, PinholeObs> (smoothing sweep)',
+                        'unit': 'GB/s', 'peak': HBM_PEAK_GBS,
+                        'achieved': bytes_per_unit * T * K / (sm * 1e-3) / 1e9,
+                        'frac': bytes_per_unit * T * K / (sm * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                        'stage_avg_ms': prof,
+                        'note': 'latency-bound, not HBM-bound: K*T/32 lanes of dependent float64 3x3 '
+                                'algebra do not fill the device at these sizes'}}
+    if not args.no_cpu_baseline:
+        from oracle import ekf_oracle as ek
+        h = ek.combine_projections([ek.make_projection_fn(c['rot'], c['tvec'], c['K'], c['dist'])
+                                    for c in prob['cams']])
+        Tc = min(T, 4000)
+        t1 = time.perf_counter()
+        ek.eks_smoother(prob['y_tko'][:Tc, 0], np.maximum(prob['var_tko'][:Tc, 0], 1e-12), prob['m0s'][0],
+                        prob['S0s'][0], prob['As'][0], prob['Qs'][0], prob['s'][0], h)
+        cdt = time.perf_counter() - t1
+        out['cpu_baseline'] = {'value': Tc / cdt, 'unit': 'frames*keypoints/s', 'cores': 1, 'kind': 'port',
+                               'sample': f'first {Tc} frames of keypoint 0: sequential extended filter + RTS '
+                                         'in NumPy float64 (oracle/ekf_oracle.py), complex-step Jacobians'}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
     import torch
@@ -253,6 +321,8 @@ def main():
         return bench_dense(args, T, K, dev, rank, world, lib)
     if args.workload == 'pupil':
         return bench_pupil(args, T, dev, lib)
+    if args.workload == 'ekf':
+        return bench_ekf(args, T, K, dev, lib)
     # every rank owns an independent session of the same shape (seed = 3 + rank)
     y, var = synth.singlecam_observations_torch(T, K, seed=3 + rank, device=dev)
     eye = torch.eye(2, dtype=torch.float64, device=dev).expand(K, 2, 2).contiguous()
