@@ -12,6 +12,8 @@
 // The losses of this path (eks_nll, eks_ar1_nll) live in eks_loss_kernels.hpp.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "eks_dense_lane.hpp"
 #include "eks_internal.hpp"
 
@@ -276,9 +278,24 @@ __global__ __launch_bounds__(64) void dense_replay_kernel(DenseGeom G, DenseMode
 // ------------------------------------------------------------------------------------------
 constexpr int kDenseSmoothChunk = 32;   // frames per lane in the smoother (the scan is parallel)
 
+// Frames per lane for a (T, K) problem.  These problems are small (a handful of keypoints), so
+// shorter chunks buy lanes and cut the sequential depth of summarize / replay, at the price of
+// more chunk elements for the scan.  EKS_DENSE_CHUNK overrides (measurement knob).
+static int dense_chunk(int T, int K) {
+  static const int forced = [] {
+    const char* e = getenv("EKS_DENSE_CHUNK");
+    const int v = e ? atoi(e) : 0;
+    return v >= 2 && v <= 256 ? v : 0;
+  }();
+  if (forced) return forced;
+  (void)T;
+  (void)K;
+  return kDenseSmoothChunk;
+}
+
 size_t dense_smooth_workspace_bytes(int T, int K, int D, int O) {
   (void)O;
-  const int B = kDenseSmoothChunk, nc = (T + B - 1) / B, nblk = (nc + kDenseCB - 1) / kDenseCB;
+  const int B = dense_chunk(T, K), nc = (T + B - 1) / B, nblk = (nc + kDenseCB - 1) / kDenseCB;
   const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
   return align_up((size_t)nc * K * nv * 8, 256) + 2 * align_up((size_t)nc * K * rec * 8, 256) +
          align_up((size_t)nblk * K * nv * 8, 256) + 2 * align_up((size_t)nblk * K * rec * 8, 256) +
@@ -290,7 +307,7 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
   const int T = d.n_frames, K = d.n_keypoints, D = d.state_dim, O = d.obs_dim;
   if (D < 1 || D > 6 || O < 1 || O > 64) return EKS_ERR_UNSUPPORTED;
   if (ws_bytes < dense_smooth_workspace_bytes(T, K, D, O)) return EKS_ERR_WORKSPACE;
-  DenseGeom G{K, T, O, kDenseSmoothChunk, 0};
+  DenseGeom G{K, T, O, dense_chunk(T, K), 0};
   G.nc = (T + G.B - 1) / G.B;
   const int nblk = (G.nc + kDenseCB - 1) / kDenseCB;
   const DenseModelPtrs M{Mm.m0, Mm.S0, Mm.A, Mm.C, Mm.Q};
@@ -379,7 +396,7 @@ __global__ __launch_bounds__(64) void ekf_finish_kernel(int K, int nc, int n_swe
 
 static size_t ekf_ws_layout(int T, int K, bool smooth, double** ptrs, char* base) {
   constexpr int D = 3;
-  const int B = kDenseSmoothChunk, nc = (T + B - 1) / B, nblk = (nc + kDenseCB - 1) / kDenseCB;
+  const int B = dense_chunk(T, K), nc = (T + B - 1) / B, nblk = (nc + kDenseCB - 1) / kDenseCB;
   const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
   const size_t sizes[10] = {(size_t)nc * K * nv * 8,   (size_t)nc * K * rec * 8,
                             (size_t)nc * K * rec * 8,  (size_t)nblk * K * nv * 8,
@@ -412,7 +429,7 @@ int ekf_smooth(const eks_dims_t& d, int n_data_keypoints, const float* y, const 
   ekf_ws_layout(T, K, smooth, w, static_cast<char*>(ws));
   double *elems = w[0], *prior = w[1], *suffix = w[2], *agg = w[3], *bprior = w[4], *bsuffix = w[5],
          *filt = w[6], *first = w[7], *ll_chunk = w[8], *resid = w[9];
-  DenseGeom G{K, T, O, kDenseSmoothChunk, 0};
+  DenseGeom G{K, T, O, dense_chunk(T, K), 0};
   G.nc = (T + G.B - 1) / G.B;
   const int nblk = (G.nc + kDenseCB - 1) / kDenseCB, lanes = K * G.nc;
   const DenseModelPtrs M{Mm.m0, Mm.S0, Mm.A, nullptr, Mm.Q};

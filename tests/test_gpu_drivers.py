@@ -192,7 +192,7 @@ def test_multicam_adam_and_errors(mouse):
     assert np.all(np.abs(np.log(s) - np.log(s_o)) < 0.25)
     with pytest.raises(ValueError):
         ensemble_kalman_smoother_multicam(ma, ['p1', 'p2'], [])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AttributeError):      # a camera group must offer `.cameras` (tests/test_gpu_ekf.py)
         ensemble_kalman_smoother_multicam(ma, ['p1', 'p2'], ['top', 'bot'], camgroup=object())
 
 

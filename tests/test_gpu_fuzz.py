@@ -46,3 +46,8 @@ def test_pupil_driver_random_sessions():
 def test_exact_median_adversarial_inputs():
     out = _run('fuzz_median.py', 707, 20)
     assert 'mismatches 0' in out, out[-2000:]
+
+
+def test_extended_filter_random_calibrated_rigs():
+    out = _run('fuzz_ekf.py', 10, 808)
+    assert 'above 1e-5' not in out and 'cases above tolerance 0' in out, out[-2000:]
