@@ -5,7 +5,8 @@
 //   D1 dense_summarize : lane = (keypoint, chunk) -> element (A, b, C, eta, J); chunk 0's lane also
 //                        updates the prior with frame 0 (the belief the scan starts from)
 //   D2 dense_scan_*    : block-parallel scan of the chunk elements (general element composition
-//                        through Cholesky / Woodbury forms, eks_dense_math.hpp delem_combine)
+//                        through Cholesky / Woodbury forms, eks_dense_math.hpp delem_combine);
+//                        forward and reverse scans run side by side in one workgroup
 //   D3 dense_replay    : lane = (keypoint, chunk): exact filter, fuse, RTS; filtered beliefs go
 //                        through a per-lane scratch record stream (these problems are tiny:
 //                        BASELINE config 4 is 4 keypoints x 50k frames, latency- not HBM-bound)
@@ -64,35 +65,48 @@ __global__ __launch_bounds__(64) void dense_summarize_kernel(DenseGeom G, DenseM
 }
 
 // ---- scan of the chunk elements, block-parallel like the scalar path (eks_diag.hip K2):
-//   DS1 reduce : block = (keypoint, 64 consecutive chunks); ordered tree reduction in LDS
+//   DS1 scan   : block = (keypoint, 64 consecutive chunks), 128 threads: threads 0..63 run a
+//                Hillis-Steele inclusive FORWARD scan of the block's elements in LDS while threads
+//                64..127 run the inclusive REVERSE scan in a second LDS array (the two are
+//                independent, so the depth is 6 compositions, not 12); both are written out per
+//                chunk, the forward total is the block aggregate
 //   DS2 blocks : per keypoint, forward / backward walk over the few block aggregates
-//   DS3 local  : Hillis-Steele inclusive scans (forward and reverse) of the block's elements in
-//                LDS; the exclusive prefix is applied to the block's incoming belief, the
-//                exclusive suffix pulls the block's outgoing information back.
+//   (replay)   : each replay lane applies its exclusive prefix (the inclusive prefix of chunk i-1)
+//                to the block's incoming belief and pulls the block's outgoing information back
+//                through its exclusive suffix (the inclusive suffix of chunk i+1) - one apply and
+//                one pull-back per lane instead of a third scan kernel.
 constexpr int kDenseCB = 64;
 
 template <int D>
-__global__ __launch_bounds__(kDenseCB) void dense_scan_reduce_kernel(DenseGeom G,
-                                                                    const double* __restrict__ elems,
-                                                                    double* __restrict__ agg,
-                                                                    Gate gate) {
+__global__ __launch_bounds__(2 * kDenseCB) void dense_scan_kernel(DenseGeom G,
+                                                                  const double* __restrict__ elems,
+                                                                  double* __restrict__ pre,
+                                                                  double* __restrict__ suf,
+                                                                  double* __restrict__ agg, Gate gate) {
   constexpr int NV = delem_doubles<D>();
-  __shared__ double lds[kDenseCB * NV];
+  __shared__ double lds[2 * kDenseCB * NV];
   if (gate.closed()) return;
-  const int k = blockIdx.x, blk = blockIdx.y, i = threadIdx.x;
+  const int k = blockIdx.x, blk = blockIdx.y;
+  const bool rev = threadIdx.x >= kDenseCB;
+  const int i = threadIdx.x - (rev ? kDenseCB : 0);
   const int j = blk * kDenseCB + i;
-  DElem<double, D> e = j < G.nc ? load_delem<double, D>(elems + ((size_t)j * G.K + k) * NV)
-                                : delem_identity<double, D>();
-  store_delem<double, D>(lds + i * NV, e);
+  const bool live = j < G.nc;
+  double* mine = lds + (rev ? kDenseCB * NV : 0);
+  DElem<double, D> e = live ? load_delem<double, D>(elems + ((size_t)j * G.K + k) * NV)
+                            : delem_identity<double, D>();
+  store_delem<double, D>(mine + i * NV, e);
   __syncthreads();
   for (int off = 1; off < kDenseCB; off <<= 1) {
-    const bool act = (i & (2 * off - 1)) == 0;
-    if (act) e = delem_combine(e, load_delem<double, D>(lds + (i + off) * NV));
+    const bool has = rev ? (i + off < kDenseCB) : (i >= off);
+    DElem<double, D> other;
+    if (has) other = load_delem<double, D>(mine + (rev ? i + off : i - off) * NV);
     __syncthreads();
-    if (act) store_delem<double, D>(lds + i * NV, e);
+    if (has) e = rev ? delem_combine(e, other) : delem_combine(other, e);
+    store_delem<double, D>(mine + i * NV, e);
     __syncthreads();
   }
-  if (i == 0) store_delem<double, D>(agg + ((size_t)blk * G.K + k) * NV, e);
+  if (live) store_delem<double, D>((rev ? suf : pre) + ((size_t)j * G.K + k) * NV, e);
+  if (!rev && i == kDenseCB - 1) store_delem<double, D>(agg + ((size_t)blk * G.K + k) * NV, e);
 }
 
 template <int D>
@@ -143,95 +157,13 @@ __global__ __launch_bounds__(64) void dense_scan_blocks_kernel(DenseGeom G, int 
   }
 }
 
-template <int D>
-__global__ __launch_bounds__(kDenseCB) void dense_scan_local_kernel(DenseGeom G,
-                                                                   const double* __restrict__ elems,
-                                                                   const double* __restrict__ bprior,
-                                                                   const double* __restrict__ bsuffix,
-                                                                   double* __restrict__ prior,
-                                                                   double* __restrict__ suffix,
-                                                                   Gate gate) {
-  constexpr int NV = delem_doubles<D>();
-  constexpr int REC = D + D * D;
-  __shared__ double lds[kDenseCB * NV];
-  if (gate.closed()) return;
-  const int k = blockIdx.x, blk = blockIdx.y, i = threadIdx.x;
-  const int j = blk * kDenseCB + i;
-  const bool live = j < G.nc;
-  const double* own = elems + ((size_t)j * G.K + k) * NV;
-  // forward inclusive scan; the exclusive prefix of chunk i is what sits in slot i-1 afterwards
-  DElem<double, D> e = live ? load_delem<double, D>(own) : delem_identity<double, D>();
-  store_delem<double, D>(lds + i * NV, e);
-  __syncthreads();
-  for (int off = 1; off < kDenseCB; off <<= 1) {
-    const bool has = i >= off;
-    DElem<double, D> other;
-    if (has) other = load_delem<double, D>(lds + (i - off) * NV);
-    __syncthreads();
-    if (has) e = delem_combine(other, e);
-    store_delem<double, D>(lds + i * NV, e);
-    __syncthreads();
-  }
-  {
-    Vec<double, D> m;
-    Mat<double, D> P;
-    const double* r = bprior + ((size_t)blk * G.K + k) * REC;
-#pragma unroll
-    for (int a = 0; a < D; ++a) {
-      m.a[a] = r[a];
-#pragma unroll
-      for (int b = 0; b < D; ++b) P.a[a][b] = r[D + a * D + b];
-    }
-    if (i > 0) delem_apply(load_delem<double, D>(lds + (i - 1) * NV), m, P);
-    if (live) {
-      double* w = prior + ((size_t)j * G.K + k) * REC;
-#pragma unroll
-      for (int a = 0; a < D; ++a) {
-        w[a] = m.a[a];
-#pragma unroll
-        for (int b = 0; b < D; ++b) w[D + a * D + b] = P.a[a][b];
-      }
-    }
-  }
-  __syncthreads();
-  // reverse inclusive scan; the exclusive suffix of chunk i sits in slot i+1 afterwards
-  e = live ? load_delem<double, D>(own) : delem_identity<double, D>();
-  store_delem<double, D>(lds + i * NV, e);
-  __syncthreads();
-  for (int off = 1; off < kDenseCB; off <<= 1) {
-    const bool has = i + off < kDenseCB;
-    DElem<double, D> other;
-    if (has) other = load_delem<double, D>(lds + (i + off) * NV);
-    __syncthreads();
-    if (has) e = delem_combine(e, other);
-    store_delem<double, D>(lds + i * NV, e);
-    __syncthreads();
-  }
-  if (!live) return;
-  Vec<double, D> eta;
-  Mat<double, D> J;
-  const double* r = bsuffix + ((size_t)blk * G.K + k) * REC;
-#pragma unroll
-  for (int a = 0; a < D; ++a) {
-    eta.a[a] = r[a];
-#pragma unroll
-    for (int b = 0; b < D; ++b) J.a[a][b] = r[D + a * D + b];
-  }
-  if (i + 1 < kDenseCB) delem_back(load_delem<double, D>(lds + (i + 1) * NV), eta, J);
-  double* w = suffix + ((size_t)j * G.K + k) * REC;
-#pragma unroll
-  for (int a = 0; a < D; ++a) {
-    w[a] = eta.a[a];
-#pragma unroll
-    for (int b = 0; b < D; ++b) w[D + a * D + b] = J.a[a][b];
-  }
-}
-
 template <int D, bool EKF, typename Obs>
 __global__ __launch_bounds__(64) void dense_replay_kernel(DenseGeom G, DenseModelPtrs M,
                                                          const double* __restrict__ s, Obs obs,
-                                                         const double* __restrict__ prior,
-                                                         const double* __restrict__ suffix,
+                                                         const double* __restrict__ pre,
+                                                         const double* __restrict__ suf,
+                                                         const double* __restrict__ bprior,
+                                                         const double* __restrict__ bsuffix,
                                                          double* __restrict__ filt,
                                                          float* __restrict__ ms,
                                                          float* __restrict__ Vs, int vs_diag,
@@ -245,10 +177,12 @@ __global__ __launch_bounds__(64) void dense_replay_kernel(DenseGeom G, DenseMode
   Mat<double, D> F, sQ;
   bool fid;
   load_dynamics<double, D>(M, k, s[k], F, sQ, fid);
+  constexpr int NV = delem_doubles<D>();
   Vec<double, D> m, eta;
   Mat<double, D> P, J;
-  const double* rp = prior + (size_t)idx * REC;
-  const double* rs = suffix + (size_t)idx * REC;
+  const int blk = j / kDenseCB, i = j % kDenseCB;
+  const double* rp = bprior + ((size_t)blk * G.K + k) * REC;
+  const double* rs = bsuffix + ((size_t)blk * G.K + k) * REC;
 #pragma unroll
   for (int a = 0; a < D; ++a) {
     m.a[a] = rp[a];
@@ -259,6 +193,10 @@ __global__ __launch_bounds__(64) void dense_replay_kernel(DenseGeom G, DenseMode
       J.a[a][b] = rs[D + a * D + b];
     }
   }
+  // exclusive prefix / suffix of this chunk inside its block of 64
+  if (i > 0) delem_apply(load_delem<double, D>(pre + ((size_t)(j - 1) * G.K + k) * NV), m, P);
+  if (i + 1 < kDenseCB && j + 1 < G.nc)
+    delem_back(load_delem<double, D>(suf + ((size_t)(j + 1) * G.K + k) * NV), eta, J);
   if (j == 0) load_prior<D>(M, k, m, P);   // chunk 0 replays frame 0's update of the prior itself
   const int t0 = j * G.B, len = min(G.B, G.T - t0);
   double ll = 0.0, ch = 0.0;
@@ -297,7 +235,7 @@ size_t dense_smooth_workspace_bytes(int T, int K, int D, int O) {
   (void)O;
   const int B = dense_chunk(T, K), nc = (T + B - 1) / B, nblk = (nc + kDenseCB - 1) / kDenseCB;
   const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
-  return align_up((size_t)nc * K * nv * 8, 256) + 2 * align_up((size_t)nc * K * rec * 8, 256) +
+  return 3 * align_up((size_t)nc * K * nv * 8, 256) +
          align_up((size_t)nblk * K * nv * 8, 256) + 2 * align_up((size_t)nblk * K * rec * 8, 256) +
          align_up((size_t)T * K * rec * 8, 256) + align_up((size_t)K * rec * 8, 256);
 }
@@ -315,10 +253,10 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
   char* p = static_cast<char*>(ws);
   double* elems = reinterpret_cast<double*>(p);
   p += align_up((size_t)G.nc * K * nv * 8, 256);
-  double* prior = reinterpret_cast<double*>(p);
-  p += align_up((size_t)G.nc * K * rec * 8, 256);
-  double* suffix = reinterpret_cast<double*>(p);
-  p += align_up((size_t)G.nc * K * rec * 8, 256);
+  double* pre = reinterpret_cast<double*>(p);       // inclusive prefix / suffix elements per chunk
+  p += align_up((size_t)G.nc * K * nv * 8, 256);
+  double* suf = reinterpret_cast<double*>(p);
+  p += align_up((size_t)G.nc * K * nv * 8, 256);
   double* agg = reinterpret_cast<double*>(p);
   p += align_up((size_t)nblk * K * nv * 8, 256);
   double* bprior = reinterpret_cast<double*>(p);
@@ -341,18 +279,16 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
     {
       ProfScope ps("dense_scan", st);
       const dim3 sgrid(K, nblk);
-      hipLaunchKernelGGL(dense_scan_reduce_kernel<DD>, sgrid, dim3(kDenseCB), 0, st, G, elems, agg,
-                         open);
+      hipLaunchKernelGGL(dense_scan_kernel<DD>, sgrid, dim3(2 * kDenseCB), 0, st, G, elems, pre, suf,
+                         agg, open);
       hipLaunchKernelGGL(dense_scan_blocks_kernel<DD>, dim3((2 * K + 63) / 64), dim3(64), 0, st, G, nblk,
                          first, agg, bprior, bsuffix, open);
-      hipLaunchKernelGGL(dense_scan_local_kernel<DD>, sgrid, dim3(kDenseCB), 0, st, G, elems, bprior,
-                         bsuffix, prior, suffix, open);
     }
     {
       ProfScope ps("dense_replay", st);
       hipLaunchKernelGGL((dense_replay_kernel<DD, false, LinearObs<DD>>), dim3((lanes + 63) / 64),
-                         dim3(64), 0, st, G, M, Mm.s, obs, prior, suffix, filt, ms, Vs, vs_diag,
-                         nullptr, nullptr, nullptr, open);
+                         dim3(64), 0, st, G, M, Mm.s, obs, pre, suf, bprior, bsuffix, filt, ms, Vs,
+                         vs_diag, nullptr, nullptr, nullptr, open);
     }
   })
   return hip_status(hipGetLastError());
@@ -398,8 +334,8 @@ static size_t ekf_ws_layout(int T, int K, bool smooth, double** ptrs, char* base
   constexpr int D = 3;
   const int B = dense_chunk(T, K), nc = (T + B - 1) / B, nblk = (nc + kDenseCB - 1) / kDenseCB;
   const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
-  const size_t sizes[10] = {(size_t)nc * K * nv * 8,   (size_t)nc * K * rec * 8,
-                            (size_t)nc * K * rec * 8,  (size_t)nblk * K * nv * 8,
+  const size_t sizes[10] = {(size_t)nc * K * nv * 8,   (size_t)nc * K * nv * 8,
+                            (size_t)nc * K * nv * 8,   (size_t)nblk * K * nv * 8,
                             (size_t)nblk * K * rec * 8, (size_t)nblk * K * rec * 8,
                             smooth ? (size_t)T * K * rec * 8 : 0, (size_t)K * rec * 8,
                             (size_t)nc * K * 8,         (size_t)(kEkfMaxSweeps + 2) * 8};
@@ -427,7 +363,7 @@ int ekf_smooth(const eks_dims_t& d, int n_data_keypoints, const float* y, const 
   if (ws_bytes < ekf_smooth_workspace_bytes(T, K, smooth)) return EKS_ERR_WORKSPACE;
   double* w[10];
   ekf_ws_layout(T, K, smooth, w, static_cast<char*>(ws));
-  double *elems = w[0], *prior = w[1], *suffix = w[2], *agg = w[3], *bprior = w[4], *bsuffix = w[5],
+  double *elems = w[0], *pre = w[1], *suf = w[2], *agg = w[3], *bprior = w[4], *bsuffix = w[5],
          *filt = w[6], *first = w[7], *ll_chunk = w[8], *resid = w[9];
   DenseGeom G{K, T, O, dense_chunk(T, K), 0};
   G.nc = (T + G.B - 1) / G.B;
@@ -441,13 +377,12 @@ int ekf_smooth(const eks_dims_t& d, int n_data_keypoints, const float* y, const 
   auto sweep = [&](const Gate& gate, double* resid_out, bool with_smoother) {
     hipLaunchKernelGGL((dense_summarize_kernel<3, PinholeObs>), dim3((lanes + 63) / 64), dim3(64), 0,
                        st, G, M, Mm.s, obs, elems, first, gate);
-    hipLaunchKernelGGL(dense_scan_reduce_kernel<3>, sgrid, dim3(kDenseCB), 0, st, G, elems, agg, gate);
+    hipLaunchKernelGGL(dense_scan_kernel<3>, sgrid, dim3(2 * kDenseCB), 0, st, G, elems, pre, suf, agg,
+                       gate);
     hipLaunchKernelGGL(dense_scan_blocks_kernel<3>, dim3((2 * K + 63) / 64), dim3(64), 0, st, G, nblk,
                        first, agg, bprior, bsuffix, gate);
-    hipLaunchKernelGGL(dense_scan_local_kernel<3>, sgrid, dim3(kDenseCB), 0, st, G, elems, bprior,
-                       bsuffix, prior, suffix, gate);
     hipLaunchKernelGGL((dense_replay_kernel<3, true, PinholeObs>), dim3((lanes + 63) / 64), dim3(64),
-                       0, st, G, M, Mm.s, obs, prior, suffix, with_smoother ? filt : nullptr,
+                       0, st, G, M, Mm.s, obs, pre, suf, bprior, bsuffix, with_smoother ? filt : nullptr,
                        with_smoother ? ms : nullptr, Vs, vs_diag, xlin, ll_chunk, resid_out, gate);
   };
   {
