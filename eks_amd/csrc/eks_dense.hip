@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void dense_summarize_kernel(DenseGeom G, DenseM
 //                64..127 run the inclusive REVERSE scan in a second LDS array (the two are
 //                independent, so the depth is 6 compositions, not 12); both are written out per
 //                chunk, the forward total is the block aggregate
-//   DS2 blocks : per keypoint, forward / backward walk over the few block aggregates
+//   DS2 blocks : per keypoint, the same two-sided scan over the block aggregates
 //   (replay)   : each replay lane applies its exclusive prefix (the inclusive prefix of chunk i-1)
 //                to the block's incoming belief and pulls the block's outgoing information back
 //                through its exclusive suffix (the inclusive suffix of chunk i+1) - one apply and
@@ -109,51 +109,72 @@ __global__ __launch_bounds__(2 * kDenseCB) void dense_scan_kernel(DenseGeom G,
   if (!rev && i == kDenseCB - 1) store_delem<double, D>(agg + ((size_t)blk * G.K + k) * NV, e);
 }
 
+// DS2: one workgroup per keypoint scans the block aggregates the same way (threads 0..63 forward,
+// 64..127 reverse), 64 aggregates per round with the running belief / information carried from
+// round to round (the forward half walks the rounds upwards, the reverse half downwards).
 template <int D>
-__global__ __launch_bounds__(64) void dense_scan_blocks_kernel(DenseGeom G, int nblk,
-                                                              const double* __restrict__ first,
-                                                              const double* __restrict__ agg,
-                                                              double* __restrict__ bprior,
-                                                              double* __restrict__ bsuffix,
-                                                              Gate gate) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= 2 * G.K || gate.closed()) return;
+__global__ __launch_bounds__(2 * kDenseCB) void dense_scan_blocks_kernel(DenseGeom G, int nblk,
+                                                                         const double* __restrict__ first,
+                                                                         const double* __restrict__ agg,
+                                                                         double* __restrict__ bprior,
+                                                                         double* __restrict__ bsuffix,
+                                                                         Gate gate) {
   constexpr int REC = D + D * D;
   constexpr int NV = delem_doubles<D>();
-  const int k = idx % G.K;
-  if (idx < G.K) {
-    Vec<double, D> m;
-    Mat<double, D> P;
+  __shared__ double lds[2 * kDenseCB * NV];
+  if (gate.closed()) return;
+  const int k = blockIdx.x;
+  const bool rev = threadIdx.x >= kDenseCB;
+  const int i = threadIdx.x - (rev ? kDenseCB : 0);
+  double* mine = lds + (rev ? kDenseCB * NV : 0);
+  // every thread of a half carries its own copy of the running state (same arithmetic, same value)
+  Vec<double, D> cv = vec_zero<double, D>();
+  Mat<double, D> cM = mat_zero<double, D>();
+  if (!rev) {
     const double* f0 = first + (size_t)k * REC;
 #pragma unroll
     for (int a = 0; a < D; ++a) {
-      m.a[a] = f0[a];
+      cv.a[a] = f0[a];
 #pragma unroll
-      for (int b = 0; b < D; ++b) P.a[a][b] = f0[D + a * D + b];
+      for (int b = 0; b < D; ++b) cM.a[a][b] = f0[D + a * D + b];
     }
-    for (int q = 0; q < nblk; ++q) {
-      double* r = bprior + ((size_t)q * G.K + k) * REC;
+  }
+  const int rounds = (nblk + kDenseCB - 1) / kDenseCB;
+  for (int r = 0; r < rounds; ++r) {
+    const int q = (rev ? rounds - 1 - r : r) * kDenseCB + i;
+    const bool live = q < nblk;
+    DElem<double, D> e = live ? load_delem<double, D>(agg + ((size_t)q * G.K + k) * NV)
+                              : delem_identity<double, D>();
+    store_delem<double, D>(mine + i * NV, e);
+    __syncthreads();
+    for (int off = 1; off < kDenseCB; off <<= 1) {
+      const bool has = rev ? (i + off < kDenseCB) : (i >= off);
+      DElem<double, D> other;
+      if (has) other = load_delem<double, D>(mine + (rev ? i + off : i - off) * NV);
+      __syncthreads();
+      if (has) e = rev ? delem_combine(e, other) : delem_combine(other, e);
+      store_delem<double, D>(mine + i * NV, e);
+      __syncthreads();
+    }
+    Vec<double, D> v = cv;
+    Mat<double, D> Mx = cM;
+    if (!rev) {
+      if (i > 0) delem_apply(load_delem<double, D>(mine + (i - 1) * NV), v, Mx);
+      delem_apply(load_delem<double, D>(mine + (kDenseCB - 1) * NV), cv, cM);
+    } else {
+      if (i + 1 < kDenseCB) delem_back(load_delem<double, D>(mine + (i + 1) * NV), v, Mx);
+      delem_back(load_delem<double, D>(mine), cv, cM);
+    }
+    if (live) {
+      double* w = (rev ? bsuffix : bprior) + ((size_t)q * G.K + k) * REC;
 #pragma unroll
       for (int a = 0; a < D; ++a) {
-        r[a] = m.a[a];
+        w[a] = v.a[a];
 #pragma unroll
-        for (int b = 0; b < D; ++b) r[D + a * D + b] = P.a[a][b];
+        for (int b = 0; b < D; ++b) w[D + a * D + b] = Mx.a[a][b];
       }
-      delem_apply(load_delem<double, D>(agg + ((size_t)q * G.K + k) * NV), m, P);
     }
-  } else {
-    Vec<double, D> eta = vec_zero<double, D>();
-    Mat<double, D> J = mat_zero<double, D>();
-    for (int q = nblk - 1; q >= 0; --q) {
-      double* r = bsuffix + ((size_t)q * G.K + k) * REC;
-#pragma unroll
-      for (int a = 0; a < D; ++a) {
-        r[a] = eta.a[a];
-#pragma unroll
-        for (int b = 0; b < D; ++b) r[D + a * D + b] = J.a[a][b];
-      }
-      delem_back(load_delem<double, D>(agg + ((size_t)q * G.K + k) * NV), eta, J);
-    }
+    __syncthreads();
   }
 }
 
@@ -216,19 +237,21 @@ __global__ __launch_bounds__(64) void dense_replay_kernel(DenseGeom G, DenseMode
 // ------------------------------------------------------------------------------------------
 constexpr int kDenseSmoothChunk = 32;   // frames per lane in the smoother (the scan is parallel)
 
-// Frames per lane for a (T, K) problem.  These problems are small (a handful of keypoints), so
-// shorter chunks buy lanes and cut the sequential depth of summarize / replay, at the price of
-// more chunk elements for the scan.  EKS_DENSE_CHUNK overrides (measurement knob).
-static int dense_chunk(int T, int K) {
+// Frames per lane for a (T, K) problem.  Shorter chunks buy lanes and cut the sequential depth of
+// summarize / replay; the two-level scan costs about the same up to 64 x 64 chunks per keypoint.
+// Linear path: 16 frames while that does not oversubscribe the device (measured on BASELINE config
+// 4, T = 50 000 x K = 4: 0.202 ms at 32, 0.148 at 16, 0.154 at 8), else 32.  Extended filter: 32
+// (its sweeps converge chunk-wise: 16-frame chunks are shorter than the filter's memory and need
+// 8+ sweeps where 32-frame chunks need 3).  EKS_DENSE_CHUNK overrides (measurement knob).
+static int dense_chunk(int T, int K, bool ekf = false) {
   static const int forced = [] {
     const char* e = getenv("EKS_DENSE_CHUNK");
     const int v = e ? atoi(e) : 0;
     return v >= 2 && v <= 256 ? v : 0;
   }();
   if (forced) return forced;
-  (void)T;
-  (void)K;
-  return kDenseSmoothChunk;
+  if (ekf) return kDenseSmoothChunk;
+  return (long long)K * ((T + 15) / 16) <= (1 << 18) ? 16 : kDenseSmoothChunk;
 }
 
 size_t dense_smooth_workspace_bytes(int T, int K, int D, int O) {
@@ -281,7 +304,7 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
       const dim3 sgrid(K, nblk);
       hipLaunchKernelGGL(dense_scan_kernel<DD>, sgrid, dim3(2 * kDenseCB), 0, st, G, elems, pre, suf,
                          agg, open);
-      hipLaunchKernelGGL(dense_scan_blocks_kernel<DD>, dim3((2 * K + 63) / 64), dim3(64), 0, st, G, nblk,
+      hipLaunchKernelGGL(dense_scan_blocks_kernel<DD>, dim3(K), dim3(2 * kDenseCB), 0, st, G, nblk,
                          first, agg, bprior, bsuffix, open);
     }
     {
@@ -332,7 +355,7 @@ __global__ __launch_bounds__(64) void ekf_finish_kernel(int K, int nc, int n_swe
 
 static size_t ekf_ws_layout(int T, int K, bool smooth, double** ptrs, char* base) {
   constexpr int D = 3;
-  const int B = dense_chunk(T, K), nc = (T + B - 1) / B, nblk = (nc + kDenseCB - 1) / kDenseCB;
+  const int B = dense_chunk(T, K, true), nc = (T + B - 1) / B, nblk = (nc + kDenseCB - 1) / kDenseCB;
   const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
   const size_t sizes[10] = {(size_t)nc * K * nv * 8,   (size_t)nc * K * nv * 8,
                             (size_t)nc * K * nv * 8,   (size_t)nblk * K * nv * 8,
@@ -365,7 +388,7 @@ int ekf_smooth(const eks_dims_t& d, int n_data_keypoints, const float* y, const 
   ekf_ws_layout(T, K, smooth, w, static_cast<char*>(ws));
   double *elems = w[0], *pre = w[1], *suf = w[2], *agg = w[3], *bprior = w[4], *bsuffix = w[5],
          *filt = w[6], *first = w[7], *ll_chunk = w[8], *resid = w[9];
-  DenseGeom G{K, T, O, dense_chunk(T, K), 0};
+  DenseGeom G{K, T, O, dense_chunk(T, K, true), 0};
   G.nc = (T + G.B - 1) / G.B;
   const int nblk = (G.nc + kDenseCB - 1) / kDenseCB, lanes = K * G.nc;
   const DenseModelPtrs M{Mm.m0, Mm.S0, Mm.A, nullptr, Mm.Q};
@@ -379,7 +402,7 @@ int ekf_smooth(const eks_dims_t& d, int n_data_keypoints, const float* y, const 
                        st, G, M, Mm.s, obs, elems, first, gate);
     hipLaunchKernelGGL(dense_scan_kernel<3>, sgrid, dim3(2 * kDenseCB), 0, st, G, elems, pre, suf, agg,
                        gate);
-    hipLaunchKernelGGL(dense_scan_blocks_kernel<3>, dim3((2 * K + 63) / 64), dim3(64), 0, st, G, nblk,
+    hipLaunchKernelGGL(dense_scan_blocks_kernel<3>, dim3(K), dim3(2 * kDenseCB), 0, st, G, nblk,
                        first, agg, bprior, bsuffix, gate);
     hipLaunchKernelGGL((dense_replay_kernel<3, true, PinholeObs>), dim3((lanes + 63) / 64), dim3(64),
                        0, st, G, M, Mm.s, obs, pre, suf, bprior, bsuffix, with_smoother ? filt : nullptr,
