@@ -179,12 +179,17 @@ def optimize_smooth_param(ys, m0s, S0s, As, Cs, Qs, Rs, blocks, s_finals, s_fram
     """One s per block of keypoints by Adam on log s over the summed constant-R filter NLL
     (reference eks/core.py:306-559, :562-699).  `Rs` is the reference's (K,T,O,O) stack of
     diagonal R_t; only its diagonal is used.  Writes `s_finals` in place."""
-    if h_fn_combined is not None:
-        raise NotImplementedError('nonlinear emission functions are outside the accelerated path')
     K = np.shape(ys)[0]
     if not blocks:
         blocks = [[k] for k in range(K)]
     Rd = np.diagonal(_to_numpy(Rs), axis1=-2, axis2=-1)                 # (K,T,O)
+    if h_fn_combined is not None:       # calibrated projection: extended filter (reference :478-510)
+        s, _, _ = _run_kalman_smoother_pinhole(
+            ys, m0s, S0s, As, Qs, np.swapaxes(Rd, 0, 1), h_fn_combined, s_frames, None, blocks, lr,
+            s_bounds_log, tol, safety_cap, 'adam', 0, True, True, None,
+            guesses=np.asarray(s_guess_per_k, float))
+        s_finals[:] = s
+        return
     P = _DeviceProblem(ys, m0s, S0s, As, Cs, Qs, np.swapaxes(Rd, 0, 1))
     s, info = _optimize_on_device(P, blocks, s_frames, np.asarray(s_guess_per_k, float), lr,
                                   s_bounds_log, tol, safety_cap, min_R_var, 'adam', 0)
@@ -195,7 +200,7 @@ def optimize_smooth_param(ys, m0s, S0s, As, Cs, Qs, Rs, blocks, s_finals, s_fram
 def _run_kalman_smoother_pinhole(ys, m0s, S0s, As, Qs, ensemble_vars, h_fn, s_frames, smooth_param,
                                  blocks, lr, s_bounds_log, tol, safety_cap, s_mode, n_grid, vs_diag,
                                  return_device, x_init, fd_step: float = 1e-3,
-                                 lin_tol: float = 1e-10, max_sweeps: int = 16):
+                                 lin_tol: float = 1e-10, max_sweeps: int = 16, guesses=None):
     """run_kalman_smoother with the calibrated multi-camera projection (reference eks/core.py:
     159-302 with h_fn; optimiser :562-699 / :306-559).  Extended filter = eks_ekf_smooth.  The
     reference differentiates the loss through the filter (jax.value_and_grad); here d NLL / d log s
@@ -272,12 +277,13 @@ def _run_kalman_smoother_pinhole(ys, m0s, S0s, As, Qs, ensemble_vars, h_fn, s_fr
             s_dev = s_blk[torch.as_tensor(of_kp, device=dev)].contiguous()
             info = dict(mode='grid', nll=nll, argmin=amin, candidates=cand)
         else:
-            ev_host = _to_numpy(ensemble_vars)[:2000] if not hasattr(ensemble_vars, 'detach') \
-                else ensemble_vars[:2000].detach().cpu().numpy()
-            guesses = np.full(K, 2.0)
-            for k in range(K):
-                g = float(compute_initial_guesses(ev_host[:, k, :]) or 2.0)
-                guesses[k] = g if (np.isfinite(g) and g > 0.0) else 2.0
+            if guesses is None:
+                ev_host = _to_numpy(ensemble_vars)[:2000] if not hasattr(ensemble_vars, 'detach') \
+                    else ensemble_vars[:2000].detach().cpu().numpy()
+                guesses = np.full(K, 2.0)
+                for k in range(K):
+                    g = float(compute_initial_guesses(ev_host[:, k, :]) or 2.0)
+                    guesses[k] = g if (np.isfinite(g) and g > 0.0) else 2.0
             u0 = np.array([np.float32(np.log(np.clip(np.mean([guesses[k] for k in b]), 1e-6, 1e3)))
                            for b in blocks], dtype=np.float64)
             state = np.zeros((nb, 6))

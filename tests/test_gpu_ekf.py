@@ -215,3 +215,19 @@ def test_calibrated_multicam_driver_end_to_end():
             np.testing.assert_allclose(got[:, k, 3:5], st[c, :, k, 0:2], rtol=1e-6)
             np.testing.assert_allclose(got[:, k, 5:7], st[c, :, k, 2:4], rtol=1e-5)
             np.testing.assert_allclose(got[:, k, 2], st[c, :, k, 4], rtol=1e-6)
+
+
+def test_optimize_smooth_param_with_projection_writes_s_in_place():
+    from eks_amd.core import optimize_smooth_param, run_kalman_smoother
+    T, K, V = 300, 2, 2
+    prob = synth.calibrated_multicam(T, K, V, seed=13)
+    h = cal.PinholeProjection(prob['cams_packed'])
+    ys = np.swapaxes(prob['y_tko'], 0, 1)
+    Rs = np.stack([[np.diag(r) for r in np.maximum(prob['var_tko'][:, k], 1e-12)] for k in range(K)])
+    guesses = [orc.compute_initial_guess(prob['var_tko'][:, k, :]) for k in range(K)]
+    s_finals = np.zeros(K)
+    optimize_smooth_param(ys, prob['m0s'], prob['S0s'], prob['As'], None, prob['Qs'], Rs, None, s_finals,
+                          None, guesses, tol=1e-2, h_fn_combined=h)
+    s_ref, _, _ = run_kalman_smoother(ys, prob['m0s'], prob['S0s'], prob['As'], None, prob['Qs'],
+                                      prob['var_tko'], h_fn=h)
+    np.testing.assert_allclose(s_finals, s_ref, rtol=1e-12)
