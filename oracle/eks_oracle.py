@@ -3,7 +3,9 @@
 This file is a from-scratch restatement of the algorithm the reference runs on its hot path
 (`run_kalman_smoother`, /root/reference/eks/core.py:159-302) and of the host-side stages either
 side of it.  It exists to check the HIP kernels; nothing under ``eks_amd/`` may import it.  Only
-``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg use it.
+``tests/`` (and the parity-sweep / check scripts under ``tools/`` that ``tests/test_gpu_fuzz.py``
+drives), ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg use it - always as
+the checker, never as the thing measured or shipped.
 
 PARITY UNPINNED: the reference's arithmetic lives in third-party ``dynamax`` (pyproject.toml:39-46
 pins ``dynamax<=1.0.1``; jax/jaxlib/optax unpinned), which together with ``jax`` is absent from this
