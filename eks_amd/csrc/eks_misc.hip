@@ -26,10 +26,11 @@ __device__ __forceinline__ uint32_t var_key(float v, bool& valid) {
 //                (coalesced both ways; 4 % of the data).
 //   S2 bracket : per chain, the sample's order statistics 4.5 sigma either side of its median
 //                (two histogram passes in LDS) bracket the true median: [lo, hi] holds ~6 % of the frames.
-//   S3 collect : the full pass.  Lanes = chains, 128 rows per wave with 32 loads in flight per
+//   S3 collect : the full pass.  Lanes = chains, 64 rows per wave in two flights of 32 loads per
 //                lane; frames below lo and valid frames are counted in registers, frames inside
-//                [lo, hi] are staged per chain in LDS by the 8 waves of a block and appended to
-//                the chain's list as one contiguous run (one global atomic per chain and block).
+//                [lo, hi] are staged per chain and wave in LDS (branch-free, register slot
+//                counters) and appended to the chain's list as one contiguous run per block
+//                (one global atomic per chain and block).
 //   S4 finish  : per chain, exact selection of the two middle ranks inside the list (radix select
 //                in LDS).
 // A chain whose bracket misses the median, or whose bracket holds more than kMedList frames
@@ -43,10 +44,9 @@ __device__ __forceinline__ uint32_t var_key(float v, bool& valid) {
 constexpr int kMedSmall = 1024;      // T up to here: one block per chain selects from the column
 constexpr int kMedSamples = 4096;    // sample rows per chain (fewer for short sequences)
 constexpr int kMedList = 16384;      // capacity of a chain's in-bracket list
-constexpr int kColRows = 128;        // rows per wave in the full pass
+constexpr int kColRows = 64;        // rows per wave in the full pass
 constexpr int kColFlight = 32;       // loads in flight per lane
 constexpr int kColWaves = 8;         // waves per block of the full pass (same 64 chains)
-constexpr int kColStage = 160;      // per-chain LDS staging slots per block (expected ~75 in-bracket keys)
 
 struct BracketWs {
   uint32_t *lo, *hi, *less, *valid, *cnt;   // [N]
@@ -297,74 +297,112 @@ __global__ __launch_bounds__(256) void sample_bracket_kernel(int N, int S, Brack
   }
 }
 
-// S3: the full pass.  Block = 8 waves over the SAME 64 chains (8 consecutive 128-row slabs);
-// in-bracket keys are staged per chain in LDS and written out as whole runs, one global atomic
-// per chain and block.
+// S3: the full pass.  Block = 8 waves over the SAME 64 chains (8 consecutive 64-row slabs, two
+// flights of 32 loads per lane).  Every wave stages its in-bracket keys per chain in its OWN LDS
+// slots with the slot counter in a register - no atomics and no branches on the per-row path.
+// After the barrier the runs of the 8 waves are written out back to back, one global atomic per
+// chain and block.
+constexpr int kColSlots = 16;   // expected 64 rows x ~7 % = 4.5 in-bracket keys per lane and wave
+static_assert(kColWaves == 8, "the run write-out maps lanes to (8 source waves) x (8 slots)");
+
 __global__ __launch_bounds__(64 * kColWaves) void bracket_collect_kernel(int T, int N,
                                                                         const float* __restrict__ var,
                                                                         BracketWs B) {
-  __shared__ uint32_t stage[kColStage][65];      // [slot][chain], padded: both phases conflict-free
-  __shared__ uint32_t staged[64], base[64];
+  __shared__ uint32_t stage[kColWaves][kColSlots][65];   // [wave][slot][chain], padded
+  __shared__ uint32_t counts[kColWaves][64], base[64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int ntile = (N + 63) / 64;
   const int tile = blockIdx.x % ntile, slab = blockIdx.x / ntile;
   const int n = tile * 64 + lane;
-  if (w == 0) staged[lane] = 0u;
-  __syncthreads();
   const bool live = n < N && !B.fallback[n];
   const int t_begin = (slab * kColWaves + w) * kColRows;
   const int t_end = min(T, t_begin + kColRows);
-  uint32_t less = 0, nvalid = 0;
+  uint32_t less = 0, nvalid = 0, mine = 0;
   if (live && t_begin < T) {
-    const uint32_t lo = B.lo[n], hi = B.hi[n];
+    const uint32_t lo = B.lo[n], span = B.hi[n] - lo, cap = (uint32_t)kColSlots - 1u;
     // rows through a buffer resource based at this wave's first row and tile: the row offset is
-    // scalar arithmetic, rows past t_end fall outside num_records and read 0 -> replaced by NaN
+    // scalar arithmetic
     const int t_beg_u = __builtin_amdgcn_readfirstlane(t_begin);
     const int rows = __builtin_amdgcn_readfirstlane(t_end - t_begin);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(var + (size_t)t_beg_u * N + tile * 64), 0, 0x7FFFFFFF, 0x00020000);
     const unsigned voff = (unsigned)lane * 4u, row_bytes = (unsigned)N * 4u;
-    for (int t = 0; t < rows; t += kColFlight) {
-      float v[kColFlight];
-#pragma unroll
-      for (int u = 0; u < kColFlight; ++u)
-        v[u] = t + u < rows ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                  rsrc, voff, (unsigned)(t + u) * row_bytes, 0))
-                            : __uint_as_float(0x7FC00000u);
+    // branch-free per key: it is written to the lane's next slot and the slot only advances for
+    // an in-bracket key (LDS write bandwidth is nowhere near a limit; per-element branches and the
+    // mask bookkeeping they forced on the compiler were).  Slot kColSlots-1 is scratch; a lane
+    // that finds more in-bracket keys than slots (heavy duplicates) keeps counting and appends the
+    // surplus directly afterwards (rescan below).
+    auto eat = [&](const float (&v)[kColFlight]) {
 #pragma unroll
       for (int u = 0; u < kColFlight; ++u) {
         bool valid;
         const uint32_t key = var_key(v[u], valid);
         nvalid += valid;
         less += valid && key < lo;
-        if (valid && key >= lo && key <= hi) {
-          const uint32_t pos = atomicAdd(&staged[lane], 1u);
-          if (pos < (uint32_t)kColStage) {
-            stage[pos][lane] = key;
-          } else {                                    // staging full (heavy duplicates): go direct
-            const uint32_t g = atomicAdd(&B.cnt[n], 1u);
-            if (g < (uint32_t)kMedList) B.list[(size_t)n * kMedList + g] = key;
-          }
+        const bool in = valid && (key - lo) <= span;
+        stage[w][mine < cap ? mine : cap][lane] = key;
+        mine += in;
+      }
+    };
+    if (rows == kColRows) {          // whole slab: unconditional loads, kColFlight in flight
+      for (int t = 0; t < kColRows; t += kColFlight) {
+        float v[kColFlight];
+#pragma unroll
+        for (int u = 0; u < kColFlight; ++u)
+          v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+              rsrc, voff, (unsigned)(t + u) * row_bytes, 0));
+        eat(v);
+      }
+    } else {                         // the ragged last slab: rows past the end count as NaN
+      for (int t = 0; t < rows; t += kColFlight) {
+        float v[kColFlight];
+#pragma unroll
+        for (int u = 0; u < kColFlight; ++u)
+          v[u] = t + u < rows ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                    rsrc, voff, (unsigned)(t + u) * row_bytes, 0))
+                              : __uint_as_float(0x7FC00000u);
+        eat(v);
+      }
+    }
+    if (mine > cap) {       // rare: rescan this lane's rows (L2-hot) and append the keys past the slots
+      uint32_t seen = 0;
+      for (int t = 0; t < rows; ++t) {
+        bool valid;
+        const uint32_t key = var_key(var[(size_t)(t_begin + t) * N + n], valid);
+        if (valid && (key - lo) <= span && seen++ >= cap) {
+          const uint32_t g = atomicAdd(&B.cnt[n], 1u);
+          if (g < (uint32_t)kMedList) B.list[(size_t)n * kMedList + g] = key;
         }
       }
+      mine = cap;
     }
     if (less) atomicAdd(&B.less[n], less);
     if (nvalid) atomicAdd(&B.valid[n], nvalid);
   }
+  counts[w][lane] = mine;
   __syncthreads();
-  if (w == 0 && live) {
-    const uint32_t c = min(staged[lane], (uint32_t)kColStage);
-    staged[lane] = c;
-    base[lane] = c ? atomicAdd(&B.cnt[n], c) : 0u;
+  if (w == 0) {
+    uint32_t tot = 0;
+#pragma unroll
+    for (int q = 0; q < kColWaves; ++q) tot += counts[q][lane];
+    base[lane] = tot ? atomicAdd(&B.cnt[n], tot) : 0u;     // tot > 0 implies a live chain
   }
   __syncthreads();
-  // wave w writes the runs of chains w, w + 8, ...: lanes along the run (contiguous in memory)
+  // wave w writes the runs of chains w, w + 8, ...; lane = (source wave, slot within a group of 8)
+  const int sw = lane >> 3, sq = lane & 7;
   for (int c = w; c < 64; c += kColWaves) {
     const int nn = tile * 64 + c;
     if (nn >= N) break;
-    const uint32_t cnt = staged[c], b = base[c];
-    for (uint32_t q = lane; q < cnt; q += 64)
-      if (b + q < (uint32_t)kMedList) B.list[(size_t)nn * kMedList + b + q] = stage[q][c];
+    uint32_t off = base[c];
+#pragma unroll
+    for (int q = 0; q < kColWaves; ++q) off += q < sw ? counts[q][c] : 0u;
+    const uint32_t cnt = counts[sw][c];
+#pragma unroll
+    for (int q0 = 0; q0 < kColSlots; q0 += 8) {
+      const uint32_t q = (uint32_t)(q0 + sq);
+      if (q < cnt && off + q < (uint32_t)kMedList)
+        B.list[(size_t)nn * kMedList + off + q] = stage[sw][q][c];
+    }
   }
 }
 
