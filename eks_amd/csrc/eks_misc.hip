@@ -145,6 +145,113 @@ __device__ uint32_t lds_radix_select(const uint32_t* vals, int L, uint32_t rank,
   return (prefix >> lsh) + base;
 }
 
+// Same selection, but after the first histogram pass the keys of the rank's bin (about L / 256 of
+// them once the keys are range-normalised) are compacted into `small` and the rank is resolved
+// there by counting - one more sweep over the list instead of three.  Also returns, when it lies
+// in the same bin, the next order statistic (rank + 1) through *next (has_next says whether it
+// did).  Bins with more than kSelSmall keys (heavy duplicates) take the remaining radix passes.
+// hist: 256 counters, sh: 6 words, small: kSelSmall words of LDS.
+constexpr int kSelSmall = 256;
+
+__device__ uint32_t lds_select_compact(const uint32_t* vals, int L, uint32_t rank, uint32_t base, int lsh,
+                                       uint32_t* hist, uint32_t* sh, uint32_t* small, uint32_t* next,
+                                       bool* has_next) {
+  hist[threadIdx.x] = 0u;
+  if (threadIdx.x == 0) sh[3] = 0u;
+  __syncthreads();
+  for (int i = threadIdx.x; i < L; i += 256) atomicAdd(&hist[radix_norm(vals[i], base, lsh) >> 24], 1u);
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    uint32_t c[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c[q] = hist[4 * lane + q];
+    const uint32_t mine = c[0] + c[1] + c[2] + c[3];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = __shfl_up(incl, off);
+      if (lane >= off) incl += up;
+    }
+    uint32_t cum = incl - mine;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (rank >= cum && rank < cum + c[q]) {
+        sh[0] = (uint32_t)(4 * lane + q);     // the bin
+        sh[1] = rank - cum;                   // rank inside the bin
+        sh[2] = c[q];                         // keys in the bin
+      }
+      cum += c[q];
+    }
+  }
+  __syncthreads();
+  const uint32_t bin = sh[0], q_in = sh[1], m = sh[2];
+  __syncthreads();
+  if (m > (uint32_t)kSelSmall) {              // heavy duplicates: finish with the radix passes
+    *has_next = false;
+    uint32_t prefix = bin;
+    uint32_t r = q_in;
+    for (int pass = 1; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      hist[threadIdx.x] = 0u;
+      __syncthreads();
+      for (int i = threadIdx.x; i < L; i += 256) {
+        const uint32_t key = radix_norm(vals[i], base, lsh);
+        if ((key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        uint32_t c[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q] = hist[4 * lane + q];
+        const uint32_t mine = c[0] + c[1] + c[2] + c[3];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t up = __shfl_up(incl, off);
+          if (lane >= off) incl += up;
+        }
+        uint32_t cum = incl - mine;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (r >= cum && r < cum + c[q]) {
+            sh[0] = (prefix << 8) | (uint32_t)(4 * lane + q);
+            sh[1] = r - cum;
+          }
+          cum += c[q];
+        }
+      }
+      __syncthreads();
+      prefix = sh[0];
+      r = sh[1];
+      __syncthreads();
+    }
+    return (prefix >> lsh) + base;
+  }
+  for (int i = threadIdx.x; i < L; i += 256) {
+    const uint32_t key = radix_norm(vals[i], base, lsh);
+    if ((key >> 24) == bin) small[atomicAdd(&sh[3], 1u)] = key;
+  }
+  __syncthreads();
+  const bool want_next = q_in + 1u < m;
+  if (threadIdx.x < (int)m) {                 // m <= 256: one key per thread, counted against all
+    const uint32_t v = small[threadIdx.x];
+    uint32_t less = 0, eq = 0;
+    for (uint32_t j = 0; j < m; ++j) {
+      const uint32_t o = small[j];
+      less += o < v;
+      eq += o == v;
+    }
+    if (less <= q_in && q_in < less + eq) sh[4] = v;                       // equal keys write the same value
+    if (want_next && less <= q_in + 1u && q_in + 1u < less + eq) sh[5] = v;
+  }
+  __syncthreads();
+  *has_next = want_next;
+  if (want_next) *next = (sh[5] >> lsh) + base;
+  return (sh[4] >> lsh) + base;
+}
+
 // Bracket two ranks r_lo <= r_hi of vals[0..L) at 16-bit resolution of the normalised keys: two
 // histogram passes (the second one refines the two first-pass bins at once) instead of two exact
 // radix selects.  Returns the low edge of r_lo's cell and the high edge of r_hi's: every key of
@@ -496,7 +603,7 @@ __global__ __launch_bounds__(256) void bracket_finish_kernel(int T, int N, const
                                                             double min_var, BracketWs B,
                                                             double* __restrict__ rconst) {
   __shared__ uint32_t vals[kMedList];
-  __shared__ uint32_t hist[256];
+  __shared__ uint32_t hist[256], small[kSelSmall];
   __shared__ uint32_t sh[2], sc[6];
   const int n = blockIdx.x;
   const uint32_t cnt = B.valid[n], less = B.less[n], inside = B.cnt[n];
@@ -512,9 +619,14 @@ __global__ __launch_bounds__(256) void bracket_finish_kernel(int T, int N, const
   __syncthreads();
   const uint32_t blo = B.lo[n], bhi = B.hi[n];          // every listed key lies in [blo, bhi]
   const int lsh = bhi > blo ? __clz((int)(bhi - blo)) : 0;
-  const uint32_t v_lo = lds_radix_select(vals, (int)inside, r_lo - less, blo, lsh, hist, sh);
+  uint32_t nxt_in_bin = 0;
+  bool has_next = false;
+  const uint32_t v_lo = lds_select_compact(vals, (int)inside, r_lo - less, blo, lsh, hist, sc, small,
+                                           &nxt_in_bin, &has_next);
   uint32_t v_hi = v_lo;
-  if (r_hi != r_lo) {
+  if (r_hi != r_lo && has_next) {
+    v_hi = nxt_in_bin;                       // the upper middle rank sits in the same first-pass bin
+  } else if (r_hi != r_lo) {
     // the upper middle rank is v_lo again if enough keys are <= v_lo, else the next larger key
     if (threadIdx.x == 0) {
       sh[0] = 0u;
