@@ -79,6 +79,17 @@ def drain_profile(lib):
     return out
 
 
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(y_dev, var_dev, T, n_cand, budget_s):
     """Time the C twin of the oracle (general-matrix port of the reference recursion, OpenMP over
     keypoints) on a bounded sample of the same workload: the first Kc keypoints, all T frames."""
@@ -109,6 +120,7 @@ def cpu_baseline(y_dev, var_dev, T, n_cand, budget_s):
     dt = time.perf_counter() - t0
     ref = dict(nll=nll if n_cand else None, ms=ms_cpu, Vs=Vs_cpu)
     return dict(value=T * Kc / dt, unit='frames*keypoints/s', cores=cores, kind='port',
+                cpu_model=_cpu_model(),
                 sample=f'first {Kc} of the keypoints x all {T} frames of the same workload '
                        f'({n_cand}-candidate NLL grid + smooth), float64 C port of the reference '
                        f'recursion (oracle/eks_oracle.c), OpenMP over keypoints, {dt:.1f} s'), s, ref
