@@ -15,6 +15,7 @@ for the smoothing parameter.  There is no CPU fallback.
 from __future__ import annotations
 
 import logging
+import os
 import time
 from typing import Callable, Literal
 
@@ -31,6 +32,22 @@ logger = logging.getLogger(__name__)
 def _torch():
     import torch
     return torch
+
+
+def _to_host(*tensors):
+    """Device tensors -> NumPy through page-locked staging buffers (torch's caching host
+    allocator keeps them across calls): the D2H copies run at the link rate instead of the
+    pageable rate, and overlap each other.  The arrays alias the staging tensors, which stay
+    alive as their `.base`."""
+    torch = _torch()
+    # very large results stay pageable: page-locked memory is a scarce host resource
+    if os.environ.get('EKS_PAGEABLE_D2H') or sum(t.numel() * t.element_size() for t in tensors) > (2 << 30):
+        return tuple(t.cpu().numpy() for t in tensors)
+    host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]
+    for h, t in zip(host, tensors):
+        h.copy_(t, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return tuple(h.numpy() for h in host)
 
 
 def _to_numpy(a, dtype=None) -> np.ndarray:
@@ -53,7 +70,7 @@ def ensemble(marker_array: MarkerArray, avg_mode: Literal['mean', 'median'] = 'm
         arr = arr[..., [fields.index(f) for f in ('x', 'y', 'likelihood')]]
     mk = torch.as_tensor(np.ascontiguousarray(arr, dtype=np.float32), device=dev)
     stats = hip_ops.ensemble(mk, avg_mode, var_mode, nan_replacement)
-    return MarkerArray(stats.cpu().numpy()[None], data_fields=['x', 'y', 'var_x', 'var_y', 'likelihood'])
+    return MarkerArray(_to_host(stats)[0][None], data_fields=['x', 'y', 'var_x', 'var_y', 'likelihood'])
 
 
 def compute_initial_guesses(ensemble_vars) -> float:
@@ -327,7 +344,8 @@ def _run_kalman_smoother_pinhole(ys, m0s, S0s, As, Qs, ensemble_vars, h_fn, s_fr
                        'the sequential extended Kalman filter')
     if return_device:
         return s_finals, ms.transpose(0, 1), Vs.transpose(0, 1)
-    return s_finals, np.swapaxes(ms.cpu().numpy(), 0, 1), np.swapaxes(Vs.cpu().numpy(), 0, 1)
+    ms_h, Vs_h = _to_host(ms, Vs)
+    return s_finals, np.swapaxes(ms_h, 0, 1), np.swapaxes(Vs_h, 0, 1)
 
 
 def _log_opt(blocks, s_finals, info) -> None:
@@ -406,6 +424,7 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
     if return_device:
         out = s_finals, ms.transpose(0, 1), Vs.transpose(0, 1)
     else:
-        out = s_finals, np.swapaxes(ms.cpu().numpy(), 0, 1), np.swapaxes(Vs.cpu().numpy(), 0, 1)
+        ms_h, Vs_h = _to_host(ms, Vs)
+        out = s_finals, np.swapaxes(ms_h, 0, 1), np.swapaxes(Vs_h, 0, 1)
     logger.debug(f'[profile]   final smoother pass ({K} keypoints): {time.perf_counter() - t2:.3f}s')
     return out
