@@ -56,6 +56,13 @@ def ensemble_kalman_smoother_singlecam(marker_array: MarkerArray, keypoint_names
     (reference eks/singlecam_smoother.py:105-243).  `kalman_kwargs` are forwarded to
     run_kalman_smoother (e.g. s_mode='grid')."""
     M, V, T, K, _ = marker_array.shape
+    if V == 1 and not os.environ.get('EKS_HOST_DRIVER'):
+        out = _singlecam_on_device(marker_array, smooth_param, s_frames, blocks, avg_mode, var_mode,
+                                   kalman_kwargs)
+        if out is not None:
+            table, s_finals = out
+            return pd.DataFrame(table.reshape(T, K * 9),
+                                columns=make_dlc_pandas_index(keypoint_names, labels=OUTPUT_LABELS)), s_finals
     ens = ensemble(marker_array, avg_mode=avg_mode, var_mode=var_mode)       # (1,1,T,K,5) float32
     _, centered, _, means = center_predictions(ens, quantile_keep_pca=100)
     stats = np.asarray(ens.array)[0, 0]                                       # (T,K,5)
@@ -77,6 +84,49 @@ def ensemble_kalman_smoother_singlecam(marker_array: MarkerArray, keypoint_names
     df = pd.DataFrame(out.reshape(T, K * 9), columns=make_dlc_pandas_index(keypoint_names,
                                                                            labels=OUTPUT_LABELS))
     return df, s_finals
+
+
+def _singlecam_on_device(marker_array, smooth_param, s_frames, blocks, avg_mode, var_mode,
+                         kalman_kwargs):
+    """The same pipeline with every array resident on the device between the upload of the markers
+    and the download of the finished (T, K, 9) table (the
+    reference's per-keypoint assembly loop, singlecam_smoother.py:183-241, as one gather):
+    ensemble kernel -> centring and prior variances (float64 reductions over frames) ->
+    run_kalman_smoother on device tensors -> table.  Returns None when the ensemble variances
+    contain NaN (the percentile branch of center_predictions applies; the host path handles it)."""
+    import torch
+
+    from . import hip_ops
+    from .core import _to_host
+    dev = hip_ops.require_gpu()
+    fields = list(marker_array.data_fields)
+    arr = np.asarray(marker_array.array)
+    if fields != ['x', 'y', 'likelihood']:
+        arr = arr[..., [fields.index(f) for f in ('x', 'y', 'likelihood')]]
+    # upload in the caller's dtype, convert on the device (a host-side float32 copy of a large
+    # float64 ensemble costs more than the transfer)
+    mk = torch.as_tensor(np.ascontiguousarray(arr), device=dev).to(torch.float32)
+    stats = hip_ops.ensemble(mk, avg_mode, var_mode, 1000.0)[0]               # (T,K,5) float32
+    del mk
+    if bool(torch.isnan(stats[..., 2:4]).any()):
+        return None
+    T, K = stats.shape[0], stats.shape[1]
+    xy = stats[..., 0:2].double()
+    mu = xy.mean(dim=0)                                                        # (K,2)
+    cen = xy - mu
+    v = cen.var(dim=0, unbiased=False).cpu().numpy()                           # (K,2)
+    eye = np.tile(np.eye(2), (K, 1, 1))
+    s_finals, ms, Vs = run_kalman_smoother(
+        ys=cen.to(torch.float32).transpose(0, 1), m0s=np.zeros((K, 2)), S0s=eye * v[:, :, None],
+        As=eye, Cs=eye.copy(), Qs=eye.copy(), ensemble_vars=stats[..., 2:4].contiguous(),
+        s_frames=s_frames, smooth_param=smooth_param, blocks=blocks, vs_diag=True,
+        return_device=True, **kalman_kwargs)
+    table = torch.empty((T, K, 9), dtype=torch.float64, device=dev)
+    table[..., 0:2] = ms.transpose(0, 1).double() + mu
+    table[..., 2] = stats[..., 4]
+    table[..., 3:7] = stats[..., 0:4]
+    table[..., 7:9] = Vs.transpose(0, 1)
+    return _to_host(table)[0], s_finals
 
 
 def initialize_kalman_filter(emA_centered_preds: MarkerArray) -> tuple:
