@@ -16,6 +16,8 @@ python bench.py --workload c2 --no-cpu-baseline > $O/bench_c2.json 2>/dev/null
 python bench.py --workload pupil > $O/bench_pupil.json 2>/dev/null
 python bench.py --workload ekf > $O/bench_ekf.json 2>/dev/null
 python tools/ekf_time.py > $O/ekf_time.txt 2>&1
+python tools/driver_time.py 2>&1 | grep -E "ms \(" > $O/driver_time.txt
+python tools/host_path_time.py > $O/host_path_time.txt 2>&1
 python tools/adam_time.py > $O/adam_time.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-events"
