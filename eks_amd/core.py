@@ -319,8 +319,11 @@ def _run_kalman_smoother_pinhole(ys, m0s, S0s, As, Qs, ensemble_vars, h_fn, s_fr
             while iters < cap:
                 for _ in range(min(8, cap - iters)):
                     s3 = (step[:, None] * s_kp[None, :]).reshape(-1).contiguous()
+                    # warm-started iterations settle in 1-3 sweeps; every enqueued-but-gated sweep
+                    # still costs its four empty launches
                     _, _, nll3, inf = hip_ops.ekf_smooth(y_c, None, rconst, m3, S3, A3, Q3, s3, cams, x3,
-                                                         max_sweeps, lin_tol, want_smoother=False)
+                                                         max_sweeps if iters == 0 else min(max_sweeps, 8),
+                                                         lin_tol, want_smoother=False)
                     worst = torch.maximum(worst, inf[1])
                     nll3 = nll3.view(3, K)
                     dnll = ((nll3[1] - nll3[2]) / (2.0 * fd_step)).contiguous()
