@@ -1,5 +1,6 @@
 """eks_amd - MI355X-native ensemble Kalman smoother: drop-in for the Kalman hot path of
-paninski-lab/eks (run_kalman_smoother and its singlecam / linear-multicam drivers).
+paninski-lab/eks (run_kalman_smoother and its singlecam, multicam - linear and calibrated - and
+IBL-pupil drivers).
 
 The public names mirror the reference's `eks/__init__.py`.  Importing this package needs no GPU;
 calling the smoothers does (there is no CPU fallback)."""
