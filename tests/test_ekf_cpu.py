@@ -192,3 +192,61 @@ def test_only_calibrated_projections_are_accepted_as_h_fn():
     with pytest.raises(NotImplementedError):
         run_kalman_smoother(z((1, 4, 4)), z((1, 3)), z((1, 3, 3)), z((1, 3, 3)), z((1, 4, 3)),
                             z((1, 3, 3)), z((4, 1, 4)), smooth_param=1.0, h_fn=lambda x: x)
+
+
+# ---- the reference's own calibrated data set (data/fly + calibration.toml), tests/golden ----------
+@pytest.fixture(scope='module')
+def fly(golden_dir):
+    return np.load(os.path.join(golden_dir, 'fly_calibrated_multicam.npz'))
+
+
+def test_real_calibration_file_loads_and_triangulates_the_fly_markers(fly, tmp_path):
+    fn = tmp_path / 'calibration.toml'
+    fn.write_text(str(fly['toml']))
+    group = cal.CameraGroup.load(str(fn))
+    assert [c.name for c in group.cameras] == list(fly['cameras']) == ['Cam-A', 'Cam-B', 'Cam-C']
+    packed = cal.cameras_of(group)
+    assert packed.shape == (3, 32) and packed[0, 12] == 20003.023008090135 and packed[2, 17] == -6468.60716369641
+    from eks_amd import MarkerArray
+    from eks_amd.multicam_smoother import initialize_kalman_filter_geometric
+    ma = MarkerArray(fly['markers'].astype(np.float64), data_fields=['x', 'y', 'likelihood'])
+    ys3 = cal.triangulate_3d_models(ma, group).mean(axis=0)                   # (K,T,3)
+    assert np.abs(ys3 - fly['ys3']).max() < 1e-5 * np.abs(fly['ys3']).max()
+    m0s, S0s, _, Qs, _ = initialize_kalman_filter_geometric(ys3)
+    np.testing.assert_allclose(m0s, fly['m0s'], rtol=1e-6)
+    np.testing.assert_allclose(S0s, fly['S0s'], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(Qs, fly['Qs'], rtol=1e-4, atol=1e-14)
+
+
+def test_oracle_reproduces_the_fly_golden_for_one_keypoint(fly, tmp_path):
+    """Guards the committed vectors against drift of the oracle (keypoint 3, smooth_param 10)."""
+    import ast
+    cams = []
+    for block in str(fly['toml']).split('[cam_')[1:]:
+        d = {}
+        for line in block.split('\n')[1:]:
+            if '=' in line and not line.startswith('['):
+                k, v = line.split('=', 1)
+                d[k.strip()] = ast.literal_eval(v.strip())
+            elif line.startswith('['):
+                break
+        cams.append(dict(rot=np.array(d['rotation']), tvec=np.array(d['translation']),
+                         K=np.array(d['matrix']), dist=np.array(d['distortions'])))
+    mk = fly['markers']
+    M, V, T, K, _ = mk.shape
+    k = 3
+    heads = [ek.make_projection_fn(c['rot'], c['tvec'], c['K'], c['dist']) for c in cams]
+    st = orc.ensemble(mk[:, :, :, k:k + 1])[0]                                  # (V,T,1,5)
+    tri = np.stack([ek.triangulate_dlt(cams, mk[m, :, :, k, :2].astype(np.float64)) for m in range(M)]).mean(axis=0)
+    m0s, S0s, As, Qs, _ = ek.initialize_kalman_filter_geometric(tri[None])
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    ys = np.transpose(st[..., 0:2], (2, 1, 0, 3)).reshape(1, T, 2 * V)
+    evs = np.transpose(st[..., 2:4], (2, 1, 0, 3)).reshape(1, T, 2 * V)
+    _, ms, Vs, _ = ek.run_kalman_smoother_nonlinear(f32(ys), m0s, S0s, As, Qs, np.swapaxes(f32(evs), 0, 1),
+                                                    ek.combine_projections(heads), smooth_param=10.0)
+    idx = fly['keep_idx']
+    ref = fly['s10_cam1_rows'].reshape(len(idx), K, 9)[:, k]
+    got = heads[1](ms[0])[idx]
+    assert np.abs(got - ref[:, 0:2]).max() < 1e-5 * np.abs(ref[:, 0:2]).max()
+    lat = fly['s10_latent_rows'].reshape(len(idx), K, 6)[:, k]
+    assert np.abs(ms[0][idx] - lat[:, :3]).max() < 1e-6 * np.abs(lat[:, :3]).max()

@@ -75,8 +75,96 @@ def pupil():
     print('ibl-pupil (pupil smoother): s_adam', s, 'iters', info['iters'], 'loss', info['last_loss'])
 
 
+def fly():
+    """data/fly through the CALIBRATED multicam path (reference eks/multicam_smoother.py:367-407 with
+    its own data/fly/calibration.toml: 3 cameras x 3 ensemble members x 502 frames x 12 keypoints).
+    Expected outputs: oracle/ekf_oracle.py (sequential extended filter + RTS, complex-step
+    Jacobians) on the triangulation-initialised model, smooth_param = 10 for all keypoints and the
+    Adam search for the first two."""
+    import ast
+    from oracle import ekf_oracle as ek
+    d = os.path.join(REF, 'fly')
+    text = open(os.path.join(d, 'calibration.toml')).read()
+    cams, cur = [], None
+    for line in text.split('\n'):
+        line = line.strip()
+        if line.startswith('[cam_'):
+            cur = {}
+            cams.append(cur)
+        elif line.startswith('['):
+            cur = None
+        elif cur is not None and '=' in line:
+            k, v = line.split('=', 1)
+            cur[k.strip()] = ast.literal_eval(v.strip())
+    names = [c['name'] for c in cams]
+    files = sorted(f for f in os.listdir(d) if f.endswith('.csv'))
+    per_cam = [[pd.read_csv(os.path.join(d, f), header=[0, 1, 2], index_col=0) for f in files if n in f]
+               for n in names]
+    df0 = per_cam[0][0]
+    scorer = df0.columns[0][0]
+    kps = df0.columns[df0.columns.get_level_values('coords') == 'x'].get_level_values('bodyparts').tolist()
+    M, V, T, K = len(per_cam[0]), len(names), len(df0), len(kps)
+    mk = np.empty((M, V, T, K, 3), np.float32)
+    for v in range(V):
+        for m in range(M):
+            for k, kp in enumerate(kps):
+                for f, c in enumerate(('x', 'y', 'likelihood')):
+                    mk[m, v, :, k, f] = per_cam[v][m][(scorer, kp, c)].to_numpy()
+    ocams = [dict(rot=np.array(c['rotation'], float), tvec=np.array(c['translation'], float),
+                  K=np.array(c['matrix'], float), dist=np.array(c['distortions'], float)) for c in cams]
+    heads = [ek.make_projection_fn(c['rot'], c['tvec'], c['K'], c['dist']) for c in ocams]
+    h = ek.combine_projections(heads)
+    st = orc.ensemble(mk)[0]                                                     # (V,T,K,5)
+    tri = np.stack([np.stack([ek.triangulate_dlt(ocams, mk[m, :, :, k, :2].astype(np.float64))
+                              for k in range(K)]) for m in range(M)])            # (M,K,T,3)
+    ys3 = tri.mean(axis=0)
+    m0s, S0s, As, Qs, _ = ek.initialize_kalman_filter_geometric(ys3)
+    ys = np.transpose(st[..., 0:2], (2, 1, 0, 3)).reshape(K, T, 2 * V)
+    evs = np.transpose(st[..., 2:4], (2, 1, 0, 3)).reshape(K, T, 2 * V)
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    out = dict(markers=mk, keypoints=np.array(kps), cameras=np.array(names), toml=np.array(text),
+               keep_idx=keep_idx(T), ys3=ys3.astype(np.float32), m0s=m0s, S0s=S0s, Qs=Qs)
+
+    def tables(ms, Vs, kk):
+        res = []
+        for c in range(V):
+            tab = np.empty((T, len(kk), 9))
+            for j, k in enumerate(kk):
+                tab[:, j, 0:2] = heads[c](ms[j])
+                tab[:, j, 7], tab[:, j, 8] = ek.project_3d_covariance_to_2d(ms[j], Vs[j], heads[c], evs[k])
+                tab[:, j, 2] = st[c, :, k, 4]
+                tab[:, j, 3:5] = st[c, :, k, 0:2]
+                tab[:, j, 5:7] = st[c, :, k, 2:4]
+            res.append(tab.reshape(T, len(kk) * 9))
+        lat = np.concatenate([np.swapaxes(ms, 0, 1), np.swapaxes(np.diagonal(Vs, axis1=2, axis2=3), 0, 1)],
+                             axis=2).reshape(T, len(kk) * 6)
+        return res, lat
+
+    s, ms, Vs, _ = ek.run_kalman_smoother_nonlinear(f32(ys), m0s, S0s, As, Qs, np.swapaxes(f32(evs), 0, 1), h,
+                                                    smooth_param=10.0)
+    cams_out, lat = tables(ms, Vs, list(range(K)))
+    for c, co in enumerate(cams_out):
+        for k, v in pack(co).items():
+            out[f's10_cam{c}_{k}'] = v
+    for k, v in pack(lat).items():
+        out[f's10_latent_{k}'] = v
+    kk = [0, 1]
+    s_a, ms, Vs, info = ek.run_kalman_smoother_nonlinear(f32(ys[kk]), m0s[kk], S0s[kk], As[kk], Qs[kk],
+                                                         np.swapaxes(f32(evs[kk]), 0, 1), h)
+    out['adam_s'] = s_a
+    out['adam_iters'] = info['iters']
+    cams_out, lat = tables(ms, Vs, kk)
+    for c, co in enumerate(cams_out):
+        for k, v in pack(co).items():
+            out[f'adam_cam{c}_{k}'] = v
+    np.savez_compressed(os.path.join(OUT, 'fly_calibrated_multicam.npz'), **out)
+    print('fly: T', T, 'K', K, 'V', V, 'M', M, 's_adam', s_a, 'iters', info['iters'])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ['fly']:
+        return fly()
     if sys.argv[1:] == ['pupil']:
         return pupil()
     # ---------------- ibl-pupil: singlecam, 5 models x 2000 frames x 4 keypoints
