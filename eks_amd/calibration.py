@@ -179,14 +179,20 @@ def triangulate(cams_packed: np.ndarray, xy_views) -> np.ndarray:
 
 
 def triangulate_3d_models(marker_array, camgroup: Any) -> np.ndarray:
-    """Per model, keypoint and frame: (M, K, T, 3) (reference :901-921)."""
-    cams = cameras_of(camgroup)
-    raw = marker_array.get_array()                                       # (M,V,T,K,F)
+    """Per model, keypoint and frame: (M, K, T, 3) (reference :901-921).  Like the reference this
+    calls the camera group's own `triangulate(xy_views (C,T,2), fast=True, disable_64bit=True)`
+    when it has one (aniposelib's, or `CameraGroup` below); a bare `.cameras` holder is
+    triangulated here."""
+    raw = np.asarray(marker_array.get_array())                           # (M,V,T,K,F)
     M, V, T, K, _ = raw.shape
+    tri_fn = getattr(camgroup, 'triangulate', None)
+    cams = None if tri_fn is not None else cameras_of(camgroup)
     out = np.empty((M, K, T, 3))
     for m in range(M):
-        xy = np.transpose(raw[m, :, :, :, :2], (0, 2, 1, 3)).reshape(V, K * T, 2)
-        out[m] = triangulate(cams, xy).reshape(K, T, 3)
+        for k in range(K):
+            xy = raw[m, :, :, k, :2]
+            out[m, k] = tri_fn(xy, fast=True, disable_64bit=True) if tri_fn is not None \
+                else triangulate(cams, xy)
     return out
 
 

@@ -250,3 +250,119 @@ def test_oracle_reproduces_the_fly_golden_for_one_keypoint(fly, tmp_path):
     assert np.abs(got - ref[:, 0:2]).max() < 1e-5 * np.abs(ref[:, 0:2]).max()
     lat = fly['s10_latent_rows'].reshape(len(idx), K, 6)[:, k]
     assert np.abs(ms[0][idx] - lat[:, :3]).max() < 1e-6 * np.abs(lat[:, :3]).max()
+
+
+# ---- what the reference's own helper tests assert (tests/test_multicam_smoother.py:484-640) --------
+class _Cam:
+    def __init__(self, rotation, translation, K, dist):
+        self._r, self._t, self._K, self._d = rotation, translation, K, dist
+
+    def get_rotation(self):
+        return self._r
+
+    def get_translation(self):
+        return self._t
+
+    def get_camera_matrix(self):
+        return self._K
+
+    def get_distortions(self):
+        return self._d
+
+
+class _Group:
+    """A camera group whose triangulate() is a recognisable stand-in (mean pixel, z = 1)."""
+
+    def __init__(self, cameras):
+        self.cameras = cameras
+
+    def triangulate(self, xy_views, fast=True, disable_64bit=False):
+        xy = np.asarray(xy_views)
+        return np.stack([xy[:, :, 0].mean(axis=0), xy[:, :, 1].mean(axis=0), np.ones(xy.shape[1])], axis=-1)
+
+
+def _random_camera(rng, with_dist):
+    rvec = rng.normal(size=3) * rng.uniform(0.0, 2.0)
+    tvec = rng.normal(size=3) * 0.5
+    Km = np.array([[rng.uniform(500, 1500), 0.0, rng.uniform(200, 800)],
+                   [0.0, rng.uniform(500, 1500), rng.uniform(200, 800)], [0.0, 0.0, 1.0]])
+    dist = np.zeros(14)
+    if with_dist:
+        dist[:5] = rng.normal(size=5) * np.array([1e-3, 1e-4, 1e-4, 1e-4, 1e-5])
+    return rvec, tvec, Km, dist
+
+
+def test_combined_projection_concatenates_cameras_in_order():
+    rng = np.random.default_rng(0)
+    rA, tA, KA, dA = _random_camera(rng, True)
+    rB, tB, KB, dB = _random_camera(rng, False)
+    group = _Group([_Cam(cal.rodrigues(rA), tA, KA, dA), _Cam(rB, tB, KB, dB)])   # matrix and vector forms
+    h, heads = cal.make_projection_from_camgroup(group)
+    x = rng.normal(size=3)
+    x[2] = abs(x[2]) + 0.5
+    uv = h(x)
+    assert uv.shape == (4,)
+    np.testing.assert_allclose(uv, np.concatenate([heads[0](x), heads[1](x)]))
+    np.testing.assert_allclose(heads[0](x), ek.make_projection_fn(rA, tA, KA, dA)(x), rtol=1e-12)
+    np.testing.assert_allclose(heads[1](x), ek.make_projection_fn(rB, tB, KB, dB)(x), rtol=1e-12)
+
+
+def test_triangulate_3d_models_uses_the_groups_triangulate_and_shapes():
+    class _Markers:
+        def __init__(self, a):
+            self._a = a
+            self.shape = a.shape
+
+        def get_array(self):
+            return self._a
+
+    rng = np.random.default_rng(0)
+    M, C, T, K = 2, 3, 5, 4
+    arr = rng.normal(size=(M, C, T, K, 3))
+    group = _Group([_Cam(np.eye(3), np.zeros(3), np.eye(3), np.zeros(14)) for _ in range(C)])
+    tri = cal.triangulate_3d_models(_Markers(arr), group)
+    assert tri.shape == (M, K, T, 3)
+    expected = np.stack([arr[..., 0].mean(axis=1), arr[..., 1].mean(axis=1), np.ones((M, T, K))], axis=-1)
+    np.testing.assert_allclose(tri, np.transpose(expected, (0, 2, 1, 3)), atol=1e-12)
+
+
+def test_projected_covariance_matches_a_finite_difference_linearisation():
+    rng = np.random.default_rng(0)
+    rvec, tvec, Km, dist = _random_camera(rng, True)
+    head = cal.PinholeProjection(cal.pack_camera(rvec, tvec, Km, dist)[None]).heads[0]
+    T = 8
+    ms = rng.normal(size=(T, 3))
+    ms[:, 2] = np.abs(ms[:, 2]) + 0.5
+    A = rng.normal(size=(T, 3, 3)) * 1e-2
+    Vs = np.einsum('tij,tik->tjk', A, A) + np.eye(3)[None] * 1e-6
+    infl = np.abs(rng.normal(size=(T, 3))) * 1e-4
+    vx, vy = cal.project_3d_covariance_to_2d(ms, Vs, head, infl)
+    assert vx.shape == (T,) and vy.shape == (T,)
+    for t in range(T):
+        J = np.zeros((2, 3))
+        for i in range(3):
+            e = np.zeros(3)
+            e[i] = 1e-5
+            J[:, i] = (head(ms[t] + e) - head(ms[t] - e)) / 2e-5
+        cov = J @ Vs[t] @ J.T
+        np.testing.assert_allclose(vx[t] - infl[t, 0], cov[0, 0], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(vy[t] - infl[t, 1], cov[1, 1], rtol=1e-4, atol=1e-6)
+
+
+def test_distortion_padding_order_and_ignored_tilt():
+    """OpenCV order k1 k2 p1 p2 k3 ... zero-padded; the tilt terms tx, ty change nothing
+    (reference parse_dist, eks/multicam_smoother.py:799-811)."""
+    rng = np.random.default_rng(1)
+    rvec, tvec, Km, _ = _random_camera(rng, False)
+    x = np.array([0.2, -0.1, 1.5])
+    five = np.array([0.1, -0.2, 0.01, -0.01, 0.001])
+    full = np.zeros(14)
+    full[:5] = five
+    a = cal.project(cal.pack_camera(rvec, tvec, Km, five), x)
+    b = cal.project(cal.pack_camera(rvec, tvec, Km, full), x)
+    full[12:] = [0.3, -0.4]
+    c = cal.project(cal.pack_camera(rvec, tvec, Km, full), x)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a, c)
+    packed = cal.pack_camera(rvec, tvec, Km, np.arange(14) / 100.0)
+    np.testing.assert_array_equal(packed[17:31], np.arange(14) / 100.0)
