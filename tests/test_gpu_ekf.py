@@ -319,3 +319,23 @@ def test_fly_calibrated_multicam_matches_golden(golden_dir, tmp_path):
     assert np.abs(s / g['adam_s'] - 1.0).max() < 1e-3
     for c in range(3):
         _fly_against_golden(dfs[c].values, g, f'adam_cam{c}', 2, tol=1e-4)
+
+
+def test_fly_integration_configuration_with_variance_inflation(golden_dir, tmp_path):
+    """The reference's integration test on this data (tests/integration/test_multicam.py:46-58):
+    bodyparts L1A, L1B, quantile_keep_pca=95, inflate_vars=True, smooth_param=[10.0]."""
+    import os
+    from eks_amd import MarkerArray
+    from eks_amd.multicam_smoother import ensemble_kalman_smoother_multicam
+    g = np.load(os.path.join(golden_dir, 'fly_calibrated_multicam.npz'))
+    fn = tmp_path / 'calibration.toml'
+    fn.write_text(str(g['toml']))
+    group = cal.CameraGroup.load(str(fn))
+    names, cams = list(g['keypoints'][:2]), list(g['cameras'])
+    assert names == ['L1A', 'L1B']
+    ma = MarkerArray(g['markers'][:, :, :, :2].astype(np.float64), data_fields=['x', 'y', 'likelihood'])
+    dfs, s, _ = ensemble_kalman_smoother_multicam(ma, names, cams, smooth_param=[10.0], quantile_keep_pca=95,
+                                                  inflate_vars=True, camgroup=group)
+    np.testing.assert_array_equal(s, 10.0)
+    for c in range(3):
+        _fly_against_golden(dfs[c].values, g, f'infl_s10_cam{c}', 2)

@@ -157,6 +157,27 @@ def fly():
     for c, co in enumerate(cams_out):
         for k, v in pack(co).items():
             out[f'adam_cam{c}_{k}'] = v
+    # the configuration of the reference's integration test (tests/integration/test_multicam.py:
+    # 32-58): bodyparts L1A, L1B, quantile_keep_pca=95, inflate_vars=True, smooth_param=[10.0]
+    from sklearn.decomposition import PCA
+
+    def sk_pca(X, n):
+        p = PCA(n_components=n).fit(X)
+        return p.components_, p.mean_
+
+    arrs = orc.multicam_arrays(mk[:, :, :, :2], quantile_keep_pca=95.0, n_latent=3, pca_fit=sk_pca,
+                               inflate_vars=True)
+    evs_i = np.swapaxes(arrs['ensemble_vars'], 0, 1)                            # (K,T,2V), inflated
+    out['infl_vars'] = evs_i.astype(np.float32)
+    _, ms, Vs, _ = ek.run_kalman_smoother_nonlinear(f32(ys[kk]), m0s[kk], S0s[kk], As[kk], Qs[kk],
+                                                    np.swapaxes(f32(evs_i), 0, 1), h, smooth_param=[10.0])
+    evs_all = evs.copy()
+    evs[kk] = evs_i                       # tables() adds the (inflated) variances of camera 0
+    cams_out, lat = tables(ms, Vs, kk)
+    evs[:] = evs_all
+    for c, co in enumerate(cams_out):
+        for k, v in pack(co).items():
+            out[f'infl_s10_cam{c}_{k}'] = v
     np.savez_compressed(os.path.join(OUT, 'fly_calibrated_multicam.npz'), **out)
     print('fly: T', T, 'K', K, 'V', V, 'M', M, 's_adam', s_a, 'iters', info['iters'])
 
