@@ -224,6 +224,36 @@ def test_mirrored_multicam_upstream_integration_config(mouse, tmp_path):
     assert bps2 == paws
 
 
+def test_multicam_upstream_integration_config_separate_files(mouse, tmp_path):
+    """The reference's tests/integration/test_multicam.py:4-30 (data/mirror-mouse-separate): one
+    CSV per camera and ensemble member, camera name in the file name, bodyparts paw1LH / paw2LF,
+    quantile_keep_pca=95, inflate_vars=True, smooth_param=[10.0], through fit_eks_multicam."""
+    from eks_amd.multicam_smoother import fit_eks_multicam
+    paws, cams = list(mouse['keypoints']), list(mouse['cameras'])
+    cols = pd.MultiIndex.from_product([[str(mouse['scorer'])], paws, ['x', 'y', 'likelihood']],
+                                      names=['scorer', 'bodyparts', 'coords'])
+    src = tmp_path / 'in'
+    src.mkdir()
+    for m in range(5):
+        for v, cam in enumerate(cams):
+            pd.DataFrame(mouse['markers'][m, v].reshape(2000, -1).astype(np.float64), columns=cols).to_csv(
+                src / f'180607_004.train_frames=75.rng={m}.{cam}.csv')
+    out = tmp_path / 'out'
+    dfs, s, input_dfs, bps, df3 = fit_eks_multicam(str(src), str(out), bodypart_list=['paw1LH', 'paw2LF'],
+                                                  camera_names=['top', 'bot'], smooth_param=[10.0],
+                                                  quantile_keep_pca=95, inflate_vars=True)
+    assert bps == ['paw1LH', 'paw2LF'] and len(dfs) == 2 and len(input_dfs) == 2 and len(input_dfs[0]) == 5
+    np.testing.assert_array_equal(s, 10.0)
+    for c, cam in enumerate(cams):
+        assert (out / f'multicam_{cam}_results.csv').exists()
+        assert dfs[c].shape == (2000, 18)
+        _against_golden(dfs[c].values, mouse, f'infl_s10_cam{c}')
+    assert not (out / 'multicam_3d_results.csv').exists()        # only written with a calibration
+    assert df3.shape == (2000, 2 * 6)
+    with pytest.raises(ValueError):
+        fit_eks_multicam(str(src), str(out))                      # no camera names, no calibration
+
+
 def test_ensemble_operator_properties():
     """Properties the reference asserts in tests/test_core.py:8-152."""
     from eks_amd import MarkerArray
