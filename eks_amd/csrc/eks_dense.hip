@@ -21,7 +21,10 @@
 namespace eks {
 
 struct DenseGeom {
-  int K, T, O, B, nc;
+  int K, T, O;
+  int B, nc;      // frames per replay lane, number of replay chunks
+  int Bs, ncs;    // frames per chunk ELEMENT (summarize / scan), number of elements; B % Bs == 0,
+                  // (B / Bs) divides 64 so a replay chunk's elements never straddle a scan block
 };
 
 // Sweeps of the extended filter (eks_ekf_smooth) are enqueued without host round trips: a sweep's
@@ -38,12 +41,12 @@ __global__ __launch_bounds__(64) void dense_summarize_kernel(DenseGeom G, DenseM
                                                             double* __restrict__ elems,
                                                             double* __restrict__ first, Gate gate) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= G.K * G.nc || gate.closed()) return;
+  if (idx >= G.K * G.ncs || gate.closed()) return;
   const int k = idx % G.K, j = idx / G.K;
   Mat<double, D> F, sQ;
   bool fid;
   load_dynamics<double, D>(M, k, s[k], F, sQ, fid);
-  const int t0 = j * G.B, len = min(G.B, G.T - t0);
+  const int t0 = j * G.Bs, len = min(G.Bs, G.T - t0);
   const DElem<double, D> e = dense_smooth_element_obs<D>(obs, k, t0, len, F, sQ, fid);
   store_delem<double, D>(elems + (size_t)idx * delem_doubles<D>(), e);
   if (j == 0) {   // the belief the scan starts from: the prior updated with frame 0
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(2 * kDenseCB) void dense_scan_kernel(DenseGeom G,
   const bool rev = threadIdx.x >= kDenseCB;
   const int i = threadIdx.x - (rev ? kDenseCB : 0);
   const int j = blk * kDenseCB + i;
-  const bool live = j < G.nc;
+  const bool live = j < G.ncs;
   double* mine = lds + (rev ? kDenseCB * NV : 0);
   DElem<double, D> e = live ? load_delem<double, D>(elems + ((size_t)j * G.K + k) * NV)
                             : delem_identity<double, D>();
@@ -201,7 +204,10 @@ __global__ __launch_bounds__(64) void dense_replay_kernel(DenseGeom G, DenseMode
   constexpr int NV = delem_doubles<D>();
   Vec<double, D> m, eta;
   Mat<double, D> P, J;
-  const int blk = j / kDenseCB, i = j % kDenseCB;
+  // this lane's frames are covered by the elements ea .. eb (one element on the linear path)
+  const int sub = G.B / G.Bs;
+  const int ea = j * sub, eb = min(ea + sub - 1, G.ncs - 1);
+  const int blk = ea / kDenseCB, ia = ea % kDenseCB, ib = eb % kDenseCB;
   const double* rp = bprior + ((size_t)blk * G.K + k) * REC;
   const double* rs = bsuffix + ((size_t)blk * G.K + k) * REC;
 #pragma unroll
@@ -214,10 +220,10 @@ __global__ __launch_bounds__(64) void dense_replay_kernel(DenseGeom G, DenseMode
       J.a[a][b] = rs[D + a * D + b];
     }
   }
-  // exclusive prefix / suffix of this chunk inside its block of 64
-  if (i > 0) delem_apply(load_delem<double, D>(pre + ((size_t)(j - 1) * G.K + k) * NV), m, P);
-  if (i + 1 < kDenseCB && j + 1 < G.nc)
-    delem_back(load_delem<double, D>(suf + ((size_t)(j + 1) * G.K + k) * NV), eta, J);
+  // exclusive prefix of the first / exclusive suffix of the last element inside the block of 64
+  if (ia > 0) delem_apply(load_delem<double, D>(pre + ((size_t)(ea - 1) * G.K + k) * NV), m, P);
+  if (ib + 1 < kDenseCB && eb + 1 < G.ncs)
+    delem_back(load_delem<double, D>(suf + ((size_t)(eb + 1) * G.K + k) * NV), eta, J);
   if (j == 0) load_prior<D>(M, k, m, P);   // chunk 0 replays frame 0's update of the prior itself
   const int t0 = j * G.B, len = min(G.B, G.T - t0);
   double ll = 0.0, ch = 0.0;
@@ -268,8 +274,10 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
   const int T = d.n_frames, K = d.n_keypoints, D = d.state_dim, O = d.obs_dim;
   if (D < 1 || D > 6 || O < 1 || O > 64) return EKS_ERR_UNSUPPORTED;
   if (ws_bytes < dense_smooth_workspace_bytes(T, K, D, O)) return EKS_ERR_WORKSPACE;
-  DenseGeom G{K, T, O, dense_chunk(T, K), 0};
+  DenseGeom G{K, T, O, dense_chunk(T, K), 0, 0, 0};
   G.nc = (T + G.B - 1) / G.B;
+  G.Bs = G.B;
+  G.ncs = G.nc;
   const int nblk = (G.nc + kDenseCB - 1) / kDenseCB;
   const DenseModelPtrs M{Mm.m0, Mm.S0, Mm.A, Mm.C, Mm.Q};
   const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
@@ -331,6 +339,9 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
 // because the filter forgets its entry belief within a few frames.  Sweeps are gated on the
 // device (Gate), so the whole solve is one enqueue without host round trips.
 constexpr int kEkfMaxSweeps = 64;
+// The replay lanes keep 32-frame chunks (the sweeps converge chunk-wise) but the chunk ELEMENTS are
+// built over half chunks: twice the lanes and half the sequential depth in the summarize kernel.
+constexpr int kEkfSub = 2;
 
 __global__ __launch_bounds__(64) void ekf_finish_kernel(int K, int nc, int n_sweeps, double tol,
                                                        const double* __restrict__ ll_chunk,
@@ -355,10 +366,12 @@ __global__ __launch_bounds__(64) void ekf_finish_kernel(int K, int nc, int n_swe
 
 static size_t ekf_ws_layout(int T, int K, bool smooth, double** ptrs, char* base) {
   constexpr int D = 3;
-  const int B = dense_chunk(T, K, true), nc = (T + B - 1) / B, nblk = (nc + kDenseCB - 1) / kDenseCB;
+  const int B = dense_chunk(T, K, true), nc = (T + B - 1) / B;
+  const int Bs = B % kEkfSub == 0 ? B / kEkfSub : B, ncs = (T + Bs - 1) / Bs;
+  const int nblk = (ncs + kDenseCB - 1) / kDenseCB;
   const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
-  const size_t sizes[10] = {(size_t)nc * K * nv * 8,   (size_t)nc * K * nv * 8,
-                            (size_t)nc * K * nv * 8,   (size_t)nblk * K * nv * 8,
+  const size_t sizes[10] = {(size_t)ncs * K * nv * 8,  (size_t)ncs * K * nv * 8,
+                            (size_t)ncs * K * nv * 8,  (size_t)nblk * K * nv * 8,
                             (size_t)nblk * K * rec * 8, (size_t)nblk * K * rec * 8,
                             smooth ? (size_t)T * K * rec * 8 : 0, (size_t)K * rec * 8,
                             (size_t)nc * K * 8,         (size_t)(kEkfMaxSweeps + 2) * 8};
@@ -388,9 +401,11 @@ int ekf_smooth(const eks_dims_t& d, int n_data_keypoints, const float* y, const 
   ekf_ws_layout(T, K, smooth, w, static_cast<char*>(ws));
   double *elems = w[0], *pre = w[1], *suf = w[2], *agg = w[3], *bprior = w[4], *bsuffix = w[5],
          *filt = w[6], *first = w[7], *ll_chunk = w[8], *resid = w[9];
-  DenseGeom G{K, T, O, dense_chunk(T, K, true), 0};
+  DenseGeom G{K, T, O, dense_chunk(T, K, true), 0, 0, 0};
   G.nc = (T + G.B - 1) / G.B;
-  const int nblk = (G.nc + kDenseCB - 1) / kDenseCB, lanes = K * G.nc;
+  G.Bs = G.B % kEkfSub == 0 ? G.B / kEkfSub : G.B;
+  G.ncs = (T + G.Bs - 1) / G.Bs;
+  const int nblk = (G.ncs + kDenseCB - 1) / kDenseCB, lanes = K * G.nc, lanes_k1 = K * G.ncs;
   const DenseModelPtrs M{Mm.m0, Mm.S0, Mm.A, nullptr, Mm.Q};
   const PinholeObs obs{y, ObsNoise{var, rconst}, Kd, O, T, cams, xlin};
   const int vs_diag = (d.flags & EKS_FLAG_VS_DIAG) ? 1 : 0;
@@ -398,7 +413,7 @@ int ekf_smooth(const eks_dims_t& d, int n_data_keypoints, const float* y, const 
   hipError_t e = hipMemsetAsync(resid, 0, (kEkfMaxSweeps + 2) * 8, st);
   if (e != hipSuccess) return hip_status(e);
   auto sweep = [&](const Gate& gate, double* resid_out, bool with_smoother) {
-    hipLaunchKernelGGL((dense_summarize_kernel<3, PinholeObs>), dim3((lanes + 63) / 64), dim3(64), 0,
+    hipLaunchKernelGGL((dense_summarize_kernel<3, PinholeObs>), dim3((lanes_k1 + 63) / 64), dim3(64), 0,
                        st, G, M, Mm.s, obs, elems, first, gate);
     hipLaunchKernelGGL(dense_scan_kernel<3>, sgrid, dim3(2 * kDenseCB), 0, st, G, elems, pre, suf, agg,
                        gate);
