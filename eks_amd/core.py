@@ -43,7 +43,10 @@ def _to_host(*tensors):
     # very large results stay pageable: page-locked memory is a scarce host resource
     if os.environ.get('EKS_PAGEABLE_D2H') or sum(t.numel() * t.element_size() for t in tensors) > (2 << 30):
         return tuple(t.cpu().numpy() for t in tensors)
-    host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]
+    try:
+        host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]
+    except RuntimeError:            # page-locked memory exhausted or unavailable: plain copies
+        return tuple(t.cpu().numpy() for t in tensors)
     for h, t in zip(host, tensors):
         h.copy_(t, non_blocking=True)
     torch.cuda.current_stream().synchronize()
