@@ -339,3 +339,21 @@ def test_fly_integration_configuration_with_variance_inflation(golden_dir, tmp_p
     np.testing.assert_array_equal(s, 10.0)
     for c in range(3):
         _fly_against_golden(dfs[c].values, g, f'infl_s10_cam{c}', 2)
+
+
+def test_fly_integration_defaults_optimise_s_with_variance_inflation(golden_dir, tmp_path):
+    """tests/integration/test_multicam.py:32-44 of the reference: the same call with the default
+    smooth_param=None (Adam on log s through the extended filter)."""
+    import os
+    from eks_amd import MarkerArray
+    from eks_amd.multicam_smoother import ensemble_kalman_smoother_multicam
+    g = np.load(os.path.join(golden_dir, 'fly_calibrated_multicam.npz'))
+    fn = tmp_path / 'calibration.toml'
+    fn.write_text(str(g['toml']))
+    group = cal.CameraGroup.load(str(fn))
+    ma = MarkerArray(g['markers'][:, :, :, :2].astype(np.float64), data_fields=['x', 'y', 'likelihood'])
+    dfs, s, _ = ensemble_kalman_smoother_multicam(ma, ['L1A', 'L1B'], list(g['cameras']), quantile_keep_pca=95,
+                                                  inflate_vars=True, camgroup=group)
+    assert np.abs(s / g['infl_adam_s'] - 1.0).max() < 1e-3
+    for c in range(3):
+        _fly_against_golden(dfs[c].values, g, f'infl_adam_cam{c}', 2, tol=1e-4)

@@ -178,6 +178,17 @@ def fly():
     for c, co in enumerate(cams_out):
         for k, v in pack(co).items():
             out[f'infl_s10_cam{c}_{k}'] = v
+    # ... and its default-arguments twin (test_multicam_defaults_nonlinear, :32-44): s optimised
+    s_i, ms, Vs, info_i = ek.run_kalman_smoother_nonlinear(f32(ys[kk]), m0s[kk], S0s[kk], As[kk], Qs[kk],
+                                                           np.swapaxes(f32(evs_i), 0, 1), h)
+    out['infl_adam_s'] = s_i
+    out['infl_adam_iters'] = info_i['iters']
+    evs[kk] = evs_i
+    cams_out, lat = tables(ms, Vs, kk)
+    evs[:] = evs_all
+    for c, co in enumerate(cams_out):
+        for k, v in pack(co).items():
+            out[f'infl_adam_cam{c}_{k}'] = v
     np.savez_compressed(os.path.join(OUT, 'fly_calibrated_multicam.npz'), **out)
     print('fly: T', T, 'K', K, 'V', V, 'M', M, 's_adam', s_a, 'iters', info['iters'])
 
