@@ -163,19 +163,28 @@ def undistort_points(cam: np.ndarray, uv, iters: int = 20) -> np.ndarray:
 def triangulate(cams_packed: np.ndarray, xy_views) -> np.ndarray:
     """xy_views (V, N, 2) pixels -> (N, 3) world points: undistort, then the least-squares
     solution of the homogeneous system x P_3 - P_1 = 0, y P_3 - P_2 = 0 over the cameras (what
-    aniposelib's CameraGroup.triangulate(fast=True) solves; reference call at :912-913)."""
+    aniposelib's CameraGroup.triangulate solves per point; reference call at :912-913).  Like
+    aniposelib, a view whose marker is not finite is left out of THAT point's system, and a point
+    seen by fewer than two cameras comes back NaN (a single NaN must not abort the whole run)."""
     xy_views = np.asarray(xy_views, dtype=np.float64)
+    ok = np.isfinite(xy_views).all(axis=-1)                              # (V, N)
     rows = []
     for c, cam in enumerate(cams_packed):
         Pm = np.concatenate([cam[0:9].reshape(3, 3), cam[9:12].reshape(3, 1)], axis=1)
-        n = undistort_points(cam, xy_views[c])
-        rows.append(n[:, 0, None] * Pm[2][None] - Pm[0][None])
-        rows.append(n[:, 1, None] * Pm[2][None] - Pm[1][None])
+        n = undistort_points(cam, np.where(ok[c][:, None], xy_views[c], 0.0))
+        w = ok[c].astype(np.float64)[:, None]                            # dropped views: zero rows
+        rows.append(w * (n[:, 0, None] * Pm[2][None] - Pm[0][None]))
+        rows.append(w * (n[:, 1, None] * Pm[2][None] - Pm[1][None]))
     A = np.stack(rows, axis=1)                                           # (N, 2V, 4)
-    # smallest right singular vector = smallest eigenvector of the 4x4 normal matrix
-    _, vecs = np.linalg.eigh(np.swapaxes(A, 1, 2) @ A)
-    p = vecs[..., 0]
-    return p[:, :3] / p[:, 3:4]
+    enough = ok.sum(axis=0) >= 2
+    out = np.full((A.shape[0], 3), np.nan)
+    if enough.any():
+        # smallest right singular vector = smallest eigenvector of the 4x4 normal matrix
+        Ag = A[enough]
+        _, vecs = np.linalg.eigh(np.swapaxes(Ag, 1, 2) @ Ag)
+        p = vecs[..., 0]
+        out[enough] = p[:, :3] / p[:, 3:4]
+    return out
 
 
 def triangulate_3d_models(marker_array, camgroup: Any) -> np.ndarray:
@@ -241,8 +250,8 @@ class CameraGroup:
         the flat key = value subset those files use is parsed here.)"""
         tables = _read_flat_toml(path)
         cams = []
-        for key in sorted((k for k in tables if k.startswith('cam_')),
-                          key=lambda k: int(k.split('_')[1])):
+        # aniposelib orders the tables by their keys sorted AS STRINGS (cam_0, cam_1, cam_10, cam_2 ...)
+        for key in sorted(k for k in tables if k.startswith('cam_')):
             t = tables[key]
             cams.append(Camera(np.asarray(t['rotation'], float), t['translation'], t['matrix'],
                                t.get('distortions', ()), name=str(t.get('name', key))))

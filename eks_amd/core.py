@@ -34,14 +34,28 @@ def _torch():
     return torch
 
 
-def _to_host(*tensors):
-    """Device tensors -> NumPy through page-locked staging buffers (torch's caching host
-    allocator keeps them across calls): the D2H copies run at the link rate instead of the
-    pageable rate, and overlap each other.  The arrays alias the staging tensors, which stay
-    alive as their `.base`."""
+_PINNED_CAP_BYTES = int(os.environ.get('EKS_PINNED_CAP_BYTES', 1 << 30))
+_pinned_live = [0]          # bytes of page-locked result buffers callers still hold
+
+
+def _release_pinned(nbytes: int) -> None:
+    _pinned_live[0] -= nbytes
+
+
+def _to_host(*tensors, pinned: bool | None = None):
+    """Device tensors -> NumPy.  Fast path: page-locked staging buffers (torch's caching host
+    allocator keeps them across calls), so the D2H copies run at the link rate and overlap each
+    other; the arrays alias the staging tensors, which stay alive as their `.base`.  Page-locked
+    memory is unswappable, so the bytes of such results that callers still hold are counted
+    (weakref finalisers) and capped at EKS_PINNED_CAP_BYTES (1 GiB): beyond the cap - a loop that
+    keeps every session's output, `distributed.smooth_sessions` - or with pinned=False results come
+    back in ordinary pageable arrays."""
+    import weakref
     torch = _torch()
-    # very large results stay pageable: page-locked memory is a scarce host resource
-    if os.environ.get('EKS_PAGEABLE_D2H') or sum(t.numel() * t.element_size() for t in tensors) > (2 << 30):
+    nbytes = sum(t.numel() * t.element_size() for t in tensors)
+    if pinned is None:
+        pinned = not os.environ.get('EKS_PAGEABLE_D2H')
+    if not pinned or nbytes > (2 << 30) or _pinned_live[0] + nbytes > _PINNED_CAP_BYTES:
         return tuple(t.cpu().numpy() for t in tensors)
     try:
         host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]
@@ -49,6 +63,9 @@ def _to_host(*tensors):
         return tuple(t.cpu().numpy() for t in tensors)
     for h, t in zip(host, tensors):
         h.copy_(t, non_blocking=True)
+        n = h.numel() * h.element_size()
+        _pinned_live[0] += n
+        weakref.finalize(h, _release_pinned, n)
     torch.cuda.current_stream().synchronize()
     return tuple(h.numpy() for h in host)
 
@@ -139,10 +156,18 @@ class _DeviceProblem:
 
 
 def _block_csr(blocks, K):
-    members = np.concatenate([np.asarray(b, dtype=np.int32) for b in blocks])
+    """CSR form of `blocks` for the device optimiser.  The blocks must partition range(K): the
+    reference (eks/core.py:553-554) would leave the s_finals of an uncovered keypoint unset, and a
+    stray index would address device memory out of bounds here."""
+    members = np.concatenate([np.asarray(b, dtype=np.int64).reshape(-1) for b in blocks]) \
+        if len(blocks) else np.zeros(0, dtype=np.int64)
+    if members.size != K or not np.array_equal(np.sort(members), np.arange(K)):
+        raise ValueError(f'blocks must partition the {K} keypoints (every index 0..{K - 1} exactly '
+                         f'once); got {[list(map(int, b)) for b in blocks]}')
+    members = members.astype(np.int32)
     offs = np.zeros(len(blocks) + 1, dtype=np.int32)
     offs[1:] = np.cumsum([len(b) for b in blocks])
-    of_kp = np.empty(K, dtype=np.int64)
+    of_kp = np.full(K, -1, dtype=np.int64)
     for i, b in enumerate(blocks):
         of_kp[np.asarray(b, dtype=int)] = i
     return offs, members, of_kp
@@ -207,7 +232,7 @@ def optimize_smooth_param(ys, m0s, S0s, As, Cs, Qs, Rs, blocks, s_finals, s_fram
         s, _, _ = _run_kalman_smoother_pinhole(
             ys, m0s, S0s, As, Qs, np.swapaxes(Rd, 0, 1), h_fn_combined, s_frames, None, blocks, lr,
             s_bounds_log, tol, safety_cap, 'adam', 0, True, True, None,
-            guesses=np.asarray(s_guess_per_k, float))
+            guesses=np.asarray(s_guess_per_k, float), min_R_var=min_R_var, final_pass=False)
         s_finals[:] = s
         return
     P = _DeviceProblem(ys, m0s, S0s, As, Cs, Qs, np.swapaxes(Rd, 0, 1))
@@ -220,7 +245,8 @@ def optimize_smooth_param(ys, m0s, S0s, As, Cs, Qs, Rs, blocks, s_finals, s_fram
 def _run_kalman_smoother_pinhole(ys, m0s, S0s, As, Qs, ensemble_vars, h_fn, s_frames, smooth_param,
                                  blocks, lr, s_bounds_log, tol, safety_cap, s_mode, n_grid, vs_diag,
                                  return_device, x_init, fd_step: float = 1e-3,
-                                 lin_tol: float = 1e-10, max_sweeps: int = 16, guesses=None):
+                                 lin_tol: float = 1e-10, max_sweeps: int = 16, guesses=None,
+                                 min_R_var: float = 1e-4, final_pass: bool = True):
     """run_kalman_smoother with the calibrated multi-camera projection (reference eks/core.py:
     159-302 with h_fn; optimiser :562-699 / :306-559).  Extended filter = eks_ekf_smooth.  The
     reference differentiates the loss through the filter (jax.value_and_grad); here d NLL / d log s
@@ -249,6 +275,8 @@ def _run_kalman_smoother_pinhole(ys, m0s, S0s, As, Qs, ensemble_vars, h_fn, s_fr
         var = torch.as_tensor(np.ascontiguousarray(_to_numpy(ensemble_vars)), device=dev)
         var = var.to(torch.float32).contiguous()
     T, O = y.shape[0], y.shape[2]
+    if T < 2:                       # reference eks/core.py:233-236 (initial guesses, unconditional)
+        raise ValueError('Not enough frames to compute temporal differences.')
     if tuple(y.shape) != (T, K, O) or tuple(var.shape) != (T, K, O) or O != 2 * h_fn.n_cameras:
         raise ValueError(f'ys must be (K,T,2V) and ensemble_vars (T,K,2V); got {tuple(y.shape)} '
                          f'(frame-major) and {tuple(var.shape)} for {h_fn.n_cameras} cameras')
@@ -278,7 +306,7 @@ def _run_kalman_smoother_pinhole(ys, m0s, S0s, As, Qs, ensemble_vars, h_fn, s_fr
         y_c, idx = crop(y)
         var_c = var if idx is None else var.index_select(0, idx).contiguous()
         x_c = xlin if idx is None else xlin.index_select(1, idx).contiguous()
-        rconst = hip_ops.const_r(var_c, 1e-4)
+        rconst = hip_ops.const_r(var_c, min_R_var)
         lo, hi = float(s_bounds_log[0]), float(s_bounds_log[1])
         offs, members, of_kp = _block_csr(blocks, K)
         nb = len(blocks)
@@ -341,17 +369,23 @@ def _run_kalman_smoother_pinhole(ys, m0s, S0s, As, Qs, ensemble_vars, h_fn, s_fr
                 xlin = x3[:K].contiguous()          # warm start of the final pass
         s_finals[:] = s_dev.cpu().numpy()
         _log_opt(blocks, s_finals, info)
+    if not final_pass:                  # optimize_smooth_param only wants s (reference :306-559)
+        _warn_if_unconverged(float(worst.item()), lin_tol, max_sweeps)
+        return s_finals, None, None
     ms, Vs, _, inf = hip_ops.ekf_smooth(y, var, None, m0, S0, A, Q, s_dev.contiguous(), cams, xlin,
                                         max_sweeps, lin_tol, want_smoother=True, vs_diag=vs_diag)
-    worst = float(torch.maximum(worst, inf[1]).item())
-    if not worst <= lin_tol:
-        logger.warning(f'extended filter: linearisation points still moving by {worst:.2e} after '
-                       f'{max_sweeps} sweeps (tolerance {lin_tol:.0e}); the result may differ from '
-                       'the sequential extended Kalman filter')
+    _warn_if_unconverged(float(torch.maximum(worst, inf[1]).item()), lin_tol, max_sweeps)
     if return_device:
         return s_finals, ms.transpose(0, 1), Vs.transpose(0, 1)
     ms_h, Vs_h = _to_host(ms, Vs)
     return s_finals, np.swapaxes(ms_h, 0, 1), np.swapaxes(Vs_h, 0, 1)
+
+
+def _warn_if_unconverged(worst: float, lin_tol: float, max_sweeps: int) -> None:
+    if not worst <= lin_tol:
+        logger.warning(f'extended filter: linearisation points still moving by {worst:.2e} after '
+                       f'{max_sweeps} sweeps (tolerance {lin_tol:.0e}); the result may differ from '
+                       'the sequential extended Kalman filter')
 
 
 def _log_opt(blocks, s_finals, info) -> None:
@@ -403,6 +437,10 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
     logger.debug(f'correlated keypoint blocks: {blocks}')
     logger.debug(f'[profile]   build_R: {time.perf_counter() - t0:.3f}s')   # upload; R is never built
 
+    # the reference computes the initial guesses before it looks at smooth_param (eks/core.py:
+    # 233-236), so fewer than two frames raise whether or not s is given
+    if P.T < 2:
+        raise ValueError('Not enough frames to compute temporal differences.')
     s_finals = np.empty(K, dtype=float)
     if smooth_param is not None:
         if isinstance(smooth_param, (int, float)):

@@ -288,14 +288,19 @@ EKS_HD void dense_replay_chunk_obs(const Obs& obs, int K, int k, int t0, int len
       P = mat_add(P, sQ);
     }
     if constexpr (EKF) {
+      // A non-finite predicted mean (a camera-plane crossing or garbage from a poor linearisation
+      // in an EARLY sweep - the sequential filter never sees it) must not be stored: the next
+      // sweep's elements would be built from NaN and every later prefix poisoned for good.  Such a
+      // frame keeps its old linearisation point and reports an unconverged sweep.
       double xl[D];
 #pragma unroll
       for (int a = 0; a < D; ++a) {
-        xl[a] = m.a[a];
         const double old = xlin[a + (size_t)i * D];
+        const bool fin = fabs(m.a[a]) <= 1.7e308;          // false for NaN and +-inf
+        xl[a] = fin ? m.a[a] : old;
         const double scale = fabs(old) > 1.0 ? fabs(old) : 1.0;
-        const double ch = fabs(xl[a] - old) / scale;
-        resid = (ch > resid || ch != ch) ? ch : resid;     // a NaN sticks
+        const double ch = fin ? fabs(xl[a] - old) / scale : 1e300;
+        resid = ch > resid ? ch : resid;
         xlin[a + (size_t)i * D] = xl[a];
       }
       ll += belief_update_obs<D, true>(obs, k, t, xl, m, P);

@@ -2,11 +2,20 @@
 RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 
 The path partitions into independent units - sessions, and keypoints (or blocks of keypoints that
-share one s) inside a session (reference eks/core.py:223-224, vmapped at :293/:684) - so ranks
-exchange nothing while smoothing.  The only collective is a terminal all-gather of the
-per-keypoint s_finals (K float64 per session: a few hundred bytes); smoothed means / covariances
-stay on the rank that produced them (gathering them would be root-ingress bound over xGMI,
-SURVEY.md 8e).
+share one s) inside a session (reference eks/core.py:223-224, vmapped at :293/:684; the only
+coupling is the summed loss of a block, :474-476) - so ranks exchange nothing while smoothing.
+The only collective is a terminal TENSOR all-gather of the per-keypoint s_finals (K float64 per
+session); smoothed means / covariances stay on the rank that produced them (gathering them would
+be root-ingress bound over xGMI) unless a caller asks for them.
+
+    smooth_sessions_batched      many sessions: each rank stacks its sessions along the keypoint
+                                 axis ON THE DEVICE and issues one kernel sequence per batch
+                                 (BASELINE.json configs[4]: 128 sessions x 32 keypoints per GPU
+                                 become one 4096-keypoint launch)
+    smooth_session_keypoint_sharded   one large session: keypoint blocks are dealt to the ranks,
+                                 blocks kept whole (configs[2] at 32 keypoints per GPU)
+    smooth_sessions              the simple session-at-a-time loop (kept for callers whose
+                                 sessions differ in length)
 """
 from __future__ import annotations
 
@@ -15,6 +24,9 @@ from typing import Callable, Sequence
 import numpy as np
 
 
+# ------------------------------------------------------------------------------------------
+# partitioning (pure functions)
+# ------------------------------------------------------------------------------------------
 def session_shard(n_sessions: int, world_size: int, rank: int) -> list[int]:
     """Round-robin session ids owned by `rank`."""
     return list(range(rank, n_sessions, world_size))
@@ -32,39 +44,247 @@ def keypoint_block_shard(blocks: Sequence[Sequence[int]], world_size: int, rank:
     return sorted(i for i, r in owner if r == rank)
 
 
-def gather_session_results(local: dict[int, np.ndarray], n_sessions: int, group=None) -> list[np.ndarray]:
-    """All-gather {session id: s_finals} from every rank; returns the list ordered by session id."""
+def plan_batches(shapes: Sequence[tuple], max_keypoints: int) -> list[list[int]]:
+    """Group positions of `shapes` = [(T, K, D, O), ...] into batches that can be stacked along K:
+    equal (T, D, O), at most `max_keypoints` keypoints per batch (a single larger session is its
+    own batch).  Order inside a batch is the input order."""
+    groups: dict[tuple, list[int]] = {}
+    for pos, (T, K, D, O) in enumerate(shapes):
+        groups.setdefault((T, D, O), []).append(pos)
+    out = []
+    for members in groups.values():
+        cur, n = [], 0
+        for pos in members:
+            k = shapes[pos][1]
+            if cur and n + k > max_keypoints:
+                out.append(cur)
+                cur, n = [], 0
+            cur.append(pos)
+            n += k
+        if cur:
+            out.append(cur)
+    return sorted(out, key=lambda b: b[0])
+
+
+# ------------------------------------------------------------------------------------------
+# collectives
+# ------------------------------------------------------------------------------------------
+def _dist():
     import torch.distributed as dist
-    world = dist.get_world_size(group)
-    bucket = [None] * world
-    dist.all_gather_object(bucket, {int(k): np.asarray(v, dtype=np.float64) for k, v in local.items()},
-                           group=group)
+    return dist
+
+
+def _rank_world(group=None) -> tuple[int, int]:
+    """(rank, world size); a process that never initialised torch.distributed is a world of one,
+    so the drivers below also serve a single GPU."""
+    dist = _dist()
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def _collective_device(group=None):
+    """Tensors handed to the collective live where the backend wants them: the rank's GPU for
+    nccl (RCCL), host memory for gloo."""
+    import torch
+    dist = _dist()
+    if dist.get_backend(group) == 'nccl':
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
+
+
+def all_gather_ragged(values: np.ndarray, group=None) -> list[np.ndarray]:
+    """All-gather one float64 vector per rank (lengths may differ) with two tensor collectives
+    (lengths, then zero-padded payloads) - no pickling.  Returns the per-rank vectors."""
+    import torch
+    dist = _dist()
+    values = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+    world = _rank_world(group)[1]
+    if world == 1:
+        return [values.copy()]
+    dev = _collective_device(group)
+    n = torch.tensor([values.size], dtype=torch.int64, device=dev)
+    lens = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(lens, n, group=group)
+    lens = [int(x.item()) for x in lens]
+    cap = max(max(lens), 1)
+    buf = torch.zeros(cap, dtype=torch.float64, device=dev)
+    buf[:values.size] = torch.as_tensor(values, device=dev)
+    parts = [torch.empty(cap, dtype=torch.float64, device=dev) for _ in range(world)]
+    dist.all_gather(parts, buf, group=group)
+    return [p[:n_r].cpu().numpy() for p, n_r in zip(parts, lens)]
+
+
+def gather_session_results(local: dict[int, np.ndarray], n_sessions: int, group=None) -> list[np.ndarray]:
+    """All-gather {session id: s_finals} from every rank (tensor collectives: a header vector of
+    (id, K) pairs and the concatenated values); returns the list ordered by session id."""
+    ids = sorted(int(i) for i in local)
+    header = np.array([[i, np.asarray(local[i]).size] for i in ids], dtype=np.float64).reshape(-1)
+    flat = np.concatenate([np.asarray(local[i], dtype=np.float64).reshape(-1) for i in ids]) \
+        if ids else np.zeros(0)
+    headers = all_gather_ragged(header, group)
+    payloads = all_gather_ragged(flat, group)
     merged: dict[int, np.ndarray] = {}
-    for part in bucket:
-        for k, v in part.items():
-            if k in merged:
-                raise RuntimeError(f'session {k} was produced by two ranks')
-            merged[k] = v
+    for h, p in zip(headers, payloads):
+        off = 0
+        for sid, k in h.reshape(-1, 2).astype(np.int64):
+            if int(sid) in merged:
+                raise RuntimeError(f'session {int(sid)} was produced by two ranks')
+            merged[int(sid)] = p[off:off + int(k)].copy()
+            off += int(k)
     missing = [i for i in range(n_sessions) if i not in merged]
     if missing:
         raise RuntimeError(f'sessions {missing} were produced by no rank')
     return [merged[i] for i in range(n_sessions)]
 
 
+# ------------------------------------------------------------------------------------------
+# drivers
+# ------------------------------------------------------------------------------------------
+def _default_smooth_fn():
+    from .core import run_kalman_smoother
+    return run_kalman_smoother
+
+
 def smooth_sessions(load_session: Callable[[int], dict], n_sessions: int, smooth_fn: Callable | None = None,
                     group=None, **kalman_kwargs):
-    """Smooth `n_sessions` independent sessions across the ranks of `group`.
+    """Smooth `n_sessions` independent sessions across the ranks of `group`, one session per call.
 
     load_session(i) returns the keyword arguments of run_kalman_smoother for session i
     (ys, m0s, S0s, As, Cs, Qs, ensemble_vars).  Each rank processes its round-robin shard on its
     own GPU and keeps the smoothed arrays; returns (local results {i: (s_finals, ms, Vs)},
-    s_finals of ALL sessions gathered on every rank)."""
-    import torch.distributed as dist
+    s_finals of ALL sessions gathered on every rank).  Sessions of equal length are smoothed
+    far faster by `smooth_sessions_batched`."""
     if smooth_fn is None:
-        from .core import run_kalman_smoother as smooth_fn
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+        smooth_fn = _default_smooth_fn()
+    rank, world = _rank_world(group)
     mine = {}
     for i in session_shard(n_sessions, world, rank):
         mine[i] = smooth_fn(**load_session(i), **kalman_kwargs)
     all_s = gather_session_results({i: r[0] for i, r in mine.items()}, n_sessions, group)
     return mine, all_s
+
+
+def _cat(parts, axis):
+    """Concatenate NumPy arrays or torch tensors (device tensors stay on the device)."""
+    if hasattr(parts[0], 'detach'):
+        import torch
+        return torch.cat(list(parts), dim=axis)
+    return np.concatenate([np.asarray(p) for p in parts], axis=axis)
+
+
+def stack_sessions(sessions: Sequence[dict], blocks: Sequence[Sequence[Sequence[int]] | None] | None = None):
+    """Stack run_kalman_smoother inputs of several sessions of equal (T, D, O) along the keypoint
+    axis.  Returns (kwargs of ONE run_kalman_smoother call, keypoint offsets [n+1], blocks of the
+    stacked problem - each session's blocks shifted by its offset, singletons where a session gave
+    none)."""
+    offs = np.zeros(len(sessions) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([np.shape(s['m0s'])[0] for s in sessions])
+    kw = dict(ys=_cat([s['ys'] for s in sessions], 0),
+              ensemble_vars=_cat([s['ensemble_vars'] for s in sessions], 1))
+    for name in ('m0s', 'S0s', 'As', 'Cs', 'Qs'):
+        kw[name] = np.concatenate([np.asarray(s[name], dtype=np.float64) for s in sessions], axis=0)
+    stacked_blocks = []
+    for j, s in enumerate(sessions):
+        b = blocks[j] if blocks is not None and blocks[j] else [[k] for k in range(int(offs[j + 1] - offs[j]))]
+        stacked_blocks += [[int(offs[j]) + int(k) for k in blk] for blk in b]
+    return kw, offs, stacked_blocks
+
+
+def smooth_sessions_batched(load_session: Callable[[int], dict], n_sessions: int,
+                            smooth_fn: Callable | None = None, group=None,
+                            max_batch_keypoints: int = 8192, session_blocks: Callable | None = None,
+                            **kalman_kwargs):
+    """Many independent sessions across the ranks of `group`, batched on the device.
+
+    Each rank takes its round-robin shard, stacks sessions of equal (T, D, O) along the keypoint
+    axis (at most `max_batch_keypoints` keypoints per batch: 8192 x 50 000 frames = 16 GB of
+    inputs and outputs at 40 B per keypoint-frame) and runs ONE run_kalman_smoother per batch -
+    keypoints are independent (reference eks/core.py:293), so a batch is exactly the sessions
+    smoothed one by one.  `smooth_param` may be a scalar, or a callable i -> per-session value.
+    `session_blocks(i)` optionally returns session i's keypoint blocks.
+
+    Returns (local {i: (s_finals, ms, Vs)} - views into the batch outputs, on the device when
+    return_device=True is passed through - and s_finals of ALL sessions, gathered with tensor
+    collectives, on every rank)."""
+    if smooth_fn is None:
+        smooth_fn = _default_smooth_fn()
+    rank, world = _rank_world(group)
+    ids = session_shard(n_sessions, world, rank)
+    loaded = {i: load_session(i) for i in ids}
+    shapes = [(np.shape(loaded[i]['ys'])[1], np.shape(loaded[i]['ys'])[0],
+               np.shape(loaded[i]['m0s'])[1], np.shape(loaded[i]['ys'])[2]) for i in ids]
+    sp = kalman_kwargs.pop('smooth_param', None)
+    mine = {}
+    for batch in plan_batches(shapes, max_batch_keypoints):
+        sess = [loaded[ids[p]] for p in batch]
+        blk = [session_blocks(ids[p]) for p in batch] if session_blocks is not None else None
+        kw, offs, blocks = stack_sessions(sess, blk)
+        if callable(sp):
+            per = [np.broadcast_to(np.asarray(sp(ids[p]), dtype=float), (int(offs[j + 1] - offs[j]),))
+                   for j, p in enumerate(batch)]
+            kw['smooth_param'] = list(np.concatenate(per))
+        else:
+            kw['smooth_param'] = sp
+        s, ms, Vs = smooth_fn(**kw, blocks=blocks, **kalman_kwargs)
+        for j, p in enumerate(batch):
+            a, b = int(offs[j]), int(offs[j + 1])
+            mine[ids[p]] = (np.asarray(s[a:b]), ms[a:b], Vs[a:b])
+        for p in batch:                       # inputs of a finished batch are released
+            loaded.pop(ids[p], None)
+    all_s = gather_session_results({i: r[0] for i, r in mine.items()}, n_sessions, group)
+    return mine, all_s
+
+
+def smooth_session_keypoint_sharded(ys, m0s, S0s, As, Cs, Qs, ensemble_vars,
+                                    blocks: Sequence[Sequence[int]] | None = None,
+                                    smooth_fn: Callable | None = None, group=None,
+                                    smooth_param=None, **kalman_kwargs):
+    """ONE large session across the ranks of `group`: keypoint blocks are dealt to the ranks
+    (greedy balance, a block - whose members share one s, reference eks/core.py:474-476 - is never
+    split), every rank smooths its keypoints on its own GPU with no exchange, and the per-keypoint
+    s_finals are all-gathered (tensor collective).  Arguments as run_kalman_smoother; every rank
+    passes the full arrays (or at least its own keypoints' slices filled in).
+
+    Returns (s_finals of all K keypoints, owned keypoint indices (sorted), ms, Vs of the owned
+    keypoints in that order)."""
+    if smooth_fn is None:
+        smooth_fn = _default_smooth_fn()
+    rank, world = _rank_world(group)
+    K = np.shape(m0s)[0]
+    if not blocks:
+        blocks = [[k] for k in range(K)]
+    flat = sorted(int(k) for b in blocks for k in b)
+    if flat != list(range(K)):
+        raise ValueError(f'blocks must partition the {K} keypoints')
+    own_blocks = [list(map(int, blocks[i])) for i in keypoint_block_shard(blocks, world, rank)]
+    own = sorted(k for b in own_blocks for k in b)
+    local_of = {k: j for j, k in enumerate(own)}
+    if own:
+        idx = np.asarray(own)
+        take = (lambda a, axis: a.index_select(axis, _index_like(a, idx)) if hasattr(a, 'detach')
+                else np.take(np.asarray(a), idx, axis=axis))
+        sp = smooth_param
+        if sp is not None and not isinstance(sp, (int, float)):
+            sp = np.broadcast_to(np.asarray(sp, dtype=float), (K,))[idx]
+            sp = list(sp)
+        s, ms, Vs = smooth_fn(ys=take(ys, 0), m0s=np.asarray(m0s)[idx], S0s=np.asarray(S0s)[idx],
+                              As=np.asarray(As)[idx], Cs=np.asarray(Cs)[idx], Qs=np.asarray(Qs)[idx],
+                              ensemble_vars=take(ensemble_vars, 1), smooth_param=sp,
+                              blocks=[[local_of[k] for k in b] for b in own_blocks], **kalman_kwargs)
+        s = np.asarray(s, dtype=np.float64)
+    else:
+        s, ms, Vs = np.zeros(0), None, None
+    keys = all_gather_ragged(np.asarray(own, dtype=np.float64), group)
+    vals = all_gather_ragged(s, group)
+    s_all = np.full(K, np.nan)
+    for kk, vv in zip(keys, vals):
+        s_all[kk.astype(np.int64)] = vv
+    if np.isnan(s_all).any():
+        raise RuntimeError('some keypoints were smoothed by no rank')
+    return s_all, np.asarray(own, dtype=np.int64), ms, Vs
+
+
+def _index_like(t, idx):
+    import torch
+    return torch.as_tensor(idx, dtype=torch.int64, device=t.device)

@@ -151,6 +151,40 @@ def test_triangulation_and_geometric_initialisation():
         assert np.allclose(g, r, rtol=1e-12, atol=0)
 
 
+def test_triangulation_drops_non_finite_views_per_point():
+    """One NaN marker must not abort the run (aniposelib drops that view for that point only and
+    returns NaN when fewer than two views are left)."""
+    prob = synth.calibrated_multicam(200, 1, 4, seed=6)
+    xy = np.stack([cal.project(c, prob['latent'][:, 0]) for c in prob['cams_packed']])     # (V,T,2)
+    clean = cal.triangulate(prob['cams_packed'], xy)
+    bad = xy.copy()
+    bad[1, 10, 0] = np.nan                 # one view gone at frame 10
+    bad[0, 20] = np.inf                    # another at frame 20
+    bad[:3, 30] = np.nan                   # only one view left at frame 30
+    bad[:, 40] = np.nan                    # none at frame 40
+    tri = cal.triangulate(prob['cams_packed'], bad)
+    keep = np.ones(200, bool)
+    keep[[10, 20, 30, 40]] = False
+    np.testing.assert_array_equal(tri[keep], clean[keep])
+    # exact projections: three views triangulate the same point
+    assert np.abs(tri[[10, 20]] - prob['latent'][[10, 20], 0]).max() < 1e-6
+    assert np.isnan(tri[30]).all() and np.isnan(tri[40]).all()
+    ref10 = cal.triangulate(prob['cams_packed'][[0, 2, 3]], xy[[0, 2, 3], 10:11])
+    np.testing.assert_allclose(tri[10], ref10[0], rtol=1e-9)
+
+
+def test_camera_group_orders_tables_like_aniposelib(tmp_path):
+    """aniposelib sorts the TOML keys as strings: cam_10 comes before cam_2."""
+    fn = tmp_path / 'calibration.toml'
+    body = ''
+    for i in (0, 1, 2, 10):
+        body += (f'[cam_{i}]\nname = "c{i}"\nmatrix = [ [ 900.0, 0.0, 320.0,], [ 0.0, 900.0, 240.0,], '
+                 f'[ 0.0, 0.0, 1.0,],]\ndistortions = [ 0.0, 0.0, 0.0, 0.0, 0.0,]\n'
+                 f'rotation = [ 0.0, 0.{i}, 0.0,]\ntranslation = [ 0.0, 0.0, 900.0,]\n\n')
+    fn.write_text(body)
+    assert [c.name for c in cal.CameraGroup.load(str(fn)).cameras] == ['c0', 'c1', 'c10', 'c2']
+
+
 def test_camera_group_from_calibration_toml(tmp_path):
     fn = tmp_path / 'calibration.toml'
     fn.write_text('''[cam_0]

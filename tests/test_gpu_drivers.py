@@ -64,9 +64,10 @@ def test_singlecam_adam_matches_golden_basin_and_oracle_at_same_s(pupil):
     from eks_amd.singlecam_smoother import ensemble_kalman_smoother_singlecam
     ma = MarkerArray(pupil['markers'].astype(np.float64), data_fields=['x', 'y', 'likelihood'])
     df, s = ensemble_kalman_smoother_singlecam(ma, list(pupil['keypoints']))      # smooth_param=None
-    # the Adam stop test is chaotic in the last digits: s is compared loosely ...
-    assert np.all(np.abs(np.log(s) - np.log(pupil['adam_s'])) < 0.25)
-    # ... and the smoothed output strictly, against the oracle run at the SAME s
+    # the device optimiser reproduces the oracle's float64 Adam trajectory (same stopping
+    # iteration): |d log s| <= 1e-3 (tools/fuzz_adam.py measures 5e-7 on this path) ...
+    assert np.all(np.abs(np.log(s) - np.log(pupil['adam_s'])) < 1e-3)
+    # ... and the smoothed output, against the oracle run at the SAME s
     arrs = orc.singlecam_arrays(pupil['markers'])
     Rd = orc.build_R_from_vars(np.swapaxes(arrs['ensemble_vars'], 0, 1))
     ms, Vs, _ = orc.kalman_smoother(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'],
@@ -102,13 +103,20 @@ def test_run_kalman_smoother_contract_and_blocks(pupil):
     np.testing.assert_allclose(s_b, s_o, rtol=1e-3)           # 5 Adam steps, no stop-test chaos yet
     s_f, _, _ = run_kalman_smoother(*args, s_frames=[(0, 200), (300, None)])
     s_fo, _, _, _ = orc.run_kalman_smoother(*args, s_frames=[(0, 200), (300, None)])
-    assert np.all(np.abs(np.log(s_f) - np.log(s_fo)) < 0.25)
+    assert np.all(np.abs(np.log(s_f) - np.log(s_fo)) < 1e-3)
     with pytest.raises(NotImplementedError):
         run_kalman_smoother(*args, smooth_param=1.0, h_fn=lambda x: x)
     with pytest.raises(ValueError):
         run_kalman_smoother(*args, s_frames=[(5, 5)])
     with pytest.raises(ValueError):
         run_kalman_smoother(arrs['ys'][:, :1], *args[1:6], arrs['ensemble_vars'][:1])   # < 2 frames
+    # ... also with a given s: the reference computes its initial guesses first (eks/core.py:233-236)
+    with pytest.raises(ValueError, match='Not enough frames'):
+        run_kalman_smoother(arrs['ys'][:, :1], *args[1:6], arrs['ensemble_vars'][:1], smooth_param=3.0)
+    # blocks that do not partition the keypoints are refused before anything reaches the device
+    for bad in ([[0, 1], [2]], [[0, 1], [2], [3], [4]], [[0, 0], [1], [2, 3]]):
+        with pytest.raises(ValueError, match='partition'):
+            run_kalman_smoother(*args, blocks=bad, safety_cap=2)
 
 
 def test_fit_eks_singlecam_from_csv(pupil, tmp_path):
@@ -189,7 +197,7 @@ def test_multicam_adam_and_errors(mouse):
     arrs = orc.multicam_arrays(mouse['markers'][:, :, :800, :2], quantile_keep_pca=95.0, n_latent=3, pca_fit=_sk)
     s_o, _, _, _ = orc.run_kalman_smoother(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'],
                                            arrs['Qs'], arrs['ensemble_vars'])
-    assert np.all(np.abs(np.log(s) - np.log(s_o)) < 0.25)
+    assert np.all(np.abs(np.log(s) - np.log(s_o)) < 1e-3)
     with pytest.raises(ValueError):
         ensemble_kalman_smoother_multicam(ma, ['p1', 'p2'], [])
     with pytest.raises(AttributeError):      # a camera group must offer `.cameras` (tests/test_gpu_ekf.py)
