@@ -15,7 +15,14 @@
 //                       REGISTERS, fuses the outgoing belief with the future information and runs
 //                       RTS backwards over the registers, streaming ms / Vs out.
 //
-// HBM traffic: 2 x (y + var) in, 1 x (ms + Vs) out (+ ~7 % for the chunk elements); no filtered
+// For N > 32 chains the scan is folded into its neighbours (round 2): a block of K1 / K3 is 8
+// consecutive chunks of one 64-chain tile, K1's block composes its 8 elements into the block
+// aggregate (LDS, one barrier), one small launch scans the aggregates per chain, and every K3 wave
+// composes the <= 7 elements before / after its own chunk inside the block itself - 3 launches
+// instead of 5, the per-chunk scan results (25.6 MB written + read on the C3 shape) and the second
+// read of the elements never exist.
+//
+// HBM traffic: 2 x (y + var) in, 1 x (ms + Vs) out (+ ~4 % for the chunk elements); no filtered
 // state ever touches memory.  No MFMA: the algebra is scalar.  No LDS in K1/K3: each datum is
 // consumed by the lane that loads it; lanes of a wave are consecutive chains, so every row access
 // is a contiguous 256 B (x4 for the four waves of a block: 1 KiB contiguous per frame).
@@ -274,6 +281,208 @@ __global__ __launch_bounds__(kScanCH* kScanCB) void diag_scan_local_kernel(int N
 }
 
 // ------------------------------------------------------------------------------------------
+// Fused form for N > 32 (64-chain tiles): block = kFW waves = kFW consecutive chunks of one tile.
+// ------------------------------------------------------------------------------------------
+constexpr int kFW = 4;
+
+struct BlockMap {
+  int N, T, nc;
+  int ntile;     // ceil(N / 64)
+  int ngrp;      // chunk groups = ceil(nc / kFW)
+  int reverse;   // walk the chunk groups backwards in time
+};
+
+// K1f: chunk elements + the block's aggregate (time-ordered composition of its kFW elements by
+// wave 0, lanes = chains; rows past the end of the sequence are identities).
+template <int B, bool UNIT>
+__global__ __launch_bounds__(64 * kFW) void diag_summarize_blk_kernel(BlockMap L, DiagModel M, DiagWs W,
+                                                                     ScanWs S,
+                                                                     const float* __restrict__ y,
+                                                                     const float* __restrict__ var) {
+  __shared__ float sh[5][kFW][64];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tile = blockIdx.x % L.ntile;
+  int grp = blockIdx.x / L.ntile;
+  if (L.reverse) grp = L.ngrp - 1 - grp;
+  const int n = tile * 64 + lane, j = grp * kFW + w;
+  Elem<float> e = elem_identity<float>();
+  if (n < L.N && j < L.nc) {
+    const ChainParams<float> p = load_chain_params(M, n);
+    const int t0 = j * B;
+    e = summarize_chunk<B, UNIT>(y, var, L.N, n, t0, min(B, L.T - t0), p);
+    const size_t o = (size_t)j * L.N + n;
+    W.eA[o] = e.A;
+    W.eb[o] = e.b;
+    W.eC[o] = e.C;
+    W.eEta[o] = e.eta;
+    W.eJ[o] = e.J;
+  }
+  sh[0][w][lane] = e.A;
+  sh[1][w][lane] = e.b;
+  sh[2][w][lane] = e.C;
+  sh[3][w][lane] = e.eta;
+  sh[4][w][lane] = e.J;
+  __syncthreads();
+  if (w != 0 || n >= L.N) return;
+  Elem<float> a = e;
+#pragma unroll
+  for (int q = 1; q < kFW; ++q)
+    a = elem_combine(a, Elem<float>{sh[0][q][lane], sh[1][q][lane], sh[2][q][lane], sh[3][q][lane],
+                                    sh[4][q][lane]});
+  const size_t o = (size_t)grp * L.N + n;
+  S.gA[o] = a.A;
+  S.gb[o] = a.b;
+  S.gC[o] = a.C;
+  S.gEta[o] = a.eta;
+  S.gJ[o] = a.J;
+}
+
+// K3f: replay of chunk j = grp * kFW + w.  The belief entering the block and the information
+// leaving it come from the scan of the block aggregates; the wave pushes the former through the
+// elements of the chunks before its own and pulls the latter back through those after it (<= 7
+// compositions each, element rows shared by the block's waves through L2) before it streams its
+// own 64 rows of y, var (holding both sets of elements in registers beside the chunk cost 180 VGPRs
+// and two thirds of the occupancy).
+template <int B, bool UNIT, int VS_ROW>
+__global__ __launch_bounds__(64 * kFW) void diag_replay_blk_kernel(BlockMap L, DiagModel M, DiagWs W,
+                                                                  ScanWs S,
+                                                                  const float* __restrict__ y,
+                                                                  const float* __restrict__ var,
+                                                                  float* __restrict__ ms,
+                                                                  float* __restrict__ Vs) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tile = blockIdx.x % L.ntile;
+  int grp = blockIdx.x / L.ntile;
+  if (L.reverse) grp = L.ngrp - 1 - grp;
+  const int n = tile * 64 + lane, j = grp * kFW + w;
+  if (n >= L.N || j >= L.nc) return;
+  const int j0 = grp * kFW, j1 = min(j0 + kFW, L.nc);
+  // everything the forward pass needs is requested at once: the chunk's own 64 rows, then the
+  // elements of the block's earlier chunks (wave-uniform predicate)
+  const ChainParams<float> p = load_chain_params(M, n);
+  const int t0 = j * B;
+  const int len = min(B, L.T - t0);
+  float v0[B], v1[B];
+  load_chunk<B>(y, var, L.N, n, t0, len, v0, v1);
+  Elem<float> ef[kFW - 1];
+#pragma unroll
+  for (int q = 0; q < kFW - 1; ++q)
+    if (j0 + q < j) ef[q] = load_elem(W, (size_t)(j0 + q) * L.N + n);
+  const size_t ob = (size_t)grp * L.N + n;
+  float m = S.bm[ob], P = S.bP[ob], eta = S.bEta[ob], J = S.bJ[ob];
+#pragma unroll
+  for (int q = 0; q < kFW - 1; ++q)
+    if (j0 + q < j) elem_apply(ef[q], m, P);
+  // the later chunks' elements arrive while the filter runs over the registers
+  Elem<float> eb[kFW - 1];
+#pragma unroll
+  for (int q = 0; q < kFW - 1; ++q)
+    if (j + 1 + q < j1) eb[q] = load_elem(W, (size_t)(j + 1 + q) * L.N + n);
+  filter_loaded<B, UNIT>(v0, v1, len, p, m, P);
+#pragma unroll
+  for (int q = kFW - 2; q >= 0; --q)
+    if (j + 1 + q < j1) elem_back(eb[q], eta, J);
+  fuse_info(m, P, eta, J);
+  smooth_store<B, UNIT, VS_ROW>(v0, v1, ms, Vs, L.N, n, n % M.D, t0, len, p, m, P);
+}
+
+// S2f: scan of the block aggregates, ngrp per chain (hundreds to thousands).  Block = 4 chains x
+// 64 slots (thread t: chain t & 3, slot t >> 2); a slot owns `per` consecutive aggregates, all
+// requested at once (registers, PER at a time): it composes them, the slots of a chain are scanned
+// by stride-4 shuffles inside each wave (16 slots) and through LDS across the 4 waves, and each
+// slot walks its aggregates again from the belief entering its first one (forward) / the
+// information leaving its last one (backward), writing the per-block results.
+template <int PER>
+__global__ __launch_bounds__(256) void diag_scan_groups_kernel(int N, DiagModel M, ScanWs S) {
+  __shared__ float tot[2][5][4][4];        // [direction][field][wave][chain]
+  const int c = threadIdx.x & 3, slot = threadIdx.x >> 2, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + c;
+  const int per = (S.nblk + 63) / 64;      // <= PER, or the slot re-reads in batches of PER
+  const int q0 = min(slot * per, S.nblk), q1 = min(q0 + per, S.nblk);
+  const bool live = n < N;
+  auto agg = [&](int q) {
+    const size_t o = (size_t)q * N + n;
+    return Elem<float>{S.gA[o], S.gb[o], S.gC[o], S.gEta[o], S.gJ[o]};
+  };
+  Elem<float> own = elem_identity<float>();
+  Elem<float> e[PER];
+  if (live) {
+    for (int b0 = q0; b0 < q1; b0 += PER) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i)
+        if (b0 + i < q1) e[i] = agg(b0 + i);
+#pragma unroll
+      for (int i = 0; i < PER; ++i)
+        if (b0 + i < q1) own = elem_combine(own, e[i]);
+    }
+  }
+  // inclusive scans over the wave's 16 slots of each chain (lanes 4 apart), both directions
+  Elem<float> f = own, r = own;
+#pragma unroll
+  for (int off = 4; off < 64; off <<= 1) {
+    const Elem<float> up = shfl_up_elem(f, off), dn = shfl_down_elem(r, off);
+    if (lane >= off) f = elem_combine(up, f);
+    if (lane + off < 64) r = elem_combine(r, dn);
+  }
+  if (lane >= 60) {                        // the wave's whole composition, per chain
+    tot[0][0][w][c] = f.A; tot[0][1][w][c] = f.b; tot[0][2][w][c] = f.C; tot[0][3][w][c] = f.eta; tot[0][4][w][c] = f.J;
+  }
+  if (lane < 4) {
+    tot[1][0][w][c] = r.A; tot[1][1][w][c] = r.b; tot[1][2][w][c] = r.C; tot[1][3][w][c] = r.eta; tot[1][4][w][c] = r.J;
+  }
+  __syncthreads();
+  if (!live) return;
+  // exclusive prefix of this slot: earlier waves' totals, then the wave's earlier slots
+  Elem<float> pre = elem_identity<float>(), post = elem_identity<float>();
+  for (int v = 0; v < w; ++v)
+    pre = elem_combine(pre, Elem<float>{tot[0][0][v][c], tot[0][1][v][c], tot[0][2][v][c], tot[0][3][v][c], tot[0][4][v][c]});
+  for (int v = 3; v > w; --v)
+    post = elem_combine(Elem<float>{tot[1][0][v][c], tot[1][1][v][c], tot[1][2][v][c], tot[1][3][v][c], tot[1][4][v][c]}, post);
+  Elem<float> fe = shfl_up_elem(f, 4), re = shfl_down_elem(r, 4);
+  if (lane < 4) fe = elem_identity<float>();
+  if (lane >= 60) re = elem_identity<float>();
+  pre = elem_combine(pre, fe);
+  post = elem_combine(re, post);
+  float m, P;
+  load_chain_prior(M, n, m, P);
+  elem_apply(pre, m, P);                   // belief entering aggregate q0
+  float eta = 0.f, J = 0.f;
+  elem_back(post, eta, J);                 // information leaving aggregate q1 - 1
+  const bool held = q1 - q0 <= PER;        // the single batch is still in registers
+  for (int b0 = q0; b0 < q1; b0 += PER) {
+    if (!held) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i)
+        if (b0 + i < q1) e[i] = agg(b0 + i);
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+      if (b0 + i < q1) {
+        const size_t o = (size_t)(b0 + i) * N + n;
+        S.bm[o] = m;
+        S.bP[o] = P;
+        elem_apply(e[i], m, P);
+      }
+  }
+  for (int b1 = q1; b1 > q0; b1 -= PER) {  // batches [b1 - PER, b1) from the end
+    const int lo = max(q0, b1 - PER);
+    if (!held) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i)
+        if (lo + i < b1) e[i] = agg(lo + i);
+    }
+#pragma unroll
+    for (int i = PER - 1; i >= 0; --i)
+      if (lo + i < b1) {
+        const size_t o = (size_t)(lo + i) * N + n;
+        S.bEta[o] = eta;
+        S.bJ[o] = J;
+        elem_back(e[i], eta, J);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 constexpr int kChunk = 32;  // frames per lane; 2*B VGPRs hold the chunk in K3
@@ -282,7 +491,7 @@ static inline size_t plane_bytes(int nc, int N) { return align_up((size_t)nc * N
 
 size_t diag_smooth_workspace_bytes(int T, int N) {
   const int nc = (T + kChunk - 1) / kChunk;
-  const int nblk = (nc + kScanCB - 1) / kScanCB;
+  const int nblk = (nc + kFW - 1) / kFW;       // fused grouping (>= the legacy nc / kScanCB blocks)
   return 9 * plane_bytes(nc, N) + 9 * plane_bytes(nblk, N);
 }
 
@@ -334,21 +543,75 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
   DiagWs W;
   float** planes[9] = {&W.eA, &W.eb, &W.eC, &W.eEta, &W.eJ, &W.pm, &W.pP, &W.sEta, &W.sJ};
   for (int i = 0; i < 9; ++i) *planes[i] = reinterpret_cast<float*>(base + i * pb);
+  // Fused scan (measured, MI355X, fixed s, full Vs): 100 000 x 256 keypoints 0.309 -> 0.287 ms,
+  // 10 000 x 64 31 -> 22 us, 50 000 x 1024 0.632 -> 0.623 ms.  Not for very wide problems (50 000
+  // x 4096 keypoints 2.45 -> 2.48 ms: the three-kernel scan is already 12 % of the time there and
+  // the 256-row blocks of the fused kernels stride further) nor for sequences whose group scan
+  // would leave its registers (more than 16 aggregates per slot: 400 000 x 64 0.345 -> 0.391 ms).
+  const char* legacy = getenv("EKS_SMOOTH_UNFUSED");
+  const int ngrp_f = (L.nc + kFW - 1) / kFW;
+  const bool fused = L.nt_log2 == 6 && (legacy ? legacy[0] == '0' : (N <= 4096 && ngrp_f <= 1024));
   ScanWs S;
-  S.nblk = (L.nc + kScanCB - 1) / kScanCB;
+  S.nblk = fused ? (L.nc + kFW - 1) / kFW : (L.nc + kScanCB - 1) / kScanCB;
   const size_t sb = plane_bytes(S.nblk, N);
   float** splanes[9] = {&S.gA, &S.gb, &S.gC, &S.gEta, &S.gJ, &S.bm, &S.bP, &S.bEta, &S.bJ};
   for (int i = 0; i < 9; ++i) *splanes[i] = reinterpret_cast<float*>(base + 9 * pb + i * sb);
-
-  const int cpw = 64 >> L.nt_log2;
-  const long waves = (long)L.ntile * ((L.nc + cpw - 1) / cpw);
-  const dim3 grid((unsigned)((waves + 3) / 4));
+  const int vs_row = vs_diag ? 0 : D;
   const bool unit = d.flags & EKS_FLAG_UNIT_AC;
   // K1 and K3 walk the chunks in opposite directions: the tail of one stream of y, var is the
   // head of the next and can be served from the 256 MiB Infinity Cache.  EKS_SUMMARIZE_REVERSE
   // picks which of the two runs backwards (A/B knob).
   const char* k1r = getenv("EKS_SUMMARIZE_REVERSE");
   const int k1_reverse = (k1r && k1r[0] == '1') ? 1 : 0;
+  const char* fwd = getenv("EKS_REPLAY_FORWARD");
+  const int k3_reverse = (fwd && fwd[0] == '1') ? 0 : (fwd && fwd[0] == '0') ? 1 : !k1_reverse;
+  if (fused) {
+    BlockMap Bm{N, T, L.nc, L.ntile, S.nblk, k1_reverse};
+    const dim3 bgrid((unsigned)((long)Bm.ntile * Bm.ngrp)), bblock(64 * kFW);
+    {
+      ProfScope ps("diag_summarize", st);
+      if (unit)
+        hipLaunchKernelGGL((diag_summarize_blk_kernel<kChunk, true>), bgrid, bblock, 0, st, Bm, M, W, S, y, var);
+      else
+        hipLaunchKernelGGL((diag_summarize_blk_kernel<kChunk, false>), bgrid, bblock, 0, st, Bm, M, W, S, y, var);
+    }
+    {
+      ProfScope ps("diag_scan", st);
+      // a slot's aggregates stay in registers when there are at most 16 of them (T <= 131 072)
+      if ((S.nblk + 63) / 64 <= 8)
+        hipLaunchKernelGGL(diag_scan_groups_kernel<8>, dim3((N + 3) / 4), dim3(256), 0, st, N, M, S);
+      else
+        hipLaunchKernelGGL(diag_scan_groups_kernel<16>, dim3((N + 3) / 4), dim3(256), 0, st, N, M, S);
+    }
+    ProfScope ps("diag_replay", st);
+    Bm.reverse = k3_reverse;
+#define EKS_REPLAY_BLK(R)                                                                              \
+  case R:                                                                                              \
+    if (unit)                                                                                          \
+      hipLaunchKernelGGL((diag_replay_blk_kernel<kChunk, true, R>), bgrid, bblock, 0, st, Bm, M, W, S, \
+                         y, var, ms, Vs);                                                              \
+    else                                                                                               \
+      hipLaunchKernelGGL((diag_replay_blk_kernel<kChunk, false, R>), bgrid, bblock, 0, st, Bm, M, W, S, \
+                         y, var, ms, Vs);                                                              \
+    break;
+    switch (vs_row) {
+      EKS_REPLAY_BLK(0)
+      EKS_REPLAY_BLK(1)
+      EKS_REPLAY_BLK(2)
+      EKS_REPLAY_BLK(3)
+      EKS_REPLAY_BLK(4)
+      EKS_REPLAY_BLK(5)
+      EKS_REPLAY_BLK(6)
+      EKS_REPLAY_BLK(7)
+      EKS_REPLAY_BLK(8)
+    }
+#undef EKS_REPLAY_BLK
+    return hip_status(hipGetLastError());
+  }
+
+  const int cpw = 64 >> L.nt_log2;
+  const long waves = (long)L.ntile * ((L.nc + cpw - 1) / cpw);
+  const dim3 grid((unsigned)((waves + 3) / 4));
   {
     ProfScope ps("diag_summarize", st);
     LaneMap L = Lf;
@@ -365,12 +628,10 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
     hipLaunchKernelGGL(diag_scan_blocks_kernel, dim3((N + 3) / 4), dim3(256), 0, st, N, M, S);
     hipLaunchKernelGGL(diag_scan_local_kernel, sgrid, sblock, 0, st, N, L.nc, W, S);
   }
-  const int vs_row = vs_diag ? 0 : D;
   {
     ProfScope ps("diag_replay", st);
     LaneMap L = Lf;
-    const char* fwd = getenv("EKS_REPLAY_FORWARD");
-    L.reverse = (fwd && fwd[0] == '1') ? 0 : (fwd && fwd[0] == '0') ? 1 : !k1_reverse;
+    L.reverse = k3_reverse;
     if (unit)
       launch_replay<true>(vs_row, grid, st, L, M, W, y, var, ms, Vs);
     else

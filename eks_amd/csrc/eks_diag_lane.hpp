@@ -71,12 +71,10 @@ EKS_HD Elem<float> summarize_chunk(const float* __restrict__ y, const float* __r
 // means ms[t][n] and covariances: VS_ROW == 0 -> Vs[t][n] (diagonal only);
 // VS_ROW == D -> row d of the keypoint's DxD matrix, Vs[t][n*D + e] (zeros off the diagonal,
 // the full `Vs (K,T,D,D)` contract of eks/core.py:297).
-template <int B, bool UNIT, int VS_ROW>
-EKS_HD void replay_chunk(const float* __restrict__ y, const float* __restrict__ var,
-                         float* __restrict__ ms_out, float* __restrict__ Vs_out, int N, int n,
-                         int d, int t0, int len, const ChainParams<float>& p, float m, float P,
-                         float etaS, float JS) {
-  float v0[B], v1[B];  // y -> mf -> (consumed);  r -> Pf
+// the chunk's observations and variances into registers (2 B loads in flight per lane)
+template <int B>
+EKS_HD void load_chunk(const float* __restrict__ y, const float* __restrict__ var, int N, int n, int t0,
+                       int len, float (&v0)[B], float (&v1)[B]) {
   const size_t base = (size_t)t0 * N + n;
 #pragma unroll
   for (int i = 0; i < B; ++i) {
@@ -85,6 +83,14 @@ EKS_HD void replay_chunk(const float* __restrict__ y, const float* __restrict__ 
       v1[i] = var[base + (size_t)i * N];
     }
   }
+}
+
+// forward filter over the loaded chunk: (v0, v1) = (y, var) become the filtered (mean, variance);
+// (m, P) enters as the predicted belief on the chunk's first frame and leaves as the predicted
+// belief on the frame after the chunk
+template <int B, bool UNIT>
+EKS_HD void filter_loaded(float (&v0)[B], float (&v1)[B], int len, const ChainParams<float>& p, float& m,
+                          float& P) {
 #pragma unroll
   for (int i = 0; i < B; ++i) {
     if (i < len) {
@@ -95,7 +101,15 @@ EKS_HD void replay_chunk(const float* __restrict__ y, const float* __restrict__ 
       v1[i] = Pf;
     }
   }
-  fuse_info(m, P, etaS, JS);  // (m, P) is now the smoothed belief on the frame after the chunk
+}
+
+// RTS pass backwards over the filtered chunk from the smoothed belief (m, P) on the frame after
+// it; streams ms / Vs out
+template <int B, bool UNIT, int VS_ROW>
+EKS_HD void smooth_store(const float (&v0)[B], const float (&v1)[B], float* __restrict__ ms_out,
+                         float* __restrict__ Vs_out, int N, int n, int d, int t0, int len,
+                         const ChainParams<float>& p, float m, float P) {
+  const size_t base = (size_t)t0 * N + n;
 #pragma unroll
   for (int i = B - 1; i >= 0; --i) {
     if (i < len) {
@@ -117,6 +131,25 @@ EKS_HD void replay_chunk(const float* __restrict__ y, const float* __restrict__ 
       }
     }
   }
+}
+
+template <int B, bool UNIT, int VS_ROW>
+EKS_HD void replay_loaded(float (&v0)[B], float (&v1)[B], float* __restrict__ ms_out,
+                          float* __restrict__ Vs_out, int N, int n, int d, int t0, int len,
+                          const ChainParams<float>& p, float m, float P, float etaS, float JS) {
+  filter_loaded<B, UNIT>(v0, v1, len, p, m, P);
+  fuse_info(m, P, etaS, JS);  // (m, P) is now the smoothed belief on the frame after the chunk
+  smooth_store<B, UNIT, VS_ROW>(v0, v1, ms_out, Vs_out, N, n, d, t0, len, p, m, P);
+}
+
+template <int B, bool UNIT, int VS_ROW>
+EKS_HD void replay_chunk(const float* __restrict__ y, const float* __restrict__ var,
+                         float* __restrict__ ms_out, float* __restrict__ Vs_out, int N, int n,
+                         int d, int t0, int len, const ChainParams<float>& p, float m, float P,
+                         float etaS, float JS) {
+  float v0[B], v1[B];  // y -> mf -> (consumed);  r -> Pf
+  load_chunk<B>(y, var, N, n, t0, len, v0, v1);
+  replay_loaded<B, UNIT, VS_ROW>(v0, v1, ms_out, Vs_out, N, n, d, t0, len, p, m, P, etaS, JS);
 }
 
 }  // namespace eks

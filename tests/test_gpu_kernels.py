@@ -46,6 +46,33 @@ def _params_dev(arrs):
     return [_dev(arrs[k], torch.float64) for k in ('m0s', 'S0s', 'As', 'Cs', 'Qs')]
 
 
+def test_smooth_diag_long_sequence_fused_and_unfused_scan_agree_with_oracle(monkeypatch):
+    """T = 140 000 (4 375 chunks): the fused path's group scan re-reads its aggregates in batches
+    (more than 16 per slot); both scan organisations against the C oracle on every frame."""
+    from eks_amd import hip_ops
+    from oracle import c_oracle
+    T, K = 140_000, 40
+    rng = np.random.default_rng(9)
+    y = np.cumsum(rng.standard_normal((T, K, 2)), axis=0).astype(np.float32)
+    var = (0.3 * rng.gamma(2.0, 1.0, (T, K, 2)) + 0.02).astype(np.float32)
+    eye = np.tile(np.eye(2), (K, 1, 1))
+    m0, S0 = np.zeros((K, 2)), eye * 25.0
+    s = np.exp(rng.uniform(-6, 6, K))
+    flags = hip_ops.model_flags(S0, eye, eye, eye)
+    ms_o, Vs_o, _ = c_oracle.smooth(np.transpose(y, (1, 0, 2)).astype(np.float64),
+                                    np.clip(np.transpose(var, (1, 0, 2)).astype(np.float64), 1e-12, None),
+                                    m0, S0, eye, eye, eye, s)
+    Vd_o = np.diagonal(Vs_o, axis1=2, axis2=3)
+    for unfused in ('0', '1'):
+        monkeypatch.setenv('EKS_SMOOTH_UNFUSED', unfused)
+        ms, Vs = hip_ops.smooth(_dev(y), _dev(var), _dev(m0), _dev(S0), _dev(eye), _dev(eye), _dev(eye), _dev(s),
+                                flags=flags, vs_diag=True)
+        ms_k = np.transpose(ms.cpu().numpy().astype(np.float64), (1, 0, 2))
+        Vd = np.transpose(Vs.cpu().numpy().astype(np.float64), (1, 0, 2))
+        assert _rel(ms_k, ms_o, axis_scale=(1, 2)) < 1e-5
+        assert (np.abs(Vd - Vd_o) / Vd_o).max() < 1e-5
+
+
 @pytest.mark.parametrize('T,K,unit,vs_diag', [
     (2000, 4, True, False),      # ibl-pupil-like: 8 chains, several chunks per wave
     (1537, 37, True, True),      # ragged T (not a multiple of the 32-frame chunk), ragged N
