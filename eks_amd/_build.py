@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libeks_hip.so')
 SOURCES = ['eks_api.hip', 'eks_diag.hip', 'eks_diag_nll.hip', 'eks_dense.hip', 'eks_loss.hip',
-           'eks_loss_ar1.hip', 'eks_misc.hip', 'eks_profile.hip']
+           'eks_loss_ar1.hip', 'eks_misc.hip', 'eks_multicam.hip', 'eks_profile.hip']
 ARCH = 'gfx950'
 
 

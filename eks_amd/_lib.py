@@ -54,6 +54,9 @@ SIGNATURES = {
     'eks_ekf_smooth': (ctypes.c_int, [POINTER(EksDims), c_int32] + [c_void_p] * 9 + [c_int32, c_void_p,
                                                                                     c_int32, c_double]
                        + [c_void_p] * 5 + [c_size_t, c_void_p]),
+    'eks_maha_inflate': (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32] + [c_void_p] * 5
+                         + [c_double, c_double, c_double, c_void_p, c_void_p, c_void_p]),
+    'eks_multicam_tables': (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32] + [c_void_p] * 9),
     'eks_profile_enable': (ctypes.c_int, [ctypes.c_int]),
     'eks_profile_drain': (ctypes.c_int, [c_void_p, c_size_t, c_void_p, c_int32]),
     'eks_ensemble': (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32,

@@ -218,4 +218,24 @@ int eks_ensemble(int32_t n_models, int32_t n_cameras, int32_t n_frames, int32_t 
                         nan_replacement, stats, reinterpret_cast<hipStream_t>(stream));
 }
 
+int eks_maha_inflate(int32_t n_keypoints, int32_t n_frames, int32_t n_views, int32_t n_latent,
+                     const double* x, float* v, const double* W, const double* mu,
+                     const int32_t* active, double epsilon, double threshold, double scalar,
+                     double* maha, int32_t* n_inflated, eks_stream_t stream) {
+  if (n_keypoints <= 0 || n_frames <= 0 || n_views <= 0 || n_latent <= 0) return EKS_ERR_SHAPE;
+  if (!x || !v || !W || !mu || !n_inflated) return EKS_ERR_NULL;
+  return maha_inflate(n_keypoints, n_frames, n_views, n_latent, x, v, W, mu, active, epsilon, threshold,
+                      scalar, maha, n_inflated, reinterpret_cast<hipStream_t>(stream));
+}
+
+int eks_multicam_tables(int32_t n_views, int32_t n_frames, int32_t n_keypoints, int32_t state_dim,
+                        const float* stats, const float* ev, const float* ms, const float* Vs,
+                        const double* C, const double* mean, double* tables, double* latent,
+                        eks_stream_t stream) {
+  if (n_views <= 0 || n_frames <= 0 || n_keypoints <= 0 || state_dim <= 0) return EKS_ERR_SHAPE;
+  if (!stats || !ev || !ms || !Vs || !C || !mean || !tables) return EKS_ERR_NULL;
+  return multicam_tables(n_views, n_frames, n_keypoints, state_dim, stats, ev, ms, Vs, C, mean, tables, latent,
+                         reinterpret_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

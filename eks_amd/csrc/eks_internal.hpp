@@ -75,6 +75,14 @@ int pupil_adam_step(int n, const double* latent_var, const double* nll, const do
 int ensemble_stats(int M, int V, int T, int K, const float* markers, int avg_mode, int var_mode,
                    float nan_replacement, float* stats, hipStream_t st);
 
+// multicam helpers (eks_multicam.hip)
+int maha_inflate(int K, int N, int C, int L, const double* x, float* v, const double* W, const double* mu,
+                 const int32_t* active, double epsilon, double threshold, double scalar, double* maha,
+                 int32_t* n_inflated, hipStream_t st);
+int multicam_tables(int V, int T, int K, int D, const float* stats, const float* ev, const float* ms,
+                    const float* Vs, const double* Cm, const double* mean, double* tables, double* latent,
+                    hipStream_t st);
+
 // dispatch on the state dimension of the general path (D = 1 .. 6 are instantiated)
 #define EKS_DISPATCH_D(D_, BODY) \
   switch (D_) {                  \

@@ -214,6 +214,52 @@ def ensemble(markers, avg_mode: str = 'median', var_mode: str = 'confidence_weig
     return out
 
 
+def maha_inflate(x, v, W, mu, active=None, epsilon: float = 1e-6, threshold: float = 5.0,
+                 scalar: float = 10.0, want_maha: bool = False):
+    """eks_maha_inflate: one pass of the variance-inflation loop for every active keypoint.
+    x (K, N, 2C) float64, v (K, N, 2C) float32 (updated in place), W (K, 2C, L), mu (K, 2C) float64,
+    active (K,) int32 or None.  Returns (n_inflated (K,) int32 device tensor, maha (K, N, C) float64
+    or None)."""
+    lib = _lib.load()
+    K, N, O = x.shape
+    C = O // 2
+    L = W.shape[-1]
+    x = _chk(x, torch.float64, 'x')
+    if not v.is_contiguous():
+        raise ValueError('v must be contiguous (it is updated in place)')
+    _chk(v, torch.float32, 'v', (K, N, O))
+    W = _chk(W, torch.float64, 'W', (K, O, L))
+    mu = _chk(mu, torch.float64, 'mu', (K, O))
+    if active is not None:
+        active = _chk(active, torch.int32, 'active', (K,))
+    n_inf = torch.empty(K, dtype=torch.int32, device=x.device)
+    maha = torch.empty((K, N, C), dtype=torch.float64, device=x.device) if want_maha else None
+    rc = lib.eks_maha_inflate(K, N, C, L, _ptr(x), _ptr(v), _ptr(W), _ptr(mu), _ptr(active), float(epsilon),
+                              float(threshold), float(scalar), _ptr(maha), _ptr(n_inf), _stream())
+    _lib.check(rc, 'eks_maha_inflate')
+    return n_inf, maha
+
+
+def multicam_tables(stats, ev, ms, Vs, C, mean, want_latent: bool = True):
+    """eks_multicam_tables: stats (V, T, K, 5), ev (T, K, 2V), ms (T, K, D), Vs (T, K, D, D) float32;
+    C (K, 2V, D), mean (V, K, 2) float64 -> tables (V, T, K, 9) float64 and latent (T, K, 2D)."""
+    lib = _lib.load()
+    V, T, K, _ = stats.shape
+    D = ms.shape[-1]
+    stats = _chk(stats, torch.float32, 'stats', (V, T, K, 5))
+    ev = _chk(ev, torch.float32, 'ev', (T, K, 2 * V))
+    ms = _chk(ms, torch.float32, 'ms', (T, K, D))
+    Vs = _chk(Vs, torch.float32, 'Vs', (T, K, D, D))
+    C = _chk(C, torch.float64, 'C', (K, 2 * V, D))
+    mean = _chk(mean, torch.float64, 'mean', (V, K, 2))
+    tables = torch.empty((V, T, K, 9), dtype=torch.float64, device=stats.device)
+    latent = torch.empty((T, K, 2 * D), dtype=torch.float64, device=stats.device) if want_latent else None
+    rc = lib.eks_multicam_tables(V, T, K, D, _ptr(stats), _ptr(ev), _ptr(ms), _ptr(Vs), _ptr(C), _ptr(mean),
+                                 _ptr(tables), _ptr(latent), _stream())
+    _lib.check(rc, 'eks_multicam_tables')
+    return tables, latent
+
+
 class Ar1Loss:
     """eks_ar1_nll with every buffer allocated once: the pupil optimiser evaluates this loss (and
     its two sensitivities) thousands of times on the same arrays (reference

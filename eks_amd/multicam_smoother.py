@@ -122,6 +122,13 @@ def ensemble_kalman_smoother_multicam(marker_array: MarkerArray, keypoint_names:
         raise ValueError('camera_names must be provided')
     M, V, T, K, _ = marker_array.shape
     t_all = time.perf_counter()
+    if camgroup is None and not os.environ.get('EKS_HOST_DRIVER'):
+        out = _linear_on_device(marker_array, keypoint_names, smooth_param, quantile_keep_pca, s_frames,
+                                avg_mode, var_mode, inflate_vars, inflate_vars_kwargs, pca_object, n_latent,
+                                kalman_kwargs)
+        logger.debug(f'[profile] ensemble_kalman_smoother_multicam total: '
+                     f'{time.perf_counter() - t_all:.3f}s')
+        return out
     ens = ensemble(marker_array, avg_mode=avg_mode, var_mode=var_mode)       # (1,V,T,K,5)
     valid_mask, centered, good_centered, means = center_predictions(ens, quantile_keep_pca)
     vars_ma = ens.slice_fields('var_x', 'var_y')
@@ -173,6 +180,147 @@ def ensemble_kalman_smoother_multicam(marker_array: MarkerArray, keypoint_names:
     logger.debug(f'[profile] ensemble_kalman_smoother_multicam total: '
                  f'{time.perf_counter() - t_all:.3f}s')
     return camera_dfs, s_finals, df_3d
+
+
+def _linear_on_device(marker_array, keypoint_names, smooth_param, quantile_keep_pca, s_frames, avg_mode,
+                      var_mode, inflate_vars, inflate_vars_kwargs, pca_object, n_latent, kalman_kwargs):
+    """The linear multi-camera pipeline with every (T, ...) array resident on the device between
+    the upload of the markers and the download of the finished per-camera tables (SURVEY.md
+    section 8(f) ranks 2 and 4; reference eks/multicam_smoother.py:335-348, :409-443, :481-551):
+
+        eks_ensemble -> worst variance per (frame, keypoint) -> percentile mask and good-frame
+        indices (utils.py:318-343; the K thresholds come from numpy.percentile on the downloaded
+        (T, K) float32 maxima, so the mask is bit-identical to the host path) -> means over the
+        good frames, centring -> [eks_maha_inflate passes; the factor-analysis fits on the host]
+        -> PCA fit on the host from the good-frame subset only (n_good x 2V per keypoint), prior
+        variances / process noise from the device-side principal components -> run_kalman_smoother
+        on device tensors -> eks_multicam_tables (reprojection + posterior variances, (V, T, K, 9))
+        -> ONE download.
+
+    Small host <-> device traffic only: the (T, K) maxima, the good-frame subset for the PCA fits,
+    the factor-analysis fit rows, K x (D + D^2) statistics."""
+    import torch
+
+    from . import hip_ops
+    from .core import _to_host
+    from .stats import PCA
+    dev = hip_ops.require_gpu()
+    M, V, T, K, _ = marker_array.shape
+    fields = list(marker_array.data_fields)
+    arr = np.asarray(marker_array.array)
+    if fields != ['x', 'y', 'likelihood']:
+        arr = arr[..., [fields.index(f) for f in ('x', 'y', 'likelihood')]]
+    mk = torch.as_tensor(np.ascontiguousarray(arr), device=dev).to(torch.float32)
+    stats = hip_ops.ensemble(mk, avg_mode, var_mode, 1000.0)                  # (V,T,K,5) float32
+    del mk
+    preds = stats[..., 0:2].double()                                          # (V,T,K,2)
+    vars32 = stats[..., 2:4]                                                  # (V,T,K,2) float32
+    # ---- center_predictions (reference eks/utils.py:293-365)
+    if quantile_keep_pca >= 100 and not bool(torch.isnan(vars32).any()):
+        mask = torch.ones((T, K), dtype=torch.bool, device=dev)
+        n_good = T
+        order = torch.arange(T, device=dev)[:, None].expand(T, K)
+    else:
+        worst = vars32.amax(dim=(0, 3))                                       # (T,K) float32
+        thr = np.percentile(worst.cpu().numpy(), quantile_keep_pca, axis=0)   # numpy's own interpolation
+        mask = worst <= torch.as_tensor(thr, device=dev)
+        n_good = int(mask.sum(dim=0).min().item())
+        # first n_good kept frames of every keypoint (the reference truncates to the shortest list)
+        order = torch.argsort((~mask).to(torch.uint8), dim=0, stable=True)[:n_good]   # (n_good,K)
+    kk = torch.arange(K, device=dev)[None, :].expand(n_good, K)
+    good = preds[:, order, kk, :]                                             # (V,n_good,K,2)
+    means = good.mean(dim=1)                                                  # (V,K,2) float64
+    centered = preds - means[:, None]                                         # (V,T,K,2)
+    # stacked views per keypoint: (K, T, 2V), order [c0x, c0y, c1x, ...] (marker_array.py:302-324)
+    ys = centered.permute(2, 1, 0, 3).reshape(K, T, 2 * V).contiguous()
+    evs = vars32.permute(2, 1, 0, 3).reshape(K, T, 2 * V).contiguous()       # float32
+    if inflate_vars:
+        if inflate_vars_kwargs.get('mean', None) is not None:
+            inflate_vars_kwargs['mean'] = np.zeros_like(inflate_vars_kwargs['mean'])
+        likes = stats[..., 4].permute(2, 1, 0).contiguous() if inflate_vars_kwargs.get('likelihoods') is not None \
+            else None
+        evs = _inflate_on_device(ys, evs, likes, n_latent, inflate_vars_kwargs)
+    # ---- PCA per keypoint on the good frames (host, n_good x 2V each); reference eks/stats.py:9-64
+    good_c = (good - means[:, None]).permute(2, 1, 0, 3).reshape(K, n_good, 2 * V)
+    good_host = good_c.cpu().numpy()
+    pcas = [pca_object if pca_object is not None else PCA(n_components=n_latent).fit(good_host[k])
+            for k in range(K)]
+    comp = torch.as_tensor(np.stack([np.asarray(p.components_) for p in pcas]), device=dev)   # (K,L,2V)
+    pmean = torch.as_tensor(np.stack([np.asarray(p.mean_) for p in pcas]), device=dev)        # (K,2V)
+    pcs = torch.einsum('kto,klo->ktl', ys - pmean[:, None], comp)             # all frames (K,T,L)
+    # initialize_kalman_filter_pca (reference :554-597): statistics over the frames in `mask`
+    S0s, Qs = np.zeros((K, n_latent, n_latent)), np.zeros((K, n_latent, n_latent))
+    for k in range(K):
+        gp = pcs[k][mask[:, k]]                                               # (n_valid_k, L)
+        S0s[k] = np.diag(gp.var(dim=0, unbiased=False).cpu().numpy())
+        d = (gp[1:] - gp[:-1]).cpu().numpy()
+        cov = np.atleast_2d(np.cov(d.T))
+        top = np.max(np.abs(cov))
+        Qs[k] = cov / top if top > 0 else cov
+    Cs = np.stack([np.asarray(p.components_).T for p in pcas])               # (K,2V,L)
+    m0s = np.zeros((K, n_latent))
+    As = np.tile(np.eye(n_latent), (K, 1, 1))
+    t0 = time.perf_counter()
+    ev_tk = evs.transpose(0, 1).contiguous()                                  # (T,K,2V)
+    s_finals, ms, Vs = run_kalman_smoother(
+        ys=ys.to(torch.float32), m0s=m0s, S0s=S0s, As=As, Qs=Qs, Cs=Cs, ensemble_vars=ev_tk,
+        s_frames=s_frames, smooth_param=smooth_param, return_device=True, **kalman_kwargs)
+    logger.debug(f'[profile] run_kalman_smoother (total): {time.perf_counter() - t0:.3f}s')
+    tables, latent = hip_ops.multicam_tables(stats, ev_tk, ms.transpose(0, 1), Vs.transpose(0, 1),
+                                             torch.as_tensor(Cs, device=dev), means)
+    tables_h, latent_h = _to_host(tables, latent)
+    index = make_dlc_pandas_index(keypoint_names, labels=OUTPUT_LABELS)
+    camera_dfs = [pd.DataFrame(tables_h[c].reshape(T, K * 9), columns=index) for c in range(V)]
+    base = ['x', 'y', 'z'] if n_latent == 3 else [f'latent{i}' for i in range(n_latent)]
+    labels_3d = base + [f'{b}_posterior_var' for b in base]
+    df_3d = pd.DataFrame(latent_h.reshape(T, K * 2 * n_latent),
+                         columns=make_dlc_pandas_index(keypoint_names, labels=labels_3d))
+    return camera_dfs, s_finals, df_3d
+
+
+def _inflate_on_device(ys, evs, likes, n_latent, inflate_vars_kwargs, threshold: float = 5.0,
+                       scalar: float = 10.0):
+    """mA_compute_maha (reference eks/multicam_smoother.py:653-721) with the per-frame work on the
+    device: every pass, the keypoints still inflating get a factor-analysis fit on the host (rows
+    chosen as compute_mahalanobis does, eks/stats.py:103-118, from the CURRENT variances) and one
+    eks_maha_inflate launch covers them all; a keypoint stops when a pass inflates nothing.
+    ys (K,T,2V) float64, evs (K,T,2V) float32 -> inflated evs (new tensor)."""
+    import torch
+    from sklearn.decomposition import FactorAnalysis
+
+    from . import hip_ops
+    K, T, O = ys.shape
+    dev = ys.device
+    kw = inflate_vars_kwargs
+    kw.setdefault('likelihood_threshold', 0.9)           # written INTO the caller's dict, like upstream
+    kw.setdefault('v_quantile_threshold', 50.0)
+    eps = kw.get('epsilon', 1e-6)
+    v = evs.clone()
+    x_host = ys.cpu().numpy()
+    likes_host = likes.cpu().numpy() if likes is not None else None
+    W = torch.zeros((K, O, n_latent), dtype=torch.float64, device=dev)
+    mu = torch.zeros((K, O), dtype=torch.float64, device=dev)
+    active = np.ones(K, dtype=bool)
+    while active.any():
+        worst = v.amax(dim=2).cpu().numpy()                                   # (K,T) float32
+        for k in np.flatnonzero(active):
+            logger.info(f'inflating keypoint: {k}')
+            if kw.get('loading_matrix') is not None and kw.get('mean') is not None:
+                Wk, muk = np.asarray(kw['loading_matrix']), np.asarray(kw['mean'])
+            else:
+                rows = np.ones(T, dtype=bool)
+                if likes_host is not None and kw.get('likelihood_threshold') is not None:
+                    rows &= np.min(likes_host[k], axis=1) >= kw['likelihood_threshold']
+                if kw.get('v_quantile_threshold') is not None:
+                    rows &= worst[k] < np.percentile(worst[k], kw['v_quantile_threshold'])
+                fa = FactorAnalysis(n_components=n_latent).fit(x_host[k][rows])
+                Wk, muk = fa.components_.T, fa.mean_
+            W[k] = torch.as_tensor(np.ascontiguousarray(Wk, dtype=np.float64), device=dev)
+            mu[k] = torch.as_tensor(np.ascontiguousarray(muk, dtype=np.float64), device=dev)
+        n_inf, _ = hip_ops.maha_inflate(ys, v, W, mu, torch.as_tensor(active.astype(np.int32), device=dev),
+                                        epsilon=eps, threshold=threshold, scalar=scalar)
+        active &= n_inf.cpu().numpy() > 0
+    return v
 
 
 def _calibrated_branch(marker_array, keypoint_names, camera_names, camgroup, ens, vars_ma,

@@ -190,6 +190,33 @@ int eks_ensemble(int32_t n_models, int32_t n_cameras, int32_t n_frames, int32_t 
                  const float* markers, int32_t avg_mode, int32_t var_mode, float nan_replacement,
                  float* stats, eks_stream_t stream);
 
+/* ---- variance inflation, one pass of the loop of
+ * eks/multicam_smoother.py:695-708 for every ACTIVE keypoint: the per-frame factor-analysis
+ * reconstruction residual and per-view 2x2 Mahalanobis distance of compute_mahalanobis
+ * (eks/stats.py:119-151) given the loading matrix W and mean mu, then inflate_variance
+ * (eks/multicam_smoother.py:724-764): v *= scalar for every (frame, view) whose distance exceeds
+ * threshold, the whole frame when n_views == 2.  The factor-analysis fit between passes stays on
+ * the host.  x [K][N][2C] float64 (centred predictions, stacked views c0x c0y c1x ...),
+ * v [K][N][2C] float32 in/out, W [K][2C][L], mu [K][2C] float64, active [K] (NULL = all),
+ * maha [K][N][C] float64 out (may be NULL), n_inflated [K] out = number of frames with a hit
+ * (0 = this keypoint's loop is finished).  2 <= C <= 8, 1 <= L <= 6. ------------------------- */
+int eks_maha_inflate(int32_t n_keypoints, int32_t n_frames, int32_t n_views, int32_t n_latent,
+                     const double* x, float* v, const double* W, const double* mu,
+                     const int32_t* active, double epsilon, double threshold, double scalar,
+                     double* maha, int32_t* n_inflated, eks_stream_t stream);
+
+/* ---- output epilogue of the linear multi-camera driver (eks/multicam_smoother.py:481-544):
+ * stats [V][T][K][5] float32 (eks_ensemble's x, y, var_x, var_y, likelihood), ev [T][K][2V]
+ * float32 (the variances the filter used, possibly inflated), ms [T][K][D], Vs [T][K][D][D]
+ * float32 (eks_smooth), C [K][2V][D], mean [V][K][2] float64 ->
+ * tables [V][T][K][9] float64: x, y = C m + mean | likelihood | x, y ensemble average |
+ * x, y ensemble variance (= ev, :505-508) | x, y posterior variance = diag(C V C') + ev (:509-510);
+ * latent [T][K][2D] float64 = (m, diag V) (:529-544; may be NULL).  D <= 6. ------------------ */
+int eks_multicam_tables(int32_t n_views, int32_t n_frames, int32_t n_keypoints, int32_t state_dim,
+                        const float* stats, const float* ev, const float* ms, const float* Vs,
+                        const double* C, const double* mean, double* tables, double* latent,
+                        eks_stream_t stream);
+
 /* ---- optional per-kernel timing (used by bench.py's roofline object).  on = 1: each kernel launch
  * (stage) is bracketed by hipEvents on the caller's stream; on = 2: only the smoother's replay
  * kernels (the HBM-roofline kernels); 0: off. eks_profile_drain waits for the

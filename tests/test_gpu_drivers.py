@@ -279,3 +279,84 @@ def test_ensemble_operator_properties():
     e1 = ensemble(MarkerArray(a[:1], data_fields=['x', 'y', 'likelihood']))
     assert np.all(e1.array[..., 2] > 0)
     np.testing.assert_allclose(e1.array[0, ..., 2], 1.0 / np.maximum(a[0, ..., 2].astype(np.float32), 1e-5), rtol=1e-6)
+
+
+# ---- device-resident linear multicam pipeline -------------------
+def test_maha_inflate_kernel_matches_the_oracles_loop_restatement():
+    """eks_maha_inflate against oracle.mahalanobis_loop (the reference's per-frame loops,
+    eks/stats.py:119-151) and inflate_variance (eks/multicam_smoother.py:724-764): distances
+    <= 1e-5, inflated-frame mask bit-exact, for 2 and 3 views."""
+    import torch
+    from sklearn.decomposition import FactorAnalysis
+    from eks_amd import hip_ops
+    for V, n_latent, seed in ((2, 3, 0), (3, 3, 1), (4, 4, 2)):
+        rng = np.random.default_rng(seed)
+        N, O = 3000, 2 * V
+        z = rng.standard_normal((N, n_latent))
+        W0 = rng.standard_normal((O, n_latent))
+        v = (0.3 * rng.gamma(2.0, 1.0, (N, O)) + 0.05).astype(np.float32)
+        x = z @ W0.T * 3.0 + rng.standard_normal((N, O)) * np.sqrt(v)
+        x[rng.random(N) < 0.03] += rng.standard_normal(O) * 12.0              # outlier frames
+        worst = v.max(axis=1)
+        rows = worst < np.percentile(worst, 50.0)
+        fa = FactorAnalysis(n_components=n_latent).fit(x[rows])
+        W, mu = fa.components_.T, fa.mean_
+        # oracle: loops over frames, float64 (1 / (v + eps) in float32 first, as NumPy does for the
+        # reference's float32 variance arrays)
+        out = {c: np.zeros(N) for c in range(V)}
+        for i in range(N):
+            Dinv = np.diag((1.0 / (v[i] + np.float32(1e-6))).astype(np.float64))
+            B = np.linalg.inv(W.T @ Dinv @ W)
+            zz = B @ W.T @ Dinv @ (x[i] - mu)
+            diff = x[i] - (W @ zz + mu)
+            for c in range(V):
+                sl = slice(2 * c, 2 * c + 2)
+                Qc = np.diag(v[i, sl].astype(np.float64)) + W[sl] @ B @ W[sl].T
+                out[c][i] = diff[sl] @ np.linalg.inv(Qc) @ diff[sl]
+        hit = np.stack([out[c] > 5.0 for c in range(V)], axis=1)
+        mask = np.repeat(hit, 2, axis=1)
+        if V == 2:
+            mask = mask | mask.any(axis=1, keepdims=True)
+        v_ref = v.copy()
+        v_ref[mask] *= np.float32(10.0)
+        dev = hip_ops.require_gpu()
+        vd = torch.as_tensor(v[None].copy(), device=dev)
+        n_inf, maha = hip_ops.maha_inflate(torch.as_tensor(x[None], device=dev), vd,
+                                           torch.as_tensor(W[None].copy(), device=dev),
+                                           torch.as_tensor(mu[None].copy(), device=dev), want_maha=True)
+        m = maha.cpu().numpy()[0]
+        ref = np.stack([out[c] for c in range(V)], axis=1)
+        assert (np.abs(m - ref) / np.maximum(np.abs(ref), 1e-3)).max() < 1e-5
+        np.testing.assert_array_equal(vd.cpu().numpy()[0], v_ref)           # mask and values bit-exact
+        assert int(n_inf.item()) == int(hit.any(axis=1).sum()) and hit.any()
+        # the same numbers as the host implementation (eks_amd.stats.compute_mahalanobis)
+        from eks_amd.stats import compute_mahalanobis
+        res = compute_mahalanobis(x, v, n_latent=n_latent, loading_matrix=W, mean=mu)
+        for c in range(V):
+            assert (np.abs(m[:, c] - res['mahalanobis'][c][:, 0]) / np.maximum(np.abs(ref[:, c]), 1e-3)).max() < 1e-9
+
+
+@pytest.mark.parametrize('inflate', [False, True])
+def test_multicam_device_pipeline_equals_host_pipeline(mouse, inflate, monkeypatch):
+    """The device-resident linear pipeline (ensemble -> percentile mask -> centring -> [inflation]
+    -> PCA set-up -> smoother -> table epilogue) against the host pipeline on the reference's
+    mirror-mouse data: validity mask / good-frame choice identical (same PCA, same prior), every
+    output column within 1e-5 (float64 reductions are summed in a different order)."""
+    from eks_amd import MarkerArray
+    from eks_amd.multicam_smoother import ensemble_kalman_smoother_multicam
+    ma = MarkerArray(mouse['markers'].astype(np.float64), data_fields=['x', 'y', 'likelihood'])
+    names, cams = list(mouse['keypoints']), list(mouse['cameras'])
+    kw = dict(smooth_param=[10.0], quantile_keep_pca=95.0, n_latent=3, inflate_vars=inflate)
+    dfs_d, s_d, lat_d = ensemble_kalman_smoother_multicam(ma, names, cams, **kw)
+    monkeypatch.setenv('EKS_HOST_DRIVER', '1')
+    dfs_h, s_h, lat_h = ensemble_kalman_smoother_multicam(ma, names, cams, **kw)
+    np.testing.assert_array_equal(s_d, s_h)
+    for c in range(2):
+        assert list(dfs_d[c].columns) == list(dfs_h[c].columns)
+        a, b = dfs_d[c].values, dfs_h[c].values
+        assert (np.abs(a - b) / np.abs(b).max(axis=0)).max() < 1e-5
+        # the (possibly inflated) ensemble variances are float32 values copied through: identical
+        np.testing.assert_array_equal(a[:, 5::9], b[:, 5::9])
+        np.testing.assert_array_equal(a[:, 6::9], b[:, 6::9])
+    assert list(lat_d.columns) == list(lat_h.columns)
+    assert (np.abs(lat_d.values - lat_h.values) / np.abs(lat_h.values).max(axis=0)).max() < 1e-5
