@@ -9,11 +9,19 @@ One "step" = one pass of that whole path over one session already resident in HB
     eks_const_r -> eks_nll (64 candidates) -> eks_argmin_s -> eks_smooth.
 1 unit = one keypoint at one frame.  Inputs are synthetic (seeded, generated on device).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
-N > 1 is launched by torch.distributed.run, one rank per GPU; every rank smooths its own
-independent session of the same shape (sessions shard with no data-path collective, "weak"
-scaling) and the per-keypoint s_finals are all-gathered over RCCL inside the timed region.
-Rank 0 prints ONE JSON line.
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5|c4|pupil|ekf]
+                  [--scaling weak|strong] [--gather-outputs]
+N > 1 is launched by torch.distributed.run, one rank per GPU over RCCL.  Default ("weak"): every
+rank smooths its own independent session of the workload's shape (sessions shard with no data-path
+collective; `--workload c5` is BASELINE configs[4]: 128 sessions x 32 keypoints stacked along K per
+GPU) and the per-keypoint s_finals are all-gathered inside the timed region.  `--scaling strong`:
+ONE session of the workload's shape, its keypoints dealt to the GPUs (configs[2] at 32 keypoints
+per GPU on 8 GPUs); `--gather-outputs` adds a second timed loop that also all-gathers ms / Vs to
+every rank (compute + gather beside compute only).  Rank 0 prints ONE JSON line: `value` is the
+whole-job rate with inputs resident in HBM; `roofline` is the dominant HBM-bound kernel,
+`roofline_longest_kernel` the (VALU-bound) longest one, `cpu_baseline` the C port of the reference
+recursion on the host cores, `cpu_baseline_numpy` the NumPy restatement, `host_boundary` the same
+step through host arrays (PCIe included; never `value`).
 """
 from __future__ import annotations
 
@@ -54,18 +62,33 @@ def parse():
     p.add_argument('--no-kernel-events', action='store_true',
                    help='do not bracket kernels with HIP events inside the timed region')
     p.add_argument('--cpu-seconds', type=float, default=15.0)
+    p.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                   help="N > 1: 'weak' = one session of the workload's shape per GPU (sessions shard, "
+                        "BASELINE configs[4] style); 'strong' = ONE session, its keypoints dealt to the GPUs "
+                        "(configs[2] at K / N keypoints per GPU)")
+    p.add_argument('--gather-outputs', action='store_true',
+                   help='strong scaling: also time a second loop that all-gathers ms / Vs to every rank')
     return p.parse_args()
 
 
+TRAFFIC_FILES = ('r02_traffic.json', 'r01_traffic.json')
+
+
 def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` on the C3 shape, from the committed rocprofv3 PMC passes
-    (profiles/r01_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
-    MI355X_MICROARCH.md; separate --pmc runs of this same command).  None if not recorded."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as f:
-            return json.load(f)['hbm_bytes_per_launch'].get(kernel)
-    except Exception:
-        return None
+    """HBM bytes per launch of `kernel` on the C3 shape.  NOT measured in this run (hardware
+    counters need rocprofv3's own passes): read from the committed summary of separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command
+    (profiles/r02_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
+    MI355X_MICROARCH.md).  Returns (bytes or None, source file or None)."""
+    for name in TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                v = json.load(f)['hbm_bytes_per_launch'].get(kernel)
+            if v is not None:
+                return v, f'profiles/{name}'
+        except Exception:
+            continue
+    return None, None
 
 
 def drain_profile(lib):
@@ -90,12 +113,50 @@ def _cpu_model():
     return 'unknown'
 
 
+def _physical_cores(cpus):
+    """Distinct (socket, core) pairs among the logical CPUs this process may run on."""
+    seen, cur = set(), {}
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f.read().split('\n') + ['']:
+                if not line.strip():
+                    if 'processor' in cur and int(cur['processor']) in cpus:
+                        seen.add((cur.get('physical id', '0'), cur.get('core id', cur['processor'])))
+                    cur = {}
+                elif ':' in line:
+                    k, v = line.split(':', 1)
+                    cur[k.strip()] = v.strip()
+    except OSError:
+        pass
+    return len(seen) or len(cpus)
+
+
+def numpy_baseline(y_dev, var_dev, T, n_cand, budget_s=6.0):
+    """SURVEY.md 8(d) baseline (i): the NumPy float64 restatement (oracle/eks_oracle.py), vectorised
+    over keypoints and sequential in time - the structure of the reference's jit(vmap(scan)) - on
+    one process, on a bounded sample: all keypoints, the first Tn frames, fixed s (one filter + RTS
+    pass; the grid would multiply the time by 64 / 2.5)."""
+    from oracle import eks_oracle as orc
+    K = y_dev.shape[1]
+    Tn = 1500
+    y = np.transpose(y_dev[:Tn].cpu().numpy().astype(np.float64), (1, 0, 2)).copy()
+    Rd = np.clip(np.transpose(var_dev[:Tn].cpu().numpy().astype(np.float64), (1, 0, 2)), 1e-12, None)
+    eye = np.tile(np.eye(2), (K, 1, 1))
+    t0 = time.perf_counter()
+    orc.kalman_smoother(y, np.zeros((K, 2)), eye.copy(), eye, eye, eye, np.full(K, 10.0), Rd)
+    dt = time.perf_counter() - t0
+    return dict(value=Tn * K / dt, unit='frames*keypoints/s', cores=1, threads=1, kind='port',
+                sample=f'first {Tn} frames x all {K} keypoints, fixed s, one filter + RTS pass in NumPy float64 '
+                       f'(oracle/eks_oracle.py: vectorised over keypoints, sequential in time), {dt:.1f} s')
+
+
 def cpu_baseline(y_dev, var_dev, T, n_cand, budget_s):
     """Time the C twin of the oracle (general-matrix port of the reference recursion, OpenMP over
     keypoints) on a bounded sample of the same workload: the first Kc keypoints, all T frames."""
     from oracle import c_oracle, eks_oracle as orc
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
-    cores = max(1, min(cores, c_oracle.max_threads()))
+    cpus = os.sched_getaffinity(0) if hasattr(os, 'sched_getaffinity') else set(range(os.cpu_count() or 1))
+    cores = max(1, min(len(cpus), c_oracle.max_threads()))          # OpenMP threads used
+    physical = _physical_cores(cpus)
     # ~0.3 us per frame per filter pass per core for the 2x2 general-matrix port (measured here)
     per_kp = T * 0.3e-6 * (max(n_cand, 0) + 2.5)
     Kc = int(max(cores, min(y_dev.shape[1], round(budget_s * cores / per_kp))))
@@ -119,7 +180,7 @@ def cpu_baseline(y_dev, var_dev, T, n_cand, budget_s):
     ms_cpu, Vs_cpu, _ = c_oracle.smooth(y, Rd, m0, S0, eye, eye, eye, s, nthreads=cores)
     dt = time.perf_counter() - t0
     ref = dict(nll=nll if n_cand else None, ms=ms_cpu, Vs=Vs_cpu)
-    return dict(value=T * Kc / dt, unit='frames*keypoints/s', cores=cores, kind='port',
+    return dict(value=T * Kc / dt, unit='frames*keypoints/s', cores=physical, threads=cores, kind='port',
                 cpu_model=_cpu_model(),
                 sample=f'first {Kc} of the keypoints x all {T} frames of the same workload '
                        f'({n_cand}-candidate NLL grid + smooth), float64 C port of the reference '
@@ -335,8 +396,22 @@ def main():
         return bench_pupil(args, T, dev, lib)
     if args.workload == 'ekf':
         return bench_ekf(args, T, K, dev, lib)
-    # every rank owns an independent session of the same shape (seed = 3 + rank)
-    y, var = synth.singlecam_observations_torch(T, K, seed=3 + rank, device=dev)
+    strong = args.scaling == 'strong' and world > 1
+    if strong:
+        # ONE session (the same on every rank: seed 3), its keypoints dealt to the ranks in
+        # contiguous blocks (keypoints are independent, reference eks/core.py:223-224, :293)
+        from eks_amd.distributed import keypoint_block_shard
+        K_total = K
+        own = [k for b in keypoint_block_shard([[k] for k in range(K_total)], world, rank) for k in [b]]
+        y_all, var_all = synth.singlecam_observations_torch(T, K_total, seed=3, device=dev)
+        idx = torch.as_tensor(own, device=dev)
+        y, var = y_all.index_select(1, idx).contiguous(), var_all.index_select(1, idx).contiguous()
+        del y_all, var_all
+        K = len(own)
+    else:
+        # every rank owns an independent session of the same shape (seed = 3 + rank)
+        K_total = K * world
+        y, var = synth.singlecam_observations_torch(T, K, seed=3 + rank, device=dev)
     eye = torch.eye(2, dtype=torch.float64, device=dev).expand(K, 2, 2).contiguous()
     m0 = torch.zeros(K, 2, dtype=torch.float64, device=dev)
     S0 = torch.diag_embed(y.double().var(dim=0, unbiased=False)).contiguous()
@@ -345,10 +420,12 @@ def main():
     s_fixed = torch.full((K,), 10.0, dtype=torch.float64, device=dev)
     ms = torch.empty((T, K, 2), dtype=torch.float32, device=dev)
     Vs = torch.empty((T, K, 2, 2), dtype=torch.float32, device=dev)
-    gathered = [torch.empty(K, dtype=torch.float64, device=dev) for _ in range(world)]
-    gathered_host = [torch.empty(K, dtype=torch.float64) for _ in range(world)]
+    Kmax = (K_total + world - 1) // world if strong else K
+    s_pad = torch.zeros(Kmax, dtype=torch.float64, device=dev)
+    gathered = [torch.empty(Kmax, dtype=torch.float64, device=dev) for _ in range(world)]
+    gathered_host = [torch.empty(Kmax, dtype=torch.float64) for _ in range(world)]
 
-    def step():
+    def step(gather_outputs=False):
         if n_cand:
             rc = hip_ops.const_r(var, 1e-4)
             nll = hip_ops.nll(y, rc, m0, S0, eye, eye, eye, cand, flags=flags)
@@ -357,13 +434,18 @@ def main():
             s = s_fixed
         hip_ops.smooth(y, var, m0, S0, eye, eye, eye, s, flags=flags, out=(ms, Vs))
         if world > 1:
-            # the per-session gather of s_finals (K float64 per rank) is asynchronous: it runs on
-            # the collective stream while this rank's next session is being smoothed, and is waited
-            # for before the timed region closes
+            # the gather of s_finals (K float64 per rank) is asynchronous: it runs on the collective
+            # stream while this rank's next step is being enqueued, and is waited for before the
+            # timed region closes
+            s_pad[:K] = s
             if backend == 'nccl':
-                pending.append(dist.all_gather(gathered, s, async_op=True))
+                pending.append(dist.all_gather(gathered, s_pad, async_op=True))
             else:
-                pending.append(dist.all_gather(gathered_host, s.cpu(), async_op=True))
+                pending.append(dist.all_gather(gathered_host, s_pad.cpu(), async_op=True))
+            if gather_outputs and backend == 'nccl':
+                # every rank ends with the whole session's ms / Vs (24 B per keypoint-frame over xGMI)
+                pending.append(dist.all_gather_into_tensor(ms_all, ms, async_op=True))
+                pending.append(dist.all_gather_into_tensor(Vs_all, Vs, async_op=True))
         return s
 
     pending = []
@@ -403,48 +485,97 @@ def main():
         for _ in range(5):          # keep the ranks' collectives matched
             step()
         sync()
+    dt_gather = None
+    if strong and args.gather_outputs and backend == 'nccl' and K * world == K_total:
+        ms_all = torch.empty((world, T, K, 2), dtype=torch.float32, device=dev)
+        Vs_all = torch.empty((world, T, K, 2, 2), dtype=torch.float32, device=dev)
+        step(True)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(True)
+        sync()
+        dt_gather = time.perf_counter() - t1
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+        tt = [dt] + ([dt_gather] if dt_gather is not None else [])
+        t = torch.tensor(tt, dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = float(t[0].item())
+        if dt_gather is not None:
+            dt_gather = float(t[1].item())
 
-    units_per_step = T * K
-    value = world * args.steps * units_per_step / dt
+    units_per_step = T * K_total if strong else T * K * world      # all ranks together
+    value = args.steps * units_per_step / dt
+    shape = f'singlecam T={T} x K={K_total if strong else K} keypoints (D=O=2)'
+    headline = args.workload == 'c3'
+    metric = ('frames*keypoints smoothed/s + achieved HBM GB/s fraction, singlecam 100k x 256' if headline else
+              f'frames*keypoints smoothed/s + achieved HBM GB/s fraction, {shape}'
+              + (' [configs[1]: 10k x 64, fixed s]' if args.workload == 'c2' else
+                 ' [configs[4]: one GPU\'s share, 128 sessions x 32 keypoints stacked along K]'
+                 if args.workload == 'c5' else ''))
     out = {
-        'metric': 'frames*keypoints smoothed/s + achieved HBM GB/s fraction, singlecam 100k x 256',
+        'metric': metric,
         'value': value, 'unit': 'frames*keypoints/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'singlecam T={T} x K={K} keypoints (D=O=2), '
+        'scaling': 'strong' if strong else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': shape + ', '
                                + (f'{n_cand}-candidate NLL grid + ' if n_cand else 'fixed s=10, ')
-                               + 'filter+RTS smooth, full ms/Vs outputs; one session per GPU',
-                   'frames': T, 'keypoints': K, 'candidates': n_cand,
-                   'parallelism': f'sessions x{world}' if world > 1 else 'single GPU'},
+                               + 'filter+RTS smooth, full ms/Vs outputs; '
+                               + (f'one session, {K} keypoints per GPU, all-gather of s_finals' if strong
+                                  else 'one session per GPU'),
+                   'frames': T, 'keypoints': K_total if strong else K, 'candidates': n_cand,
+                   'parallelism': (f'keypoints x{world}' if strong else f'sessions x{world}') if world > 1
+                   else 'single GPU'},
     }
+    if dt_gather is not None:
+        out['ms_per_step_with_output_gather'] = 1e3 * dt_gather / args.steps
+        out['value_with_output_gather'] = args.steps * units_per_step / dt_gather
     if rank == 0:
         if prof:
+            local_units = T * K
             k3 = float(np.mean(prof['diag_replay']))
             avg = dict(stages)
             smooth_ms = sum(avg.get(k, 0.0) for k in ('diag_summarize', 'diag_scan', 'diag_replay'))
-            achieved = SMOOTH_BYTES_PER_UNIT * units_per_step / (k3 * 1e-3) / 1e9
+            achieved = SMOOTH_BYTES_PER_UNIT * local_units / (k3 * 1e-3) / 1e9
+            traffic, traffic_src = measured_traffic('diag_replay_blk_kernel') if headline else (None, None)
             out['roofline'] = {
-                'bound': 'hbm', 'kernel': 'diag_replay_kernel', 'achieved': achieved,
+                'bound': 'hbm', 'kernel': 'diag_replay_blk_kernel', 'achieved': achieved,
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                'traffic': measured_traffic('diag_replay_kernel') if args.workload == 'c3' else None,
-                'algorithmic_bytes_per_launch': SMOOTH_BYTES_PER_UNIT * units_per_step,
+                'traffic': traffic,
+                'traffic_source': (f'{traffic_src}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this '
+                                   'command (not measured in this run)') if traffic_src else None,
+                'algorithmic_bytes_per_launch': SMOOTH_BYTES_PER_UNIT * local_units,
                 'kernel_avg_ms': k3, 'launches_timed': len(prof.get('diag_replay', [])),
                 'stage_avg_ms': avg,
                 'stage_avg_ms_source': 'HIP events, 5 untimed steps after the timed region',
-                'smooth_stage_frac': SMOOTH_BYTES_PER_UNIT * units_per_step / (smooth_ms * 1e-3)
+                'smooth_stage_frac': SMOOTH_BYTES_PER_UNIT * local_units / (smooth_ms * 1e-3)
                                      / 1e9 / HBM_PEAK_GBS,
                 'whole_step_frac': ((SMOOTH_BYTES_PER_UNIT + (NLL_BYTES_PER_UNIT if n_cand else 0))
-                                    * units_per_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS),
+                                    * local_units / (dt / args.steps) / 1e9 / HBM_PEAK_GBS),
             }
+            if n_cand and avg.get('diag_nll_summarize'):
+                # the LONGEST kernel of the step is not HBM-bound: 2 FMAs per frame, chain and
+                # candidate on the vector ALUs (no MFMA: scalar recursions)
+                flops = 2.0 * 2.0 * local_units * 2 * n_cand
+                t_nll = avg['diag_nll_summarize'] * 1e-3
+                out['roofline_longest_kernel'] = {
+                    'bound': 'valu', 'kernel': 'diag_nll_summarize_kernel', 'unit': 'TFLOP/s',
+                    'achieved': flops / t_nll / 1e12, 'peak': 157.3, 'frac': flops / t_nll / 1e12 / 157.3,
+                    'kernel_avg_ms': avg['diag_nll_summarize'],
+                    'algorithmic_flops_per_launch': flops,
+                    'note': 'useful FMA flops only (2 per frame x chain x candidate); fp32 vector peak 157.3 TFLOP/s '
+                            'is 2 cycles per v_fma_f32 at 2.4 GHz - tools/micro/fma_rate.hip sustains 89 (2 waves per '
+                            'SIMD) to 113 (6 waves) TFLOP/s on this dependency structure at the 2.04-2.17 GHz the '
+                            'chip holds under it (profiles/r02_overlap_probes.txt)'}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cb, s_cpu, ref = cpu_baseline(y, var, T, n_cand, args.cpu_seconds)
                 out['cpu_baseline'] = cb
                 out['gpu_over_cpu'] = value / cb['value']
+                try:
+                    out['cpu_baseline_numpy'] = numpy_baseline(y, var, T, n_cand)
+                except Exception as e:
+                    out['cpu_baseline_numpy'] = {'value': None, 'sample': f'failed: {e!r}'}
                 if n_cand:
                     # compare grid INDICES (the candidate values differ by an ulp between
                     # torch.linspace and numpy.linspace)
@@ -475,9 +606,35 @@ def main():
             except Exception as e:                      # the baseline must never sink the bench line
                 out['cpu_baseline'] = {'value': None, 'unit': 'frames*keypoints/s', 'cores': 0,
                                        'kind': 'port', 'sample': f'failed: {e!r}'}
+            try:
+                out['host_boundary'] = host_boundary_rate(y, var, T, K, n_cand)
+            except Exception as e:
+                out['host_boundary'] = {'value': None, 'note': f'failed: {e!r}'}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def host_boundary_rate(y, var, T, K, n_cand, reps=3):
+    """The same step through the reference-shaped NumPy boundary (run_kalman_smoother on HOST arrays:
+    upload of y, var, download of ms, Vs over PCIe included).  Never `value`: reported beside it."""
+    import torch
+    from eks_amd.core import run_kalman_smoother
+    ys_h = np.ascontiguousarray(y.transpose(0, 1).cpu().numpy())              # (K,T,2)
+    var_h = var.cpu().numpy()
+    eye = np.tile(np.eye(2), (K, 1, 1))
+    S0 = eye * ys_h.astype(np.float64).var(axis=1)[:, :, None]
+    kw = dict(s_mode='grid', n_grid=n_cand) if n_cand else dict(smooth_param=10.0)
+    best = 1e9
+    for _ in range(reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = run_kalman_smoother(ys_h, np.zeros((K, 2)), S0, eye, eye, eye, var_h, **kw)
+        best = min(best, time.perf_counter() - t0)
+        del out
+    return {'value': T * K / best, 'unit': 'frames*keypoints/s', 'ms_per_step': 1e3 * best,
+            'note': 'run_kalman_smoother on host NumPy arrays, best of 3: includes the H2D copy of y, var (16 B per '
+                    'unit) and the D2H copy of ms, Vs (24 B per unit) over PCIe - transfer-bound, not the kernels'}
 
 
 if __name__ == '__main__':
