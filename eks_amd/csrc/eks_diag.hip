@@ -22,6 +22,12 @@
 // instead of 5, the per-chunk scan results (25.6 MB written + read on the C3 shape) and the second
 // read of the elements never exist.
 //
+// (Tried for small problems, round 2: ONE launch with two grid barriers and the chunk kept in
+// registers in between.  Bit-identical results, but a counter barrier over 158-391 workgroups costs
+// far more than the 1.5-1.9 us of a kernel boundary on this part - 10 000 x 64 keypoints: 52 us
+// against 20 us for the three launches, 50 000 x 30: 187 against 29 - see
+// profiles/r02_overlap_probes.txt.  Dropped.)
+//
 // HBM traffic: 2 x (y + var) in, 1 x (ms + Vs) out (+ ~4 % for the chunk elements); no filtered
 // state ever touches memory.  No MFMA: the algebra is scalar.  No LDS in K1/K3: each datum is
 // consumed by the lane that loads it; lanes of a wave are consecutive chains, so every row access
@@ -393,10 +399,10 @@ __global__ __launch_bounds__(64 * kFW) void diag_replay_blk_kernel(BlockMap L, D
 // slot walks its aggregates again from the belief entering its first one (forward) / the
 // information leaving its last one (backward), writing the per-block results.
 template <int PER>
-__global__ __launch_bounds__(256) void diag_scan_groups_kernel(int N, DiagModel M, ScanWs S) {
-  __shared__ float tot[2][5][4][4];        // [direction][field][wave][chain]
+__device__ __forceinline__ void scan_groups_block(int N, const DiagModel& M, const ScanWs& S, int blk,
+                                                  float (&tot)[2][5][4][4]) {
   const int c = threadIdx.x & 3, slot = threadIdx.x >> 2, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + c;
+  const int n = blk * 4 + c;
   const int per = (S.nblk + 63) / 64;      // <= PER, or the slot re-reads in batches of PER
   const int q0 = min(slot * per, S.nblk), q1 = min(q0 + per, S.nblk);
   const bool live = n < N;
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(256) void diag_scan_groups_kernel(int N, DiagModel 
   if (lane < 4) {
     tot[1][0][w][c] = r.A; tot[1][1][w][c] = r.b; tot[1][2][w][c] = r.C; tot[1][3][w][c] = r.eta; tot[1][4][w][c] = r.J;
   }
-  __syncthreads();
+  __syncthreads();                         // (every thread of the block reaches this)
   if (!live) return;
   // exclusive prefix of this slot: earlier waves' totals, then the wave's earlier slots
   Elem<float> pre = elem_identity<float>(), post = elem_identity<float>();
@@ -480,6 +486,12 @@ __global__ __launch_bounds__(256) void diag_scan_groups_kernel(int N, DiagModel 
         elem_back(e[i], eta, J);
       }
   }
+}
+
+template <int PER>
+__global__ __launch_bounds__(256) void diag_scan_groups_kernel(int N, DiagModel M, ScanWs S) {
+  __shared__ float tot[2][5][4][4];        // [direction][field][wave][chain]
+  scan_groups_block<PER>(N, M, S, blockIdx.x, tot);
 }
 
 // ------------------------------------------------------------------------------------------

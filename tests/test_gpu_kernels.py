@@ -73,6 +73,36 @@ def test_smooth_diag_long_sequence_fused_and_unfused_scan_agree_with_oracle(monk
         assert (np.abs(Vd - Vd_o) / Vd_o).max() < 1e-5
 
 
+@pytest.mark.parametrize('T,K,vs_diag', [(10_007, 64, True), (2_100, 500, False), (16_000, 33, False)])
+def test_smooth_diag_fused_and_three_kernel_scan_match_oracle(monkeypatch, T, K, vs_diag):
+    """Both organisations of the scan (folded into summarize / replay, and the separate three-kernel
+    scan) on observations far from the origin, ragged T and ragged tiles: each within 1e-5 of the
+    C oracle on every frame."""
+    from eks_amd import hip_ops
+    from oracle import c_oracle
+    rng = np.random.default_rng(T)
+    y = (np.cumsum(rng.standard_normal((T, K, 2)), axis=0) + 300.0).astype(np.float32)
+    var = (0.3 * rng.gamma(2.0, 1.0, (T, K, 2)) + 0.02).astype(np.float32)
+    eye = np.tile(np.eye(2), (K, 1, 1))
+    m0, S0 = np.full((K, 2), 300.0), eye * 25.0
+    s = np.exp(rng.uniform(-6, 6, K))
+    flags = hip_ops.model_flags(S0, eye, eye, eye)
+    ms_o, Vs_o, _ = c_oracle.smooth(np.transpose(y, (1, 0, 2)).astype(np.float64),
+                                    np.clip(np.transpose(var, (1, 0, 2)).astype(np.float64), 1e-12, None),
+                                    m0, S0, eye, eye, eye, s)
+    Vd_o = np.diagonal(Vs_o, axis1=2, axis2=3)
+    for unfused in ('0', '1'):
+        monkeypatch.setenv('EKS_SMOOTH_UNFUSED', unfused)
+        ms, Vs = hip_ops.smooth(_dev(y), _dev(var), _dev(m0), _dev(S0), _dev(eye), _dev(eye), _dev(eye), _dev(s),
+                                flags=flags, vs_diag=vs_diag)
+        ms, Vs = ms.cpu().numpy().astype(np.float64), Vs.cpu().numpy().astype(np.float64)
+        ms_k = np.transpose(ms, (1, 0, 2))
+        assert _rel(ms_k - 300.0, ms_o - 300.0, axis_scale=(1, 2)) < 1e-5
+        Vd = np.transpose(Vs, (1, 0, 2)) if vs_diag else \
+            np.diagonal(np.transpose(Vs, (1, 0, 2, 3)), axis1=2, axis2=3)
+        assert (np.abs(Vd - Vd_o) / Vd_o).max() < 1e-5
+
+
 @pytest.mark.parametrize('T,K,unit,vs_diag', [
     (2000, 4, True, False),      # ibl-pupil-like: 8 chains, several chunks per wave
     (1537, 37, True, True),      # ragged T (not a multiple of the 32-frame chunk), ragged N
