@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/evidence
 rm -rf $O; mkdir -p $O
 cd $R
-python -m pytest tests -q -m gpu 2>&1 | tail -2 > $O/pytest_gpu.txt
+python -m pytest tests -q -m gpu 2>&1 | tail -3 > $O/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 python bench.py > $O/bench_c3.json 2> $O/bench_c3.err
 python bench.py --workload c4 --no-cpu-baseline > $O/bench_c4.json 2>/dev/null
@@ -16,7 +16,7 @@ python bench.py --workload c2 --no-cpu-baseline > $O/bench_c2.json 2>/dev/null
 python bench.py --workload pupil > $O/bench_pupil.json 2>/dev/null
 python bench.py --workload ekf > $O/bench_ekf.json 2>/dev/null
 python tools/ekf_time.py > $O/ekf_time.txt 2>&1
-python tools/driver_time.py 2>&1 | grep -E "ms \(" > $O/driver_time.txt
+python tools/driver_time.py 2>&1 | grep -E " ms" > $O/driver_time.txt
 python tools/host_path_time.py > $O/host_path_time.txt 2>&1
 python tools/adam_time.py > $O/adam_time.txt 2>&1
 cd /tmp; export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Turn gpurun_out/evidence/ (written by tools/collect_evidence.sh on the GPU box) into the committed
 summaries profiles/<tag>_kernel_stats.txt, <tag>_pmc_summary.txt, <tag>_bench*.json and
-profiles/r01_traffic.json.  Usage: python tools/make_profiles.py r01_f"""
+profiles/<round>_traffic.json.  Usage: python tools/make_profiles.py r01_f"""
 import collections, csv, glob, json, os, shutil, sys
 
 tag = sys.argv[1]
@@ -58,7 +58,7 @@ json.dump({'source': f'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate p
                      f'--warmup 1 --no-cpu-baseline --no-kernel-events; see {tag}_pmc_summary.txt',
            'correction': 'hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reads half of a '
                          'coalesced stream, MI355X_MICROARCH.md HBM section)',
-           'hbm_bytes_per_launch': traffic}, open(os.path.join(prof, 'r01_traffic.json'), 'w'), indent=1)
+           'hbm_bytes_per_launch': traffic}, open(os.path.join(prof, f"{tag.split('_')[0]}_traffic.json"), 'w'), indent=1)
 for name in ('c3', 'c4', 'c5', 'c2', 'pupil', 'ekf'):
     src = os.path.join(ev, f'bench_{name}.json')
     if os.path.exists(src) and os.path.getsize(src):
