@@ -76,3 +76,34 @@ def test_oracle_reproduces_multicam_fixed_s(mouse):
     cams, lat = orc.multicam_outputs(arrs, ms, Vs)
     for c, co in enumerate(cams):
         _check(co, mouse, f's10_cam{c}')        # observation space: PCA-sign invariant
+
+
+# ---- second golden tier: vectors produced by the REFERENCE itself (tools/make_golden.py --from-reference)
+def test_oracle_against_reference_generated_vectors_when_present(golden_dir):
+    """The day jax / dynamax / optax are importable in the build container, `python
+    tools/make_golden.py --from-reference` runs the reference's own drivers on its own data and
+    commits tests/golden/ref_*.npz; this test then pins the oracle to upstream numbers at the
+    reference's own tolerance (atol 1e-4, tests/conftest.py:95-101).  Until then the oracle is
+    PARITY UNPINNED and this test says so."""
+    import glob
+    files = sorted(glob.glob(os.path.join(golden_dir, 'ref_*.npz')))
+    if not files:
+        pytest.skip('parity unpinned: no reference-generated vectors (jax / dynamax / optax absent when the '
+                    'goldens were made; run tools/make_golden.py --from-reference where they import)')
+    pup = np.load(os.path.join(golden_dir, 'ibl_pupil_singlecam.npz'))
+    for f in files:
+        ref = np.load(f)
+        name = os.path.basename(f)
+        if name.startswith('ref_singlecam'):
+            arrs = orc.singlecam_arrays(pup['markers'])
+            fixed = 's10' in name
+            s, ms, Vs, _ = orc.run_kalman_smoother(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'],
+                                                   arrs['Qs'], arrs['ensemble_vars'],
+                                                   smooth_param=[10.0] if fixed else None)
+            out = orc.singlecam_outputs(arrs, s, ms, Vs)
+            idx = np.unique(np.concatenate([np.arange(0, 16), np.arange(0, out.shape[0], 4),
+                                            np.arange(out.shape[0] - 16, out.shape[0])]))
+            if fixed:          # outputs at a given s: the reference's own bar
+                np.testing.assert_allclose(out[idx], ref['rows'], rtol=0, atol=1e-4, err_msg=name)
+            else:              # the optimiser's float32 stop test is chaotic: s within its flat basin
+                assert np.all(np.abs(np.log(s) - np.log(ref['s_finals'])) < 0.5), name

@@ -360,3 +360,67 @@ def test_multicam_device_pipeline_equals_host_pipeline(mouse, inflate, monkeypat
         np.testing.assert_array_equal(a[:, 6::9], b[:, 6::9])
     assert list(lat_d.columns) == list(lat_h.columns)
     assert (np.abs(lat_d.values - lat_h.values) / np.abs(lat_h.values).max(axis=0)).max() < 1e-5
+
+
+def test_ibl_paw_wrapper_interpolates_flips_and_smooths(tmp_path):
+    """fit_eks_multicam_ibl_paw (reference eks/ibl_paw_multicam_smoother.py:79-256): right-camera
+    markers interpolated onto the left camera's timestamps (checked against a per-timestamp
+    scipy.interp1d loop, the reference's formulation), paws swapped and x flipped for the right
+    camera, zero likelihood field, then the linear multicam smoother; CSVs written per camera."""
+    from scipy.interpolate import interp1d
+    from eks_amd import MarkerArray, fit_eks_multicam_ibl_paw
+    from eks_amd.multicam_smoother import ensemble_kalman_smoother_multicam
+    rng = np.random.default_rng(0)
+    TL, TR, M, W = 400, 1000, 3, 128
+    ts_r = np.sort(rng.uniform(10.0, 30.0, TR))
+    ts_l = np.sort(rng.uniform(9.5, 30.5, TL))               # a few left frames fall outside
+    src = tmp_path / 'in'
+    src.mkdir()
+    np.save(src / 'sess.timestamps.left.npy', ts_l)
+    np.save(src / 'sess.timestamps.right.npy', ts_r)
+    cols = pd.MultiIndex.from_product([['tracker'], ['paw_l', 'paw_r'], ['x', 'y', 'likelihood']],
+                                      names=['scorer', 'bodyparts', 'coords'])
+    lat_l = np.cumsum(rng.standard_normal((TL, 4)), axis=0) + 60.0
+    lat_r = np.stack([np.interp(ts_r, ts_l, lat_l[:, j]) for j in range(4)], axis=1)
+    raw = {}
+    for m in range(M):
+        for cam, lat, n in (('left', lat_l, TL), ('right', lat_r, TR)):
+            a = np.empty((n, 6))
+            xy = lat + rng.standard_normal((n, 4)) * 0.7
+            if cam == 'right':                               # mirrored view: paws swapped, x flipped
+                xy = xy[:, [2, 3, 0, 1]]
+                xy[:, [0, 2]] = W - xy[:, [0, 2]]
+            a[:, [0, 1, 3, 4]] = xy
+            a[:, [2, 5]] = rng.uniform(0.9, 1.0, (n, 2))
+            raw[(cam, m)] = a
+            pd.DataFrame(a, columns=cols).to_csv(src / f'sess.{cam}.rng={m}.csv')
+    out = tmp_path / 'out'
+    dfs, s, input_dfs, bps = fit_eks_multicam_ibl_paw(str(src), str(out), smooth_param=[10.0], var_mode='var',
+                                                      quantile_keep_pca=95)
+    assert bps == ['paw_l', 'paw_r'] and len(dfs) == 2 and np.all(s == 10.0)
+    assert (out / 'multicam_left_results.csv').exists() and (out / 'multicam_right_results.csv').exists()
+    # the reference's formulation of the interpolation, frame by frame
+    keep = [i for i, t in enumerate(ts_l) if ts_r[0] <= t <= ts_r[-1]]
+    assert 0 < len(keep) < TL and dfs[0].shape == (len(keep), 18)
+    order = sorted(os.listdir(src))
+    lefts = [f for f in os.listdir(src) if 'left' in f and 'timestamps' not in f]
+    rights = [f for f in os.listdir(src) if 'right' in f and 'timestamps' not in f]
+    arr = np.zeros((M, 2, len(keep), 2, 3))
+    for mi, (fl, fr) in enumerate(zip(lefts, rights)):
+        a_l = pd.read_csv(src / fl, header=[0, 1, 2], index_col=0).to_numpy()
+        a_r = pd.read_csv(src / fr, header=[0, 1, 2], index_col=0).to_numpy()
+        a_r = a_r[:, [3, 4, 5, 0, 1, 2]]                     # right camera: paw_l <-> paw_r
+        f = [interp1d(ts_r, a_r[:, j]) for j in range(6)]
+        for row, i in enumerate(keep):
+            arr[mi, 0, row, :, :2] = a_l[i, [0, 1, 3, 4]].reshape(2, 2)
+            r = np.array([f[j](ts_l[i]) for j in (0, 1, 3, 4)])
+            r[[0, 2]] = W - r[[0, 2]]
+            arr[mi, 1, row, :, :2] = r.reshape(2, 2)
+    ref_dfs, _, _ = ensemble_kalman_smoother_multicam(
+        MarkerArray(arr, data_fields=['x', 'y', 'likelihood']), ['paw_l', 'paw_r'], ['left', 'right'],
+        smooth_param=[10.0], quantile_keep_pca=95, var_mode='var', inflate_vars_kwargs={'likelihoods': None})
+    for c in range(2):
+        np.testing.assert_allclose(dfs[c].values, ref_dfs[c].values, rtol=1e-9, atol=1e-9)
+        back = pd.read_csv(out / f"multicam_{['left', 'right'][c]}_results.csv", header=[0, 1, 2], index_col=0)
+        np.testing.assert_allclose(back.values, dfs[c].values, rtol=1e-12)
+    assert order  # (directory listing is what pairs the members, as upstream)

@@ -294,5 +294,58 @@ def main():
     pupil()
 
 
+def reference_available():
+    """True when the reference's own arithmetic can run here: jax + dynamax + optax importable."""
+    import importlib.util
+    return all(importlib.util.find_spec(m) is not None for m in ('jax', 'dynamax', 'optax'))
+
+
+def from_reference():
+    """PIN-WHEN-POSSIBLE HOOK.  When jax / dynamax / optax are importable in the build container,
+    run the REFERENCE's own drivers (imported from /root/reference, never copied) on its own data
+    with the configurations of its integration tests (tests/integration/test_singlecam.py:4-20,
+    test_mirrored_multicam.py:4-30, test_multicam.py:4-30, test_ibl_pupil.py:4-22) and store the
+    resulting DataFrames (decimated rows + column sums, like the oracle goldens) as
+    tests/golden/ref_*.npz.  Only DATA travels.  tests/test_golden_oracle.py compares the oracle to
+    these files when they exist - at that moment the oracle stops being "parity unpinned"."""
+    if not reference_available():
+        print('parity unpinned: jax / dynamax / optax are not importable here; no ref_*.npz written')
+        return 1
+    import tempfile
+    sys.path.insert(0, '/root/reference')
+    from eks.ibl_pupil_smoother import fit_eks_pupil
+    from eks.multicam_smoother import fit_eks_mirrored_multicam, fit_eks_multicam
+    from eks.singlecam_smoother import fit_eks_singlecam
+    tmp = tempfile.mkdtemp()
+    jobs = {
+        'ref_singlecam_defaults': lambda: fit_eks_singlecam(os.path.join(REF, 'ibl-pupil'),
+                                                            os.path.join(tmp, 'a', 'o.csv')),
+        'ref_singlecam_s10': lambda: fit_eks_singlecam(os.path.join(REF, 'ibl-pupil'),
+                                                       os.path.join(tmp, 'b', 'o.csv'), smooth_param=[10.0]),
+        'ref_mirrored_defaults': lambda: fit_eks_mirrored_multicam(
+            os.path.join(REF, 'mirror-mouse'), os.path.join(tmp, 'c', 'o.csv'),
+            bodypart_list=['paw1LH', 'paw2LF'], camera_names=['top', 'bot'], quantile_keep_pca=95,
+            inflate_vars=True),
+        'ref_mirrored_s10': lambda: fit_eks_mirrored_multicam(
+            os.path.join(REF, 'mirror-mouse'), os.path.join(tmp, 'd', 'o.csv'),
+            bodypart_list=['paw1LH', 'paw2LF'], camera_names=['top', 'bot'], smooth_param=[10.0],
+            quantile_keep_pca=95, inflate_vars=True),
+        'ref_pupil_defaults': lambda: fit_eks_pupil(os.path.join(REF, 'ibl-pupil'),
+                                                    os.path.join(tmp, 'e', 'o.csv'), smooth_params=[None, None]),
+        'ref_pupil_fixed': lambda: fit_eks_pupil(os.path.join(REF, 'ibl-pupil'),
+                                                 os.path.join(tmp, 'f', 'o.csv'), smooth_params=[0.99, 0.99]),
+    }
+    for name, job in jobs.items():
+        res = job()
+        df, s = res[0], res[1]
+        vals = np.asarray(df.select_dtypes('number').values, dtype=np.float64)
+        np.savez_compressed(os.path.join(OUT, f'{name}.npz'), columns=np.array([str(c) for c in df.columns]),
+                            s_finals=np.asarray(s, dtype=np.float64), **pack(vals))
+        print(name, vals.shape, 's =', np.asarray(s))
+    return 0
+
+
 if __name__ == '__main__':
+    if '--from-reference' in sys.argv:
+        sys.exit(from_reference())
     main()
