@@ -44,28 +44,6 @@ def keypoint_block_shard(blocks: Sequence[Sequence[int]], world_size: int, rank:
     return sorted(i for i, r in owner if r == rank)
 
 
-def plan_batches(shapes: Sequence[tuple], max_keypoints: int) -> list[list[int]]:
-    """Group positions of `shapes` = [(T, K, D, O), ...] into batches that can be stacked along K:
-    equal (T, D, O), at most `max_keypoints` keypoints per batch (a single larger session is its
-    own batch).  Order inside a batch is the input order."""
-    groups: dict[tuple, list[int]] = {}
-    for pos, (T, K, D, O) in enumerate(shapes):
-        groups.setdefault((T, D, O), []).append(pos)
-    out = []
-    for members in groups.values():
-        cur, n = [], 0
-        for pos in members:
-            k = shapes[pos][1]
-            if cur and n + k > max_keypoints:
-                out.append(cur)
-                cur, n = [], 0
-            cur.append(pos)
-            n += k
-        if cur:
-            out.append(cur)
-    return sorted(out, key=lambda b: b[0])
-
-
 # ------------------------------------------------------------------------------------------
 # collectives
 # ------------------------------------------------------------------------------------------
@@ -197,9 +175,9 @@ def smooth_sessions_batched(load_session: Callable[[int], dict], n_sessions: int
                             **kalman_kwargs):
     """Many independent sessions across the ranks of `group`, batched on the device.
 
-    Each rank takes its round-robin shard, stacks sessions of equal (T, D, O) along the keypoint
-    axis (at most `max_batch_keypoints` keypoints per batch: 8192 x 50 000 frames = 16 GB of
-    inputs and outputs at 40 B per keypoint-frame) and runs ONE run_kalman_smoother per batch -
+    Each rank takes its round-robin shard, stacks CONSECUTIVE sessions of equal (T, D, O) along the
+    keypoint axis (at most `max_batch_keypoints` keypoints per batch: 8192 x 50 000 frames = 16 GB
+    of inputs and outputs at 40 B per keypoint-frame) and runs ONE run_kalman_smoother per batch -
     keypoints are independent (reference eks/core.py:293), so a batch is exactly the sessions
     smoothed one by one.  `smooth_param` may be a scalar, or a callable i -> per-session value.
     `session_blocks(i)` optionally returns session i's keypoint blocks.
@@ -211,27 +189,39 @@ def smooth_sessions_batched(load_session: Callable[[int], dict], n_sessions: int
         smooth_fn = _default_smooth_fn()
     rank, world = _rank_world(group)
     ids = session_shard(n_sessions, world, rank)
-    loaded = {i: load_session(i) for i in ids}
-    shapes = [(np.shape(loaded[i]['ys'])[1], np.shape(loaded[i]['ys'])[0],
-               np.shape(loaded[i]['m0s'])[1], np.shape(loaded[i]['ys'])[2]) for i in ids]
     sp = kalman_kwargs.pop('smooth_param', None)
     mine = {}
-    for batch in plan_batches(shapes, max_batch_keypoints):
-        sess = [loaded[ids[p]] for p in batch]
-        blk = [session_blocks(ids[p]) for p in batch] if session_blocks is not None else None
-        kw, offs, blocks = stack_sessions(sess, blk)
+
+    def flush(batch):                       # batch: [(session id, its loaded arrays)]
+        if not batch:
+            return
+        blk = [session_blocks(i) for i, _ in batch] if session_blocks is not None else None
+        kw, offs, blocks = stack_sessions([sess for _, sess in batch], blk)
         if callable(sp):
-            per = [np.broadcast_to(np.asarray(sp(ids[p]), dtype=float), (int(offs[j + 1] - offs[j]),))
-                   for j, p in enumerate(batch)]
+            per = [np.broadcast_to(np.asarray(sp(i), dtype=float), (int(offs[j + 1] - offs[j]),))
+                   for j, (i, _) in enumerate(batch)]
             kw['smooth_param'] = list(np.concatenate(per))
         else:
             kw['smooth_param'] = sp
         s, ms, Vs = smooth_fn(**kw, blocks=blocks, **kalman_kwargs)
-        for j, p in enumerate(batch):
+        for j, (i, _) in enumerate(batch):
             a, b = int(offs[j]), int(offs[j + 1])
-            mine[ids[p]] = (np.asarray(s[a:b]), ms[a:b], Vs[a:b])
-        for p in batch:                       # inputs of a finished batch are released
-            loaded.pop(ids[p], None)
+            mine[i] = (np.asarray(s[a:b]), ms[a:b], Vs[a:b])
+
+    # sessions are loaded one at a time and a batch is smoothed as soon as it is full (or the next
+    # session has another shape), so at most one batch of inputs is alive beside its stacked copy
+    batch, shape, n_kp = [], None, 0
+    for i in ids:
+        sess = load_session(i)
+        K_i, T_i, O_i = np.shape(sess['ys'])
+        sh = (T_i, np.shape(sess['m0s'])[1], O_i)
+        if batch and (sh != shape or n_kp + K_i > max_batch_keypoints):
+            flush(batch)
+            batch, n_kp = [], 0
+        shape = sh
+        batch.append((i, sess))
+        n_kp += K_i
+    flush(batch)
     all_s = gather_session_results({i: r[0] for i, r in mine.items()}, n_sessions, group)
     return mine, all_s
 

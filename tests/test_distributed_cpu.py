@@ -23,14 +23,7 @@ def test_shards_partition_the_work():
     assert max(loads) - min(loads) <= 2
 
 
-def test_batch_plan_and_stacking():
-    shapes = [(60, 2, 2, 2), (60, 3, 2, 2), (40, 2, 2, 2), (60, 4, 2, 2), (60, 9, 2, 2), (60, 1, 3, 4)]
-    plan = D.plan_batches(shapes, max_keypoints=6)
-    assert sorted(p for b in plan for p in b) == list(range(len(shapes)))
-    for b in plan:
-        assert len({(shapes[p][0],) + shapes[p][2:] for p in b}) == 1          # equal (T, D, O)
-        assert sum(shapes[p][1] for p in b) <= 6 or len(b) == 1                  # a big session stands alone
-    assert [0, 1] in plan and [3] in plan and [4] in plan and [2] in plan and [5] in plan
+def test_session_stacking():
     rng = np.random.default_rng(0)
     sess = [dict(ys=rng.standard_normal((k, 7, 2)), ensemble_vars=rng.random((7, k, 2)),
                  m0s=np.zeros((k, 2)), S0s=np.tile(np.eye(2), (k, 1, 1)), As=np.tile(np.eye(2), (k, 1, 1)),
