@@ -392,17 +392,20 @@ __global__ __launch_bounds__(64 * kFW) void diag_replay_blk_kernel(BlockMap L, D
   smooth_store<B, UNIT, VS_ROW>(v0, v1, ms, Vs, L.N, n, n % M.D, t0, len, p, m, P);
 }
 
-// S2f: scan of the block aggregates, ngrp per chain (hundreds to thousands).  Block = 4 chains x
-// 64 slots (thread t: chain t & 3, slot t >> 2); a slot owns `per` consecutive aggregates, all
+// S2f: scan of the block aggregates, ngrp per chain (hundreds to thousands).  Block = CH chains x
+// 64 slots (thread t: chain t % CH, slot t / CH; CH = 16: 1024 threads, every load instruction
+// reads whole 64-byte segments of the [group][chain] planes - with 4 chains per block the 16-byte
+// pieces moved 77 MB for 20 MB of aggregates); a slot owns `per` consecutive aggregates, all
 // requested at once (registers, PER at a time): it composes them, the slots of a chain are scanned
-// by stride-4 shuffles inside each wave (16 slots) and through LDS across the 4 waves, and each
+// by stride-CH shuffles inside each wave (64 / CH slots) and through LDS across the waves, and each
 // slot walks its aggregates again from the belief entering its first one (forward) / the
 // information leaving its last one (backward), writing the per-block results.
-template <int PER>
-__device__ __forceinline__ void scan_groups_block(int N, const DiagModel& M, const ScanWs& S, int blk,
-                                                  float (&tot)[2][5][4][4]) {
-  const int c = threadIdx.x & 3, slot = threadIdx.x >> 2, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int n = blk * 4 + c;
+template <int PER, int CH>
+__global__ __launch_bounds__(64 * CH) void diag_scan_groups_kernel(int N, DiagModel M, ScanWs S) {
+  constexpr int NW = CH;                   // waves per block (64 slots x CH chains / 64 lanes)
+  __shared__ float tot[2][5][NW][CH];      // [direction][field][wave][chain]
+  const int c = threadIdx.x % CH, slot = threadIdx.x / CH, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.x * CH + c;
   const int per = (S.nblk + 63) / 64;      // <= PER, or the slot re-reads in batches of PER
   const int q0 = min(slot * per, S.nblk), q1 = min(q0 + per, S.nblk);
   const bool live = n < N;
@@ -422,31 +425,31 @@ __device__ __forceinline__ void scan_groups_block(int N, const DiagModel& M, con
         if (b0 + i < q1) own = elem_combine(own, e[i]);
     }
   }
-  // inclusive scans over the wave's 16 slots of each chain (lanes 4 apart), both directions
+  // inclusive scans over the wave's slots of each chain (lanes CH apart), both directions
   Elem<float> f = own, r = own;
 #pragma unroll
-  for (int off = 4; off < 64; off <<= 1) {
+  for (int off = CH; off < 64; off <<= 1) {
     const Elem<float> up = shfl_up_elem(f, off), dn = shfl_down_elem(r, off);
     if (lane >= off) f = elem_combine(up, f);
     if (lane + off < 64) r = elem_combine(r, dn);
   }
-  if (lane >= 60) {                        // the wave's whole composition, per chain
+  if (lane >= 64 - CH) {                   // the wave's whole composition, per chain
     tot[0][0][w][c] = f.A; tot[0][1][w][c] = f.b; tot[0][2][w][c] = f.C; tot[0][3][w][c] = f.eta; tot[0][4][w][c] = f.J;
   }
-  if (lane < 4) {
+  if (lane < CH) {
     tot[1][0][w][c] = r.A; tot[1][1][w][c] = r.b; tot[1][2][w][c] = r.C; tot[1][3][w][c] = r.eta; tot[1][4][w][c] = r.J;
   }
-  __syncthreads();                         // (every thread of the block reaches this)
+  __syncthreads();
   if (!live) return;
   // exclusive prefix of this slot: earlier waves' totals, then the wave's earlier slots
   Elem<float> pre = elem_identity<float>(), post = elem_identity<float>();
   for (int v = 0; v < w; ++v)
     pre = elem_combine(pre, Elem<float>{tot[0][0][v][c], tot[0][1][v][c], tot[0][2][v][c], tot[0][3][v][c], tot[0][4][v][c]});
-  for (int v = 3; v > w; --v)
+  for (int v = NW - 1; v > w; --v)
     post = elem_combine(Elem<float>{tot[1][0][v][c], tot[1][1][v][c], tot[1][2][v][c], tot[1][3][v][c], tot[1][4][v][c]}, post);
-  Elem<float> fe = shfl_up_elem(f, 4), re = shfl_down_elem(r, 4);
-  if (lane < 4) fe = elem_identity<float>();
-  if (lane >= 60) re = elem_identity<float>();
+  Elem<float> fe = shfl_up_elem(f, CH), re = shfl_down_elem(r, CH);
+  if (lane < CH) fe = elem_identity<float>();
+  if (lane >= 64 - CH) re = elem_identity<float>();
   pre = elem_combine(pre, fe);
   post = elem_combine(re, post);
   float m, P;
@@ -486,12 +489,6 @@ __device__ __forceinline__ void scan_groups_block(int N, const DiagModel& M, con
         elem_back(e[i], eta, J);
       }
   }
-}
-
-template <int PER>
-__global__ __launch_bounds__(256) void diag_scan_groups_kernel(int N, DiagModel M, ScanWs S) {
-  __shared__ float tot[2][5][4][4];        // [direction][field][wave][chain]
-  scan_groups_block<PER>(N, M, S, blockIdx.x, tot);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -555,14 +552,15 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
   DiagWs W;
   float** planes[9] = {&W.eA, &W.eb, &W.eC, &W.eEta, &W.eJ, &W.pm, &W.pP, &W.sEta, &W.sJ};
   for (int i = 0; i < 9; ++i) *planes[i] = reinterpret_cast<float*>(base + i * pb);
-  // Fused scan (measured, MI355X, fixed s, full Vs): 100 000 x 256 keypoints 0.309 -> 0.287 ms,
-  // 10 000 x 64 31 -> 22 us, 50 000 x 1024 0.632 -> 0.623 ms.  Not for very wide problems (50 000
-  // x 4096 keypoints 2.45 -> 2.48 ms: the three-kernel scan is already 12 % of the time there and
-  // the 256-row blocks of the fused kernels stride further) nor for sequences whose group scan
-  // would leave its registers (more than 16 aggregates per slot: 400 000 x 64 0.345 -> 0.391 ms).
+  // Fused scan (measured, MI355X, fixed s, full Vs; three-kernel scan -> fused): 100 000 x 256
+  // keypoints 0.309 -> 0.293 ms, 10 000 x 64 31 -> 22 us, 50 000 x 1024 0.632 -> 0.602 ms,
+  // 50 000 x 4096 2.45 -> 2.41 ms (there the fused summarize / replay run 17 % / 7 % slower than
+  // the plain ones - barrier, neighbour compositions - which eats most of what the scan saves).
+  // Not for sequences whose group scan would leave its registers (more than 16 aggregates per
+  // slot, T > 131 072: 400 000 x 64 0.345 -> 0.391 ms).
   const char* legacy = getenv("EKS_SMOOTH_UNFUSED");
   const int ngrp_f = (L.nc + kFW - 1) / kFW;
-  const bool fused = L.nt_log2 == 6 && (legacy ? legacy[0] == '0' : (N <= 4096 && ngrp_f <= 1024));
+  const bool fused = L.nt_log2 == 6 && (legacy ? legacy[0] == '0' : ngrp_f <= 1024);
   ScanWs S;
   S.nblk = fused ? (L.nc + kFW - 1) / kFW : (L.nc + kScanCB - 1) / kScanCB;
   const size_t sb = plane_bytes(S.nblk, N);
@@ -590,10 +588,22 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
     {
       ProfScope ps("diag_scan", st);
       // a slot's aggregates stay in registers when there are at most 16 of them (T <= 131 072)
-      if ((S.nblk + 63) / 64 <= 8)
-        hipLaunchKernelGGL(diag_scan_groups_kernel<8>, dim3((N + 3) / 4), dim3(256), 0, st, N, M, S);
-      else
-        hipLaunchKernelGGL(diag_scan_groups_kernel<16>, dim3((N + 3) / 4), dim3(256), 0, st, N, M, S);
+      // 4 chains per block for narrow problems (more blocks: 10 000 x 64 keypoints 7.1 vs 9.4 us),
+      // 16 for wide ones (whole 64-byte segments: 50 000 x 4096 keypoints 119 -> 46 us)
+      const char* ch_env = getenv("EKS_SCAN_CH");
+      const bool ch4 = ch_env ? ch_env[0] == '4' : N < 2048;
+      const bool per8 = (S.nblk + 63) / 64 <= 8;
+      if (ch4) {
+        if (per8)
+          hipLaunchKernelGGL((diag_scan_groups_kernel<8, 4>), dim3((N + 3) / 4), dim3(256), 0, st, N, M, S);
+        else
+          hipLaunchKernelGGL((diag_scan_groups_kernel<16, 4>), dim3((N + 3) / 4), dim3(256), 0, st, N, M, S);
+      } else {
+        if (per8)
+          hipLaunchKernelGGL((diag_scan_groups_kernel<8, 16>), dim3((N + 15) / 16), dim3(1024), 0, st, N, M, S);
+        else
+          hipLaunchKernelGGL((diag_scan_groups_kernel<16, 16>), dim3((N + 15) / 16), dim3(1024), 0, st, N, M, S);
+      }
     }
     ProfScope ps("diag_replay", st);
     Bm.reverse = k3_reverse;
