@@ -416,7 +416,7 @@ __global__ __launch_bounds__(64 * kColWaves) void bracket_collect_kernel(int T, 
                                                                         const float* __restrict__ var,
                                                                         BracketWs B) {
   __shared__ uint32_t stage[kColWaves][kColSlots][65];   // [wave][slot][chain], padded
-  __shared__ uint32_t counts[kColWaves][64], base[64];
+  __shared__ uint32_t counts[kColWaves][64], lessv[kColWaves][64], validv[kColWaves][64], base[64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int ntile = (N + 63) / 64;
   const int tile = blockIdx.x % ntile, slab = blockIdx.x / ntile;
@@ -485,16 +485,25 @@ __global__ __launch_bounds__(64 * kColWaves) void bracket_collect_kernel(int T, 
       }
       mine = cap;
     }
-    if (less) atomicAdd(&B.less[n], less);
-    if (nvalid) atomicAdd(&B.valid[n], nvalid);
   }
+  // the 8 waves' counters meet in LDS and wave 0 issues ONE atomic per counter and chain: every
+  // wave adding its own `less` / `valid` (1 568 waves per tile onto the same 256-byte row) cost
+  // ~10 us of the pass on the C3 shape
   counts[w][lane] = mine;
+  lessv[w][lane] = less;
+  validv[w][lane] = nvalid;
   __syncthreads();
   if (w == 0) {
-    uint32_t tot = 0;
+    uint32_t tot = 0, tl = 0, tv = 0;
 #pragma unroll
-    for (int q = 0; q < kColWaves; ++q) tot += counts[q][lane];
+    for (int q = 0; q < kColWaves; ++q) {
+      tot += counts[q][lane];
+      tl += lessv[q][lane];
+      tv += validv[q][lane];
+    }
     base[lane] = tot ? atomicAdd(&B.cnt[n], tot) : 0u;     // tot > 0 implies a live chain
+    if (tl) atomicAdd(&B.less[n], tl);                      // (non-zero only for live chains)
+    if (tv) atomicAdd(&B.valid[n], tv);
   }
   __syncthreads();
   // wave w writes the runs of chains w, w + 8, ...; lane = (source wave, slot within a group of 8)
