@@ -75,11 +75,12 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get('EKS_HIP_LIB', LIB_PATH)      # A/B builds of the same sources (tools/)
+    if not os.path.exists(path):
         raise EksHipError(
-            f'{LIB_PATH} not found: the HIP extension has not been built. '
+            f'{path} not found: the HIP extension has not been built. '
             'Run `python -m eks_amd._build` (needs hipcc). There is no CPU fallback.')
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

@@ -324,15 +324,15 @@ EKS_HD void dense_replay_chunk_obs(const Obs& obs, int K, int k, int t0, int len
   auto emit = [&](int i, const Vec<double, D>& mo, const Mat<double, D>& Po) {
     const size_t ko = (size_t)(t0 + i) * K + k;
 #pragma unroll
-    for (int a = 0; a < D; ++a) ms[ko * D + a] = (float)mo.a[a];
+    for (int a = 0; a < D; ++a) EKS_STREAM_STORE(ms + ko * D + a, (float)mo.a[a]);
     if (vs_diag) {
 #pragma unroll
-      for (int a = 0; a < D; ++a) Vs[ko * D + a] = (float)Po.a[a][a];
+      for (int a = 0; a < D; ++a) EKS_STREAM_STORE(Vs + ko * D + a, (float)Po.a[a][a]);
     } else {
 #pragma unroll
       for (int a = 0; a < D; ++a)
 #pragma unroll
-        for (int b = 0; b < D; ++b) Vs[(ko * D + a) * D + b] = (float)Po.a[a][b];
+        for (int b = 0; b < D; ++b) EKS_STREAM_STORE(Vs + (ko * D + a) * D + b, (float)Po.a[a][b]);
     }
   };
   Vec<double, D> m_s;

@@ -115,19 +115,18 @@ EKS_HD void smooth_store(const float (&v0)[B], const float (&v1)[B], float* __re
     if (i < len) {
       rts_step<float, UNIT>(m, P, v0[i], v1[i], p);
       const size_t o = base + (size_t)i * N;
-      ms_out[o] = m;
+      EKS_STREAM_STORE(ms_out + o, m);
       if constexpr (VS_ROW == 0) {
-        Vs_out[o] = P;
+        EKS_STREAM_STORE(Vs_out + o, P);
       } else if constexpr (VS_ROW == 1) {
-        Vs_out[o] = P;
+        EKS_STREAM_STORE(Vs_out + o, P);
       } else if constexpr (VS_ROW == 2) {
-        float2 row;
-        row.x = d == 0 ? P : 0.0f;
-        row.y = d == 1 ? P : 0.0f;
-        *reinterpret_cast<float2*>(Vs_out + o * 2) = row;
+        // the two chains of a keypoint write adjacent halves of its 2x2 row pair
+        EKS_STREAM_STORE(Vs_out + o * 2, d == 0 ? P : 0.0f);
+        EKS_STREAM_STORE(Vs_out + o * 2 + 1, d == 1 ? P : 0.0f);
       } else {
 #pragma unroll
-        for (int e = 0; e < VS_ROW; ++e) Vs_out[o * VS_ROW + e] = (e == d) ? P : 0.0f;
+        for (int e = 0; e < VS_ROW; ++e) EKS_STREAM_STORE(Vs_out + o * VS_ROW + e, (e == d) ? P : 0.0f);
       }
     }
   }

@@ -25,6 +25,18 @@ struct float2 {
 };
 #endif
 
+// Final outputs (ms, Vs, output tables) are written once and never read again by this library.  A
+// plain store leaves them dirty in the L2s and the 256 MB Infinity Cache, and the NEXT kernels'
+// reads then pay for the write-back (MI355X: K3 leaves 614 MB of ms / Vs behind on the C3 shape;
+// the median pass that follows took 111 us behind plain stores and 94 us behind non-temporal ones,
+// the whole step 0.600 -> 0.580 ms, the C5 share 2.185 -> 2.123 ms; same box, alternating runs).
+// -DEKS_PLAIN_STORES restores plain stores for A/B builds (tools: EKS_HIP_LIB selects the library).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(EKS_PLAIN_STORES)
+#define EKS_STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define EKS_STREAM_STORE(ptr, val) (*(ptr) = (val))
+#endif
+
 namespace eks {
 
 template <typename R>

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include "eks_internal.hpp"
+#include "eks_math.hpp"
 
 namespace eks {
 
@@ -244,13 +245,13 @@ __global__ __launch_bounds__(256) void multicam_tables_kernel(int V, int T, int 
   out[4] = (double)st[1];
   double* dst = tables + (size_t)idx * 9;
 #pragma unroll
-  for (int q = 0; q < 9; ++q) dst[q] = out[q];
+  for (int q = 0; q < 9; ++q) EKS_STREAM_STORE(dst + q, out[q]);
   if (latent && c == 0) {
     double* lt = latent + tk * 2 * D;
 #pragma unroll
     for (int a = 0; a < D; ++a) {
-      lt[a] = m[a];
-      lt[D + a] = S[a][a];
+      EKS_STREAM_STORE(lt + a, m[a]);
+      EKS_STREAM_STORE(lt + D + a, S[a][a]);
     }
   }
 }
