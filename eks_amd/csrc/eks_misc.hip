@@ -348,15 +348,20 @@ __global__ __launch_bounds__(256) void sample_transpose_kernel(int T, int N, int
   __shared__ uint32_t tile[64][65];
   const int n0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int r = w; r < 64; r += 4) {
-    const int i = i0 + r, n = n0 + lane;
-    uint32_t key = 0xFFFFFFFFu;                            // NaNs (and padding) sort last
-    if (i < S && n < N) {
-      bool valid;
-      const uint32_t k = var_key(var[(size_t)(((long)i * T) / S) * N + n], valid);
-      if (valid) key = k;
-    }
-    tile[r][lane] = key;
+  // all 16 rows of the wave requested before the first is used (the rows are ~T / S frames apart:
+  // one dependent HBM latency each if the loop is left rolled - 14.7 us for 17 MB of traffic)
+  float v[16];
+  const int n = n0 + lane;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = i0 + w + 4 * q;
+    v[q] = (i < S && n < N) ? var[(size_t)(((long)i * T) / S) * N + n] : __uint_as_float(0x7FC00000u);
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    bool valid;
+    const uint32_t k = var_key(v[q], valid);
+    tile[w + 4 * q][lane] = valid ? k : 0xFFFFFFFFu;         // NaNs (and padding) sort last
   }
   __syncthreads();
   for (int c = w; c < 64; c += 4) {

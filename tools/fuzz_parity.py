@@ -41,7 +41,12 @@ for case in range(n_cases):
     cand = np.exp(np.sort(rng.uniform(-8, 8, n_cand)))
     nll = hip_ops.nll(tg._dev(y_tk), tg._dev(rc), *tg._params_dev(arrs), tg._dev(cand), flags=flags).cpu().numpy()
     ref = c_oracle.nll_grid(arrs['ys'], rc, arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], cand)
-    e_nll = float((np.abs(nll - ref) / np.maximum(np.abs(ref), 1.0)).max())
+    # relative to the NLL or - where the log-determinant and quadratic parts cancel and the NLL itself
+    # passes through zero (small R: log S < 0) - to the size of the parts, T * sum_chains (|log R| + 1):
+    # against |nll| alone two such cases read 2.7e-5 / 1.5e-5 for absolute errors of 3e-5 on parts
+    # of 2e3 (seed 2222, cases 18 and 21)
+    gross = T * (np.abs(np.log(rc)) + 1.0).sum(axis=1, keepdims=True)
+    e_nll = float((np.abs(nll - ref) / np.maximum(np.abs(ref), 1e-2 * gross)).max())
     # smoother
     s = np.exp(rng.uniform(-8, 8, K))
     ms, Vs = hip_ops.smooth(tg._dev(y_tk), tg._dev(var_tk), *tg._params_dev(arrs), tg._dev(s), flags=flags, vs_diag=True)
