@@ -299,14 +299,17 @@ struct BlockMap {
 };
 
 // K1f: chunk elements + the block's aggregate (time-ordered composition of its kFW elements by
-// wave 0, lanes = chains; rows past the end of the sequence are identities).
+// the last wave to arrive, lanes = chains; rows past the end of the sequence are identities).
 template <int B, bool UNIT>
 __global__ __launch_bounds__(64 * kFW) void diag_summarize_blk_kernel(BlockMap L, DiagModel M, DiagWs W,
                                                                      ScanWs S,
                                                                      const float* __restrict__ y,
                                                                      const float* __restrict__ var) {
   __shared__ float sh[5][kFW][64];
+  __shared__ int arrived;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) arrived = 0;
+  __syncthreads();                         // (at the very start: costs nothing, the waves launch together)
   const int tile = blockIdx.x % L.ntile;
   int grp = blockIdx.x / L.ntile;
   if (L.reverse) grp = L.ngrp - 1 - grp;
@@ -328,9 +331,16 @@ __global__ __launch_bounds__(64 * kFW) void diag_summarize_blk_kernel(BlockMap L
   sh[2][w][lane] = e.C;
   sh[3][w][lane] = e.eta;
   sh[4][w][lane] = e.J;
-  __syncthreads();
-  if (w != 0 || n >= L.N) return;
-  Elem<float> a = e;
+  // no workgroup barrier: the wave that arrives LAST composes the block aggregate (LDS operations
+  // of a wave complete in order, so its ticket is taken after its element is in LDS), the others
+  // retire at once and free their slots
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  int ticket = 0;
+  if (lane == 0) ticket = atomicAdd(&arrived, 1);
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  if (ticket != kFW - 1 || n >= L.N) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  Elem<float> a{sh[0][0][lane], sh[1][0][lane], sh[2][0][lane], sh[3][0][lane], sh[4][0][lane]};
 #pragma unroll
   for (int q = 1; q < kFW; ++q)
     a = elem_combine(a, Elem<float>{sh[0][q][lane], sh[1][q][lane], sh[2][q][lane], sh[3][q][lane],
