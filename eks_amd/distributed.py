@@ -151,15 +151,24 @@ def _cat(parts, axis):
     return np.concatenate([np.asarray(p) for p in parts], axis=axis)
 
 
-def stack_sessions(sessions: Sequence[dict], blocks: Sequence[Sequence[Sequence[int]] | None] | None = None):
+def stack_sessions(sessions: Sequence[dict], blocks: Sequence[Sequence[Sequence[int]] | None] | None = None,
+                   device=None):
     """Stack run_kalman_smoother inputs of several sessions of equal (T, D, O) along the keypoint
     axis.  Returns (kwargs of ONE run_kalman_smoother call, keypoint offsets [n+1], blocks of the
     stacked problem - each session's blocks shifted by its offset, singletons where a session gave
-    none)."""
+    none).  With `device`, host arrays of ys / ensemble_vars are uploaded session by session (as
+    float32) and concatenated ON THE DEVICE - no host-side copy of the whole batch."""
     offs = np.zeros(len(sessions) + 1, dtype=np.int64)
     offs[1:] = np.cumsum([np.shape(s['m0s'])[0] for s in sessions])
-    kw = dict(ys=_cat([s['ys'] for s in sessions], 0),
-              ensemble_vars=_cat([s['ensemble_vars'] for s in sessions], 1))
+
+    def big(a):
+        if device is None or hasattr(a, 'detach'):
+            return a
+        import torch
+        return torch.as_tensor(np.ascontiguousarray(a), device=device).to(torch.float32)
+
+    kw = dict(ys=_cat([big(s['ys']) for s in sessions], 0),
+              ensemble_vars=_cat([big(s['ensemble_vars']) for s in sessions], 1))
     for name in ('m0s', 'S0s', 'As', 'Cs', 'Qs'):
         kw[name] = np.concatenate([np.asarray(s[name], dtype=np.float64) for s in sessions], axis=0)
     stacked_blocks = []
@@ -185,8 +194,11 @@ def smooth_sessions_batched(load_session: Callable[[int], dict], n_sessions: int
     Returns (local {i: (s_finals, ms, Vs)} - views into the batch outputs, on the device when
     return_device=True is passed through - and s_finals of ALL sessions, gathered with tensor
     collectives, on every rank)."""
+    device = None
     if smooth_fn is None:
         smooth_fn = _default_smooth_fn()
+        from . import hip_ops
+        device = hip_ops.require_gpu()         # host sessions go up one by one, stacked on the device
     rank, world = _rank_world(group)
     ids = session_shard(n_sessions, world, rank)
     sp = kalman_kwargs.pop('smooth_param', None)
@@ -196,7 +208,7 @@ def smooth_sessions_batched(load_session: Callable[[int], dict], n_sessions: int
         if not batch:
             return
         blk = [session_blocks(i) for i, _ in batch] if session_blocks is not None else None
-        kw, offs, blocks = stack_sessions([sess for _, sess in batch], blk)
+        kw, offs, blocks = stack_sessions([sess for _, sess in batch], blk, device)
         if callable(sp):
             per = [np.broadcast_to(np.asarray(sp(i), dtype=float), (int(offs[j + 1] - offs[j]),))
                    for j, (i, _) in enumerate(batch)]
