@@ -298,6 +298,52 @@ struct BlockMap {
   int reverse;   // walk the chunk groups backwards in time
 };
 
+// Row access of the fused kernels through buffer resources based at the first row of the wave's
+// chunk and tile (scalar): `buffer_load_dword v, v_lane, s[rsrc], s_row offen` - the row offset is
+// an SGPR, the lane offset a constant VGPR, so loads and stores cost no VALU address arithmetic
+// (K1 ran 27 VALU instructions per frame for 13 of arithmetic before; a chunk's rows span
+// 32 x N x 4 W bytes, checked against the 2 GiB offset range by the launch code).
+struct BufferRows {
+  __amdgpu_buffer_rsrc_t ry, rv;
+  unsigned voff, row_bytes;
+  __device__ __forceinline__ float load_y(int i) const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, voff, (unsigned)i * row_bytes, 0));
+  }
+  __device__ __forceinline__ float load_var(int i) const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, (unsigned)i * row_bytes, 0));
+  }
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7FFFFFFF, 0x00020000);
+}
+
+constexpr int kAuxNt = 2;                  // gfx950 cache policy: non-temporal (see EKS_STREAM_STORE)
+
+template <int VS_ROW>
+struct BufferStore {
+  __amdgpu_buffer_rsrc_t rm, rV;
+  unsigned voff, row_bytes;                // of ms; Vs rows are W times as wide
+  int d;
+  __device__ __forceinline__ void operator()(int i, float m, float P) const {
+    constexpr unsigned W = VS_ROW == 0 ? 1 : VS_ROW;
+    const unsigned so = (unsigned)i * row_bytes;
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), rm, voff, so, kAuxNt);
+    if constexpr (VS_ROW <= 1) {
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, P), rV, voff, so, kAuxNt);
+    } else if constexpr (VS_ROW == 2) {
+      typedef unsigned u2 __attribute__((ext_vector_type(2)));
+      const u2 v = {__builtin_bit_cast(unsigned, d == 0 ? P : 0.0f), __builtin_bit_cast(unsigned, d == 1 ? P : 0.0f)};
+      __builtin_amdgcn_raw_buffer_store_b64(v, rV, voff * 2, so * 2, kAuxNt);
+    } else {
+#pragma unroll
+      for (unsigned e = 0; e < W; ++e)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (int)e == d ? P : 0.0f), rV,
+                                              voff * W + 4 * e, so * W, kAuxNt);
+    }
+  }
+};
+
 // K1f: chunk elements + the block's aggregate (time-ordered composition of its kFW elements by
 // the last wave to arrive, lanes = chains; rows past the end of the sequence are identities).
 template <int B, bool UNIT>
@@ -307,7 +353,9 @@ __global__ __launch_bounds__(64 * kFW) void diag_summarize_blk_kernel(BlockMap L
                                                                      const float* __restrict__ var) {
   __shared__ float sh[5][kFW][64];
   __shared__ int arrived;
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // the wave index through readfirstlane: chunk, first frame and length are then scalars to the
+  // compiler (row addresses in SGPRs, the tail test a scalar branch)
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (threadIdx.x == 0) arrived = 0;
   __syncthreads();                         // (at the very start: costs nothing, the waves launch together)
   const int tile = blockIdx.x % L.ntile;
@@ -317,8 +365,17 @@ __global__ __launch_bounds__(64 * kFW) void diag_summarize_blk_kernel(BlockMap L
   Elem<float> e = elem_identity<float>();
   if (n < L.N && j < L.nc) {
     const ChainParams<float> p = load_chain_params(M, n);
-    const int t0 = j * B;
-    e = summarize_chunk<B, UNIT>(y, var, L.N, n, t0, min(B, L.T - t0), p);
+    const int t0 = j * B, len = min(B, L.T - t0);
+    const size_t first = (size_t)t0 * L.N + (size_t)tile * 64;
+    const BufferRows rows{rows_rsrc(y + first), rows_rsrc(var + first), (unsigned)lane * 4, (unsigned)L.N * 4};
+    float yy[B], rr[B];
+    if (len == B) {                        // wave-uniform: all chunks but a sequence's last
+      load_rows<B, true>(rows, B, yy, rr);
+      e = summarize_loaded<B, UNIT, true>(yy, rr, B, p);
+    } else {
+      load_rows<B, false>(rows, len, yy, rr);
+      e = summarize_loaded<B, UNIT, false>(yy, rr, len, p);
+    }
     const size_t o = (size_t)j * L.N + n;
     W.eA[o] = e.A;
     W.eb[o] = e.b;
@@ -366,7 +423,7 @@ __global__ __launch_bounds__(64 * kFW) void diag_replay_blk_kernel(BlockMap L, D
                                                                   const float* __restrict__ var,
                                                                   float* __restrict__ ms,
                                                                   float* __restrict__ Vs) {
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int tile = blockIdx.x % L.ntile;
   int grp = blockIdx.x / L.ntile;
   if (L.reverse) grp = L.ngrp - 1 - grp;
@@ -378,8 +435,12 @@ __global__ __launch_bounds__(64 * kFW) void diag_replay_blk_kernel(BlockMap L, D
   const ChainParams<float> p = load_chain_params(M, n);
   const int t0 = j * B;
   const int len = min(B, L.T - t0);
+  const bool full = len == B;              // wave-uniform: all chunks but a sequence's last
+  const size_t first = (size_t)t0 * L.N + (size_t)tile * 64;
+  const BufferRows rows{rows_rsrc(y + first), rows_rsrc(var + first), (unsigned)lane * 4, (unsigned)L.N * 4};
   float v0[B], v1[B];
-  load_chunk<B>(y, var, L.N, n, t0, len, v0, v1);
+  if (full) load_rows<B, true>(rows, B, v0, v1);
+  else load_rows<B, false>(rows, len, v0, v1);
   Elem<float> ef[kFW - 1];
 #pragma unroll
   for (int q = 0; q < kFW - 1; ++q)
@@ -394,12 +455,17 @@ __global__ __launch_bounds__(64 * kFW) void diag_replay_blk_kernel(BlockMap L, D
 #pragma unroll
   for (int q = 0; q < kFW - 1; ++q)
     if (j + 1 + q < j1) eb[q] = load_elem(W, (size_t)(j + 1 + q) * L.N + n);
-  filter_loaded<B, UNIT>(v0, v1, len, p, m, P);
+  if (full) filter_loaded<B, UNIT, true>(v0, v1, B, p, m, P);
+  else filter_loaded<B, UNIT, false>(v0, v1, len, p, m, P);
 #pragma unroll
   for (int q = kFW - 2; q >= 0; --q)
     if (j + 1 + q < j1) elem_back(eb[q], eta, J);
   fuse_info(m, P, eta, J);
-  smooth_store<B, UNIT, VS_ROW>(v0, v1, ms, Vs, L.N, n, n % M.D, t0, len, p, m, P);
+  constexpr int VW = VS_ROW == 0 ? 1 : VS_ROW;
+  const BufferStore<VS_ROW> st{rows_rsrc(ms + first), rows_rsrc(Vs + first * VW), (unsigned)lane * 4,
+                               (unsigned)L.N * 4, n % M.D};
+  if (full) smooth_rows<B, UNIT, true>(v0, v1, B, p, m, P, st);
+  else smooth_rows<B, UNIT, false>(v0, v1, len, p, m, P, st);
 }
 
 // S2f: scan of the block aggregates, ngrp per chain (hundreds to thousands).  Block = CH chains x
@@ -570,7 +636,9 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
   // slot, T > 131 072: 400 000 x 64 0.345 -> 0.391 ms).
   const char* legacy = getenv("EKS_SMOOTH_UNFUSED");
   const int ngrp_f = (L.nc + kFW - 1) / kFW;
-  const bool fused = L.nt_log2 == 6 && (legacy ? legacy[0] == '0' : ngrp_f <= 1024);
+  // (the fused kernels address a chunk's rows with 32-bit buffer offsets: 32 rows of N x D floats)
+  const bool in_range = (size_t)32 * N * (vs_diag ? 1 : D) * sizeof(float) < ((size_t)1 << 31);
+  const bool fused = L.nt_log2 == 6 && in_range && (legacy ? legacy[0] == '0' : ngrp_f <= 1024);
   ScanWs S;
   S.nblk = fused ? (L.nc + kFW - 1) / kFW : (L.nc + kScanCB - 1) / kScanCB;
   const size_t sb = plane_bytes(S.nblk, N);
