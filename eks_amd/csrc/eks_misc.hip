@@ -44,8 +44,17 @@ __device__ __forceinline__ uint32_t var_key(float v, bool& valid) {
 constexpr int kMedSmall = 1024;      // T up to here: one block per chain selects from the column
 constexpr int kMedSamples = 4096;    // sample rows per chain (fewer for short sequences)
 constexpr int kMedList = 16384;      // capacity of a chain's in-bracket list
-constexpr int kColRows = 64;        // rows per wave in the full pass
-constexpr int kColFlight = 32;       // loads in flight per lane
+#ifndef EKS_COL_ROWS
+#define EKS_COL_ROWS 64
+#endif
+#ifndef EKS_COL_FLIGHT
+#define EKS_COL_FLIGHT 32
+#endif
+#ifndef EKS_COL_SLOTS
+#define EKS_COL_SLOTS 16
+#endif
+constexpr int kColRows = EKS_COL_ROWS;        // rows per wave in the full pass
+constexpr int kColFlight = EKS_COL_FLIGHT;       // loads in flight per lane
 constexpr int kColWaves = 8;         // waves per block of the full pass (same 64 chains)
 
 struct BracketWs {
@@ -414,7 +423,7 @@ __global__ __launch_bounds__(256) void sample_bracket_kernel(int N, int S, Brack
 // slots with the slot counter in a register - no atomics and no branches on the per-row path.
 // After the barrier the runs of the 8 waves are written out back to back, one global atomic per
 // chain and block.
-constexpr int kColSlots = 16;   // expected 64 rows x ~7 % = 4.5 in-bracket keys per lane and wave
+constexpr int kColSlots = EKS_COL_SLOTS;   // expected 64 rows x ~7 % = 4.5 in-bracket keys per lane and wave
 static_assert(kColWaves == 8, "the run write-out maps lanes to (8 source waves) x (8 slots)");
 
 __global__ __launch_bounds__(64 * kColWaves) void bracket_collect_kernel(int T, int N,

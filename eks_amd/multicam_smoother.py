@@ -26,7 +26,7 @@ from .calibration import (CameraGroup, make_projection_from_camgroup, project_3d
 from .core import ensemble, run_kalman_smoother
 from .marker_array import (MarkerArray, input_dfs_to_markerArray, mA_to_stacked_array,
                            stacked_array_to_mA)
-from .stats import compute_mahalanobis, compute_pca
+from .stats import compute_mahalanobis, compute_pca, factor_analysis_from_moments
 from .utils import center_predictions, format_data, make_dlc_pandas_index
 
 __all__ = ['fit_eks_mirrored_multicam', 'fit_eks_multicam', 'ensemble_kalman_smoother_multicam']
@@ -281,9 +281,11 @@ def _linear_on_device(marker_array, keypoint_names, smooth_param, quantile_keep_
 def _inflate_on_device(ys, evs, likes, n_latent, inflate_vars_kwargs, threshold: float = 5.0,
                        scalar: float = 10.0):
     """mA_compute_maha (reference eks/multicam_smoother.py:653-721) with the per-frame work on the
-    device: every pass, the keypoints still inflating get a factor-analysis fit on the host (rows
-    chosen as compute_mahalanobis does, eks/stats.py:103-118, from the CURRENT variances) and one
-    eks_maha_inflate launch covers them all; a keypoint stops when a pass inflates nothing.
+    device: every pass, the keypoints still inflating get a factor-analysis fit (rows chosen as
+    compute_mahalanobis does, eks/stats.py:103-118, from the CURRENT variances; the fitted rows are
+    reduced to their mean and covariance on the device and sklearn's EM loop runs on that 2V x 2V
+    matrix on the host, stats.factor_analysis_from_moments) and one eks_maha_inflate launch covers
+    them all; a keypoint stops when a pass inflates nothing.
     ys (K,T,2V) float64, evs (K,T,2V) float32 -> inflated evs (new tensor)."""
     import torch
     from sklearn.decomposition import FactorAnalysis
@@ -296,27 +298,51 @@ def _inflate_on_device(ys, evs, likes, n_latent, inflate_vars_kwargs, threshold:
     kw.setdefault('v_quantile_threshold', 50.0)
     eps = kw.get('epsilon', 1e-6)
     v = evs.clone()
-    x_host = ys.cpu().numpy()
-    likes_host = likes.cpu().numpy() if likes is not None else None
+    fixed = kw.get('loading_matrix') is not None and kw.get('mean') is not None
+    # sklearn's default randomized SVD is an exact SVD when its n_latent + 10 random directions
+    # span all 2V columns: the fit then only needs the fitted rows' mean and covariance, which are
+    # reduced on the device (stats.factor_analysis_from_moments); wider problems use sklearn itself
+    moments = not fixed and O <= n_latent + 10
+    x_host = None if (fixed or moments) else ys.cpu().numpy()
+    rows_ok = np.ones((K, T), dtype=bool)
+    if likes is not None and kw.get('likelihood_threshold') is not None and not fixed:
+        rows_ok &= (likes.amin(dim=2) >= kw['likelihood_threshold']).cpu().numpy()
     W = torch.zeros((K, O, n_latent), dtype=torch.float64, device=dev)
     mu = torch.zeros((K, O), dtype=torch.float64, device=dev)
+    if fixed:
+        W[:] = torch.as_tensor(np.ascontiguousarray(kw['loading_matrix'], dtype=np.float64), device=dev)
+        mu[:] = torch.as_tensor(np.ascontiguousarray(kw['mean'], dtype=np.float64), device=dev)
     active = np.ones(K, dtype=bool)
     while active.any():
-        worst = v.amax(dim=2).cpu().numpy()                                   # (K,T) float32
         for k in np.flatnonzero(active):
             logger.info(f'inflating keypoint: {k}')
-            if kw.get('loading_matrix') is not None and kw.get('mean') is not None:
-                Wk, muk = np.asarray(kw['loading_matrix']), np.asarray(kw['mean'])
-            else:
-                rows = np.ones(T, dtype=bool)
-                if likes_host is not None and kw.get('likelihood_threshold') is not None:
-                    rows &= np.min(likes_host[k], axis=1) >= kw['likelihood_threshold']
-                if kw.get('v_quantile_threshold') is not None:
-                    rows &= worst[k] < np.percentile(worst[k], kw['v_quantile_threshold'])
-                fa = FactorAnalysis(n_components=n_latent).fit(x_host[k][rows])
-                Wk, muk = fa.components_.T, fa.mean_
-            W[k] = torch.as_tensor(np.ascontiguousarray(Wk, dtype=np.float64), device=dev)
-            mu[k] = torch.as_tensor(np.ascontiguousarray(muk, dtype=np.float64), device=dev)
+        if not fixed:
+            rows = rows_ok.copy()
+            if kw.get('v_quantile_threshold') is not None:
+                worst = v.amax(dim=2).cpu().numpy()                               # (K,T) float32
+                for k in np.flatnonzero(active):
+                    rows[k] &= worst[k] < np.percentile(worst[k], kw['v_quantile_threshold'])
+        if moments:
+            act = torch.as_tensor(np.flatnonzero(active), device=dev)
+            w = torch.as_tensor(rows[active], device=dev).to(torch.float64)       # (Ka,T)
+            n_rows = w.sum(dim=1)
+            xa = ys.index_select(0, act)
+            mean = torch.einsum('kt,kto->ko', w, xa) / n_rows[:, None]
+            xc = (xa - mean[:, None, :]) * w[:, :, None]
+            cov = (torch.einsum('kto,ktp->kop', xc, xc) / n_rows[:, None, None]).cpu().numpy()
+            n_host, mean_host = n_rows.cpu().numpy(), mean.cpu().numpy()
+            for i, k in enumerate(np.flatnonzero(active)):
+                if n_host[i] < 1:
+                    raise ValueError(f'Found array with 0 sample(s) (shape=(0, {O})) while a minimum of 1 is '
+                                     'required by FactorAnalysis.')
+                Wk, _, _ = factor_analysis_from_moments(cov[i], int(n_host[i]), n_latent)
+                W[k] = torch.as_tensor(np.ascontiguousarray(Wk), device=dev)
+                mu[k] = torch.as_tensor(mean_host[i], device=dev)
+        elif not fixed:
+            for k in np.flatnonzero(active):
+                fa = FactorAnalysis(n_components=n_latent).fit(x_host[k][rows[k]])
+                W[k] = torch.as_tensor(np.ascontiguousarray(fa.components_.T, dtype=np.float64), device=dev)
+                mu[k] = torch.as_tensor(np.ascontiguousarray(fa.mean_, dtype=np.float64), device=dev)
         n_inf, _ = hip_ops.maha_inflate(ys, v, W, mu, torch.as_tensor(active.astype(np.int32), device=dev),
                                         epsilon=eps, threshold=threshold, scalar=scalar)
         active &= n_inf.cpu().numpy() > 0

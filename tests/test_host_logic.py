@@ -254,3 +254,27 @@ def test_variance_inflation_pipeline_matches_oracle(golden_dir):
     raw = np.stack([mA_to_stacked_array(ma.slice_fields('var_x', 'var_y'), k) for k in range(2)])
     ratio = got / raw
     assert np.all(np.isclose(ratio, 1) | (ratio > 9.99)) and (ratio > 9.99).any()   # only x10^n inflations
+
+
+@pytest.mark.parametrize('p,k,n', [(4, 3, 20000), (6, 3, 4000), (12, 3, 3000), (4, 2, 500), (13, 3, 2000)])
+def test_factor_analysis_from_moments_is_sklearns_fit(p, k, n):
+    """stats.factor_analysis_from_moments (the variance-inflation driver's fit, from the fitted rows'
+    covariance alone) against sklearn.decomposition.FactorAnalysis(n_components).fit - what the
+    reference calls (eks/stats.py:114-117): same number of EM iterations, noise variances and
+    loadings (up to the sign of a column) to 1e-9, for every width p <= n_components + 10 where
+    sklearn's randomized SVD is exact."""
+    from sklearn.decomposition import FactorAnalysis
+
+    from eks_amd.stats import factor_analysis_from_moments
+    rng = np.random.default_rng(p * 100 + k)
+    Wt = rng.normal(size=(p, k)) * 3
+    X = rng.normal(size=(n, k)) @ Wt.T + rng.normal(size=(n, p)) * rng.uniform(0.3, 2, size=p) + rng.normal(size=p) * 10
+    fa = FactorAnalysis(n_components=k).fit(X)
+    Xc = X - X.mean(0)
+    W, psi, it = factor_analysis_from_moments(Xc.T @ Xc / n, n, k)
+    assert it == fa.n_iter_
+    np.testing.assert_allclose(psi, fa.noise_variance_, rtol=1e-9)
+    np.testing.assert_allclose(np.abs(W), np.abs(fa.components_.T), rtol=0, atol=1e-9 * np.abs(W).max())
+    # what the Mahalanobis step uses: the column space
+    P1, P2 = W @ np.linalg.pinv(W), fa.components_.T @ np.linalg.pinv(fa.components_.T)
+    assert np.abs(P1 - P2).max() < 1e-10
