@@ -382,7 +382,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     backend = os.environ.get('EKS_BENCH_BACKEND', 'nccl')       # nccl == RCCL over xGMI on ROCm
-    if world > 1:
+    # EKS_BENCH_FORCE_DIST=1: build the process group and run every collective of the multi-rank path
+    # with a world of one too (the 1-GPU box's way of exercising the RCCL branch: tests/test_gpu_distributed.py)
+    use_dist = world > 1 or os.environ.get('EKS_BENCH_FORCE_DIST') == '1'
+    if use_dist:
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:                                                    # test hook: ranks may share a GPU
@@ -396,7 +399,7 @@ def main():
         return bench_pupil(args, T, dev, lib)
     if args.workload == 'ekf':
         return bench_ekf(args, T, K, dev, lib)
-    strong = args.scaling == 'strong' and world > 1
+    strong = args.scaling == 'strong' and use_dist
     if strong:
         # ONE session (the same on every rank: seed 3), its keypoints dealt to the ranks in
         # contiguous blocks (keypoints are independent, reference eks/core.py:223-224, :293)
@@ -433,7 +436,7 @@ def main():
         else:
             s = s_fixed
         hip_ops.smooth(y, var, m0, S0, eye, eye, eye, s, flags=flags, out=(ms, Vs))
-        if world > 1:
+        if use_dist:
             # the gather of s_finals (K float64 per rank) is asynchronous: it runs on the collective
             # stream while this rank's next step is being enqueued, and is waited for before the
             # timed region closes
@@ -454,7 +457,7 @@ def main():
         while pending:
             pending.pop(0).wait()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -481,7 +484,7 @@ def main():
         sync()
         lib.eks_profile_enable(0)
         stages = {k: float(np.mean(v)) for k, v in drain_profile(lib).items()}
-    elif events_on and world > 1:
+    elif events_on and use_dist:
         for _ in range(5):          # keep the ranks' collectives matched
             step()
         sync()
@@ -496,7 +499,7 @@ def main():
             step(True)
         sync()
         dt_gather = time.perf_counter() - t1
-    if world > 1:
+    if use_dist:
         tt = [dt] + ([dt_gather] if dt_gather is not None else [])
         t = torch.tensor(tt, dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -611,7 +614,7 @@ def main():
             except Exception as e:
                 out['host_boundary'] = {'value': None, 'note': f'failed: {e!r}'}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

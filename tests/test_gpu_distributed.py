@@ -12,9 +12,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _torchrun(script_args, port, backend='gloo'):
-    env = dict(os.environ, EKS_BENCH_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+def _torchrun(script_args, port, backend='gloo', nproc=2, **extra_env):
+    env = dict(os.environ, EKS_BENCH_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0', **extra_env)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc),
            '--master-addr', '127.0.0.1', '--master-port', str(port)] + script_args
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
 
@@ -45,3 +45,20 @@ def test_bench_two_rank_code_path():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
     out = json.loads(line)
     assert out['n_gpus'] == 2 and out['steps'] == 3 and out['scaling'] == 'weak' and out['value'] > 0
+
+
+def test_rccl_branch_with_a_world_of_one():
+    """What a 1-GPU box can exercise of the RCCL path: a process group of ONE rank on backend nccl.  The
+    distributed drivers' tensor all-gathers (eks_amd.distributed.all_gather_ragged) and bench.py's
+    collectives (async all_gather of s_finals, all_gather_into_tensor of ms / Vs, MAX all_reduce of the
+    time, barriers) all run through RCCL on the device; results are checked as in the two-rank tests."""
+    r = _torchrun([os.path.join('tools', 'dist_smoke.py')], 29614, backend='nccl', nproc=1)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'rank 0: sessions [0, 1, 2, 3, 4] ok' in r.stdout and '(nccl)' in r.stdout
+    r = _torchrun(['bench.py', '--gpus', '1', '--steps', '3', '--warmup', '1', '--workload', 'c2',
+                   '--no-cpu-baseline', '--scaling', 'strong', '--gather-outputs'], 29615, backend='nccl',
+                  nproc=1, EKS_BENCH_FORCE_DIST='1')
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert out['n_gpus'] == 1 and out['scaling'] == 'strong' and out['value'] > 0
+    assert out['ms_per_step_with_output_gather'] >= out['ms_per_step'] * 0.5
