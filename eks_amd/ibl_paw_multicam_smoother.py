@@ -23,11 +23,38 @@ from .marker_array import MarkerArray, input_dfs_to_markerArray
 from .multicam_smoother import ensemble_kalman_smoother_multicam
 from .utils import convert_lp_dlc
 
-__all__ = ['fit_eks_multicam_ibl_paw']
+__all__ = ['fit_eks_multicam_ibl_paw', 'remove_camera_means', 'add_camera_means', 'pca']
 
 BODYPARTS = ['paw_l', 'paw_r']          # the only keypoints this smoother knows (reference :138)
 CAMERAS = ['left', 'right']
 _KEYS = ['paw_l_x', 'paw_l_y', 'paw_r_x', 'paw_r_y']
+
+
+def _shift_camera_columns(ensemble_stacks, camera_means, sign):
+    out = list(ensemble_stacks)
+    for stack in out:
+        for cam, mean in enumerate(camera_means):
+            stack[:, cam] = stack[:, cam] + sign * mean
+    return out
+
+
+def remove_camera_means(ensemble_stacks: list, camera_means) -> list:
+    """Subtract camera c's mean from column c of every keypoint's (T, n_columns) stack (reference
+    eks/ibl_paw_multicam_smoother.py:21-39).  As upstream, only the LIST is copied: the arrays are
+    shifted in place and the same arrays are returned."""
+    return _shift_camera_columns(ensemble_stacks, camera_means, -1.0)
+
+
+def add_camera_means(ensemble_stacks: list, camera_means) -> list:
+    """Inverse of remove_camera_means (reference :42-60), same in-place semantics."""
+    return _shift_camera_columns(ensemble_stacks, camera_means, 1.0)
+
+
+def pca(S: np.ndarray, n_comps: int) -> tuple:
+    """(fitted sklearn PCA with n_comps components, its explained-variance ratios) (reference :63-76)."""
+    from sklearn.decomposition import PCA
+    model = PCA(n_components=n_comps).fit(S)
+    return model, model.explained_variance_ratio_
 
 
 def fit_eks_multicam_ibl_paw(input_source: str, save_dir: str, smooth_param: float | list | None = None,
