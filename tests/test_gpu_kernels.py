@@ -426,6 +426,42 @@ def test_adam_step_matches_oracle_sequence():
     np.testing.assert_allclose(s_kp.cpu().numpy(), np.exp(np.clip(u_ref, -8, 8))[member_block], rtol=1e-12)
 
 
+@pytest.mark.parametrize('nb', [300, 5000])
+def test_adam_step_both_launch_forms_count_running_blocks(nb):
+    """eks_adam_step walks up to 4096 optimiser blocks with ONE workgroup that writes the number still
+    running itself, and uses a grid with an atomic counter beyond that: both against the oracle's
+    trajectory on singleton blocks with a quadratic loss, and n_active against the count of blocks that
+    have neither stopped nor reached the cap after every step."""
+    from eks_amd import hip_ops
+    rng = np.random.default_rng(nb)
+    centers = rng.uniform(-3, 3, nb)
+    u0 = rng.uniform(-6, 6, nb)
+    cap = 25
+
+    def lg(u):
+        return 50.0 + (u - centers) ** 2, 2.0 * (u - centers)
+
+    u_ref, last_ref, it_ref = orc.adam_optimize_s(lg, u0, tol=1e-3, safety_cap=cap)
+    offs = _dev(np.arange(nb + 1, dtype=np.int32))
+    mem = _dev(np.arange(nb, dtype=np.int32))
+    state = np.zeros((nb, 6))
+    state[:, 0] = u0
+    state[:, 3] = np.inf
+    state = _dev(state)
+    s_kp = torch.empty(nb, dtype=torch.float64, device='cuda')
+    n_act = torch.full((1,), -7, dtype=torch.int32, device='cuda')     # garbage: the launch must overwrite it
+    for it in range(cap + 3):
+        u_now = state[:, 0].cpu().numpy()
+        L, g = lg(np.clip(u_now, -8, 8))
+        hip_ops.adam_step(offs, mem, _dev(L), _dev(g), state, s_kp, n_act, 0.25, -8.0, 8.0, 1e-3, cap)
+        st = state.cpu().numpy()
+        assert int(n_act.item()) == int(((st[:, 5] == 0) & (st[:, 4] < cap)).sum())
+        if int(n_act.item()) == 0:
+            break
+    np.testing.assert_allclose(st[:, 0], u_ref, rtol=1e-12, atol=1e-12)
+    np.testing.assert_array_equal(st[:, 4].astype(int), it_ref)
+
+
 @pytest.mark.parametrize('M,avg,varm', [(5, 'median', 'confidence_weighted_var'), (4, 'mean', 'var'),
                                         (1, 'median', 'confidence_weighted_var'), (9, 'median', 'var'),
                                         (2, 'median', 'confidence_weighted_var')])
