@@ -139,6 +139,34 @@ def test_smooth_diag_matches_oracle(T, K, unit, vs_diag):
         Vd_o = np.diagonal(Vs_o, axis1=2, axis2=3)
         assert (np.abs(Vd - Vd_o) / Vd_o).max() < 1e-5
 
+@pytest.mark.parametrize('T,K', [(3000, 64), (700, 5)])
+def test_smooth_diag_into_buffers_at_odd_float_offsets(T, K):
+    """The C ABI takes plain pointers: inputs and outputs that are only 4-byte aligned (views starting
+    at an odd float of a larger allocation) must give bit-identical results to aligned ones - the 2x2
+    covariance rows leave as 8-byte stores, the rows are addressed through buffer resources."""
+    from eks_amd import hip_ops
+    arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=T + K, unit=True)
+    s = _dev(np.exp(np.random.default_rng(2).uniform(-4, 4, K)))
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    y, var = _dev(y_tk), _dev(var_tk)
+    ms0, Vs0 = hip_ops.smooth(y, var, *_params_dev(arrs), s, flags=flags)
+
+    def shifted(n, like=None):
+        buf = torch.zeros(n + 3, dtype=torch.float32, device='cuda')
+        v = buf[1:1 + n]
+        assert v.data_ptr() % 8 == 4
+        if like is not None:
+            v.copy_(like.reshape(-1))
+        return v
+
+    y1 = shifted(y.numel(), y).view(T, K, 2)
+    var1 = shifted(var.numel(), var).view(T, K, 2)
+    ms1 = shifted(ms0.numel()).view(T, K, 2)
+    Vs1 = shifted(Vs0.numel()).view(T, K, 2, 2)
+    hip_ops.smooth(y1, var1, *_params_dev(arrs), s, flags=flags, out=(ms1, Vs1))
+    assert torch.equal(ms1, ms0) and torch.equal(Vs1, Vs0)
+
+
 @pytest.mark.parametrize('sval', [np.exp(-8.0), 0.3, 2980.0])
 def test_smooth_diag_with_variances_at_the_clip(sval):
     """Ensemble variance 0 -> 1e-12 (eks/utils.py:373) on the scalar-chain path: whole frames,
