@@ -132,7 +132,10 @@ EKS_HD void riccati_fixed_point(double a, double c, double r, double sq, double&
 template <typename R, int NCL, bool UNIT>
 struct NllLane {
   ChainParams<R> pc[NCL];
-  R CinfR[NCL], gI[NCL], rgI[NCL], tI[NCL], cgI[NCL], logSinf[NCL];
+  R CinfR[NCL], gI[NCL], rgI[NCL], cgI[NCL], logSinf[NCL];
+  R rhoI[NCL];        // steady-state pole a r g = a (1 - c t) of the innovation recursion when a != 1
+                      // (with a = c = 1 it IS r g: pole() reads rgI and this array is never live)
+  EKS_HD R pole(int k) const { return UNIT ? rgI[k] : rhoI[k]; }
   Elem<R> e[NCL];
   R dl[NCL];          // innovation of the last consumed frame
   R rg_last[NCL];     // r g = 1 - c K of the last consumed frame
@@ -165,7 +168,7 @@ struct NllLane {
       float yp = y_last;
       if (phase[k] == 2) {
         // ---- regime 2: only the squared innovations advance
-        const R rho = UNIT ? rgI[k] : pc[k].a * rgI[k];
+        const R rho = pole(k);
         R s2 = R(0.f), d = dl[k];
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
@@ -179,7 +182,7 @@ struct NllLane {
         n_post[k] += NB;
       } else if (phase[k] == 1) {
         // ---- regime 1: C frozen; A still decays, eta / J still accumulate
-        const R rho = UNIT ? rgI[k] : pc[k].a * rgI[k];
+        const R rho = pole(k);
         R s2 = R(0.f), d = dl[k];
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
@@ -278,12 +281,24 @@ EKS_HD void nll_lane_init(NllLane<R, NCL, UNIT>& L, double r_d, double a_d, doub
     double Ci, dCi;
     riccati_fixed_point(UNIT ? 1.0 : a_d, UNIT ? 1.0 : c_d, r_d, sq_d[k], Ci, dCi);
     L.CinfR[k] = make_real(R(), (float)Ci, (float)dCi);
-    const R Sinf = UNIT ? (L.rR + L.CinfR[k]) : (L.rR + L.CinfR[k] * L.pc[k].c * L.pc[k].c);
-    L.gI[k] = rcp(Sinf);
-    L.rgI[k] = L.rR * L.gI[k];
-    L.cgI[k] = UNIT ? L.gI[k] : L.pc[k].c * L.gI[k];
-    L.tI[k] = L.CinfR[k] * L.cgI[k];
-    L.logSinf[k] = log_with_rcp(Sinf, L.gI[k]);
+    // The steady-state constants in float64 (values and d / d log s), each rounded ONCE.  Formed in
+    // float32 the pole rho = a (1 - c t) picked up 2-3 roundings at magnitude ~1, i.e. an absolute
+    // error of ~1e-7 against a distance 1 - rho of ~1e-2 for the slowest candidates (s near exp(-8),
+    // R of a few px^2): the filter then runs with a gain that is off by 1e-5 relative, and so is the
+    // NLL (fuzz seed 77: 1.1e-5 on a general diagonal model).  One rounding leaves the 3e-8 / (1 - rho)
+    // that a float32 pole cannot avoid.
+    {
+      const double a1 = UNIT ? 1.0 : a_d, c1 = UNIT ? 1.0 : c_d;
+      const double S_d = r_d + Ci * c1 * c1, dS_d = dCi * c1 * c1;
+      const double g_d = 1.0 / S_d, dg_d = -g_d * g_d * dS_d;
+      const double cg_d = c1 * g_d, dcg_d = c1 * dg_d;
+      const double t_d = Ci * cg_d, dt_d = dCi * cg_d + Ci * dcg_d;
+      L.gI[k] = make_real(R(), (float)g_d, (float)dg_d);
+      L.rgI[k] = make_real(R(), (float)(r_d * g_d), (float)(r_d * dg_d));
+      L.cgI[k] = make_real(R(), (float)cg_d, (float)dcg_d);
+      L.logSinf[k] = make_real(R(), (float)log(S_d), (float)(dS_d * g_d));
+      L.rhoI[k] = make_real(R(), (float)(a1 * (1.0 - c1 * t_d)), (float)(-a1 * c1 * dt_d));
+    }
     L.e[k] = elem_identity<R>();
     L.dl[k] = R(0.f);
     L.rg_last[k] = R(0.f);
@@ -370,7 +385,7 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
     float rho[NCL];
 #pragma unroll
     for (int k = 0; k < NCL; ++k) {
-      rho[k] = UNIT ? (1.f - L.tI[k]) : L.pc[k].a * (1.f - L.pc[k].c * L.tI[k]);
+      rho[k] = L.pole(k);
       const float nl = -logf(fmaxf(fabsf(rho[k]), 1e-30f));         // -ln |rho| > 0
       // rho^(2 t0) < 1e-20, and rho^t < kDeadA (ln 1e5 = 11.5) well inside the chunk's whole blocks
       ok = ok && fabsf(rho[k]) < 1.f && 2.f * (float)t0 * nl > 46.f &&
@@ -465,7 +480,7 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
     R rho[NCL], dk[NCL], s2[NCL];
 #pragma unroll
     for (int k = 0; k < NCL; ++k) {
-      rho[k] = UNIT ? (R(1.f) - L.tI[k]) : L.pc[k].a * (R(1.f) - L.pc[k].c * L.tI[k]);
+      rho[k] = L.pole(k);
       dk[k] = L.dl[k];
       s2[k] = R(0.f);
     }
