@@ -351,12 +351,16 @@ def test_nll_grid_staged_kernel_matches_c_oracle(T, K, unit):
     assert clear.mean() > 0.9
 
 @pytest.mark.parametrize('T,K,unit,var_scale', [(40000, 32, True, 1.0), (26001, 40, False, 1.0),
-                                                (40000, 32, True, 60.0), (9000, 70, True, 0.05)])
+                                                (40000, 32, True, 60.0), (9000, 70, True, 0.05),
+                                                (20011, 70, False, 9.0), (20011, 70, True, 44.0)])
 def test_nll_grid_converged_entry_chunks_match_c_oracle(T, K, unit, var_scale):
     """Long sequences: chunks after the first are summarised for an entering belief N(m, P_inf)
     (no start-up transient), the first chunk is short, rows are read through buffer resources.
     var_scale moves the candidates' closed-loop poles: large R makes the slow candidates fall back
-    to exact-entry summaries in the early chunks, small R makes every candidate fast."""
+    to exact-entry summaries in the early chunks, small R makes every candidate fast.  The last two
+    cases are the corner a fuzz sweep found (tools/fuzz_parity.py 40 77): poles within 1e-2 of one,
+    where a pole assembled in float32 cost 1.1e-5 / 8.9e-6 on the NLL (now formed in float64, rounded
+    once: bound 8e-6 there)."""
     from eks_amd import hip_ops
     from oracle import c_oracle
     arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=5 + T, unit=unit)
@@ -367,7 +371,7 @@ def test_nll_grid_converged_entry_chunks_match_c_oracle(T, K, unit, var_scale):
     nll = hip_ops.nll(_dev(y_tk), rconst, *_params_dev(arrs), _dev(cand), flags=flags).cpu().numpy()
     ref = c_oracle.nll_grid(arrs['ys'], rconst.cpu().numpy(), arrs['m0s'], arrs['S0s'], arrs['As'],
                             arrs['Cs'], arrs['Qs'], cand)
-    assert (np.abs(nll - ref) / np.abs(ref)).max() < 1e-5
+    assert (np.abs(nll - ref) / np.abs(ref)).max() < (8e-6 if T == 20011 else 1e-5)
     srt = np.sort(ref, axis=1)
     clear = (srt[:, 1] - srt[:, 0]) > 2e-5 * np.abs(srt[:, 0])
     np.testing.assert_array_equal(nll.argmin(axis=1)[clear], ref.argmin(axis=1)[clear])
