@@ -570,7 +570,10 @@ __global__ __launch_bounds__(64 * CH) void diag_scan_groups_kernel(int N, DiagMo
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-constexpr int kChunk = 32;  // frames per lane; 2*B VGPRs hold the chunk in K3
+#ifndef EKS_DIAG_CHUNK
+#define EKS_DIAG_CHUNK 32
+#endif
+constexpr int kChunk = EKS_DIAG_CHUNK;  // frames per lane; 2*B VGPRs hold the chunk in K3
 
 static inline size_t plane_bytes(int nc, int N) { return align_up((size_t)nc * N * sizeof(float), 256); }
 
