@@ -346,7 +346,7 @@ struct BufferStore {
 
 // K1f: chunk elements + the block's aggregate (time-ordered composition of its kFW elements by
 // the last wave to arrive, lanes = chains; rows past the end of the sequence are identities).
-template <int B, bool UNIT>
+template <int B, bool UNIT, bool RC>
 __global__ __launch_bounds__(64 * kFW) void diag_summarize_blk_kernel(BlockMap L, DiagModel M, DiagWs W,
                                                                      ScanWs S,
                                                                      const float* __restrict__ y,
@@ -376,12 +376,14 @@ __global__ __launch_bounds__(64 * kFW) void diag_summarize_blk_kernel(BlockMap L
       load_rows<B, false>(rows, len, yy, rr);
       e = summarize_loaded<B, UNIT, false>(yy, rr, len, p);
     }
-    const size_t o = (size_t)j * L.N + n;
-    W.eA[o] = e.A;
-    W.eb[o] = e.b;
-    W.eC[o] = e.C;
-    W.eEta[o] = e.eta;
-    W.eJ[o] = e.J;
+    if constexpr (!RC) {                   // RC: K3 summarises its chunks again, nothing to keep
+      const size_t o = (size_t)j * L.N + n;
+      W.eA[o] = e.A;
+      W.eb[o] = e.b;
+      W.eC[o] = e.C;
+      W.eEta[o] = e.eta;
+      W.eJ[o] = e.J;
+    }
   }
   sh[0][w][lane] = e.A;
   sh[1][w][lane] = e.b;
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(64 * kFW) void diag_summarize_blk_kernel(BlockMap L
 // compositions each, element rows shared by the block's waves through L2) before it streams its
 // own 64 rows of y, var (holding both sets of elements in registers beside the chunk cost 180 VGPRs
 // and two thirds of the occupancy).
-template <int B, bool UNIT, int VS_ROW>
+template <int B, bool UNIT, int VS_ROW, bool RC>
 __global__ __launch_bounds__(64 * kFW) void diag_replay_blk_kernel(BlockMap L, DiagModel M, DiagWs W,
                                                                   ScanWs S,
                                                                   const float* __restrict__ y,
@@ -428,44 +430,96 @@ __global__ __launch_bounds__(64 * kFW) void diag_replay_blk_kernel(BlockMap L, D
   int grp = blockIdx.x / L.ntile;
   if (L.reverse) grp = L.ngrp - 1 - grp;
   const int n = tile * 64 + lane, j = grp * kFW + w;
-  if (n >= L.N || j >= L.nc) return;
   const int j0 = grp * kFW, j1 = min(j0 + kFW, L.nc);
-  // everything the forward pass needs is requested at once: the chunk's own 64 rows, then the
-  // elements of the block's earlier chunks (wave-uniform predicate)
-  const ChainParams<float> p = load_chain_params(M, n);
-  const int t0 = j * B;
-  const int len = min(B, L.T - t0);
-  const bool full = len == B;              // wave-uniform: all chunks but a sequence's last
-  const size_t first = (size_t)t0 * L.N + (size_t)tile * 64;
-  const BufferRows rows{rows_rsrc(y + first), rows_rsrc(var + first), (unsigned)lane * 4, (unsigned)L.N * 4};
-  float v0[B], v1[B];
-  if (full) load_rows<B, true>(rows, B, v0, v1);
-  else load_rows<B, false>(rows, len, v0, v1);
-  Elem<float> ef[kFW - 1];
-#pragma unroll
-  for (int q = 0; q < kFW - 1; ++q)
-    if (j0 + q < j) ef[q] = load_elem(W, (size_t)(j0 + q) * L.N + n);
-  const size_t ob = (size_t)grp * L.N + n;
-  float m = S.bm[ob], P = S.bP[ob], eta = S.bEta[ob], J = S.bJ[ob];
-#pragma unroll
-  for (int q = 0; q < kFW - 1; ++q)
-    if (j0 + q < j) elem_apply(ef[q], m, P);
-  // the later chunks' elements arrive while the filter runs over the registers
-  Elem<float> eb[kFW - 1];
-#pragma unroll
-  for (int q = 0; q < kFW - 1; ++q)
-    if (j + 1 + q < j1) eb[q] = load_elem(W, (size_t)(j + 1 + q) * L.N + n);
-  if (full) filter_loaded<B, UNIT, true>(v0, v1, B, p, m, P);
-  else filter_loaded<B, UNIT, false>(v0, v1, len, p, m, P);
-#pragma unroll
-  for (int q = kFW - 2; q >= 0; --q)
-    if (j + 1 + q < j1) elem_back(eb[q], eta, J);
-  fuse_info(m, P, eta, J);
   constexpr int VW = VS_ROW == 0 ? 1 : VS_ROW;
-  const BufferStore<VS_ROW> st{rows_rsrc(ms + first), rows_rsrc(Vs + first * VW), (unsigned)lane * 4,
-                               (unsigned)L.N * 4, n % M.D};
-  if (full) smooth_rows<B, UNIT, true>(v0, v1, B, p, m, P, st);
-  else smooth_rows<B, UNIT, false>(v0, v1, len, p, m, P, st);
+  if constexpr (!RC) {
+    if (n >= L.N || j >= L.nc) return;
+    // everything the forward pass needs is requested at once: the chunk's own 64 rows, then the
+    // elements of the block's earlier chunks (wave-uniform predicate)
+    const ChainParams<float> p = load_chain_params(M, n);
+    const int t0 = j * B;
+    const int len = min(B, L.T - t0);
+    const bool full = len == B;            // wave-uniform: all chunks but a sequence's last
+    const size_t first = (size_t)t0 * L.N + (size_t)tile * 64;
+    const BufferRows rows{rows_rsrc(y + first), rows_rsrc(var + first), (unsigned)lane * 4, (unsigned)L.N * 4};
+    float v0[B], v1[B];
+    if (full) load_rows<B, true>(rows, B, v0, v1);
+    else load_rows<B, false>(rows, len, v0, v1);
+    Elem<float> ef[kFW - 1];
+#pragma unroll
+    for (int q = 0; q < kFW - 1; ++q)
+      if (j0 + q < j) ef[q] = load_elem(W, (size_t)(j0 + q) * L.N + n);
+    const size_t ob = (size_t)grp * L.N + n;
+    float m = S.bm[ob], P = S.bP[ob], eta = S.bEta[ob], J = S.bJ[ob];
+#pragma unroll
+    for (int q = 0; q < kFW - 1; ++q)
+      if (j0 + q < j) elem_apply(ef[q], m, P);
+    // the later chunks' elements arrive while the filter runs over the registers
+    Elem<float> eb[kFW - 1];
+#pragma unroll
+    for (int q = 0; q < kFW - 1; ++q)
+      if (j + 1 + q < j1) eb[q] = load_elem(W, (size_t)(j + 1 + q) * L.N + n);
+    if (full) filter_loaded<B, UNIT, true>(v0, v1, B, p, m, P);
+    else filter_loaded<B, UNIT, false>(v0, v1, len, p, m, P);
+#pragma unroll
+    for (int q = kFW - 2; q >= 0; --q)
+      if (j + 1 + q < j1) elem_back(eb[q], eta, J);
+    fuse_info(m, P, eta, J);
+    const BufferStore<VS_ROW> st{rows_rsrc(ms + first), rows_rsrc(Vs + first * VW), (unsigned)lane * 4,
+                                 (unsigned)L.N * 4, n % M.D};
+    if (full) smooth_rows<B, UNIT, true>(v0, v1, B, p, m, P, st);
+    else smooth_rows<B, UNIT, false>(v0, v1, len, p, m, P, st);
+  } else {
+    // K1 kept no chunk elements: every wave summarises its own chunk again from the rows it has just
+    // loaded (15 VALU instructions per frame) and the block's waves exchange the elements through
+    // LDS, read where they are used - no neighbour-element registers (124 VGPRs, 4 waves per SIMD).
+    __shared__ float sh[5][kFW][64];
+    const bool live = n < L.N && j < L.nc;   // every wave reaches the block's barrier
+    ChainParams<float> p{1.f, 1.f, 0.f};
+    const int t0 = j < L.nc ? j * B : 0;
+    const int len = j < L.nc ? min(B, L.T - t0) : 0;
+    const bool full = len == B;
+    const size_t first = (size_t)t0 * L.N + (size_t)tile * 64;
+    const BufferRows rows{rows_rsrc(y + first), rows_rsrc(var + first), (unsigned)lane * 4, (unsigned)L.N * 4};
+    float v0[B], v1[B];
+    Elem<float> own = elem_identity<float>();
+    if (live) {
+      p = load_chain_params(M, n);
+      if (full) {
+        load_rows<B, true>(rows, B, v0, v1);
+        own = summarize_loaded<B, UNIT, true>(v0, v1, B, p);
+      } else {
+        load_rows<B, false>(rows, len, v0, v1);
+        own = summarize_loaded<B, UNIT, false>(v0, v1, len, p);
+      }
+    }
+    sh[0][w][lane] = own.A; sh[1][w][lane] = own.b; sh[2][w][lane] = own.C; sh[3][w][lane] = own.eta;
+    sh[4][w][lane] = own.J;
+    __syncthreads();
+    if (!live) return;
+    auto lds_elem = [&](int q) {
+      return Elem<float>{sh[0][q][lane], sh[1][q][lane], sh[2][q][lane], sh[3][q][lane], sh[4][q][lane]};
+    };
+    const size_t ob = (size_t)grp * L.N + n;
+    float m = S.bm[ob], P = S.bP[ob], eta = S.bEta[ob], J = S.bJ[ob];
+#pragma unroll
+    for (int q = 0; q < kFW - 1; ++q)
+      if (q < w) elem_apply(lds_elem(q), m, P);
+    Elem<float> eb[kFW - 1];
+#pragma unroll
+    for (int q = 0; q < kFW - 1; ++q)
+      if (j + 1 + q < j1) eb[q] = lds_elem(w + 1 + q);
+    if (full) filter_loaded<B, UNIT, true>(v0, v1, B, p, m, P);
+    else filter_loaded<B, UNIT, false>(v0, v1, len, p, m, P);
+#pragma unroll
+    for (int q = kFW - 2; q >= 0; --q)
+      if (j + 1 + q < j1) elem_back(eb[q], eta, J);
+    fuse_info(m, P, eta, J);
+    const BufferStore<VS_ROW> st{rows_rsrc(ms + first), rows_rsrc(Vs + first * VW), (unsigned)lane * 4,
+                                 (unsigned)L.N * 4, n % M.D};
+    if (full) smooth_rows<B, UNIT, true>(v0, v1, B, p, m, P, st);
+    else smooth_rows<B, UNIT, false>(v0, v1, len, p, m, P, st);
+  }
 }
 
 // S2f: scan of the block aggregates, ngrp per chain (hundreds to thousands).  Block = CH chains x
@@ -659,12 +713,38 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
   if (fused) {
     BlockMap Bm{N, T, L.nc, L.ntile, S.nblk, k1_reverse};
     const dim3 bgrid((unsigned)((long)Bm.ntile * Bm.ngrp)), bblock(64 * kFW);
+    // Problems whose chunk elements do not stay on chip do not keep them between K1 and K3: K3
+    // summarises its chunks again (diag_replay_blk_kernel, RC).  Same box, alternating runs
+    // (EKS_REPLAY_RECOMPUTE = 0 / 1): C5's share (8192 chains x 1563 chunks, 256 MB of elements) K1
+    // 0.64 -> 0.56 ms, K3 1.37 -> 1.33 ms, step 2.06 -> 1.94 ms; C3 (512 chains, 32 MB) K1 83 -> 75 us,
+    // K3 168 -> 165 us, step 0.597 -> 0.591 ms; C2 (128 chains, 0.8 MB) K3 8.9 -> 13.3 us - one more
+    // dependent pass in a latency-bound launch.  Hence the threshold on the element bytes.
+    const char* rce = getenv("EKS_REPLAY_RECOMPUTE");
+    const bool rc = rce ? rce[0] == '1' : 5 * pb >= ((size_t)16 << 20);
+#define EKS_K1_BLK(UN)                                                                                  \
+  do {                                                                                                  \
+    if (rc)                                                                                             \
+      hipLaunchKernelGGL((diag_summarize_blk_kernel<kChunk, UN, true>), bgrid, bblock, 0, st, Bm, M, W, \
+                         S, y, var);                                                                    \
+    else                                                                                                \
+      hipLaunchKernelGGL((diag_summarize_blk_kernel<kChunk, UN, false>), bgrid, bblock, 0, st, Bm, M,   \
+                         W, S, y, var);                                                                 \
+  } while (0)
+#define EKS_K3_BLK(UN, R)                                                                               \
+  do {                                                                                                  \
+    if (rc)                                                                                             \
+      hipLaunchKernelGGL((diag_replay_blk_kernel<kChunk, UN, R, true>), bgrid, bblock, 0, st, Bm, M, W, \
+                         S, y, var, ms, Vs);                                                            \
+    else                                                                                                \
+      hipLaunchKernelGGL((diag_replay_blk_kernel<kChunk, UN, R, false>), bgrid, bblock, 0, st, Bm, M,   \
+                         W, S, y, var, ms, Vs);                                                         \
+  } while (0)
     {
       ProfScope ps("diag_summarize", st);
       if (unit)
-        hipLaunchKernelGGL((diag_summarize_blk_kernel<kChunk, true>), bgrid, bblock, 0, st, Bm, M, W, S, y, var);
+        EKS_K1_BLK(true);
       else
-        hipLaunchKernelGGL((diag_summarize_blk_kernel<kChunk, false>), bgrid, bblock, 0, st, Bm, M, W, S, y, var);
+        EKS_K1_BLK(false);
     }
     {
       ProfScope ps("diag_scan", st);
@@ -691,11 +771,9 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
 #define EKS_REPLAY_BLK(R)                                                                              \
   case R:                                                                                              \
     if (unit)                                                                                          \
-      hipLaunchKernelGGL((diag_replay_blk_kernel<kChunk, true, R>), bgrid, bblock, 0, st, Bm, M, W, S, \
-                         y, var, ms, Vs);                                                              \
+      EKS_K3_BLK(true, R);                                                                             \
     else                                                                                               \
-      hipLaunchKernelGGL((diag_replay_blk_kernel<kChunk, false, R>), bgrid, bblock, 0, st, Bm, M, W, S, \
-                         y, var, ms, Vs);                                                              \
+      EKS_K3_BLK(false, R);                                                                            \
     break;
     switch (vs_row) {
       EKS_REPLAY_BLK(0)
@@ -709,6 +787,8 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
       EKS_REPLAY_BLK(8)
     }
 #undef EKS_REPLAY_BLK
+#undef EKS_K3_BLK
+#undef EKS_K1_BLK
     return hip_status(hipGetLastError());
   }
 

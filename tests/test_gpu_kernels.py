@@ -91,16 +91,23 @@ def test_smooth_diag_fused_and_three_kernel_scan_match_oracle(monkeypatch, T, K,
                                     np.clip(np.transpose(var, (1, 0, 2)).astype(np.float64), 1e-12, None),
                                     m0, S0, eye, eye, eye, s)
     Vd_o = np.diagonal(Vs_o, axis1=2, axis2=3)
-    for unfused in ('0', '1'):
+    kept = {}
+    for unfused, recompute in (('0', '0'), ('0', '1'), ('1', '0')):
         monkeypatch.setenv('EKS_SMOOTH_UNFUSED', unfused)
-        ms, Vs = hip_ops.smooth(_dev(y), _dev(var), _dev(m0), _dev(S0), _dev(eye), _dev(eye), _dev(eye), _dev(s),
-                                flags=flags, vs_diag=vs_diag)
-        ms, Vs = ms.cpu().numpy().astype(np.float64), Vs.cpu().numpy().astype(np.float64)
+        # fused form: chunk elements kept between summarize and replay, or summarised again in replay
+        # (what wide problems run) - the same arithmetic, so bit-identical outputs
+        monkeypatch.setenv('EKS_REPLAY_RECOMPUTE', recompute)
+        ms_d, Vs_d = hip_ops.smooth(_dev(y), _dev(var), _dev(m0), _dev(S0), _dev(eye), _dev(eye), _dev(eye),
+                                    _dev(s), flags=flags, vs_diag=vs_diag)
+        if unfused == '0':
+            kept[recompute] = (ms_d.clone(), Vs_d.clone())
+        ms, Vs = ms_d.cpu().numpy().astype(np.float64), Vs_d.cpu().numpy().astype(np.float64)
         ms_k = np.transpose(ms, (1, 0, 2))
         assert _rel(ms_k - 300.0, ms_o - 300.0, axis_scale=(1, 2)) < 1e-5
         Vd = np.transpose(Vs, (1, 0, 2)) if vs_diag else \
             np.diagonal(np.transpose(Vs, (1, 0, 2, 3)), axis1=2, axis2=3)
         assert (np.abs(Vd - Vd_o) / Vd_o).max() < 1e-5
+    assert torch.equal(kept['0'][0], kept['1'][0]) and torch.equal(kept['0'][1], kept['1'][1])
 
 
 @pytest.mark.parametrize('T,K,unit,vs_diag', [
