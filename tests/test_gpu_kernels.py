@@ -118,8 +118,11 @@ def test_smooth_diag_fused_and_three_kernel_scan_match_oracle(monkeypatch, T, K,
     (1, 2, True, False),         # single frame
     (700, 200, False, True),     # several chain tiles
 ])
-def test_smooth_diag_matches_oracle(T, K, unit, vs_diag):
+@pytest.mark.parametrize('recompute', ['0', '1'])
+def test_smooth_diag_matches_oracle(T, K, unit, vs_diag, recompute, monkeypatch):
     from eks_amd import hip_ops
+    # fused form (>= 64 chains): chunk elements kept between the two kernels or summarised again
+    monkeypatch.setenv('EKS_REPLAY_RECOMPUTE', recompute)
     arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=T + K, unit=unit)
     rng = np.random.default_rng(1)
     if T == 1:      # nanvar over one frame is 0: give the prior a real variance
