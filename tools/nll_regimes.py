@@ -20,7 +20,8 @@ def drain():
     for nm, t in zip(names, list(ms)[:n]): out.setdefault(nm.decode(), []).append(float(t))
     return {k: float(np.mean(v)) for k, v in out.items()}
 for name, lo, hi in (('real grid -8..8', -8, 8), ('fast 2..8', 2, 8), ('mid -2..2', -2, 2), ('slow -8..-6', -8, -6),
-                     ('slowest -8', -8, -8), ('-4', -4, -4), ('0', 0, 0)):
+                     ('slowest -8', -8, -8), ('-4', -4, -4), ('0', 0, 0), ('2', 2, 2), ('4', 4, 4), ('6', 6, 6), ('8', 8, 8),
+                     ('-1..1', -1, 1), ('3..5', 3, 5), ('-6..-4', -6, -4), ('-8..0', -8, 0), ('0..8', 0, 8)):
     cand = torch.exp(torch.linspace(lo, hi, 64, dtype=torch.float64, device=dev))
     for _ in range(3): hip_ops.nll(y, rc, m0, S0, eye, eye, eye, cand, flags=flags)
     torch.cuda.synchronize(); drain(); lib.eks_profile_enable(1)
