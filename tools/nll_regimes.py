@@ -28,3 +28,20 @@ for name, lo, hi in (('real grid -8..8', -8, 8), ('fast 2..8', 2, 8), ('mid -2..
     for _ in range(10): hip_ops.nll(y, rc, m0, S0, eye, eye, eye, cand, flags=flags)
     torch.cuda.synchronize(); lib.eks_profile_enable(0)
     print(name, drain(), flush=True)
+
+# Is the in-step slowdown memory residency (y served from the 256 MB Infinity Cache when the kernel runs back to back)
+# or clock state?  The same launches with a 1 GB streaming kernel between them (evicts y), and with a compute-only
+# kernel between them.
+cand = torch.exp(torch.linspace(-8, 8, 64, dtype=torch.float64, device=dev))
+big = torch.zeros(256 * 1024 * 1024, dtype=torch.float32, device=dev)
+small = torch.randn(1 << 20, dtype=torch.float32, device=dev)
+for name, between in (('back to back', lambda: None), ('1 GB stream between', lambda: big.add_(1.0)),
+                      ('compute-only between', lambda: [small.mul_(1.0001) for _ in range(20)]),
+                      ('back to back again', lambda: None)):
+    for _ in range(3):
+        hip_ops.nll(y, rc, m0, S0, eye, eye, eye, cand, flags=flags); between()
+    torch.cuda.synchronize(); drain(); lib.eks_profile_enable(1)
+    for _ in range(10):
+        hip_ops.nll(y, rc, m0, S0, eye, eye, eye, cand, flags=flags); between()
+    torch.cuda.synchronize(); lib.eks_profile_enable(0)
+    print(name, drain(), flush=True)
