@@ -4,6 +4,7 @@
 // of y [T][N] (the 8 waves stand for the 8 candidate groups), 2 waves per SIMD, one block per CU.
 //   regs8  : each wave loads its own rows, 8 in flight while 8 are consumed (what ships)
 //   regs16 : the same with three 8-row buffers (rows requested 16 ahead)
+//   dma    : every wave keeps its own LDS ring filled by direct-to-LDS loads, RING - 8 rows ahead, no barrier
 //   ring   : the block's waves share an LDS ring of 2 x HALF rows: wave w requests the rows r = w (mod 8) of the next
 //            half before consuming the current one from LDS, stores them when they arrive, one barrier per half
 // Each variant is timed back to back (y stays in the 256 MB Infinity Cache) and with a 1 GB streaming kernel between
@@ -108,6 +109,38 @@ __global__ __launch_bounds__(512) void ring(const float* __restrict__ y, int N, 
   out[(size_t)blockIdx.x * 512 + threadIdx.x] = S.total();
 }
 
+// per-wave ring filled by direct-to-LDS loads (buffer_load_dword ... lds: no registers, no barrier): the rows are
+// requested RING - 8 frames ahead; the wave waits with vmcnt(RING - 8) for the block it is about to read
+template <int RING>
+__global__ __launch_bounds__(512) void dma(const float* __restrict__ y, int N, int ntile, int len, float* out) {
+  __shared__ float lds[8][RING][64];
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int tile = blockIdx.x % ntile, chunk = blockIdx.x / ntile;
+  const __amdgpu_buffer_rsrc_t r = rsrc(y + (size_t)chunk * len * N + (size_t)tile * 64);
+  const unsigned voff = lane * 4, rb = N * 4;
+  State S; S.init(w, lane);
+  const int nb = len / 8;
+  auto issue = [&](int blk) {              // rows of block blk -> their ring slots
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = blk * 8 + q;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, &lds[w][i % RING][0], 4, voff, (unsigned)i * rb, 0, 0);
+    }
+  };
+  constexpr int AHEAD = RING / 8 - 1;       // blocks in flight beyond the one being read
+  for (int b = 0; b < AHEAD && b < nb; ++b) issue(b);
+  for (int blk = 0; blk < nb; ++blk) {
+    if (blk + AHEAD < nb) issue(blk + AHEAD);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | ((AHEAD * 8) & 0xF) | ((((AHEAD * 8) >> 4) & 0x3) << 14));   // vmcnt(AHEAD * 8)
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = lds[w][(blk * 8 + q) % RING][lane];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) S.eat(v[q]);
+  }
+  out[(size_t)blockIdx.x * 512 + threadIdx.x] = S.total();
+}
+
 __global__ void stream(float* p, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] += 1.f;
 }
@@ -152,6 +185,8 @@ int main(int argc, char** argv) {
   timed("ring32", [&] { hipLaunchKernelGGL(ring<32>, grid, blk, 0, 0, y, N, ntile, len, out); }, big, nbig);
   timed("ring64", [&] { hipLaunchKernelGGL(ring<64>, grid, blk, 0, 0, y, N, ntile, len, out); }, big, nbig);
   timed("ring128", [&] { hipLaunchKernelGGL(ring<128>, grid, blk, 0, 0, y, N, ntile, len, out); }, big, nbig);
+  timed("dma32", [&] { hipLaunchKernelGGL(dma<32>, grid, blk, 0, 0, y, N, ntile, len, out); }, big, nbig);
+  timed("dma64", [&] { hipLaunchKernelGGL(dma<64>, grid, blk, 0, 0, y, N, ntile, len, out); }, big, nbig);
   (void)hipDeviceSynchronize();
   return 0;
 }
