@@ -68,10 +68,51 @@ def parse():
                         "(configs[2] at K / N keypoints per GPU)")
     p.add_argument('--gather-outputs', action='store_true',
                    help='strong scaling: also time a second loop that all-gathers ms / Vs to every rank')
+    p.add_argument('--regions', type=int, default=5,
+                   help='how many back-to-back timed regions of --steps steps each; ms_per_step / value are the '
+                        'MEDIAN region (max over ranks per region), min / max are reported beside it')
+    p.add_argument('--master-port', type=int, default=0,
+                   help='self-launch (N > 1 without an outer torchrun): rendezvous port, 0 = pick a free one')
     return p.parse_args()
 
 
-TRAFFIC_FILES = ('r02_traffic.json', 'r01_traffic.json')
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no outer torchrun: start
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a
+    CHILD process (never an exec: a process that has touched the GPU must not be replaced, and this one
+    has not even imported torch), pass rank 0's JSON line through on stdout and return the child's exit
+    code.  Keypoints and sessions are independent (reference eks/core.py:223-224, :293), so the ranks
+    only meet in the barriers and the terminal gather of s_finals."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if not port:
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in child.stdout:                    # stream: the JSON line appears as soon as rank 0 prints it
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
+
+
+TRAFFIC_FILES = ('r03_traffic.json',)
+# the sources whose kernels the traffic summary describes: a summary taken before any of them changed
+# is STALE and is not reported (tests/test_abi_surface.py fails on a stale committed summary)
+TRAFFIC_SOURCES = ('eks_diag.hip', 'eks_diag_lane.hpp', 'eks_math.hpp')
+
+
+def kernel_sources_sha16():
+    import hashlib
+    h = hashlib.sha256()
+    for name in TRAFFIC_SOURCES:
+        with open(os.path.join(ROOT, 'eks_amd', 'csrc', name), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def measured_traffic(kernel):
@@ -83,11 +124,17 @@ def measured_traffic(kernel):
     for name in TRAFFIC_FILES:
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
-                v = json.load(f)['hbm_bytes_per_launch'].get(kernel)
-            if v is not None:
-                return v, f'profiles/{name}'
+                doc = json.load(f)
         except Exception:
             continue
+        if doc.get('kernel_sources_sha16') != kernel_sources_sha16():
+            print(f'bench.py: profiles/{name} was measured on other kernel sources '
+                  f'({doc.get("kernel_sources_sha16")} != {kernel_sources_sha16()}): roofline.traffic = null; '
+                  'rerun tools/collect_evidence.sh + tools/make_profiles.py', file=sys.stderr, flush=True)
+            return None, f'profiles/{name} is STALE (kernel sources changed since it was measured)'
+        v = doc['hbm_bytes_per_launch'].get(kernel)
+        if v is not None:
+            return v, f'profiles/{name}'
     return None, None
 
 
@@ -368,14 +415,19 @@ def bench_ekf(args, T, K, dev, lib, V=4):
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args))      # before torch is imported: the parent never touches a GPU
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch multi-GPU runs with torch.distributed.run (one rank per GPU)')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU')
+    if (world > torch.cuda.device_count() and os.environ.get('EKS_BENCH_BACKEND', 'nccl') == 'nccl'):
+        raise SystemExit(f'--gpus {world} but only {torch.cuda.device_count()} device(s) visible: RCCL needs one GPU '
+                         'per rank (EKS_BENCH_BACKEND=gloo lets ranks share a GPU: a code-path test, not a '
+                         'measurement)')
     from eks_amd import _lib, hip_ops, synth
     hip_ops.require_gpu()
     local_rank = local_rank % max(1, torch.cuda.device_count())
@@ -469,11 +521,16 @@ def main():
     # inside the timed region only the roofline kernel (diag_replay) is bracketed by HIP events:
     # two event records per step; the stage breakdown comes from a short untimed pass afterwards
     lib.eks_profile_enable(2 if events_on else 0)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        s_last = step()
-    sync()
-    dt = time.perf_counter() - t0
+    # `--regions` back-to-back timed regions of exactly `--steps` steps, each closed by the barrier +
+    # synchronize of sync(); the headline is the MEDIAN region (box-to-box and run-to-run spread of a
+    # 12 ms region is larger than most kernel changes), min / max beside it
+    region_dt = []
+    for _ in range(max(1, args.regions)):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            s_last = step()
+        sync()
+        region_dt.append(time.perf_counter() - t0)
     lib.eks_profile_enable(0)
     prof = drain_profile(lib) if events_on else {}
     stages = {}
@@ -499,13 +556,14 @@ def main():
             step(True)
         sync()
         dt_gather = time.perf_counter() - t1
-    if use_dist:
-        tt = [dt] + ([dt_gather] if dt_gather is not None else [])
+    if use_dist:                                                  # every region: MAX over the ranks
+        tt = region_dt + ([dt_gather] if dt_gather is not None else [])
         t = torch.tensor(tt, dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0].item())
+        region_dt = [float(v) for v in t[:len(region_dt)].tolist()]
         if dt_gather is not None:
-            dt_gather = float(t[1].item())
+            dt_gather = float(t[-1].item())
+    dt = float(np.median(region_dt))
 
     units_per_step = T * K_total if strong else T * K * world      # all ranks together
     value = args.steps * units_per_step / dt
@@ -521,6 +579,9 @@ def main():
         'value': value, 'unit': 'frames*keypoints/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
         'scaling': 'strong' if strong else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'regions': len(region_dt), 'ms_per_step_min': 1e3 * min(region_dt) / args.steps,
+        'ms_per_step_max': 1e3 * max(region_dt) / args.steps,
+        'timing': f'median of {len(region_dt)} back-to-back regions of {args.steps} steps (max over ranks per region)',
         'config': {'workload': shape + ', '
                                + (f'{n_cand}-candidate NLL grid + ' if n_cand else 'fixed s=10, ')
                                + 'filter+RTS smooth, full ms/Vs outputs; '

@@ -58,6 +58,7 @@ SIGNATURES = {
                          + [c_double, c_double, c_double, c_void_p, c_void_p, c_void_p]),
     'eks_multicam_tables': (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32] + [c_void_p] * 9),
     'eks_profile_enable': (ctypes.c_int, [ctypes.c_int]),
+    'eks_knobs_reload': (ctypes.c_int, []),
     'eks_profile_drain': (ctypes.c_int, [c_void_p, c_size_t, c_void_p, c_int32]),
     'eks_ensemble': (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32,
                                     c_float, c_void_p, c_void_p]),

@@ -42,14 +42,20 @@ def _release_pinned(nbytes: int) -> None:
     _pinned_live[0] -= nbytes
 
 
+def _pinned_empty(shape, dtype):
+    return _torch().empty(shape, dtype=dtype, pin_memory=True)
+
+
 def _to_host(*tensors, pinned: bool | None = None):
     """Device tensors -> NumPy.  Fast path: page-locked staging buffers (torch's caching host
     allocator keeps them across calls), so the D2H copies run at the link rate and overlap each
-    other; the arrays alias the staging tensors, which stay alive as their `.base`.  Page-locked
-    memory is unswappable, so the bytes of such results that callers still hold are counted
-    (weakref finalisers) and capped at EKS_PINNED_CAP_BYTES (1 GiB): beyond the cap - a loop that
-    keeps every session's output, `distributed.smooth_sessions` - or with pinned=False results come
-    back in ordinary pageable arrays."""
+    other; the arrays alias the staging storage.  Page-locked memory is unswappable, so the bytes of
+    such results that callers still hold are counted and capped at EKS_PINNED_CAP_BYTES (1 GiB):
+    beyond the cap - a loop that keeps every session's output, `distributed.smooth_sessions` - or
+    with pinned=False results come back in ordinary pageable arrays.  The count is released by a
+    finaliser on the array's `.base` - the tensor object NumPy itself keeps alive for as long as the
+    array or any view of it exists (`tensor.numpy().base` is a fresh tensor object, not the staging
+    tensor, so a finaliser on the latter would fire as soon as this function returned)."""
     import weakref
     torch = _torch()
     nbytes = sum(t.numel() * t.element_size() for t in tensors)
@@ -58,16 +64,22 @@ def _to_host(*tensors, pinned: bool | None = None):
     if not pinned or nbytes > (2 << 30) or _pinned_live[0] + nbytes > _PINNED_CAP_BYTES:
         return tuple(t.cpu().numpy() for t in tensors)
     try:
-        host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]
+        host = [_pinned_empty(t.shape, t.dtype) for t in tensors]
     except RuntimeError:            # page-locked memory exhausted or unavailable: plain copies
         return tuple(t.cpu().numpy() for t in tensors)
     for h, t in zip(host, tensors):
         h.copy_(t, non_blocking=True)
+    if torch.cuda.is_available():
+        torch.cuda.current_stream().synchronize()
+    out = []
+    for h in host:
+        arr = h.numpy()
         n = h.numel() * h.element_size()
+        owner = arr.base if arr.base is not None else h
         _pinned_live[0] += n
-        weakref.finalize(h, _release_pinned, n)
-    torch.cuda.current_stream().synchronize()
-    return tuple(h.numpy() for h in host)
+        weakref.finalize(owner, _release_pinned, n)
+        out.append(arr)
+    return tuple(out)
 
 
 def _to_numpy(a, dtype=None) -> np.ndarray:

@@ -250,12 +250,8 @@ constexpr int kDenseSmoothChunk = 32;   // frames per lane in the smoother (the 
 // (its sweeps converge chunk-wise: 16-frame chunks are shorter than the filter's memory and need
 // 8+ sweeps where 32-frame chunks need 3).  EKS_DENSE_CHUNK overrides (measurement knob).
 static int dense_chunk(int T, int K, bool ekf = false) {
-  static const int forced = [] {
-    const char* e = getenv("EKS_DENSE_CHUNK");
-    const int v = e ? atoi(e) : 0;
-    return v >= 2 && v <= 256 ? v : 0;
-  }();
-  if (forced) return forced;
+  const int forced = knob_int(KNOB_DENSE_CHUNK, 0);
+  if (forced >= 2 && forced <= 256) return forced;
   if (ekf) return kDenseSmoothChunk;
   return (long long)K * ((T + 15) / 16) <= (1 << 18) ? 16 : kDenseSmoothChunk;
 }

@@ -15,10 +15,11 @@
 //                       REGISTERS, fuses the outgoing belief with the future information and runs
 //                       RTS backwards over the registers, streaming ms / Vs out.
 //
-// For N > 32 chains the scan is folded into its neighbours (round 2): a block of K1 / K3 is 8
-// consecutive chunks of one 64-chain tile, K1's block composes its 8 elements into the block
-// aggregate (LDS, one barrier), one small launch scans the aggregates per chain, and every K3 wave
-// composes the <= 7 elements before / after its own chunk inside the block itself - 3 launches
+// For N > 32 chains the scan is folded into its neighbours (round 2): a block of K1 / K3 is
+// kFW (= 4) consecutive chunks of one 64-chain tile, K1's block composes its kFW elements into the
+// block aggregate (LDS ticket: the last wave to arrive), one small launch scans the aggregates per
+// chain, and every K3 wave composes the <= kFW - 1 elements before / after its own chunk inside the
+// block itself - 3 launches
 // instead of 5, the per-chunk scan results (25.6 MB written + read on the C3 shape) and the second
 // read of the elements never exist.
 //
@@ -290,6 +291,8 @@ __global__ __launch_bounds__(kScanCH* kScanCB) void diag_scan_local_kernel(int N
 // Fused form for N > 32 (64-chain tiles): block = kFW waves = kFW consecutive chunks of one tile.
 // ------------------------------------------------------------------------------------------
 constexpr int kFW = 4;
+static_assert(kFW == 4, "the fused kernels' LDS exchange, the group scan's slot sizes and the measured "
+                        "thresholds in diag_smooth() assume four chunks per block");
 
 struct BlockMap {
   int N, T, nc;
@@ -691,11 +694,11 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
   // the plain ones - barrier, neighbour compositions - which eats most of what the scan saves).
   // Not for sequences whose group scan would leave its registers (more than 16 aggregates per
   // slot, T > 131 072: 400 000 x 64 0.345 -> 0.391 ms).
-  const char* legacy = getenv("EKS_SMOOTH_UNFUSED");
   const int ngrp_f = (L.nc + kFW - 1) / kFW;
-  // (the fused kernels address a chunk's rows with 32-bit buffer offsets: 32 rows of N x D floats)
-  const bool in_range = (size_t)32 * N * (vs_diag ? 1 : D) * sizeof(float) < ((size_t)1 << 31);
-  const bool fused = L.nt_log2 == 6 && in_range && (legacy ? legacy[0] == '0' : ngrp_f <= 1024);
+  // (the fused kernels address a chunk's rows with 32-bit buffer offsets: kChunk rows of N x D floats)
+  const bool in_range = (size_t)kChunk * N * (vs_diag ? 1 : D) * sizeof(float) < ((size_t)1 << 31);
+  const bool fused = L.nt_log2 == 6 && in_range &&
+                     (knob_set(KNOB_SMOOTH_UNFUSED) ? knob_int(KNOB_SMOOTH_UNFUSED, 0) == 0 : ngrp_f <= 1024);
   ScanWs S;
   S.nblk = fused ? (L.nc + kFW - 1) / kFW : (L.nc + kScanCB - 1) / kScanCB;
   const size_t sb = plane_bytes(S.nblk, N);
@@ -706,10 +709,8 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
   // K1 and K3 walk the chunks in opposite directions: the tail of one stream of y, var is the
   // head of the next and can be served from the 256 MiB Infinity Cache.  EKS_SUMMARIZE_REVERSE
   // picks which of the two runs backwards (A/B knob).
-  const char* k1r = getenv("EKS_SUMMARIZE_REVERSE");
-  const int k1_reverse = (k1r && k1r[0] == '1') ? 1 : 0;
-  const char* fwd = getenv("EKS_REPLAY_FORWARD");
-  const int k3_reverse = (fwd && fwd[0] == '1') ? 0 : (fwd && fwd[0] == '0') ? 1 : !k1_reverse;
+  const int k1_reverse = knob_int(KNOB_SUMMARIZE_REVERSE, 0) == 1 ? 1 : 0;
+  const int k3_reverse = knob_set(KNOB_REPLAY_FORWARD) ? (knob_int(KNOB_REPLAY_FORWARD, 0) == 1 ? 0 : 1) : !k1_reverse;
   if (fused) {
     BlockMap Bm{N, T, L.nc, L.ntile, S.nblk, k1_reverse};
     const dim3 bgrid((unsigned)((long)Bm.ntile * Bm.ngrp)), bblock(64 * kFW);
@@ -719,8 +720,8 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
     // 0.64 -> 0.56 ms, K3 1.37 -> 1.33 ms, step 2.06 -> 1.94 ms; C3 (512 chains, 32 MB) K1 83 -> 75 us,
     // K3 168 -> 165 us, step 0.597 -> 0.591 ms; C2 (128 chains, 0.8 MB) K3 8.9 -> 13.3 us - one more
     // dependent pass in a latency-bound launch.  Hence the threshold on the element bytes.
-    const char* rce = getenv("EKS_REPLAY_RECOMPUTE");
-    const bool rc = rce ? rce[0] == '1' : 5 * pb >= ((size_t)16 << 20);
+    const bool rc = knob_set(KNOB_REPLAY_RECOMPUTE) ? knob_int(KNOB_REPLAY_RECOMPUTE, 0) == 1
+                                                    : 5 * pb >= ((size_t)16 << 20);
 #define EKS_K1_BLK(UN)                                                                                  \
   do {                                                                                                  \
     if (rc)                                                                                             \
@@ -751,8 +752,7 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
       // a slot's aggregates stay in registers when there are at most 16 of them (T <= 131 072)
       // 4 chains per block for narrow problems (more blocks: 10 000 x 64 keypoints 7.1 vs 9.4 us),
       // 16 for wide ones (whole 64-byte segments: 50 000 x 4096 keypoints 119 -> 46 us)
-      const char* ch_env = getenv("EKS_SCAN_CH");
-      const bool ch4 = ch_env ? ch_env[0] == '4' : N < 2048;
+      const bool ch4 = knob_set(KNOB_SCAN_CH) ? knob_int(KNOB_SCAN_CH, 4) == 4 : N < 2048;
       const bool per8 = (S.nblk + 63) / 64 <= 8;
       if (ch4) {
         if (per8)

@@ -423,11 +423,6 @@ __global__ __launch_bounds__(64 * kAsmWaves) void diag_nll_assemble_par_kernel(N
   nll[(size_t)k * G.n_cand + ci] = isfinite(v) ? v : 1e12;                // eks/core.py:650
 }
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-
 static NllGeom make_geom(int T, int N, int D, int n_cand, int per_keypoint, bool grad, int ncl) {
   NllGeom G;
   G.N = N;
@@ -447,7 +442,7 @@ static NllGeom make_geom(int T, int N, int D, int n_cand, int per_keypoint, bool
     bn = (bn + 64 - 1) / 64 * 64;
     if (bn < kNllChunkMin) bn = kNllChunkMin;   // short chunks cost accuracy (one float32 element
                                                 // per chunk) and transient work
-    G.BN = env_int("EKS_NLL_CHUNK", bn);
+    G.BN = knob_int(KNOB_NLL_CHUNK, bn);
     if (G.BN < kNllChunkGrad) G.BN = kNllChunkGrad;
     G.B0 = G.BN;
     // Chunk 0 is the only one that always pays the start-up transient (its element starts from a
@@ -455,8 +450,8 @@ static NllGeom make_geom(int T, int N, int D, int n_cand, int per_keypoint, bool
     // kept shorter than the others - its block must not be the one every other block waits for -
     // and the other chunks share the remaining frames so that the block count is unchanged.
     const long nch = (T + G.BN - 1) / G.BN;
-    const int b0 = env_int("EKS_NLL_CHUNK0", kNllChunk0);
-    if (nch >= 3 && b0 < G.BN && !getenv("EKS_NLL_CHUNK")) {
+    const int b0 = knob_int(KNOB_NLL_CHUNK0, kNllChunk0);
+    if (nch >= 3 && b0 < G.BN && !knob_set(KNOB_NLL_CHUNK)) {
       G.B0 = b0;
       G.BN = (int)((T - b0 + nch - 2) / (nch - 1));
       G.BN = (G.BN + 63) / 64 * 64;
@@ -478,7 +473,7 @@ static NllGeom make_geom(int T, int N, int D, int n_cand, int per_keypoint, bool
 // frames per lane.  Defaults are what bench.py measured best on MI355X.
 static inline int pick_ncl(int n_cand, bool grad) {
   if (grad || n_cand < 2) return 1;
-  int ncl = env_int("EKS_NLL_NCL", kNclGrid);
+  int ncl = knob_int(KNOB_NLL_NCL, kNclGrid);
   if (ncl != 1 && ncl != 2 && ncl != 4 && ncl != 8) ncl = kNclGrid;
   while (ncl > 1 && n_cand < ncl) ncl >>= 1;
   return ncl;
@@ -504,8 +499,8 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
   // few (keypoint, candidate) pairs and many chunks: the chunk summaries are composed by a tree
   // (which cannot take converged-entry summaries: they are only valid in sequential order)
   const bool tree = (long)K * n_cand * D <= 8192 && G.ncn >= 8 && D <= 16 &&
-                    !env_int("EKS_NLL_ASSEMBLE_SEQ", 0);
-  G.converged_entry = !grad && !tree && !env_int("EKS_NLL_EXACT_ENTRY", 0);
+                    !knob_int(KNOB_NLL_ASSEMBLE_SEQ, 0);
+  G.converged_entry = !grad && !tree && !knob_int(KNOB_NLL_EXACT_ENTRY, 0);
   NllWs W;
   W.ncp = G.ngrp * ncl;
   const size_t fl = align_up((size_t)G.ncn * W.ncp * N * sizeof(float), 256);
@@ -526,7 +521,7 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
       break;
     }
   {
-    const int ew = env_int("EKS_NLL_WPB", 0);
+    const int ew = knob_int(KNOB_NLL_WPB, 0);
     if (ew == 1 || ew == 2 || ew == 4 || ew == 8) wpb = ew;
   }
   const dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
@@ -576,7 +571,7 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
     return hip_status(hipGetLastError());
   }
   if (!grad && G.converged_entry && G.nt_log2 == 6 && (D & (D - 1)) == 0 && 64 % D == 0 && G.ncn >= 4 &&
-      !env_int("EKS_NLL_ASSEMBLE_SEQ", 0)) {
+      !knob_int(KNOB_NLL_ASSEMBLE_SEQ, 0)) {
     const size_t shm = ((size_t)G.ncn + kAsmWaves) * 64 * sizeof(double);
     if (shm <= 60 * 1024) {
       hipLaunchKernelGGL(diag_nll_assemble_par_kernel, dim3((unsigned)(G.ntile * n_cand)), dim3(64 * kAsmWaves),

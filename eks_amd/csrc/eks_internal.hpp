@@ -14,6 +14,17 @@ struct DiagModel;
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int hip_status(hipError_t e) { return e == hipSuccess ? EKS_OK : EKS_ERR_HIP_BASE - (int)e; }
 
+// A/B tuning knobs: environment variables read ONCE, the first time any entry
+// point asks (thread-safe function-local static), never in the per-call host path - the library stays
+// re-entrant and a hot loop of eks_smooth calls does not walk the environment block.
+enum Knob {
+  KNOB_SMOOTH_UNFUSED, KNOB_SUMMARIZE_REVERSE, KNOB_REPLAY_FORWARD, KNOB_REPLAY_RECOMPUTE, KNOB_SCAN_CH,
+  KNOB_SMOOTH_TILE, KNOB_DENSE_CHUNK, KNOB_NLL_NCL, KNOB_NLL_CHUNK, KNOB_NLL_CHUNK0, KNOB_NLL_WPB,
+  KNOB_NLL_EXACT_ENTRY, KNOB_NLL_ASSEMBLE_SEQ, KNOB_MEDIAN_UNFUSED, KNOB_DENSE_LEGACY, KNOB_COUNT
+};
+bool knob_set(Knob k);               // the variable exists
+int knob_int(Knob k, int dflt);      // its integer value, or dflt when unset
+
 // per-kernel timing scope (eks_profile.hip); a no-op unless eks_profile_enable(1) was called
 class ProfScope {
  public:

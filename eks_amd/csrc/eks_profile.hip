@@ -6,6 +6,7 @@
 // records per step instead of twelve inside bench.py's timed region.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -13,6 +14,35 @@
 #include "eks_internal.hpp"
 
 namespace eks {
+
+namespace {
+struct KnobTable {
+  bool set[KNOB_COUNT];
+  int val[KNOB_COUNT];
+  KnobTable() { load(); }
+  int load() {
+    static const char* const names[KNOB_COUNT] = {
+        "EKS_SMOOTH_UNFUSED", "EKS_SUMMARIZE_REVERSE", "EKS_REPLAY_FORWARD", "EKS_REPLAY_RECOMPUTE", "EKS_SCAN_CH",
+        "EKS_SMOOTH_TILE", "EKS_DENSE_CHUNK", "EKS_NLL_NCL", "EKS_NLL_CHUNK", "EKS_NLL_CHUNK0", "EKS_NLL_WPB",
+        "EKS_NLL_EXACT_ENTRY", "EKS_NLL_ASSEMBLE_SEQ", "EKS_MEDIAN_UNFUSED", "EKS_DENSE_LEGACY"};
+    int n = 0;
+    for (int i = 0; i < KNOB_COUNT; ++i) {
+      const char* v = getenv(names[i]);
+      set[i] = v != nullptr;
+      val[i] = v ? atoi(v) : 0;
+      n += set[i];
+    }
+    return n;
+  }
+};
+KnobTable& knob_table() {
+  static KnobTable t;                // read once, on first use (eks_knobs_reload: the tests' hook)
+  return t;
+}
+}  // namespace
+
+bool knob_set(Knob k) { return knob_table().set[k]; }
+int knob_int(Knob k, int dflt) { return knob_table().set[k] ? knob_table().val[k] : dflt; }
 
 struct ProfEntry {
   const char* name;
@@ -58,6 +88,8 @@ ProfScope::~ProfScope() {
 }  // namespace eks
 
 extern "C" {
+
+int eks_knobs_reload(void) { return eks::knob_table().load(); }
 
 int eks_profile_enable(int on) {
   eks::g_prof_level = on < 0 ? 0 : on > 2 ? 1 : on;

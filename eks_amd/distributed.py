@@ -187,8 +187,10 @@ def smooth_sessions_batched(load_session: Callable[[int], dict], n_sessions: int
     Each rank takes its round-robin shard, stacks CONSECUTIVE sessions of equal (T, D, O) along the
     keypoint axis (at most `max_batch_keypoints` keypoints per batch: 8192 x 50 000 frames = 16 GB
     of inputs and outputs at 40 B per keypoint-frame) and runs ONE run_kalman_smoother per batch -
-    keypoints are independent (reference eks/core.py:293), so a batch is exactly the sessions
-    smoothed one by one.  `smooth_param` may be a scalar, or a callable i -> per-session value.
+    keypoints are independent (reference eks/core.py:293), so a batch equals the sessions smoothed
+    one by one up to float32 rounding (the NLL kernels take wave-uniform regime decisions that see
+    the neighbouring chains of a 64-chain tile).  `smooth_param` may be a scalar, a per-keypoint list
+    (every session must then have that many keypoints), or a callable i -> per-session value(s).
     `session_blocks(i)` optionally returns session i's keypoint blocks.
 
     Returns (local {i: (s_finals, ms, Vs)} - views into the batch outputs, on the device when
@@ -213,8 +215,20 @@ def smooth_sessions_batched(load_session: Callable[[int], dict], n_sessions: int
             per = [np.broadcast_to(np.asarray(sp(i), dtype=float), (int(offs[j + 1] - offs[j]),))
                    for j, (i, _) in enumerate(batch)]
             kw['smooth_param'] = list(np.concatenate(per))
-        else:
+        elif sp is None or isinstance(sp, (int, float)):
             kw['smooth_param'] = sp
+        else:
+            # a per-keypoint list is per SESSION (run_kalman_smoother's meaning): tiled over the batch's
+            # sessions, which must then all have that many keypoints
+            spa = np.asarray(sp, dtype=float).reshape(-1)
+            sizes = [int(offs[j + 1] - offs[j]) for j in range(len(batch))]
+            if spa.size == 1:
+                kw['smooth_param'] = float(spa[0])
+            elif all(n == spa.size for n in sizes):
+                kw['smooth_param'] = list(np.tile(spa, len(batch)))
+            else:
+                raise ValueError(f'smooth_param has {spa.size} entries but the sessions of this batch have '
+                                 f'{sorted(set(sizes))} keypoints; pass a scalar or a callable i -> value(s)')
         s, ms, Vs = smooth_fn(**kw, blocks=blocks, **kalman_kwargs)
         for j, (i, _) in enumerate(batch):
             a, b = int(offs[j]), int(offs[j + 1])
@@ -238,22 +252,31 @@ def smooth_sessions_batched(load_session: Callable[[int], dict], n_sessions: int
     return mine, all_s
 
 
-def smooth_session_keypoint_sharded(ys, m0s, S0s, As, Cs, Qs, ensemble_vars,
+def smooth_session_keypoint_sharded(ys=None, m0s=None, S0s=None, As=None, Cs=None, Qs=None, ensemble_vars=None,
                                     blocks: Sequence[Sequence[int]] | None = None,
                                     smooth_fn: Callable | None = None, group=None,
-                                    smooth_param=None, **kalman_kwargs):
+                                    smooth_param=None, load_keypoints: Callable | None = None,
+                                    n_keypoints: int | None = None, **kalman_kwargs):
     """ONE large session across the ranks of `group`: keypoint blocks are dealt to the ranks
     (greedy balance, a block - whose members share one s, reference eks/core.py:474-476 - is never
     split), every rank smooths its keypoints on its own GPU with no exchange, and the per-keypoint
-    s_finals are all-gathered (tensor collective).  Arguments as run_kalman_smoother; every rank
-    passes the full arrays (or at least its own keypoints' slices filled in).
+    s_finals are all-gathered (tensor collective).  Arguments as run_kalman_smoother.  Either every
+    rank passes the full arrays, or - so that no rank ever holds the whole session (C3: 410 MB of
+    inputs per rank otherwise) - `load_keypoints(idx) -> dict(ys (len(idx),T,O), m0s, S0s, As, Cs, Qs,
+    ensemble_vars (T,len(idx),O))` with `n_keypoints` = K: a rank then loads only the keypoints it
+    owns (idx sorted ascending).
 
     Returns (s_finals of all K keypoints, owned keypoint indices (sorted), ms, Vs of the owned
     keypoints in that order)."""
     if smooth_fn is None:
         smooth_fn = _default_smooth_fn()
     rank, world = _rank_world(group)
-    K = np.shape(m0s)[0]
+    if load_keypoints is not None:
+        if n_keypoints is None:
+            raise ValueError('load_keypoints needs n_keypoints (the session\'s K)')
+        K = int(n_keypoints)
+    else:
+        K = np.shape(m0s)[0]
     if not blocks:
         blocks = [[k] for k in range(K)]
     flat = sorted(int(k) for b in blocks for k in b)
@@ -270,9 +293,17 @@ def smooth_session_keypoint_sharded(ys, m0s, S0s, As, Cs, Qs, ensemble_vars,
         if sp is not None and not isinstance(sp, (int, float)):
             sp = np.broadcast_to(np.asarray(sp, dtype=float), (K,))[idx]
             sp = list(sp)
-        s, ms, Vs = smooth_fn(ys=take(ys, 0), m0s=np.asarray(m0s)[idx], S0s=np.asarray(S0s)[idx],
-                              As=np.asarray(As)[idx], Cs=np.asarray(Cs)[idx], Qs=np.asarray(Qs)[idx],
-                              ensemble_vars=take(ensemble_vars, 1), smooth_param=sp,
+        if load_keypoints is not None:
+            part = load_keypoints(idx)
+            arrays = {n: part[n] for n in ('ys', 'm0s', 'S0s', 'As', 'Cs', 'Qs', 'ensemble_vars')}
+            if np.shape(arrays['m0s'])[0] != len(own):
+                raise ValueError(f'load_keypoints returned {np.shape(arrays["m0s"])[0]} keypoints for '
+                                 f'{len(own)} requested')
+        else:
+            arrays = dict(ys=take(ys, 0), m0s=np.asarray(m0s)[idx], S0s=np.asarray(S0s)[idx],
+                          As=np.asarray(As)[idx], Cs=np.asarray(Cs)[idx], Qs=np.asarray(Qs)[idx],
+                          ensemble_vars=take(ensemble_vars, 1))
+        s, ms, Vs = smooth_fn(**arrays, smooth_param=sp,
                               blocks=[[local_of[k] for k in b] for b in own_blocks], **kalman_kwargs)
         s = np.asarray(s, dtype=np.float64)
     else:

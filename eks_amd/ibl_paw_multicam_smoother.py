@@ -90,11 +90,15 @@ def fit_eks_multicam_ibl_paw(input_source: str, save_dir: str, smooth_param: flo
     # left frames whose timestamp lies inside the right camera's recording (reference :190-196)
     keep = (ts_left >= ts_right[0]) & (ts_left <= ts_right[-1])
     t_keep = ts_left[keep]
+    # scipy's interp1d (assume_sorted=False, what upstream calls) sorts the abscissa first; np.interp
+    # silently assumes it is increasing - dropped / reordered frames would interpolate garbage
+    order = np.argsort(ts_right, kind='stable')
+    ts_sorted = np.asarray(ts_right)[order]
     per_cam = [[], []]
     for df_l, df_r in zip(left, right):
         lv = df_l.to_numpy()[:, [0, 1, 3, 4]][keep]
         rv_all = df_r.to_numpy()[:, [0, 1, 3, 4]]
-        rv = np.stack([np.interp(t_keep, ts_right, rv_all[:, j]) for j in range(4)], axis=1)
+        rv = np.stack([np.interp(t_keep, ts_sorted, rv_all[order, j]) for j in range(4)], axis=1)
         rv[:, 0] = img_width - rv[:, 0]                      # flip x into the left camera's frame
         rv[:, 2] = img_width - rv[:, 2]
         per_cam[0].append(pd.DataFrame(lv, columns=_KEYS))

@@ -122,7 +122,8 @@ def ensemble_kalman_smoother_multicam(marker_array: MarkerArray, keypoint_names:
         raise ValueError('camera_names must be provided')
     M, V, T, K, _ = marker_array.shape
     t_all = time.perf_counter()
-    if camgroup is None and not os.environ.get('EKS_HOST_DRIVER'):
+    if camgroup is None and not os.environ.get('EKS_HOST_DRIVER') \
+            and _device_pipeline_covers(V, n_latent, inflate_vars, kalman_kwargs):
         out = _linear_on_device(marker_array, keypoint_names, smooth_param, quantile_keep_pca, s_frames,
                                 avg_mode, var_mode, inflate_vars, inflate_vars_kwargs, pca_object, n_latent,
                                 kalman_kwargs)
@@ -180,6 +181,17 @@ def ensemble_kalman_smoother_multicam(marker_array: MarkerArray, keypoint_names:
     logger.debug(f'[profile] ensemble_kalman_smoother_multicam total: '
                  f'{time.perf_counter() - t_all:.3f}s')
     return camera_dfs, s_finals, df_3d
+
+
+def _device_pipeline_covers(V: int, n_latent: int, inflate_vars: bool, kalman_kwargs: dict) -> bool:
+    """Shapes / options the device-resident pipeline handles; anything else takes the host pipeline (same
+    kernels for the Kalman path, NumPy around them): eks_maha_inflate covers 2..8 views and n_latent <= 6,
+    eks_multicam_tables wants the full (T,K,D,D) covariances on the device."""
+    if kalman_kwargs.get('vs_diag') or 'return_device' in kalman_kwargs:
+        return False
+    if inflate_vars and not (2 <= V <= 8 and 1 <= n_latent <= 6):
+        return False
+    return 1 <= n_latent <= 6
 
 
 def _linear_on_device(marker_array, keypoint_names, smooth_param, quantile_keep_pca, s_frames, avg_mode,

@@ -225,6 +225,13 @@ int eks_multicam_tables(int32_t n_views, int32_t n_frames, int32_t n_keypoints, 
 int eks_profile_enable(int on);
 int eks_profile_drain(char* names, size_t names_bytes, float* ms, int32_t max_n);
 
+/* ---- measurement hook.  The EKS_* tuning variables (alternative kernel
+ * organisations kept for A/B runs; none is needed in use) are read ONCE, on the first call into the
+ * library, never per call.  eks_knobs_reload re-reads them (a test that flips a variable between two
+ * calls of one process); not to be called while another thread is inside the library.  Returns the
+ * number of EKS_* variables found set.  No reference counterpart. ------------------------------ */
+int eks_knobs_reload(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,3 +37,20 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def set_knob(monkeypatch):
+    """set_knob('EKS_SMOOTH_UNFUSED', '1'): set one of the library's A/B variables for the rest of the
+    test.  The library reads its EKS_* variables once (never per call), so the change is followed by
+    eks_knobs_reload(), and again when the test's environment is restored."""
+    from eks_amd import _lib
+    lib = _lib.load()
+
+    def _set(name, value):
+        monkeypatch.setenv(name, value)
+        lib.eks_knobs_reload()
+
+    yield _set
+    monkeypatch.undo()
+    lib.eks_knobs_reload()

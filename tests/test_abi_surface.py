@@ -75,3 +75,17 @@ def test_product_package_never_imports_the_oracle():
                 if re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M) or 'host_sim' in src:
                     bad.append(os.path.join(dirpath, f))
     assert not bad, f'product code must not touch oracle/ or tests/host_sim: {bad}'
+
+
+def test_committed_traffic_summary_matches_the_kernel_sources():
+    """bench.py's roofline.traffic comes from profiles/r03_traffic.json (separate rocprofv3 --pmc passes); the
+    summary records a hash of the smoother's kernel sources and must be re-measured when they change."""
+    import json
+    import bench
+    path = os.path.join(ROOT, 'profiles', bench.TRAFFIC_FILES[0])
+    if not os.path.exists(path):
+        pytest.skip(f'{bench.TRAFFIC_FILES[0]} not measured yet this round (bench reports traffic = null)')
+    with open(path) as f:
+        doc = json.load(f)
+    assert doc.get('kernel_sources_sha16') == bench.kernel_sources_sha16(), \
+        'profiles traffic summary is stale: rerun tools/collect_evidence.sh + tools/make_profiles.py'

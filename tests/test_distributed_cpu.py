@@ -132,6 +132,24 @@ def _worker_batched(rank, world, port, out_dir):
     s_fix, own2, _, _ = D.smooth_session_keypoint_sharded(**big, smooth_fn=_cpu_smooth,
                                                           smooth_param=[1., 2., 3., 4., 5., 6.])
     assert list(s_fix) == [1., 2., 3., 4., 5., 6.]
+    # per-rank loader: a rank is only ever handed the keypoints it owns (never the whole session)
+    asked = []
+
+    def load_kp(idx):
+        asked.append(list(map(int, idx)))
+        return dict(ys=big['ys'][idx], m0s=big['m0s'][idx], S0s=big['S0s'][idx], As=big['As'][idx],
+                    Cs=big['Cs'][idx], Qs=big['Qs'][idx], ensemble_vars=big['ensemble_vars'][:, idx])
+
+    s_ld, own_ld, ms_ld, _ = D.smooth_session_keypoint_sharded(load_keypoints=load_kp, n_keypoints=6, blocks=blocks,
+                                                               smooth_fn=_cpu_smooth, safety_cap=3)
+    assert asked == [list(own)] and 0 < len(own) < 6
+    np.testing.assert_array_equal(s_ld, s_all)
+    np.testing.assert_array_equal(ms_ld, ms)
+    # a per-keypoint smooth_param list is per session: tiled over a batch of equal sessions, refused otherwise
+    mine_l, _ = D.smooth_sessions_batched(lambda i: _session(i), 4, smooth_fn=_cpu_smooth, smooth_param=[3.0, 7.0])
+    assert all(list(r[0]) == [3.0, 7.0] for r in mine_l.values()) and len(mine_l) == 2
+    with pytest.raises(ValueError, match='smooth_param has 2 entries'):
+        D.smooth_sessions_batched(lambda i: _session(i, K=3), 4, smooth_fn=_cpu_smooth, smooth_param=[3.0, 7.0])
     dist.barrier()
     dist.destroy_process_group()
 

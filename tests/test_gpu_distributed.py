@@ -47,6 +47,42 @@ def test_bench_two_rank_code_path():
     assert out['n_gpus'] == 2 and out['steps'] == 3 and out['scaling'] == 'weak' and out['value'] > 0
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` the way the round-end driver invokes it - NO outer torchrun: the parent
+    (which never touches the GPU) starts torch.distributed.run as a child, the two ranks share this box's GPU
+    (gloo rendezvous), rank 0's JSON line comes through the parent's stdout and the exit code is the child's."""
+    env = dict(os.environ, EKS_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--workload', 'c2', '--steps', '3', '--warmup', '1',
+                        '--no-cpu-baseline'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['value'] > 0
+    assert out['regions'] >= 5 and out['ms_per_step_min'] <= out['ms_per_step'] <= out['ms_per_step_max']
+    # strong scaling (ONE session, its keypoints dealt to the ranks) through the same self-launch
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--workload', 'c2', '--steps', '3', '--warmup', '1',
+                        '--no-cpu-baseline', '--scaling', 'strong'], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'strong' and out['config']['keypoints'] == 64
+
+
+def test_bench_refuses_more_rccl_ranks_than_gpus():
+    import torch
+    n = torch.cuda.device_count()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('EKS_BENCH_BACKEND', None)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', str(n + 1), '--workload', 'c2', '--steps', '2',
+                        '--no-cpu-baseline'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and 'RCCL needs one GPU per rank' in (r.stdout + r.stderr)
+
+
 def test_rccl_branch_with_a_world_of_one():
     """What a 1-GPU box can exercise of the RCCL path: a process group of ONE rank on backend nccl.  The
     distributed drivers' tensor all-gathers (eks_amd.distributed.all_gather_ragged) and bench.py's

@@ -46,7 +46,7 @@ def _params_dev(arrs):
     return [_dev(arrs[k], torch.float64) for k in ('m0s', 'S0s', 'As', 'Cs', 'Qs')]
 
 
-def test_smooth_diag_long_sequence_fused_and_unfused_scan_agree_with_oracle(monkeypatch):
+def test_smooth_diag_long_sequence_fused_and_unfused_scan_agree_with_oracle(set_knob):
     """T = 140 000 (4 375 chunks): the fused path's group scan re-reads its aggregates in batches
     (more than 16 per slot); both scan organisations against the C oracle on every frame."""
     from eks_amd import hip_ops
@@ -64,7 +64,7 @@ def test_smooth_diag_long_sequence_fused_and_unfused_scan_agree_with_oracle(monk
                                     m0, S0, eye, eye, eye, s)
     Vd_o = np.diagonal(Vs_o, axis1=2, axis2=3)
     for unfused in ('0', '1'):
-        monkeypatch.setenv('EKS_SMOOTH_UNFUSED', unfused)
+        set_knob('EKS_SMOOTH_UNFUSED', unfused)
         ms, Vs = hip_ops.smooth(_dev(y), _dev(var), _dev(m0), _dev(S0), _dev(eye), _dev(eye), _dev(eye), _dev(s),
                                 flags=flags, vs_diag=True)
         ms_k = np.transpose(ms.cpu().numpy().astype(np.float64), (1, 0, 2))
@@ -74,7 +74,7 @@ def test_smooth_diag_long_sequence_fused_and_unfused_scan_agree_with_oracle(monk
 
 
 @pytest.mark.parametrize('T,K,vs_diag', [(10_007, 64, True), (2_100, 500, False), (16_000, 33, False)])
-def test_smooth_diag_fused_and_three_kernel_scan_match_oracle(monkeypatch, T, K, vs_diag):
+def test_smooth_diag_fused_and_three_kernel_scan_match_oracle(set_knob, T, K, vs_diag):
     """Both organisations of the scan (folded into summarize / replay, and the separate three-kernel
     scan) on observations far from the origin, ragged T and ragged tiles: each within 1e-5 of the
     C oracle on every frame."""
@@ -93,10 +93,10 @@ def test_smooth_diag_fused_and_three_kernel_scan_match_oracle(monkeypatch, T, K,
     Vd_o = np.diagonal(Vs_o, axis1=2, axis2=3)
     kept = {}
     for unfused, recompute in (('0', '0'), ('0', '1'), ('1', '0')):
-        monkeypatch.setenv('EKS_SMOOTH_UNFUSED', unfused)
+        set_knob('EKS_SMOOTH_UNFUSED', unfused)
         # fused form: chunk elements kept between summarize and replay, or summarised again in replay
         # (what wide problems run) - the same arithmetic, so bit-identical outputs
-        monkeypatch.setenv('EKS_REPLAY_RECOMPUTE', recompute)
+        set_knob('EKS_REPLAY_RECOMPUTE', recompute)
         ms_d, Vs_d = hip_ops.smooth(_dev(y), _dev(var), _dev(m0), _dev(S0), _dev(eye), _dev(eye), _dev(eye),
                                     _dev(s), flags=flags, vs_diag=vs_diag)
         if unfused == '0':
@@ -119,10 +119,10 @@ def test_smooth_diag_fused_and_three_kernel_scan_match_oracle(monkeypatch, T, K,
     (700, 200, False, True),     # several chain tiles
 ])
 @pytest.mark.parametrize('recompute', ['0', '1'])
-def test_smooth_diag_matches_oracle(T, K, unit, vs_diag, recompute, monkeypatch):
+def test_smooth_diag_matches_oracle(T, K, unit, vs_diag, recompute, set_knob):
     from eks_amd import hip_ops
     # fused form (>= 64 chains): chunk elements kept between the two kernels or summarised again
-    monkeypatch.setenv('EKS_REPLAY_RECOMPUTE', recompute)
+    set_knob('EKS_REPLAY_RECOMPUTE', recompute)
     arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=T + K, unit=unit)
     rng = np.random.default_rng(1)
     if T == 1:      # nanvar over one frame is 0: give the prior a real variance

@@ -278,3 +278,36 @@ def test_factor_analysis_from_moments_is_sklearns_fit(p, k, n):
     # what the Mahalanobis step uses: the column space
     P1, P2 = W @ np.linalg.pinv(W), fa.components_.T @ np.linalg.pinv(fa.components_.T)
     assert np.abs(P1 - P2).max() < 1e-10
+
+
+def test_page_locked_result_cap_follows_the_arrays_callers_hold(monkeypatch):
+    """core._to_host counts page-locked result bytes for as long as the CALLER holds the arrays (or views
+    of them) and switches to pageable results beyond the cap (a finaliser on the staging
+    tensor fired on return because ndarray.base is another tensor object).  Plain host tensors stand in
+    for page-locked ones here (no GPU)."""
+    import gc
+    import torch
+    from eks_amd import core
+    made = []
+
+    def fake_pinned(shape, dtype):
+        made.append(1)
+        return torch.empty(shape, dtype=dtype)
+
+    monkeypatch.setattr(core, '_pinned_empty', fake_pinned)
+    monkeypatch.setattr(core, '_PINNED_CAP_BYTES', 3000)
+    monkeypatch.setattr(core, '_pinned_live', [0])
+    a, = core._to_host(torch.arange(500, dtype=torch.float32))            # 2000 B, staged
+    assert len(made) == 1 and core._pinned_live[0] == 2000
+    view = np.swapaxes(a.reshape(10, 50), 0, 1)
+    del a
+    gc.collect()
+    assert core._pinned_live[0] == 2000                                   # a view still holds the buffer
+    b, = core._to_host(torch.arange(500, dtype=torch.float32))            # 2000 + 2000 > cap: pageable
+    assert len(made) == 1 and core._pinned_live[0] == 2000
+    np.testing.assert_array_equal(b, np.arange(500, dtype=np.float32))
+    del view
+    gc.collect()
+    assert core._pinned_live[0] == 0
+    c, = core._to_host(torch.arange(500, dtype=torch.float32))            # room again
+    assert len(made) == 2 and core._pinned_live[0] == 2000
