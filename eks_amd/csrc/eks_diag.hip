@@ -296,9 +296,10 @@ static_assert(kFW == 4, "the fused kernels' LDS exchange, the group scan's slot 
 
 struct BlockMap {
   int N, T, nc;
-  int ntile;     // ceil(N / 64)
+  int ntile;     // 64-chain tiles covered by THIS launch (all of ceil(N / 64), or one pass's share)
   int ngrp;      // chunk groups = ceil(nc / kFW)
   int reverse;   // walk the chunk groups backwards in time
+  int tile0;     // first tile of this launch (keypoint-tiled passes, diag_smooth)
 };
 
 // Row access of the fused kernels through buffer resources based at the first row of the wave's
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(64 * kFW) void diag_summarize_blk_kernel(BlockMap L
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (threadIdx.x == 0) arrived = 0;
   __syncthreads();                         // (at the very start: costs nothing, the waves launch together)
-  const int tile = blockIdx.x % L.ntile;
+  const int tile = L.tile0 + blockIdx.x % L.ntile;
   int grp = blockIdx.x / L.ntile;
   if (L.reverse) grp = L.ngrp - 1 - grp;
   const int n = tile * 64 + lane, j = grp * kFW + w;
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(64 * kFW) void diag_replay_blk_kernel(BlockMap L, D
                                                                   float* __restrict__ ms,
                                                                   float* __restrict__ Vs) {
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int tile = blockIdx.x % L.ntile;
+  const int tile = L.tile0 + blockIdx.x % L.ntile;
   int grp = blockIdx.x / L.ntile;
   if (L.reverse) grp = L.ngrp - 1 - grp;
   const int n = tile * 64 + lane, j = grp * kFW + w;
@@ -534,14 +535,14 @@ __global__ __launch_bounds__(64 * kFW) void diag_replay_blk_kernel(BlockMap L, D
 // slot walks its aggregates again from the belief entering its first one (forward) / the
 // information leaving its last one (backward), writing the per-block results.
 template <int PER, int CH>
-__global__ __launch_bounds__(64 * CH) void diag_scan_groups_kernel(int N, DiagModel M, ScanWs S) {
+__global__ __launch_bounds__(64 * CH) void diag_scan_groups_kernel(int N, int n0, int n1, DiagModel M, ScanWs S) {
   constexpr int NW = CH;                   // waves per block (64 slots x CH chains / 64 lanes)
   __shared__ float tot[2][5][NW][CH];      // [direction][field][wave][chain]
   const int c = threadIdx.x % CH, slot = threadIdx.x / CH, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int n = blockIdx.x * CH + c;
+  const int n = n0 + blockIdx.x * CH + c;   // n0: first chain of this launch (keypoint-tiled passes)
   const int per = (S.nblk + 63) / 64;      // <= PER, or the slot re-reads in batches of PER
   const int q0 = min(slot * per, S.nblk), q1 = min(q0 + per, S.nblk);
-  const bool live = n < N;
+  const bool live = n < n1;                // chains [n0, n1) of the N whose planes these are
   auto agg = [&](int q) {
     const size_t o = (size_t)q * N + n;
     return Elem<float>{S.gA[o], S.gb[o], S.gC[o], S.gEta[o], S.gJ[o]};
@@ -712,7 +713,18 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
   const int k1_reverse = knob_int(KNOB_SUMMARIZE_REVERSE, 0) == 1 ? 1 : 0;
   const int k3_reverse = knob_set(KNOB_REPLAY_FORWARD) ? (knob_int(KNOB_REPLAY_FORWARD, 0) == 1 ? 0 : 1) : !k1_reverse;
   if (fused) {
-    BlockMap Bm{N, T, L.nc, L.ntile, S.nblk, k1_reverse};
+    // Keypoint-tiled passes (round 3): y + var of a wide session do not fit the 256 MiB Infinity Cache,
+    // so K3 reads them from HBM a second time.  With `tp` 64-chain tiles per pass the three launches run
+    // per pass and a pass's rows (tp x 64 chains x T x 8 B) are still on chip when its K3 asks for them;
+    // the outputs leave non-temporally.  EKS_SMOOTH_TILE = tiles per pass (0 = one pass).
+    const bool rc_all = knob_set(KNOB_REPLAY_RECOMPUTE) ? knob_int(KNOB_REPLAY_RECOMPUTE, 0) == 1
+                                                        : 5 * pb >= ((size_t)16 << 20);
+    int tp = knob_int(KNOB_SMOOTH_TILE, 0);
+    if (tp <= 0 || tp > L.ntile) tp = L.ntile;
+    for (int tile0 = 0; tile0 < L.ntile; tile0 += tp) {
+    const int ntl = min(tp, L.ntile - tile0);
+    const int n0 = tile0 * 64, Np = min(N - n0, ntl * 64);
+    BlockMap Bm{N, T, L.nc, ntl, S.nblk, k1_reverse, tile0};
     const dim3 bgrid((unsigned)((long)Bm.ntile * Bm.ngrp)), bblock(64 * kFW);
     // Problems whose chunk elements do not stay on chip do not keep them between K1 and K3: K3
     // summarises its chunks again (diag_replay_blk_kernel, RC).  Same box, alternating runs
@@ -720,8 +732,7 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
     // 0.64 -> 0.56 ms, K3 1.37 -> 1.33 ms, step 2.06 -> 1.94 ms; C3 (512 chains, 32 MB) K1 83 -> 75 us,
     // K3 168 -> 165 us, step 0.597 -> 0.591 ms; C2 (128 chains, 0.8 MB) K3 8.9 -> 13.3 us - one more
     // dependent pass in a latency-bound launch.  Hence the threshold on the element bytes.
-    const bool rc = knob_set(KNOB_REPLAY_RECOMPUTE) ? knob_int(KNOB_REPLAY_RECOMPUTE, 0) == 1
-                                                    : 5 * pb >= ((size_t)16 << 20);
+    const bool rc = rc_all;
 #define EKS_K1_BLK(UN)                                                                                  \
   do {                                                                                                  \
     if (rc)                                                                                             \
@@ -752,18 +763,19 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
       // a slot's aggregates stay in registers when there are at most 16 of them (T <= 131 072)
       // 4 chains per block for narrow problems (more blocks: 10 000 x 64 keypoints 7.1 vs 9.4 us),
       // 16 for wide ones (whole 64-byte segments: 50 000 x 4096 keypoints 119 -> 46 us)
-      const bool ch4 = knob_set(KNOB_SCAN_CH) ? knob_int(KNOB_SCAN_CH, 4) == 4 : N < 2048;
+      const bool ch4 = knob_set(KNOB_SCAN_CH) ? knob_int(KNOB_SCAN_CH, 4) == 4 : Np < 2048;
       const bool per8 = (S.nblk + 63) / 64 <= 8;
+      const int Ne = n0 + Np;                 // chains [n0, Ne) are scanned by this launch
       if (ch4) {
         if (per8)
-          hipLaunchKernelGGL((diag_scan_groups_kernel<8, 4>), dim3((N + 3) / 4), dim3(256), 0, st, N, M, S);
+          hipLaunchKernelGGL((diag_scan_groups_kernel<8, 4>), dim3((Np + 3) / 4), dim3(256), 0, st, N, n0, Ne, M, S);
         else
-          hipLaunchKernelGGL((diag_scan_groups_kernel<16, 4>), dim3((N + 3) / 4), dim3(256), 0, st, N, M, S);
+          hipLaunchKernelGGL((diag_scan_groups_kernel<16, 4>), dim3((Np + 3) / 4), dim3(256), 0, st, N, n0, Ne, M, S);
       } else {
         if (per8)
-          hipLaunchKernelGGL((diag_scan_groups_kernel<8, 16>), dim3((N + 15) / 16), dim3(1024), 0, st, N, M, S);
+          hipLaunchKernelGGL((diag_scan_groups_kernel<8, 16>), dim3((Np + 15) / 16), dim3(1024), 0, st, N, n0, Ne, M, S);
         else
-          hipLaunchKernelGGL((diag_scan_groups_kernel<16, 16>), dim3((N + 15) / 16), dim3(1024), 0, st, N, M, S);
+          hipLaunchKernelGGL((diag_scan_groups_kernel<16, 16>), dim3((Np + 15) / 16), dim3(1024), 0, st, N, n0, Ne, M, S);
       }
     }
     ProfScope ps("diag_replay", st);
@@ -786,6 +798,7 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
       EKS_REPLAY_BLK(7)
       EKS_REPLAY_BLK(8)
     }
+    }  // passes
 #undef EKS_REPLAY_BLK
 #undef EKS_K3_BLK
 #undef EKS_K1_BLK
