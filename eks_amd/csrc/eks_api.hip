@@ -2,6 +2,7 @@
 // dispatch between the scalar-chain path (EKS_FLAG_DIAG_MODEL) and the general small-matrix path.
 #include <hip/hip_runtime.h>
 
+#include "eks_adam.hpp"
 #include "eks_diag_lane.hpp"
 #include "eks_internal.hpp"
 
@@ -156,6 +157,47 @@ int eks_adam_run(const eks_dims_t* d, const float* y, const double* rconst, cons
                  void* workspace, size_t workspace_bytes, eks_stream_t stream) {
   if (n_iters < 0) return EKS_ERR_SHAPE;
   if (!dnll) return EKS_ERR_NULL;
+  {
+    const int rc0 = check_dims(d);
+    if (rc0 != EKS_OK) return rc0;
+  }
+  if (n_blocks <= 0) return EKS_ERR_SHAPE;
+  if (!y || !rconst || !m0 || !S0 || !A || !C || !Q || !block_offsets || !block_members || !state ||
+      !s_keypoint || !nll || !n_active)
+    return EKS_ERR_NULL;
+  if (!workspace) return EKS_ERR_WORKSPACE;
+  if ((d->flags & EKS_FLAG_DIAG_MODEL) && n_iters > 0) {
+    // Scalar chains: the loss kernels read the optimiser state and skip the keypoints whose block has
+    // stopped (a wave none of whose 64 chains is still running returns at once; results of the others
+    // are bit for bit those of the ungated loop), and when every block is one keypoint - the reference's
+    // default, blocks = [] (eks/core.py:223-224) - the step is applied by the loss assembly itself:
+    // two launches per iteration instead of three.
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int K = d->n_keypoints, N = K * d->state_dim;
+    const size_t need = diag_nll_workspace_bytes(d->n_frames, N, 1);
+    if (workspace_bytes < need) return EKS_ERR_WORKSPACE;
+    char* tail = static_cast<char*>(workspace) + need - adam_extra_bytes(N);
+    int32_t* kp_block = reinterpret_cast<int32_t*>(tail);
+    int32_t* counter_b = reinterpret_cast<int32_t*>(tail + adam_extra_bytes(N) - 256);
+    int rc = adam_prepare(n_blocks, K, block_offsets, block_members, kp_block, n_active, counter_b, st);
+    if (rc != EKS_OK) return rc;
+    const bool in_kernel = n_blocks == K && diag_nll_grad_tree(d->n_frames, K, d->state_dim);
+    const DiagModel M{m0, S0, A, C, Q, nullptr, d->state_dim};
+    for (int it = 0; it < n_iters; ++it) {
+      // the LAST iteration of the call counts into n_active, the one before into the spare counter, ...
+      const bool last_parity = ((n_iters - 1 - it) & 1) == 0;
+      AdamFuse F{block_offsets, block_members, kp_block, lr, lo, hi, tol, safety_cap, in_kernel ? 1 : 0,
+                 state, s_keypoint, last_parity ? n_active : counter_b, last_parity ? counter_b : n_active};
+      rc = diag_nll(*d, y, rconst, M, s_keypoint, 1, 1, nll, dnll, workspace, workspace_bytes, st, &F);
+      if (rc != EKS_OK) return rc;
+      if (!in_kernel) {
+        rc = adam_step(n_blocks, block_offsets, block_members, nll, dnll, lr, lo, hi, tol, safety_cap, state,
+                       s_keypoint, n_active, st);
+        if (rc != EKS_OK) return rc;
+      }
+    }
+    return EKS_OK;
+  }
   for (int it = 0; it < n_iters; ++it) {
     int rc = eks_nll(d, y, rconst, m0, S0, A, C, Q, s_keypoint, 1, 1, nll, dnll, workspace,
                      workspace_bytes, stream);

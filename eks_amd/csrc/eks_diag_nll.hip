@@ -24,6 +24,7 @@
 
 #include <cstdlib>
 
+#include "eks_adam.hpp"
 #include "eks_internal.hpp"
 #include "eks_nll_lane.hpp"
 
@@ -68,7 +69,7 @@ template <typename R, int NCL, bool UNIT, bool TILE64>
 __global__ __launch_bounds__(512) void diag_nll_summarize_kernel(NllGeom G, DiagModel M, NllWs W,
                                           const float* __restrict__ y,
                                           const double* __restrict__ rconst,
-                                          const double* __restrict__ s_cand) {
+                                          const double* __restrict__ s_cand, AdamFuse F) {
   // TILE64: a wave holds 64 chains of ONE chunk and one candidate group, so everything derived
   // from the wave index is scalar (readfirstlane tells the compiler): chunk bounds, loop trip
   // counts and the row addresses of y (SGPR base + per-lane offset, no VALU address arithmetic)
@@ -84,6 +85,13 @@ __global__ __launch_bounds__(512) void diag_nll_summarize_kernel(NllGeom G, Diag
   const int j = TILE64 ? cg : cg * (64 >> G.nt_log2) + (lane >> G.nt_log2);
   if (n >= G.N || j >= G.ncn) return;
   const int k = n / G.D, d = n - k * G.D;
+  // Adam loop: keypoints whose optimiser block has stopped (or reached the cap) need no loss any more -
+  // a wave none of whose chains is still being optimised returns at once (wave-uniform, so the arithmetic
+  // of the chains that go on is untouched; reference eks/core.py:669-674 masks finished lanes the same way)
+  if (F.state != nullptr) {
+    const bool running = adam_block_running(F.state, F.kp_block[k], F.cap);
+    if (!__any(running)) return;
+  }
   const size_t dd = (size_t)k * G.D * G.D + (size_t)d * (G.D + 1);
   const double q = M.Q[dd];
   double sq[NCL];
@@ -251,12 +259,17 @@ constexpr int kAsmLanes = 64;
 
 template <bool GRAD>
 __global__ void diag_nll_assemble_tree_kernel(NllGeom G, DiagModel M, NllWs W, int K,
-                                              double* __restrict__ nll, double* __restrict__ dnll) {
+                                              double* __restrict__ nll, double* __restrict__ dnll,
+                                              AdamFuse F) {
   using RD = typename std::conditional<GRAD, DualD, double>::type;
   constexpr int NF = GRAD ? 13 : 7;               // 6 element fields (+ derivatives) + reference
   extern __shared__ double lds[];                 // [D][NF][64] + [D][2]
   const int i = threadIdx.x, d = threadIdx.y;
   const int k = blockIdx.x % K, ci = blockIdx.x / K;
+  if (F.state != nullptr) {                       // Adam loop (see AdamFuse)
+    if (blockIdx.x == 0 && i == 0 && d == 0) *F.n_active_next = 0;
+    if (!adam_block_running(F.state, F.kp_block[k], F.cap)) return;   // block-uniform
+  }
   const int n = k * G.D + d;
   double* my = lds + (size_t)d * NF * kAsmLanes;
   auto get = [&](int j) {
@@ -341,6 +354,15 @@ __global__ void diag_nll_assemble_tree_kernel(NllGeom G, DiagModel M, NllWs W, i
     const bool fin = isfinite(v);              // eks/core.py:650
     nll[(size_t)k * G.n_cand + ci] = fin ? v : 1e12;
     if constexpr (GRAD) dnll[(size_t)k * G.n_cand + ci] = fin ? -g : 0.0;
+    if constexpr (GRAD) {
+      // every optimiser block is this one keypoint: the step follows at once (this thread reads back
+      // the two values it has just written), no separate launch
+      if (F.state != nullptr && F.step_in_kernel) {
+        if (adam_step_block(F.kp_block[k], F.offs, F.members, nll, dnll, F.lr, F.lo, F.hi, F.tol, F.cap,
+                            F.state, F.s_keypoint))
+          atomicAdd(F.n_active_cur, 1);
+      }
+    }
   }
 }
 
@@ -479,27 +501,44 @@ static inline int pick_ncl(int n_cand, bool grad) {
   return ncl;
 }
 
+// few (keypoint, candidate) pairs and many chunks: the chunk summaries are composed by a tree
+static bool nll_uses_tree(int K, int D, int n_cand, int ncn) {
+  return (long)K * n_cand * D <= 8192 && ncn >= 8 && D <= 16 && !knob_int(KNOB_NLL_ASSEMBLE_SEQ, 0);
+}
+
+// does the gradient evaluation of a (T, K, D) problem (one value of s per keypoint) end in the tree
+// assembly - the kernel that can apply the optimiser step itself (AdamFuse::step_in_kernel)?
+bool diag_nll_grad_tree(int T, int K, int D) {
+  const NllGeom G = make_geom(T, K * D, D, 1, 1, true, 1);
+  return nll_uses_tree(K, D, 1, G.ncn);
+}
+
 size_t diag_nll_workspace_bytes(int T, int N, int n_cand) {
   // sized for the larger of the two modes (grad planes + smaller chunks)
   const int ncn = (T + kNllChunkGrad - 1) / kNllChunkGrad + 1;
   const size_t ncp = align_up((size_t)n_cand, kNclGrid);
   const size_t fl = align_up((size_t)ncn * ncp * N * sizeof(float), 256);
   const size_t db = align_up((size_t)ncn * ncp * N * sizeof(double), 256);
-  return 11 * fl + 2 * db;   // 10 element planes + the chunk references (one candidate's worth is used)
+  // 10 element planes + the chunk references (one candidate's worth is used) + the Adam loop's
+  // keypoint -> block map and its second counter (eks_adam_run)
+  return 11 * fl + 2 * db + adam_extra_bytes(N);
 }
+
+size_t adam_extra_bytes(int N) { return align_up((size_t)N * sizeof(int32_t), 256) + 256; }
 
 int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M,
              const double* s_cand, int n_cand, int per_keypoint, double* nll, double* dnll,
-             void* ws, size_t ws_bytes, hipStream_t st) {
+             void* ws, size_t ws_bytes, hipStream_t st, const AdamFuse* fuse) {
   const int T = d.n_frames, D = d.state_dim, K = d.n_keypoints, N = K * D;
   if (ws_bytes < diag_nll_workspace_bytes(T, N, n_cand)) return EKS_ERR_WORKSPACE;
   const bool grad = dnll != nullptr;
+  AdamFuse F{};                                   // all null: no gating, no fused step
+  if (fuse) F = *fuse;
   const int ncl = pick_ncl(n_cand, grad);
   NllGeom G = make_geom(T, N, D, n_cand, per_keypoint, grad, ncl);
-  // few (keypoint, candidate) pairs and many chunks: the chunk summaries are composed by a tree
-  // (which cannot take converged-entry summaries: they are only valid in sequential order)
-  const bool tree = (long)K * n_cand * D <= 8192 && G.ncn >= 8 && D <= 16 &&
-                    !knob_int(KNOB_NLL_ASSEMBLE_SEQ, 0);
+  // (the tree cannot take converged-entry summaries: they are only valid in sequential order)
+  const bool tree = nll_uses_tree(K, D, n_cand, G.ncn);
+  if (F.state && F.step_in_kernel && !(grad && tree)) return EKS_ERR_UNSUPPORTED;   // (caller asks diag_nll_grad_tree)
   G.converged_entry = !grad && !tree && !knob_int(KNOB_NLL_EXACT_ENTRY, 0);
   NllWs W;
   W.ncp = G.ngrp * ncl;
@@ -529,7 +568,7 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
   const bool tile64 = G.nt_log2 == 6 && (long)(G.BN > G.B0 ? G.BN : G.B0) * N * 4 < (1L << 31);
 #define EKS_NLL_LAUNCH2(RT, NCL, UN, T64)                                                          \
   hipLaunchKernelGGL((diag_nll_summarize_kernel<RT, NCL, UN, T64>), grid, block, 0, st, G, M, W, y, \
-                     rconst, s_cand)
+                     rconst, s_cand, F)
 #define EKS_NLL_LAUNCH(RT, NCL)                          \
   do {                                                   \
     if (unit && tile64)                                  \
@@ -564,10 +603,10 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
     const size_t shm = ((size_t)D * (grad ? 13 : 7) * kAsmLanes + 2 * D) * sizeof(double);
     if (grad)
       hipLaunchKernelGGL(diag_nll_assemble_tree_kernel<true>, dim3(total), tb, shm, st, G, M, W, K, nll,
-                         dnll);
+                         dnll, F);
     else
       hipLaunchKernelGGL(diag_nll_assemble_tree_kernel<false>, dim3(total), tb, shm, st, G, M, W, K,
-                         nll, dnll);
+                         nll, dnll, F);
     return hip_status(hipGetLastError());
   }
   if (!grad && G.converged_entry && G.nt_log2 == 6 && (D & (D - 1)) == 0 && 64 % D == 0 && G.ncn >= 4 &&

@@ -43,9 +43,14 @@ size_t diag_smooth_workspace_bytes(int T, int N);
 int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const DiagModel& M,
                 float* ms, float* Vs, void* ws, size_t ws_bytes, hipStream_t st);
 size_t diag_nll_workspace_bytes(int T, int N, int n_cand);
+struct AdamFuse;   // eks_adam.hpp
 int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M,
              const double* s_cand, int n_cand, int per_keypoint, double* nll, double* dnll,
-             void* ws, size_t ws_bytes, hipStream_t st);
+             void* ws, size_t ws_bytes, hipStream_t st, const AdamFuse* fuse = nullptr);
+bool diag_nll_grad_tree(int T, int K, int D);
+size_t adam_extra_bytes(int N);     // tail of the NLL workspace used by eks_adam_run
+int adam_prepare(int n_blocks, int K, const int32_t* offs, const int32_t* members, int32_t* kp_block,
+                 int32_t* counter_a, int32_t* counter_b, hipStream_t st);
 
 // general small-matrix path (eks_dense.hip)
 struct DenseModel {

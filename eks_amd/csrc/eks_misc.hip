@@ -5,6 +5,7 @@
 #include <cfloat>
 #include <cstdlib>
 
+#include "eks_adam.hpp"
 #include "eks_internal.hpp"
 
 namespace eks {
@@ -767,41 +768,6 @@ int argmin_s(int K, int n_cand, const double* nll, const double* s_cand, double*
 // ==========================================================================================
 // Adam on log s with the reference's stop rule (eks/core.py:652-681, :509-549)
 // ==========================================================================================
-// one optimiser block b (a set of keypoints sharing one s); returns whether it is still running
-__device__ __forceinline__ bool adam_step_block(int b, const int32_t* __restrict__ offs,
-                                                const int32_t* __restrict__ members,
-                                                const double* __restrict__ nll,
-                                                const double* __restrict__ dnll, double lr, double lo,
-                                                double hi, double tol, int cap, double* __restrict__ state,
-                                                double* __restrict__ s_keypoint) {
-  double* st = state + (size_t)b * 6;
-  double u = st[0], mom = st[1], vel = st[2], prev = st[3], iters = st[4], done = st[5];
-  if (done == 0.0 && iters < (double)cap) {
-    double L = 0.0, g = 0.0;
-    for (int i = offs[b]; i < offs[b + 1]; ++i) {
-      L += nll[members[i]];
-      g += dnll[members[i]];
-    }
-    if (u < lo || u > hi) g = 0.0;
-    g *= lr;
-    const double cnt = iters + 1.0;
-    mom = 0.9 * mom + 0.1 * g;
-    vel = 0.999 * vel + 0.001 * g * g;
-    const double mhat = mom / (1.0 - pow(0.9, cnt));
-    const double vhat = vel / (1.0 - pow(0.999, cnt));
-    u = u - mhat / (sqrt(vhat) + 1e-8);
-    const bool stop = isfinite(prev) &&
-                      fabs(L - prev) < tol * fabs(log(fmax(prev, 1e-12))) + 1e-6;
-    prev = L;
-    iters = cnt;
-    done = stop ? 1.0 : 0.0;
-    st[0] = u; st[1] = mom; st[2] = vel; st[3] = prev; st[4] = iters; st[5] = done;
-  }
-  const double s = exp(fmin(fmax(u, lo), hi));
-  for (int i = offs[b]; i < offs[b + 1]; ++i) s_keypoint[members[i]] = s;
-  return done == 0.0 && iters < (double)cap;
-}
-
 __global__ void adam_step_kernel(int nb, const int32_t* __restrict__ offs,
                                  const int32_t* __restrict__ members, const double* __restrict__ nll,
                                  const double* __restrict__ dnll, double lr, double lo, double hi,
@@ -845,6 +811,27 @@ int adam_step(int n_blocks, const int32_t* offs, const int32_t* members, const d
   if (e != hipSuccess) return hip_status(e);
   hipLaunchKernelGGL(adam_step_kernel, dim3((n_blocks + 127) / 128), dim3(128), 0, st, n_blocks, offs,
                      members, nll, dnll, lr, lo, hi, tol, cap, state, s_keypoint, n_active);
+  return hip_status(hipGetLastError());
+}
+
+// keypoint -> optimiser block map of the CSR block list and two zeroed counters, once per eks_adam_run
+__global__ void adam_prepare_kernel(int nb, const int32_t* __restrict__ offs, const int32_t* __restrict__ members,
+                                    int32_t* __restrict__ kp_block, int32_t* __restrict__ ca,
+                                    int32_t* __restrict__ cb) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b == 0) {
+    *ca = 0;
+    *cb = 0;
+  }
+  if (b >= nb) return;
+  for (int i = offs[b]; i < offs[b + 1]; ++i) kp_block[members[i]] = b;
+}
+
+int adam_prepare(int n_blocks, int K, const int32_t* offs, const int32_t* members, int32_t* kp_block,
+                 int32_t* counter_a, int32_t* counter_b, hipStream_t st) {
+  (void)K;
+  hipLaunchKernelGGL(adam_prepare_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, n_blocks, offs, members,
+                     kp_block, counter_a, counter_b);
   return hip_status(hipGetLastError());
 }
 

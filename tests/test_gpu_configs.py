@@ -128,6 +128,73 @@ def test_c3_singlecam_100k_x_256_grid_search_and_smooth():
 
 
 # ------------------------------------------------------------------------------------------
+def test_c3_singlecam_100k_x_256_adam():
+    """configs[2]'s session in the REFERENCE's own mode: smooth_param=None -> Adam on log s per keypoint
+    (eks/core.py:562-699), loss over all 100 000 frames.  The device loop (loss + forward-mode gradient,
+    finished keypoints skipped, the step applied at the end of the loss assembly) against the oracle's
+    optimiser (oracle/eks_oracle.py: adam_optimize_s) fed by the C port's complex-step gradient, on a
+    16-keypoint sample: same stopping iteration, |d log s| <= 1e-3; then the smoothed outputs at the
+    device's s within 1e-5 of the C port on every frame."""
+    from concurrent.futures import ThreadPoolExecutor
+    from eks_amd import hip_ops, synth
+    from eks_amd.core import (_DeviceProblem, _optimize_on_device, compute_initial_guesses,
+                              run_kalman_smoother)
+    T, K, KS = 100_000, 256, 16
+    dev = hip_ops.require_gpu()
+    y, var = synth.singlecam_observations_torch(T, K, seed=3, device=dev)
+    eye = np.tile(np.eye(2), (K, 1, 1))
+    m0 = np.zeros((K, 2))
+    S0 = eye * y.double().var(dim=0, unbiased=False).cpu().numpy()[:, :, None]
+    ev_head = var[:2000].cpu().numpy()
+    guesses = np.array([compute_initial_guesses(ev_head[:, k]) or 2.0 for k in range(K)])
+    P = _DeviceProblem(y.transpose(0, 1), m0, S0, eye, eye, eye, var)
+    s_dev, info = _optimize_on_device(P, [[k] for k in range(K)], None, guesses, 0.25, (-8.0, 8.0), 1e-2, 300,
+                                      1e-4, 'adam', 0)
+    s = s_dev.cpu().numpy()
+    st = info['state'].cpu().numpy()
+    assert np.all(st[:, 5] == 1.0) and st[:, 4].max() < 300           # every keypoint stopped by the rule
+    assert np.all(np.isfinite(s)) and np.all((s > np.exp(-8.0) * 0.999) & (s < np.exp(8.0) * 1.001))
+
+    # ---- the oracle's trajectory on a sample (all frames; keypoints in parallel threads: ctypes drops the GIL)
+    sel = np.linspace(0, K - 1, KS).round().astype(int)
+    y_s = np.transpose(y[:, sel].cpu().numpy().astype(np.float64), (1, 0, 2)).copy()
+    Rd = np.clip(np.transpose(var[:, sel].cpu().numpy().astype(np.float64), (1, 0, 2)), 1e-12, None)
+    Rc = orc.constant_R_from_timevarying(Rd)
+    u0 = np.array([np.float32(np.log(np.clip(g, 1e-6, 1e3))) for g in guesses[sel]], dtype=np.float64)
+    zero = np.zeros((1, 2, 2))
+
+    def one(k, u):
+        sQ = np.exp(u) * np.eye(2)
+        L, g = c_oracle.nll_directional(y_s[k], Rc[k], m0[sel[k]], S0[sel[k]], np.eye(2), np.eye(2), sQ, zero,
+                                        sQ[None])
+        return L, g[0]
+
+    with ThreadPoolExecutor(max_workers=min(KS, _threads())) as pool:
+        def loss_and_grad(u):
+            res = list(pool.map(lambda k: one(k, u[k]), range(KS)))
+            return np.array([r[0] for r in res]), np.array([r[1] for r in res])
+        u_o, last_o, it_o = orc.adam_optimize_s(loss_and_grad, u0)
+    s_o = np.exp(np.clip(u_o, -8.0, 8.0))
+    np.testing.assert_array_equal(st[sel, 4].astype(int), it_o)        # same stopping iteration
+    assert np.abs(np.log(s[sel]) - np.log(s_o)).max() < 1e-3
+    assert (np.abs(st[sel, 3] - last_o) / np.abs(last_o)).max() < TOL   # the last loss each saw
+
+    # ---- final pass at the device's s, sample against the C port on every frame
+    s2, ms, Vs = run_kalman_smoother(y.transpose(0, 1), m0, S0, eye, eye, eye, var, smooth_param=list(s),
+                                     return_device=True)
+    np.testing.assert_array_equal(s2, s)
+    ms_o, Vs_o, _ = c_oracle.smooth(y_s, Rd, m0[sel], S0[sel], eye[sel], eye[sel], eye[sel], s[sel],
+                                    nthreads=_threads())
+    sel_d = torch.as_tensor(sel, device=dev)
+    ms_g = ms.index_select(0, sel_d).cpu().numpy().astype(np.float64)
+    Vs_g = Vs.index_select(0, sel_d).cpu().numpy().astype(np.float64)
+    assert _kp_rel(ms_g, ms_o) < TOL
+    Vd_g, Vd_o = np.diagonal(Vs_g, axis1=2, axis2=3), np.diagonal(Vs_o, axis1=2, axis2=3)
+    assert (np.abs(Vd_g - Vd_o) / Vd_o).max() < TOL
+    assert np.all(Vs_g[..., 0, 1] == 0) and np.all(Vs_g[..., 1, 0] == 0)
+
+
+# ------------------------------------------------------------------------------------------
 def _sk(X, n):
     from sklearn.decomposition import PCA
     p = PCA(n_components=n).fit(X)
