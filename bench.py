@@ -44,6 +44,7 @@ WORKLOADS = {
     'c2': (10_000, 64, 0),       # configs[1]
     'c5': (50_000, 128 * 32, 0), # configs[4], one GPU's share: 128 sessions x 32 keypoints batched
     'c4': (50_000, 4, 0),        # configs[3]: mirrored multicam, 2 views x 4 paws, D = 3, O = 4 (dense path)
+    'c4w': (50_000, 256, 0),     # the same model on a WIDE session (256 keypoints): can the dense kernels stream?
     'pupil': (100_000, 1, 0),    # IBL pupil AR(1) session, one optimiser iteration per step
     'ekf': (50_000, 16, 0),      # calibrated multicam, 4 cameras, D = 3, O = 8, fixed s
 }
@@ -235,8 +236,9 @@ def cpu_baseline(y_dev, var_dev, T, n_cand, budget_s):
 
 
 def bench_dense(args, T, K, dev, rank, world, lib):
-    """configs[3] shape through the general (D, O) kernels: 2 views x 4 paws, n_latent 3, fixed s.
-    Latency-bound by construction (4 keypoints): reported for the record, not the headline."""
+    """The general (D, O) kernels on the mirrored-multicam model (2 views, n_latent 3, fixed s): configs[3]
+    itself (K = 4 paws: depth-bound by construction - two launches of float64 3x3 chains, no bytes to speak of)
+    and, as `c4w`, the same model on a wide session (K = 256) to see whether the kernels can stream."""
     import torch
     from eks_amd import hip_ops
     D, O = 3, 4
@@ -254,30 +256,54 @@ def bench_dense(args, T, K, dev, rank, world, lib):
     Q = (Q / Q.abs().amax(dim=(1, 2), keepdim=True)).contiguous()
     eye = torch.eye(D, dtype=torch.float64, device=dev).expand(K, D, D).contiguous()
     m0 = torch.zeros(K, D, dtype=torch.float64, device=dev)
+    S0 = (eye * 4.0).contiguous()
     s = torch.full((K,), 10.0, dtype=torch.float64, device=dev)
+    ms = torch.empty((T, K, D), dtype=torch.float32, device=dev)
+    Vs = torch.empty((T, K, D, D), dtype=torch.float32, device=dev)
+
+    def step():
+        hip_ops.smooth(y, var, m0, S0, eye, C, Q, s, out=(ms, Vs))
+
     for _ in range(args.warmup):
-        hip_ops.smooth(y, var, m0, eye * 4.0, eye, C, Q, s)
+        step()
     torch.cuda.synchronize()
+    region_dt = []
+    for _ in range(max(1, args.regions)):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        region_dt.append(time.perf_counter() - t0)
+    dt = float(np.median(region_dt))
     lib.eks_profile_drain(None, 0, None, 0)
     lib.eks_profile_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        hip_ops.smooth(y, var, m0, eye * 4.0, eye, C, Q, s)
+    for _ in range(5):
+        step()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
     lib.eks_profile_enable(0)
     prof = {k: float(np.mean(v)) for k, v in drain_profile(lib).items()}
-    out = {'metric': 'frames*keypoints smoothed/s, mirrored multicam 50k x 4 (D=3, O=4)',
+    narrow = K <= 16
+    longest = max(prof, key=prof.get) if prof else None
+    bytes_per_unit = 4 * O * 2 + 4 * D + 4 * D * D           # y, var in; ms, Vs out: 80 B at D = 3, O = 4
+    whole = bytes_per_unit * T * K / (dt / args.steps) / 1e9
+    out = {'metric': f'frames*keypoints smoothed/s, mirrored multicam {T // 1000}k x {K} (D={D}, O={O})',
            'value': args.steps * T * K / dt, 'unit': 'frames*keypoints/s', 'n_gpus': 1,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+           'regions': len(region_dt), 'ms_per_step_min': 1e3 * min(region_dt) / args.steps,
+           'ms_per_step_max': 1e3 * max(region_dt) / args.steps,
            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
            'data': 'synthetic',
-           'config': {'workload': f'multicam linear T={T} x K={K} keypoints, D={D}, O={O}, fixed s=10'},
-           'roofline': {'bound': 'hbm', 'kernel': 'dense_replay_kernel', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS,
-                        'achieved': 80 * T * K / (prof.get('dense_replay', float('nan')) * 1e-3) / 1e9,
-                        'frac': 80 * T * K / (prof.get('dense_replay', float('nan')) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        'traffic': None, 'stage_avg_ms': prof,
-                        'note': 'latency-bound: 4 keypoints give 4 x ceil(T/256) lanes; not an HBM-bound shape'}}
+           'config': {'workload': f'multicam linear T={T} x K={K} keypoints, D={D}, O={O}, fixed s=10, full ms/Vs'},
+           'roofline': {'bound': 'hbm', 'kernel': 'whole step (' + ' + '.join(sorted(prof)) + ')', 'unit': 'GB/s',
+                        'peak': HBM_PEAK_GBS, 'achieved': whole, 'frac': whole / HBM_PEAK_GBS, 'traffic': None,
+                        'algorithmic_bytes_per_unit': bytes_per_unit, 'stage_avg_ms': prof,
+                        'longest_stage': longest,
+                        'note': ('depth-bound: 4 keypoints x 3 125 chunks = 196 workgroups of dependent float64 3x3 '
+                                 'algebra; the bytes (16 MB) are irrelevant, the fraction is reported for the record'
+                                 if narrow else
+                                 'float64 3x3 algebra per frame (about 800 FMAs per keypoint-frame through summarize, '
+                                 'scan and replay) against 80 B: the FP64 vector rate (78.6 TFLOP/s peak) bounds this '
+                                 'shape at about the same level as HBM does')}}
     print(json.dumps(out), flush=True)
 
 
@@ -445,7 +471,7 @@ def main():
     lib = _lib.load()
 
     T, K, n_cand = WORKLOADS[args.workload]
-    if args.workload == 'c4':
+    if args.workload in ('c4', 'c4w'):
         return bench_dense(args, T, K, dev, rank, world, lib)
     if args.workload == 'pupil':
         return bench_pupil(args, T, dev, lib)

@@ -97,15 +97,17 @@ __global__ __launch_bounds__(2 * kDenseCB) void dense_scan_kernel(DenseGeom G,
   double* mine = lds + (rev ? kDenseCB * NV : 0);
   DElem<double, D> e = live ? load_delem<double, D>(elems + ((size_t)j * G.K + k) * NV)
                             : delem_identity<double, D>();
-  store_delem<double, D>(mine + i * NV, e);
+  // records field-major in LDS (stride kDenseCB between fields: conflict-free; record-major rows of 34
+  // doubles put every 8th lane on the same banks); the smoother's scans need no log-likelihood term
+  store_delem<double, D>(mine + i, e, kDenseCB);
   __syncthreads();
   for (int off = 1; off < kDenseCB; off <<= 1) {
     const bool has = rev ? (i + off < kDenseCB) : (i >= off);
     DElem<double, D> other;
-    if (has) other = load_delem<double, D>(mine + (rev ? i + off : i - off) * NV);
+    if (has) other = load_delem<double, D>(mine + (rev ? i + off : i - off), kDenseCB);
     __syncthreads();
-    if (has) e = rev ? delem_combine(e, other) : delem_combine(other, e);
-    store_delem<double, D>(mine + i * NV, e);
+    if (has) e = rev ? delem_combine<double, D, false>(e, other) : delem_combine<double, D, false>(other, e);
+    store_delem<double, D>(mine + i, e, kDenseCB);
     __syncthreads();
   }
   if (live) store_delem<double, D>((rev ? suf : pre) + ((size_t)j * G.K + k) * NV, e);
@@ -148,25 +150,25 @@ __global__ __launch_bounds__(2 * kDenseCB) void dense_scan_blocks_kernel(DenseGe
     const bool live = q < nblk;
     DElem<double, D> e = live ? load_delem<double, D>(agg + ((size_t)q * G.K + k) * NV)
                               : delem_identity<double, D>();
-    store_delem<double, D>(mine + i * NV, e);
+    store_delem<double, D>(mine + i, e, kDenseCB);
     __syncthreads();
     for (int off = 1; off < kDenseCB; off <<= 1) {
       const bool has = rev ? (i + off < kDenseCB) : (i >= off);
       DElem<double, D> other;
-      if (has) other = load_delem<double, D>(mine + (rev ? i + off : i - off) * NV);
+      if (has) other = load_delem<double, D>(mine + (rev ? i + off : i - off), kDenseCB);
       __syncthreads();
-      if (has) e = rev ? delem_combine(e, other) : delem_combine(other, e);
-      store_delem<double, D>(mine + i * NV, e);
+      if (has) e = rev ? delem_combine<double, D, false>(e, other) : delem_combine<double, D, false>(other, e);
+      store_delem<double, D>(mine + i, e, kDenseCB);
       __syncthreads();
     }
     Vec<double, D> v = cv;
     Mat<double, D> Mx = cM;
     if (!rev) {
-      if (i > 0) delem_apply(load_delem<double, D>(mine + (i - 1) * NV), v, Mx);
-      delem_apply(load_delem<double, D>(mine + (kDenseCB - 1) * NV), cv, cM);
+      if (i > 0) delem_apply(load_delem<double, D>(mine + (i - 1), kDenseCB), v, Mx);
+      delem_apply(load_delem<double, D>(mine + (kDenseCB - 1), kDenseCB), cv, cM);
     } else {
-      if (i + 1 < kDenseCB) delem_back(load_delem<double, D>(mine + (i + 1) * NV), v, Mx);
-      delem_back(load_delem<double, D>(mine), cv, cM);
+      if (i + 1 < kDenseCB) delem_back(load_delem<double, D>(mine + (i + 1), kDenseCB), v, Mx);
+      delem_back(load_delem<double, D>(mine, kDenseCB), cv, cM);
     }
     if (live) {
       double* w = (rev ? bsuffix : bprior) + ((size_t)q * G.K + k) * REC;
@@ -228,9 +230,9 @@ __global__ __launch_bounds__(64) void dense_replay_kernel(DenseGeom G, DenseMode
   const int t0 = j * G.B, len = min(G.B, G.T - t0);
   double ll = 0.0, ch = 0.0;
   dense_replay_chunk_obs<D, EKF>(obs, G.K, k, t0, len, F, sQ, fid, m, P, eta, J,
-                                 filt ? filt + ((size_t)k * G.T + t0) * REC : nullptr, ms, Vs,
+                                 filt ? filt + (size_t)t0 * REC * G.K + k : nullptr, ms, Vs,
                                  vs_diag != 0, EKF ? xlin + ((size_t)k * G.T + t0) * D : nullptr, &ll,
-                                 &ch);
+                                 &ch, (size_t)G.K);
   if constexpr (EKF) {
     ll_chunk[idx] = ll;
     // non-negative doubles order like their bit patterns; a NaN (diverged linearisation) has the
@@ -270,6 +272,9 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
   const int T = d.n_frames, K = d.n_keypoints, D = d.state_dim, O = d.obs_dim;
   if (D < 1 || D > 6 || O < 1 || O > 64) return EKS_ERR_UNSUPPORTED;
   if (ws_bytes < dense_smooth_workspace_bytes(T, K, D, O)) return EKS_ERR_WORKSPACE;
+  // narrow sessions (configs[3]: 4 keypoints) are depth-bound: two launches with the scan in wave
+  // shuffles and the filtered beliefs in LDS (eks_dense_wave.hip); wide ones stream keypoint-major here
+  if (dense_wave_covers(T, K, D, O)) return dense_wave_smooth(d, y, var, Mm, ms, Vs, ws, ws_bytes, st);
   DenseGeom G{K, T, O, dense_chunk(T, K), 0, 0, 0};
   G.nc = (T + G.B - 1) / G.B;
   G.Bs = G.B;

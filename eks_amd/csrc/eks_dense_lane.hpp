@@ -275,7 +275,11 @@ EKS_HD void dense_replay_chunk_obs(const Obs& obs, int K, int k, int t0, int len
                                    const Vec<double, D>& eta_s, const Mat<double, D>& J_s,
                                    double* __restrict__ filt, float* __restrict__ ms,
                                    float* __restrict__ Vs, bool vs_diag, double* __restrict__ xlin,
-                                   double* ll_out, double* resid_out) {
+                                   double* ll_out, double* resid_out, size_t fs = 1) {
+  // fs: distance in doubles between consecutive fields of the scratch records (1: a lane's records are
+  // contiguous; K: the records of the K keypoints are interleaved field by field, so the lanes of a wave -
+  // consecutive keypoints - read and write whole segments.  Per-lane contiguous records cost the wide
+  // multicam shape 1.28 ms in the replay: every 8-byte access of a wave touched 64 different lines.)
   constexpr int REC = D + D * D;
   double ll = 0.0, resid = 0.0;
   for (int i = 0; i < len; ++i) {
@@ -308,12 +312,12 @@ EKS_HD void dense_replay_chunk_obs(const Obs& obs, int K, int k, int t0, int len
       belief_update_obs<D>(obs, k, t, nullptr, m, P);
     }
     if (ms == nullptr) continue;
-    double* rec = filt + (size_t)i * REC;
+    double* rec = filt + (size_t)i * REC * fs;
 #pragma unroll
     for (int a = 0; a < D; ++a) {
-      rec[a] = m.a[a];
+      rec[a * fs] = m.a[a];
 #pragma unroll
-      for (int b = 0; b < D; ++b) rec[D + a * D + b] = P.a[a][b];
+      for (int b = 0; b < D; ++b) rec[(D + a * D + b) * fs] = P.a[a][b];
     }
   }
   if constexpr (EKF) {
@@ -341,14 +345,14 @@ EKS_HD void dense_replay_chunk_obs(const Obs& obs, int K, int k, int t0, int len
   condition_on_info(m, P, eta_s, J_s, m_s, P_s, logdet);      // smoothed last frame of the chunk
   emit(len - 1, m_s, P_s);
   for (int i = len - 2; i >= 0; --i) {
-    const double* rec = filt + (size_t)i * REC;
+    const double* rec = filt + (size_t)i * REC * fs;
     Vec<double, D> mf;
     Mat<double, D> Pf;
 #pragma unroll
     for (int a = 0; a < D; ++a) {
-      mf.a[a] = rec[a];
+      mf.a[a] = rec[a * fs];
 #pragma unroll
-      for (int b = 0; b < D; ++b) Pf.a[a][b] = rec[D + a * D + b];
+      for (int b = 0; b < D; ++b) Pf.a[a][b] = rec[(D + a * D + b) * fs];
     }
     const Mat<double, D> FP = f_identity ? Pf : mat_mul(F, Pf);                 // F Pf
     const Mat<double, D> Pp = mat_symmetrize(

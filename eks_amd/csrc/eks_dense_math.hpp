@@ -413,7 +413,9 @@ EKS_HD void delem_back(const DElem<S, D>& e, Vec<S, D>& eta, Mat<S, D>& J) {
 //   A = A_j M A_i           b = A_j M (b_i + C_i eta_j) + b_j        C = A_j M C_i A_j^T + C_j
 //   eta = A_i^T M^T (eta_j - J_j b_i) + eta_i                        J = A_i^T M^T J_j A_i + J_i
 //   ell = ell_i + ell_j - log|G|/2 + b_i.eta_j - b_i^T J_j b_i / 2 + v^T (M C_i) v / 2,  v = eta_j - J_j b_i
-template <typename S, int D>
+//   (ELL = false: the smoother's scans do not need the log-likelihood term - three logs and two
+//    quadratic forms less per composition)
+template <typename S, int D, bool ELL = true>
 EKS_HD DElem<S, D> delem_combine(const DElem<S, D>& ei, const DElem<S, D>& ej) {
   const Mat<S, D> L = chol_psd(ei.C);
   const Mat<S, D> JL = mat_mul(ej.J, L);
@@ -456,11 +458,15 @@ EKS_HD DElem<S, D> delem_combine(const DElem<S, D>& ei, const DElem<S, D>& ej) {
   for (int i = 0; i < D; ++i) o.eta.a[i] = AtMtv.a[i] + ei.eta.a[i];
   const Mat<S, D> MtJ = mat_symmetrize(mat_sub(ej.J, mat_mul(JL, chol_solve_mat(Lg, JLt))));
   o.J = mat_symmetrize(mat_add(mat_mul_tn(ei.A, mat_mul(MtJ, ei.A)), ei.J));
-  S logdet = S(0.0);
+  if constexpr (ELL) {
+    S logdet = S(0.0);
 #pragma unroll
-  for (int i = 0; i < D; ++i) logdet = logdet + S(2.0) * log_s(Lg.a[i][i]);
-  o.ell = ei.ell + ej.ell - S(0.5) * logdet + dot(ei.b, ej.eta) - S(0.5) * dot(ei.b, Jb) +
-          S(0.5) * dot(v, mat_vec(MC, v));
+    for (int i = 0; i < D; ++i) logdet = logdet + S(2.0) * log_s(Lg.a[i][i]);
+    o.ell = ei.ell + ej.ell - S(0.5) * logdet + dot(ei.b, ej.eta) - S(0.5) * dot(ei.b, Jb) +
+            S(0.5) * dot(v, mat_vec(MC, v));
+  } else {
+    o.ell = S(0.0);
+  }
   return o;
 }
 

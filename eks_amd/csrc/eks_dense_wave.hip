@@ -1,0 +1,546 @@
+// gfx950 kernels for the general (D, O) smoother on NARROW sessions - BASELINE configs[3]: mirrored
+// multicam, 2 views x 4 paws x 50 000 frames, D = 3, O = 4 (reference eks/multicam_smoother.py:409-443,
+// :481-511) - where a few keypoints offer no parallelism but time.  Such a problem is DEPTH-bound: what
+// counts is the longest chain of dependent float64 operations and of dependent memory round trips, not
+// bytes.  Round 1's three-phase form (eks_dense.hip) spent 149 us on configs[3]: per-frame loads one HBM
+// latency apart, filtered beliefs through a float64 scratch stream, and the scan as two launches of
+// barrier-separated LDS passes.  Here (round 3):
+//
+//   DW1 dw_summarize : block = (keypoint, 64 consecutive 16-frame chunks), lane = chunk.  A lane requests
+//                      all rows of its chunk at once (one memory latency per chunk instead of one per
+//                      frame) and builds the chunk element in registers; then the block's two waves - both
+//                      hold the same 64 elements, no exchange - run the forward and the reverse
+//                      Hillis-Steele scan of them by WAVE SHUFFLES (no LDS, no barrier): exclusive prefix /
+//                      suffix per chunk and the block aggregate.  The first scan level of the old design,
+//                      its element stores and loads and one kernel boundary are gone.
+//   DW2 dw_replay    : same blocks.  Wave 0 reduces the aggregates of the earlier blocks (shuffle tree) and
+//                      pushes the prior through them, wave 1 pulls the information back through the later
+//                      ones; one LDS hand-over.  Then lane = chunk: exact filter from the chunk's entering
+//                      belief with the filtered beliefs kept in LDS ([frame][field][lane], conflict-free),
+//                      fuse with the future's information, RTS backwards, outputs.  The second scan level is
+//                      part of this launch: two launches in all instead of four.
+//
+// Matrices are float64 in registers; R_t is diagonal, so a frame's observations are absorbed one scalar at
+// a time (rank-1 forms, no inverse); the scan's compositions use the Cholesky / Woodbury forms of
+// eks_dense_math.hpp without the log-likelihood term the smoother does not need.  Wide sessions (more than
+// ~1000 blocks) keep the keypoint-major kernels of eks_dense.hip, whose rows are coalesced across keypoints.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "eks_dense_lane.hpp"
+#include "eks_internal.hpp"
+
+namespace eks {
+
+#ifndef EKS_DW_B
+#define EKS_DW_B 8
+#endif
+constexpr int kDwB = EKS_DW_B;   // frames per lane (measured on configs[3]: 16 -> 94 us, 8 -> see DESIGN.md)
+
+// Diagnostic build only (-DEKS_DW_STAMPS, tools/dw_stamps.py): wave 0's lane 0 of the first 64 blocks
+// stamps the 100 MHz real-time counter at the phase boundaries; nothing reads the stamps but the tool.
+#ifdef EKS_DW_STAMPS
+__device__ unsigned long long g_dw_stamps[2][64][16];
+#define DW_STAMP(kern, ph)                                                              \
+  do {                                                                                  \
+    if ((threadIdx.x & 127) == 0 && blockIdx.x < 32) g_dw_stamps[kern][blockIdx.x * 2 + (threadIdx.x >> 7)][ph] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define DW_STAMP(kern, ph) do { } while (0)
+#endif
+
+struct DwGeom {
+  int K, T, nc, nwb;         // keypoints, frames, chunks (ceil(T / kDwB)), blocks per keypoint (ceil(nc / 64))
+};
+
+// ---- an element moves between lanes as A (D x D), the upper triangles of C and J, b and eta ----------
+template <int D>
+__device__ __forceinline__ DElem<double, D> delem_shfl_up(const DElem<double, D>& e, int off) {
+  DElem<double, D> o;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    o.b.a[i] = __shfl_up(e.b.a[i], off);
+    o.eta.a[i] = __shfl_up(e.eta.a[i], off);
+#pragma unroll
+    for (int j = 0; j < D; ++j) o.A.a[i][j] = __shfl_up(e.A.a[i][j], off);
+#pragma unroll
+    for (int j = i; j < D; ++j) {
+      o.C.a[i][j] = o.C.a[j][i] = __shfl_up(e.C.a[i][j], off);
+      o.J.a[i][j] = o.J.a[j][i] = __shfl_up(e.J.a[i][j], off);
+    }
+  }
+  o.ell = 0.0;
+  return o;
+}
+template <int D>
+__device__ __forceinline__ DElem<double, D> delem_shfl_down(const DElem<double, D>& e, int off) {
+  DElem<double, D> o;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    o.b.a[i] = __shfl_down(e.b.a[i], off);
+    o.eta.a[i] = __shfl_down(e.eta.a[i], off);
+#pragma unroll
+    for (int j = 0; j < D; ++j) o.A.a[i][j] = __shfl_down(e.A.a[i][j], off);
+#pragma unroll
+    for (int j = i; j < D; ++j) {
+      o.C.a[i][j] = o.C.a[j][i] = __shfl_down(e.C.a[i][j], off);
+      o.J.a[i][j] = o.J.a[j][i] = __shfl_down(e.J.a[i][j], off);
+    }
+  }
+  o.ell = 0.0;
+  return o;
+}
+
+// observation rows of ONE keypoint (the block's keypoint is uniform: these live in scalar registers)
+template <int D, int O>
+struct ObsRows {
+  double c[O][D];
+  __device__ __forceinline__ Vec<double, D> row(int o) const {
+    Vec<double, D> h;
+#pragma unroll
+    for (int i = 0; i < D; ++i) h.a[i] = c[o][i];
+    return h;
+  }
+};
+template <int D, int O>
+__device__ __forceinline__ ObsRows<D, O> load_obs_rows(const DenseModelPtrs& M, int k) {
+  ObsRows<D, O> R;
+#pragma unroll
+  for (int o = 0; o < O; ++o)
+#pragma unroll
+    for (int i = 0; i < D; ++i) R.c[o][i] = M.C[((size_t)k * O + o) * D + i];
+  return R;
+}
+
+// A lane's chunk: all kDwB rows (O floats of y, O of var each) are requested at once - one memory latency
+// per chunk - and parked in LDS as [frame][lane][O], so the frame loops below stay ROLLED: these kernels run
+// their code once per wave, and straight-line code for 16 frames x O observations (38 KB at O = 4) was
+// fetched cold from L2 at ~7 cycles per instruction (in-kernel stamps, profiles/r03_probes.txt).
+template <int O>
+__device__ __forceinline__ void dw_stage_rows(const float* __restrict__ y, const float* __restrict__ var,
+                                              size_t row0, size_t row_stride, int nrows, float* __restrict__ ly,
+                                              float* __restrict__ lv, int lane) {
+  // a keypoint's O values of one frame are contiguous and (O even) 8-byte, (O % 4 == 0) 16-byte aligned
+  constexpr int W = O % 4 == 0 ? 4 : 2;
+  typedef float fw __attribute__((ext_vector_type(W)));
+  fw a[kDwB][O / W], b[kDwB][O / W];
+#pragma unroll
+  for (int i = 0; i < kDwB; ++i) {
+    const size_t r = row0 + (size_t)i * row_stride;
+#pragma unroll
+    for (int o = 0; o < O / W; ++o) {
+      if (i < nrows) {
+        a[i][o] = *reinterpret_cast<const fw*>(y + r + o * W);
+        b[i][o] = *reinterpret_cast<const fw*>(var + r + o * W);
+      } else {
+        a[i][o] = fw(0.f);
+        b[i][o] = fw(1.f);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kDwB; ++i)
+#pragma unroll
+    for (int o = 0; o < O / W; ++o) {
+      *reinterpret_cast<fw*>(ly + ((size_t)i * 64 + lane) * O + o * W) = a[i][o];
+      *reinterpret_cast<fw*>(lv + ((size_t)i * 64 + lane) * O + o * W) = b[i][o];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// SUBS wave pairs per workgroup (each pair = one (keypoint, 64 chunks) unit): with more units than CUs, two
+// 2-wave workgroups on one CU could land on the same SIMDs and halve each other's float64 rate (measured:
+// 392 units of 2 waves 45 us, their own lifetime 28 us); a 4-wave workgroup spreads over the CU's four SIMDs.
+template <int D, int O, int SUBS>
+__global__ __launch_bounds__(128 * SUBS) void dw_summarize_kernel(DwGeom G, DenseModelPtrs M,
+                                                          const double* __restrict__ s,
+                                                          const float* __restrict__ y,
+                                                          const float* __restrict__ var,
+                                                          double* __restrict__ pre_ex,
+                                                          double* __restrict__ suf_ex,
+                                                          double* __restrict__ agg,
+                                                          double* __restrict__ first) {
+  constexpr int NV = delem_doubles<D>();
+  __shared__ float ly[2 * SUBS][kDwB * 64 * O], lv[2 * SUBS][kDwB * 64 * O];   // each wave parks its own copy
+  const int unit = blockIdx.x * SUBS + (threadIdx.x >> 7);
+  if (unit >= G.K * G.nwb) return;                    // (no barrier in this kernel)
+  const int k = unit % G.K, wb = unit / G.K;
+  const int lane = threadIdx.x & 63;
+  const bool rev = (threadIdx.x & 64) != 0;           // odd wave: the reverse scan
+  const int j = wb * 64 + lane;
+  const bool live = j < G.nc;
+  DW_STAMP(0, 0);
+  const int t0 = live ? j * kDwB : 0, len = live ? min(kDwB, G.T - t0) : 0;
+  float* my_y = ly[threadIdx.x >> 6];
+  float* my_v = lv[threadIdx.x >> 6];
+  dw_stage_rows<O>(y, var, ((size_t)t0 * G.K + k) * O, (size_t)G.K * O, len, my_y, my_v, lane);
+  Mat<double, D> F, sQ;
+  bool fid;
+  load_dynamics<double, D>(M, k, s[k], F, sQ, fid);
+  const ObsRows<D, O> H = load_obs_rows<D, O>(M, k);
+  DElem<double, D> e = delem_identity<double, D>();
+  DW_STAMP(0, 1);
+#pragma unroll 1
+  for (int i = 0; i < len; ++i) {
+    if (t0 + i == 0) continue;                        // frame 0 updates the prior itself (dw_replay)
+    delem_predict(e, F, sQ, fid);
+    const float* py = my_y + ((size_t)i * 64 + lane) * O;
+    const float* pv = my_v + ((size_t)i * 64 + lane) * O;
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+      const float v = pv[o];
+      delem_observe(e, H.row(o), (double)py[o], v > kVarFloor ? (double)v : (double)kVarFloor, false);
+    }
+  }
+  DW_STAMP(0, 2);
+  // inclusive scan over the block's 64 chunk elements, forward in wave 0, reverse in wave 1 (rolled: the
+  // composition's code exists once)
+  DElem<double, D> x = e;
+#pragma unroll 1
+  for (int off = 1; off < 64; off <<= 1) {
+    if (!rev) {
+      const DElem<double, D> other = delem_shfl_up<D>(x, off);
+      if (lane >= off) x = delem_combine<double, D, false>(other, x);
+    } else {
+      const DElem<double, D> other = delem_shfl_down<D>(x, off);
+      if (lane + off < 64) x = delem_combine<double, D, false>(x, other);
+    }
+  }
+  DW_STAMP(0, 3);
+  if (!rev) {
+    if (lane == 63) store_delem<double, D>(agg + ((size_t)wb * G.K + k) * NV, x);
+    DElem<double, D> ex = delem_shfl_up<D>(x, 1);     // exclusive prefix: the elements before this chunk
+    if (lane == 0) ex = delem_identity<double, D>();
+    if (live) store_delem<double, D>(pre_ex + ((size_t)j * G.K + k) * NV, ex);
+    if (wb == 0 && lane == 0) {                       // the belief the scan starts from: prior + frame 0
+      Vec<double, D> m;
+      Mat<double, D> P;
+      load_prior<D>(M, k, m, P);
+      belief_update_obs<D>(make_linear_obs<D>(y, var, G.K, O, M), k, 0, nullptr, m, P);
+      double* r = first + (size_t)k * (D + D * D);
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        r[a] = m.a[a];
+#pragma unroll
+        for (int b = 0; b < D; ++b) r[D + a * D + b] = P.a[a][b];
+      }
+    }
+    DW_STAMP(0, 4);
+  } else {
+    DElem<double, D> ex = delem_shfl_down<D>(x, 1);   // exclusive suffix: the elements after this chunk
+    if (lane == 63) ex = delem_identity<double, D>();
+    if (live) store_delem<double, D>(suf_ex + ((size_t)j * G.K + k) * NV, ex);
+  }
+}
+
+// Time-ordered composition of the block aggregates [q_lo, q_hi) of keypoint k, delivered in lane 0: every
+// lane composes its run of ceil(n / 64) consecutive aggregates, then a shuffle tree over the lanes that hold
+// one (depth: run length - 1 + ceil(log2(lanes)) compositions; rolled: one copy of the composition's code).
+template <int D>
+__device__ __forceinline__ DElem<double, D> dw_compose_range(const double* __restrict__ agg, int K, int k,
+                                                             int q_lo, int q_hi, int lane) {
+  constexpr int NV = delem_doubles<D>();
+  const int n = q_hi - q_lo, per = (n + 63) / 64;
+  const int nl = per > 0 ? (n + per - 1) / per : 0;   // lanes that hold a run
+  DElem<double, D> x = delem_identity<double, D>();
+  const int a0 = q_lo + lane * per, a1 = min(q_hi, a0 + per);
+  if (a0 < a1) {
+    x = load_delem<double, D>(agg + ((size_t)a0 * K + k) * NV);
+#pragma unroll 1
+    for (int q = a0 + 1; q < a1; ++q)
+      x = delem_combine<double, D, false>(x, load_delem<double, D>(agg + ((size_t)q * K + k) * NV));
+  }
+#pragma unroll 1
+  for (int off = 1; off < nl; off <<= 1) {
+    const DElem<double, D> other = delem_shfl_down<D>(x, off);
+    if ((lane & (2 * off - 1)) == 0 && lane + off < nl) x = delem_combine<double, D, false>(x, other);
+  }
+  return x;
+}
+
+template <int D, int O, int SUBS>
+__global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseModelPtrs M,
+                                                       const double* __restrict__ s,
+                                                       const float* __restrict__ y,
+                                                       const float* __restrict__ var,
+                                                       const double* __restrict__ pre_ex,
+                                                       const double* __restrict__ suf_ex,
+                                                       const double* __restrict__ agg,
+                                                       const double* __restrict__ first,
+                                                       float* __restrict__ ms, float* __restrict__ Vs,
+                                                       int vs_diag) {
+  constexpr int NV = delem_doubles<D>();
+  constexpr int NF = D + D * (D + 1) / 2;             // filtered mean + upper triangle of the covariance
+  constexpr int REC = D + D * D;
+  __shared__ double recs_all[SUBS][kDwB * NF * 64];   // [frame][field][lane]
+  __shared__ double xch_all[SUBS][REC];
+  __shared__ float ly_all[SUBS][kDwB * 64 * O], lv_all[SUBS][kDwB * 64 * O];
+  const int sub = threadIdx.x >> 7;
+  double* recs = recs_all[sub];
+  double* xch = xch_all[sub];
+  float* ly = ly_all[sub];
+  float* lv = lv_all[sub];
+  const int unit = blockIdx.x * SUBS + sub;
+  if (unit >= G.K * G.nwb) {                          // a spare wave pair still meets the workgroup's barrier
+    __syncthreads();
+    return;
+  }
+  const int k = unit % G.K, wb = unit / G.K;
+  const int lane = threadIdx.x & 63;
+  const bool rev = (threadIdx.x & 64) != 0;
+  const int j = wb * 64 + lane;
+  const bool live = j < G.nc;
+  if (rev) {
+    // information about the state leaving this block, from the aggregates of all later blocks
+    Vec<double, D> eta = vec_zero<double, D>();
+    Mat<double, D> J = mat_zero<double, D>();
+    if (wb + 1 < G.nwb) {
+      const DElem<double, D> tot = dw_compose_range<D>(agg, G.K, k, wb + 1, G.nwb, lane);
+      if (lane == 0) delem_back(tot, eta, J);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        xch[a] = eta.a[a];
+#pragma unroll
+        for (int b = 0; b < D; ++b) xch[D + a * D + b] = J.a[a][b];
+      }
+    }
+    __syncthreads();
+    return;
+  }
+  // ---- wave 0: everything this lane will need is requested before the reduction starts
+  DW_STAMP(1, 0);
+  Mat<double, D> F, sQ;
+  bool fid;
+  load_dynamics<double, D>(M, k, s[k], F, sQ, fid);
+  const ObsRows<D, O> H = load_obs_rows<D, O>(M, k);
+  const int t0 = live ? j * kDwB : 0, len = live ? min(kDwB, G.T - t0) : 0;
+  dw_stage_rows<O>(y, var, ((size_t)t0 * G.K + k) * O, (size_t)G.K * O, len, ly, lv, lane);
+  DElem<double, D> pe = delem_identity<double, D>(), se = delem_identity<double, D>();
+  if (live) {
+    pe = load_delem<double, D>(pre_ex + ((size_t)j * G.K + k) * NV);
+    se = load_delem<double, D>(suf_ex + ((size_t)j * G.K + k) * NV);
+  }
+  // belief entering this block: the prior (updated with frame 0) through the aggregates of all earlier blocks
+  Vec<double, D> m;
+  Mat<double, D> P;
+  {
+    const double* f0 = first + (size_t)k * REC;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      m.a[a] = f0[a];
+#pragma unroll
+      for (int b = 0; b < D; ++b) P.a[a][b] = f0[D + a * D + b];
+    }
+  }
+  DW_STAMP(1, 1);
+  if (wb > 0) {
+    const DElem<double, D> tot = dw_compose_range<D>(agg, G.K, k, 0, wb, lane);
+    if (lane == 0) delem_apply(tot, m, P);
+#pragma unroll
+    for (int a = 0; a < D; ++a) {                     // lane 0's belief to every lane
+      m.a[a] = __shfl(m.a[a], 0);
+#pragma unroll
+      for (int b = 0; b < D; ++b) P.a[a][b] = __shfl(P.a[a][b], 0);
+    }
+  }
+  DW_STAMP(1, 2);
+  __syncthreads();                                    // wave 1's information is in LDS
+  DW_STAMP(1, 3);
+  Vec<double, D> eta;
+  Mat<double, D> J;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    eta.a[a] = xch[a];
+#pragma unroll
+    for (int b = 0; b < D; ++b) J.a[a][b] = xch[D + a * D + b];
+  }
+  if (!live) return;
+  if (lane > 0) delem_apply(pe, m, P);                // through the block's chunks before this one
+  if (lane < 63 && j + 1 < G.nc) delem_back(se, eta, J);   // back through those after it
+  if (j == 0) load_prior<D>(M, k, m, P);              // chunk 0 replays frame 0's update of the prior itself
+  DW_STAMP(1, 4);
+  // ---- exact filter over the chunk; filtered beliefs to LDS
+  double* mine = recs + lane;
+#pragma unroll 1
+  for (int i = 0; i < len; ++i) {
+    if (t0 + i > 0) {
+      if (!fid) {
+        m = mat_vec(F, m);
+        P = mat_mul_nt(mat_mul(F, P), F);
+      }
+      P = mat_add(P, sQ);
+    }
+    const float* py = ly + ((size_t)i * 64 + lane) * O;
+    const float* pv = lv + ((size_t)i * 64 + lane) * O;
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+      const Vec<double, D> h = H.row(o);
+      const Vec<double, D> u = mat_vec(P, h);
+      const float vf = pv[o];
+      const double r = vf > kVarFloor ? (double)vf : (double)kVarFloor;
+      const double g = 1.0 / (r + dot(h, u));
+      const double gd = g * ((double)py[o] - dot(h, m));
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        m.a[a] += u.a[a] * gd;
+#pragma unroll
+        for (int b = 0; b < D; ++b) P.a[a][b] -= u.a[a] * u.a[b] * g;
+      }
+    }
+    double* rc = mine + (size_t)i * NF * 64;
+    int f = 0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) rc[(f++) * 64] = m.a[a];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = a; b < D; ++b) rc[(f++) * 64] = 0.5 * (P.a[a][b] + P.a[b][a]);
+  }
+  // a frame's outputs of one keypoint are contiguous (D and D x D floats, 4-byte aligned): few wide stores
+  // instead of D + D x D scalar ones - each store instruction of these lanes touches 64 different lines
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+  auto put = [&](float* __restrict__ dst, const float* v, auto n_tag) {
+    constexpr int n = decltype(n_tag)::value;
+    int q = 0;
+#pragma unroll
+    // PLAIN stores: a line of ms / Vs is shared by the K keypoints' workgroups, each writing its 12 / 36
+    // bytes; the L2s merge such pieces, non-temporal stores send every piece on by itself (configs[3]:
+    // replay 54 -> 42 us)
+    for (; q + 4 <= n; q += 4) *reinterpret_cast<f4u*>(dst + q) = f4u{v[q], v[q + 1], v[q + 2], v[q + 3]};
+    if constexpr (n % 4 >= 2) {
+      *reinterpret_cast<f2u*>(dst + q) = f2u{v[q], v[q + 1]};
+      q += 2;
+    }
+    if constexpr (n % 2 == 1) dst[q] = v[q];
+  };
+  auto emit = [&](int i, const Vec<double, D>& mo, const Mat<double, D>& Po) {
+    const size_t ko = (size_t)(t0 + i) * G.K + k;
+    float mv[D], pv[D * D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      mv[a] = (float)mo.a[a];
+#pragma unroll
+      for (int b = 0; b < D; ++b) pv[a * D + b] = (float)Po.a[a][b];
+    }
+    put(ms + ko * D, mv, std::integral_constant<int, D>{});
+    if (vs_diag) {
+      float dv[D];
+#pragma unroll
+      for (int a = 0; a < D; ++a) dv[a] = pv[a * D + a];
+      put(Vs + ko * D, dv, std::integral_constant<int, D>{});
+    } else {
+      put(Vs + ko * D * D, pv, std::integral_constant<int, D * D>{});
+    }
+  };
+  DW_STAMP(1, 5);
+  Vec<double, D> m_s;
+  Mat<double, D> P_s;
+  double logdet;
+  condition_on_info(m, P, eta, J, m_s, P_s, logdet);  // smoothed last frame of the chunk
+  emit(len - 1, m_s, P_s);
+  DW_STAMP(1, 6);
+  for (int i = len - 2; i >= 0; --i) {                // RTS backwards over the LDS records
+    const double* rc = mine + (size_t)i * NF * 64;
+    Vec<double, D> mf;
+    Mat<double, D> Pf;
+    int f = 0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) mf.a[a] = rc[(f++) * 64];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = a; b < D; ++b) Pf.a[a][b] = Pf.a[b][a] = rc[(f++) * 64];
+    const Mat<double, D> FP = fid ? Pf : mat_mul(F, Pf);
+    const Mat<double, D> Pp = mat_symmetrize(mat_add(fid ? Pf : mat_mul_nt(FP, F), sQ));
+    const Mat<double, D> Z = chol_solve_mat(chol_psd(Pp), FP);      // Pp^-1 F Pf = G^T
+    const Vec<double, D> mp = fid ? mf : mat_vec(F, mf);
+    Vec<double, D> dm;
+#pragma unroll
+    for (int a = 0; a < D; ++a) dm.a[a] = m_s.a[a] - mp.a[a];
+    const Vec<double, D> Gdm = mat_t_vec(Z, dm);
+#pragma unroll
+    for (int a = 0; a < D; ++a) m_s.a[a] = mf.a[a] + Gdm.a[a];
+    P_s = mat_symmetrize(mat_add(Pf, mat_mul(mat_mul_tn(Z, mat_sub(P_s, Pp)), Z)));
+    emit(i, m_s, P_s);
+  }
+  DW_STAMP(1, 7);
+}
+
+// ------------------------------------------------------------------------------------------------------
+bool dense_wave_covers(int T, int K, int D, int O) {
+  if (knob_int(KNOB_DENSE_LEGACY, 0)) return false;
+  if (!(D == 2 || D == 3) || !(O == 2 || O == 4 || O == 6 || O == 8)) return false;
+  const long nc = ((long)T + kDwB - 1) / kDwB, nwb = (nc + 63) / 64;
+  return (long)K * nwb <= 1024;                       // depth-bound problems: every block resident at once
+}
+
+int dense_wave_smooth(const eks_dims_t& d, const float* y, const float* var, const DenseModel& Mm, float* ms,
+                      float* Vs, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int T = d.n_frames, K = d.n_keypoints, D = d.state_dim, O = d.obs_dim;
+  DwGeom G{K, T, (T + kDwB - 1) / kDwB, 0};
+  G.nwb = (G.nc + 63) / 64;
+  const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
+  const size_t need = 2 * align_up((size_t)G.nc * K * nv * 8, 256) + align_up((size_t)G.nwb * K * nv * 8, 256) +
+                      align_up((size_t)K * rec * 8, 256);
+  if (ws_bytes < need) return EKS_ERR_WORKSPACE;
+  char* p = static_cast<char*>(ws);
+  double* pre_ex = reinterpret_cast<double*>(p);
+  p += align_up((size_t)G.nc * K * nv * 8, 256);
+  double* suf_ex = reinterpret_cast<double*>(p);
+  p += align_up((size_t)G.nc * K * nv * 8, 256);
+  double* agg = reinterpret_cast<double*>(p);
+  p += align_up((size_t)G.nwb * K * nv * 8, 256);
+  double* first = reinterpret_cast<double*>(p);
+  const DenseModelPtrs M{Mm.m0, Mm.S0, Mm.A, Mm.C, Mm.Q};
+  const int vs_diag = (d.flags & EKS_FLAG_VS_DIAG) ? 1 : 0;
+  const int units = K * G.nwb;
+  const bool two = units > 256;                       // more (keypoint, 64-chunk) units than CUs: 4-wave workgroups
+  const dim3 grid((unsigned)(two ? (units + 1) / 2 : units)), block(two ? 256 : 128);
+#define EKS_DW_S(DD, OO, SS)                                                                             \
+  {                                                                                                      \
+    {                                                                                                    \
+      ProfScope ps("dense_summarize", st);                                                               \
+      hipLaunchKernelGGL((dw_summarize_kernel<DD, OO, SS>), grid, block, 0, st, G, M, Mm.s, y, var,       \
+                         pre_ex, suf_ex, agg, first);                                                    \
+    }                                                                                                    \
+    ProfScope ps("dense_replay", st);                                                                    \
+    hipLaunchKernelGGL((dw_replay_kernel<DD, OO, SS>), grid, block, 0, st, G, M, Mm.s, y, var, pre_ex,    \
+                       suf_ex, agg, first, ms, Vs, vs_diag);                                             \
+  }
+#define EKS_DW(DD, OO)        \
+  if (two)                    \
+    EKS_DW_S(DD, OO, 2)       \
+  else                        \
+    EKS_DW_S(DD, OO, 1)
+#define EKS_DW_O(DD)                    \
+  switch (O) {                          \
+    case 2: EKS_DW(DD, 2) break;        \
+    case 4: EKS_DW(DD, 4) break;        \
+    case 6: EKS_DW(DD, 6) break;        \
+    case 8: EKS_DW(DD, 8) break;        \
+    default: return EKS_ERR_UNSUPPORTED; \
+  }
+  if (D == 2) {
+    EKS_DW_O(2)
+  } else if (D == 3) {
+    EKS_DW_O(3)
+  } else {
+    return EKS_ERR_UNSUPPORTED;
+  }
+#undef EKS_DW_O
+#undef EKS_DW
+#undef EKS_DW_S
+  return hip_status(hipGetLastError());
+}
+
+}  // namespace eks
+
+#ifdef EKS_DW_STAMPS
+extern "C" int eks_debug_dw_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(eks::g_dw_stamps), sizeof(eks::g_dw_stamps));
+}
+#endif

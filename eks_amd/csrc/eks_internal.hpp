@@ -59,6 +59,10 @@ struct DenseModel {
 size_t dense_smooth_workspace_bytes(int T, int K, int D, int O);
 int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const DenseModel& M,
                  float* ms, float* Vs, void* ws, size_t ws_bytes, hipStream_t st);
+// narrow sessions: wave-per-64-chunks form (eks_dense_wave.hip)
+bool dense_wave_covers(int T, int K, int D, int O);
+int dense_wave_smooth(const eks_dims_t& d, const float* y, const float* var, const DenseModel& M, float* ms,
+                      float* Vs, void* ws, size_t ws_bytes, hipStream_t st);
 size_t dense_nll_workspace_bytes(int T, int K, int D, int O, int n_cand);
 int dense_nll(const eks_dims_t& d, const float* y, const double* rconst, const DenseModel& M,
               const double* s_cand, int n_cand, int per_keypoint, double* nll, double* dnll,

@@ -1,0 +1,6 @@
+# A/B of dense-wave builds on configs[3] (same box, alternating): tools/c4_ab.sh default b16 ...
+for rep in 1 2; do
+for v in "$@"; do
+  if [ $v = default ]; then L=""; else L="EKS_HIP_LIB=build_alt/$v/libeks_hip.so"; fi
+  echo -n "$v: "; env $L python bench.py --workload c4 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step']*1e3,1), {k: round(v*1e3,1) for k,v in d['roofline']['stage_avg_ms'].items()})"
+done; done
