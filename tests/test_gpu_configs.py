@@ -7,12 +7,12 @@ same inputs - whole-output comparison in the spirit of the reference's integrati
   C3  singlecam 100 000 x 256, 64-candidate NLL grid + smooth            run_kalman_smoother(s_mode='grid')
   C4  mirrored multicam 2 views x 4 paws, 50 000 frames, 3-D state       ensemble_kalman_smoother_multicam
   C5  one GPU's share of 1024 sessions x 50 000 x 32 keypoints           distributed.smooth_sessions_batched
-      (128 sessions -> one 4096-keypoint batch)
+      (128 sessions -> one 4096-keypoint batch, full (K,T,2,2) covariances)
 
 Bars (BASELINE.json): smoothed means / variances within 1e-5 relative to the keypoint's magnitude
-(variances elementwise), NLL within 1e-5 relative, grid argmin indices bit-exact.  C2 and C4
-compare every output column of every keypoint; C3 and C5 compare every frame of a 32-keypoint
-sample against the oracle (the C port needs ~0.5 core-seconds per keypoint on C3's grid) and
+(variances elementwise - every bar in this file is the stated 1e-5), NLL within 1e-5 relative, grid
+argmin indices bit-exact.  C2 and C4 compare every output column of every keypoint; C3 (grid and Adam)
+and C5 compare every frame of a 32- / 16- / 32-keypoint sample against the oracle (the C port needs ~0.5 core-seconds per keypoint on C3's grid) and
 check the remaining keypoints for finiteness and for the size-independent identities of the
 smoother (posterior variance below both the prior-predictive and the observation variance,
 smoothed path inside the observations' envelope)."""
@@ -60,9 +60,9 @@ def test_c2_singlecam_10k_x_64_x_5_fixed_s():
     col_scale = np.abs(ref).max(axis=0)
     assert (np.abs(got - ref) / col_scale).max() < TOL                    # every column, every frame
     pv = slice(7, None, 9)                                                # posterior variances: elementwise
-    assert (np.abs(got[:, pv] - ref[:, pv]) / ref[:, pv]).max() < 5e-5
+    assert (np.abs(got[:, pv] - ref[:, pv]) / ref[:, pv]).max() < TOL
     pv2 = slice(8, None, 9)
-    assert (np.abs(got[:, pv2] - ref[:, pv2]) / ref[:, pv2]).max() < 5e-5
+    assert (np.abs(got[:, pv2] - ref[:, pv2]) / ref[:, pv2]).max() < TOL
 
 
 # ------------------------------------------------------------------------------------------
@@ -227,7 +227,7 @@ def test_c4_mirrored_multicam_2_views_x_4_paws_50k_frames():
     lat = df_3d.values.reshape(T, K, 6)
     lat_o = lat_o.reshape(T, K, 6)
     assert (np.abs(lat[..., :3] - lat_o[..., :3]) / np.abs(lat_o[..., :3]).max(axis=(0, 2), keepdims=True)).max() < TOL
-    assert (np.abs(lat[..., 3:] - lat_o[..., 3:]) / lat_o[..., 3:]).max() < 5e-5
+    assert (np.abs(lat[..., 3:] - lat_o[..., 3:]) / lat_o[..., 3:]).max() < TOL          # elementwise
 
     # the reference's default (smooth_param=None -> Adam, eks/core.py:562-699) on the same session,
     # loss on a 6 000-frame crop (s_frames): the device optimiser must reproduce the oracle's
@@ -292,16 +292,19 @@ def test_c5_share_128_sessions_x_50k_x_32_keypoints_batched():
         return run_kalman_smoother(**kw)
 
     s_of = lambda i: 2.0 + 0.25 * (i % 8)                 # a different fixed s per session
-    mine, all_s = smooth_sessions_batched(load, NS, smooth_fn=counted, smooth_param=s_of, return_device=True,
-                                          vs_diag=True)
+    # the full (K,T,2,2) covariance contract, as `bench.py --workload c5` times it
+    mine, all_s = smooth_sessions_batched(load, NS, smooth_fn=counted, smooth_param=s_of, return_device=True)
     assert calls == [(NS * KS, T, 2)]                     # ONE batch of 4096 keypoints
     assert sorted(mine) == list(range(NS)) and len(all_s) == NS
     for i in range(NS):
         assert np.all(all_s[i] == s_of(i)) and tuple(mine[i][1].shape) == (KS, T, 2)
-        assert bool(torch.isfinite(mine[i][1]).all()) and bool((mine[i][2] > 0).all())
-    # 4 sessions x 8 keypoints against the oracle, all frames
-    kp = np.arange(0, KS, 4)
-    for i in (0, 37, 90, 127):
+        assert tuple(mine[i][2].shape) == (KS, T, 2, 2)
+        assert bool(torch.isfinite(mine[i][1]).all())
+        assert bool((torch.diagonal(mine[i][2], dim1=2, dim2=3) > 0).all())
+        assert bool((mine[i][2][..., 0, 1] == 0).all()) and bool((mine[i][2][..., 1, 0] == 0).all())
+    # 8 sessions x 4 keypoints (32 keypoints spread over the batch) against the oracle, all frames
+    kp = np.arange(1, KS, 8)
+    for i in (0, 19, 37, 58, 77, 90, 111, 127):
         y, var = synth.singlecam_observations_torch(T, KS, seed=5000 + i, device=dev)
         y_s = np.transpose(y[:, kp].cpu().numpy().astype(np.float64), (1, 0, 2)).copy()
         Rd = np.clip(np.transpose(var[:, kp].cpu().numpy().astype(np.float64), (1, 0, 2)), 1e-12, None)
@@ -309,7 +312,7 @@ def test_c5_share_128_sessions_x_50k_x_32_keypoints_batched():
                                         np.full(len(kp), s_of(i)), nthreads=_threads())
         kp_d = torch.as_tensor(kp, device=dev)
         ms_g = mine[i][1].index_select(0, kp_d).cpu().numpy().astype(np.float64)
-        Vd_g = mine[i][2].index_select(0, kp_d).cpu().numpy().astype(np.float64)
+        Vs_g = mine[i][2].index_select(0, kp_d).cpu().numpy().astype(np.float64)
         assert _kp_rel(ms_g, ms_o) < TOL
-        Vd_o = np.diagonal(Vs_o, axis1=2, axis2=3)
-        assert (np.abs(Vd_g - Vd_o) / Vd_o).max() < TOL
+        Vd_g, Vd_o = np.diagonal(Vs_g, axis1=2, axis2=3), np.diagonal(Vs_o, axis1=2, axis2=3)
+        assert (np.abs(Vd_g - Vd_o) / Vd_o).max() < TOL                        # elementwise
