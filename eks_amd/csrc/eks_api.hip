@@ -100,6 +100,14 @@ int eks_nll(const eks_dims_t* d, const float* y, const double* rconst, const dou
                    workspace_bytes, st);
 }
 
+int eks_order_stats(int32_t n_rows, int32_t n_cols, const float* x, int32_t rank_lo, int32_t rank_hi,
+                    float* out, int32_t* nan_count, eks_stream_t stream) {
+  if (n_rows <= 0 || n_cols <= 0 || rank_lo < 0 || rank_hi < rank_lo || rank_hi >= n_rows || rank_hi > rank_lo + 1)
+    return EKS_ERR_SHAPE;
+  if (!x || !out || !nan_count) return EKS_ERR_NULL;
+  return order_stats(n_rows, n_cols, x, rank_lo, rank_hi, out, nan_count, reinterpret_cast<hipStream_t>(stream));
+}
+
 int eks_argmin_s(int32_t n_keypoints, int32_t n_cand, const double* nll, const double* s_cand,
                  double* s_out, int32_t* idx_out, eks_stream_t stream) {
   if (n_keypoints <= 0 || n_cand <= 0) return EKS_ERR_SHAPE;

@@ -84,6 +84,8 @@ int ar1_nll(const eks_dims_t& d, const float* y, const float* var, const double*
 size_t const_r_workspace_bytes(int N);
 int const_r(int T, int N, const float* var, double min_var, double* rconst, void* ws,
             size_t ws_bytes, hipStream_t st);
+int order_stats(int T, int N, const float* x, int r_lo, int r_hi, float* out, int32_t* nan_count,
+                hipStream_t st);
 int argmin_s(int K, int n_cand, const double* nll, const double* s_cand, double* s_out,
              int32_t* idx_out, hipStream_t st);
 int adam_step(int n_blocks, const int32_t* offs, const int32_t* members, const double* nll,

@@ -721,6 +721,105 @@ int const_r(int T, int N, const float* var, double min_var, double* rconst, void
 }
 
 // ==========================================================================================
+// Order statistics of the columns of a [T][N] float32 matrix: the two neighbours numpy.percentile
+// interpolates between (reference eks/utils.py:318-322 center_predictions, eks/stats.py:109-112 the
+// variance-inflation loop; numpy sorts NaNs to the end and the drivers need to know whether a column has any).
+// One block per column, exact MSB-first radix select on the order-preserving bit pattern of the floats
+// (four strided sweeps, 16 loads in flight per thread) plus one sweep for the successor of the selected key.
+// These matrices are small (frames x keypoints of one session), the sweeps are not a hot path.
+// ==========================================================================================
+__device__ __forceinline__ uint32_t float_order_key(float v) {
+  if (v != v) return 0xFFFFFFFFu;                       // NaN: after everything else, +inf included
+  const uint32_t u = __float_as_uint(v);
+  const uint32_t k = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return k == 0xFFFFFFFFu ? 0xFFFFFFFEu : k;            // (no finite value or infinity maps there anyway)
+}
+__device__ __forceinline__ float float_from_order_key(uint32_t k) {
+  const uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  return __uint_as_float(u);
+}
+
+__global__ __launch_bounds__(256) void order_stats_kernel(int T, int N, const float* __restrict__ x,
+                                                         int r_lo, int r_hi, float* __restrict__ out,
+                                                         int32_t* __restrict__ nan_count) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sh_prefix, sh_rank, sh_less, sh_eq, sh_next, sh_nan;
+  const int n = blockIdx.x;
+  auto sweep = [&](auto&& f) {
+    constexpr int kU = 16;
+    for (int t0 = threadIdx.x; t0 < T; t0 += 256 * kU) {
+      float v[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int t = t0 + 256 * u;
+        v[u] = t < T ? x[(size_t)t * N + n] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if (t0 + 256 * u < T) f(float_order_key(v[u]));
+    }
+  };
+  uint32_t prefix = 0, rank = (uint32_t)r_lo, less = 0;
+  if (threadIdx.x == 0) sh_nan = 0u;
+  for (int pass = 0; pass < 4; ++pass) {
+    hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const int shift = 24 - 8 * pass;
+    uint32_t nans = 0;
+    sweep([&](uint32_t key) {
+      if (pass == 0) nans += key == 0xFFFFFFFFu;
+      if (pass > 0 && (key >> (shift + 8)) != prefix) return;
+      atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    });
+    if (pass == 0 && nans) atomicAdd(&sh_nan, nans);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t cum = 0;
+      int bin = 255;
+      for (int b = 0; b < 256; ++b) {
+        if (cum + hist[b] > rank) {
+          bin = b;
+          break;
+        }
+        cum += hist[b];
+      }
+      less += cum;
+      rank -= cum;
+      prefix = (prefix << 8) | (uint32_t)bin;
+      sh_prefix = prefix;
+      sh_rank = rank;
+      sh_less = less;
+      sh_eq = hist[bin];
+      sh_next = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    prefix = sh_prefix;
+    rank = sh_rank;
+    less = sh_less;
+  }
+  const uint32_t key_lo = prefix, eq = sh_eq;
+  uint32_t best = 0xFFFFFFFFu;
+  sweep([&](uint32_t key) {
+    if (key > key_lo && key < best) best = key;
+  });
+  if (best != 0xFFFFFFFFu) atomicMin(&sh_next, best);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // rank r_hi holds key_lo again while it lies inside the run of equal keys, else the next larger key
+    const uint32_t key_hi = ((uint32_t)r_hi < less + eq) ? key_lo : sh_next;
+    out[2 * n] = float_from_order_key(key_lo);
+    out[2 * n + 1] = key_hi == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : float_from_order_key(key_hi);
+    if (key_lo == 0xFFFFFFFFu) out[2 * n] = __uint_as_float(0x7FC00000u);
+    nan_count[n] = (int32_t)sh_nan;
+  }
+}
+
+int order_stats(int T, int N, const float* x, int r_lo, int r_hi, float* out, int32_t* nan_count, hipStream_t st) {
+  hipLaunchKernelGGL(order_stats_kernel, dim3(N), dim3(256), 0, st, T, N, x, r_lo, r_hi, out, nan_count);
+  return hip_status(hipGetLastError());
+}
+
+// ==========================================================================================
 // argmin over candidates (first minimum, numpy.argmin semantics) + gather of s
 // ==========================================================================================
 // one wave per keypoint: lanes stride over the candidates, (value, index) min-reduction that

@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import ctypes
 
+import numpy as np
+
 import torch
 
 from . import _lib
@@ -107,6 +109,30 @@ def const_r(var, min_var: float = 1e-4):
                          _stream())
     _lib.check(rc, 'eks_const_r')
     return out
+
+
+def order_stats(x, rank_lo: int, rank_hi: int):
+    """eks_order_stats: x (T, N) float32 -> (vals (N, 2) float32 = the order statistics rank_lo and rank_hi of
+    every column with NaNs sorted last, nan_count (N,) int32), device tensors."""
+    lib = _lib.load()
+    x = _chk(x, torch.float32, 'x')
+    T, N = x.shape
+    vals = torch.empty((N, 2), dtype=torch.float32, device=x.device)
+    nans = torch.empty(N, dtype=torch.int32, device=x.device)
+    rc = lib.eks_order_stats(T, N, _ptr(x), int(rank_lo), int(rank_hi), _ptr(vals), _ptr(nans), _stream())
+    _lib.check(rc, 'eks_order_stats')
+    return vals, nans
+
+
+def percentile(x, q: float):
+    """numpy.percentile(x, q, axis=0) for a device matrix x (T, N) float32, bit for bit: the two order
+    statistics come from eks_order_stats, the interpolation is numpy's own arithmetic on 2 N floats
+    (utils.percentile_from_order_stats).  Returns a float32 NumPy array (N,); a column with a NaN gives NaN."""
+    from .utils import percentile_from_order_stats, percentile_ranks
+    T = x.shape[0]
+    r_lo, r_hi, gamma = percentile_ranks(T, q, np.float32)
+    vals, nans = order_stats(x, r_lo, r_hi)
+    return percentile_from_order_stats(vals.cpu().numpy(), gamma, nans.cpu().numpy())
 
 
 def nll(y, rconst, m0, S0, A, C, Q, s_cand, per_keypoint: bool = False, want_grad: bool = False,

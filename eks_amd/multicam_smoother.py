@@ -201,16 +201,16 @@ def _linear_on_device(marker_array, keypoint_names, smooth_param, quantile_keep_
     section 8(f) ranks 2 and 4; reference eks/multicam_smoother.py:335-348, :409-443, :481-551):
 
         eks_ensemble -> worst variance per (frame, keypoint) -> percentile mask and good-frame
-        indices (utils.py:318-343; the K thresholds come from numpy.percentile on the downloaded
-        (T, K) float32 maxima, so the mask is bit-identical to the host path) -> means over the
+        indices (utils.py:318-343; the K thresholds are numpy.percentile's, bit for bit, from two order
+        statistics per keypoint selected on the device: hip_ops.percentile) -> means over the
         good frames, centring -> [eks_maha_inflate passes; the factor-analysis fits on the host]
         -> PCA fit on the host from the good-frame subset only (n_good x 2V per keypoint), prior
         variances / process noise from the device-side principal components -> run_kalman_smoother
         on device tensors -> eks_multicam_tables (reprojection + posterior variances, (V, T, K, 9))
         -> ONE download.
 
-    Small host <-> device traffic only: the (T, K) maxima, the good-frame subset for the PCA fits,
-    the factor-analysis fit rows, K x (D + D^2) statistics."""
+    Small host <-> device traffic only: 2 K order statistics, the good-frame subset for the PCA fits,
+    the factor-analysis moments, K x (D + D^2) statistics."""
     import torch
 
     from . import hip_ops
@@ -233,8 +233,10 @@ def _linear_on_device(marker_array, keypoint_names, smooth_param, quantile_keep_
         n_good = T
         order = torch.arange(T, device=dev)[:, None].expand(T, K)
     else:
-        worst = vars32.amax(dim=(0, 3))                                       # (T,K) float32
-        thr = np.percentile(worst.cpu().numpy(), quantile_keep_pca, axis=0)   # numpy's own interpolation
+        worst = vars32.amax(dim=(0, 3)).contiguous()                          # (T,K) float32
+        # numpy.percentile(worst, q, axis=0) without downloading (T, K): the two order statistics per
+        # keypoint by exact selection on the device, numpy's interpolation on those 2 K floats
+        thr = hip_ops.percentile(worst, quantile_keep_pca)
         mask = worst <= torch.as_tensor(thr, device=dev)
         n_good = int(mask.sum(dim=0).min().item())
         # first n_good kept frames of every keypoint (the reference truncates to the shortest list)
@@ -316,9 +318,9 @@ def _inflate_on_device(ys, evs, likes, n_latent, inflate_vars_kwargs, threshold:
     # reduced on the device (stats.factor_analysis_from_moments); wider problems use sklearn itself
     moments = not fixed and O <= n_latent + 10
     x_host = None if (fixed or moments) else ys.cpu().numpy()
-    rows_ok = np.ones((K, T), dtype=bool)
+    rows_ok = torch.ones((K, T), dtype=torch.bool, device=dev)
     if likes is not None and kw.get('likelihood_threshold') is not None and not fixed:
-        rows_ok &= (likes.amin(dim=2) >= kw['likelihood_threshold']).cpu().numpy()
+        rows_ok &= likes.amin(dim=2) >= kw['likelihood_threshold']
     W = torch.zeros((K, O, n_latent), dtype=torch.float64, device=dev)
     mu = torch.zeros((K, O), dtype=torch.float64, device=dev)
     if fixed:
@@ -329,14 +331,16 @@ def _inflate_on_device(ys, evs, likes, n_latent, inflate_vars_kwargs, threshold:
         for k in np.flatnonzero(active):
             logger.info(f'inflating keypoint: {k}')
         if not fixed:
-            rows = rows_ok.copy()
+            rows = rows_ok.clone()
             if kw.get('v_quantile_threshold') is not None:
-                worst = v.amax(dim=2).cpu().numpy()                               # (K,T) float32
-                for k in np.flatnonzero(active):
-                    rows[k] &= worst[k] < np.percentile(worst[k], kw['v_quantile_threshold'])
+                # eks/stats.py:109-112: frames whose worst variance lies below the keypoint's percentile;
+                # numpy.percentile's value per keypoint from two device-selected order statistics
+                worst = v.amax(dim=2)                                             # (K,T) float32
+                thr = hip_ops.percentile(worst.transpose(0, 1).contiguous(), kw['v_quantile_threshold'])
+                rows &= worst < torch.as_tensor(thr, device=dev)[:, None]
         if moments:
             act = torch.as_tensor(np.flatnonzero(active), device=dev)
-            w = torch.as_tensor(rows[active], device=dev).to(torch.float64)       # (Ka,T)
+            w = rows.index_select(0, act).to(torch.float64)                       # (Ka,T)
             n_rows = w.sum(dim=1)
             xa = ys.index_select(0, act)
             mean = torch.einsum('kt,kto->ko', w, xa) / n_rows[:, None]
@@ -351,8 +355,9 @@ def _inflate_on_device(ys, evs, likes, n_latent, inflate_vars_kwargs, threshold:
                 W[k] = torch.as_tensor(np.ascontiguousarray(Wk), device=dev)
                 mu[k] = torch.as_tensor(mean_host[i], device=dev)
         elif not fixed:
+            rows_h = rows.cpu().numpy()
             for k in np.flatnonzero(active):
-                fa = FactorAnalysis(n_components=n_latent).fit(x_host[k][rows[k]])
+                fa = FactorAnalysis(n_components=n_latent).fit(x_host[k][rows_h[k]])
                 W[k] = torch.as_tensor(np.ascontiguousarray(fa.components_.T, dtype=np.float64), device=dev)
                 mu[k] = torch.as_tensor(np.ascontiguousarray(fa.mean_, dtype=np.float64), device=dev)
         n_inf, _ = hip_ops.maha_inflate(ys, v, W, mu, torch.as_tensor(active.astype(np.int32), device=dev),

@@ -192,3 +192,39 @@ def center_predictions(ensemble_marker_array: MarkerArray, quantile_keep_pca: fl
     fields = ['x', 'y']
     return (mask, MarkerArray(centered, data_fields=fields),
             MarkerArray(good - means, data_fields=fields), MarkerArray(means, data_fields=fields))
+
+
+def percentile_ranks(n: int, q: float, dtype=np.float32):
+    """What numpy.percentile(a, q, axis=0) (method 'linear') does before it touches the data, for `n`
+    values of floating `dtype`: the indices of the two order statistics it interpolates between and the
+    weight `gamma`, formed with numpy's own expressions (numpy/lib/_function_base_impl.py: _quantile_unchecked
+    -> _quantile -> _get_indexes / _get_gamma) so that the result is bit-identical under whatever promotion
+    rules the installed numpy applies.  Returns (prev_index, next_index, gamma as a 0-d array)."""
+    dtype = np.dtype(dtype)
+    qq = np.asanyarray(np.true_divide(q, dtype.type(100)))      # percentile -> quantile, as numpy.percentile
+    if not (0.0 <= float(qq) <= 1.0):
+        raise ValueError('Percentiles must be in the range [0, 100]')
+    vi = np.asanyarray((n - 1) * qq)                            # 'linear': virtual index (n - 1) q
+    prev = int(np.floor(vi))
+    nxt = prev + 1
+    if vi >= n - 1:
+        prev = nxt = n - 1
+    if vi < 0:
+        prev = nxt = 0
+    gamma = np.asanyarray(np.asanyarray(vi - np.intp(prev)), dtype=vi.dtype)
+    return prev, min(nxt, n - 1), gamma
+
+
+def percentile_from_order_stats(vals, gamma, nan_count=None):
+    """The interpolation step of numpy.percentile ('linear'; numpy's _lerp) from the two order statistics
+    vals (..., 2) of each slice; slices with NaNs give NaN like numpy (its partition puts NaNs last and the
+    result is overwritten).  Same operations in the same dtype as numpy, hence bit-identical."""
+    vals = np.asarray(vals)
+    a, b = vals[..., 0], vals[..., 1]
+    t = gamma
+    diff = np.subtract(b, a)
+    out = np.asanyarray(np.add(a, diff * t))
+    np.subtract(b, diff * (1 - t), out=out, where=t >= 0.5, casting='unsafe', dtype=type(out.dtype))
+    if nan_count is not None:
+        out = np.where(np.asarray(nan_count) > 0, np.asarray(np.nan, dtype=out.dtype), out)
+    return out

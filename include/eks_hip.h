@@ -84,6 +84,16 @@ int eks_nll(const eks_dims_t* dims, const float* y, const double* rconst, const 
             const double* s_cand, int32_t n_cand, int32_t per_keypoint, double* nll, double* dnll,
             void* workspace, size_t workspace_bytes, eks_stream_t stream);
 
+/* ---- order statistics for numpy.percentile's linear interpolation: center_predictions' per-keypoint
+ * threshold on the worst ensemble variance (eks/utils.py:318-322, np.percentile(..., axis=0)) and the
+ * v_quantile_threshold of the variance-inflation loop (eks/stats.py:109-112).  x [n_rows][n_cols] float32;
+ * out[c] = {x_sorted[rank_lo], x_sorted[rank_hi]} of column c with NaNs sorted last as numpy sorts them
+ * (rank_hi = rank_lo or rank_lo + 1), nan_count[c] = number of NaNs in the column (numpy returns NaN for
+ * such a slice).  The interpolation itself is three float32 operations per column and stays with the
+ * caller, which forms it with numpy's own expressions (eks_amd/utils.py percentile_from_order_stats). ---- */
+int eks_order_stats(int32_t n_rows, int32_t n_cols, const float* x, int32_t rank_lo, int32_t rank_hi,
+                    float* out, int32_t* nan_count, eks_stream_t stream);
+
 /* ---- argmin over candidates + gather: s_out[k] = s_cand[argmin_c nll[k][c]] (first minimum,
  * like numpy.argmin).  idx_out (optional) receives the int32 indices. ---------------------- */
 int eks_argmin_s(int32_t n_keypoints, int32_t n_cand, const double* nll, const double* s_cand,

@@ -543,3 +543,39 @@ def test_abi_error_codes():
                         p(x), x.numel() * 8, None)
     assert rc == -3                                                             # D = 7 not built
     assert b'unsupported' in lib.eks_status_string(rc)
+
+
+@pytest.mark.parametrize('T,N', [(1, 3), (2, 1), (257, 5), (5000, 8), (50_000, 4), (4097, 70)])
+def test_order_stats_and_percentile_match_numpy_bit_for_bit(T, N):
+    """eks_order_stats (exact selection, NaNs last) against numpy.sort, and hip_ops.percentile against
+    numpy.percentile(x, q, axis=0) - the thresholds of center_predictions and of the variance-inflation loop
+    (reference eks/utils.py:318-322, eks/stats.py:109-112): float32 in, float32 out, the same bits; columns
+    with NaNs, infinities, negative values, zeros of both signs and heavy duplicates."""
+    from eks_amd import hip_ops
+    rng = np.random.default_rng(T * 31 + N)
+    x = (rng.gamma(2.0, 1.0, (T, N)) * 10.0 ** rng.integers(-6, 4, (1, N))).astype(np.float32)
+    if N > 1:
+        x[:, 1] = np.round(x[:, 1] / x[:, 1].max() * 3)                  # four distinct values
+    if N > 2:
+        x[:, 2] = rng.standard_normal(T).astype(np.float32)             # negative values
+        x[::3, 2] = 0.0
+        x[1::7, 2] = -0.0
+    if N > 3 and T > 4:
+        x[rng.integers(0, T, 3), 3] = np.inf
+    if N > 4:
+        x[rng.integers(0, T, 2), 4] = np.nan
+    xd = _dev(x, torch.float32)
+    srt = np.sort(x, axis=0)
+    for r in sorted({0, T // 2, (T - 1) // 2, max(T - 2, 0), T - 1}):
+        r_hi = min(r + 1, T - 1)
+        vals, nans = hip_ops.order_stats(xd, r, r_hi)
+        np.testing.assert_array_equal(nans.cpu().numpy(), np.isnan(x).sum(axis=0))
+        got = vals.cpu().numpy()
+        want = np.stack([srt[r], srt[r_hi]], axis=1)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) or \
+            np.array_equal(got, want, equal_nan=True) and np.array_equal(np.signbit(got), np.signbit(want)) or \
+            np.array_equal(np.where(got == 0, 0.0, got), np.where(want == 0, 0.0, want), equal_nan=True)
+    for q in (0.0, 12.5, 50.0, 95.0, 99.99, 100.0):
+        got = hip_ops.percentile(xd, q)
+        ref = np.percentile(x, q, axis=0)
+        assert got.dtype == ref.dtype and np.array_equal(got, ref, equal_nan=True), (q, got, ref)

@@ -311,3 +311,27 @@ def test_page_locked_result_cap_follows_the_arrays_callers_hold(monkeypatch):
     assert core._pinned_live[0] == 0
     c, = core._to_host(torch.arange(500, dtype=torch.float32))            # room again
     assert len(made) == 2 and core._pinned_live[0] == 2000
+
+
+def test_percentile_from_two_order_statistics_is_numpys_bit_for_bit():
+    """utils.percentile_ranks + percentile_from_order_stats (what hip_ops.percentile does with the two
+    device-selected order statistics) against numpy.percentile on float32 columns: same dtype, same bits -
+    NaN slices, duplicates, q = 0 / 100 and single-row matrices included (reference eks/utils.py:318-322,
+    eks/stats.py:109-112 call numpy.percentile on float32 arrays)."""
+    from eks_amd.utils import percentile_from_order_stats, percentile_ranks
+    rng = np.random.default_rng(0)
+    for trial in range(600):
+        n, K = int(rng.integers(1, 3000)), int(rng.integers(1, 5))
+        q = float(rng.choice([0, 100, 50, 95, 25, 37.5, 99.9, rng.uniform(0, 100)]))
+        a = (rng.standard_normal((n, K)) * rng.choice([1e-3, 1, 1e4])).astype(np.float32)
+        if trial % 7 == 0:
+            a = np.abs(a)
+        if trial % 11 == 0:
+            a[rng.integers(0, n), rng.integers(0, K)] = np.nan
+        if trial % 13 == 0:
+            a = np.round(a)
+        ref = np.percentile(a, q, axis=0)
+        lo, hi, g = percentile_ranks(n, q, np.float32)
+        srt = np.sort(a, axis=0)                                        # NaNs last, as the device kernel orders them
+        got = percentile_from_order_stats(np.stack([srt[lo], srt[hi]], axis=-1), g, np.isnan(a).sum(axis=0))
+        assert got.dtype == ref.dtype and np.array_equal(got, ref, equal_nan=True), (n, q)
