@@ -12,6 +12,10 @@ python -m pytest tests -q -m gpu 2>&1 | tail -3 > $O/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 python bench.py > $O/bench_c3.json 2> $O/bench_c3.err
 python bench.py --workload c4 --no-cpu-baseline > $O/bench_c4.json 2>/dev/null
+python bench.py --workload c4w --no-cpu-baseline > $O/bench_c4w.json 2>/dev/null
+# the N > 1 launch path as the round-end driver invokes it (no outer torchrun); two ranks share this box's GPU
+EKS_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload c3 --steps 10 --no-cpu-baseline > $O/bench_c3_2ranks_gloo.json 2>/dev/null
+EKS_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload c3 --steps 10 --no-cpu-baseline --scaling strong > $O/bench_c3_2ranks_gloo_strong.json 2>/dev/null
 python bench.py --workload c5 --no-cpu-baseline > $O/bench_c5.json 2>/dev/null
 python bench.py --workload c2 --no-cpu-baseline > $O/bench_c2.json 2>/dev/null
 python bench.py --workload pupil > $O/bench_pupil.json 2>/dev/null
