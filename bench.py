@@ -96,8 +96,10 @@ def self_launch(args):
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     for line in child.stdout:                    # stream: the JSON line appears as soon as rank 0 prints it
-        sys.stdout.write(line)
-        sys.stdout.flush()
+        # only rank 0's result line belongs on stdout; library chatter (gloo's connection notes) goes to stderr
+        out = sys.stdout if line.lstrip().startswith('{') else sys.stderr
+        out.write(line)
+        out.flush()
     return child.wait()
 
 
