@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libeks_hip.so')
-SOURCES = ['eks_api.hip', 'eks_diag.hip', 'eks_diag_nll.hip', 'eks_dense.hip', 'eks_dense_wave.hip', 'eks_loss.hip',
+SOURCES = ['eks_api.hip', 'eks_diag.hip', 'eks_diag_nll.hip', 'eks_dense.hip', 'eks_dense_wave.hip', 'eks_dense_wide.hip', 'eks_loss.hip',
            'eks_loss_ar1.hip', 'eks_misc.hip', 'eks_multicam.hip', 'eks_profile.hip']
 ARCH = 'gfx950'
 

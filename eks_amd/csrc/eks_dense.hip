@@ -301,12 +301,18 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
   const int lanes = K * G.nc;
   const int vs_diag = (d.flags & EKS_FLAG_VS_DIAG) ? 1 : 0;
   const Gate open{nullptr, 0.0};
+  const bool wide = dense_wide_covers(D, O, G.B);   // prefetching summarize / checkpointed replay
   EKS_DISPATCH_D(D, {
     const LinearObs<DD> obs = make_linear_obs<DD>(y, var, K, O, M);
     {
       ProfScope ps("dense_summarize", st);
-      hipLaunchKernelGGL((dense_summarize_kernel<DD, LinearObs<DD>>), dim3((lanes + 63) / 64),
-                         dim3(64), 0, st, G, M, Mm.s, obs, elems, first, open);
+      if (wide) {
+        const int rc = dense_wide_summarize(T, K, D, O, G.B, G.nc, M, Mm.s, y, var, elems, first, st);
+        if (rc != EKS_OK) return rc;
+      } else {
+        hipLaunchKernelGGL((dense_summarize_kernel<DD, LinearObs<DD>>), dim3((lanes + 63) / 64),
+                           dim3(64), 0, st, G, M, Mm.s, obs, elems, first, open);
+      }
     }
     {
       ProfScope ps("dense_scan", st);
@@ -318,9 +324,15 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
     }
     {
       ProfScope ps("dense_replay", st);
-      hipLaunchKernelGGL((dense_replay_kernel<DD, false, LinearObs<DD>>), dim3((lanes + 63) / 64),
-                         dim3(64), 0, st, G, M, Mm.s, obs, pre, suf, bprior, bsuffix, filt, ms, Vs,
-                         vs_diag, nullptr, nullptr, nullptr, open);
+      if (wide) {
+        const int rc = dense_wide_replay(T, K, D, O, G.B, G.nc, M, Mm.s, y, var, pre, suf, bprior, bsuffix, ms,
+                                         Vs, vs_diag, st);
+        if (rc != EKS_OK) return rc;
+      } else {
+        hipLaunchKernelGGL((dense_replay_kernel<DD, false, LinearObs<DD>>), dim3((lanes + 63) / 64),
+                           dim3(64), 0, st, G, M, Mm.s, obs, pre, suf, bprior, bsuffix, filt, ms, Vs,
+                           vs_diag, nullptr, nullptr, nullptr, open);
+      }
     }
   })
   return hip_status(hipGetLastError());

@@ -1,0 +1,402 @@
+// gfx950 kernels for the general (D, O) smoother on WIDE sessions (many keypoints: lanes = consecutive
+// keypoints, so every row access of a wave is one contiguous segment) - the summarize and replay phases of
+// eks_dense.hip's three-phase scan for linear observations with D <= 3 and O = 2, 4, 6, 8 (multicam linear
+// path, reference eks/multicam_smoother.py:409-443; O = 2 x cameras), rebuilt in round 3 around what the
+// profile of `bench.py --workload c4w` (50 000 frames x 256 keypoints, D = 3, O = 4) showed:
+//   * both phases asked for a frame's rows when they needed them - one exposed memory latency per frame and
+//     lane: now the rows of the NEXT group of four frames are in flight while a group is processed;
+//   * the replay kept its filtered beliefs (12 doubles per frame and keypoint) in a float64 scratch stream -
+//     2.4 GB written and read back for 1.0 GB of algorithmic traffic, 0.97 ms of the step's 1.39: now only a
+//     CHECKPOINT of the belief entering every group of four frames is kept, in LDS ([group][field][lane],
+//     36 KB per wave at 32-frame chunks), and on the way back each group is filtered again from its checkpoint
+//     (+0.75 filter steps per frame, no scratch traffic) with its four filtered beliefs in registers for the
+//     RTS steps.
+// Same arithmetic as eks_dense_lane.hpp (rank-1 updates per scalar observation, float64), same scan kernels
+// in between (eks_dense.hip), outputs bit-compatible within float64 rounding.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "eks_dense_lane.hpp"
+#include "eks_internal.hpp"
+
+namespace eks {
+
+constexpr int kWideGroup = 4;          // frames per group (one checkpoint per group)
+constexpr int kWideMaxB = 32;          // frames per lane at most (dense_chunk): 8 checkpoints
+
+struct WideGeom {
+  int K, T, O, B, nc;
+};
+
+template <int O>
+struct FrameRows {
+  float y[O], v[O];
+};
+
+// the O values of (frame t, keypoint k): contiguous, 8-byte (O even) or 16-byte (O % 4 == 0) aligned
+template <int O>
+__device__ __forceinline__ void wide_load(const float* __restrict__ y, const float* __restrict__ var,
+                                          size_t row, bool ok, FrameRows<O>& f) {
+  constexpr int W = O % 4 == 0 ? 4 : 2;
+  typedef float fw __attribute__((ext_vector_type(W)));
+#pragma unroll
+  for (int o = 0; o < O; o += W) {
+    fw a = fw(0.f), b = fw(1.f);
+    if (ok) {
+      a = *reinterpret_cast<const fw*>(y + row + o);
+      b = *reinterpret_cast<const fw*>(var + row + o);
+    }
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+      f.y[o + q] = a[q];
+      f.v[o + q] = b[q];
+    }
+  }
+}
+
+template <int O>
+__device__ __forceinline__ void wide_load_group(const float* __restrict__ y, const float* __restrict__ var,
+                                                int K, int k, int t_first, int t_end, FrameRows<O> (&g)[kWideGroup]) {
+#pragma unroll
+  for (int f = 0; f < kWideGroup; ++f) {
+    const int t = t_first + f;
+    wide_load<O>(y, var, ((size_t)t * K + k) * O, t < t_end, g[f]);
+  }
+}
+
+template <int D, int O>
+struct WideRowsC {          // observation rows of the lane's keypoint
+  double c[O][D];
+  __device__ __forceinline__ Vec<double, D> row(int o) const {
+    Vec<double, D> h;
+#pragma unroll
+    for (int i = 0; i < D; ++i) h.a[i] = c[o][i];
+    return h;
+  }
+};
+template <int D, int O>
+__device__ __forceinline__ WideRowsC<D, O> wide_obs_rows(const DenseModelPtrs& M, int k) {
+  WideRowsC<D, O> R;
+#pragma unroll
+  for (int o = 0; o < O; ++o)
+#pragma unroll
+    for (int i = 0; i < D; ++i) R.c[o][i] = M.C[((size_t)k * O + o) * D + i];
+  return R;
+}
+
+template <int D, int O>
+__device__ __forceinline__ void wide_filter_frame(const WideRowsC<D, O>& H, const FrameRows<O>& fr,
+                                                  Vec<double, D>& m, Mat<double, D>& P) {
+#pragma unroll
+  for (int o = 0; o < O; ++o) {
+    const Vec<double, D> h = H.row(o);
+    const Vec<double, D> u = mat_vec(P, h);
+    const double r = fr.v[o] > kVarFloor ? (double)fr.v[o] : (double)kVarFloor;
+    const double g = 1.0 / (r + dot(h, u));
+    const double gd = g * ((double)fr.y[o] - dot(h, m));
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      m.a[a] += u.a[a] * gd;
+#pragma unroll
+      for (int b = 0; b < D; ++b) P.a[a][b] -= u.a[a] * u.a[b] * g;
+    }
+  }
+}
+
+template <int D>
+__device__ __forceinline__ void wide_predict(const Mat<double, D>& F, const Mat<double, D>& sQ, bool fid,
+                                             Vec<double, D>& m, Mat<double, D>& P) {
+  if (!fid) {
+    m = mat_vec(F, m);
+    P = mat_mul_nt(mat_mul(F, P), F);
+  }
+  P = mat_add(P, sQ);
+}
+
+// ------------------------------------------------------------------------------------------------------
+template <int D, int O>
+__global__ __launch_bounds__(64) void dwide_summarize_kernel(WideGeom G, DenseModelPtrs M,
+                                                            const double* __restrict__ s,
+                                                            const float* __restrict__ y,
+                                                            const float* __restrict__ var,
+                                                            double* __restrict__ elems,
+                                                            double* __restrict__ first) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= G.K * G.nc) return;
+  const int k = idx % G.K, j = idx / G.K;
+  Mat<double, D> F, sQ;
+  bool fid;
+  load_dynamics<double, D>(M, k, s[k], F, sQ, fid);
+  const WideRowsC<D, O> H = wide_obs_rows<D, O>(M, k);
+  const int t0 = j * G.B, t1 = min(t0 + G.B, G.T);
+  DElem<double, D> e = delem_identity<double, D>();
+  FrameRows<O> cur[kWideGroup], nxt[kWideGroup];
+  wide_load_group<O>(y, var, G.K, k, t0, t1, cur);
+  for (int tg = t0; tg < t1; tg += kWideGroup) {
+    if (tg + kWideGroup < t1) wide_load_group<O>(y, var, G.K, k, tg + kWideGroup, t1, nxt);
+#pragma unroll
+    for (int f = 0; f < kWideGroup; ++f) {
+      const int t = tg + f;
+      if (t < t1 && t > 0) {                           // frame 0 updates the prior itself (below, and in replay)
+        delem_predict(e, F, sQ, fid);
+#pragma unroll
+        for (int o = 0; o < O; ++o)
+          delem_observe(e, H.row(o), (double)cur[f].y[o],
+                        cur[f].v[o] > kVarFloor ? (double)cur[f].v[o] : (double)kVarFloor, false);
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < kWideGroup; ++f) cur[f] = nxt[f];
+  }
+  store_delem<double, D>(elems + (size_t)idx * delem_doubles<D>(), e);
+  if (j == 0) {   // the belief the scan starts from: the prior updated with frame 0
+    Vec<double, D> m;
+    Mat<double, D> P;
+    load_prior<D>(M, k, m, P);
+    FrameRows<O> f0;
+    wide_load<O>(y, var, (size_t)k * O, true, f0);
+    wide_filter_frame<D, O>(H, f0, m, P);
+    double* r = first + (size_t)k * (D + D * D);
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      r[a] = m.a[a];
+#pragma unroll
+      for (int b = 0; b < D; ++b) r[D + a * D + b] = P.a[a][b];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+constexpr int kWideCB = 64;            // elements per block of the scan in between (eks_dense.hip: kDenseCB)
+
+template <int D, int O>
+__global__ __launch_bounds__(64) void dwide_replay_kernel(WideGeom G, DenseModelPtrs M,
+                                                         const double* __restrict__ s,
+                                                         const float* __restrict__ y,
+                                                         const float* __restrict__ var,
+                                                         const double* __restrict__ pre,
+                                                         const double* __restrict__ suf,
+                                                         const double* __restrict__ bprior,
+                                                         const double* __restrict__ bsuffix,
+                                                         float* __restrict__ ms, float* __restrict__ Vs,
+                                                         int vs_diag) {
+  constexpr int NF = D + D * (D + 1) / 2;            // mean + upper triangle of the covariance
+  constexpr int REC = D + D * D;
+  constexpr int NV = delem_doubles<D>();
+  __shared__ double ck[(kWideMaxB / kWideGroup) * NF * 64];   // [group][field][lane]
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= G.K * G.nc) return;
+  const int lane = threadIdx.x;
+  const int k = idx % G.K, j = idx / G.K;
+  Mat<double, D> F, sQ;
+  bool fid;
+  load_dynamics<double, D>(M, k, s[k], F, sQ, fid);
+  const WideRowsC<D, O> H = wide_obs_rows<D, O>(M, k);
+  const int t0 = j * G.B, t1 = min(t0 + G.B, G.T), len = t1 - t0;
+  FrameRows<O> cur[kWideGroup], nxt[kWideGroup];
+  wide_load_group<O>(y, var, G.K, k, t0, t1, cur);    // in flight while the boundary operations run
+  // belief entering the chunk / information leaving it, from the scan (as dense_replay_kernel)
+  Vec<double, D> m, eta;
+  Mat<double, D> P, J;
+  const int blk = j / kWideCB, ia = j % kWideCB;
+  const double* rp = bprior + ((size_t)blk * G.K + k) * REC;
+  const double* rs = bsuffix + ((size_t)blk * G.K + k) * REC;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    m.a[a] = rp[a];
+    eta.a[a] = rs[a];
+#pragma unroll
+    for (int b = 0; b < D; ++b) {
+      P.a[a][b] = rp[D + a * D + b];
+      J.a[a][b] = rs[D + a * D + b];
+    }
+  }
+  if (ia > 0) delem_apply(load_delem<double, D>(pre + ((size_t)(j - 1) * G.K + k) * NV), m, P);
+  if (ia + 1 < kWideCB && j + 1 < G.nc)
+    delem_back(load_delem<double, D>(suf + ((size_t)(j + 1) * G.K + k) * NV), eta, J);
+  if (j == 0) load_prior<D>(M, k, m, P);              // chunk 0 replays frame 0's update of the prior itself
+  // ---- forward: exact filter, one checkpoint (the belief entering the group) per four frames
+  double* mine = ck + lane;
+  auto save = [&](int g) {
+    double* c = mine + (size_t)g * NF * 64;
+    int f = 0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) c[(f++) * 64] = m.a[a];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = a; b < D; ++b) c[(f++) * 64] = 0.5 * (P.a[a][b] + P.a[b][a]);
+  };
+  auto restore = [&](int g) {
+    const double* c = mine + (size_t)g * NF * 64;
+    int f = 0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) m.a[a] = c[(f++) * 64];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = a; b < D; ++b) P.a[a][b] = P.a[b][a] = c[(f++) * 64];
+  };
+  const int ng = (len + kWideGroup - 1) / kWideGroup;
+  for (int g = 0; g < ng; ++g) {
+    const int tg = t0 + g * kWideGroup;
+    if (g + 1 < ng) wide_load_group<O>(y, var, G.K, k, tg + kWideGroup, t1, nxt);
+    save(g);
+#pragma unroll
+    for (int f = 0; f < kWideGroup; ++f) {
+      const int t = tg + f;
+      if (t < t1) {
+        if (t > 0) wide_predict<D>(F, sQ, fid, m, P);
+        wide_filter_frame<D, O>(H, cur[f], m, P);
+      }
+    }
+    if (g + 1 < ng) {
+#pragma unroll
+      for (int f = 0; f < kWideGroup; ++f) cur[f] = nxt[f];
+    }
+  }
+  // (cur now holds the rows of the LAST group)
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+  auto put = [&](float* __restrict__ dst, const float* v, auto n_tag) {
+    constexpr int n = decltype(n_tag)::value;
+    int q = 0;
+#pragma unroll
+    for (; q + 4 <= n; q += 4) EKS_STREAM_STORE(reinterpret_cast<f4u*>(dst + q), (f4u{v[q], v[q + 1], v[q + 2], v[q + 3]}));
+    if constexpr (n % 4 >= 2) {
+      EKS_STREAM_STORE(reinterpret_cast<f2u*>(dst + q), (f2u{v[q], v[q + 1]}));
+      q += 2;
+    }
+    if constexpr (n % 2 == 1) EKS_STREAM_STORE(dst + q, v[q]);
+  };
+  auto emit = [&](int t, const Vec<double, D>& mo, const Mat<double, D>& Po) {
+    const size_t ko = (size_t)t * G.K + k;
+    float mv[D], pv[D * D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      mv[a] = (float)mo.a[a];
+#pragma unroll
+      for (int b = 0; b < D; ++b) pv[a * D + b] = (float)Po.a[a][b];
+    }
+    put(ms + ko * D, mv, std::integral_constant<int, D>{});
+    if (vs_diag) {
+      float dv[D];
+#pragma unroll
+      for (int a = 0; a < D; ++a) dv[a] = pv[a * D + a];
+      put(Vs + ko * D, dv, std::integral_constant<int, D>{});
+    } else {
+      put(Vs + ko * D * D, pv, std::integral_constant<int, D * D>{});
+    }
+  };
+  Vec<double, D> m_s;
+  Mat<double, D> P_s;
+  double logdet;
+  condition_on_info(m, P, eta, J, m_s, P_s, logdet);  // smoothed last frame of the chunk
+  emit(t1 - 1, m_s, P_s);
+  // ---- backward: every group is filtered again from its checkpoint, RTS over its four beliefs in registers
+  for (int g = ng - 1; g >= 0; --g) {
+    const int tg = t0 + g * kWideGroup;
+    if (g > 0) wide_load_group<O>(y, var, G.K, k, tg - kWideGroup, t1, nxt);   // the group before, in flight
+    restore(g);
+    Vec<double, D> mf[kWideGroup];
+    Mat<double, D> Pf[kWideGroup];
+#pragma unroll
+    for (int f = 0; f < kWideGroup; ++f) {
+      const int t = tg + f;
+      if (t < t1) {
+        if (t > 0) wide_predict<D>(F, sQ, fid, m, P);
+        wide_filter_frame<D, O>(H, cur[f], m, P);
+      }
+      mf[f] = m;
+      Pf[f] = mat_symmetrize(P);
+    }
+#pragma unroll
+    for (int f = kWideGroup - 1; f >= 0; --f) {
+      const int t = tg + f;
+      if (t < t1 - 1) {                               // the chunk's last frame is smoothed already
+        const Mat<double, D> FP = fid ? Pf[f] : mat_mul(F, Pf[f]);
+        const Mat<double, D> Pp = mat_symmetrize(mat_add(fid ? Pf[f] : mat_mul_nt(FP, F), sQ));
+        const Mat<double, D> Z = chol_solve_mat(chol_psd(Pp), FP);   // Pp^-1 F Pf = G^T
+        const Vec<double, D> mp = fid ? mf[f] : mat_vec(F, mf[f]);
+        Vec<double, D> dm;
+#pragma unroll
+        for (int a = 0; a < D; ++a) dm.a[a] = m_s.a[a] - mp.a[a];
+        const Vec<double, D> Gdm = mat_t_vec(Z, dm);
+#pragma unroll
+        for (int a = 0; a < D; ++a) m_s.a[a] = mf[f].a[a] + Gdm.a[a];
+        P_s = mat_symmetrize(mat_add(Pf[f], mat_mul(mat_mul_tn(Z, mat_sub(P_s, Pp)), Z)));
+        emit(t, m_s, P_s);
+      }
+    }
+    if (g > 0) {
+#pragma unroll
+      for (int f = 0; f < kWideGroup; ++f) cur[f] = nxt[f];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+bool dense_wide_covers(int D, int O, int B) {
+  return (D == 2 || D == 3) && (O == 2 || O == 4 || O == 6 || O == 8) && B <= kWideMaxB &&
+         B % kWideGroup == 0 && !knob_int(KNOB_DENSE_LEGACY, 0);
+}
+
+int dense_wide_summarize(int T, int K, int D, int O, int B, int nc, const DenseModelPtrs& M, const double* s,
+                         const float* y, const float* var, double* elems, double* first, hipStream_t st) {
+  const WideGeom G{K, T, O, B, nc};
+  const int lanes = K * nc;
+  const dim3 grid((lanes + 63) / 64), block(64);
+#define EKS_WS(DD, OO) \
+  hipLaunchKernelGGL((dwide_summarize_kernel<DD, OO>), grid, block, 0, st, G, M, s, y, var, elems, first)
+#define EKS_WS_O(DD)                    \
+  switch (O) {                          \
+    case 2: EKS_WS(DD, 2); break;       \
+    case 4: EKS_WS(DD, 4); break;       \
+    case 6: EKS_WS(DD, 6); break;       \
+    case 8: EKS_WS(DD, 8); break;       \
+    default: return EKS_ERR_UNSUPPORTED; \
+  }
+  if (D == 2) {
+    EKS_WS_O(2)
+  } else if (D == 3) {
+    EKS_WS_O(3)
+  } else {
+    return EKS_ERR_UNSUPPORTED;
+  }
+#undef EKS_WS_O
+#undef EKS_WS
+  return hip_status(hipGetLastError());
+}
+
+int dense_wide_replay(int T, int K, int D, int O, int B, int nc, const DenseModelPtrs& M, const double* s,
+                      const float* y, const float* var, const double* pre, const double* suf,
+                      const double* bprior, const double* bsuffix, float* ms, float* Vs, int vs_diag,
+                      hipStream_t st) {
+  const WideGeom G{K, T, O, B, nc};
+  const int lanes = K * nc;
+  const dim3 grid((lanes + 63) / 64), block(64);
+#define EKS_WR(DD, OO)                                                                                     \
+  hipLaunchKernelGGL((dwide_replay_kernel<DD, OO>), grid, block, 0, st, G, M, s, y, var, pre, suf, bprior, \
+                     bsuffix, ms, Vs, vs_diag)
+#define EKS_WR_O(DD)                    \
+  switch (O) {                          \
+    case 2: EKS_WR(DD, 2); break;       \
+    case 4: EKS_WR(DD, 4); break;       \
+    case 6: EKS_WR(DD, 6); break;       \
+    case 8: EKS_WR(DD, 8); break;       \
+    default: return EKS_ERR_UNSUPPORTED; \
+  }
+  if (D == 2) {
+    EKS_WR_O(2)
+  } else if (D == 3) {
+    EKS_WR_O(3)
+  } else {
+    return EKS_ERR_UNSUPPORTED;
+  }
+#undef EKS_WR_O
+#undef EKS_WR
+  return hip_status(hipGetLastError());
+}
+
+}  // namespace eks

@@ -63,6 +63,15 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
 bool dense_wave_covers(int T, int K, int D, int O);
 int dense_wave_smooth(const eks_dims_t& d, const float* y, const float* var, const DenseModel& M, float* ms,
                       float* Vs, void* ws, size_t ws_bytes, hipStream_t st);
+// wide sessions: prefetching summarize / checkpointed replay (eks_dense_wide.hip), same scan in between
+struct DenseModelPtrs;
+bool dense_wide_covers(int D, int O, int B);
+int dense_wide_summarize(int T, int K, int D, int O, int B, int nc, const DenseModelPtrs& M, const double* s,
+                         const float* y, const float* var, double* elems, double* first, hipStream_t st);
+int dense_wide_replay(int T, int K, int D, int O, int B, int nc, const DenseModelPtrs& M, const double* s,
+                      const float* y, const float* var, const double* pre, const double* suf,
+                      const double* bprior, const double* bsuffix, float* ms, float* Vs, int vs_diag,
+                      hipStream_t st);
 size_t dense_nll_workspace_bytes(int T, int K, int D, int O, int n_cand);
 int dense_nll(const eks_dims_t& d, const float* y, const double* rconst, const DenseModel& M,
               const double* s_cand, int n_cand, int per_keypoint, double* nll, double* dnll,

@@ -255,6 +255,34 @@ def test_smooth_dense_matches_oracle(T, K, D, O, general_A):
             ref = Vs_o
         assert _rel(Vk, ref, axis_scale=tuple(range(1, ref.ndim))) < 1e-5
 
+@pytest.mark.parametrize('T,K,D,O,general_A', [
+    (100, 1200, 3, 4, False),   # 1 200 (keypoint, 64-chunk) units > 1 024: keypoint-major kernels, 16-frame chunks
+    (8000, 600, 3, 4, False),   # K T / 16 > 2^18: 32-frame chunks, eight checkpoints per lane, scan over 250 chunks
+    (131, 1100, 2, 6, False),   # ragged last chunk and last group, D = 2, three cameras
+    (70, 1100, 3, 8, True),     # non-identity dynamics, four cameras
+])
+def test_smooth_dense_wide_sessions_match_oracle(T, K, D, O, general_A, set_knob):
+    """Wide sessions run the keypoint-major kernels: rows prefetched a group of four frames ahead, filtered beliefs
+    as LDS checkpoints per group with the group filtered again on the way back (eks_dense_wide.hip), and
+    (EKS_DENSE_LEGACY=1) the round-1 kernels with their scratch stream; both against the C port of the reference
+    recursion on every frame."""
+    from eks_amd import hip_ops
+    from oracle import c_oracle
+    arrs, y, var = _dense_problem(T, K, D, O, seed=T + K)
+    if general_A:
+        arrs['As'] = arrs['As'] * 0.97 + 0.02 * np.random.default_rng(9).standard_normal((K, D, D))
+    s = np.exp(np.random.default_rng(3).uniform(-3, 4, K))
+    Rd = orc.build_R_from_vars(np.swapaxes(arrs['ensemble_vars'], 0, 1))
+    ms_o, Vs_o, _ = c_oracle.smooth(arrs['ys'], Rd, arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], s)
+    for legacy in ('0', '1'):
+        set_knob('EKS_DENSE_LEGACY', legacy)
+        ms, Vs = hip_ops.smooth(_dev(y), _dev(var), *_params_dev(arrs), _dev(s), flags=0)
+        ms = np.transpose(ms.cpu().numpy().astype(np.float64), (1, 0, 2))
+        Vs = np.transpose(Vs.cpu().numpy().astype(np.float64), (1, 0, 2, 3))
+        assert _rel(ms, ms_o, axis_scale=(1, 2)) < 1e-5
+        assert _rel(Vs, Vs_o, axis_scale=(1, 2, 3)) < 1e-5
+
+
 @pytest.mark.parametrize('case', ['all_clipped', 'tiny', 'one_clipped'])
 @pytest.mark.parametrize('sval', [10.0, 1e-3])
 def test_smooth_dense_with_variances_at_the_clip(case, sval):
