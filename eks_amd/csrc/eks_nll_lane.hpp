@@ -35,7 +35,20 @@
 namespace eks {
 
 // two float32 lanes in one 64-bit register pair: arithmetic on it compiles to gfx950's packed
-// VALU (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32), i.e. two candidate filters per instruction
+// VALU (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32), i.e. two candidate filters per instruction.
+// Round 3: the steady loops keep the candidates PAIRED in such registers from start to end (no shuffles in
+// the loop).  A v_pk_fma_f32 occupies the SIMD for the cycles of two v_fma_f32, but ONE wave can issue it
+// back to back where it can issue a plain VALU instruction only every ~4 cycles: at the kernel's two waves
+// per SIMD the loop's dependency structure runs 2.60 instead of 3.23 cycles per candidate-FMA
+// (tools/micro/pk_fma_rate.hip; round 1's attempt let the SLP vectoriser pack and paid for its v_mov
+// shuffles).  Component-wise the arithmetic is the same fused multiply-add: results are bit-identical.
+#ifndef EKS_NLL_PACKED
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EKS_NLL_PACKED 1
+#else
+#define EKS_NLL_PACKED 0
+#endif
+#endif
 #if defined(__clang__)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #else
@@ -392,6 +405,8 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
            11.6f / nl + 48.f < (float)(nfull * 8);
     }
     if (EKS_WAVE_ALL(ok)) {
+      constexpr bool PK = EKS_NLL_PACKED && (NCL % 2 == 0);
+      constexpr int NP = PK ? NCL / 2 : 1;
       float dk[NCL], w[NCL];
       double s1acc[NCL];
 #pragma unroll
@@ -404,17 +419,40 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
       float s1[NCL], s2[NCL];
 #pragma unroll
       for (int k = 0; k < NCL; ++k) s1[k] = s2[k] = 0.f;
+      // packed form: candidate pairs (2p, 2p + 1) live in 64-bit registers for the whole loop
+      f32x2 rho2[NP], dk2[NP], w2[NP], s12[NP], s22[NP];
+      if constexpr (PK) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          rho2[p] = f32x2{rho[2 * p], rho[2 * p + 1]};
+          dk2[p] = f32x2{0.f, 0.f};
+          w2[p] = f32x2{1.f, 1.f};
+          s12[p] = f32x2{0.f, 0.f};
+          s22[p] = f32x2{0.f, 0.f};
+        }
+      }
       auto eat4 = [&](const float (&yy)[8]) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const float dy = UNIT ? (yy[q] - yprev) : (float)((double)yy[q] - a_d * (double)yprev);
           yprev = yy[q];
+          if constexpr (PK) {
+            const f32x2 dy2 = f32x2{dy, dy};
 #pragma unroll
-          for (int k = 0; k < NCL; ++k) {
-            dk[k] = rho[k] * dk[k] + dy;
-            s2[k] += dk[k] * dk[k];
-            s1[k] += dk[k] * w[k];
-            w[k] *= rho[k];
+            for (int p = 0; p < NP; ++p) {
+              dk2[p] = rho2[p] * dk2[p] + dy2;
+              s22[p] = s22[p] + dk2[p] * dk2[p];
+              s12[p] = s12[p] + dk2[p] * w2[p];
+              w2[p] = w2[p] * rho2[p];
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < NCL; ++k) {
+              dk[k] = rho[k] * dk[k] + dy;
+              s2[k] += dk[k] * dk[k];
+              s1[k] += dk[k] * w[k];
+              w[k] *= rho[k];
+            }
           }
         }
       };
@@ -436,6 +474,16 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
         blk += 2;
         if ((blk & 2) == 0 || blk + 2 > nfull) {
           bool dead = true;
+          if constexpr (PK) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+              s2[2 * p] = s22[p].x; s2[2 * p + 1] = s22[p].y;
+              s1[2 * p] = s12[p].x; s1[2 * p + 1] = s12[p].y;
+              w[2 * p] = w2[p].x; w[2 * p + 1] = w2[p].y;
+              s22[p] = f32x2{0.f, 0.f};
+              s12[p] = f32x2{0.f, 0.f};
+            }
+          }
 #pragma unroll
           for (int k = 0; k < NCL; ++k) {
             L.acc2[k].add(s2[k]);
@@ -444,6 +492,13 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
             dead = dead && fabsf(w[k]) < L.kDeadA;
           }
           alive = !EKS_WAVE_ALL(dead);
+        }
+      }
+      if constexpr (PK) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          dk[2 * p] = dk2[p].x;
+          dk[2 * p + 1] = dk2[p].y;
         }
       }
 #pragma unroll
@@ -477,12 +532,23 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
   //      candidates interleaved inside the frame loop (independent chains issue back to back).
   //      Loads are double-buffered: the next 8 frames are in flight while 8 are consumed.
   if (steady && blk < nfull) {
+    constexpr bool PK = EKS_NLL_PACKED && sizeof(R) == sizeof(float) && (NCL % 2 == 0);
+    constexpr int NP = PK ? NCL / 2 : 1;
     R rho[NCL], dk[NCL], s2[NCL];
 #pragma unroll
     for (int k = 0; k < NCL; ++k) {
       rho[k] = L.pole(k);
       dk[k] = L.dl[k];
       s2[k] = R(0.f);
+    }
+    f32x2 rho2[NP], dk2[NP], s22[NP];        // packed form: candidate pairs in 64-bit registers (see f32x2)
+    if constexpr (PK) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        rho2[p] = f32x2{val(rho[2 * p]), val(rho[2 * p + 1])};
+        dk2[p] = f32x2{val(dk[2 * p]), val(dk[2 * p + 1])};
+        s22[p] = f32x2{0.f, 0.f};
+      }
     }
     float yprev = L.y_last;
     float ya[8], yb[8];
@@ -494,18 +560,36 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
       for (int q = 0; q < 8; ++q) {
         const float dy = UNIT ? (yy[q] - yprev) : (float)((double)yy[q] - a_d * (double)yprev);
         yprev = yy[q];
+        if constexpr (PK) {
+          const f32x2 dy2 = f32x2{dy, dy};
 #pragma unroll
-        for (int k = 0; k < NCL; ++k) {
-          dk[k] = rho[k] * dk[k] + R(dy);
-          s2[k] = s2[k] + dk[k] * dk[k];
+          for (int p = 0; p < NP; ++p) {
+            dk2[p] = rho2[p] * dk2[p] + dy2;
+            s22[p] = s22[p] + dk2[p] * dk2[p];
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < NCL; ++k) {
+            dk[k] = rho[k] * dk[k] + R(dy);
+            s2[k] = s2[k] + dk[k] * dk[k];
+          }
         }
       }
     };
     auto flush = [&]() {
+      if constexpr (PK) {
 #pragma unroll
-      for (int k = 0; k < NCL; ++k) {
-        L.acc2[k].add(s2[k]);
-        s2[k] = R(0.f);
+        for (int p = 0; p < NP; ++p) {
+          L.acc2[2 * p].add(make_real(R(), s22[p].x, 0.f));
+          L.acc2[2 * p + 1].add(make_real(R(), s22[p].y, 0.f));
+          s22[p] = f32x2{0.f, 0.f};
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < NCL; ++k) {
+          L.acc2[k].add(s2[k]);
+          s2[k] = R(0.f);
+        }
       }
     };
     for (; blk + 2 <= nfull; blk += 2) {
@@ -526,6 +610,13 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
     flush();
     // back to the (d, y) state of the transient code so a ragged tail can continue
     const int eaten = (blk - first) * 8;
+    if constexpr (PK) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        dk[2 * p] = make_real(R(), dk2[p].x, 0.f);
+        dk[2 * p + 1] = make_real(R(), dk2[p].y, 0.f);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < NCL; ++k) {
       L.n_post[k] += eaten;
