@@ -230,6 +230,11 @@ def _dense_problem(T, K, D, O, seed):
     (150, 5, 2, 2, True),        # non-diagonal 2x2 goes through the dense path
     (64, 2, 1, 3, False),
     (100, 2, 6, 8, False),
+    (1, 3, 3, 4, False),         # a single frame: the prior updated once, nothing to scan
+    (2, 2, 3, 4, False),
+    (7, 5, 2, 6, False),         # one ragged 8-frame chunk
+    (9, 4, 3, 2, False),         # two chunks, the second of one frame
+    (513, 2, 3, 4, True),        # 65 chunks: two 64-chunk units per keypoint, the second nearly empty
 ])
 def test_smooth_dense_matches_oracle(T, K, D, O, general_A):
     from eks_amd import hip_ops
@@ -260,6 +265,8 @@ def test_smooth_dense_matches_oracle(T, K, D, O, general_A):
     (8000, 600, 3, 4, False),   # K T / 16 > 2^18: 32-frame chunks, eight checkpoints per lane, scan over 250 chunks
     (131, 1100, 2, 6, False),   # ragged last chunk and last group, D = 2, three cameras
     (70, 1100, 3, 8, True),     # non-identity dynamics, four cameras
+    (1, 1500, 3, 4, False),     # a single frame
+    (3, 1300, 2, 2, False),     # one ragged group
 ])
 def test_smooth_dense_wide_sessions_match_oracle(T, K, D, O, general_A, set_knob):
     """Wide sessions run the keypoint-major kernels: rows prefetched a group of four frames ahead, filtered beliefs
