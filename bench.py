@@ -457,9 +457,13 @@ def main():
                          'per rank (EKS_BENCH_BACKEND=gloo lets ranks share a GPU: a code-path test, not a '
                          'measurement)')
     from eks_amd import _lib, hip_ops, synth
+    # the rank's own device FIRST (device_count does not create a context): nothing of this process touches GPU 0
+    # unless it is its own
+    n_dev = torch.cuda.device_count()
+    local_rank = local_rank % max(1, n_dev)
+    if n_dev:
+        torch.cuda.set_device(local_rank)
     hip_ops.require_gpu()
-    local_rank = local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     backend = os.environ.get('EKS_BENCH_BACKEND', 'nccl')       # nccl == RCCL over xGMI on ROCm
     # EKS_BENCH_FORCE_DIST=1: build the process group and run every collective of the multi-rank path
