@@ -274,7 +274,10 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
   if (ws_bytes < dense_smooth_workspace_bytes(T, K, D, O)) return EKS_ERR_WORKSPACE;
   // narrow sessions (configs[3]: 4 keypoints) are depth-bound: two launches with the scan in wave
   // shuffles and the filtered beliefs in LDS (eks_dense_wave.hip); wide ones stream keypoint-major here
-  if (dense_wave_covers(T, K, D, O)) return dense_wave_smooth(d, y, var, Mm, ms, Vs, ws, ws_bytes, st);
+  // (both newer forms read a keypoint's O values of a frame as 8- / 16-byte pieces: the arrays must be
+  //  16-byte aligned, which device allocations are; an oddly offset view takes the generic kernels)
+  const bool aligned = ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(var)) & 15u) == 0;
+  if (aligned && dense_wave_covers(T, K, D, O)) return dense_wave_smooth(d, y, var, Mm, ms, Vs, ws, ws_bytes, st);
   DenseGeom G{K, T, O, dense_chunk(T, K), 0, 0, 0};
   G.nc = (T + G.B - 1) / G.B;
   G.Bs = G.B;
@@ -301,7 +304,7 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
   const int lanes = K * G.nc;
   const int vs_diag = (d.flags & EKS_FLAG_VS_DIAG) ? 1 : 0;
   const Gate open{nullptr, 0.0};
-  const bool wide = dense_wide_covers(D, O, G.B);   // prefetching summarize / checkpointed replay
+  const bool wide = aligned && dense_wide_covers(D, O, G.B);   // prefetching summarize / checkpointed replay
   EKS_DISPATCH_D(D, {
     const LinearObs<DD> obs = make_linear_obs<DD>(y, var, K, O, M);
     {
