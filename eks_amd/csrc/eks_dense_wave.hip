@@ -118,33 +118,45 @@ __device__ __forceinline__ ObsRows<D, O> load_obs_rows(const DenseModelPtrs& M, 
 // their code once per wave, and straight-line code for 16 frames x O observations (38 KB at O = 4) was
 // fetched cold from L2 at ~7 cycles per instruction (in-kernel stamps, profiles/r03_probes.txt).
 template <int O>
-__device__ __forceinline__ void dw_stage_rows(const float* __restrict__ y, const float* __restrict__ var,
-                                              size_t row0, size_t row_stride, int nrows, float* __restrict__ ly,
-                                              float* __restrict__ lv, int lane) {
-  // a keypoint's O values of one frame are contiguous and (O even) 8-byte, (O % 4 == 0) 16-byte aligned
-  constexpr int W = O % 4 == 0 ? 4 : 2;
+struct DwRows {
+  static constexpr int W = O % 4 == 0 ? 4 : 2;
   typedef float fw __attribute__((ext_vector_type(W)));
   fw a[kDwB][O / W], b[kDwB][O / W];
+};
+// request: all loads of the chunk in flight (nothing waits here - the caller issues its model loads next);
+// park: into LDS, [frame][lane][O]
+template <int O>
+__device__ __forceinline__ void dw_request_rows(const float* __restrict__ y, const float* __restrict__ var,
+                                                size_t row0, size_t row_stride, int nrows, DwRows<O>& R) {
+  // a keypoint's O values of one frame are contiguous and (O even) 8-byte, (O % 4 == 0) 16-byte aligned
+  constexpr int W = DwRows<O>::W;
+  typedef typename DwRows<O>::fw fw;
 #pragma unroll
   for (int i = 0; i < kDwB; ++i) {
     const size_t r = row0 + (size_t)i * row_stride;
 #pragma unroll
     for (int o = 0; o < O / W; ++o) {
       if (i < nrows) {
-        a[i][o] = *reinterpret_cast<const fw*>(y + r + o * W);
-        b[i][o] = *reinterpret_cast<const fw*>(var + r + o * W);
+        R.a[i][o] = *reinterpret_cast<const fw*>(y + r + o * W);
+        R.b[i][o] = *reinterpret_cast<const fw*>(var + r + o * W);
       } else {
-        a[i][o] = fw(0.f);
-        b[i][o] = fw(1.f);
+        R.a[i][o] = fw(0.f);
+        R.b[i][o] = fw(1.f);
       }
     }
   }
+}
+template <int O>
+__device__ __forceinline__ void dw_park_rows(const DwRows<O>& R, float* __restrict__ ly, float* __restrict__ lv,
+                                             int lane) {
+  constexpr int W = DwRows<O>::W;
+  typedef typename DwRows<O>::fw fw;
 #pragma unroll
   for (int i = 0; i < kDwB; ++i)
 #pragma unroll
     for (int o = 0; o < O / W; ++o) {
-      *reinterpret_cast<fw*>(ly + ((size_t)i * 64 + lane) * O + o * W) = a[i][o];
-      *reinterpret_cast<fw*>(lv + ((size_t)i * 64 + lane) * O + o * W) = b[i][o];
+      *reinterpret_cast<fw*>(ly + ((size_t)i * 64 + lane) * O + o * W) = R.a[i][o];
+      *reinterpret_cast<fw*>(lv + ((size_t)i * 64 + lane) * O + o * W) = R.b[i][o];
     }
 }
 
@@ -174,11 +186,13 @@ __global__ __launch_bounds__(128 * SUBS) void dw_summarize_kernel(DwGeom G, Dens
   const int t0 = live ? j * kDwB : 0, len = live ? min(kDwB, G.T - t0) : 0;
   float* my_y = ly[threadIdx.x >> 6];
   float* my_v = lv[threadIdx.x >> 6];
-  dw_stage_rows<O>(y, var, ((size_t)t0 * G.K + k) * O, (size_t)G.K * O, len, my_y, my_v, lane);
-  Mat<double, D> F, sQ;
+  DwRows<O> rows;
+  dw_request_rows<O>(y, var, ((size_t)t0 * G.K + k) * O, (size_t)G.K * O, len, rows);
+  Mat<double, D> F, sQ;                               // (the model's loads go out behind the rows': one round trip)
   bool fid;
   load_dynamics<double, D>(M, k, s[k], F, sQ, fid);
   const ObsRows<D, O> H = load_obs_rows<D, O>(M, k);
+  dw_park_rows<O>(rows, my_y, my_v, lane);
   DElem<double, D> e = delem_identity<double, D>();
   DW_STAMP(0, 1);
 #pragma unroll 1
@@ -312,12 +326,17 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
   }
   // ---- wave 0: everything this lane will need is requested before the reduction starts
   DW_STAMP(1, 0);
+  DwRows<O> rows;
+  {
+    const int jj = wb * 64 + lane;
+    const int tt0 = jj < G.nc ? jj * kDwB : 0, ll = jj < G.nc ? min(kDwB, G.T - tt0) : 0;
+    dw_request_rows<O>(y, var, ((size_t)tt0 * G.K + k) * O, (size_t)G.K * O, ll, rows);
+  }
   Mat<double, D> F, sQ;
   bool fid;
   load_dynamics<double, D>(M, k, s[k], F, sQ, fid);
   const ObsRows<D, O> H = load_obs_rows<D, O>(M, k);
   const int t0 = live ? j * kDwB : 0, len = live ? min(kDwB, G.T - t0) : 0;
-  dw_stage_rows<O>(y, var, ((size_t)t0 * G.K + k) * O, (size_t)G.K * O, len, ly, lv, lane);
   DElem<double, D> pe = delem_identity<double, D>(), se = delem_identity<double, D>();
   if (live) {
     pe = load_delem<double, D>(pre_ex + ((size_t)j * G.K + k) * NV);
@@ -335,6 +354,7 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
       for (int b = 0; b < D; ++b) P.a[a][b] = f0[D + a * D + b];
     }
   }
+  dw_park_rows<O>(rows, ly, lv, lane);
   DW_STAMP(1, 1);
   if (wb > 0) {
     const DElem<double, D> tot = dw_compose_range<D>(agg, G.K, k, 0, wb, lane);
