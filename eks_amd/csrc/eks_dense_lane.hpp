@@ -357,7 +357,7 @@ EKS_HD void dense_replay_chunk_obs(const Obs& obs, int K, int k, int t0, int len
     const Mat<double, D> FP = f_identity ? Pf : mat_mul(F, Pf);                 // F Pf
     const Mat<double, D> Pp = mat_symmetrize(
         mat_add(f_identity ? Pf : mat_mul_nt(FP, F), sQ));                      // F Pf F^T + sQ
-    const Mat<double, D> Z = chol_solve_mat(chol_psd(Pp), FP);                  // Pp^-1 F Pf = G^T
+    const Mat<double, D> Z = chol_solve_mat(chol_factor(Pp), FP);                  // Pp^-1 F Pf = G^T
     const Vec<double, D> mp = f_identity ? mf : mat_vec(F, mf);
     Vec<double, D> dm;
 #pragma unroll

@@ -156,45 +156,80 @@ EKS_HD Mat<S, D> mat_symmetrize(const Mat<S, D>& x) {
   return o;
 }
 
-// Lower Cholesky factor of a symmetric PSD matrix; a non-positive pivot zeroes its column
-// (semi-definite factor) so singular covariances do not poison the recursion.
+// Pivot of the Cholesky factorisation: l = sqrt(sum) and 1 / l.  In float64 on the device both come from ONE
+// v_rsq_f64 seed refined by two Newton steps (y <- y (1.5 - 0.5 x y^2): full double accuracy after the second,
+// l = x y) instead of an IEEE square root followed by an IEEE division - about 8 dependent instructions instead
+// of 27, on the critical path of every composition of the scans and of every RTS step (round 3: the narrow-
+// session kernels are bounded by exactly these chains).  Dual numbers and the host keep sqrt and 1 / x.
+template <typename S>
+EKS_HD void chol_pivot(const S& sum, S& l, S& inv) {
+  l = sqrt_s(sum);
+  inv = rcp(l);
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+template <>
+EKS_HD void chol_pivot<double>(const double& sum, double& l, double& inv) {
+  double y = __builtin_amdgcn_rsq(sum);
+  const double h = 0.5 * sum;
+  y = y * (1.5 - h * y * y);
+  y = y * (1.5 - h * y * y);
+  inv = y;
+  l = sum * y;
+}
+#endif
+
+// Lower Cholesky factor of a symmetric PSD matrix with the inverse of its diagonal (the solves multiply by
+// it); a non-positive pivot zeroes its column (semi-definite factor) so singular covariances do not poison
+// the recursion.
 template <typename S, int D>
-EKS_HD Mat<S, D> chol_psd(const Mat<S, D>& P) {
-  Mat<S, D> L = mat_zero<S, D>();
+struct CholF {
+  Mat<S, D> L;
+  Vec<S, D> invd;
+};
+
+template <typename S, int D>
+EKS_HD CholF<S, D> chol_factor(const Mat<S, D>& P) {
+  CholF<S, D> F;
+  F.L = mat_zero<S, D>();
 #pragma unroll
   for (int j = 0; j < D; ++j) {
     S sum = P.a[j][j];
 #pragma unroll
     for (int k = 0; k < D; ++k)
-      if (k < j) sum = sum - L.a[j][k] * L.a[j][k];
+      if (k < j) sum = sum - F.L.a[j][k] * F.L.a[j][k];
     const bool ok = val(sum) > 0.0;
-    const S ljj = ok ? sqrt_s(sum) : S(0.0);
-    const S inv = ok ? rcp(ljj) : S(0.0);
-    L.a[j][j] = ljj;
+    S ljj = S(0.0), inv = S(0.0);
+    if (ok) chol_pivot(sum, ljj, inv);
+    F.L.a[j][j] = ljj;
+    F.invd.a[j] = inv;
 #pragma unroll
     for (int i = 0; i < D; ++i)
       if (i > j) {
         S t = P.a[i][j];
 #pragma unroll
         for (int k = 0; k < D; ++k)
-          if (k < j) t = t - L.a[i][k] * L.a[j][k];
-        L.a[i][j] = t * inv;
+          if (k < j) t = t - F.L.a[i][k] * F.L.a[j][k];
+        F.L.a[i][j] = t * inv;
       }
   }
-  return L;
+  return F;
+}
+template <typename S, int D>
+EKS_HD Mat<S, D> chol_psd(const Mat<S, D>& P) {
+  return chol_factor(P).L;
 }
 
 // Solve (Lg Lg^T) x = z for a vector (Lg lower, positive diagonal).
 template <typename S, int D>
-EKS_HD Vec<S, D> chol_solve(const Mat<S, D>& Lg, const Vec<S, D>& z) {
+EKS_HD Vec<S, D> chol_solve(const CholF<S, D>& F, const Vec<S, D>& z) {
   Vec<S, D> w;
 #pragma unroll
   for (int i = 0; i < D; ++i) {
     S t = z.a[i];
 #pragma unroll
     for (int k = 0; k < D; ++k)
-      if (k < i) t = t - Lg.a[i][k] * w.a[k];
-    w.a[i] = t * rcp(Lg.a[i][i]);
+      if (k < i) t = t - F.L.a[i][k] * w.a[k];
+    w.a[i] = t * F.invd.a[i];
   }
   Vec<S, D> x;
 #pragma unroll
@@ -203,21 +238,21 @@ EKS_HD Vec<S, D> chol_solve(const Mat<S, D>& Lg, const Vec<S, D>& z) {
     S t = w.a[i];
 #pragma unroll
     for (int k = 0; k < D; ++k)
-      if (k > i) t = t - Lg.a[k][i] * x.a[k];
-    x.a[i] = t * rcp(Lg.a[i][i]);
+      if (k > i) t = t - F.L.a[k][i] * x.a[k];
+    x.a[i] = t * F.invd.a[i];
   }
   return x;
 }
 // Solve (Lg Lg^T) X = Z column by column.
 template <typename S, int D>
-EKS_HD Mat<S, D> chol_solve_mat(const Mat<S, D>& Lg, const Mat<S, D>& Z) {
+EKS_HD Mat<S, D> chol_solve_mat(const CholF<S, D>& F, const Mat<S, D>& Z) {
   Mat<S, D> X;
 #pragma unroll
   for (int c = 0; c < D; ++c) {
     Vec<S, D> z;
 #pragma unroll
     for (int i = 0; i < D; ++i) z.a[i] = Z.a[i][c];
-    const Vec<S, D> x = chol_solve(Lg, z);
+    const Vec<S, D> x = chol_solve(F, z);
 #pragma unroll
     for (int i = 0; i < D; ++i) X.a[i][c] = x.a[i];
   }
@@ -337,10 +372,10 @@ EKS_HD void condition_on_info(const Vec<S, D>& m, const Mat<S, D>& P, const Vec<
   Mat<S, D> G = mat_mul_tn(L, mat_mul(J, L));
 #pragma unroll
   for (int i = 0; i < D; ++i) G.a[i][i] = G.a[i][i] + S(1.0);
-  const Mat<S, D> Lg = chol_psd(mat_symmetrize(G));
+  const CholF<S, D> Lg = chol_factor(mat_symmetrize(G));
   logdet = S(0.0);
 #pragma unroll
-  for (int i = 0; i < D; ++i) logdet = logdet + S(2.0) * log_s(Lg.a[i][i]);
+  for (int i = 0; i < D; ++i) logdet = logdet + S(2.0) * log_s(Lg.L.a[i][i]);
   Vec<S, D> w = mat_vec(P, eta);
 #pragma unroll
   for (int i = 0; i < D; ++i) w.a[i] = w.a[i] + m.a[i];
@@ -386,7 +421,7 @@ EKS_HD void delem_back(const DElem<S, D>& e, Vec<S, D>& eta, Mat<S, D>& J) {
   Mat<S, D> G = mat_mul_tn(L, JL);
 #pragma unroll
   for (int i = 0; i < D; ++i) G.a[i][i] = G.a[i][i] + S(1.0);
-  const Mat<S, D> Lg = chol_psd(mat_symmetrize(G));
+  const CholF<S, D> Lg = chol_factor(mat_symmetrize(G));
   const Vec<S, D> Jb = mat_vec(J, e.b);
   Vec<S, D> v;
 #pragma unroll
@@ -422,7 +457,7 @@ EKS_HD DElem<S, D> delem_combine(const DElem<S, D>& ei, const DElem<S, D>& ej) {
   Mat<S, D> G = mat_mul_tn(L, JL);
 #pragma unroll
   for (int i = 0; i < D; ++i) G.a[i][i] = G.a[i][i] + S(1.0);
-  const Mat<S, D> Lg = chol_psd(mat_symmetrize(G));
+  const CholF<S, D> Lg = chol_factor(mat_symmetrize(G));
   Mat<S, D> JLt;
 #pragma unroll
   for (int i = 0; i < D; ++i)
@@ -461,7 +496,7 @@ EKS_HD DElem<S, D> delem_combine(const DElem<S, D>& ei, const DElem<S, D>& ej) {
   if constexpr (ELL) {
     S logdet = S(0.0);
 #pragma unroll
-    for (int i = 0; i < D; ++i) logdet = logdet + S(2.0) * log_s(Lg.a[i][i]);
+    for (int i = 0; i < D; ++i) logdet = logdet + S(2.0) * log_s(Lg.L.a[i][i]);
     o.ell = ei.ell + ej.ell - S(0.5) * logdet + dot(ei.b, ej.eta) - S(0.5) * dot(ei.b, Jb) +
             S(0.5) * dot(v, mat_vec(MC, v));
   } else {

@@ -476,7 +476,7 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
       for (int b = a; b < D; ++b) Pf.a[a][b] = Pf.a[b][a] = rc[(f++) * 64];
     const Mat<double, D> FP = fid ? Pf : mat_mul(F, Pf);
     const Mat<double, D> Pp = mat_symmetrize(mat_add(fid ? Pf : mat_mul_nt(FP, F), sQ));
-    const Mat<double, D> Z = chol_solve_mat(chol_psd(Pp), FP);      // Pp^-1 F Pf = G^T
+    const Mat<double, D> Z = chol_solve_mat(chol_factor(Pp), FP);      // Pp^-1 F Pf = G^T
     const Vec<double, D> mp = fid ? mf : mat_vec(F, mf);
     Vec<double, D> dm;
 #pragma unroll

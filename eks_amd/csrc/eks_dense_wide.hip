@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64) void dwide_replay_kernel(WideGeom G, DenseModel
       if (t < t1 - 1) {                               // the chunk's last frame is smoothed already
         const Mat<double, D> FP = fid ? Pf[f] : mat_mul(F, Pf[f]);
         const Mat<double, D> Pp = mat_symmetrize(mat_add(fid ? Pf[f] : mat_mul_nt(FP, F), sQ));
-        const Mat<double, D> Z = chol_solve_mat(chol_psd(Pp), FP);   // Pp^-1 F Pf = G^T
+        const Mat<double, D> Z = chol_solve_mat(chol_factor(Pp), FP);   // Pp^-1 F Pf = G^T
         const Vec<double, D> mp = fid ? mf[f] : mat_vec(F, mf[f]);
         Vec<double, D> dm;
 #pragma unroll
