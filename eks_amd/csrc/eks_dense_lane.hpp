@@ -97,7 +97,7 @@ EKS_HD DElem<S, D> loss_summarize_chunk(const float* __restrict__ y, const ObsNo
     double c = O * kLog2Pi, rmin = 1e300, rmax = 0.0;
     for (int o = 0; o < O; ++o) {
       const double r = R.at(row, k, O, o);
-      const double yo = (double)y[row + o], w = 1.0 / r;
+      const double yo = (double)y[row + o], w = rcp(r);
       rmin = fmin(rmin, r);
       rmax = fmax(rmax, r);
       const Vec<double, D> h = load_obs_row<double, D>(M, k, O, o);
@@ -210,7 +210,7 @@ EKS_HD double belief_update_obs(const Obs& obs, int k, int t, const double* xl, 
   obs.visit(t, k, xl, [&](const Vec<double, D>& h, double yv, double r) {
     const Vec<double, D> u = mat_vec(P, h);
     const double sigma = r + dot(h, u);
-    const double g = 1.0 / sigma;
+    const double g = rcp(sigma);
     const double d = yv - dot(h, m), gd = g * d;
     if (LL) ll -= 0.5 * (kLog2Pi + log(sigma) + d * gd);
 #pragma unroll

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
       const Vec<double, D> u = mat_vec(P, h);
       const float vf = pv[o];
       const double r = vf > kVarFloor ? (double)vf : (double)kVarFloor;
-      const double g = 1.0 / (r + dot(h, u));
+      const double g = rcp(r + dot(h, u));
       const double gd = g * ((double)py[o] - dot(h, m));
 #pragma unroll
       for (int a = 0; a < D; ++a) {

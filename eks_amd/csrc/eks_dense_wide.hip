@@ -93,7 +93,7 @@ __device__ __forceinline__ void wide_filter_frame(const WideRowsC<D, O>& H, cons
     const Vec<double, D> h = H.row(o);
     const Vec<double, D> u = mat_vec(P, h);
     const double r = fr.v[o] > kVarFloor ? (double)fr.v[o] : (double)kVarFloor;
-    const double g = 1.0 / (r + dot(h, u));
+    const double g = rcp(r + dot(h, u));
     const double gd = g * ((double)fr.y[o] - dot(h, m));
 #pragma unroll
     for (int a = 0; a < D; ++a) {
