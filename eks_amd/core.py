@@ -218,14 +218,28 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
     loop = hip_ops.AdamLoop(y_c, rconst, *P.params, offs_d, mem_d, state, s_kp, lr, lo, hi, tol,
                             safety_cap, flags=P.flags)
     iters, cap = 0, int(safety_cap)
+    # several iterations per host round trip: a step enqueued after a block has stopped (or reached the
+    # cap) leaves that block untouched (its loss waves exit at once), so over-issuing changes nothing.
+    # The count of still-running blocks after round r is copied to pinned memory behind round r and read
+    # only after round r + 1 has been enqueued: the device never waits for the host's answer, at the price
+    # of one round of no-op launches after the last block stops.
+    rounds = (cap + sync_every - 1) // sync_every
+    snap = _pinned_empty((max(rounds, 1),), torch.int32)
+    pending = None                                        # (round index, event) of the newest unread count
+    r = 0
     while iters < cap:
-        # several iterations per host round trip: a step enqueued after a block has stopped (or
-        # reached the cap) leaves that block untouched, so over-issuing changes nothing
         n = min(sync_every, cap - iters)
         loop.run(n)
         iters += n
-        if int(loop.n_active.item()) == 0:
-            break
+        snap[r:r + 1].copy_(loop.n_active, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        if pending is not None:
+            pending[1].synchronize()
+            if int(snap[pending[0]]) == 0:
+                break
+        pending = (r, ev)
+        r += 1
     return s_kp, dict(mode='adam', state=state, launches=iters)
 
 

@@ -189,6 +189,11 @@ int eks_adam_run(const eks_dims_t* d, const float* y, const double* rconst, cons
     int32_t* counter_b = reinterpret_cast<int32_t*>(tail + adam_extra_bytes(N) - 256);
     int rc = adam_prepare(n_blocks, K, block_offsets, block_members, kp_block, n_active, counter_b, st);
     if (rc != EKS_OK) return rc;
+    {   // tile tickets of the single-launch loss kernel: zero once, every evaluation leaves them zero
+      const hipError_t e = hipMemsetAsync(nll_ws_tickets(workspace, d->n_frames, N, 1), 0,
+                                          (size_t)((N + 63) / 64) * sizeof(int32_t), st);
+      if (e != hipSuccess) return EKS_ERR_HIP_BASE - (int)e;
+    }
     const bool in_kernel = n_blocks == K && diag_nll_grad_tree(d->n_frames, K, d->state_dim);
     const DiagModel M{m0, S0, A, C, Q, nullptr, d->state_dim};
     for (int it = 0; it < n_iters; ++it) {

@@ -305,12 +305,16 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
   const int vs_diag = (d.flags & EKS_FLAG_VS_DIAG) ? 1 : 0;
   const Gate open{nullptr, 0.0};
   const bool wide = aligned && dense_wide_covers(D, O, G.B);   // prefetching summarize / checkpointed replay
+  // ... with a per-lane sequential scan in between: its run aggregates live in the (otherwise unused)
+  // filtered-belief stream, its per-chunk results where the tree scan keeps prefix / suffix elements
+  const bool runs = wide && dense_wide_scan_scratch_doubles(K, D, G.nc) <= (size_t)T * K * rec &&
+                    !knob_int(KNOB_DENSE_TREE_SCAN, 0);
   EKS_DISPATCH_D(D, {
     const LinearObs<DD> obs = make_linear_obs<DD>(y, var, K, O, M);
     {
       ProfScope ps("dense_summarize", st);
       if (wide) {
-        const int rc = dense_wide_summarize(T, K, D, O, G.B, G.nc, M, Mm.s, y, var, elems, first, st);
+        const int rc = dense_wide_summarize(T, K, D, O, G.B, G.nc, M, Mm.s, y, var, elems, runs ? 1 : 0, first, st);
         if (rc != EKS_OK) return rc;
       } else {
         hipLaunchKernelGGL((dense_summarize_kernel<DD, LinearObs<DD>>), dim3((lanes + 63) / 64),
@@ -319,17 +323,22 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
     }
     {
       ProfScope ps("dense_scan", st);
-      const dim3 sgrid(K, nblk);
-      hipLaunchKernelGGL(dense_scan_kernel<DD>, sgrid, dim3(2 * kDenseCB), 0, st, G, elems, pre, suf,
-                         agg, open);
-      hipLaunchKernelGGL(dense_scan_blocks_kernel<DD>, dim3(K), dim3(2 * kDenseCB), 0, st, G, nblk,
-                         first, agg, bprior, bsuffix, open);
+      if (runs) {
+        const int rc = dense_wide_scan(K, D, G.nc, elems, first, filt, pre, suf, st);
+        if (rc != EKS_OK) return rc;
+      } else {
+        const dim3 sgrid(K, nblk);
+        hipLaunchKernelGGL(dense_scan_kernel<DD>, sgrid, dim3(2 * kDenseCB), 0, st, G, elems, pre, suf,
+                           agg, open);
+        hipLaunchKernelGGL(dense_scan_blocks_kernel<DD>, dim3(K), dim3(2 * kDenseCB), 0, st, G, nblk,
+                           first, agg, bprior, bsuffix, open);
+      }
     }
     {
       ProfScope ps("dense_replay", st);
       if (wide) {
-        const int rc = dense_wide_replay(T, K, D, O, G.B, G.nc, M, Mm.s, y, var, pre, suf, bprior, bsuffix, ms,
-                                         Vs, vs_diag, st);
+        const int rc = dense_wide_replay(T, K, D, O, G.B, G.nc, M, Mm.s, y, var, pre, suf, bprior, bsuffix,
+                                         runs ? pre : nullptr, runs ? suf : nullptr, ms, Vs, vs_diag, st);
         if (rc != EKS_OK) return rc;
       } else {
         hipLaunchKernelGGL((dense_replay_kernel<DD, false, LinearObs<DD>>), dim3((lanes + 63) / 64),

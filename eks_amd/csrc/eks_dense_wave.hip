@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "eks_dense_lane.hpp"
+#include "eks_dense_shfl.hpp"
 #include "eks_internal.hpp"
 
 namespace eks {
@@ -53,44 +54,6 @@ __device__ unsigned long long g_dw_stamps[2][64][16];
 struct DwGeom {
   int K, T, nc, nwb;         // keypoints, frames, chunks (ceil(T / kDwB)), blocks per keypoint (ceil(nc / 64))
 };
-
-// ---- an element moves between lanes as A (D x D), the upper triangles of C and J, b and eta ----------
-template <int D>
-__device__ __forceinline__ DElem<double, D> delem_shfl_up(const DElem<double, D>& e, int off) {
-  DElem<double, D> o;
-#pragma unroll
-  for (int i = 0; i < D; ++i) {
-    o.b.a[i] = __shfl_up(e.b.a[i], off);
-    o.eta.a[i] = __shfl_up(e.eta.a[i], off);
-#pragma unroll
-    for (int j = 0; j < D; ++j) o.A.a[i][j] = __shfl_up(e.A.a[i][j], off);
-#pragma unroll
-    for (int j = i; j < D; ++j) {
-      o.C.a[i][j] = o.C.a[j][i] = __shfl_up(e.C.a[i][j], off);
-      o.J.a[i][j] = o.J.a[j][i] = __shfl_up(e.J.a[i][j], off);
-    }
-  }
-  o.ell = 0.0;
-  return o;
-}
-template <int D>
-__device__ __forceinline__ DElem<double, D> delem_shfl_down(const DElem<double, D>& e, int off) {
-  DElem<double, D> o;
-#pragma unroll
-  for (int i = 0; i < D; ++i) {
-    o.b.a[i] = __shfl_down(e.b.a[i], off);
-    o.eta.a[i] = __shfl_down(e.eta.a[i], off);
-#pragma unroll
-    for (int j = 0; j < D; ++j) o.A.a[i][j] = __shfl_down(e.A.a[i][j], off);
-#pragma unroll
-    for (int j = i; j < D; ++j) {
-      o.C.a[i][j] = o.C.a[j][i] = __shfl_down(e.C.a[i][j], off);
-      o.J.a[i][j] = o.J.a[j][i] = __shfl_down(e.J.a[i][j], off);
-    }
-  }
-  o.ell = 0.0;
-  return o;
-}
 
 // observation rows of ONE keypoint (the block's keypoint is uniform: these live in scalar registers)
 template <int D, int O>

@@ -11,13 +11,26 @@
 //     36 KB per wave at 32-frame chunks), and on the way back each group is filtered again from its checkpoint
 //     (+0.75 filter steps per frame, no scratch traffic) with its four filtered beliefs in registers for the
 //     RTS steps.
-// Same arithmetic as eks_dense_lane.hpp (rank-1 updates per scalar observation, float64), same scan kernels
-// in between (eks_dense.hip), outputs bit-compatible within float64 rounding.
+//   * the scan in between was the narrow path's: per (keypoint, block of 64 chunks) a Hillis-Steele scan of
+//     whole ELEMENTS in both directions (6 levels x 64 compositions x 2, twelve barriers) writing an inclusive
+//     prefix and suffix element per chunk (2 x 34 doubles), 0.20 ms of the step.  Wide sessions have lanes to
+//     spare across keypoints, so the scan is now work-efficient and sequential per lane (dwide_scan_*): runs of
+//     R consecutive chunk elements are composed once (R - 1 compositions per run), runs of R run aggregates
+//     again, a lane per keypoint and direction walks the ~nc / R^2 top aggregates carrying a BELIEF /
+//     INFORMATION pair (apply / pull-back), and on the way down a lane per (keypoint, run, direction) pushes
+//     the pair through its run's rows, leaving for every chunk the belief entering it and the information
+//     leaving it (2 x 12 doubles, field-major: coalesced) - which is all the replay wants.  Elements are
+//     field-major too ([chunk][field][keypoint]).  c4w: scan 0.20 -> 0.14 ms, and the replay loses its own
+//     apply / pull-back and reads coalesced (0.51 -> 0.45 ms).
+// Same arithmetic as eks_dense_lane.hpp (rank-1 updates per scalar observation, float64), outputs bit-compatible
+// within float64 rounding.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <type_traits>
 
 #include "eks_dense_lane.hpp"
+#include "eks_dense_shfl.hpp"
 #include "eks_internal.hpp"
 
 namespace eks {
@@ -120,7 +133,7 @@ __global__ __launch_bounds__(64) void dwide_summarize_kernel(WideGeom G, DenseMo
                                                             const double* __restrict__ s,
                                                             const float* __restrict__ y,
                                                             const float* __restrict__ var,
-                                                            double* __restrict__ elems,
+                                                            double* __restrict__ elems, int soa,
                                                             double* __restrict__ first) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= G.K * G.nc) return;
@@ -149,7 +162,10 @@ __global__ __launch_bounds__(64) void dwide_summarize_kernel(WideGeom G, DenseMo
 #pragma unroll
     for (int f = 0; f < kWideGroup; ++f) cur[f] = nxt[f];
   }
-  store_delem<double, D>(elems + (size_t)idx * delem_doubles<D>(), e);
+  if (soa)   // [chunk][field][keypoint] for dwide_scan_*; else records, for the scan kernels of eks_dense.hip
+    store_delem<double, D>(elems + (size_t)j * delem_doubles<D>() * G.K + k, e, G.K);
+  else
+    store_delem<double, D>(elems + (size_t)idx * delem_doubles<D>(), e);
   if (j == 0) {   // the belief the scan starts from: the prior updated with frame 0
     Vec<double, D> m;
     Mat<double, D> P;
@@ -168,7 +184,128 @@ __global__ __launch_bounds__(64) void dwide_summarize_kernel(WideGeom G, DenseMo
 }
 
 // ------------------------------------------------------------------------------------------------------
-constexpr int kWideCB = 64;            // elements per block of the scan in between (eks_dense.hip: kDenseCB)
+// The scan between summarize and replay (see the header).  Records are field-major: field f of (row r,
+// keypoint k) at base[(r * NFIELDS + f) * K + k].
+struct WideScan {
+  int K, nc, R, nr;              // chunks, chunks per run, runs
+  const double* elems;           // [nc][NV][K]
+  const double* first;           // [K][REC] (record-major, from the summarize kernel)
+  double *agg;                   // [nr][NV][K]
+  double *run_in, *run_out;      // [nr][REC][K]  belief entering / information leaving each run
+  double *chunk_in, *chunk_out;  // [nc][REC][K]  the same per chunk: what the replay reads
+};
+
+template <int D>
+__device__ __forceinline__ void wide_put_pair(double* __restrict__ p, int K, const Vec<double, D>& v,
+                                              const Mat<double, D>& M) {
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    p[(size_t)a * K] = v.a[a];
+#pragma unroll
+    for (int b = 0; b < D; ++b) p[(size_t)(D + a * D + b) * K] = M.a[a][b];
+  }
+}
+template <int D>
+__device__ __forceinline__ void wide_get_pair(const double* __restrict__ p, int K, Vec<double, D>& v,
+                                              Mat<double, D>& M) {
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    v.a[a] = p[(size_t)a * K];
+#pragma unroll
+    for (int b = 0; b < D; ++b) M.a[a][b] = p[(size_t)(D + a * D + b) * K];
+  }
+}
+
+// lane = (keypoint, run): the run's elements composed in time order
+template <int D>
+__global__ __launch_bounds__(64) void dwide_scan_runs_kernel(WideScan W) {
+  constexpr int NV = delem_doubles<D>();
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= W.K * W.nr) return;
+  const int k = idx % W.K, r = idx / W.K;
+  const int j0 = r * W.R, j1 = min(W.nc, j0 + W.R);
+  DElem<double, D> e = load_delem<double, D>(W.elems + (size_t)j0 * NV * W.K + k, W.K);
+  for (int j = j0 + 1; j < j1; ++j)
+    e = delem_combine<double, D, false>(e, load_delem<double, D>(W.elems + (size_t)j * NV * W.K + k, W.K));
+  store_delem<double, D>(W.agg + (size_t)r * NV * W.K + k, e, W.K);
+}
+
+// The top of the scan: at most 64 rows per keypoint.  Block = keypoint, wave 0 forward, wave 1 reverse, lane =
+// row: inclusive prefix / suffix of the rows by a Hillis-Steele scan in wave shuffles (6 levels), then every lane
+// pushes the starting belief through the rows before it / pulls zero information back through the rows after it.
+struct WideTop {
+  int K, n;                      // rows (<= 64)
+  const double* rows;            // [n][NV][K]
+  const double* first;           // [K][REC]
+  double *row_in, *row_out;      // [n][REC][K]
+};
+
+template <int D>
+__global__ __launch_bounds__(128) void dwide_scan_top_kernel(WideTop W) {
+  constexpr int NV = delem_doubles<D>(), REC = D + D * D;
+  const int k = blockIdx.x, lane = threadIdx.x & 63;
+  const bool rev = threadIdx.x >= 64;
+  const bool live = lane < W.n;
+  DElem<double, D> x = live ? load_delem<double, D>(W.rows + (size_t)lane * NV * W.K + k, W.K)
+                            : delem_identity<double, D>();
+  for (int off = 1; off < 64; off <<= 1) {
+    if (!rev) {
+      const DElem<double, D> other = delem_shfl_up<D>(x, off);
+      if (lane >= off) x = delem_combine<double, D, false>(other, x);
+    } else {
+      const DElem<double, D> other = delem_shfl_down<D>(x, off);
+      if (lane + off < 64) x = delem_combine<double, D, false>(x, other);
+    }
+  }
+  Vec<double, D> v = vec_zero<double, D>();
+  Mat<double, D> M = mat_zero<double, D>();
+  if (!rev) {
+    const DElem<double, D> ex = delem_shfl_up<D>(x, 1);         // the rows before this one
+    const double* f0 = W.first + (size_t)k * REC;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      v.a[a] = f0[a];
+#pragma unroll
+      for (int b = 0; b < D; ++b) M.a[a][b] = f0[D + a * D + b];
+    }
+    if (lane > 0) delem_apply(ex, v, M);
+    if (live) wide_put_pair<D>(W.row_in + (size_t)lane * REC * W.K + k, W.K, v, M);
+  } else {
+    const DElem<double, D> ex = delem_shfl_down<D>(x, 1);       // the rows after this one
+    if (lane + 1 < W.n) delem_back(ex, v, M);
+    if (live) wide_put_pair<D>(W.row_out + (size_t)lane * REC * W.K + k, W.K, v, M);
+  }
+}
+
+// lane = (keypoint, run, direction): the same inside the run, per chunk
+template <int D>
+__global__ __launch_bounds__(64) void dwide_scan_chunks_kernel(WideScan W) {
+  constexpr int NV = delem_doubles<D>(), REC = D + D * D;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 2 * W.K * W.nr) return;
+  const int k = idx % W.K, rr = idx / W.K;
+  const bool rev = rr >= W.nr;
+  const int r = rev ? rr - W.nr : rr;
+  const int j0 = r * W.R, j1 = min(W.nc, j0 + W.R);
+  Vec<double, D> v;
+  Mat<double, D> M;
+  if (!rev) {
+    wide_get_pair<D>(W.run_in + (size_t)r * REC * W.K + k, W.K, v, M);
+    for (int j = j0; j < j1; ++j) {
+      wide_put_pair<D>(W.chunk_in + (size_t)j * REC * W.K + k, W.K, v, M);
+      if (j + 1 < j1) delem_apply(load_delem<double, D>(W.elems + (size_t)j * NV * W.K + k, W.K), v, M);
+    }
+  } else {
+    wide_get_pair<D>(W.run_out + (size_t)r * REC * W.K + k, W.K, v, M);
+    for (int j = j1 - 1; j >= j0; --j) {
+      wide_put_pair<D>(W.chunk_out + (size_t)j * REC * W.K + k, W.K, v, M);
+      if (j > j0) delem_back(load_delem<double, D>(W.elems + (size_t)j * NV * W.K + k, W.K), v, M);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+constexpr int kWideCB = 64;            // elements per block of the narrow path's scan (eks_dense.hip: kDenseCB)
 
 template <int D, int O>
 __global__ __launch_bounds__(64) void dwide_replay_kernel(WideGeom G, DenseModelPtrs M,
@@ -179,6 +316,8 @@ __global__ __launch_bounds__(64) void dwide_replay_kernel(WideGeom G, DenseModel
                                                          const double* __restrict__ suf,
                                                          const double* __restrict__ bprior,
                                                          const double* __restrict__ bsuffix,
+                                                         const double* __restrict__ chunk_in,
+                                                         const double* __restrict__ chunk_out,
                                                          float* __restrict__ ms, float* __restrict__ Vs,
                                                          int vs_diag) {
   constexpr int NF = D + D * (D + 1) / 2;            // mean + upper triangle of the covariance
@@ -199,22 +338,27 @@ __global__ __launch_bounds__(64) void dwide_replay_kernel(WideGeom G, DenseModel
   // belief entering the chunk / information leaving it, from the scan (as dense_replay_kernel)
   Vec<double, D> m, eta;
   Mat<double, D> P, J;
-  const int blk = j / kWideCB, ia = j % kWideCB;
-  const double* rp = bprior + ((size_t)blk * G.K + k) * REC;
-  const double* rs = bsuffix + ((size_t)blk * G.K + k) * REC;
+  if (chunk_in != nullptr) {                          // dwide_scan_*: ready per chunk
+    wide_get_pair<D>(chunk_in + (size_t)j * REC * G.K + k, G.K, m, P);
+    wide_get_pair<D>(chunk_out + (size_t)j * REC * G.K + k, G.K, eta, J);
+  } else {                                            // the scan kernels of eks_dense.hip
+    const int blk = j / kWideCB, ia = j % kWideCB;
+    const double* rp = bprior + ((size_t)blk * G.K + k) * REC;
+    const double* rs = bsuffix + ((size_t)blk * G.K + k) * REC;
 #pragma unroll
-  for (int a = 0; a < D; ++a) {
-    m.a[a] = rp[a];
-    eta.a[a] = rs[a];
+    for (int a = 0; a < D; ++a) {
+      m.a[a] = rp[a];
+      eta.a[a] = rs[a];
 #pragma unroll
-    for (int b = 0; b < D; ++b) {
-      P.a[a][b] = rp[D + a * D + b];
-      J.a[a][b] = rs[D + a * D + b];
+      for (int b = 0; b < D; ++b) {
+        P.a[a][b] = rp[D + a * D + b];
+        J.a[a][b] = rs[D + a * D + b];
+      }
     }
+    if (ia > 0) delem_apply(load_delem<double, D>(pre + ((size_t)(j - 1) * G.K + k) * NV), m, P);
+    if (ia + 1 < kWideCB && j + 1 < G.nc)
+      delem_back(load_delem<double, D>(suf + ((size_t)(j + 1) * G.K + k) * NV), eta, J);
   }
-  if (ia > 0) delem_apply(load_delem<double, D>(pre + ((size_t)(j - 1) * G.K + k) * NV), m, P);
-  if (ia + 1 < kWideCB && j + 1 < G.nc)
-    delem_back(load_delem<double, D>(suf + ((size_t)(j + 1) * G.K + k) * NV), eta, J);
   if (j == 0) load_prior<D>(M, k, m, P);              // chunk 0 replays frame 0's update of the prior itself
   // ---- forward: exact filter, one checkpoint (the belief entering the group) per four frames
   double* mine = ck + lane;
@@ -342,13 +486,98 @@ bool dense_wide_covers(int D, int O, int B) {
          B % kWideGroup == 0 && !knob_int(KNOB_DENSE_LEGACY, 0);
 }
 
+// Levels of runs under the 64-row top: L levels of R rows per run bring nc chunk elements down to
+// ceil(nc / R^L) <= 64 rows.  Sequential depth: L (R - 1) compositions going up (~2.4 us each at these
+// occupancies: rocprofv3 per launch on c4w, tools/c4w_prof.sh), the top's 6 shuffle levels, L (R - 1) apply /
+// pull-back steps going down (~1.7 us each); every level costs two launches (~4 us each) and two passes over
+// its rows (~16 ns per row at c4w's width; level 0's rows are the chunk elements themselves, whatever the plan).
+constexpr int kWideTopRows = 64;
+constexpr int kWideMaxLevels = 6;
+struct WidePlan {
+  int L, R;
+  int n[kWideMaxLevels + 1];     // rows per level: n[0] = nc ... n[L] <= 64
+};
+static WidePlan wide_scan_plan(int nc) {
+  WidePlan best{};
+  double best_cost = 1e300;
+  for (int L = 0; L <= kWideMaxLevels; ++L)
+    for (int R = 2; R <= 32; ++R) {
+      WidePlan p{};
+      p.L = L;
+      p.R = R;
+      p.n[0] = nc;
+      for (int l = 0; l < L; ++l) p.n[l + 1] = (p.n[l] + R - 1) / R;
+      if (p.n[L] > kWideTopRows) continue;
+      double cost = L * ((R - 1) * 4.1 + 8.0);
+      for (int l = 1; l <= L; ++l) cost += 0.032 * p.n[l];      // two passes over the rows of the upper levels
+      if (cost < best_cost) {
+        best_cost = cost;
+        best = p;
+      }
+      if (L == 0) break;
+    }
+  return best;
+}
+// doubles of scratch the scan needs besides the two per-chunk arrays: rows and belief / information pairs of
+// the levels above the chunks
+size_t dense_wide_scan_scratch_doubles(int K, int D, int nc) {
+  const WidePlan p = wide_scan_plan(nc);
+  size_t rows = 0;
+  for (int l = 1; l <= p.L; ++l) rows += p.n[l];
+  return rows * K * (3 * D * D + 2 * D + 1 + 2 * (D + D * D));
+}
+
+template <int D>
+static void wide_scan_launches(const WidePlan& p, const WideScan* lv, const WideTop& top, hipStream_t st) {
+  for (int l = 0; l < p.L; ++l)     // up: rows of level l -> run aggregates = rows of level l + 1
+    hipLaunchKernelGGL(dwide_scan_runs_kernel<D>, dim3((unsigned)(((long)lv[l].K * lv[l].nr + 63) / 64)), dim3(64), 0,
+                       st, lv[l]);
+  hipLaunchKernelGGL(dwide_scan_top_kernel<D>, dim3((unsigned)top.K), dim3(128), 0, st, top);
+  for (int l = p.L - 1; l >= 0; --l)   // down: a level's per-row pairs are the per-run pairs of the level below
+    hipLaunchKernelGGL(dwide_scan_chunks_kernel<D>, dim3((unsigned)((2L * lv[l].K * lv[l].nr + 63) / 64)), dim3(64),
+                       0, st, lv[l]);
+}
+
+int dense_wide_scan(int K, int D, int nc, const double* elems, const double* first, double* scratch,
+                    double* chunk_in, double* chunk_out, hipStream_t st) {
+  const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
+  const WidePlan p = wide_scan_plan(nc);
+  const double* rows[kWideMaxLevels + 1];
+  double *in[kWideMaxLevels + 1], *out[kWideMaxLevels + 1];
+  rows[0] = elems;
+  in[0] = chunk_in;
+  out[0] = chunk_out;
+  double* q = scratch;
+  for (int l = 1; l <= p.L; ++l) {
+    rows[l] = q;
+    q += (size_t)p.n[l] * K * nv;
+    in[l] = q;
+    q += (size_t)p.n[l] * K * rec;
+    out[l] = q;
+    q += (size_t)p.n[l] * K * rec;
+  }
+  WideScan lv[kWideMaxLevels];
+  for (int l = 0; l < p.L; ++l)
+    lv[l] = WideScan{K, p.n[l], p.R, p.n[l + 1], rows[l], first, const_cast<double*>(rows[l + 1]), in[l + 1], out[l + 1],
+                     in[l], out[l]};
+  const WideTop top{K, p.n[p.L], rows[p.L], first, in[p.L], out[p.L]};
+  if (D == 2)
+    wide_scan_launches<2>(p, lv, top, st);
+  else if (D == 3)
+    wide_scan_launches<3>(p, lv, top, st);
+  else
+    return EKS_ERR_UNSUPPORTED;
+  return hip_status(hipGetLastError());
+}
+
 int dense_wide_summarize(int T, int K, int D, int O, int B, int nc, const DenseModelPtrs& M, const double* s,
-                         const float* y, const float* var, double* elems, double* first, hipStream_t st) {
+                         const float* y, const float* var, double* elems, int soa, double* first,
+                         hipStream_t st) {
   const WideGeom G{K, T, O, B, nc};
   const int lanes = K * nc;
   const dim3 grid((lanes + 63) / 64), block(64);
 #define EKS_WS(DD, OO) \
-  hipLaunchKernelGGL((dwide_summarize_kernel<DD, OO>), grid, block, 0, st, G, M, s, y, var, elems, first)
+  hipLaunchKernelGGL((dwide_summarize_kernel<DD, OO>), grid, block, 0, st, G, M, s, y, var, elems, soa, first)
 #define EKS_WS_O(DD)                    \
   switch (O) {                          \
     case 2: EKS_WS(DD, 2); break;       \
@@ -371,14 +600,14 @@ int dense_wide_summarize(int T, int K, int D, int O, int B, int nc, const DenseM
 
 int dense_wide_replay(int T, int K, int D, int O, int B, int nc, const DenseModelPtrs& M, const double* s,
                       const float* y, const float* var, const double* pre, const double* suf,
-                      const double* bprior, const double* bsuffix, float* ms, float* Vs, int vs_diag,
-                      hipStream_t st) {
+                      const double* bprior, const double* bsuffix, const double* chunk_in,
+                      const double* chunk_out, float* ms, float* Vs, int vs_diag, hipStream_t st) {
   const WideGeom G{K, T, O, B, nc};
   const int lanes = K * nc;
   const dim3 grid((lanes + 63) / 64), block(64);
 #define EKS_WR(DD, OO)                                                                                     \
   hipLaunchKernelGGL((dwide_replay_kernel<DD, OO>), grid, block, 0, st, G, M, s, y, var, pre, suf, bprior, \
-                     bsuffix, ms, Vs, vs_diag)
+                     bsuffix, chunk_in, chunk_out, ms, Vs, vs_diag)
 #define EKS_WR_O(DD)                    \
   switch (O) {                          \
     case 2: EKS_WR(DD, 2); break;       \

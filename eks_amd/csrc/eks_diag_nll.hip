@@ -366,6 +366,200 @@ __global__ void diag_nll_assemble_tree_kernel(NllGeom G, DiagModel M, NllWs W, i
   }
 }
 
+// N1+N2 in ONE launch for the Adam loop (one value of s per keypoint, value + d/d log s; round 3).  The
+// two-launch form above spent 36 us in the chunk summaries and 21 us + a launch gap composing them: the
+// tree kernel is one block per keypoint whose lanes gather 13 planes x ~200 chunks with a stride of a whole
+// plane row (1.3 M scattered loads per evaluation).  Here
+//   * block = (64-chain tile, group of kGfWaves CONSECUTIVE chunks), wave = chunk, lane = chain: the
+//     chunk summaries never leave registers as float32 - they are promoted to float64 duals and composed
+//     in time order by a 3-level tree through LDS; wave 0 stores ONE group summary (13 doubles per chain,
+//     [tile][group][field][lane]: coalesced);
+//   * the block that takes the LAST ticket of its tile (agent-scope release / acquire around an atomic
+//     counter - no spinning, so no co-residency assumption) reads the tile's group summaries back
+//     (coalesced, a contiguous run of groups per wave), composes them the same way, pushes the prior
+//     through the result, sums the D chains of a keypoint with wave shuffles, writes nll / dnll and - when
+//     every optimiser block is one keypoint - applies the Adam step of its 64 / D keypoints on the spot;
+//   * all blocks of a tile share its chains, so the "every keypoint of the tile has stopped" exit is
+//     block-uniform and the ticket count of a tile is all or nothing.
+// The chunk length is chosen so that the grid is a whole number of 256-CU rounds (C3: 8 tiles x 32 groups).
+constexpr int kGfWaves = 8;
+constexpr int kGfFields = 13;          // (A, b, C, eta, J, ell) x (value, derivative) + reference state
+constexpr int kGfChunkMin = 256;      // (shorter chunks never leave the full recursion: nll_summarize_chunk)
+
+// Diagnostic build only (-DEKS_GF_STAMPS, tools/gf_stamps.py): lane 0 of every wave of the first 256 blocks
+// stamps the 100 MHz real-time counter at the phase boundaries.
+#ifdef EKS_GF_STAMPS
+__device__ unsigned long long g_gf_stamps[256][kGfWaves][8];
+#define GF_STAMP(ph)                                                                                         \
+  do {                                                                                                       \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 256)                                                         \
+      g_gf_stamps[blockIdx.x][threadIdx.x >> 6][ph] = __builtin_amdgcn_s_memrealtime();                      \
+  } while (0)
+#else
+#define GF_STAMP(ph) do { } while (0)
+#endif
+
+struct GradFuseWs {
+  double* grp;          // [ntile][ngroups][kGfFields][64]
+  int32_t* tickets;     // [ntile], zero between evaluations (the last block of a tile resets its own)
+  int ngroups;
+};
+
+__device__ __forceinline__ void gf_put(double* slot, const NllAcc<DualD>& a) {
+  const DualD f[6] = {a.e.A, a.e.b, a.e.C, a.e.eta, a.e.J, a.ell};
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    slot[q * 64] = f[q].v;
+    slot[(6 + q) * 64] = f[q].d;
+  }
+  slot[12 * 64] = a.xr;
+}
+__device__ __forceinline__ NllAcc<DualD> gf_take(const double* slot) {
+  DualD f[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) f[q] = DualD(slot[q * 64], slot[(6 + q) * 64]);
+  NllAcc<DualD> a;
+  a.e.A = f[0]; a.e.b = f[1]; a.e.C = f[2]; a.e.eta = f[3]; a.e.J = f[4]; a.ell = f[5];
+  a.xr = slot[12 * 64];
+  return a;
+}
+// compose the accumulators of the block's first `nvalid` waves in wave order; the result is wave 0's.
+// Every LDS slot is written once per call.
+__device__ __forceinline__ void gf_block_tree(double* lds, int w, int lane, int nvalid, NllAcc<DualD>& acc) {
+#pragma unroll
+  for (int half = 1; half < kGfWaves; half <<= 1) {
+    const int span = half << 1;
+    if ((w & (span - 1)) == half && w < nvalid) gf_put(lds + (size_t)w * kGfFields * 64 + lane, acc);
+    __syncthreads();
+    if ((w & (span - 1)) == 0 && w + half < nvalid)
+      acc = nll_acc_combine(acc, gf_take(lds + (size_t)(w + half) * kGfFields * 64 + lane));
+  }
+}
+
+// Publication of a block's results to blocks on OTHER XCDs (each XCD has its own L2).  A release fence at
+// agent scope is `buffer_wbl2 sc1` - it walks the whole L2 and cost 5 us per block here (in-kernel stamps,
+// tools/gf_stamps.py).  Instead every published value is stored with an agent-scope atomic store (gfx950:
+// `global_store ... sc1`, written through the L2), the wave waits for the stores to be acknowledged
+// (s_waitcnt vmcnt(0): the same ordering the memory model's own release sequences rely on between two
+// agent-scope atomics) and only then takes the ticket with an agent-scope atomic.  The
+// readers use an agent-scope acquire fence (`buffer_inv sc1`) after observing the atomic.  No plain store
+// is published this way, so no dirty L2 line has to be written back.
+__device__ __forceinline__ void gf_publish(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gf_put_published(double* slot, const NllAcc<DualD>& a) {
+  const DualD f[6] = {a.e.A, a.e.b, a.e.C, a.e.eta, a.e.J, a.ell};
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    gf_publish(slot + q * 64, f[q].v);
+    gf_publish(slot + (6 + q) * 64, f[q].d);
+  }
+  gf_publish(slot + 12 * 64, a.xr);
+}
+__device__ __forceinline__ void gf_stores_acknowledged() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+}
+
+template <bool UNIT>
+__global__ __launch_bounds__(64 * kGfWaves) void diag_nll_grad_fused_kernel(NllGeom G, DiagModel M, GradFuseWs W,
+                                                                           const float* __restrict__ y,
+                                                                           const double* __restrict__ rconst,
+                                                                           const double* __restrict__ s_kp,
+                                                                           double* __restrict__ nll,
+                                                                           double* __restrict__ dnll, AdamFuse F) {
+  __shared__ double lds[kGfWaves * kGfFields * 64];
+  __shared__ int last_flag;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int tile = blockIdx.x % G.ntile, grp = blockIdx.x / G.ntile;
+  if (F.state != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *F.n_active_next = 0;
+  const int n_raw = tile * 64 + lane;
+  const bool chain_ok = n_raw < G.N;
+  const int n = chain_ok ? n_raw : G.N - 1;          // lanes past the last chain shadow it (results unused)
+  const int k = n / G.D, d = n - k * G.D;
+  const size_t dd = (size_t)k * G.D * G.D + (size_t)d * (G.D + 1);
+  const int j = grp * kGfWaves + w;
+  const int nvalid = min(kGfWaves, G.ncn - grp * kGfWaves);
+  const int t0 = j * G.BN, len = j < G.ncn ? min(G.BN, G.T - t0) : 0;
+  const double r_n = rconst[n], a_n = M.A[dd], c_n = M.C[dd], q_n = M.Q[dd];
+  const BufferRows ld{__builtin_amdgcn_make_buffer_rsrc(
+                          const_cast<float*>(y + (size_t)(j < G.ncn ? t0 : 0) * G.N + tile * 64), 0, 0x7FFFFFFF,
+                          0x00020000),
+                      (unsigned)((n - tile * 64) * 4), (unsigned)(G.N * 4)};
+  double* mine = W.grp + ((size_t)tile * W.ngroups + grp) * kGfFields * 64 + lane;
+  const int kb = F.state != nullptr ? F.kp_block[k] : 0;
+  bool running = chain_ok;
+  if (F.state != nullptr) {
+    running = chain_ok && adam_block_running(F.state, kb, F.cap);
+    if (!__any(running)) return;                     // the same answer in every wave of the tile's blocks
+  }
+  GF_STAMP(0);
+  NllAcc<DualD> acc;
+  if (j < G.ncn) {
+    double sq[1] = {s_kp[k] * q_n};
+    NllElem<Dual> out[1];
+    nll_summarize_chunk<Dual, 1, UNIT>(ld, t0, len, r_n, a_n, c_n, sq, out, false);
+    acc.e.A = DualD(out[0].e.A.v, out[0].e.A.d);
+    acc.e.b = DualD(out[0].e.b.v, out[0].e.b.d);
+    acc.e.C = DualD(out[0].e.C.v, out[0].e.C.d);
+    acc.e.eta = DualD(out[0].e.eta.v, out[0].e.eta.d);
+    acc.e.J = DualD(out[0].e.J.v, out[0].e.J.d);
+    acc.ell = DualD(out[0].ell, out[0].dell);
+    acc.xr = (double)out[0].xref;
+  }
+  GF_STAMP(1);
+  gf_block_tree(lds, w, lane, nvalid, acc);
+  GF_STAMP(2);
+  if (w == 0) {
+    gf_put_published(mine, acc);
+    gf_stores_acknowledged();
+    if (lane == 0) last_flag = atomicAdd(W.tickets + tile, 1) == W.ngroups - 1;
+  }
+  __syncthreads();
+  GF_STAMP(3);
+  if (!last_flag) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other blocks' group summaries
+  // ---- the tile's last block: compose its groups (a contiguous run per wave), finish, step
+  const int per = (W.ngroups + kGfWaves - 1) / kGfWaves;
+  const int g0 = w * per, g1 = min(W.ngroups, g0 + per);
+  const int nlive = (W.ngroups + per - 1) / per;
+  const double* base = W.grp + (size_t)tile * W.ngroups * kGfFields * 64 + lane;
+  if (g0 < g1) {
+    acc = gf_take(base + (size_t)g0 * kGfFields * 64);
+    for (int g = g0 + 1; g < g1; ++g) acc = nll_acc_combine(acc, gf_take(base + (size_t)g * kGfFields * 64));
+  }
+  GF_STAMP(4);
+  gf_block_tree(lds, w, lane, nlive, acc);
+  GF_STAMP(5);
+  if (w != 0) return;
+  if (lane == 0) W.tickets[tile] = 0;                // ready for the next evaluation (stream order)
+  const DualD m = DualD(M.m0[(size_t)k * G.D + d] - acc.xr), P = DualD(M.S0[dd]);   // relative to the reference
+  const DualD den = DualD(1.0) + acc.e.J * P;
+  const DualD inv = rcp(den);
+  const DualD ll = acc.ell - DualD(0.5) * log_with_rcp(den, inv) +
+                   (acc.e.eta * m + DualD(0.5) * acc.e.eta * acc.e.eta * P - DualD(0.5) * acc.e.J * m * m) * inv;
+  double v = ll.v, g = ll.d;
+  for (int off = 1; off < G.D; off <<= 1) {          // the D chains of a keypoint sit in adjacent lanes
+    v += __shfl_xor(v, off);
+    g += __shfl_xor(g, off);
+  }
+  bool still = false;
+  if (running && d == 0) {
+    v = -v;
+    const bool fin = isfinite(v);                    // eks/core.py:650
+    nll[k] = fin ? v : 1e12;
+    dnll[k] = fin ? -g : 0.0;
+    if (F.state != nullptr && F.step_in_kernel)
+      still = adam_step_block(kb, F.offs, F.members, nll, dnll, F.lr, F.lo, F.hi, F.tol, F.cap, F.state,
+                              F.s_keypoint);
+  }
+  if (F.state != nullptr && F.step_in_kernel) {
+    const int cnt = __popcll(__ballot(still));
+    if (lane == 0 && cnt) atomicAdd(F.n_active_cur, cnt);
+  }
+  GF_STAMP(6);
+}
+
 // N2'' chunk-parallel assembly for the grid search (value only, converged-entry summaries): a
 // converged-entry summary has A = 0 - the mean entering the NEXT chunk is its b, whatever came
 // before - so the walk over the chunks has no sequential dependency beyond chunk 0:
@@ -445,12 +639,38 @@ __global__ __launch_bounds__(64 * kAsmWaves) void diag_nll_assemble_par_kernel(N
   nll[(size_t)k * G.n_cand + ci] = isfinite(v) ? v : 1e12;                // eks/core.py:650
 }
 
+// may the gradient evaluation take the single-launch kernel (diag_nll_grad_fused_kernel)?  One value of s
+// per keypoint, whole 64-chain tiles addressed through 32-bit buffer offsets, the chains of a keypoint in
+// adjacent lanes of one wave.
+static int grad_fused_chunk(int T, int N);
+static bool grad_fused_ok(int T, int N, int D, int n_cand, int per_keypoint) {
+  return n_cand == 1 && per_keypoint && N > 32 && (D & (D - 1)) == 0 && D <= 64 &&
+         (long)grad_fused_chunk(T, N) * N * 4 < (1L << 31) && !knob_int(KNOB_NLL_GRAD_UNFUSED, 0);
+}
+// frames per chunk of that kernel: blocks = tiles x groups of kGfWaves chunks, a whole number of 256-CU
+// rounds when the problem is large enough (C3: 8 tiles x 32 groups x 8 chunks of 392 frames)
+static int grad_fused_chunk(int T, int N) {
+  const long ntile = (N + 63) / 64;
+  long rounds = ((long)T * ntile + 128L * kGfWaves * kNllChunkGrad) / (256L * kGfWaves * kNllChunkGrad);
+  if (rounds < 1) rounds = 1;
+  long groups = (256 * rounds + ntile - 1) / ntile;
+  if (groups < 1) groups = 1;
+  long bn = (T + groups * kGfWaves - 1) / (groups * kGfWaves);
+  bn = (bn + 7) / 8 * 8;
+  if (bn < kGfChunkMin) bn = kGfChunkMin;
+  const int b = knob_int(KNOB_NLL_GRAD_CHUNK, (int)bn);
+  return b < 8 ? 8 : b;
+}
+
 static NllGeom make_geom(int T, int N, int D, int n_cand, int per_keypoint, bool grad, int ncl) {
   NllGeom G;
   G.N = N;
   G.T = T;
   G.D = D;
   G.BN = grad ? kNllChunkGrad : kNllChunk;
+  if (grad && grad_fused_ok(T, N, D, n_cand, per_keypoint)) {
+    G.BN = grad_fused_chunk(T, N);
+  }
   G.B0 = G.BN;
   if (!grad) {
     // one block per (64-chain tile, chunk): pick the chunk length so that the grid is a whole
@@ -510,7 +730,7 @@ static bool nll_uses_tree(int K, int D, int n_cand, int ncn) {
 // assembly - the kernel that can apply the optimiser step itself (AdamFuse::step_in_kernel)?
 bool diag_nll_grad_tree(int T, int K, int D) {
   const NllGeom G = make_geom(T, K * D, D, 1, 1, true, 1);
-  return nll_uses_tree(K, D, 1, G.ncn);
+  return grad_fused_ok(T, K * D, D, 1, 1) || nll_uses_tree(K, D, 1, G.ncn);
 }
 
 size_t diag_nll_workspace_bytes(int T, int N, int n_cand) {
@@ -524,7 +744,14 @@ size_t diag_nll_workspace_bytes(int T, int N, int n_cand) {
   return 11 * fl + 2 * db + adam_extra_bytes(N);
 }
 
-size_t adam_extra_bytes(int N) { return align_up((size_t)N * sizeof(int32_t), 256) + 256; }
+// [keypoint -> block map : N ints][tile tickets : ceil(N / 64) ints][second counter : 256 B]
+size_t adam_extra_bytes(int N) {
+  return align_up((size_t)N * sizeof(int32_t), 256) + align_up((size_t)((N + 63) / 64) * sizeof(int32_t), 256) + 256;
+}
+int32_t* nll_ws_tickets(void* ws, int T, int N, int n_cand) {
+  char* tail = static_cast<char*>(ws) + diag_nll_workspace_bytes(T, N, n_cand) - adam_extra_bytes(N);
+  return reinterpret_cast<int32_t*>(tail + align_up((size_t)N * sizeof(int32_t), 256));
+}
 
 int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M,
              const double* s_cand, int n_cand, int per_keypoint, double* nll, double* dnll,
@@ -536,6 +763,29 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
   if (fuse) F = *fuse;
   const int ncl = pick_ncl(n_cand, grad);
   NllGeom G = make_geom(T, N, D, n_cand, per_keypoint, grad, ncl);
+  if (grad && grad_fused_ok(T, N, D, n_cand, per_keypoint)) {
+    GradFuseWs FW;
+    FW.ngroups = (G.ncn + kGfWaves - 1) / kGfWaves;
+    FW.grp = static_cast<double*>(ws);
+    FW.tickets = nll_ws_tickets(ws, T, N, n_cand);
+    const size_t grp_bytes = (size_t)G.ntile * FW.ngroups * kGfFields * 64 * sizeof(double);
+    if (grp_bytes > diag_nll_workspace_bytes(T, N, n_cand) - adam_extra_bytes(N)) return EKS_ERR_WORKSPACE;
+    {
+      if (!fuse) {   // (eks_adam_run zeroes the tickets once; every evaluation leaves them zero)
+        const hipError_t e = hipMemsetAsync(FW.tickets, 0, (size_t)G.ntile * sizeof(int32_t), st);
+        if (e != hipSuccess) return hip_status(e);
+      }
+      ProfScope ps("diag_nll_grad_fused", st);
+      const dim3 grid((unsigned)(G.ntile * FW.ngroups)), block(64 * kGfWaves);
+      if (d.flags & EKS_FLAG_UNIT_AC)
+        hipLaunchKernelGGL(diag_nll_grad_fused_kernel<true>, grid, block, 0, st, G, M, FW, y, rconst, s_cand, nll,
+                           dnll, F);
+      else
+        hipLaunchKernelGGL(diag_nll_grad_fused_kernel<false>, grid, block, 0, st, G, M, FW, y, rconst, s_cand, nll,
+                           dnll, F);
+      return hip_status(hipGetLastError());
+    }
+  }
   // (the tree cannot take converged-entry summaries: they are only valid in sequential order)
   const bool tree = nll_uses_tree(K, D, n_cand, G.ncn);
   if (F.state && F.step_in_kernel && !(grad && tree)) return EKS_ERR_UNSUPPORTED;   // (caller asks diag_nll_grad_tree)
@@ -638,3 +888,9 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
 }
 
 }  // namespace eks
+
+#ifdef EKS_GF_STAMPS
+extern "C" int eks_debug_gf_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(eks::g_gf_stamps), sizeof(eks::g_gf_stamps));
+}
+#endif

@@ -20,7 +20,8 @@ static inline int hip_status(hipError_t e) { return e == hipSuccess ? EKS_OK : E
 enum Knob {
   KNOB_SMOOTH_UNFUSED, KNOB_SUMMARIZE_REVERSE, KNOB_REPLAY_FORWARD, KNOB_REPLAY_RECOMPUTE, KNOB_SCAN_CH,
   KNOB_SMOOTH_TILE, KNOB_DENSE_CHUNK, KNOB_NLL_NCL, KNOB_NLL_CHUNK, KNOB_NLL_CHUNK0, KNOB_NLL_WPB,
-  KNOB_NLL_EXACT_ENTRY, KNOB_NLL_ASSEMBLE_SEQ, KNOB_DENSE_LEGACY, KNOB_COUNT
+  KNOB_NLL_EXACT_ENTRY, KNOB_NLL_ASSEMBLE_SEQ, KNOB_DENSE_LEGACY, KNOB_NLL_GRAD_UNFUSED, KNOB_NLL_GRAD_CHUNK,
+  KNOB_DENSE_TREE_SCAN, KNOB_COUNT
 };
 bool knob_set(Knob k);               // the variable exists
 int knob_int(Knob k, int dflt);      // its integer value, or dflt when unset
@@ -48,7 +49,8 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
              const double* s_cand, int n_cand, int per_keypoint, double* nll, double* dnll,
              void* ws, size_t ws_bytes, hipStream_t st, const AdamFuse* fuse = nullptr);
 bool diag_nll_grad_tree(int T, int K, int D);
-size_t adam_extra_bytes(int N);     // tail of the NLL workspace used by eks_adam_run
+size_t adam_extra_bytes(int N);     // tail of the NLL workspace: keypoint -> block map, tile tickets, counter
+int32_t* nll_ws_tickets(void* ws, int T, int N, int n_cand);   // the tile tickets inside that tail
 int adam_prepare(int n_blocks, int K, const int32_t* offs, const int32_t* members, int32_t* kp_block,
                  int32_t* counter_a, int32_t* counter_b, hipStream_t st);
 
@@ -63,15 +65,19 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
 bool dense_wave_covers(int T, int K, int D, int O);
 int dense_wave_smooth(const eks_dims_t& d, const float* y, const float* var, const DenseModel& M, float* ms,
                       float* Vs, void* ws, size_t ws_bytes, hipStream_t st);
-// wide sessions: prefetching summarize / checkpointed replay (eks_dense_wide.hip), same scan in between
+// wide sessions: prefetching summarize / per-lane sequential scan / checkpointed replay (eks_dense_wide.hip)
 struct DenseModelPtrs;
 bool dense_wide_covers(int D, int O, int B);
 int dense_wide_summarize(int T, int K, int D, int O, int B, int nc, const DenseModelPtrs& M, const double* s,
-                         const float* y, const float* var, double* elems, double* first, hipStream_t st);
+                         const float* y, const float* var, double* elems, int soa, double* first,
+                         hipStream_t st);
+size_t dense_wide_scan_scratch_doubles(int K, int D, int nc);
+int dense_wide_scan(int K, int D, int nc, const double* elems, const double* first, double* scratch,
+                    double* chunk_in, double* chunk_out, hipStream_t st);
 int dense_wide_replay(int T, int K, int D, int O, int B, int nc, const DenseModelPtrs& M, const double* s,
                       const float* y, const float* var, const double* pre, const double* suf,
-                      const double* bprior, const double* bsuffix, float* ms, float* Vs, int vs_diag,
-                      hipStream_t st);
+                      const double* bprior, const double* bsuffix, const double* chunk_in,
+                      const double* chunk_out, float* ms, float* Vs, int vs_diag, hipStream_t st);
 size_t dense_nll_workspace_bytes(int T, int K, int D, int O, int n_cand);
 int dense_nll(const eks_dims_t& d, const float* y, const double* rconst, const DenseModel& M,
               const double* s_cand, int n_cand, int per_keypoint, double* nll, double* dnll,

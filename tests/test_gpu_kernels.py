@@ -270,8 +270,9 @@ def test_smooth_dense_matches_oracle(T, K, D, O, general_A):
 ])
 def test_smooth_dense_wide_sessions_match_oracle(T, K, D, O, general_A, set_knob):
     """Wide sessions run the keypoint-major kernels: rows prefetched a group of four frames ahead, filtered beliefs
-    as LDS checkpoints per group with the group filtered again on the way back (eks_dense_wide.hip), and
-    (EKS_DENSE_LEGACY=1) the round-1 kernels with their scratch stream; both against the C port of the reference
+    as LDS checkpoints per group with the group filtered again on the way back, a per-lane sequential two-level
+    scan in between (eks_dense_wide.hip); the same with the narrow path's tree scan (EKS_DENSE_TREE_SCAN=1), and
+    (EKS_DENSE_LEGACY=1) the round-1 kernels with their scratch stream; all against the C port of the reference
     recursion on every frame."""
     from eks_amd import hip_ops
     from oracle import c_oracle
@@ -281,8 +282,9 @@ def test_smooth_dense_wide_sessions_match_oracle(T, K, D, O, general_A, set_knob
     s = np.exp(np.random.default_rng(3).uniform(-3, 4, K))
     Rd = orc.build_R_from_vars(np.swapaxes(arrs['ensemble_vars'], 0, 1))
     ms_o, Vs_o, _ = c_oracle.smooth(arrs['ys'], Rd, arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], s)
-    for legacy in ('0', '1'):
+    for legacy, tree in (('0', '0'), ('0', '1'), ('1', '0')):
         set_knob('EKS_DENSE_LEGACY', legacy)
+        set_knob('EKS_DENSE_TREE_SCAN', tree)        # the narrow path's tree scan under the wide kernels
         ms, Vs = hip_ops.smooth(_dev(y), _dev(var), *_params_dev(arrs), _dev(s), flags=0)
         ms = np.transpose(ms.cpu().numpy().astype(np.float64), (1, 0, 2))
         Vs = np.transpose(Vs.cpu().numpy().astype(np.float64), (1, 0, 2, 3))
@@ -437,6 +439,49 @@ def test_nll_grad_diag_matches_oracle(T, K, unit):
                                arrs['Qs'], s, Rc, want_grad=True)
     assert (np.abs(nll.cpu().numpy()[:, 0] - ref) / np.abs(ref)).max() < 1e-5
     assert (np.abs(g.cpu().numpy()[:, 0] - gref) / np.abs(gref).max()).max() < 1e-4
+
+
+@pytest.mark.parametrize('T,K,unit', [(5000, 40, True), (2111, 33, False)])
+def test_nll_grad_single_launch_matches_oracle_and_two_launch_form(T, K, unit, set_knob):
+    """More than 32 chains: value + gradient come from ONE launch (diag_nll_grad_fused_kernel: chunk summaries
+    composed in the block, the tile's last block finishes) - against the oracle, and against the two-launch
+    form (float32 summary planes + tree kernel) it replaces.  K = 40 / 33: the last 64-chain tile is partial."""
+    from eks_amd import hip_ops
+    arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=5 + T, unit=unit)
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    rconst = hip_ops.const_r(_dev(var_tk), 1e-4)
+    s = np.exp(np.random.default_rng(1).uniform(-6, 6, K))
+    args = (_dev(y_tk), rconst, *_params_dev(arrs), _dev(s[:, None]))
+    nll, g = [a.cpu().numpy()[:, 0] for a in hip_ops.nll(*args, per_keypoint=True, want_grad=True, flags=flags)]
+    ref, gref = orc.filter_nll(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], s,
+                               rconst.cpu().numpy(), want_grad=True)
+    assert (np.abs(nll - ref) / np.abs(ref)).max() < 1e-5
+    assert (np.abs(g - gref) / np.abs(gref).max()).max() < 1e-4
+    set_knob('EKS_NLL_GRAD_UNFUSED', '1')
+    nll2, g2 = [a.cpu().numpy()[:, 0] for a in hip_ops.nll(*args, per_keypoint=True, want_grad=True, flags=flags)]
+    assert (np.abs(nll - nll2) / np.abs(ref)).max() < 2e-6
+    assert (np.abs(g - g2) / np.abs(gref).max()).max() < 2e-5
+
+
+def test_nll_grad_single_launch_is_bit_reproducible():
+    """The tile's last block - whichever block that is in a given launch - reads the group summaries the other
+    blocks (on other XCDs) published without an L2 write-back (agent-scope atomic stores, see gf_publish): the
+    composition order is fixed, so every evaluation of the same problem must return the same bits.  A summary
+    read before it was visible would show up here."""
+    from eks_amd import _lib, hip_ops, synth
+    T, K = 60_000, 128
+    y, var = synth.singlecam_observations_torch(T, K, seed=9, device=torch.device('cuda', 0))
+    eye = torch.eye(2, dtype=torch.float64, device=y.device).expand(K, 2, 2).contiguous()
+    m0 = torch.zeros(K, 2, dtype=torch.float64, device=y.device)
+    rconst = hip_ops.const_r(var)
+    s = torch.exp(torch.linspace(-5, 5, K, dtype=torch.float64, device=y.device))[:, None].contiguous()
+    flags = _lib.FLAG_DIAG_MODEL | _lib.FLAG_UNIT_AC
+    first = hip_ops.nll(y, rconst, m0, eye * 4.0, eye, eye, eye, s, per_keypoint=True, want_grad=True, flags=flags)
+    first = [a.clone() for a in first]
+    assert bool(torch.isfinite(first[0]).all()) and bool(torch.isfinite(first[1]).all())
+    for _ in range(200):
+        out = hip_ops.nll(y, rconst, m0, eye * 4.0, eye, eye, eye, s, per_keypoint=True, want_grad=True, flags=flags)
+        assert torch.equal(out[0], first[0]) and torch.equal(out[1], first[1])
 
 
 @pytest.mark.parametrize('T,K,D,O', [(800, 3, 3, 4), (300, 2, 4, 8), (200, 2, 2, 2)])
