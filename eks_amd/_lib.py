@@ -13,6 +13,7 @@ EKS_OK = 0
 FLAG_DIAG_MODEL = 1
 FLAG_VS_DIAG = 2
 FLAG_UNIT_AC = 4
+FLAG_Q_PD = 8
 
 
 class EksDims(ctypes.Structure):

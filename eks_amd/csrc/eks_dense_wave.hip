@@ -20,6 +20,17 @@
 //                      fuse with the future's information, RTS backwards, outputs.  The second scan level is
 //                      part of this launch: two launches in all instead of four.
 //
+// SCORE form of the same two kernels (round 3; the optimiser's loss on this path, eks/core.py:640-650 with
+// jax.value_and_grad at :652): constant R instead of the frames' variances, no outputs; the replay's exact
+// filter sums the innovation log-densities (the marginal log-likelihood) and its RTS pass sums Fisher's
+// identity for the score,
+//     d loglik / d log s = sum_t  E[ d/d log s  log N(x_t; F x_{t-1}, s Q) | y ]
+//                        = sum_t  ( tr((sQ)^-1 E[w_t w_t^T | y]) - D ) / 2,     w_t = x_t - F x_{t-1},
+//     E[w w^T | y] = dm dm^T + V_t + F V_{t-1} F^T - F V_{t-1,t} - (F V_{t-1,t})^T,  V_{t-1,t} = G_{t-1} V_t,
+// exact for the exact smoothing distribution and Q positive definite (the caller's EKS_FLAG_Q_PD) - plain
+// float64 where the dual-number kernels (eks_loss.hip) carry 68 doubles per element through every
+// composition and spill (0.26 ms per evaluation on configs[3] against 0.08 here).
+//
 // Matrices are float64 in registers; R_t is diagonal, so a frame's observations are absorbed one scalar at
 // a time (rank-1 forms, no inverse); the scan's compositions use the Cholesky / Woodbury forms of
 // eks_dense_math.hpp without the log-likelihood term the smoother does not need.  Wide sessions (more than
@@ -101,7 +112,7 @@ __device__ __forceinline__ void dw_request_rows(const float* __restrict__ y, con
     for (int o = 0; o < O / W; ++o) {
       if (i < nrows) {
         R.a[i][o] = *reinterpret_cast<const fw*>(y + r + o * W);
-        R.b[i][o] = *reinterpret_cast<const fw*>(var + r + o * W);
+        R.b[i][o] = var ? *reinterpret_cast<const fw*>(var + r + o * W) : fw(1.f);   // (SCORE: constant R)
       } else {
         R.a[i][o] = fw(0.f);
         R.b[i][o] = fw(1.f);
@@ -119,7 +130,7 @@ __device__ __forceinline__ void dw_park_rows(const DwRows<O>& R, float* __restri
 #pragma unroll
     for (int o = 0; o < O / W; ++o) {
       *reinterpret_cast<fw*>(ly + ((size_t)i * 64 + lane) * O + o * W) = R.a[i][o];
-      *reinterpret_cast<fw*>(lv + ((size_t)i * 64 + lane) * O + o * W) = R.b[i][o];
+      if (lv) *reinterpret_cast<fw*>(lv + ((size_t)i * 64 + lane) * O + o * W) = R.b[i][o];
     }
 }
 
@@ -127,17 +138,19 @@ __device__ __forceinline__ void dw_park_rows(const DwRows<O>& R, float* __restri
 // SUBS wave pairs per workgroup (each pair = one (keypoint, 64 chunks) unit): with more units than CUs, two
 // 2-wave workgroups on one CU could land on the same SIMDs and halve each other's float64 rate (measured:
 // 392 units of 2 waves 45 us, their own lifetime 28 us); a 4-wave workgroup spreads over the CU's four SIMDs.
-template <int D, int O, int SUBS>
+template <int D, int O, int SUBS, bool SCORE>
 __global__ __launch_bounds__(128 * SUBS) void dw_summarize_kernel(DwGeom G, DenseModelPtrs M,
                                                           const double* __restrict__ s,
                                                           const float* __restrict__ y,
                                                           const float* __restrict__ var,
+                                                          const double* __restrict__ rconst,
                                                           double* __restrict__ pre_ex,
                                                           double* __restrict__ suf_ex,
                                                           double* __restrict__ agg,
                                                           double* __restrict__ first) {
   constexpr int NV = delem_doubles<D>();
-  __shared__ float ly[2 * SUBS][kDwB * 64 * O], lv[2 * SUBS][kDwB * 64 * O];   // each wave parks its own copy
+  // each wave parks its own copy of its rows (SCORE reads no variances: constant R)
+  __shared__ float ly[2 * SUBS][kDwB * 64 * O], lv[SCORE ? 1 : 2 * SUBS][SCORE ? 1 : kDwB * 64 * O];
   const int unit = blockIdx.x * SUBS + (threadIdx.x >> 7);
   if (unit >= G.K * G.nwb) return;                    // (no barrier in this kernel)
   const int k = unit % G.K, wb = unit / G.K;
@@ -148,13 +161,16 @@ __global__ __launch_bounds__(128 * SUBS) void dw_summarize_kernel(DwGeom G, Dens
   DW_STAMP(0, 0);
   const int t0 = live ? j * kDwB : 0, len = live ? min(kDwB, G.T - t0) : 0;
   float* my_y = ly[threadIdx.x >> 6];
-  float* my_v = lv[threadIdx.x >> 6];
+  float* my_v = SCORE ? nullptr : lv[threadIdx.x >> 6];
   DwRows<O> rows;
   dw_request_rows<O>(y, var, ((size_t)t0 * G.K + k) * O, (size_t)G.K * O, len, rows);
   Mat<double, D> F, sQ;                               // (the model's loads go out behind the rows': one round trip)
   bool fid;
   load_dynamics<double, D>(M, k, s[k], F, sQ, fid);
   const ObsRows<D, O> H = load_obs_rows<D, O>(M, k);
+  double rk[O];                                       // SCORE: the keypoint's constant variances
+#pragma unroll
+  for (int o = 0; o < O; ++o) rk[o] = SCORE ? rconst[(size_t)k * O + o] : 0.0;
   dw_park_rows<O>(rows, my_y, my_v, lane);
   DElem<double, D> e = delem_identity<double, D>();
   DW_STAMP(0, 1);
@@ -163,11 +179,14 @@ __global__ __launch_bounds__(128 * SUBS) void dw_summarize_kernel(DwGeom G, Dens
     if (t0 + i == 0) continue;                        // frame 0 updates the prior itself (dw_replay)
     delem_predict(e, F, sQ, fid);
     const float* py = my_y + ((size_t)i * 64 + lane) * O;
-    const float* pv = my_v + ((size_t)i * 64 + lane) * O;
 #pragma unroll
     for (int o = 0; o < O; ++o) {
-      const float v = pv[o];
-      delem_observe(e, H.row(o), (double)py[o], v > kVarFloor ? (double)v : (double)kVarFloor, false);
+      double r = rk[o];
+      if constexpr (!SCORE) {
+        const float v = my_v[((size_t)i * 64 + lane) * O + o];
+        r = v > kVarFloor ? (double)v : (double)kVarFloor;
+      }
+      delem_observe(e, H.row(o), (double)py[o], r, false);
     }
   }
   DW_STAMP(0, 2);
@@ -194,7 +213,23 @@ __global__ __launch_bounds__(128 * SUBS) void dw_summarize_kernel(DwGeom G, Dens
       Vec<double, D> m;
       Mat<double, D> P;
       load_prior<D>(M, k, m, P);
-      belief_update_obs<D>(make_linear_obs<D>(y, var, G.K, O, M), k, 0, nullptr, m, P);
+      if constexpr (SCORE) {
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+          const Vec<double, D> h = H.row(o);
+          const Vec<double, D> u = mat_vec(P, h);
+          const double g = rcp(rk[o] + dot(h, u));
+          const double gd = g * ((double)y[(size_t)k * O + o] - dot(h, m));
+#pragma unroll
+          for (int a = 0; a < D; ++a) {
+            m.a[a] += u.a[a] * gd;
+#pragma unroll
+            for (int b = 0; b < D; ++b) P.a[a][b] -= u.a[a] * u.a[b] * g;
+          }
+        }
+      } else {
+        belief_update_obs<D>(make_linear_obs<D>(y, var, G.K, O, M), k, 0, nullptr, m, P);
+      }
       double* r = first + (size_t)k * (D + D * D);
 #pragma unroll
       for (int a = 0; a < D; ++a) {
@@ -236,11 +271,13 @@ __device__ __forceinline__ DElem<double, D> dw_compose_range(const double* __res
   return x;
 }
 
-template <int D, int O, int SUBS>
+template <int D, int O, int SUBS, bool SCORE>
 __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseModelPtrs M,
                                                        const double* __restrict__ s,
                                                        const float* __restrict__ y,
                                                        const float* __restrict__ var,
+                                                       const double* __restrict__ rconst,
+                                                       double* __restrict__ part,
                                                        const double* __restrict__ pre_ex,
                                                        const double* __restrict__ suf_ex,
                                                        const double* __restrict__ agg,
@@ -252,12 +289,12 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
   constexpr int REC = D + D * D;
   __shared__ double recs_all[SUBS][kDwB * NF * 64];   // [frame][field][lane]
   __shared__ double xch_all[SUBS][REC];
-  __shared__ float ly_all[SUBS][kDwB * 64 * O], lv_all[SUBS][kDwB * 64 * O];
+  __shared__ float ly_all[SUBS][kDwB * 64 * O], lv_all[SCORE ? 1 : SUBS][SCORE ? 1 : kDwB * 64 * O];
   const int sub = threadIdx.x >> 7;
   double* recs = recs_all[sub];
   double* xch = xch_all[sub];
   float* ly = ly_all[sub];
-  float* lv = lv_all[sub];
+  float* lv = SCORE ? nullptr : lv_all[sub];
   const int unit = blockIdx.x * SUBS + sub;
   if (unit >= G.K * G.nwb) {                          // a spare wave pair still meets the workgroup's barrier
     __syncthreads();
@@ -340,11 +377,17 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
 #pragma unroll
     for (int b = 0; b < D; ++b) J.a[a][b] = xch[D + a * D + b];
   }
-  if (!live) return;
+  if (!SCORE && !live) return;                        // (SCORE: every lane joins the wave's sums at the end)
   if (lane > 0) delem_apply(pe, m, P);                // through the block's chunks before this one
   if (lane < 63 && j + 1 < G.nc) delem_back(se, eta, J);   // back through those after it
   if (j == 0) load_prior<D>(M, k, m, P);              // chunk 0 replays frame 0's update of the prior itself
   DW_STAMP(1, 4);
+  double rk[O];                                       // SCORE: the keypoint's constant variances
+#pragma unroll
+  for (int o = 0; o < O; ++o) rk[o] = SCORE ? rconst[(size_t)k * O + o] : 0.0;
+  const Vec<double, D> m_in = m;                      // filtered belief of frame t0 - 1 (SCORE: the transition
+  const Mat<double, D> P_in = P;                      //  into this chunk's first frame is this lane's)
+  double ll = 0.0, score = 0.0;
   // ---- exact filter over the chunk; filtered beliefs to LDS
   double* mine = recs + lane;
 #pragma unroll 1
@@ -357,15 +400,20 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
       P = mat_add(P, sQ);
     }
     const float* py = ly + ((size_t)i * 64 + lane) * O;
-    const float* pv = lv + ((size_t)i * 64 + lane) * O;
 #pragma unroll
     for (int o = 0; o < O; ++o) {
       const Vec<double, D> h = H.row(o);
       const Vec<double, D> u = mat_vec(P, h);
-      const float vf = pv[o];
-      const double r = vf > kVarFloor ? (double)vf : (double)kVarFloor;
-      const double g = rcp(r + dot(h, u));
-      const double gd = g * ((double)py[o] - dot(h, m));
+      double r = rk[o];
+      if constexpr (!SCORE) {
+        const float vf = lv[((size_t)i * 64 + lane) * O + o];
+        r = vf > kVarFloor ? (double)vf : (double)kVarFloor;
+      }
+      const double sigma = r + dot(h, u);
+      const double g = rcp(sigma);
+      const double dv = (double)py[o] - dot(h, m);
+      const double gd = g * dv;
+      if constexpr (SCORE) ll -= 0.5 * (kLog2Pi + log(sigma) + dv * gd);   // log N(y_o; h.m, sigma)
 #pragma unroll
       for (int a = 0; a < D; ++a) {
         m.a[a] += u.a[a] * gd;
@@ -424,19 +472,34 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
   Mat<double, D> P_s;
   double logdet;
   condition_on_info(m, P, eta, J, m_s, P_s, logdet);  // smoothed last frame of the chunk
-  emit(len - 1, m_s, P_s);
+  if constexpr (!SCORE) emit(len - 1, m_s, P_s);
   DW_STAMP(1, 6);
-  for (int i = len - 2; i >= 0; --i) {                // RTS backwards over the LDS records
-    const double* rc = mine + (size_t)i * NF * 64;
+  Mat<double, D> Qi;                                  // SCORE: (sQ)^-1
+  if constexpr (SCORE) {
+    Mat<double, D> eye = mat_zero<double, D>();
+#pragma unroll
+    for (int a = 0; a < D; ++a) eye.a[a][a] = 1.0;
+    Qi = chol_solve_mat(chol_factor(sQ), eye);
+  }
+  // RTS backwards over the LDS records; SCORE goes one step further, to the filtered belief that entered the
+  // chunk (frame t0 - 1): the transition into the chunk's first frame
+  for (int i = len - 2; i >= (SCORE ? -1 : 0); --i) {
     Vec<double, D> mf;
     Mat<double, D> Pf;
-    int f = 0;
+    if (i >= 0) {
+      const double* rc = mine + (size_t)i * NF * 64;
+      int f = 0;
 #pragma unroll
-    for (int a = 0; a < D; ++a) mf.a[a] = rc[(f++) * 64];
+      for (int a = 0; a < D; ++a) mf.a[a] = rc[(f++) * 64];
 #pragma unroll
-    for (int a = 0; a < D; ++a)
+      for (int a = 0; a < D; ++a)
 #pragma unroll
-      for (int b = a; b < D; ++b) Pf.a[a][b] = Pf.a[b][a] = rc[(f++) * 64];
+        for (int b = a; b < D; ++b) Pf.a[a][b] = Pf.a[b][a] = rc[(f++) * 64];
+    } else {
+      if (t0 == 0 || len == 0) break;                 // frame 0 has no transition into it
+      mf = m_in;
+      Pf = mat_symmetrize(P_in);
+    }
     const Mat<double, D> FP = fid ? Pf : mat_mul(F, Pf);
     const Mat<double, D> Pp = mat_symmetrize(mat_add(fid ? Pf : mat_mul_nt(FP, F), sQ));
     const Mat<double, D> Z = chol_solve_mat(chol_factor(Pp), FP);      // Pp^-1 F Pf = G^T
@@ -445,12 +508,62 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
 #pragma unroll
     for (int a = 0; a < D; ++a) dm.a[a] = m_s.a[a] - mp.a[a];
     const Vec<double, D> Gdm = mat_t_vec(Z, dm);
+    const Vec<double, D> m_next = m_s;                // smoothed frame i + 1
+    const Mat<double, D> P_next = P_s;
 #pragma unroll
     for (int a = 0; a < D; ++a) m_s.a[a] = mf.a[a] + Gdm.a[a];
     P_s = mat_symmetrize(mat_add(Pf, mat_mul(mat_mul_tn(Z, mat_sub(P_s, Pp)), Z)));
-    emit(i, m_s, P_s);
+    if constexpr (SCORE) {
+      // E[w w^T | y] for w = x_{i+1} - F x_i:  dm dm^T + V_{i+1} + F V_i F^T - F C - (F C)^T,  C = Cov(x_i, x_{i+1}) = Z^T V_{i+1}
+      const Vec<double, D> Fm = fid ? m_s : mat_vec(F, m_s);
+      Vec<double, D> dw;
+#pragma unroll
+      for (int a = 0; a < D; ++a) dw.a[a] = m_next.a[a] - Fm.a[a];
+      const Mat<double, D> Cx = mat_mul_tn(Z, P_next);
+      const Mat<double, D> FC = fid ? Cx : mat_mul(F, Cx);
+      const Mat<double, D> FVF = fid ? P_s : mat_mul_nt(mat_mul(F, P_s), F);
+      double tr = 0.0;
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b)
+          tr += Qi.a[a][b] * (dw.a[a] * dw.a[b] + P_next.a[a][b] + FVF.a[a][b] - FC.a[a][b] - FC.a[b][a]);
+      score += 0.5 * (tr - (double)D);
+    } else {
+      emit(i, m_s, P_s);
+    }
   }
   DW_STAMP(1, 7);
+  if constexpr (SCORE) {
+    // the unit's sums in lane order (fixed: the same bits on every run), one pair per (keypoint, block of 64 chunks)
+    if (!live) ll = score = 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      ll += __shfl_down(ll, off);
+      score += __shfl_down(score, off);
+    }
+    if (lane == 0) {
+      part[2 * (size_t)unit] = ll;
+      part[2 * (size_t)unit + 1] = score;
+    }
+  }
+}
+
+// SCORE: per keypoint the sums over its blocks, in block order -> nll, d nll / d log s (eks/core.py:650: a
+// non-finite loss becomes 1e12 with zero gradient)
+__global__ void dw_score_finish_kernel(int K, int nwb, const double* __restrict__ part, double* __restrict__ nll,
+                                       double* __restrict__ dnll) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  double ll = 0.0, sc = 0.0;
+  for (int wb = 0; wb < nwb; ++wb) {
+    ll += part[2 * ((size_t)wb * K + k)];
+    sc += part[2 * ((size_t)wb * K + k) + 1];
+  }
+  const double v = -ll;
+  const bool fin = isfinite(v);
+  nll[k] = fin ? v : 1e12;
+  dnll[k] = fin ? -sc : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -461,14 +574,31 @@ bool dense_wave_covers(int T, int K, int D, int O) {
   return (long)K * nwb <= 1024;                       // depth-bound problems: every block resident at once
 }
 
-int dense_wave_smooth(const eks_dims_t& d, const float* y, const float* var, const DenseModel& Mm, float* ms,
-                      float* Vs, void* ws, size_t ws_bytes, hipStream_t st) {
+// SCORE form: loss + gradient of one s per keypoint.  Not depth-critical like the smoother (an optimiser calls
+// it a hundred times in a row), so more units than CUs are fine.
+bool dense_wave_score_covers(int T, int K, int D, int O) {
+  if (knob_int(KNOB_DENSE_LEGACY, 0) || knob_int(KNOB_DENSE_DUAL_GRAD, 0)) return false;
+  if (!(D == 2 || D == 3) || !(O == 2 || O == 4 || O == 6 || O == 8)) return false;
+  const long nc = ((long)T + kDwB - 1) / kDwB, nwb = (nc + 63) / 64;
+  return T >= 2 && (long)K * nwb <= 16384;
+}
+size_t dense_wave_workspace_bytes(int T, int K, int D) {
+  const size_t nc = ((size_t)T + kDwB - 1) / kDwB, nwb = (nc + 63) / 64;
+  const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
+  return 2 * align_up(nc * K * nv * 8, 256) + align_up(nwb * K * nv * 8, 256) + align_up((size_t)K * rec * 8, 256) +
+         align_up(nwb * K * 2 * 8, 256);
+}
+
+// var != nullptr: the smoother (ms, Vs); var == nullptr: SCORE (rconst, nll, dnll)
+static int dense_wave_run(const eks_dims_t& d, const float* y, const float* var, const double* rconst,
+                          const DenseModel& Mm, float* ms, float* Vs, double* nll, double* dnll, void* ws,
+                          size_t ws_bytes, hipStream_t st) {
   const int T = d.n_frames, K = d.n_keypoints, D = d.state_dim, O = d.obs_dim;
+  const bool score = var == nullptr;
   DwGeom G{K, T, (T + kDwB - 1) / kDwB, 0};
   G.nwb = (G.nc + 63) / 64;
   const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
-  const size_t need = 2 * align_up((size_t)G.nc * K * nv * 8, 256) + align_up((size_t)G.nwb * K * nv * 8, 256) +
-                      align_up((size_t)K * rec * 8, 256);
+  const size_t need = dense_wave_workspace_bytes(T, K, D);
   if (ws_bytes < need) return EKS_ERR_WORKSPACE;
   char* p = static_cast<char*>(ws);
   double* pre_ex = reinterpret_cast<double*>(p);
@@ -478,27 +608,33 @@ int dense_wave_smooth(const eks_dims_t& d, const float* y, const float* var, con
   double* agg = reinterpret_cast<double*>(p);
   p += align_up((size_t)G.nwb * K * nv * 8, 256);
   double* first = reinterpret_cast<double*>(p);
+  p += align_up((size_t)K * rec * 8, 256);
+  double* part = reinterpret_cast<double*>(p);
   const DenseModelPtrs M{Mm.m0, Mm.S0, Mm.A, Mm.C, Mm.Q};
   const int vs_diag = (d.flags & EKS_FLAG_VS_DIAG) ? 1 : 0;
   const int units = K * G.nwb;
   const bool two = units > 256;                       // more (keypoint, 64-chunk) units than CUs: 4-wave workgroups
   const dim3 grid((unsigned)(two ? (units + 1) / 2 : units)), block(two ? 256 : 128);
-#define EKS_DW_S(DD, OO, SS)                                                                             \
+#define EKS_DW_S(DD, OO, SS, SC)                                                                         \
   {                                                                                                      \
     {                                                                                                    \
-      ProfScope ps("dense_summarize", st);                                                               \
-      hipLaunchKernelGGL((dw_summarize_kernel<DD, OO, SS>), grid, block, 0, st, G, M, Mm.s, y, var,       \
-                         pre_ex, suf_ex, agg, first);                                                    \
+      ProfScope ps(SC ? "dense_score_summarize" : "dense_summarize", st);                                \
+      hipLaunchKernelGGL((dw_summarize_kernel<DD, OO, SS, SC>), grid, block, 0, st, G, M, Mm.s, y, var,   \
+                         rconst, pre_ex, suf_ex, agg, first);                                            \
     }                                                                                                    \
-    ProfScope ps("dense_replay", st);                                                                    \
-    hipLaunchKernelGGL((dw_replay_kernel<DD, OO, SS>), grid, block, 0, st, G, M, Mm.s, y, var, pre_ex,    \
-                       suf_ex, agg, first, ms, Vs, vs_diag);                                             \
+    ProfScope ps(SC ? "dense_score_replay" : "dense_replay", st);                                        \
+    hipLaunchKernelGGL((dw_replay_kernel<DD, OO, SS, SC>), grid, block, 0, st, G, M, Mm.s, y, var,        \
+                       rconst, part, pre_ex, suf_ex, agg, first, ms, Vs, vs_diag);                       \
   }
-#define EKS_DW(DD, OO)        \
-  if (two)                    \
-    EKS_DW_S(DD, OO, 2)       \
-  else                        \
-    EKS_DW_S(DD, OO, 1)
+#define EKS_DW(DD, OO)            \
+  if (two && score)               \
+    EKS_DW_S(DD, OO, 2, true)     \
+  else if (two)                   \
+    EKS_DW_S(DD, OO, 2, false)    \
+  else if (score)                 \
+    EKS_DW_S(DD, OO, 1, true)     \
+  else                            \
+    EKS_DW_S(DD, OO, 1, false)
 #define EKS_DW_O(DD)                    \
   switch (O) {                          \
     case 2: EKS_DW(DD, 2) break;        \
@@ -517,7 +653,22 @@ int dense_wave_smooth(const eks_dims_t& d, const float* y, const float* var, con
 #undef EKS_DW_O
 #undef EKS_DW
 #undef EKS_DW_S
+  if (score)
+    hipLaunchKernelGGL(dw_score_finish_kernel, dim3((K + 63) / 64), dim3(64), 0, st, K, G.nwb, part, nll, dnll);
   return hip_status(hipGetLastError());
+}
+
+int dense_wave_smooth(const eks_dims_t& d, const float* y, const float* var, const DenseModel& Mm, float* ms,
+                      float* Vs, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!var) return EKS_ERR_NULL;
+  return dense_wave_run(d, y, var, nullptr, Mm, ms, Vs, nullptr, nullptr, ws, ws_bytes, st);
+}
+
+// nll[k], d nll / d log s [k] of the constant-R filter loss at Mm.s[k] (caller: Q positive definite)
+int dense_wave_score(const eks_dims_t& d, const float* y, const double* rconst, const DenseModel& Mm, double* nll,
+                     double* dnll, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!rconst || !nll || !dnll) return EKS_ERR_NULL;
+  return dense_wave_run(d, y, nullptr, rconst, Mm, nullptr, nullptr, nll, dnll, ws, ws_bytes, st);
 }
 
 }  // namespace eks

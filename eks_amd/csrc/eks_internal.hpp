@@ -21,7 +21,7 @@ enum Knob {
   KNOB_SMOOTH_UNFUSED, KNOB_SUMMARIZE_REVERSE, KNOB_REPLAY_FORWARD, KNOB_REPLAY_RECOMPUTE, KNOB_SCAN_CH,
   KNOB_SMOOTH_TILE, KNOB_DENSE_CHUNK, KNOB_NLL_NCL, KNOB_NLL_CHUNK, KNOB_NLL_CHUNK0, KNOB_NLL_WPB,
   KNOB_NLL_EXACT_ENTRY, KNOB_NLL_ASSEMBLE_SEQ, KNOB_DENSE_LEGACY, KNOB_NLL_GRAD_UNFUSED, KNOB_NLL_GRAD_CHUNK,
-  KNOB_DENSE_TREE_SCAN, KNOB_COUNT
+  KNOB_DENSE_TREE_SCAN, KNOB_DENSE_DUAL_GRAD, KNOB_COUNT
 };
 bool knob_set(Knob k);               // the variable exists
 int knob_int(Knob k, int dflt);      // its integer value, or dflt when unset
@@ -63,6 +63,10 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
                  float* ms, float* Vs, void* ws, size_t ws_bytes, hipStream_t st);
 // narrow sessions: wave-per-64-chunks form (eks_dense_wave.hip)
 bool dense_wave_covers(int T, int K, int D, int O);
+bool dense_wave_score_covers(int T, int K, int D, int O);
+size_t dense_wave_workspace_bytes(int T, int K, int D);
+int dense_wave_score(const eks_dims_t& d, const float* y, const double* rconst, const DenseModel& M, double* nll,
+                     double* dnll, void* ws, size_t ws_bytes, hipStream_t st);
 int dense_wave_smooth(const eks_dims_t& d, const float* y, const float* var, const DenseModel& M, float* ms,
                       float* Vs, void* ws, size_t ws_bytes, hipStream_t st);
 // wide sessions: prefetching summarize / per-lane sequential scan / checkpointed replay (eks_dense_wide.hip)

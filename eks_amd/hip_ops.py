@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import FLAG_DIAG_MODEL, FLAG_UNIT_AC, FLAG_VS_DIAG, EksDims
+from ._lib import FLAG_DIAG_MODEL, FLAG_Q_PD, FLAG_UNIT_AC, FLAG_VS_DIAG, EksDims
 
 
 def require_gpu() -> torch.device:
@@ -50,18 +50,23 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 
 def model_flags(S0, A, C, Q) -> int:
-    """Inspect HOST copies of the parameters (numpy) and return DIAG_MODEL / UNIT_AC flags."""
+    """Inspect HOST copies of the parameters (numpy) and return DIAG_MODEL / UNIT_AC / Q_PD flags."""
     import numpy as np
     D, O = A.shape[-1], C.shape[-2]
-    if D != O:
-        return 0
+    # Q positive definite with a margin (smallest eigenvalue > 1e-10 of the largest): the general path may take
+    # the loss gradient from the smoothing distribution (include/eks_hip.h: EKS_FLAG_Q_PD)
+    Qh = np.asarray(Q, dtype=np.float64)
+    pd = 0
+    if np.all(np.isfinite(Qh)):
+        ev = np.linalg.eigvalsh(0.5 * (Qh + np.swapaxes(Qh, -1, -2)))
+        pd = FLAG_Q_PD if bool(np.all(ev[..., 0] > 1e-10 * np.maximum(ev[..., -1], 1e-300))) else 0
 
     def is_diag(M):
         return bool(np.all(M[..., ~np.eye(D, dtype=bool)] == 0))
 
-    if not (is_diag(S0) and is_diag(A) and is_diag(C) and is_diag(Q)):
-        return 0
-    flags = FLAG_DIAG_MODEL
+    if D != O or not (is_diag(S0) and is_diag(A) and is_diag(C) and is_diag(Q)):
+        return pd
+    flags = FLAG_DIAG_MODEL | pd
     eye = np.eye(D)
     if np.array_equal(A, np.broadcast_to(eye, A.shape)) and \
             np.array_equal(C, np.broadcast_to(eye, C.shape)):

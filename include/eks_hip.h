@@ -46,6 +46,11 @@ typedef struct ihipStream_t* eks_stream_t; /* == hipStream_t */
                                   singlecam_smoother.py:210-211, multicam_smoother.py:509-510,
                                   :540-542).  Default: full [T][K][D][D]. */
 #define EKS_FLAG_UNIT_AC 4u    /* with DIAG_MODEL: caller asserts A = C = I (folds multiplies) */
+#define EKS_FLAG_Q_PD 8u       /* caller asserts every Q[k] is positive definite.  eks_nll (one s per
+                                  keypoint, with gradient) and eks_adam_run on the general (D, O) path may
+                                  then take d nll / d log s from the smoothing distribution (Fisher's
+                                  identity: exact, plain float64) instead of dual numbers through the scan.
+                                  Without the flag the dual-number kernels run (any PSD Q). */
 
 typedef struct {
   int32_t n_keypoints; /* K */

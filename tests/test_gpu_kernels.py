@@ -504,6 +504,31 @@ def test_nll_dense_matches_oracle(T, K, D, O):
     assert (np.abs(g1.cpu().numpy()[:, 0] - gref) / np.abs(gref).max()).max() < 1e-7
 
 
+@pytest.mark.parametrize('T,K,D,O,general_A', [(800, 3, 3, 4, False), (1500, 5, 3, 4, True), (131, 2, 2, 2, False),
+                                               (9, 2, 3, 8, False), (2, 3, 2, 6, False), (20000, 4, 3, 4, False)])
+def test_nll_dense_score_gradient_matches_oracle_and_dual_numbers(T, K, D, O, general_A):
+    """EKS_FLAG_Q_PD: value from the exact filter inside the smoother's wave kernels, gradient from the smoothing
+    distribution (Fisher's identity, eks_dense_wave.hip SCORE form) - against the oracle's forward-mode gradient
+    at the bars of the dual-number kernels, and against those kernels themselves (flags without Q_PD)."""
+    from eks_amd import _lib, hip_ops
+    arrs, y, var = _dense_problem(T, K, D, O, seed=17 + T)
+    if general_A:
+        arrs['As'] = arrs['As'] * 0.97 + 0.02 * np.random.default_rng(9).standard_normal((K, D, D))
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    assert flags == _lib.FLAG_Q_PD
+    rconst = hip_ops.const_r(_dev(var), 1e-4)
+    s = np.exp(np.random.default_rng(T).uniform(-4, 4, K))
+    args = (_dev(y), rconst, *_params_dev(arrs), _dev(s[:, None]))
+    nll1, g1 = [a.cpu().numpy()[:, 0] for a in hip_ops.nll(*args, per_keypoint=True, want_grad=True, flags=flags)]
+    nll0, g0 = [a.cpu().numpy()[:, 0] for a in hip_ops.nll(*args, per_keypoint=True, want_grad=True, flags=0)]
+    ref, gref = orc.filter_nll(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], s,
+                               rconst.cpu().numpy(), want_grad=True)
+    assert (np.abs(nll1 - ref) / np.abs(ref)).max() < 1e-8
+    assert (np.abs(g1 - gref) / np.abs(gref).max()).max() < 1e-7
+    assert (np.abs(nll1 - nll0) / np.abs(ref)).max() < 1e-10
+    assert (np.abs(g1 - g0) / np.abs(gref).max()).max() < 1e-7
+
+
 def test_adam_step_matches_oracle_sequence():
     """Drive eks_adam_step with a synthetic quadratic loss and compare the whole trajectory with
     the oracle's restatement of eks/core.py:652-681 (including blocks and the clip gradient)."""

@@ -335,3 +335,31 @@ def test_percentile_from_two_order_statistics_is_numpys_bit_for_bit():
         srt = np.sort(a, axis=0)                                        # NaNs last, as the device kernel orders them
         got = percentile_from_order_stats(np.stack([srt[lo], srt[hi]], axis=-1), g, np.isnan(a).sum(axis=0))
         assert got.dtype == ref.dtype and np.array_equal(got, ref, equal_nan=True), (n, q)
+
+
+def test_model_flags_diag_unit_and_positive_definite_q():
+    """hip_ops.model_flags from HOST copies of the parameters: scalar-chain model (DIAG_MODEL, UNIT_AC) as before,
+    and Q_PD - every Q[k] positive definite with a margin - which lets the general path take the loss gradient
+    from the smoothing distribution (include/eks_hip.h); a singular or indefinite Q keeps the dual-number kernels."""
+    from eks_amd import _lib, hip_ops
+    K, D, O = 3, 3, 4
+    rng = np.random.default_rng(0)
+    eyeD = np.tile(np.eye(D), (K, 1, 1))
+    L = rng.standard_normal((K, D, D))
+    Q = L @ np.swapaxes(L, 1, 2) + 0.1 * np.eye(D)
+    C = rng.standard_normal((K, O, D))
+    assert hip_ops.model_flags(eyeD, eyeD, C, Q) == _lib.FLAG_Q_PD
+    Qs = Q.copy()
+    Qs[1] = np.outer(L[1, :, 0], L[1, :, 0])                       # rank one
+    assert hip_ops.model_flags(eyeD, eyeD, C, Qs) == 0
+    Qn = Q.copy()
+    Qn[2, 0, 0] = -1.0                                             # indefinite
+    assert hip_ops.model_flags(eyeD, eyeD, C, Qn) == 0
+    Qz = Q.copy()
+    Qz[0] = 0.0
+    assert hip_ops.model_flags(eyeD, eyeD, C, Qz) == 0
+    eye2 = np.tile(np.eye(2), (K, 1, 1))
+    f = hip_ops.model_flags(eye2 * 3.0, eye2, eye2, eye2 * 0.5)
+    assert f == _lib.FLAG_DIAG_MODEL | _lib.FLAG_UNIT_AC | _lib.FLAG_Q_PD
+    f = hip_ops.model_flags(eye2 * 3.0, eye2 * 0.9, eye2, eye2 * 0.0)
+    assert f == _lib.FLAG_DIAG_MODEL
