@@ -314,7 +314,8 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
     {
       ProfScope ps("dense_summarize", st);
       if (wide) {
-        const int rc = dense_wide_summarize(T, K, D, O, G.B, G.nc, M, Mm.s, y, var, elems, runs ? 1 : 0, first, st);
+        const int rc = dense_wide_summarize(T, K, D, O, G.B, G.nc, M, Mm.s, y, var, nullptr, elems, runs ? 1 : 0,
+                                            first, st);
         if (rc != EKS_OK) return rc;
       } else {
         hipLaunchKernelGGL((dense_summarize_kernel<DD, LinearObs<DD>>), dim3((lanes + 63) / 64),
@@ -337,8 +338,9 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
     {
       ProfScope ps("dense_replay", st);
       if (wide) {
-        const int rc = dense_wide_replay(T, K, D, O, G.B, G.nc, M, Mm.s, y, var, pre, suf, bprior, bsuffix,
-                                         runs ? pre : nullptr, runs ? suf : nullptr, ms, Vs, vs_diag, st);
+        const int rc = dense_wide_replay(T, K, D, O, G.B, G.nc, M, Mm.s, y, var, nullptr, nullptr, nullptr, pre, suf,
+                                         bprior, bsuffix, runs ? pre : nullptr, runs ? suf : nullptr, ms, Vs,
+                                         vs_diag, st);
         if (rc != EKS_OK) return rc;
       } else {
         hipLaunchKernelGGL((dense_replay_kernel<DD, false, LinearObs<DD>>), dim3((lanes + 63) / 64),
@@ -348,6 +350,66 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
     }
   })
   return hip_status(hipGetLastError());
+}
+
+// ---- SCORE form: the optimiser's loss and its derivative from the smoother's own kernels ---------------
+// nll[k], d nll / d log s [k] of the constant-R filter loss at Mm.s[k] (eks/core.py:640-652), for Q positive
+// definite: the value from the exact filter inside the replay kernels, the derivative from the smoothing
+// distribution (Fisher's identity; eks_dense_wave.hip has the formula).  Narrow sessions take the wave kernels,
+// wider ones the keypoint-major kernels with the per-lane scan; other shapes have no SCORE form (the caller keeps
+// the dual-number kernels of eks_loss.hip).
+bool dense_score_covers(int T, int K, int D, int O) {
+  if (T < 2 || knob_int(KNOB_DENSE_LEGACY, 0) || knob_int(KNOB_DENSE_DUAL_GRAD, 0)) return false;
+  if (dense_wave_covers(T, K, D, O)) return true;
+  const int B = dense_chunk(T, K), nc = (T + B - 1) / B;
+  const size_t rec = D + D * D;
+  return dense_wide_covers(D, O, B) && !knob_int(KNOB_DENSE_TREE_SCAN, 0) &&
+         dense_wide_scan_scratch_doubles(K, D, nc) + 2 * (size_t)nc * K <= (size_t)T * K * rec;
+}
+size_t dense_score_workspace_bytes(int T, int K, int D, int O) {
+  const size_t a = dense_smooth_workspace_bytes(T, K, D, O), b = dense_wave_workspace_bytes(T, K, D);
+  return a > b ? a : b;
+}
+int dense_score(const eks_dims_t& d, const float* y, const double* rconst, const DenseModel& Mm, double* nll,
+                double* dnll, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int T = d.n_frames, K = d.n_keypoints, D = d.state_dim, O = d.obs_dim;
+  if (!dense_score_covers(T, K, D, O)) return EKS_ERR_UNSUPPORTED;
+  if (ws_bytes < dense_score_workspace_bytes(T, K, D, O)) return EKS_ERR_WORKSPACE;
+  if (dense_wave_covers(T, K, D, O)) return dense_wave_score(d, y, rconst, Mm, nll, dnll, ws, ws_bytes, st);
+  const int B = dense_chunk(T, K), nc = (T + B - 1) / B, nblk = (nc + kDenseCB - 1) / kDenseCB;
+  const DenseModelPtrs M{Mm.m0, Mm.S0, Mm.A, Mm.C, Mm.Q};
+  const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
+  char* p = static_cast<char*>(ws);               // (the layout of dense_smooth)
+  double* elems = reinterpret_cast<double*>(p);
+  p += align_up((size_t)nc * K * nv * 8, 256);
+  double* chunk_in = reinterpret_cast<double*>(p);
+  p += align_up((size_t)nc * K * nv * 8, 256);
+  double* chunk_out = reinterpret_cast<double*>(p);
+  p += align_up((size_t)nc * K * nv * 8, 256);
+  p += align_up((size_t)nblk * K * nv * 8, 256) + 2 * align_up((size_t)nblk * K * rec * 8, 256);
+  double* scratch = reinterpret_cast<double*>(p);   // the smoother's filtered-belief stream: scan levels + partials
+  double* part_ll = scratch + dense_wide_scan_scratch_doubles(K, D, nc);
+  double* part_score = part_ll + (size_t)nc * K;
+  p += align_up((size_t)T * K * rec * 8, 256);
+  double* first = reinterpret_cast<double*>(p);
+  int rc;
+  {
+    ProfScope ps("dense_score_summarize", st);
+    rc = dense_wide_summarize(T, K, D, O, B, nc, M, Mm.s, y, nullptr, rconst, elems, 1, first, st);
+    if (rc != EKS_OK) return rc;
+  }
+  {
+    ProfScope ps("dense_score_scan", st);
+    rc = dense_wide_scan(K, D, nc, elems, first, scratch, chunk_in, chunk_out, st);
+    if (rc != EKS_OK) return rc;
+  }
+  {
+    ProfScope ps("dense_score_replay", st);
+    rc = dense_wide_replay(T, K, D, O, B, nc, M, Mm.s, y, nullptr, rconst, part_ll, part_score, nullptr, nullptr,
+                           nullptr, nullptr, chunk_in, chunk_out, nullptr, nullptr, 0, st);
+    if (rc != EKS_OK) return rc;
+  }
+  return dense_score_finish(K, nc, part_ll, part_score, nll, dnll, st);
 }
 
 // ---- extended Kalman filter / smoother with calibrated pinhole cameras ------------------------

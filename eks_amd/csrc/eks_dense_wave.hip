@@ -542,28 +542,11 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
       ll += __shfl_down(ll, off);
       score += __shfl_down(score, off);
     }
-    if (lane == 0) {
-      part[2 * (size_t)unit] = ll;
-      part[2 * (size_t)unit + 1] = score;
+    if (lane == 0) {                                  // [block of 64 chunks][keypoint], log-likelihoods then scores
+      part[unit] = ll;
+      part[(size_t)G.K * G.nwb + unit] = score;
     }
   }
-}
-
-// SCORE: per keypoint the sums over its blocks, in block order -> nll, d nll / d log s (eks/core.py:650: a
-// non-finite loss becomes 1e12 with zero gradient)
-__global__ void dw_score_finish_kernel(int K, int nwb, const double* __restrict__ part, double* __restrict__ nll,
-                                       double* __restrict__ dnll) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= K) return;
-  double ll = 0.0, sc = 0.0;
-  for (int wb = 0; wb < nwb; ++wb) {
-    ll += part[2 * ((size_t)wb * K + k)];
-    sc += part[2 * ((size_t)wb * K + k) + 1];
-  }
-  const double v = -ll;
-  const bool fin = isfinite(v);
-  nll[k] = fin ? v : 1e12;
-  dnll[k] = fin ? -sc : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -574,14 +557,6 @@ bool dense_wave_covers(int T, int K, int D, int O) {
   return (long)K * nwb <= 1024;                       // depth-bound problems: every block resident at once
 }
 
-// SCORE form: loss + gradient of one s per keypoint.  Not depth-critical like the smoother (an optimiser calls
-// it a hundred times in a row), so more units than CUs are fine.
-bool dense_wave_score_covers(int T, int K, int D, int O) {
-  if (knob_int(KNOB_DENSE_LEGACY, 0) || knob_int(KNOB_DENSE_DUAL_GRAD, 0)) return false;
-  if (!(D == 2 || D == 3) || !(O == 2 || O == 4 || O == 6 || O == 8)) return false;
-  const long nc = ((long)T + kDwB - 1) / kDwB, nwb = (nc + 63) / 64;
-  return T >= 2 && (long)K * nwb <= 16384;
-}
 size_t dense_wave_workspace_bytes(int T, int K, int D) {
   const size_t nc = ((size_t)T + kDwB - 1) / kDwB, nwb = (nc + 63) / 64;
   const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
@@ -653,8 +628,7 @@ static int dense_wave_run(const eks_dims_t& d, const float* y, const float* var,
 #undef EKS_DW_O
 #undef EKS_DW
 #undef EKS_DW_S
-  if (score)
-    hipLaunchKernelGGL(dw_score_finish_kernel, dim3((K + 63) / 64), dim3(64), 0, st, K, G.nwb, part, nll, dnll);
+  if (score) return dense_score_finish(K, G.nwb, part, part + (size_t)K * G.nwb, nll, dnll, st);
   return hip_status(hipGetLastError());
 }
 

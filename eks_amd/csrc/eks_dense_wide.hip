@@ -58,7 +58,7 @@ __device__ __forceinline__ void wide_load(const float* __restrict__ y, const flo
     fw a = fw(0.f), b = fw(1.f);
     if (ok) {
       a = *reinterpret_cast<const fw*>(y + row + o);
-      b = *reinterpret_cast<const fw*>(var + row + o);
+      if (var) b = *reinterpret_cast<const fw*>(var + row + o);   // (SCORE form: constant R, no rows of var)
     }
 #pragma unroll
     for (int q = 0; q < W; ++q) {
@@ -98,16 +98,25 @@ __device__ __forceinline__ WideRowsC<D, O> wide_obs_rows(const DenseModelPtrs& M
   return R;
 }
 
-template <int D, int O>
+// SCORE: r = rk[o] (the keypoint's constant variances); LL: *ll accumulates the innovation log-densities
+template <int D, int O, bool SCORE = false, bool LL = false>
 __device__ __forceinline__ void wide_filter_frame(const WideRowsC<D, O>& H, const FrameRows<O>& fr,
-                                                  Vec<double, D>& m, Mat<double, D>& P) {
+                                                  Vec<double, D>& m, Mat<double, D>& P,
+                                                  const double* rk = nullptr, double* ll = nullptr) {
 #pragma unroll
   for (int o = 0; o < O; ++o) {
     const Vec<double, D> h = H.row(o);
     const Vec<double, D> u = mat_vec(P, h);
-    const double r = fr.v[o] > kVarFloor ? (double)fr.v[o] : (double)kVarFloor;
-    const double g = rcp(r + dot(h, u));
-    const double gd = g * ((double)fr.y[o] - dot(h, m));
+    double r;
+    if constexpr (SCORE)
+      r = rk[o];
+    else
+      r = fr.v[o] > kVarFloor ? (double)fr.v[o] : (double)kVarFloor;
+    const double sigma = r + dot(h, u);
+    const double g = rcp(sigma);
+    const double dv = (double)fr.y[o] - dot(h, m);
+    const double gd = g * dv;
+    if constexpr (LL) *ll -= 0.5 * (kLog2Pi + log(sigma) + dv * gd);
 #pragma unroll
     for (int a = 0; a < D; ++a) {
       m.a[a] += u.a[a] * gd;
@@ -128,11 +137,12 @@ __device__ __forceinline__ void wide_predict(const Mat<double, D>& F, const Mat<
 }
 
 // ------------------------------------------------------------------------------------------------------
-template <int D, int O>
+template <int D, int O, bool SCORE>
 __global__ __launch_bounds__(64) void dwide_summarize_kernel(WideGeom G, DenseModelPtrs M,
                                                             const double* __restrict__ s,
                                                             const float* __restrict__ y,
                                                             const float* __restrict__ var,
+                                                            const double* __restrict__ rconst,
                                                             double* __restrict__ elems, int soa,
                                                             double* __restrict__ first) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -142,6 +152,9 @@ __global__ __launch_bounds__(64) void dwide_summarize_kernel(WideGeom G, DenseMo
   bool fid;
   load_dynamics<double, D>(M, k, s[k], F, sQ, fid);
   const WideRowsC<D, O> H = wide_obs_rows<D, O>(M, k);
+  double rk[O];                                       // SCORE: the keypoint's constant variances
+#pragma unroll
+  for (int o = 0; o < O; ++o) rk[o] = SCORE ? rconst[(size_t)k * O + o] : 0.0;
   const int t0 = j * G.B, t1 = min(t0 + G.B, G.T);
   DElem<double, D> e = delem_identity<double, D>();
   FrameRows<O> cur[kWideGroup], nxt[kWideGroup];
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(64) void dwide_summarize_kernel(WideGeom G, DenseMo
 #pragma unroll
         for (int o = 0; o < O; ++o)
           delem_observe(e, H.row(o), (double)cur[f].y[o],
-                        cur[f].v[o] > kVarFloor ? (double)cur[f].v[o] : (double)kVarFloor, false);
+                        SCORE ? rk[o] : (cur[f].v[o] > kVarFloor ? (double)cur[f].v[o] : (double)kVarFloor), false);
       }
     }
 #pragma unroll
@@ -172,7 +185,7 @@ __global__ __launch_bounds__(64) void dwide_summarize_kernel(WideGeom G, DenseMo
     load_prior<D>(M, k, m, P);
     FrameRows<O> f0;
     wide_load<O>(y, var, (size_t)k * O, true, f0);
-    wide_filter_frame<D, O>(H, f0, m, P);
+    wide_filter_frame<D, O, SCORE>(H, f0, m, P, rk);
     double* r = first + (size_t)k * (D + D * D);
 #pragma unroll
     for (int a = 0; a < D; ++a) {
@@ -307,11 +320,14 @@ __global__ __launch_bounds__(64) void dwide_scan_chunks_kernel(WideScan W) {
 // ------------------------------------------------------------------------------------------------------
 constexpr int kWideCB = 64;            // elements per block of the narrow path's scan (eks_dense.hip: kDenseCB)
 
-template <int D, int O>
+template <int D, int O, bool SCORE>
 __global__ __launch_bounds__(64) void dwide_replay_kernel(WideGeom G, DenseModelPtrs M,
                                                          const double* __restrict__ s,
                                                          const float* __restrict__ y,
                                                          const float* __restrict__ var,
+                                                         const double* __restrict__ rconst,
+                                                         double* __restrict__ part_ll,
+                                                         double* __restrict__ part_score,
                                                          const double* __restrict__ pre,
                                                          const double* __restrict__ suf,
                                                          const double* __restrict__ bprior,
@@ -360,6 +376,12 @@ __global__ __launch_bounds__(64) void dwide_replay_kernel(WideGeom G, DenseModel
       delem_back(load_delem<double, D>(suf + ((size_t)(j + 1) * G.K + k) * NV), eta, J);
   }
   if (j == 0) load_prior<D>(M, k, m, P);              // chunk 0 replays frame 0's update of the prior itself
+  double rk[O];                                       // SCORE: the keypoint's constant variances
+#pragma unroll
+  for (int o = 0; o < O; ++o) rk[o] = SCORE ? rconst[(size_t)k * O + o] : 0.0;
+  const Vec<double, D> m_in = m;                      // filtered belief of frame t0 - 1 (SCORE: the transition into
+  const Mat<double, D> P_in = P;                      //  the chunk's first frame belongs to this lane)
+  double ll = 0.0, score = 0.0;
   // ---- forward: exact filter, one checkpoint (the belief entering the group) per four frames
   double* mine = ck + lane;
   auto save = [&](int g) {
@@ -392,7 +414,7 @@ __global__ __launch_bounds__(64) void dwide_replay_kernel(WideGeom G, DenseModel
       const int t = tg + f;
       if (t < t1) {
         if (t > 0) wide_predict<D>(F, sQ, fid, m, P);
-        wide_filter_frame<D, O>(H, cur[f], m, P);
+        wide_filter_frame<D, O, SCORE, SCORE>(H, cur[f], m, P, rk, &ll);
       }
     }
     if (g + 1 < ng) {
@@ -437,7 +459,47 @@ __global__ __launch_bounds__(64) void dwide_replay_kernel(WideGeom G, DenseModel
   Mat<double, D> P_s;
   double logdet;
   condition_on_info(m, P, eta, J, m_s, P_s, logdet);  // smoothed last frame of the chunk
-  emit(t1 - 1, m_s, P_s);
+  if constexpr (!SCORE) emit(t1 - 1, m_s, P_s);
+  Mat<double, D> Qi;                                  // SCORE: (sQ)^-1
+  if constexpr (SCORE) {
+    Mat<double, D> eye = mat_zero<double, D>();
+#pragma unroll
+    for (int a = 0; a < D; ++a) eye.a[a][a] = 1.0;
+    Qi = chol_solve_mat(chol_factor(sQ), eye);
+  }
+  // one RTS step from the filtered belief (mf, Pf) of a frame to its smoothed belief, given the smoothed belief
+  // (m_s, P_s) of the next frame; SCORE adds the transition's term of Fisher's identity (eks_dense_wave.hip)
+  auto rts_step = [&](const Vec<double, D>& mf, const Mat<double, D>& Pf) {
+    const Mat<double, D> FP = fid ? Pf : mat_mul(F, Pf);
+    const Mat<double, D> Pp = mat_symmetrize(mat_add(fid ? Pf : mat_mul_nt(FP, F), sQ));
+    const Mat<double, D> Z = chol_solve_mat(chol_factor(Pp), FP);   // Pp^-1 F Pf = G^T
+    const Vec<double, D> mp = fid ? mf : mat_vec(F, mf);
+    Vec<double, D> dm;
+#pragma unroll
+    for (int a = 0; a < D; ++a) dm.a[a] = m_s.a[a] - mp.a[a];
+    const Vec<double, D> Gdm = mat_t_vec(Z, dm);
+    const Vec<double, D> m_next = m_s;
+    const Mat<double, D> P_next = P_s;
+#pragma unroll
+    for (int a = 0; a < D; ++a) m_s.a[a] = mf.a[a] + Gdm.a[a];
+    P_s = mat_symmetrize(mat_add(Pf, mat_mul(mat_mul_tn(Z, mat_sub(P_s, Pp)), Z)));
+    if constexpr (SCORE) {
+      const Vec<double, D> Fm = fid ? m_s : mat_vec(F, m_s);
+      Vec<double, D> dw;
+#pragma unroll
+      for (int a = 0; a < D; ++a) dw.a[a] = m_next.a[a] - Fm.a[a];
+      const Mat<double, D> Cx = mat_mul_tn(Z, P_next);            // Cov(x_i, x_{i+1} | y)
+      const Mat<double, D> FC = fid ? Cx : mat_mul(F, Cx);
+      const Mat<double, D> FVF = fid ? P_s : mat_mul_nt(mat_mul(F, P_s), F);
+      double tr = 0.0;
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b)
+          tr += Qi.a[a][b] * (dw.a[a] * dw.a[b] + P_next.a[a][b] + FVF.a[a][b] - FC.a[a][b] - FC.a[b][a]);
+      score += 0.5 * (tr - (double)D);
+    }
+  };
   // ---- backward: every group is filtered again from its checkpoint, RTS over its four beliefs in registers
   for (int g = ng - 1; g >= 0; --g) {
     const int tg = t0 + g * kWideGroup;
@@ -450,7 +512,7 @@ __global__ __launch_bounds__(64) void dwide_replay_kernel(WideGeom G, DenseModel
       const int t = tg + f;
       if (t < t1) {
         if (t > 0) wide_predict<D>(F, sQ, fid, m, P);
-        wide_filter_frame<D, O>(H, cur[f], m, P);
+        wide_filter_frame<D, O, SCORE>(H, cur[f], m, P, rk);
       }
       mf[f] = m;
       Pf[f] = mat_symmetrize(P);
@@ -459,18 +521,8 @@ __global__ __launch_bounds__(64) void dwide_replay_kernel(WideGeom G, DenseModel
     for (int f = kWideGroup - 1; f >= 0; --f) {
       const int t = tg + f;
       if (t < t1 - 1) {                               // the chunk's last frame is smoothed already
-        const Mat<double, D> FP = fid ? Pf[f] : mat_mul(F, Pf[f]);
-        const Mat<double, D> Pp = mat_symmetrize(mat_add(fid ? Pf[f] : mat_mul_nt(FP, F), sQ));
-        const Mat<double, D> Z = chol_solve_mat(chol_factor(Pp), FP);   // Pp^-1 F Pf = G^T
-        const Vec<double, D> mp = fid ? mf[f] : mat_vec(F, mf[f]);
-        Vec<double, D> dm;
-#pragma unroll
-        for (int a = 0; a < D; ++a) dm.a[a] = m_s.a[a] - mp.a[a];
-        const Vec<double, D> Gdm = mat_t_vec(Z, dm);
-#pragma unroll
-        for (int a = 0; a < D; ++a) m_s.a[a] = mf[f].a[a] + Gdm.a[a];
-        P_s = mat_symmetrize(mat_add(Pf[f], mat_mul(mat_mul_tn(Z, mat_sub(P_s, Pp)), Z)));
-        emit(t, m_s, P_s);
+        rts_step(mf[f], Pf[f]);
+        if constexpr (!SCORE) emit(t, m_s, P_s);
       }
     }
     if (g > 0) {
@@ -478,6 +530,48 @@ __global__ __launch_bounds__(64) void dwide_replay_kernel(WideGeom G, DenseModel
       for (int f = 0; f < kWideGroup; ++f) cur[f] = nxt[f];
     }
   }
+  if constexpr (SCORE) {
+    if (t0 > 0) rts_step(m_in, mat_symmetrize(P_in));   // back to frame t0 - 1: the transition into the chunk
+    part_ll[idx] = ll;                                  // [chunk][keypoint]: coalesced
+    part_score[idx] = score;
+  }
+}
+
+// SCORE: nll[k], d nll / d log s [k] = minus the sums of the per-row partials of keypoint k (rows = chunks here,
+// blocks of 64 chunks in eks_dense_wave.hip), summed in a fixed order (the same bits on every run): block =
+// keypoint, thread i takes rows i, i + 256, ..., then a tree through LDS.  eks/core.py:650: a non-finite loss
+// becomes 1e12 with zero gradient.
+__global__ __launch_bounds__(256) void dense_score_finish_kernel(int K, int rows, const double* __restrict__ part_ll,
+                                                                const double* __restrict__ part_score,
+                                                                double* __restrict__ nll, double* __restrict__ dnll) {
+  __shared__ double a[256], b[256];
+  const int k = blockIdx.x, i = threadIdx.x;
+  double ll = 0.0, sc = 0.0;
+  for (int r = i; r < rows; r += 256) {
+    ll += part_ll[(size_t)r * K + k];
+    sc += part_score[(size_t)r * K + k];
+  }
+  a[i] = ll;
+  b[i] = sc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (i < off) {
+      a[i] += a[i + off];
+      b[i] += b[i + off];
+    }
+    __syncthreads();
+  }
+  if (i == 0) {
+    const double v = -a[0];
+    const bool fin = isfinite(v);
+    nll[k] = fin ? v : 1e12;
+    dnll[k] = fin ? -b[0] : 0.0;
+  }
+}
+int dense_score_finish(int K, int rows, const double* part_ll, const double* part_score, double* nll, double* dnll,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(dense_score_finish_kernel, dim3(K), dim3(256), 0, st, K, rows, part_ll, part_score, nll, dnll);
+  return hip_status(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -571,13 +665,19 @@ int dense_wide_scan(int K, int D, int nc, const double* elems, const double* fir
 }
 
 int dense_wide_summarize(int T, int K, int D, int O, int B, int nc, const DenseModelPtrs& M, const double* s,
-                         const float* y, const float* var, double* elems, int soa, double* first,
-                         hipStream_t st) {
+                         const float* y, const float* var, const double* rconst, double* elems, int soa,
+                         double* first, hipStream_t st) {
+  const bool score = var == nullptr;
   const WideGeom G{K, T, O, B, nc};
   const int lanes = K * nc;
   const dim3 grid((lanes + 63) / 64), block(64);
-#define EKS_WS(DD, OO) \
-  hipLaunchKernelGGL((dwide_summarize_kernel<DD, OO>), grid, block, 0, st, G, M, s, y, var, elems, soa, first)
+#define EKS_WS(DD, OO)                                                                                         \
+  if (score)                                                                                                   \
+    hipLaunchKernelGGL((dwide_summarize_kernel<DD, OO, true>), grid, block, 0, st, G, M, s, y, var, rconst,     \
+                       elems, soa, first);                                                                     \
+  else                                                                                                         \
+    hipLaunchKernelGGL((dwide_summarize_kernel<DD, OO, false>), grid, block, 0, st, G, M, s, y, var, rconst,    \
+                       elems, soa, first)
 #define EKS_WS_O(DD)                    \
   switch (O) {                          \
     case 2: EKS_WS(DD, 2); break;       \
@@ -599,15 +699,21 @@ int dense_wide_summarize(int T, int K, int D, int O, int B, int nc, const DenseM
 }
 
 int dense_wide_replay(int T, int K, int D, int O, int B, int nc, const DenseModelPtrs& M, const double* s,
-                      const float* y, const float* var, const double* pre, const double* suf,
-                      const double* bprior, const double* bsuffix, const double* chunk_in,
-                      const double* chunk_out, float* ms, float* Vs, int vs_diag, hipStream_t st) {
+                      const float* y, const float* var, const double* rconst, double* part_ll,
+                      double* part_score, const double* pre, const double* suf, const double* bprior,
+                      const double* bsuffix, const double* chunk_in, const double* chunk_out, float* ms,
+                      float* Vs, int vs_diag, hipStream_t st) {
+  const bool score = var == nullptr;
   const WideGeom G{K, T, O, B, nc};
   const int lanes = K * nc;
   const dim3 grid((lanes + 63) / 64), block(64);
-#define EKS_WR(DD, OO)                                                                                     \
-  hipLaunchKernelGGL((dwide_replay_kernel<DD, OO>), grid, block, 0, st, G, M, s, y, var, pre, suf, bprior, \
-                     bsuffix, chunk_in, chunk_out, ms, Vs, vs_diag)
+#define EKS_WR(DD, OO)                                                                                          \
+  if (score)                                                                                                    \
+    hipLaunchKernelGGL((dwide_replay_kernel<DD, OO, true>), grid, block, 0, st, G, M, s, y, var, rconst, part_ll, \
+                       part_score, pre, suf, bprior, bsuffix, chunk_in, chunk_out, ms, Vs, vs_diag);             \
+  else                                                                                                          \
+    hipLaunchKernelGGL((dwide_replay_kernel<DD, OO, false>), grid, block, 0, st, G, M, s, y, var, rconst,        \
+                       part_ll, part_score, pre, suf, bprior, bsuffix, chunk_in, chunk_out, ms, Vs, vs_diag)
 #define EKS_WR_O(DD)                    \
   switch (O) {                          \
     case 2: EKS_WR(DD, 2); break;       \

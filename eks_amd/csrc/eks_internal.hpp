@@ -63,7 +63,6 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
                  float* ms, float* Vs, void* ws, size_t ws_bytes, hipStream_t st);
 // narrow sessions: wave-per-64-chunks form (eks_dense_wave.hip)
 bool dense_wave_covers(int T, int K, int D, int O);
-bool dense_wave_score_covers(int T, int K, int D, int O);
 size_t dense_wave_workspace_bytes(int T, int K, int D);
 int dense_wave_score(const eks_dims_t& d, const float* y, const double* rconst, const DenseModel& M, double* nll,
                      double* dnll, void* ws, size_t ws_bytes, hipStream_t st);
@@ -73,15 +72,22 @@ int dense_wave_smooth(const eks_dims_t& d, const float* y, const float* var, con
 struct DenseModelPtrs;
 bool dense_wide_covers(int D, int O, int B);
 int dense_wide_summarize(int T, int K, int D, int O, int B, int nc, const DenseModelPtrs& M, const double* s,
-                         const float* y, const float* var, double* elems, int soa, double* first,
-                         hipStream_t st);
+                         const float* y, const float* var, const double* rconst, double* elems, int soa,
+                         double* first, hipStream_t st);   // var == nullptr: SCORE form (constant R)
+int dense_score_finish(int K, int rows, const double* part_ll, const double* part_score, double* nll, double* dnll,
+                       hipStream_t st);
+bool dense_score_covers(int T, int K, int D, int O);
+size_t dense_score_workspace_bytes(int T, int K, int D, int O);
+int dense_score(const eks_dims_t& d, const float* y, const double* rconst, const DenseModel& M, double* nll,
+                double* dnll, void* ws, size_t ws_bytes, hipStream_t st);
 size_t dense_wide_scan_scratch_doubles(int K, int D, int nc);
 int dense_wide_scan(int K, int D, int nc, const double* elems, const double* first, double* scratch,
                     double* chunk_in, double* chunk_out, hipStream_t st);
 int dense_wide_replay(int T, int K, int D, int O, int B, int nc, const DenseModelPtrs& M, const double* s,
-                      const float* y, const float* var, const double* pre, const double* suf,
-                      const double* bprior, const double* bsuffix, const double* chunk_in,
-                      const double* chunk_out, float* ms, float* Vs, int vs_diag, hipStream_t st);
+                      const float* y, const float* var, const double* rconst, double* part_ll,
+                      double* part_score, const double* pre, const double* suf, const double* bprior,
+                      const double* bsuffix, const double* chunk_in, const double* chunk_out, float* ms,
+                      float* Vs, int vs_diag, hipStream_t st);
 size_t dense_nll_workspace_bytes(int T, int K, int D, int O, int n_cand);
 int dense_nll(const eks_dims_t& d, const float* y, const double* rconst, const DenseModel& M,
               const double* s_cand, int n_cand, int per_keypoint, double* nll, double* dnll,

@@ -5,8 +5,8 @@ namespace eks {
 
 size_t dense_nll_workspace_bytes(int T, int K, int D, int O, int n_cand) {
   size_t need = loss_workspace_bytes(T, K, D, n_cand);
-  if (n_cand == 1 && dense_wave_score_covers(T, K, D, O)) {
-    const size_t w = dense_wave_workspace_bytes(T, K, D);
+  if (n_cand == 1 && dense_score_covers(T, K, D, O)) {
+    const size_t w = dense_score_workspace_bytes(T, K, D, O);
     if (w > need) need = w;
   }
   return need;
@@ -20,12 +20,12 @@ int dense_nll(const eks_dims_t& d, const float* y, const double* rconst, const D
   if ((long)K * n_cand > 65535) return EKS_ERR_UNSUPPORTED;
   if (ws_bytes < dense_nll_workspace_bytes(T, K, D, O, n_cand)) return EKS_ERR_WORKSPACE;
   // One s per keypoint, value + gradient, Q positive definite (the caller's word: EKS_FLAG_Q_PD): the smoother's
-  // two wave kernels in their SCORE form - the loss from the exact filter, its derivative from the smoothing
+  // own kernels in their SCORE form - the loss from the exact filter, its derivative from the smoothing
   // distribution (Fisher's identity; eks_dense_wave.hip) - instead of dual-number elements.
-  if (dnll && n_cand == 1 && per_keypoint && (d.flags & EKS_FLAG_Q_PD) && dense_wave_score_covers(T, K, D, O) &&
+  if (dnll && n_cand == 1 && per_keypoint && (d.flags & EKS_FLAG_Q_PD) && dense_score_covers(T, K, D, O) &&
       (reinterpret_cast<uintptr_t>(y) & 15u) == 0) {
     const DenseModel Ms{Mm.m0, Mm.S0, Mm.A, Mm.C, Mm.Q, s_cand};
-    return dense_wave_score(d, y, rconst, Ms, nll, dnll, ws, ws_bytes, st);
+    return dense_score(d, y, rconst, Ms, nll, dnll, ws, ws_bytes, st);
   }
   LossGeom G{K, T, O, loss_chunk(T, K * n_cand), 0, n_cand};
   G.nc = loss_chunks(T, G.B);

@@ -505,10 +505,13 @@ def test_nll_dense_matches_oracle(T, K, D, O):
 
 
 @pytest.mark.parametrize('T,K,D,O,general_A', [(800, 3, 3, 4, False), (1500, 5, 3, 4, True), (131, 2, 2, 2, False),
-                                               (9, 2, 3, 8, False), (2, 3, 2, 6, False), (20000, 4, 3, 4, False)])
+                                               (9, 2, 3, 8, False), (2, 3, 2, 6, False), (20000, 4, 3, 4, False),
+                                               # wide sessions: the keypoint-major kernels' SCORE form
+                                               (600, 1500, 3, 4, False), (1100, 700, 2, 6, True), (70, 1100, 3, 8, True),
+                                               (3, 1300, 2, 2, False)])
 def test_nll_dense_score_gradient_matches_oracle_and_dual_numbers(T, K, D, O, general_A):
-    """EKS_FLAG_Q_PD: value from the exact filter inside the smoother's wave kernels, gradient from the smoothing
-    distribution (Fisher's identity, eks_dense_wave.hip SCORE form) - against the oracle's forward-mode gradient
+    """EKS_FLAG_Q_PD: value from the exact filter inside the smoother's kernels, gradient from the smoothing
+    distribution (Fisher's identity; SCORE forms of eks_dense_wave.hip and eks_dense_wide.hip) - against the oracle's forward-mode gradient
     at the bars of the dual-number kernels, and against those kernels themselves (flags without Q_PD)."""
     from eks_amd import _lib, hip_ops
     arrs, y, var = _dense_problem(T, K, D, O, seed=17 + T)
