@@ -53,13 +53,14 @@ def model_flags(S0, A, C, Q) -> int:
     """Inspect HOST copies of the parameters (numpy) and return DIAG_MODEL / UNIT_AC / Q_PD flags."""
     import numpy as np
     D, O = A.shape[-1], C.shape[-2]
-    # Q positive definite with a margin (smallest eigenvalue > 1e-10 of the largest): the general path may take
-    # the loss gradient from the smoothing distribution (include/eks_hip.h: EKS_FLAG_Q_PD)
+    # Q positive definite with a margin (smallest eigenvalue > 1e-8 of the largest: the smoothing-distribution
+    # gradient multiplies float64 second moments by (sQ)^-1, so its error grows with Q's condition number): the
+    # general path may take the loss gradient from the smoothing distribution (include/eks_hip.h: EKS_FLAG_Q_PD)
     Qh = np.asarray(Q, dtype=np.float64)
     pd = 0
     if np.all(np.isfinite(Qh)):
         ev = np.linalg.eigvalsh(0.5 * (Qh + np.swapaxes(Qh, -1, -2)))
-        pd = FLAG_Q_PD if bool(np.all(ev[..., 0] > 1e-10 * np.maximum(ev[..., -1], 1e-300))) else 0
+        pd = FLAG_Q_PD if bool(np.all(ev[..., 0] > 1e-8 * np.maximum(ev[..., -1], 1e-300))) else 0
 
     def is_diag(M):
         return bool(np.all(M[..., ~np.eye(D, dtype=bool)] == 0))
