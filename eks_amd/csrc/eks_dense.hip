@@ -258,9 +258,51 @@ static int dense_chunk(int T, int K, bool ekf = false) {
   return (long long)K * ((T + 15) / 16) <= (1 << 18) ? 16 : kDenseSmoothChunk;
 }
 
+// Which organisation a (T, K, D, O) smoothing problem takes, and its workspace:
+//   wave : narrow sessions, eks_dense_wave.hip
+//   runs : keypoint-major kernels with the per-lane scan, eks_dense_wide.hip - chunk elements, the belief /
+//          information pair per chunk, the scan's upper levels, two partial sums per lane (SCORE form): no
+//          per-frame stream (288 GB hold 50 000 frames x ~170 000 keypoints of D = 3 this way; the generic layout's
+//          float64 filtered-belief stream alone would take 96 B per keypoint-frame)
+//   else : the generic kernels (any D <= 6, O <= 64; also the keypoint-major kernels with the tree scan behind
+//          EKS_DENSE_TREE_SCAN) with prefix / suffix elements per chunk and the filtered-belief stream
+enum DensePath { kDenseWave, kDenseRuns, kDenseGeneric };
+static DensePath dense_path(int T, int K, int D, int O) {
+  if (dense_wave_covers(T, K, D, O)) return kDenseWave;
+  if (dense_wide_covers(D, O, dense_chunk(T, K)) && !knob_int(KNOB_DENSE_TREE_SCAN, 0)) return kDenseRuns;
+  return kDenseGeneric;
+}
+struct RunsLayout {
+  double *elems, *chunk_in, *chunk_out, *scratch, *first, *part_ll, *part_score;
+  size_t bytes;
+};
+static RunsLayout runs_layout(int K, int D, int nc, char* base) {
+  const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
+  RunsLayout L;
+  size_t off = 0;
+  auto take = [&](size_t doubles) {
+    double* p = reinterpret_cast<double*>(base + off);
+    off += align_up(doubles * 8, 256);
+    return p;
+  };
+  L.elems = take((size_t)nc * K * nv);
+  L.chunk_in = take((size_t)nc * K * rec);
+  L.chunk_out = take((size_t)nc * K * rec);
+  L.scratch = take(dense_wide_scan_scratch_doubles(K, D, nc));
+  L.first = take((size_t)K * rec);
+  L.part_ll = take((size_t)nc * K);
+  L.part_score = take((size_t)nc * K);
+  L.bytes = off;
+  return L;
+}
+
 size_t dense_smooth_workspace_bytes(int T, int K, int D, int O) {
-  (void)O;
   const int B = dense_chunk(T, K), nc = (T + B - 1) / B, nblk = (nc + kDenseCB - 1) / kDenseCB;
+  switch (dense_path(T, K, D, O)) {
+    case kDenseWave: return dense_wave_workspace_bytes(T, K, D);
+    case kDenseRuns: return runs_layout(K, D, nc, nullptr).bytes;
+    default: break;
+  }
   const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
   return 3 * align_up((size_t)nc * K * nv * 8, 256) +
          align_up((size_t)nblk * K * nv * 8, 256) + 2 * align_up((size_t)nblk * K * rec * 8, 256) +
@@ -273,17 +315,33 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
   if (D < 1 || D > 6 || O < 1 || O > 64) return EKS_ERR_UNSUPPORTED;
   if (ws_bytes < dense_smooth_workspace_bytes(T, K, D, O)) return EKS_ERR_WORKSPACE;
   // narrow sessions (configs[3]: 4 keypoints) are depth-bound: two launches with the scan in wave
-  // shuffles and the filtered beliefs in LDS (eks_dense_wave.hip); wide ones stream keypoint-major here
-  // (both newer forms read a keypoint's O values of a frame as 8- / 16-byte pieces: the arrays must be
-  //  16-byte aligned, which device allocations are; an oddly offset view takes the generic kernels)
-  const bool aligned = ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(var)) & 15u) == 0;
-  if (aligned && dense_wave_covers(T, K, D, O)) return dense_wave_smooth(d, y, var, Mm, ms, Vs, ws, ws_bytes, st);
+  // shuffles and the filtered beliefs in LDS (eks_dense_wave.hip); wide ones stream keypoint-major
+  const DensePath path = dense_path(T, K, D, O);
+  if (path == kDenseWave) return dense_wave_smooth(d, y, var, Mm, ms, Vs, ws, ws_bytes, st);
   DenseGeom G{K, T, O, dense_chunk(T, K), 0, 0, 0};
   G.nc = (T + G.B - 1) / G.B;
   G.Bs = G.B;
   G.ncs = G.nc;
   const int nblk = (G.nc + kDenseCB - 1) / kDenseCB;
   const DenseModelPtrs M{Mm.m0, Mm.S0, Mm.A, Mm.C, Mm.Q};
+  if (path == kDenseRuns) {
+    const RunsLayout L = runs_layout(K, D, G.nc, static_cast<char*>(ws));
+    const int vs_diag = (d.flags & EKS_FLAG_VS_DIAG) ? 1 : 0;
+    int rc;
+    {
+      ProfScope ps("dense_summarize", st);
+      rc = dense_wide_summarize(T, K, D, O, G.B, G.nc, M, Mm.s, y, var, nullptr, L.elems, 1, L.first, st);
+      if (rc != EKS_OK) return rc;
+    }
+    {
+      ProfScope ps("dense_scan", st);
+      rc = dense_wide_scan(K, D, G.nc, L.elems, L.first, L.scratch, L.chunk_in, L.chunk_out, st);
+      if (rc != EKS_OK) return rc;
+    }
+    ProfScope ps("dense_replay", st);
+    return dense_wide_replay(T, K, D, O, G.B, G.nc, M, Mm.s, y, var, nullptr, nullptr, nullptr, nullptr, nullptr,
+                             nullptr, nullptr, L.chunk_in, L.chunk_out, ms, Vs, vs_diag, st);
+  }
   const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
   char* p = static_cast<char*>(ws);
   double* elems = reinterpret_cast<double*>(p);
@@ -304,18 +362,14 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
   const int lanes = K * G.nc;
   const int vs_diag = (d.flags & EKS_FLAG_VS_DIAG) ? 1 : 0;
   const Gate open{nullptr, 0.0};
-  const bool wide = aligned && dense_wide_covers(D, O, G.B);   // prefetching summarize / checkpointed replay
-  // ... with a per-lane sequential scan in between: its run aggregates live in the (otherwise unused)
-  // filtered-belief stream, its per-chunk results where the tree scan keeps prefix / suffix elements
-  const bool runs = wide && dense_wide_scan_scratch_doubles(K, D, G.nc) <= (size_t)T * K * rec &&
-                    !knob_int(KNOB_DENSE_TREE_SCAN, 0);
+  // (EKS_DENSE_TREE_SCAN: the keypoint-major summarize / replay around the tree scan of whole elements)
+  const bool wide = dense_wide_covers(D, O, G.B);
   EKS_DISPATCH_D(D, {
     const LinearObs<DD> obs = make_linear_obs<DD>(y, var, K, O, M);
     {
       ProfScope ps("dense_summarize", st);
       if (wide) {
-        const int rc = dense_wide_summarize(T, K, D, O, G.B, G.nc, M, Mm.s, y, var, nullptr, elems, runs ? 1 : 0,
-                                            first, st);
+        const int rc = dense_wide_summarize(T, K, D, O, G.B, G.nc, M, Mm.s, y, var, nullptr, elems, 0, first, st);
         if (rc != EKS_OK) return rc;
       } else {
         hipLaunchKernelGGL((dense_summarize_kernel<DD, LinearObs<DD>>), dim3((lanes + 63) / 64),
@@ -324,23 +378,17 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
     }
     {
       ProfScope ps("dense_scan", st);
-      if (runs) {
-        const int rc = dense_wide_scan(K, D, G.nc, elems, first, filt, pre, suf, st);
-        if (rc != EKS_OK) return rc;
-      } else {
-        const dim3 sgrid(K, nblk);
-        hipLaunchKernelGGL(dense_scan_kernel<DD>, sgrid, dim3(2 * kDenseCB), 0, st, G, elems, pre, suf,
-                           agg, open);
-        hipLaunchKernelGGL(dense_scan_blocks_kernel<DD>, dim3(K), dim3(2 * kDenseCB), 0, st, G, nblk,
-                           first, agg, bprior, bsuffix, open);
-      }
+      const dim3 sgrid(K, nblk);
+      hipLaunchKernelGGL(dense_scan_kernel<DD>, sgrid, dim3(2 * kDenseCB), 0, st, G, elems, pre, suf,
+                         agg, open);
+      hipLaunchKernelGGL(dense_scan_blocks_kernel<DD>, dim3(K), dim3(2 * kDenseCB), 0, st, G, nblk,
+                         first, agg, bprior, bsuffix, open);
     }
     {
       ProfScope ps("dense_replay", st);
       if (wide) {
         const int rc = dense_wide_replay(T, K, D, O, G.B, G.nc, M, Mm.s, y, var, nullptr, nullptr, nullptr, pre, suf,
-                                         bprior, bsuffix, runs ? pre : nullptr, runs ? suf : nullptr, ms, Vs,
-                                         vs_diag, st);
+                                         bprior, bsuffix, nullptr, nullptr, ms, Vs, vs_diag, st);
         if (rc != EKS_OK) return rc;
       } else {
         hipLaunchKernelGGL((dense_replay_kernel<DD, false, LinearObs<DD>>), dim3((lanes + 63) / 64),
@@ -360,56 +408,36 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
 // the dual-number kernels of eks_loss.hip).
 bool dense_score_covers(int T, int K, int D, int O) {
   if (T < 2 || knob_int(KNOB_DENSE_LEGACY, 0) || knob_int(KNOB_DENSE_DUAL_GRAD, 0)) return false;
-  if (dense_wave_covers(T, K, D, O)) return true;
-  const int B = dense_chunk(T, K), nc = (T + B - 1) / B;
-  const size_t rec = D + D * D;
-  return dense_wide_covers(D, O, B) && !knob_int(KNOB_DENSE_TREE_SCAN, 0) &&
-         dense_wide_scan_scratch_doubles(K, D, nc) + 2 * (size_t)nc * K <= (size_t)T * K * rec;
+  return dense_path(T, K, D, O) != kDenseGeneric;
 }
-size_t dense_score_workspace_bytes(int T, int K, int D, int O) {
-  const size_t a = dense_smooth_workspace_bytes(T, K, D, O), b = dense_wave_workspace_bytes(T, K, D);
-  return a > b ? a : b;
-}
+size_t dense_score_workspace_bytes(int T, int K, int D, int O) { return dense_smooth_workspace_bytes(T, K, D, O); }
 int dense_score(const eks_dims_t& d, const float* y, const double* rconst, const DenseModel& Mm, double* nll,
                 double* dnll, void* ws, size_t ws_bytes, hipStream_t st) {
   const int T = d.n_frames, K = d.n_keypoints, D = d.state_dim, O = d.obs_dim;
   if (!dense_score_covers(T, K, D, O)) return EKS_ERR_UNSUPPORTED;
   if (ws_bytes < dense_score_workspace_bytes(T, K, D, O)) return EKS_ERR_WORKSPACE;
-  if (dense_wave_covers(T, K, D, O)) return dense_wave_score(d, y, rconst, Mm, nll, dnll, ws, ws_bytes, st);
-  const int B = dense_chunk(T, K), nc = (T + B - 1) / B, nblk = (nc + kDenseCB - 1) / kDenseCB;
+  if (dense_path(T, K, D, O) == kDenseWave) return dense_wave_score(d, y, rconst, Mm, nll, dnll, ws, ws_bytes, st);
+  const int B = dense_chunk(T, K), nc = (T + B - 1) / B;
   const DenseModelPtrs M{Mm.m0, Mm.S0, Mm.A, Mm.C, Mm.Q};
-  const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
-  char* p = static_cast<char*>(ws);               // (the layout of dense_smooth)
-  double* elems = reinterpret_cast<double*>(p);
-  p += align_up((size_t)nc * K * nv * 8, 256);
-  double* chunk_in = reinterpret_cast<double*>(p);
-  p += align_up((size_t)nc * K * nv * 8, 256);
-  double* chunk_out = reinterpret_cast<double*>(p);
-  p += align_up((size_t)nc * K * nv * 8, 256);
-  p += align_up((size_t)nblk * K * nv * 8, 256) + 2 * align_up((size_t)nblk * K * rec * 8, 256);
-  double* scratch = reinterpret_cast<double*>(p);   // the smoother's filtered-belief stream: scan levels + partials
-  double* part_ll = scratch + dense_wide_scan_scratch_doubles(K, D, nc);
-  double* part_score = part_ll + (size_t)nc * K;
-  p += align_up((size_t)T * K * rec * 8, 256);
-  double* first = reinterpret_cast<double*>(p);
+  const RunsLayout L = runs_layout(K, D, nc, static_cast<char*>(ws));
   int rc;
   {
     ProfScope ps("dense_score_summarize", st);
-    rc = dense_wide_summarize(T, K, D, O, B, nc, M, Mm.s, y, nullptr, rconst, elems, 1, first, st);
+    rc = dense_wide_summarize(T, K, D, O, B, nc, M, Mm.s, y, nullptr, rconst, L.elems, 1, L.first, st);
     if (rc != EKS_OK) return rc;
   }
   {
     ProfScope ps("dense_score_scan", st);
-    rc = dense_wide_scan(K, D, nc, elems, first, scratch, chunk_in, chunk_out, st);
+    rc = dense_wide_scan(K, D, nc, L.elems, L.first, L.scratch, L.chunk_in, L.chunk_out, st);
     if (rc != EKS_OK) return rc;
   }
   {
     ProfScope ps("dense_score_replay", st);
-    rc = dense_wide_replay(T, K, D, O, B, nc, M, Mm.s, y, nullptr, rconst, part_ll, part_score, nullptr, nullptr,
-                           nullptr, nullptr, chunk_in, chunk_out, nullptr, nullptr, 0, st);
+    rc = dense_wide_replay(T, K, D, O, B, nc, M, Mm.s, y, nullptr, rconst, L.part_ll, L.part_score, nullptr, nullptr,
+                           nullptr, nullptr, L.chunk_in, L.chunk_out, nullptr, nullptr, 0, st);
     if (rc != EKS_OK) return rc;
   }
-  return dense_score_finish(K, nc, part_ll, part_score, nll, dnll, st);
+  return dense_score_finish(K, nc, L.part_ll, L.part_score, nll, dnll, st);
 }
 
 // ---- extended Kalman filter / smoother with calibrated pinhole cameras ------------------------

@@ -102,17 +102,20 @@ struct DwRows {
 template <int O>
 __device__ __forceinline__ void dw_request_rows(const float* __restrict__ y, const float* __restrict__ var,
                                                 size_t row0, size_t row_stride, int nrows, DwRows<O>& R) {
-  // a keypoint's O values of one frame are contiguous and (O even) 8-byte, (O % 4 == 0) 16-byte aligned
+  // a keypoint's O values of one frame are contiguous: 8- / 16-byte pieces.  The pieces are naturally aligned
+  // when y / var come from the allocator; the load type only promises 4 bytes (global loads may be misaligned),
+  // so an oddly offset view of a larger array works too
   constexpr int W = DwRows<O>::W;
   typedef typename DwRows<O>::fw fw;
+  typedef float fwu __attribute__((ext_vector_type(W), aligned(4)));
 #pragma unroll
   for (int i = 0; i < kDwB; ++i) {
     const size_t r = row0 + (size_t)i * row_stride;
 #pragma unroll
     for (int o = 0; o < O / W; ++o) {
       if (i < nrows) {
-        R.a[i][o] = *reinterpret_cast<const fw*>(y + r + o * W);
-        R.b[i][o] = var ? *reinterpret_cast<const fw*>(var + r + o * W) : fw(1.f);   // (SCORE: constant R)
+        R.a[i][o] = *reinterpret_cast<const fwu*>(y + r + o * W);
+        R.b[i][o] = var ? fw(*reinterpret_cast<const fwu*>(var + r + o * W)) : fw(1.f);   // (SCORE: constant R)
       } else {
         R.a[i][o] = fw(0.f);
         R.b[i][o] = fw(1.f);

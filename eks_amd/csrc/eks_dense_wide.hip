@@ -47,12 +47,13 @@ struct FrameRows {
   float y[O], v[O];
 };
 
-// the O values of (frame t, keypoint k): contiguous, 8-byte (O even) or 16-byte (O % 4 == 0) aligned
+// the O values of (frame t, keypoint k): contiguous 8- (O even) or 16-byte (O % 4 == 0) pieces, naturally aligned
+// when y / var come from the allocator; the load type only promises 4 bytes (an oddly offset view works too)
 template <int O>
 __device__ __forceinline__ void wide_load(const float* __restrict__ y, const float* __restrict__ var,
                                           size_t row, bool ok, FrameRows<O>& f) {
   constexpr int W = O % 4 == 0 ? 4 : 2;
-  typedef float fw __attribute__((ext_vector_type(W)));
+  typedef float fw __attribute__((ext_vector_type(W), aligned(4)));
 #pragma unroll
   for (int o = 0; o < O; o += W) {
     fw a = fw(0.f), b = fw(1.f);

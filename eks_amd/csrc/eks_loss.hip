@@ -22,8 +22,7 @@ int dense_nll(const eks_dims_t& d, const float* y, const double* rconst, const D
   // One s per keypoint, value + gradient, Q positive definite (the caller's word: EKS_FLAG_Q_PD): the smoother's
   // own kernels in their SCORE form - the loss from the exact filter, its derivative from the smoothing
   // distribution (Fisher's identity; eks_dense_wave.hip) - instead of dual-number elements.
-  if (dnll && n_cand == 1 && per_keypoint && (d.flags & EKS_FLAG_Q_PD) && dense_score_covers(T, K, D, O) &&
-      (reinterpret_cast<uintptr_t>(y) & 15u) == 0) {
+  if (dnll && n_cand == 1 && per_keypoint && (d.flags & EKS_FLAG_Q_PD) && dense_score_covers(T, K, D, O)) {
     const DenseModel Ms{Mm.m0, Mm.S0, Mm.A, Mm.C, Mm.Q, s_cand};
     return dense_score(d, y, rconst, Ms, nll, dnll, ws, ws_bytes, st);
   }

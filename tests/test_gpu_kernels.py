@@ -292,6 +292,22 @@ def test_smooth_dense_wide_sessions_match_oracle(T, K, D, O, general_A, set_knob
         assert _rel(Vs, Vs_o, axis_scale=(1, 2, 3)) < 1e-5
 
 
+@pytest.mark.parametrize('T,K,D,O', [(500, 3, 2, 2), (40, 1301, 2, 2), (300, 5, 3, 6)])
+def test_smooth_dense_accepts_views_that_are_only_4_byte_aligned(T, K, D, O):
+    """y / var as row-offset views of larger arrays (K O 4 bytes per row is not a multiple of 16 here): the narrow
+    and the keypoint-major kernels read a keypoint's O values as 8- / 16-byte pieces whose load type only promises
+    4 bytes - same bits as from freshly allocated (256-byte aligned) copies."""
+    from eks_amd import hip_ops
+    arrs, y, var = _dense_problem(T + 1, K, D, O, seed=3 + T)
+    s = _dev(np.exp(np.random.default_rng(2).uniform(-2, 2, K)))
+    yb, vb = _dev(y), _dev(var)
+    yv, vv = yb[1:], vb[1:]
+    assert yv.data_ptr() % 16 != 0 and yv.is_contiguous()
+    ms_v, Vs_v = hip_ops.smooth(yv, vv, *_params_dev(arrs), s, flags=0)
+    ms_a, Vs_a = hip_ops.smooth(yv.clone(), vv.clone(), *_params_dev(arrs), s, flags=0)
+    assert torch.equal(ms_v, ms_a) and torch.equal(Vs_v, Vs_a)
+
+
 @pytest.mark.parametrize('case', ['all_clipped', 'tiny', 'one_clipped'])
 @pytest.mark.parametrize('sval', [10.0, 1e-3])
 def test_smooth_dense_with_variances_at_the_clip(case, sval):
