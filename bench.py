@@ -45,6 +45,7 @@ WORKLOADS = {
     'c5': (50_000, 128 * 32, 0), # configs[4], one GPU's share: 128 sessions x 32 keypoints batched
     'c4': (50_000, 4, 0),        # configs[3]: mirrored multicam, 2 views x 4 paws, D = 3, O = 4 (dense path)
     'c4w': (50_000, 256, 0),     # the same model on a WIDE session (256 keypoints): can the dense kernels stream?
+    'c4adam': (50_000, 4, 0),    # configs[3] in the reference's default mode: one loss + gradient evaluation per step
     'pupil': (100_000, 1, 0),    # IBL pupil AR(1) session, one optimiser iteration per step
     'ekf': (50_000, 16, 0),      # calibrated multicam, 4 cameras, D = 3, O = 8, fixed s
 }
@@ -237,12 +238,14 @@ def cpu_baseline(y_dev, var_dev, T, n_cand, budget_s):
                        f'recursion (oracle/eks_oracle.c), OpenMP over keypoints, {dt:.1f} s'), s, ref
 
 
-def bench_dense(args, T, K, dev, rank, world, lib):
+def bench_dense(args, T, K, dev, rank, world, lib, grad=False):
     """The general (D, O) kernels on the mirrored-multicam model (2 views, n_latent 3, fixed s): configs[3]
     itself (K = 4 paws: depth-bound by construction - two launches of float64 3x3 chains, no bytes to speak of)
-    and, as `c4w`, the same model on a wide session (K = 256) to see whether the kernels can stream."""
+    and, as `c4w`, the same model on a wide session (K = 256) to see whether the kernels can stream.  `grad`
+    (`c4adam`): a step is one evaluation of the optimiser's loss and its gradient at one s per keypoint - what the
+    reference's default mode (smooth_param=None, eks/core.py:562-699) repeats ~100 times per session."""
     import torch
-    from eks_amd import hip_ops
+    from eks_amd import _lib, hip_ops
     D, O = 3, 4
     g = torch.Generator(device=dev)
     g.manual_seed(4 + rank)
@@ -266,6 +269,13 @@ def bench_dense(args, T, K, dev, rank, world, lib):
     def step():
         hip_ops.smooth(y, var, m0, S0, eye, C, Q, s, out=(ms, Vs))
 
+    if grad:
+        rconst = hip_ops.const_r(var)
+        s_col = s[:, None].contiguous()
+
+        def step():                                   # noqa: F811  (Q above is positive definite)
+            hip_ops.nll(y, rconst, m0, S0, eye, C, Q, s_col, per_keypoint=True, want_grad=True, flags=_lib.FLAG_Q_PD)
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -287,15 +297,20 @@ def bench_dense(args, T, K, dev, rank, world, lib):
     narrow = K <= 16
     longest = max(prof, key=prof.get) if prof else None
     bytes_per_unit = 4 * O * 2 + 4 * D + 4 * D * D           # y, var in; ms, Vs out: 80 B at D = 3, O = 4
+    if grad:
+        bytes_per_unit = 4 * O                               # y in; two doubles per keypoint out
     whole = bytes_per_unit * T * K / (dt / args.steps) / 1e9
-    out = {'metric': f'frames*keypoints smoothed/s, mirrored multicam {T // 1000}k x {K} (D={D}, O={O})',
+    what = 'through one loss + gradient evaluation' if grad else 'smoothed'
+    out = {'metric': f'frames*keypoints {what}/s, mirrored multicam {T // 1000}k x {K} (D={D}, O={O})',
            'value': args.steps * T * K / dt, 'unit': 'frames*keypoints/s', 'n_gpus': 1,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
            'regions': len(region_dt), 'ms_per_step_min': 1e3 * min(region_dt) / args.steps,
            'ms_per_step_max': 1e3 * max(region_dt) / args.steps,
            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
            'data': 'synthetic',
-           'config': {'workload': f'multicam linear T={T} x K={K} keypoints, D={D}, O={O}, fixed s=10, full ms/Vs'},
+           'config': {'workload': (f'multicam linear T={T} x K={K} keypoints, D={D}, O={O}, ' +
+                                   ('constant-R filter NLL and d/d log s at s=10 (the Adam loop body)' if grad
+                                    else 'fixed s=10, full ms/Vs'))},
            'roofline': {'bound': 'hbm', 'kernel': 'whole step (' + ' + '.join(sorted(prof)) + ')', 'unit': 'GB/s',
                         'peak': HBM_PEAK_GBS, 'achieved': whole, 'frac': whole / HBM_PEAK_GBS, 'traffic': None,
                         'algorithmic_bytes_per_unit': bytes_per_unit, 'stage_avg_ms': prof,
@@ -477,8 +492,8 @@ def main():
     lib = _lib.load()
 
     T, K, n_cand = WORKLOADS[args.workload]
-    if args.workload in ('c4', 'c4w'):
-        return bench_dense(args, T, K, dev, rank, world, lib)
+    if args.workload in ('c4', 'c4w', 'c4adam'):
+        return bench_dense(args, T, K, dev, rank, world, lib, grad=args.workload == 'c4adam')
     if args.workload == 'pupil':
         return bench_pupil(args, T, dev, lib)
     if args.workload == 'ekf':

@@ -13,6 +13,7 @@ python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke
 python bench.py > $O/bench_c3.json 2> $O/bench_c3.err
 python bench.py --workload c4 --no-cpu-baseline > $O/bench_c4.json 2>/dev/null
 python bench.py --workload c4w --no-cpu-baseline > $O/bench_c4w.json 2>/dev/null
+python bench.py --workload c4adam --no-cpu-baseline > $O/bench_c4adam.json 2>/dev/null
 # the N > 1 launch path as the round-end driver invokes it (no outer torchrun); two ranks share this box's GPU
 EKS_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload c3 --steps 10 --no-cpu-baseline > $O/bench_c3_2ranks_gloo.json 2>/dev/null
 EKS_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload c3 --steps 10 --no-cpu-baseline --scaling strong > $O/bench_c3_2ranks_gloo_strong.json 2>/dev/null
@@ -24,6 +25,7 @@ python tools/ekf_time.py > $O/ekf_time.txt 2>&1
 python tools/driver_time.py 2>&1 | grep -E " ms" > $O/driver_time.txt
 python tools/host_path_time.py > $O/host_path_time.txt 2>&1
 python tools/adam_time.py > $O/adam_time.txt 2>&1
+python tools/dense_adam_time.py > $O/dense_adam_time.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-events"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > /dev/null 2>&1
