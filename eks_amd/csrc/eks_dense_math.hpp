@@ -160,7 +160,7 @@ EKS_HD Mat<S, D> mat_symmetrize(const Mat<S, D>& x) {
 // v_rsq_f64 seed refined by two Newton steps (y <- y (1.5 - 0.5 x y^2): full double accuracy after the second,
 // l = x y) instead of an IEEE square root followed by an IEEE division - about 8 dependent instructions instead
 // of 27, on the critical path of every composition of the scans and of every RTS step (round 3: the narrow-
-// session kernels are bounded by exactly these chains).  Dual numbers and the host keep sqrt and 1 / x.
+// session kernels are bounded by exactly these chains).  The host keeps sqrt and 1 / x.
 template <typename S>
 EKS_HD void chol_pivot(const S& sum, S& l, S& inv) {
   l = sqrt_s(sum);
@@ -175,6 +175,15 @@ EKS_HD void chol_pivot<double>(const double& sum, double& l, double& inv) {
   y = y * (1.5 - h * y * y);
   inv = y;
   l = sum * y;
+}
+// dual numbers: the value part the same way, d l = d x / (2 l), d (1 / l) = - d l / l^2
+template <>
+EKS_HD void chol_pivot<DualD>(const DualD& sum, DualD& l, DualD& inv) {
+  double lv, iv;
+  chol_pivot<double>(sum.v, lv, iv);
+  const double dl = 0.5 * sum.d * iv;
+  l = DualD(lv, dl);
+  inv = DualD(iv, -iv * iv * dl);
 }
 #endif
 
