@@ -30,6 +30,13 @@
 // exact for the exact smoothing distribution and Q positive definite (the caller's EKS_FLAG_Q_PD) - plain
 // float64 where the dual-number kernels (eks_loss.hip) carry 68 doubles per element through every
 // composition and spill (0.26 ms per evaluation on configs[3] against 0.08 here).
+//   MODE 1: dynamics (F, s Q), constant R, derivative with respect to log s (the formula above).
+//   MODE 2: the pupil loss (eks/ibl_pupil_smoother.py:540-552): AR(1) dynamics x_t = a . x_{t-1} + N(0, diag q),
+//           the frames' own variances; the same identity per coordinate gives the two sums
+//               S_q[i] = sum_t ( E[w_i^2 | y] / q_i - 1 ) / (2 q_i),      S_a[i] = sum_t E[w_i x_{t-1,i} | y] / q_i,
+//               E[w_i x_{t-1,i}] = dm_i m_{t-1,i} + Cov(x_{t-1}, x_t)_ii - a_i V_{t-1,ii},
+//           and d loglik / d theta = sum_i S_q[i] dq_i/dtheta + S_a[i] da_i/dtheta for every tangent (da, dq) the
+//           caller passes (q > 0 in every coordinate: the caller's EKS_FLAG_Q_PD).
 //
 // Matrices are float64 in registers; R_t is diagonal, so a frame's observations are absorbed one scalar at
 // a time (rank-1 forms, no inverse); the scan's compositions use the Cholesky / Woodbury forms of
@@ -137,20 +144,42 @@ __device__ __forceinline__ void dw_park_rows(const DwRows<O>& R, float* __restri
     }
 }
 
+// dynamics of keypoint k: (F, s Q) of the model, or (MODE 2) diag(a), diag(q) given per coordinate
+template <int D, int MODE>
+__device__ __forceinline__ void dw_load_dynamics(const DenseModelPtrs& M, const double* __restrict__ s,
+                                                 const double* __restrict__ ar_a, const double* __restrict__ ar_q,
+                                                 int k, Mat<double, D>& F, Mat<double, D>& sQ, bool& fid) {
+  if constexpr (MODE == 2) {
+    F = mat_zero<double, D>();
+    sQ = mat_zero<double, D>();
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      F.a[i][i] = ar_a[(size_t)k * D + i];
+      sQ.a[i][i] = ar_q[(size_t)k * D + i];
+    }
+    fid = false;
+  } else {
+    load_dynamics<double, D>(M, k, s[k], F, sQ, fid);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // SUBS wave pairs per workgroup (each pair = one (keypoint, 64 chunks) unit): with more units than CUs, two
 // 2-wave workgroups on one CU could land on the same SIMDs and halve each other's float64 rate (measured:
 // 392 units of 2 waves 45 us, their own lifetime 28 us); a 4-wave workgroup spreads over the CU's four SIMDs.
-template <int D, int O, int SUBS, bool SCORE>
+template <int D, int O, int SUBS, int MODE>
 __global__ __launch_bounds__(128 * SUBS) void dw_summarize_kernel(DwGeom G, DenseModelPtrs M,
                                                           const double* __restrict__ s,
                                                           const float* __restrict__ y,
                                                           const float* __restrict__ var,
                                                           const double* __restrict__ rconst,
+                                                          const double* __restrict__ ar_a,
+                                                          const double* __restrict__ ar_q,
                                                           double* __restrict__ pre_ex,
                                                           double* __restrict__ suf_ex,
                                                           double* __restrict__ agg,
                                                           double* __restrict__ first) {
+  constexpr bool SCORE = MODE == 1;                   // constant R instead of rows of var
   constexpr int NV = delem_doubles<D>();
   // each wave parks its own copy of its rows (SCORE reads no variances: constant R)
   __shared__ float ly[2 * SUBS][kDwB * 64 * O], lv[SCORE ? 1 : 2 * SUBS][SCORE ? 1 : kDwB * 64 * O];
@@ -169,7 +198,7 @@ __global__ __launch_bounds__(128 * SUBS) void dw_summarize_kernel(DwGeom G, Dens
   dw_request_rows<O>(y, var, ((size_t)t0 * G.K + k) * O, (size_t)G.K * O, len, rows);
   Mat<double, D> F, sQ;                               // (the model's loads go out behind the rows': one round trip)
   bool fid;
-  load_dynamics<double, D>(M, k, s[k], F, sQ, fid);
+  dw_load_dynamics<D, MODE>(M, s, ar_a, ar_q, k, F, sQ, fid);
   const ObsRows<D, O> H = load_obs_rows<D, O>(M, k);
   double rk[O];                                       // SCORE: the keypoint's constant variances
 #pragma unroll
@@ -274,12 +303,14 @@ __device__ __forceinline__ DElem<double, D> dw_compose_range(const double* __res
   return x;
 }
 
-template <int D, int O, int SUBS, bool SCORE>
+template <int D, int O, int SUBS, int MODE>
 __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseModelPtrs M,
                                                        const double* __restrict__ s,
                                                        const float* __restrict__ y,
                                                        const float* __restrict__ var,
                                                        const double* __restrict__ rconst,
+                                                       const double* __restrict__ ar_a,
+                                                       const double* __restrict__ ar_q,
                                                        double* __restrict__ part,
                                                        const double* __restrict__ pre_ex,
                                                        const double* __restrict__ suf_ex,
@@ -287,6 +318,8 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
                                                        const double* __restrict__ first,
                                                        float* __restrict__ ms, float* __restrict__ Vs,
                                                        int vs_diag) {
+  constexpr bool SCORE = MODE == 1;                   // constant R instead of rows of var
+  constexpr bool SUMS = MODE != 0;                    // loss and derivative sums instead of ms / Vs
   constexpr int NV = delem_doubles<D>();
   constexpr int NF = D + D * (D + 1) / 2;             // filtered mean + upper triangle of the covariance
   constexpr int REC = D + D * D;
@@ -337,7 +370,7 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
   }
   Mat<double, D> F, sQ;
   bool fid;
-  load_dynamics<double, D>(M, k, s[k], F, sQ, fid);
+  dw_load_dynamics<D, MODE>(M, s, ar_a, ar_q, k, F, sQ, fid);
   const ObsRows<D, O> H = load_obs_rows<D, O>(M, k);
   const int t0 = live ? j * kDwB : 0, len = live ? min(kDwB, G.T - t0) : 0;
   DElem<double, D> pe = delem_identity<double, D>(), se = delem_identity<double, D>();
@@ -380,7 +413,7 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
 #pragma unroll
     for (int b = 0; b < D; ++b) J.a[a][b] = xch[D + a * D + b];
   }
-  if (!SCORE && !live) return;                        // (SCORE: every lane joins the wave's sums at the end)
+  if (!SUMS && !live) return;                         // (sums: every lane joins the wave's reduction at the end)
   if (lane > 0) delem_apply(pe, m, P);                // through the block's chunks before this one
   if (lane < 63 && j + 1 < G.nc) delem_back(se, eta, J);   // back through those after it
   if (j == 0) load_prior<D>(M, k, m, P);              // chunk 0 replays frame 0's update of the prior itself
@@ -391,6 +424,9 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
   const Vec<double, D> m_in = m;                      // filtered belief of frame t0 - 1 (SCORE: the transition
   const Mat<double, D> P_in = P;                      //  into this chunk's first frame is this lane's)
   double ll = 0.0, score = 0.0;
+  double sq_sum[D], sa_sum[D];                        // MODE 2: S_q, S_a per coordinate
+#pragma unroll
+  for (int a = 0; a < D; ++a) sq_sum[a] = sa_sum[a] = 0.0;
   // ---- exact filter over the chunk; filtered beliefs to LDS
   double* mine = recs + lane;
 #pragma unroll 1
@@ -416,7 +452,7 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
       const double g = rcp(sigma);
       const double dv = (double)py[o] - dot(h, m);
       const double gd = g * dv;
-      if constexpr (SCORE) ll -= 0.5 * (kLog2Pi + log(sigma) + dv * gd);   // log N(y_o; h.m, sigma)
+      if constexpr (SUMS) ll -= 0.5 * (kLog2Pi + log(sigma) + dv * gd);    // log N(y_o; h.m, sigma)
 #pragma unroll
       for (int a = 0; a < D; ++a) {
         m.a[a] += u.a[a] * gd;
@@ -475,10 +511,10 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
   Mat<double, D> P_s;
   double logdet;
   condition_on_info(m, P, eta, J, m_s, P_s, logdet);  // smoothed last frame of the chunk
-  if constexpr (!SCORE) emit(len - 1, m_s, P_s);
+  if constexpr (!SUMS) emit(len - 1, m_s, P_s);
   DW_STAMP(1, 6);
-  Mat<double, D> Qi;                                  // SCORE: (sQ)^-1
-  if constexpr (SCORE) {
+  Mat<double, D> Qi;                                  // MODE 1: (sQ)^-1
+  if constexpr (MODE == 1) {
     Mat<double, D> eye = mat_zero<double, D>();
 #pragma unroll
     for (int a = 0; a < D; ++a) eye.a[a][a] = 1.0;
@@ -486,7 +522,7 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
   }
   // RTS backwards over the LDS records; SCORE goes one step further, to the filtered belief that entered the
   // chunk (frame t0 - 1): the transition into the chunk's first frame
-  for (int i = len - 2; i >= (SCORE ? -1 : 0); --i) {
+  for (int i = len - 2; i >= (SUMS ? -1 : 0); --i) {
     Vec<double, D> mf;
     Mat<double, D> Pf;
     if (i >= 0) {
@@ -516,7 +552,19 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
 #pragma unroll
     for (int a = 0; a < D; ++a) m_s.a[a] = mf.a[a] + Gdm.a[a];
     P_s = mat_symmetrize(mat_add(Pf, mat_mul(mat_mul_tn(Z, mat_sub(P_s, Pp)), Z)));
-    if constexpr (SCORE) {
+    if constexpr (MODE == 2) {
+      // per coordinate (F = diag a, Q = diag q): E[w^2] and E[w x_i] from the same smoothed moments
+      const Mat<double, D> Cx = mat_mul_tn(Z, P_next);            // Cov(x_i, x_{i+1} | y)
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        const double av = F.a[a][a], iq = rcp(sQ.a[a][a]);
+        const double dwv = m_next.a[a] - av * m_s.a[a];
+        const double ew2 = dwv * dwv + P_next.a[a][a] + av * av * P_s.a[a][a] - 2.0 * av * Cx.a[a][a];
+        const double ewx = dwv * m_s.a[a] + Cx.a[a][a] - av * P_s.a[a][a];
+        sq_sum[a] += 0.5 * iq * (ew2 * iq - 1.0);
+        sa_sum[a] += ewx * iq;
+      }
+    } else if constexpr (MODE == 1) {
       // E[w w^T | y] for w = x_{i+1} - F x_i:  dm dm^T + V_{i+1} + F V_i F^T - F C - (F C)^T,  C = Cov(x_i, x_{i+1}) = Z^T V_{i+1}
       const Vec<double, D> Fm = fid ? m_s : mat_vec(F, m_s);
       Vec<double, D> dw;
@@ -537,17 +585,27 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
     }
   }
   DW_STAMP(1, 7);
-  if constexpr (SCORE) {
-    // the unit's sums in lane order (fixed: the same bits on every run), one pair per (keypoint, block of 64 chunks)
-    if (!live) ll = score = 0.0;
+  if constexpr (SUMS) {
+    // the unit's sums in lane order (fixed: the same bits on every run): planes [sum][block of 64 chunks][keypoint]
+    // = log-likelihood, then the score (MODE 1) or S_q[0..D), S_a[0..D) (MODE 2)
+    constexpr int NS = MODE == 1 ? 2 : 1 + 2 * D;
+    double v[NS];
+    v[0] = ll;
+    if constexpr (MODE == 1) {
+      v[1] = score;
+    } else {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      ll += __shfl_down(ll, off);
-      score += __shfl_down(score, off);
+      for (int a = 0; a < D; ++a) {
+        v[1 + a] = sq_sum[a];
+        v[1 + D + a] = sa_sum[a];
+      }
     }
-    if (lane == 0) {                                  // [block of 64 chunks][keypoint], log-likelihoods then scores
-      part[unit] = ll;
-      part[(size_t)G.K * G.nwb + unit] = score;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      if (!live) v[q] = 0.0;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v[q] += __shfl_down(v[q], off);
+      if (lane == 0) part[(size_t)q * G.K * G.nwb + unit] = v[q];
     }
   }
 }
@@ -564,15 +622,46 @@ size_t dense_wave_workspace_bytes(int T, int K, int D) {
   const size_t nc = ((size_t)T + kDwB - 1) / kDwB, nwb = (nc + 63) / 64;
   const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
   return 2 * align_up(nc * K * nv * 8, 256) + align_up(nwb * K * nv * 8, 256) + align_up((size_t)K * rec * 8, 256) +
-         align_up(nwb * K * 2 * 8, 256);
+         align_up(nwb * K * (1 + 2 * (size_t)D) * 8, 256);   // partial sums: up to 1 + 2 D planes (MODE 2)
 }
 
-// var != nullptr: the smoother (ms, Vs); var == nullptr: SCORE (rconst, nll, dnll)
-static int dense_wave_run(const eks_dims_t& d, const float* y, const float* var, const double* rconst,
-                          const DenseModel& Mm, float* ms, float* Vs, double* nll, double* dnll, void* ws,
-                          size_t ws_bytes, hipStream_t st) {
+// MODE 2: nll[k] = -loglik (no non-finite substitution in the pupil loss, eks/ibl_pupil_smoother.py:551-552),
+// dnll[t][k] = -sum_i (S_q[i] dq[t][k][i] + S_a[i] da[t][k][i]); block = keypoint, the unit sums added in block
+// order by lane 0 of each of the 1 + 2 D sums
+template <int D>
+__global__ __launch_bounds__(64) void dw_ar1_finish_kernel(int K, int nwb, int n_tan, const double* __restrict__ part,
+                                                          const double* __restrict__ da,
+                                                          const double* __restrict__ dq, double* __restrict__ nll,
+                                                          double* __restrict__ dnll) {
+  __shared__ double tot[1 + 2 * D];
+  const int k = blockIdx.x, q = threadIdx.x;
+  if (q < 1 + 2 * D) {
+    double acc = 0.0;
+    for (int wb = 0; wb < nwb; ++wb) acc += part[((size_t)q * nwb + wb) * K + k];
+    tot[q] = acc;
+  }
+  __syncthreads();
+  if (q == 0) nll[k] = -tot[0];
+  if (q < n_tan) {
+    double g = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      const size_t p = ((size_t)q * K + k) * D + i;
+      g += tot[1 + i] * dq[p] + tot[1 + D + i] * da[p];
+    }
+    dnll[(size_t)q * K + k] = -g;
+  }
+}
+
+// mode 0: the smoother (var, ms, Vs); 1: loss + d/d log s (rconst, nll, dnll); 2: pupil loss + tangents
+struct DwAr1 {
+  const double *a, *q, *da, *dq;
+  int n_tan;
+};
+static int dense_wave_run(const eks_dims_t& d, int mode, const float* y, const float* var, const double* rconst,
+                          const DwAr1& ar, const DenseModel& Mm, float* ms, float* Vs, double* nll, double* dnll,
+                          void* ws, size_t ws_bytes, hipStream_t st) {
   const int T = d.n_frames, K = d.n_keypoints, D = d.state_dim, O = d.obs_dim;
-  const bool score = var == nullptr;
   DwGeom G{K, T, (T + kDwB - 1) / kDwB, 0};
   G.nwb = (G.nc + 63) / 64;
   const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
@@ -593,26 +682,26 @@ static int dense_wave_run(const eks_dims_t& d, const float* y, const float* var,
   const int units = K * G.nwb;
   const bool two = units > 256;                       // more (keypoint, 64-chunk) units than CUs: 4-wave workgroups
   const dim3 grid((unsigned)(two ? (units + 1) / 2 : units)), block(two ? 256 : 128);
-#define EKS_DW_S(DD, OO, SS, SC)                                                                         \
+#define EKS_DW_S(DD, OO, SS, MD)                                                                         \
   {                                                                                                      \
     {                                                                                                    \
-      ProfScope ps(SC ? "dense_score_summarize" : "dense_summarize", st);                                \
-      hipLaunchKernelGGL((dw_summarize_kernel<DD, OO, SS, SC>), grid, block, 0, st, G, M, Mm.s, y, var,   \
-                         rconst, pre_ex, suf_ex, agg, first);                                            \
+      ProfScope ps(MD ? "dense_score_summarize" : "dense_summarize", st);                                \
+      hipLaunchKernelGGL((dw_summarize_kernel<DD, OO, SS, MD>), grid, block, 0, st, G, M, Mm.s, y, var,   \
+                         rconst, ar.a, ar.q, pre_ex, suf_ex, agg, first);                                \
     }                                                                                                    \
-    ProfScope ps(SC ? "dense_score_replay" : "dense_replay", st);                                        \
-    hipLaunchKernelGGL((dw_replay_kernel<DD, OO, SS, SC>), grid, block, 0, st, G, M, Mm.s, y, var,        \
-                       rconst, part, pre_ex, suf_ex, agg, first, ms, Vs, vs_diag);                       \
+    ProfScope ps(MD ? "dense_score_replay" : "dense_replay", st);                                        \
+    hipLaunchKernelGGL((dw_replay_kernel<DD, OO, SS, MD>), grid, block, 0, st, G, M, Mm.s, y, var,        \
+                       rconst, ar.a, ar.q, part, pre_ex, suf_ex, agg, first, ms, Vs, vs_diag);           \
   }
 #define EKS_DW(DD, OO)            \
-  if (two && score)               \
-    EKS_DW_S(DD, OO, 2, true)     \
+  if (two && mode == 1)           \
+    EKS_DW_S(DD, OO, 2, 1)        \
   else if (two)                   \
-    EKS_DW_S(DD, OO, 2, false)    \
-  else if (score)                 \
-    EKS_DW_S(DD, OO, 1, true)     \
+    EKS_DW_S(DD, OO, 2, 0)        \
+  else if (mode == 1)             \
+    EKS_DW_S(DD, OO, 1, 1)        \
   else                            \
-    EKS_DW_S(DD, OO, 1, false)
+    EKS_DW_S(DD, OO, 1, 0)
 #define EKS_DW_O(DD)                    \
   switch (O) {                          \
     case 2: EKS_DW(DD, 2) break;        \
@@ -620,6 +709,16 @@ static int dense_wave_run(const eks_dims_t& d, const float* y, const float* var,
     case 6: EKS_DW(DD, 6) break;        \
     case 8: EKS_DW(DD, 8) break;        \
     default: return EKS_ERR_UNSUPPORTED; \
+  }
+  if (mode == 2) {                                    // the pupil shape only (3 states, 4 markers x 2)
+    if (D != 3 || O != 8) return EKS_ERR_UNSUPPORTED;
+    if (two)
+      EKS_DW_S(3, 8, 2, 2)
+    else
+      EKS_DW_S(3, 8, 1, 2)
+    hipLaunchKernelGGL(dw_ar1_finish_kernel<3>, dim3(K), dim3(64), 0, st, K, G.nwb, ar.n_tan, part, ar.da, ar.dq, nll,
+                       dnll);
+    return hip_status(hipGetLastError());
   }
   if (D == 2) {
     EKS_DW_O(2)
@@ -631,21 +730,35 @@ static int dense_wave_run(const eks_dims_t& d, const float* y, const float* var,
 #undef EKS_DW_O
 #undef EKS_DW
 #undef EKS_DW_S
-  if (score) return dense_score_finish(K, G.nwb, part, part + (size_t)K * G.nwb, nll, dnll, st);
+  if (mode == 1) return dense_score_finish(K, G.nwb, part, part + (size_t)K * G.nwb, nll, dnll, st);
   return hip_status(hipGetLastError());
 }
 
 int dense_wave_smooth(const eks_dims_t& d, const float* y, const float* var, const DenseModel& Mm, float* ms,
                       float* Vs, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!var) return EKS_ERR_NULL;
-  return dense_wave_run(d, y, var, nullptr, Mm, ms, Vs, nullptr, nullptr, ws, ws_bytes, st);
+  return dense_wave_run(d, 0, y, var, nullptr, DwAr1{}, Mm, ms, Vs, nullptr, nullptr, ws, ws_bytes, st);
 }
 
 // nll[k], d nll / d log s [k] of the constant-R filter loss at Mm.s[k] (caller: Q positive definite)
 int dense_wave_score(const eks_dims_t& d, const float* y, const double* rconst, const DenseModel& Mm, double* nll,
                      double* dnll, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!rconst || !nll || !dnll) return EKS_ERR_NULL;
-  return dense_wave_run(d, y, nullptr, rconst, Mm, nullptr, nullptr, nll, dnll, ws, ws_bytes, st);
+  return dense_wave_run(d, 1, y, nullptr, rconst, DwAr1{}, Mm, nullptr, nullptr, nll, dnll, ws, ws_bytes, st);
+}
+
+// the pupil loss and its n_tan directional derivatives (eks_ar1_nll; caller: q > 0 in every coordinate)
+bool dense_wave_ar1_covers(int T, int K, int D, int O) {
+  return T >= 2 && D == 3 && O == 8 && dense_wave_covers(T, K, D, O) && !knob_int(KNOB_DENSE_DUAL_GRAD, 0);
+}
+int dense_wave_ar1_score(const eks_dims_t& d, const float* y, const float* var, const double* m0, const double* S0,
+                         const double* C, const double* a, const double* q, const double* da, const double* dq,
+                         int n_tan, double* nll, double* dnll, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!var || !a || !q || !da || !dq || !nll || !dnll) return EKS_ERR_NULL;
+  if (n_tan < 1 || n_tan > 64) return EKS_ERR_UNSUPPORTED;
+  const DenseModel Mm{m0, S0, nullptr, C, nullptr, nullptr};
+  return dense_wave_run(d, 2, y, var, nullptr, DwAr1{a, q, da, dq, n_tan}, Mm, nullptr, nullptr, nll, dnll, ws,
+                        ws_bytes, st);
 }
 
 }  // namespace eks

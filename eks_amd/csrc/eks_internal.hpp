@@ -64,6 +64,10 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
 // narrow sessions: wave-per-64-chunks form (eks_dense_wave.hip)
 bool dense_wave_covers(int T, int K, int D, int O);
 size_t dense_wave_workspace_bytes(int T, int K, int D);
+bool dense_wave_ar1_covers(int T, int K, int D, int O);
+int dense_wave_ar1_score(const eks_dims_t& d, const float* y, const float* var, const double* m0, const double* S0,
+                         const double* C, const double* a, const double* q, const double* da, const double* dq,
+                         int n_tan, double* nll, double* dnll, void* ws, size_t ws_bytes, hipStream_t st);
 int dense_wave_score(const eks_dims_t& d, const float* y, const double* rconst, const DenseModel& M, double* nll,
                      double* dnll, void* ws, size_t ws_bytes, hipStream_t st);
 int dense_wave_smooth(const eks_dims_t& d, const float* y, const float* var, const DenseModel& M, float* ms,

@@ -4,7 +4,12 @@
 namespace eks {
 
 size_t ar1_nll_workspace_bytes(int T, int K, int D, int n_tan) {
-  return loss_workspace_bytes(T, K, D, n_tan > 0 ? n_tan : 1);
+  size_t need = loss_workspace_bytes(T, K, D, n_tan > 0 ? n_tan : 1);
+  if (n_tan > 0 && dense_wave_ar1_covers(T, K, D, 8)) {
+    const size_t w = dense_wave_workspace_bytes(T, K, D);
+    if (w > need) need = w;
+  }
+  return need;
 }
 
 int ar1_nll(const eks_dims_t& d, const float* y, const float* var, const double* m0,
@@ -14,6 +19,11 @@ int ar1_nll(const eks_dims_t& d, const float* y, const float* var, const double*
   const int T = d.n_frames, K = d.n_keypoints, D = d.state_dim, O = d.obs_dim;
   if (D < 1 || D > 6 || O < 1 || O > 64) return EKS_ERR_UNSUPPORTED;
   if (ws_bytes < ar1_nll_workspace_bytes(T, K, D, n_tan)) return EKS_ERR_WORKSPACE;
+  // Process noise positive in every coordinate (the caller's word: EKS_FLAG_Q_PD) on the pupil's shape: loss from
+  // the exact filter inside the smoother's wave kernels, the tangents' derivatives from the smoothing distribution
+  // (eks_dense_wave.hip, MODE 2) instead of dual-number elements.
+  if (n_tan > 0 && (d.flags & EKS_FLAG_Q_PD) && dense_wave_ar1_covers(T, K, D, O))
+    return dense_wave_ar1_score(d, y, var, m0, S0, C, a, q, da, dq, n_tan, nll, dnll, ws, ws_bytes, st);
   const int ns = n_tan > 0 ? n_tan : 1;
   if ((long)K * ns > 65535) return EKS_ERR_UNSUPPORTED;
   LossGeom G{K, T, O, loss_chunk(T, K * ns), 0, ns};

@@ -299,7 +299,11 @@ class Ar1Loss:
     C (K, O, D) float64.  `a`, `q` (K, D) and the tangents `da`, `dq` (n_tan, K, D) are device
     buffers owned here that the caller (or eks_pupil_adam_step) fills before `evaluate()`."""
 
-    def __init__(self, y, var, m0, S0, C, n_tan: int = 2):
+    def __init__(self, y, var, m0, S0, C, n_tan: int = 2, positive_noise: bool = False):
+        """positive_noise: the caller guarantees q > 0 in every coordinate for every evaluation (the pupil model:
+        q = latent_var (1 - s^2) with s < 1, so latent_var > 0) - EKS_FLAG_Q_PD: on the pupil's shape the tangents'
+        derivatives then come from the smoothing distribution inside the smoother's wave kernels instead of
+        dual numbers."""
         self.lib = _lib.load()
         T, K, O = y.shape
         D = m0.shape[-1]
@@ -317,7 +321,7 @@ class Ar1Loss:
         self.dq = torch.zeros((max(n_tan, 1), K, D), **f64)
         self.nll = torch.empty(K, **f64)
         self.dnll = torch.empty((max(n_tan, 1), K), **f64)
-        self.dims = _dims(K, T, D, O, 0)
+        self.dims = _dims(K, T, D, O, FLAG_Q_PD if positive_noise else 0)
         self.ws = _workspace(self.lib.eks_ar1_nll_workspace_bytes(ctypes.byref(self.dims), self.n_tan),
                              dev)
 

@@ -217,7 +217,8 @@ def _optimize_on_device(P: _PupilProblem, s_frames, lr, tol, safety_cap, sync_ev
     Returns (s_d, s_c, info)."""
     torch = _torch()
     y_c, var_c = P.cropped(s_frames)
-    loss = hip_ops.Ar1Loss(y_c, var_c, P.m0, P.S0, P.C, n_tan=2)
+    loss = hip_ops.Ar1Loss(y_c, var_c, P.m0, P.S0, P.C, n_tan=2,
+                           positive_noise=bool(np.all(np.asarray(P.latent_vars) > 0.0)))
     s0 = np.array([0.99, 0.98], dtype=np.float32).astype(np.float64)     # :561-562
     state = np.zeros((1, 9))
     state[0, 0:2] = np.log(s0 / (1.0 - s0))

@@ -30,7 +30,7 @@ def gold(golden_dir):
     return g, src['markers'][:, :, :, g['order']], str(src['scorer'])
 
 
-def _loss(ys_list, ev_list, m0_list, S0_list, n_tan):
+def _loss(ys_list, ev_list, m0_list, S0_list, n_tan, positive_noise=False):
     """Ar1Loss over K independent chains of equal length."""
     import torch
     from eks_amd import hip_ops
@@ -41,7 +41,7 @@ def _loss(ys_list, ev_list, m0_list, S0_list, n_tan):
     m0 = torch.as_tensor(np.stack(m0_list), device=dev)
     S0 = torch.as_tensor(np.stack(S0_list), device=dev)
     C = torch.as_tensor(np.tile(orc.PUPIL_C, (K, 1, 1)), device=dev)
-    return hip_ops.Ar1Loss(y, var, m0, S0, C, n_tan=n_tan)
+    return hip_ops.Ar1Loss(y, var, m0, S0, C, n_tan=n_tan, positive_noise=positive_noise)
 
 
 def _fill(loss, us, lvs):
@@ -64,14 +64,16 @@ def _fill(loss, us, lvs):
         loss.dq.copy_(torch.as_tensor(dq))
 
 
+@pytest.mark.parametrize('positive_noise', [False, True])     # dual numbers / smoothing-distribution derivatives
 @pytest.mark.parametrize('T', [1, 2, 7, 64, 1000, 5003])
-def test_ar1_nll_and_sensitivities_match_oracle(T):
+def test_ar1_nll_and_sensitivities_match_oracle(T, positive_noise):
     probs = [synth_pupil(T, seed=10 + k) for k in range(3)]
     for p in probs:                                   # T = 1: the variance over one frame is 0
         p[3][np.diag_indices(3)] = np.maximum(np.diag(p[3]), 0.3)
     lvs = [np.maximum(p[4], 0.3) for p in probs]
     us = [(4.6, 3.9), (0.5, -1.0), (-2.0, 6.0)]
-    loss = _loss([p[0] for p in probs], [p[1] for p in probs], [p[2] for p in probs], [p[3] for p in probs], 2)
+    loss = _loss([p[0] for p in probs], [p[1] for p in probs], [p[2] for p in probs], [p[3] for p in probs], 2,
+                 positive_noise=positive_noise)
     _fill(loss, us, lvs)
     nll, dnll = loss.evaluate()
     nll, dnll = nll.cpu().numpy(), dnll.cpu().numpy()
@@ -85,10 +87,11 @@ def test_ar1_nll_and_sensitivities_match_oracle(T):
     np.testing.assert_allclose(loss0.evaluate()[0].cpu().numpy(), nll, rtol=1e-12)
 
 
-def test_ar1_nll_on_golden_probe_points(gold):
+@pytest.mark.parametrize('positive_noise', [False, True])
+def test_ar1_nll_on_golden_probe_points(gold, positive_noise):
     g, mk, _ = gold
     arrs = orc.pupil_arrays(mk)
-    loss = _loss([arrs['ys']], [arrs['ensemble_vars']], [arrs['m0']], [arrs['S0']], 2)
+    loss = _loss([arrs['ys']], [arrs['ensemble_vars']], [arrs['m0']], [arrs['S0']], 2, positive_noise=positive_noise)
     y32 = arrs['ys'].astype(np.float32).astype(np.float64)      # what the device buffers hold
     v32 = arrs['ensemble_vars'].astype(np.float32).astype(np.float64)
     for u, L, gr in zip(g['probe_u'], g['probe_nll'], g['probe_grad']):

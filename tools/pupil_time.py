@@ -19,13 +19,11 @@ for T in (2000, 20000, 200000):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     out = ips.run_pupil_kalman_smoother(ys, m0, S0, ips.PUPIL_C, ev, *lv, smooth_params=[s_d, s_c])
     torch.cuda.synchronize(); print(f'   smooth (incl. H2D/D2H) {(time.perf_counter()-t0)*1e3:.1f} ms', flush=True)
-    loss = hip_ops.Ar1Loss(P.y, P.var, P.m0, P.S0, P.C, n_tan=2)
-    loss.a.copy_(torch.tensor([[s_d, s_c, s_c]])); loss.q.copy_(torch.as_tensor(lv[None] * (1 - np.array([s_d, s_c, s_c]) ** 2)))
-    hip_ops._lib.load().eks_profile_enable(1)
-    for _ in range(20): loss.evaluate()
-    torch.cuda.synchronize()
-    import ctypes
-    names = ctypes.create_string_buffer(1 << 16); ms = (ctypes.c_float * 4096)()
-    n = hip_ops._lib.load().eks_profile_drain(names, len(names), ms, 4096)
-    hip_ops._lib.load().eks_profile_enable(0)
-    print(f'   ar1_nll kernels (value + 2 tangents): {np.mean(list(ms)[:n])*1e3:.1f} us', flush=True)
+    for pos, what in ((False, 'dual numbers'), (True, 'smoothing-distribution derivatives')):
+        loss = hip_ops.Ar1Loss(P.y, P.var, P.m0, P.S0, P.C, n_tan=2, positive_noise=pos)
+        loss.a.copy_(torch.tensor([[s_d, s_c, s_c]])); loss.q.copy_(torch.as_tensor(lv[None] * (1 - np.array([s_d, s_c, s_c]) ** 2)))
+        for _ in range(5): loss.evaluate()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(50): loss.evaluate()
+        torch.cuda.synchronize()
+        print(f'   eks_ar1_nll (value + 2 tangents), {what}: {(time.perf_counter()-t0)/50*1e6:.1f} us', flush=True)
