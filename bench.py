@@ -334,7 +334,7 @@ def bench_pupil(args, T, dev, lib):
     from eks_amd import ibl_pupil_smoother as ips
     ys, ev, m0, S0, lv = synth.pupil_observations(T, seed=1)
     P = ips._PupilProblem(ys, m0, S0, ips.PUPIL_C, ev, lv)
-    loss = hip_ops.Ar1Loss(P.y, P.var, P.m0, P.S0, P.C, n_tan=2)
+    loss = hip_ops.Ar1Loss(P.y, P.var, P.m0, P.S0, P.C, n_tan=2, positive_noise=bool(np.all(lv > 0)))   # as the driver does
     state = np.zeros((1, 9))
     state[0, 0:2] = np.log(np.array([0.99, 0.98]) / (1 - np.array([0.99, 0.98])))
     state[0, 6] = np.inf
