@@ -613,7 +613,10 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
 // ------------------------------------------------------------------------------------------------------
 bool dense_wave_covers(int T, int K, int D, int O) {
   if (knob_int(KNOB_DENSE_LEGACY, 0)) return false;
-  if (!(D == 2 || D == 3) || !(O == 2 || O == 4 || O == 6 || O == 8)) return false;
+  // D = 2, 3 with up to four cameras; five and six cameras (O = 10, 12: the reference's fly rig run without a
+  // calibration) for D = 3, one wave pair per workgroup (their rows take 2 x 24 KB of LDS per pair)
+  if (!(((D == 2 || D == 3) && (O == 2 || O == 4 || O == 6 || O == 8)) || (D == 3 && (O == 10 || O == 12))))
+    return false;
   const long nc = ((long)T + kDwB - 1) / kDwB, nwb = (nc + 63) / 64;
   return (long)K * nwb <= 1024;                       // depth-bound problems: every block resident at once
 }
@@ -680,7 +683,7 @@ static int dense_wave_run(const eks_dims_t& d, int mode, const float* y, const f
   const DenseModelPtrs M{Mm.m0, Mm.S0, Mm.A, Mm.C, Mm.Q};
   const int vs_diag = (d.flags & EKS_FLAG_VS_DIAG) ? 1 : 0;
   const int units = K * G.nwb;
-  const bool two = units > 256;                       // more (keypoint, 64-chunk) units than CUs: 4-wave workgroups
+  const bool two = units > 256 && O <= 8;             // more (keypoint, 64-chunk) units than CUs: 4-wave workgroups
   const dim3 grid((unsigned)(two ? (units + 1) / 2 : units)), block(two ? 256 : 128);
 #define EKS_DW_S(DD, OO, SS, MD)                                                                         \
   {                                                                                                      \
@@ -710,6 +713,11 @@ static int dense_wave_run(const eks_dims_t& d, int mode, const float* y, const f
     case 8: EKS_DW(DD, 8) break;        \
     default: return EKS_ERR_UNSUPPORTED; \
   }
+#define EKS_DW1(DD, OO)           \
+  if (mode == 1)                  \
+    EKS_DW_S(DD, OO, 1, 1)        \
+  else                            \
+    EKS_DW_S(DD, OO, 1, 0)
   if (mode == 2) {                                    // the pupil shape only (3 states, 4 markers x 2)
     if (D != 3 || O != 8) return EKS_ERR_UNSUPPORTED;
     if (two)
@@ -722,11 +730,16 @@ static int dense_wave_run(const eks_dims_t& d, int mode, const float* y, const f
   }
   if (D == 2) {
     EKS_DW_O(2)
+  } else if (D == 3 && O == 10) {
+    EKS_DW1(3, 10)
+  } else if (D == 3 && O == 12) {
+    EKS_DW1(3, 12)
   } else if (D == 3) {
     EKS_DW_O(3)
   } else {
     return EKS_ERR_UNSUPPORTED;
   }
+#undef EKS_DW1
 #undef EKS_DW_O
 #undef EKS_DW
 #undef EKS_DW_S

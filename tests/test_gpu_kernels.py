@@ -235,6 +235,8 @@ def _dense_problem(T, K, D, O, seed):
     (7, 5, 2, 6, False),         # one ragged 8-frame chunk
     (9, 4, 3, 2, False),         # two chunks, the second of one frame
     (513, 2, 3, 4, True),        # 65 chunks: two 64-chunk units per keypoint, the second nearly empty
+    (400, 2, 3, 12, False),      # six cameras (the fly rig without a calibration): the narrow kernels' widest rows
+    (257, 3, 3, 10, True),       # five cameras, 8-byte row pieces
 ])
 def test_smooth_dense_matches_oracle(T, K, D, O, general_A):
     from eks_amd import hip_ops
@@ -524,7 +526,8 @@ def test_nll_dense_matches_oracle(T, K, D, O):
                                                (9, 2, 3, 8, False), (2, 3, 2, 6, False), (20000, 4, 3, 4, False),
                                                # wide sessions: the keypoint-major kernels' SCORE form
                                                (600, 1500, 3, 4, False), (1100, 700, 2, 6, True), (70, 1100, 3, 8, True),
-                                               (3, 1300, 2, 2, False)])
+                                               (3, 1300, 2, 2, False),
+                                               (700, 3, 3, 12, False), (300, 2, 3, 10, True)])   # five / six cameras
 def test_nll_dense_score_gradient_matches_oracle_and_dual_numbers(T, K, D, O, general_A):
     """EKS_FLAG_Q_PD: value from the exact filter inside the smoother's kernels, gradient from the smoothing
     distribution (Fisher's identity; SCORE forms of eks_dense_wave.hip and eks_dense_wide.hip) - against the oracle's forward-mode gradient
