@@ -183,7 +183,7 @@ __global__ __launch_bounds__(2 * kDenseCB) void dense_scan_blocks_kernel(DenseGe
   }
 }
 
-template <int D, bool EKF, typename Obs>
+template <int D, bool EKF, typename Obs, bool SCORE = false>
 __global__ __launch_bounds__(64) void dense_replay_kernel(DenseGeom G, DenseModelPtrs M,
                                                          const double* __restrict__ s, Obs obs,
                                                          const double* __restrict__ pre,
@@ -229,10 +229,14 @@ __global__ __launch_bounds__(64) void dense_replay_kernel(DenseGeom G, DenseMode
   if (j == 0) load_prior<D>(M, k, m, P);   // chunk 0 replays frame 0's update of the prior itself
   const int t0 = j * G.B, len = min(G.B, G.T - t0);
   double ll = 0.0, ch = 0.0;
-  dense_replay_chunk_obs<D, EKF>(obs, G.K, k, t0, len, F, sQ, fid, m, P, eta, J,
-                                 filt ? filt + (size_t)t0 * REC * G.K + k : nullptr, ms, Vs,
-                                 vs_diag != 0, EKF ? xlin + ((size_t)k * G.T + t0) * D : nullptr, &ll,
-                                 &ch, (size_t)G.K);
+  dense_replay_chunk_obs<D, EKF, Obs, SCORE>(obs, G.K, k, t0, len, F, sQ, fid, m, P, eta, J,
+                                             filt ? filt + (size_t)t0 * REC * G.K + k : nullptr, ms, Vs,
+                                             vs_diag != 0, EKF ? xlin + ((size_t)k * G.T + t0) * D : nullptr, &ll,
+                                             &ch, (size_t)G.K);
+  if constexpr (SCORE) {                 // per-chunk partial sums, [chunk][keypoint]: ll_chunk, then resid as the score
+    ll_chunk[idx] = ll;
+    resid[idx] = ch;
+  }
   if constexpr (EKF) {
     ll_chunk[idx] = ll;
     // non-negative doubles order like their bit patterns; a NaN (diverged linearisation) has the
@@ -407,8 +411,8 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
 // wider ones the keypoint-major kernels with the per-lane scan; other shapes have no SCORE form (the caller keeps
 // the dual-number kernels of eks_loss.hip).
 bool dense_score_covers(int T, int K, int D, int O) {
-  if (T < 2 || knob_int(KNOB_DENSE_LEGACY, 0) || knob_int(KNOB_DENSE_DUAL_GRAD, 0)) return false;
-  return dense_path(T, K, D, O) != kDenseGeneric;
+  (void)K;
+  return T >= 2 && D >= 1 && D <= 6 && O >= 1 && O <= 64 && !knob_int(KNOB_DENSE_DUAL_GRAD, 0);
 }
 size_t dense_score_workspace_bytes(int T, int K, int D, int O) { return dense_smooth_workspace_bytes(T, K, D, O); }
 int dense_score(const eks_dims_t& d, const float* y, const double* rconst, const DenseModel& Mm, double* nll,
@@ -416,9 +420,60 @@ int dense_score(const eks_dims_t& d, const float* y, const double* rconst, const
   const int T = d.n_frames, K = d.n_keypoints, D = d.state_dim, O = d.obs_dim;
   if (!dense_score_covers(T, K, D, O)) return EKS_ERR_UNSUPPORTED;
   if (ws_bytes < dense_score_workspace_bytes(T, K, D, O)) return EKS_ERR_WORKSPACE;
-  if (dense_path(T, K, D, O) == kDenseWave) return dense_wave_score(d, y, rconst, Mm, nll, dnll, ws, ws_bytes, st);
+  const DensePath path = dense_path(T, K, D, O);
+  if (path == kDenseWave) return dense_wave_score(d, y, rconst, Mm, nll, dnll, ws, ws_bytes, st);
   const int B = dense_chunk(T, K), nc = (T + B - 1) / B;
   const DenseModelPtrs M{Mm.m0, Mm.S0, Mm.A, Mm.C, Mm.Q};
+  if (path == kDenseGeneric) {
+    // any D <= 6, O <= 64: the generic kernels with constant variances (layout of dense_smooth: prefix / suffix
+    // elements per chunk, the filtered-belief stream; per-chunk partial sums where the chunk elements were - they
+    // are dead once the scan has run)
+    DenseGeom G{K, T, O, B, nc, B, nc};
+    const int nblk = (nc + kDenseCB - 1) / kDenseCB;
+    const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
+    char* p = static_cast<char*>(ws);
+    double* elems = reinterpret_cast<double*>(p);
+    p += align_up((size_t)nc * K * nv * 8, 256);
+    double* pre = reinterpret_cast<double*>(p);
+    p += align_up((size_t)nc * K * nv * 8, 256);
+    double* suf = reinterpret_cast<double*>(p);
+    p += align_up((size_t)nc * K * nv * 8, 256);
+    double* agg = reinterpret_cast<double*>(p);
+    p += align_up((size_t)nblk * K * nv * 8, 256);
+    double* bprior = reinterpret_cast<double*>(p);
+    p += align_up((size_t)nblk * K * rec * 8, 256);
+    double* bsuffix = reinterpret_cast<double*>(p);
+    p += align_up((size_t)nblk * K * rec * 8, 256);
+    double* filt = reinterpret_cast<double*>(p);
+    p += align_up((size_t)T * K * rec * 8, 256);
+    double* first = reinterpret_cast<double*>(p);
+    double* part_ll = elems;
+    double* part_score = elems + (size_t)nc * K;
+    const int lanes = K * nc;
+    const Gate open{nullptr, 0.0};
+    EKS_DISPATCH_D(D, {
+      const ConstLinearObs<DD> obs = make_const_linear_obs<DD>(y, rconst, K, O, M);
+      {
+        ProfScope ps("dense_score_summarize", st);
+        hipLaunchKernelGGL((dense_summarize_kernel<DD, ConstLinearObs<DD>>), dim3((lanes + 63) / 64), dim3(64), 0, st,
+                           G, M, Mm.s, obs, elems, first, open);
+      }
+      {
+        ProfScope ps("dense_score_scan", st);
+        hipLaunchKernelGGL(dense_scan_kernel<DD>, dim3(K, nblk), dim3(2 * kDenseCB), 0, st, G, elems, pre, suf, agg,
+                           open);
+        hipLaunchKernelGGL(dense_scan_blocks_kernel<DD>, dim3(K), dim3(2 * kDenseCB), 0, st, G, nblk, first, agg,
+                           bprior, bsuffix, open);
+      }
+      ProfScope ps("dense_score_replay", st);
+      hipLaunchKernelGGL((dense_replay_kernel<DD, false, ConstLinearObs<DD>, true>), dim3((lanes + 63) / 64), dim3(64),
+                         0, st, G, M, Mm.s, obs, pre, suf, bprior, bsuffix, filt, nullptr, nullptr, 0, nullptr,
+                         part_ll, part_score, open);
+    })
+    const int rc0 = hip_status(hipGetLastError());
+    if (rc0 != EKS_OK) return rc0;
+    return dense_score_finish(K, nc, part_ll, part_score, nll, dnll, st);
+  }
   const RunsLayout L = runs_layout(K, D, nc, static_cast<char*>(ws));
   int rc;
   {

@@ -174,6 +174,25 @@ EKS_HD LinearObs<D> make_linear_obs(const float* y, const float* var, int K, int
   return LinearObs<D>{y, var, K, O, M};
 }
 
+// the same with the keypoint's CONSTANT variances (the optimiser's loss, eks/core.py:602, :702-709)
+template <int D>
+struct ConstLinearObs {
+  const float* y;           // [T][K][O]
+  const double* rconst;     // [K][O]
+  int K, O;
+  DenseModelPtrs M;
+  template <typename Fn>
+  EKS_HD void visit(int t, int k, const double* /*xl*/, Fn&& fn) const {
+    const size_t row = ((size_t)t * K + k) * O;
+    for (int o = 0; o < O; ++o) fn(load_obs_row<double, D>(M, k, O, o), (double)y[row + o], rconst[(size_t)k * O + o]);
+  }
+};
+template <int D>
+EKS_HD ConstLinearObs<D> make_const_linear_obs(const float* y, const double* rconst, int K, int O,
+                                               const DenseModelPtrs& M) {
+  return ConstLinearObs<D>{y, rconst, K, O, M};
+}
+
 struct PinholeObs {
   const float* y;           // [T][Kd][O], O = 2 * n_cams: (u, v) per camera
   ObsNoise R;               // [T][Kd][O] or constant [Kd][O]
@@ -268,7 +287,10 @@ EKS_HD DElem<double, D> dense_smooth_element(const float* __restrict__ y, const 
 // (what the reference's dynamax filter does), the predicted mean replaces the
 // stored linearisation point and the largest change is returned through `resid`; `ll` receives
 // the chunk's log-likelihood.  ms == nullptr: filter only (no records, no backward pass).
-template <int D, bool EKF, typename Obs>
+// SCORE (linear observations): no outputs; `ll_out` receives the chunk's log-likelihood and `resid_out` its
+// share of d loglik / d log s by Fisher's identity (eks_dense_wave.hip has the formula), including the
+// transition into the chunk's first frame.
+template <int D, bool EKF, typename Obs, bool SCORE = false>
 EKS_HD void dense_replay_chunk_obs(const Obs& obs, int K, int k, int t0, int len,
                                    const Mat<double, D>& F, const Mat<double, D>& sQ,
                                    bool f_identity, Vec<double, D> m, Mat<double, D> P,
@@ -276,6 +298,8 @@ EKS_HD void dense_replay_chunk_obs(const Obs& obs, int K, int k, int t0, int len
                                    double* __restrict__ filt, float* __restrict__ ms,
                                    float* __restrict__ Vs, bool vs_diag, double* __restrict__ xlin,
                                    double* ll_out, double* resid_out, size_t fs = 1) {
+  const Vec<double, D> m_in = m;
+  const Mat<double, D> P_in = P;
   // fs: distance in doubles between consecutive fields of the scratch records (1: a lane's records are
   // contiguous; K: the records of the K keypoints are interleaved field by field, so the lanes of a wave -
   // consecutive keypoints - read and write whole segments.  Per-lane contiguous records cost the wide
@@ -308,10 +332,12 @@ EKS_HD void dense_replay_chunk_obs(const Obs& obs, int K, int k, int t0, int len
         xlin[a + (size_t)i * D] = xl[a];
       }
       ll += belief_update_obs<D, true>(obs, k, t, xl, m, P);
+    } else if constexpr (SCORE) {
+      ll += belief_update_obs<D, true>(obs, k, t, nullptr, m, P);
     } else {
       belief_update_obs<D>(obs, k, t, nullptr, m, P);
     }
-    if (ms == nullptr) continue;
+    if (!SCORE && ms == nullptr) continue;
     double* rec = filt + (size_t)i * REC * fs;
 #pragma unroll
     for (int a = 0; a < D; ++a) {
@@ -324,8 +350,9 @@ EKS_HD void dense_replay_chunk_obs(const Obs& obs, int K, int k, int t0, int len
     *ll_out = ll;
     *resid_out = resid;
   }
-  if (ms == nullptr) return;
+  if (!SCORE && ms == nullptr) return;
   auto emit = [&](int i, const Vec<double, D>& mo, const Mat<double, D>& Po) {
+    if constexpr (SCORE) return;
     const size_t ko = (size_t)(t0 + i) * K + k;
 #pragma unroll
     for (int a = 0; a < D; ++a) EKS_STREAM_STORE(ms + ko * D + a, (float)mo.a[a]);
@@ -344,16 +371,32 @@ EKS_HD void dense_replay_chunk_obs(const Obs& obs, int K, int k, int t0, int len
   double logdet;
   condition_on_info(m, P, eta_s, J_s, m_s, P_s, logdet);      // smoothed last frame of the chunk
   emit(len - 1, m_s, P_s);
-  for (int i = len - 2; i >= 0; --i) {
-    const double* rec = filt + (size_t)i * REC * fs;
+  Mat<double, D> Qi;                                          // SCORE: (sQ)^-1
+  double score = 0.0;
+  if constexpr (SCORE) {
+    Mat<double, D> eye = mat_zero<double, D>();
+#pragma unroll
+    for (int a = 0; a < D; ++a) eye.a[a][a] = 1.0;
+    Qi = chol_solve_mat(chol_factor(sQ), eye);
+  }
+  for (int i = len - 2; i >= (SCORE ? -1 : 0); --i) {
     Vec<double, D> mf;
     Mat<double, D> Pf;
+    if (i >= 0) {
+      const double* rec = filt + (size_t)i * REC * fs;
 #pragma unroll
-    for (int a = 0; a < D; ++a) {
-      mf.a[a] = rec[a * fs];
+      for (int a = 0; a < D; ++a) {
+        mf.a[a] = rec[a * fs];
 #pragma unroll
-      for (int b = 0; b < D; ++b) Pf.a[a][b] = rec[(D + a * D + b) * fs];
+        for (int b = 0; b < D; ++b) Pf.a[a][b] = rec[(D + a * D + b) * fs];
+      }
+    } else {                                                  // SCORE: back to the belief that entered the chunk
+      if (t0 == 0 || len == 0) break;
+      mf = m_in;
+      Pf = mat_symmetrize(P_in);
     }
+    const Vec<double, D> m_next = m_s;
+    const Mat<double, D> P_next = P_s;
     const Mat<double, D> FP = f_identity ? Pf : mat_mul(F, Pf);                 // F Pf
     const Mat<double, D> Pp = mat_symmetrize(
         mat_add(f_identity ? Pf : mat_mul_nt(FP, F), sQ));                      // F Pf F^T + sQ
@@ -368,7 +411,28 @@ EKS_HD void dense_replay_chunk_obs(const Obs& obs, int K, int k, int t0, int len
     // P_s = Pf + G (P_s - Pp) G^T,  G = Z^T
     const Mat<double, D> dP = mat_sub(P_s, Pp);
     P_s = mat_symmetrize(mat_add(Pf, mat_mul(mat_mul_tn(Z, dP), Z)));
-    emit(i, m_s, P_s);
+    if constexpr (SCORE) {
+      const Vec<double, D> Fm = f_identity ? m_s : mat_vec(F, m_s);
+      Vec<double, D> dw;
+#pragma unroll
+      for (int a = 0; a < D; ++a) dw.a[a] = m_next.a[a] - Fm.a[a];
+      const Mat<double, D> Cx = mat_mul_tn(Z, P_next);        // Cov(x_i, x_{i+1} | y)
+      const Mat<double, D> FC = f_identity ? Cx : mat_mul(F, Cx);
+      const Mat<double, D> FVF = f_identity ? P_s : mat_mul_nt(mat_mul(F, P_s), F);
+      double tr = 0.0;
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b)
+          tr += Qi.a[a][b] * (dw.a[a] * dw.a[b] + P_next.a[a][b] + FVF.a[a][b] - FC.a[a][b] - FC.a[b][a]);
+      score += 0.5 * (tr - (double)D);
+    } else {
+      emit(i, m_s, P_s);
+    }
+  }
+  if constexpr (SCORE) {
+    *ll_out = ll;
+    *resid_out = score;
   }
 }
 

@@ -527,7 +527,10 @@ def test_nll_dense_matches_oracle(T, K, D, O):
                                                # wide sessions: the keypoint-major kernels' SCORE form
                                                (600, 1500, 3, 4, False), (1100, 700, 2, 6, True), (70, 1100, 3, 8, True),
                                                (3, 1300, 2, 2, False),
-                                               (700, 3, 3, 12, False), (300, 2, 3, 10, True)])   # five / six cameras
+                                               (700, 3, 3, 12, False), (300, 2, 3, 10, True),    # five / six cameras
+                                               # no specialised kernels: the generic ones in their SCORE form
+                                               (600, 3, 4, 8, False), (257, 2, 5, 8, True), (100, 2, 6, 8, False),
+                                               (400, 3, 3, 5, False), (64, 2, 1, 3, False), (900, 40, 4, 6, True)])
 def test_nll_dense_score_gradient_matches_oracle_and_dual_numbers(T, K, D, O, general_A):
     """EKS_FLAG_Q_PD: value from the exact filter inside the smoother's kernels, gradient from the smoothing
     distribution (Fisher's identity; SCORE forms of eks_dense_wave.hip and eks_dense_wide.hip) - against the oracle's forward-mode gradient
