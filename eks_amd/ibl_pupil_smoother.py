@@ -227,13 +227,26 @@ def _optimize_on_device(P: _PupilProblem, s_frames, lr, tol, safety_cap, sync_ev
     latent = torch.as_tensor(P.latent_vars[None], device=P.dev)
     n_active = torch.zeros(1, dtype=torch.int32, device=P.dev)
     hip_ops.pupil_adam_step(loss, latent, state, n_active, lr, tol, safety_cap, init=True)
-    launched = 0
-    while launched < int(safety_cap):
-        n = min(sync_every, int(safety_cap) - launched)
+    # The running count after round r is copied to pinned memory behind round r and read only after round r + 1
+    # has been enqueued (steps enqueued after convergence leave the state untouched): the device never waits for
+    # the host's answer (core._optimize_on_device does the same).
+    from .core import _pinned_empty
+    cap = int(safety_cap)
+    snap = _pinned_empty((max((cap + sync_every - 1) // sync_every, 1),), torch.int32)
+    launched, r, pending = 0, 0, None
+    while launched < cap:
+        n = min(sync_every, cap - launched)
         hip_ops.pupil_adam_run(loss, latent, state, n_active, lr, tol, safety_cap, n)
         launched += n
-        if int(n_active.item()) == 0:
-            break
+        snap[r:r + 1].copy_(n_active, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        if pending is not None:
+            pending[1].synchronize()
+            if int(snap[pending[0]]) == 0:
+                break
+        pending = (r, ev)
+        r += 1
     st = state.cpu().numpy()[0]
     s = _to_stable_s(st[0:2])
     return float(s[0]), float(s[1]), dict(iters=int(st[7]), last_loss=float(st[6]),
