@@ -136,7 +136,9 @@ int eks_adam_run(const eks_dims_t* dims, const float* y, const double* rconst, c
  * process noise diag(q[k][:]), observation matrix C [K][O][D], TIME-VARYING R_t = diag(max(var,
  * 1e-12)) also in the loss (:514-518).  eks_ar1_nll: nll[k] = -marginal_loglik of the filter
  * (_nll_from_u, :540-552); with n_tan > 0, dnll[i][k] = derivative of nll[k] along the tangent
- * (da[i][k][:], dq[i][k][:]) - forward sensitivities replacing jax.value_and_grad (:570).  The
+ * (da[i][k][:], dq[i][k][:]) - forward sensitivities replacing jax.value_and_grad (:570); with
+ * EKS_FLAG_Q_PD (q > 0 in every coordinate) on the pupil's shape D = 3, O = 8 the same derivatives
+ * come from the smoothing distribution inside the smoother's kernels.  The
  * final smoothing pass is eks_smooth with A = diag(a), Q = diag(q), s = 1 (:427-445). -------- */
 size_t eks_ar1_nll_workspace_bytes(const eks_dims_t* dims, int32_t n_tan);
 int eks_ar1_nll(const eks_dims_t* dims, const float* y, const float* var, const double* m0,
