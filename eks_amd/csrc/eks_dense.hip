@@ -300,17 +300,39 @@ static RunsLayout runs_layout(int K, int D, int nc, char* base) {
   return L;
 }
 
+struct GenericLayout {     // chunk elements, their inclusive prefix / suffix per chunk, block aggregates and
+  double *elems, *pre, *suf, *agg, *bprior, *bsuffix, *filt, *first;   // boundaries, the filtered-belief stream
+  size_t bytes;
+};
+static GenericLayout generic_layout(int T, int K, int D, int nc, char* base) {
+  const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
+  const size_t nblk = (nc + kDenseCB - 1) / kDenseCB;
+  GenericLayout L;
+  size_t off = 0;
+  auto take = [&](size_t doubles) {
+    double* p = reinterpret_cast<double*>(base + off);
+    off += align_up(doubles * 8, 256);
+    return p;
+  };
+  L.elems = take((size_t)nc * K * nv);
+  L.pre = take((size_t)nc * K * nv);
+  L.suf = take((size_t)nc * K * nv);
+  L.agg = take(nblk * K * nv);
+  L.bprior = take(nblk * K * rec);
+  L.bsuffix = take(nblk * K * rec);
+  L.filt = take((size_t)T * K * rec);
+  L.first = take((size_t)K * rec);
+  L.bytes = off;
+  return L;
+}
+
 size_t dense_smooth_workspace_bytes(int T, int K, int D, int O) {
-  const int B = dense_chunk(T, K), nc = (T + B - 1) / B, nblk = (nc + kDenseCB - 1) / kDenseCB;
+  const int B = dense_chunk(T, K), nc = (T + B - 1) / B;
   switch (dense_path(T, K, D, O)) {
     case kDenseWave: return dense_wave_workspace_bytes(T, K, D);
     case kDenseRuns: return runs_layout(K, D, nc, nullptr).bytes;
-    default: break;
+    default: return generic_layout(T, K, D, nc, nullptr).bytes;
   }
-  const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
-  return 3 * align_up((size_t)nc * K * nv * 8, 256) +
-         align_up((size_t)nblk * K * nv * 8, 256) + 2 * align_up((size_t)nblk * K * rec * 8, 256) +
-         align_up((size_t)T * K * rec * 8, 256) + align_up((size_t)K * rec * 8, 256);
 }
 
 int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const DenseModel& Mm,
@@ -346,23 +368,9 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
     return dense_wide_replay(T, K, D, O, G.B, G.nc, M, Mm.s, y, var, nullptr, nullptr, nullptr, nullptr, nullptr,
                              nullptr, nullptr, L.chunk_in, L.chunk_out, ms, Vs, vs_diag, st);
   }
-  const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
-  char* p = static_cast<char*>(ws);
-  double* elems = reinterpret_cast<double*>(p);
-  p += align_up((size_t)G.nc * K * nv * 8, 256);
-  double* pre = reinterpret_cast<double*>(p);       // inclusive prefix / suffix elements per chunk
-  p += align_up((size_t)G.nc * K * nv * 8, 256);
-  double* suf = reinterpret_cast<double*>(p);
-  p += align_up((size_t)G.nc * K * nv * 8, 256);
-  double* agg = reinterpret_cast<double*>(p);
-  p += align_up((size_t)nblk * K * nv * 8, 256);
-  double* bprior = reinterpret_cast<double*>(p);
-  p += align_up((size_t)nblk * K * rec * 8, 256);
-  double* bsuffix = reinterpret_cast<double*>(p);
-  p += align_up((size_t)nblk * K * rec * 8, 256);
-  double* filt = reinterpret_cast<double*>(p);
-  p += align_up((size_t)T * K * rec * 8, 256);
-  double* first = reinterpret_cast<double*>(p);
+  const GenericLayout L = generic_layout(T, K, D, G.nc, static_cast<char*>(ws));
+  double *elems = L.elems, *pre = L.pre, *suf = L.suf, *agg = L.agg, *bprior = L.bprior, *bsuffix = L.bsuffix,
+         *filt = L.filt, *first = L.first;
   const int lanes = K * G.nc;
   const int vs_diag = (d.flags & EKS_FLAG_VS_DIAG) ? 1 : 0;
   const Gate open{nullptr, 0.0};
@@ -430,23 +438,9 @@ int dense_score(const eks_dims_t& d, const float* y, const double* rconst, const
     // are dead once the scan has run)
     DenseGeom G{K, T, O, B, nc, B, nc};
     const int nblk = (nc + kDenseCB - 1) / kDenseCB;
-    const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
-    char* p = static_cast<char*>(ws);
-    double* elems = reinterpret_cast<double*>(p);
-    p += align_up((size_t)nc * K * nv * 8, 256);
-    double* pre = reinterpret_cast<double*>(p);
-    p += align_up((size_t)nc * K * nv * 8, 256);
-    double* suf = reinterpret_cast<double*>(p);
-    p += align_up((size_t)nc * K * nv * 8, 256);
-    double* agg = reinterpret_cast<double*>(p);
-    p += align_up((size_t)nblk * K * nv * 8, 256);
-    double* bprior = reinterpret_cast<double*>(p);
-    p += align_up((size_t)nblk * K * rec * 8, 256);
-    double* bsuffix = reinterpret_cast<double*>(p);
-    p += align_up((size_t)nblk * K * rec * 8, 256);
-    double* filt = reinterpret_cast<double*>(p);
-    p += align_up((size_t)T * K * rec * 8, 256);
-    double* first = reinterpret_cast<double*>(p);
+    const GenericLayout L = generic_layout(T, K, D, nc, static_cast<char*>(ws));
+    double *elems = L.elems, *pre = L.pre, *suf = L.suf, *agg = L.agg, *bprior = L.bprior, *bsuffix = L.bsuffix,
+           *filt = L.filt, *first = L.first;
     double* part_ll = elems;
     double* part_score = elems + (size_t)nc * K;
     const int lanes = K * nc;
