@@ -26,6 +26,8 @@ python tools/driver_time.py 2>&1 | grep -E " ms" > $O/driver_time.txt
 python tools/host_path_time.py > $O/host_path_time.txt 2>&1
 python tools/adam_time.py > $O/adam_time.txt 2>&1
 python tools/dense_adam_time.py > $O/dense_adam_time.txt 2>&1
+python tools/dense_adam_time_d.py 2>&1 | grep adam > $O/dense_adam_time_d.txt
+python tools/pupil_time.py 2>&1 | grep -v amdgpu > $O/pupil_time.txt
 cd /tmp; export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-events"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > /dev/null 2>&1

@@ -64,8 +64,8 @@ for name in ('c3', 'c4', 'c4w', 'c4adam', 'c5', 'c2', 'pupil', 'ekf', 'c3_2ranks
     src = os.path.join(ev, f'bench_{name}.json')
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(prof, f'{tag}_bench_{name}.json'))
-for name in ('pytest_gpu.txt', 'smoke.txt', 'adam_time.txt', 'dense_adam_time.txt', 'ekf_time.txt', 'driver_time.txt',
-             'host_path_time.txt'):
+for name in ('pytest_gpu.txt', 'smoke.txt', 'adam_time.txt', 'dense_adam_time.txt', 'dense_adam_time_d.txt',
+             'pupil_time.txt', 'ekf_time.txt', 'driver_time.txt', 'host_path_time.txt'):
     src = os.path.join(ev, name)
     if os.path.exists(src):
         shutil.copy(src, os.path.join(prof, f'{tag}_{name}'))
