@@ -26,7 +26,8 @@ from .calibration import (CameraGroup, make_projection_from_camgroup, project_3d
 from .core import ensemble, run_kalman_smoother
 from .marker_array import (MarkerArray, input_dfs_to_markerArray, mA_to_stacked_array,
                            stacked_array_to_mA)
-from .stats import compute_mahalanobis, compute_pca, factor_analysis_from_moments
+from .stats import (compute_mahalanobis, compute_pca, factor_analysis_from_moments, pca_from_moments,
+                    pca_sign_rule)
 from .utils import center_predictions, format_data, make_dlc_pandas_index
 
 __all__ = ['fit_eks_mirrored_multicam', 'fit_eks_multicam', 'ensemble_kalman_smoother_multicam']
@@ -256,22 +257,48 @@ def _linear_on_device(marker_array, keypoint_names, smooth_param, quantile_keep_
         evs = _inflate_on_device(ys, evs, likes, n_latent, inflate_vars_kwargs)
     # ---- PCA per keypoint on the good frames (host, n_good x 2V each); reference eks/stats.py:9-64
     good_c = (good - means[:, None]).permute(2, 1, 0, 3).reshape(K, n_good, 2 * V)
-    good_host = good_c.cpu().numpy()
-    pcas = [pca_object if pca_object is not None else PCA(n_components=n_latent).fit(good_host[k])
-            for k in range(K)]
-    comp = torch.as_tensor(np.stack([np.asarray(p.components_) for p in pcas]), device=dev)   # (K,L,2V)
-    pmean = torch.as_tensor(np.stack([np.asarray(p.mean_) for p in pcas]), device=dev)        # (K,2V)
+    if pca_object is None and pca_sign_rule() != 'unknown' and n_good > 2 * V and \
+            not os.environ.get('EKS_HOST_PCA'):
+        # PCA(n_latent).fit(rows) from the rows' mean and covariance, reduced on the device (what scikit-learn's
+        # own covariance_eigh solver does for tall matrices): 2V + (2V)^2 doubles per keypoint cross the bus
+        # instead of n_good x 2V, and no per-keypoint fit on the host (stats.pca_from_moments)
+        pmean = good_c.mean(dim=1)                                            # (K,2V)
+        xc = good_c - pmean[:, None]
+        cov_h = (_gram(xc) / (n_good - 1)).cpu().numpy()
+
+        def extreme(k):
+            def fn(axes):                                                     # 'u' sign rule only (old scikit-learn)
+                sc = xc[k] @ torch.as_tensor(axes.T, device=dev)              # (n_good, L)
+                idx = sc.abs().argmax(dim=0)
+                return sc[idx, torch.arange(sc.shape[1], device=dev)].cpu().numpy()
+            return fn
+
+        comp_h = np.stack([pca_from_moments(cov_h[k], n_latent, extreme(k)) for k in range(K)])   # (K,L,2V)
+    else:
+        good_host = good_c.cpu().numpy()
+        pcas = [pca_object if pca_object is not None else PCA(n_components=n_latent).fit(good_host[k])
+                for k in range(K)]
+        comp_h = np.stack([np.asarray(p.components_) for p in pcas])
+        pmean = torch.as_tensor(np.stack([np.asarray(p.mean_) for p in pcas]), device=dev)    # (K,2V)
+    comp = torch.as_tensor(comp_h, device=dev)                                # (K,L,2V)
     pcs = torch.einsum('kto,klo->ktl', ys - pmean[:, None], comp)             # all frames (K,T,L)
     # initialize_kalman_filter_pca (reference :554-597): statistics over the frames in `mask`
     S0s, Qs = np.zeros((K, n_latent, n_latent)), np.zeros((K, n_latent, n_latent))
+    var_d, cov_d = [], []
     for k in range(K):
         gp = pcs[k][mask[:, k]]                                               # (n_valid_k, L)
-        S0s[k] = np.diag(gp.var(dim=0, unbiased=False).cpu().numpy())
-        d = (gp[1:] - gp[:-1]).cpu().numpy()
-        cov = np.atleast_2d(np.cov(d.T))
+        var_d.append(gp.var(dim=0, unbiased=False))
+        dd = gp[1:] - gp[:-1]
+        # np.cov(d.T): unbiased covariance of the frame-to-frame differences, L x L - reduced where the rows are
+        cov_d.append(_gram(dd - dd.mean(dim=0)) / (dd.shape[0] - 1) if dd.shape[0] > 1
+                     else torch.full((n_latent, n_latent), float('nan'), dtype=pcs.dtype, device=dev))
+    var_h, cov_h2 = _to_host(torch.stack(var_d), torch.stack(cov_d), pinned=False)
+    for k in range(K):
+        S0s[k] = np.diag(var_h[k])
+        cov = np.atleast_2d(cov_h2[k])
         top = np.max(np.abs(cov))
         Qs[k] = cov / top if top > 0 else cov
-    Cs = np.stack([np.asarray(p.components_).T for p in pcas])               # (K,2V,L)
+    Cs = np.ascontiguousarray(np.swapaxes(comp_h, 1, 2))                      # (K,2V,L)
     m0s = np.zeros((K, n_latent))
     As = np.tile(np.eye(n_latent), (K, 1, 1))
     t0 = time.perf_counter()
@@ -290,6 +317,13 @@ def _linear_on_device(marker_array, keypoint_names, smooth_param, quantile_keep_
     df_3d = pd.DataFrame(latent_h.reshape(T, K * 2 * n_latent),
                          columns=make_dlc_pandas_index(keypoint_names, labels=labels_3d))
     return camera_dfs, s_finals, df_3d
+
+
+def _gram(x):
+    """x^T x over the second-to-last axis of a tall (..., n, F) float64 tensor with a handful of columns, as an
+    elementwise product and a sum: rocBLAS picks a 64 x 64 macro-tile float64 GEMM for these shapes - 1.3 ms for
+    47 500 x 3 (rocprofv3 on the configs[3] driver) where the reduction takes ~30 us."""
+    return (x.unsqueeze(-1) * x.unsqueeze(-2)).sum(dim=-3)
 
 
 def _inflate_on_device(ys, evs, likes, n_latent, inflate_vars_kwargs, threshold: float = 5.0,
@@ -343,9 +377,9 @@ def _inflate_on_device(ys, evs, likes, n_latent, inflate_vars_kwargs, threshold:
             w = rows.index_select(0, act).to(torch.float64)                       # (Ka,T)
             n_rows = w.sum(dim=1)
             xa = ys.index_select(0, act)
-            mean = torch.einsum('kt,kto->ko', w, xa) / n_rows[:, None]
+            mean = (w[:, :, None] * xa).sum(dim=1) / n_rows[:, None]
             xc = (xa - mean[:, None, :]) * w[:, :, None]
-            cov = (torch.einsum('kto,ktp->kop', xc, xc) / n_rows[:, None, None]).cpu().numpy()
+            cov = (_gram(xc) / n_rows[:, None, None]).cpu().numpy()          # (not a GEMM: see _gram)
             n_host, mean_host = n_rows.cpu().numpy(), mean.cpu().numpy()
             for i, k in enumerate(np.flatnonzero(active)):
                 if n_host[i] < 1:

@@ -30,6 +30,69 @@ def compute_pca(valid_frames_mask: np.ndarray, emA_centered_preds: MarkerArray,
     return models, good_pcs
 
 
+_PCA_SIGN_RULE = None      # 'v' | 'u' | 'unknown': which entry the installed sklearn makes positive (svd_flip)
+
+
+def pca_sign_rule() -> str:
+    """How the installed scikit-learn fixes the sign of a principal axis: 'v' - the largest-magnitude entry of the
+    AXIS itself is positive (svd_flip(u_based_decision=False), scikit-learn >= 1.5) - or 'u' - the largest-magnitude
+    SCORE of the fitted rows is positive (older releases).  Decided once by fitting a small matrix on which the two
+    rules disagree; 'unknown' (neither reproduces sklearn) sends callers back to sklearn itself."""
+    global _PCA_SIGN_RULE
+    if _PCA_SIGN_RULE is None:
+        from sklearn.decomposition import PCA
+        rng = np.random.default_rng(12345)
+        X = rng.standard_normal((400, 4)) @ np.diag([5.0, 2.0, 1.0, 0.3]) @ rng.standard_normal((4, 4))
+        ref = PCA(n_components=3).fit(X).components_
+        Xc = X - X.mean(axis=0)
+        rule = 'unknown'
+        for cand in ('v', 'u'):
+            comp = _pca_axes(Xc.T @ Xc / (len(X) - 1), 3)
+            scores = Xc @ comp.T if cand == 'u' else None
+            comp = _apply_sign_rule(comp, cand, scores)
+            if np.allclose(comp, ref, rtol=0, atol=1e-8):
+                rule = cand
+                break
+        _PCA_SIGN_RULE = rule
+    return _PCA_SIGN_RULE
+
+
+def _pca_axes(cov: np.ndarray, n_components: int) -> np.ndarray:
+    """Leading eigenvectors of a covariance matrix as rows, largest eigenvalue first (signs as eigh leaves them)."""
+    lam, vec = np.linalg.eigh(np.asarray(cov, dtype=np.float64))
+    return np.ascontiguousarray(vec[:, ::-1][:, :n_components].T)
+
+
+def _apply_sign_rule(comp: np.ndarray, rule: str, scores_extreme: np.ndarray | None) -> np.ndarray:
+    """comp (L, F) axes as rows.  'v': flip each axis so that its largest-magnitude entry is positive; 'u': so that
+    the largest-magnitude score of the fitted rows is - `scores_extreme` is either the (n, L) score matrix or the
+    (L,) signed extreme scores themselves."""
+    if rule == 'v':
+        idx = np.argmax(np.abs(comp), axis=1)
+        sign = np.sign(comp[np.arange(comp.shape[0]), idx])
+    else:
+        ext = np.asarray(scores_extreme)
+        if ext.ndim == 2:
+            ext = ext[np.argmax(np.abs(ext), axis=0), np.arange(ext.shape[1])]
+        sign = np.sign(ext)
+    sign = np.where(sign == 0, 1.0, sign)
+    return comp * sign[:, None]
+
+
+def pca_from_moments(cov: np.ndarray, n_components: int, extreme_scores=None) -> np.ndarray:
+    """sklearn.decomposition.PCA(n_components).fit(X).components_ from the covariance of X alone (X_c' X_c / (n - 1)):
+    what scikit-learn's own `covariance_eigh` solver computes for tall matrices, and the right singular vectors of
+    X_c otherwise.  The sign of every axis follows the installed scikit-learn (`pca_sign_rule`); the 'u' rule needs
+    the signed largest-magnitude score of the fitted rows along each UNSIGNED axis: `extreme_scores(axes) -> (L,)`,
+    a callable so that the rows can stay where they are (the multi-camera driver keeps them on the device)."""
+    rule = pca_sign_rule()
+    if rule == 'unknown':
+        raise RuntimeError('pca_from_moments: the installed scikit-learn follows neither sign rule')
+    comp = _pca_axes(cov, n_components)
+    ext = extreme_scores(comp) if rule == 'u' else None
+    return _apply_sign_rule(comp, rule, ext)
+
+
 def factor_analysis_from_moments(cov: np.ndarray, n_samples: int, n_components: int, tol: float = 1e-2,
                                  max_iter: int = 1000) -> tuple:
     """sklearn.decomposition.FactorAnalysis(n_components).fit(X) from X's second moments alone.

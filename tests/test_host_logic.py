@@ -363,3 +363,32 @@ def test_model_flags_diag_unit_and_positive_definite_q():
     assert f == _lib.FLAG_DIAG_MODEL | _lib.FLAG_UNIT_AC | _lib.FLAG_Q_PD
     f = hip_ops.model_flags(eye2 * 3.0, eye2 * 0.9, eye2, eye2 * 0.0)
     assert f == _lib.FLAG_DIAG_MODEL
+
+
+def test_pca_from_moments_reproduces_sklearn_components_and_signs():
+    """stats.pca_from_moments: principal axes from the covariance alone, signs by the installed scikit-learn's rule
+    (decided once by pca_sign_rule) - the multi-camera driver reduces the fitted rows to this covariance on the
+    device instead of downloading them for a per-keypoint sklearn fit."""
+    from sklearn.decomposition import PCA
+    from eks_amd import stats
+    assert stats.pca_sign_rule() in ('v', 'u')
+    rng = np.random.default_rng(3)
+    for n, F, L in ((20000, 4, 3), (300, 8, 3), (1000, 12, 5), (60, 4, 2)):
+        X = np.cumsum(rng.standard_normal((n, F)), axis=0) @ rng.standard_normal((F, F)) + 50.0
+        ref = PCA(n_components=L).fit(X).components_
+        Xc = X - X.mean(axis=0)
+
+        def extreme(axes):
+            sc = Xc @ axes.T
+            return sc[np.argmax(np.abs(sc), axis=0), np.arange(sc.shape[1])]
+
+        comp = stats.pca_from_moments(Xc.T @ Xc / (n - 1), L, extreme)
+        assert np.abs(comp - ref).max() < 1e-9
+    # the other rule, against a hand-written svd_flip(u_based_decision=True)
+    X = rng.standard_normal((200, 5)) @ rng.standard_normal((5, 5))
+    Xc = X - X.mean(axis=0)
+    U, S, Vt = np.linalg.svd(Xc, full_matrices=False)
+    signs = np.sign(U[np.argmax(np.abs(U), axis=0), np.arange(U.shape[1])])
+    want = (Vt * signs[:, None])[:3]
+    got = stats._apply_sign_rule(stats._pca_axes(Xc.T @ Xc / 199, 3), 'u', Xc @ stats._pca_axes(Xc.T @ Xc / 199, 3).T)
+    assert np.abs(got - want).max() < 1e-9
