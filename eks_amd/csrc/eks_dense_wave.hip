@@ -6,7 +6,7 @@
 // latency apart, filtered beliefs through a float64 scratch stream, and the scan as two launches of
 // barrier-separated LDS passes.  Here (round 3):
 //
-//   DW1 dw_summarize : block = (keypoint, 64 consecutive 16-frame chunks), lane = chunk.  A lane requests
+//   DW1 dw_summarize : block = (keypoint, 64 consecutive 8-frame chunks), lane = chunk.  A lane requests
 //                      all rows of its chunk at once (one memory latency per chunk instead of one per
 //                      frame) and builds the chunk element in registers; then the block's two waves - both
 //                      hold the same 64 elements, no exchange - run the forward and the reverse
