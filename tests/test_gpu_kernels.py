@@ -554,6 +554,23 @@ def test_nll_dense_score_gradient_matches_oracle_and_dual_numbers(T, K, D, O, ge
     assert (np.abs(g1 - g0) / np.abs(gref).max()).max() < 1e-7
 
 
+@pytest.mark.parametrize('knob', ['EKS_DENSE_LEGACY', 'EKS_DENSE_TREE_SCAN'])
+@pytest.mark.parametrize('T,K', [(900, 4), (300, 1200)])
+def test_nll_dense_score_generic_kernels_on_specialised_shapes(T, K, knob, set_knob):
+    """D = 3, O = 4 through the GENERIC kernels' SCORE form (the specialised narrow / keypoint-major kernels switched
+    off, or the keypoint-major ones with the tree scan): the same value and gradient as the specialised forms."""
+    from eks_amd import _lib, hip_ops
+    arrs, y, var = _dense_problem(T, K, 3, 4, seed=23 + T)
+    rconst = hip_ops.const_r(_dev(var), 1e-4)
+    s = np.exp(np.random.default_rng(T).uniform(-4, 4, K))
+    args = (_dev(y), rconst, *_params_dev(arrs), _dev(s[:, None]))
+    n0, g0 = [a.cpu().numpy()[:, 0] for a in hip_ops.nll(*args, per_keypoint=True, want_grad=True, flags=_lib.FLAG_Q_PD)]
+    set_knob(knob, '1')
+    n1, g1 = [a.cpu().numpy()[:, 0] for a in hip_ops.nll(*args, per_keypoint=True, want_grad=True, flags=_lib.FLAG_Q_PD)]
+    assert (np.abs(n1 - n0) / np.abs(n0)).max() < 1e-11
+    assert (np.abs(g1 - g0) / np.abs(g0).max()).max() < 1e-9
+
+
 def test_adam_step_matches_oracle_sequence():
     """Drive eks_adam_step with a synthetic quadratic loss and compare the whole trajectory with
     the oracle's restatement of eks/core.py:652-681 (including blocks and the clip gradient)."""
