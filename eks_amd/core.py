@@ -186,7 +186,7 @@ def _block_csr(blocks, K):
 
 
 def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, s_bounds_log, tol,
-                        safety_cap, min_R_var, s_mode, n_grid, sync_every: int = 16):
+                        safety_cap, min_R_var, s_mode, n_grid, sync_every: int | None = None):
     """Returns (s per keypoint as a device float64 tensor, info dict)."""
     torch = _torch()
     y_c, var_c = P.cropped(s_frames)
@@ -223,6 +223,11 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
     # The count of still-running blocks after round r is copied to pinned memory behind round r and read
     # only after round r + 1 has been enqueued: the device never waits for the host's answer, at the price
     # of one round of no-op launches after the last block stops.
+    # Iterations per round: scalar chains skip the keypoints that have stopped (an over-issued iteration is a
+    # launch that returns at once), the general path evaluates every keypoint whatever the optimiser state - a
+    # round issued after the last block stopped costs a round of full evaluations - so its rounds are short.
+    if sync_every is None:
+        sync_every = 16 if (P.flags & hip_ops.FLAG_DIAG_MODEL) else 4
     rounds = (cap + sync_every - 1) // sync_every
     snap = _pinned_empty((max(rounds, 1),), torch.int32)
     pending = None                                        # (round index, event) of the newest unread count

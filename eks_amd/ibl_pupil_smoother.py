@@ -210,7 +210,7 @@ def _to_stable_s(u, eps: float = 1e-3):
     return 1.0 / (1.0 + np.exp(-np.asarray(u, dtype=np.float64))) * (1.0 - 2 * eps) + eps
 
 
-def _optimize_on_device(P: _PupilProblem, s_frames, lr, tol, safety_cap, sync_every: int = 32):
+def _optimize_on_device(P: _PupilProblem, s_frames, lr, tol, safety_cap, sync_every: int = 8):
     """Adam on u = logit-like reparametrisation of (s_diam, s_com), entirely on the device:
     eks_pupil_adam_run = { eks_ar1_nll (loss + 2 sensitivities) -> eks_pupil_adam_step } x
     `sync_every` per host round trip (steps enqueued after convergence leave the state untouched).
