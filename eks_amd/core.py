@@ -206,8 +206,15 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
             s, idx = hip_ops.argmin_s(nll, cand)
         return s, dict(mode='grid', nll=nll, argmin=idx, candidates=cand)
     # Adam on u = log s (reference eks/core.py:612-613, :439-441: float32 initial value)
-    u0 = np.array([np.float32(np.log(np.clip(np.mean([s_guess_per_k[k] for k in b]), 1e-6, 1e3)))
-                   for b in blocks], dtype=np.float64)
+    # (block means by one segmented sum over the CSR member list: a Python loop over 256 blocks of np.mean / np.clip
+    #  calls held the first launch back by 2 ms)
+    g = np.asarray(s_guess_per_k, dtype=np.float64)[np.asarray(members, dtype=np.int64)]
+    offs64 = np.asarray(offs, dtype=np.int64)
+    if np.all(np.diff(offs64) == 1):
+        means = g
+    else:
+        means = np.array([np.mean(g[offs64[b]:offs64[b + 1]]) for b in range(nb)])
+    u0 = np.log(np.clip(means, 1e-6, 1e3)).astype(np.float32).astype(np.float64)
     state = np.zeros((nb, 6))
     state[:, 0] = u0
     state[:, 3] = np.inf
