@@ -176,13 +176,12 @@ def _block_csr(blocks, K):
     if members.size != K or not np.array_equal(np.sort(members), np.arange(K)):
         raise ValueError(f'blocks must partition the {K} keypoints (every index 0..{K - 1} exactly '
                          f'once); got {[list(map(int, b)) for b in blocks]}')
-    members = members.astype(np.int32)
+    counts = np.fromiter((len(b) for b in blocks), dtype=np.int64, count=len(blocks))
     offs = np.zeros(len(blocks) + 1, dtype=np.int32)
-    offs[1:] = np.cumsum([len(b) for b in blocks])
+    offs[1:] = np.cumsum(counts)
     of_kp = np.full(K, -1, dtype=np.int64)
-    for i, b in enumerate(blocks):
-        of_kp[np.asarray(b, dtype=int)] = i
-    return offs, members, of_kp
+    of_kp[members] = np.repeat(np.arange(len(blocks)), counts)       # block of every keypoint
+    return offs, members.astype(np.int32), of_kp
 
 
 def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, s_bounds_log, tol,
