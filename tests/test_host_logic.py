@@ -392,3 +392,26 @@ def test_pca_from_moments_reproduces_sklearn_components_and_signs():
     want = (Vt * signs[:, None])[:3]
     got = stats._apply_sign_rule(stats._pca_axes(Xc.T @ Xc / 199, 3), 'u', Xc @ stats._pca_axes(Xc.T @ Xc / 199, 3).T)
     assert np.abs(got - want).max() < 1e-9
+
+
+def test_initial_guesses_for_all_keypoints_equal_the_per_keypoint_calls_bit_for_bit():
+    """core._initial_guesses_per_keypoint (one nanstd over a (K, (T'-1) O) layout) against the loop of
+    compute_initial_guesses calls it replaces in run_kalman_smoother (reference eks/core.py:104-133, :233-236):
+    identical floats for float32 and float64 variances, NaNs, an all-NaN keypoint and a constant one (-> 2.0)."""
+    import warnings
+    from eks_amd import core
+    rng = np.random.default_rng(1)
+    for dt in (np.float32, np.float64):
+        for T, K, O in ((2000, 40, 2), (300, 7, 4), (2, 3, 2)):
+            ev = rng.gamma(2, 1, (T, K, O)).astype(dt)
+            ev[rng.random(ev.shape) < 0.02] = np.nan
+            if K > 3:
+                ev[:, 2, :] = np.nan
+                ev[:, 3, :] = 1.0
+            loop = np.full(K, 2.0)
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                for k in range(K):
+                    g = float(core.compute_initial_guesses(ev[:, k, :]) or 2.0)
+                    loop[k] = g if (np.isfinite(g) and g > 0) else 2.0
+            assert np.array_equal(loop, core._initial_guesses_per_keypoint(ev))
