@@ -253,13 +253,20 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
     if sync_every is None:
         sync_every = 16 if (P.flags & hip_ops.FLAG_DIAG_MODEL) else 4
     rounds = (cap + sync_every - 1) // sync_every
-    snap = _pinned_empty((max(rounds, 1),), torch.int32)
+    try:
+        snap = _pinned_empty((max(rounds, 1),), torch.int32)
+    except RuntimeError:          # page-locked memory exhausted or unavailable (as _to_host): blocking reads
+        snap = None
     pending = None                                        # (round index, event) of the newest unread count
     r = 0
     while iters < cap:
         n = min(sync_every, cap - iters)
         loop.run(n)
         iters += n
+        if snap is None:
+            if int(loop.n_active.item()) == 0:
+                break
+            continue
         snap[r:r + 1].copy_(loop.n_active, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -269,7 +276,9 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
                 break
         pending = (r, ev)
         r += 1
-    return s_kp, dict(mode='adam', state=state, launches=iters)
+    # `launches`: iterations ENQUEUED (the deferred count over-issues one round after the last block stops; on
+    # scalar chains those launches return at once); the iterations each block actually took are state[:, 4]
+    return s_kp, dict(mode='adam', state=state, launches=iters, deferred_count=snap is not None)
 
 
 def optimize_smooth_param(ys, m0s, S0s, As, Cs, Qs, Rs, blocks, s_finals, s_frames, s_guess_per_k,

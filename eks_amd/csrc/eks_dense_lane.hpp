@@ -68,7 +68,7 @@ struct ObsNoise {
   EKS_HD double at(size_t row, int k, int O, int o) const {
     if (rconst) return rconst[(size_t)k * O + o];
     const float v = var[row + o];
-    return v > kVarFloor ? (double)v : (double)kVarFloor;
+    return (double)clip_var(v);
   }
 };
 
@@ -163,7 +163,7 @@ struct LinearObs {
     for (int o = 0; o < O; ++o) {
       const float v = var[row + o];
       fn(load_obs_row<double, D>(M, k, O, o), (double)y[row + o],
-         v > kVarFloor ? (double)v : (double)kVarFloor);
+         (double)clip_var(v));
     }
   }
 };

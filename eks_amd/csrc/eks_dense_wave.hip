@@ -216,7 +216,7 @@ __global__ __launch_bounds__(128 * SUBS) void dw_summarize_kernel(DwGeom G, Dens
       double r = rk[o];
       if constexpr (!SCORE) {
         const float v = my_v[((size_t)i * 64 + lane) * O + o];
-        r = v > kVarFloor ? (double)v : (double)kVarFloor;
+        r = (double)clip_var(v);
       }
       delem_observe(e, H.row(o), (double)py[o], r, false);
     }
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
       double r = rk[o];
       if constexpr (!SCORE) {
         const float vf = lv[((size_t)i * 64 + lane) * O + o];
-        r = vf > kVarFloor ? (double)vf : (double)kVarFloor;
+        r = (double)clip_var(vf);
       }
       const double sigma = r + dot(h, u);
       const double g = rcp(sigma);

@@ -112,7 +112,7 @@ __device__ __forceinline__ void wide_filter_frame(const WideRowsC<D, O>& H, cons
     if constexpr (SCORE)
       r = rk[o];
     else
-      r = fr.v[o] > kVarFloor ? (double)fr.v[o] : (double)kVarFloor;
+      r = (double)clip_var(fr.v[o]);
     const double sigma = r + dot(h, u);
     const double g = rcp(sigma);
     const double dv = (double)fr.y[o] - dot(h, m);
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64) void dwide_summarize_kernel(WideGeom G, DenseMo
 #pragma unroll
         for (int o = 0; o < O; ++o)
           delem_observe(e, H.row(o), (double)cur[f].y[o],
-                        SCORE ? rk[o] : (cur[f].v[o] > kVarFloor ? (double)cur[f].v[o] : (double)kVarFloor), false);
+                        SCORE ? rk[o] : (double)clip_var(cur[f].v[o]), false);
       }
     }
 #pragma unroll

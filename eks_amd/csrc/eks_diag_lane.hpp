@@ -6,6 +6,7 @@
 // Layout (frame-major, the layout the reference's drivers hold before they transpose for JAX,
 // eks/singlecam_smoother.py:166): y, var: float [T][N], N = K*D chains, chain n = k*D + d.
 #pragma once
+#include <cmath>
 #include <cstddef>
 #include <cstdint>
 
@@ -14,6 +15,12 @@
 namespace eks {
 
 constexpr float kVarFloor = 1e-12f;  // eks/utils.py:373 clip(var, 1e-12, inf)
+// Upper clamp, not in the reference: an infinite (or > 1e30) ensemble variance means "no observation" - the gain
+// is 0 - but r g = inf * 0 is NaN in every form of the update (the reference's own P - K S K' included), and one
+// NaN poisons the chain for good.  At 1e30 the frame's weight is 1e-30 of anything a pixel variance can be, r g
+// rounds to exactly 1 and nothing overflows in float32 or float64.  NaN variances keep mapping to the floor.
+constexpr float kVarCeil = 1e30f;
+EKS_HD float clip_var(float v) { return fminf(fmaxf(v, kVarFloor), kVarCeil); }
 
 struct DiagModel {
   // device (or host, in the simulator) pointers to the reference's per-keypoint parameters
@@ -93,7 +100,7 @@ EKS_HD Elem<float> summarize_loaded(const float (&yy)[B], const float (&rr)[B], 
 #pragma unroll
   for (int i = 0; i < B; ++i) {
     if (FULL || i < len) {
-      const float r = rr[i] > kVarFloor ? rr[i] : kVarFloor;
+      const float r = clip_var(rr[i]);
       elem_append<float, UNIT>(e, yy[i], r, p);
     }
   }
@@ -122,7 +129,7 @@ EKS_HD void filter_loaded(float (&v0)[B], float (&v1)[B], int len, const ChainPa
 #pragma unroll
   for (int i = 0; i < B; ++i) {
     if (FULL || i < len) {
-      const float r = v1[i] > kVarFloor ? v1[i] : kVarFloor;
+      const float r = clip_var(v1[i]);
       float mf, Pf;
       filter_step<float, UNIT>(m, P, v0[i], r, p, mf, Pf);
       v0[i] = mf;

@@ -456,6 +456,15 @@ __device__ __forceinline__ void gf_put_published(double* slot, const NllAcc<Dual
   }
   gf_publish(slot + 12 * 64, a.xr);
 }
+// This ordering argument is about gfx950's caches, not about the HIP memory model (which promises nothing for a
+// relaxed store followed by a relaxed read-modify-write): an sc1 store is acknowledged only once it has been
+// written through the XCD's L2, so after vmcnt(0) every published value is in memory before the ticket moves.
+// The library is built for gfx950 only; any other target must take the portable form (a release at agent
+// scope on the ticket, i.e. the 5 us L2 write-back) - hence the guard.  tests/test_gpu_kernels.py repeats the
+// fused evaluation against EKS_NLL_GRAD_UNFUSED bit for bit (a stale summary would show as a mismatch).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "gf_publish / gf_stores_acknowledged rely on gfx950's write-through sc1 stores: use a release at agent scope on the ticket for other targets"
+#endif
 __device__ __forceinline__ void gf_stores_acknowledged() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);

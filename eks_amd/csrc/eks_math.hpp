@@ -53,18 +53,22 @@ template <typename R>
 EKS_HD R rcp(R x) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (sizeof(R) == 4) {
-    // v_rcp_f32 (1 ulp) + one Newton step: <= 0.5 ulp-ish, keeps the 1e-6 budget
+    // v_rcp_f32 (1 ulp) + one Newton step: <= 0.5 ulp-ish, keeps the 1e-6 budget.  The step is NaN exactly
+    // where the seed already is the IEEE answer (x = inf -> 0, x = 0 -> inf: x * r0 = inf * 0): keep the seed
     float r0 = __builtin_amdgcn_rcpf(x);
-    return r0 * (2.0f - x * r0);
+    const float r1 = r0 * (2.0f - x * r0);
+    return r1 == r1 ? r1 : r0;
   } else {
     // v_rcp_f64 seed + two Newton steps (y <- y + y (1 - x y)): within an ulp of the IEEE quotient in 5
-    // dependent instructions instead of the 12-deep v_div_scale / v_div_fmas / v_div_fixup sequence.  Every
-    // caller divides by an innovation variance or 1 + C J (>= the variance floor, finite), so the
-    // special cases that sequence exists for do not arise.
-    double y = __builtin_amdgcn_rcp(x);
+    // dependent instructions instead of the 12-deep v_div_scale / v_div_fmas / v_div_fixup sequence.  Callers
+    // divide by an innovation variance or 1 + C J (>= the variance floor; variances are clamped to 1e30 at
+    // load, eks_diag_lane.hpp: clip_var), so the special cases that sequence exists for do not arise in a
+    // healthy chain; where they do (x = inf, 0 or denormal: the refinement is inf * 0 = NaN) the seed, which is
+    // the IEEE answer there, is returned instead of a NaN that would poison the chain.
+    const double y0 = __builtin_amdgcn_rcp(x);
+    double y = __builtin_fma(y0, __builtin_fma(-x, y0, 1.0), y0);
     y = __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
-    y = __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
-    return y;
+    return y == y ? y : y0;
   }
 #else
   return R(1) / x;

@@ -49,18 +49,24 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+Q_PD_MIN_EIG_RATIO = 1e-6      # EKS_FLAG_Q_PD is asserted for cond(Q) <= 1e6 (every keypoint)
+
+
 def model_flags(S0, A, C, Q) -> int:
     """Inspect HOST copies of the parameters (numpy) and return DIAG_MODEL / UNIT_AC / Q_PD flags."""
     import numpy as np
     D, O = A.shape[-1], C.shape[-2]
-    # Q positive definite with a margin (smallest eigenvalue > 1e-8 of the largest: the smoothing-distribution
-    # gradient multiplies float64 second moments by (sQ)^-1, so its error grows with Q's condition number): the
-    # general path may take the loss gradient from the smoothing distribution (include/eks_hip.h: EKS_FLAG_Q_PD)
+    # Q positive definite with a margin: the smoothing-distribution gradient forms tr((sQ)^-1 E[w w']) - D, a
+    # cancellation whose error grows with Q's condition number and is summed over T frames, so it is only taken for
+    # cond(Q) <= 1e6 per keypoint (measured against the dual-number kernels at the threshold and T = 50 000:
+    # tests/test_gpu_kernels.py::test_score_gradient_at_the_conditioning_threshold); worse-conditioned Q - the
+    # normalised covariance of principal-component differences the multicam driver feeds can be - takes the
+    # dual-number kernels, which do not invert Q (include/eks_hip.h: EKS_FLAG_Q_PD)
     Qh = np.asarray(Q, dtype=np.float64)
     pd = 0
     if np.all(np.isfinite(Qh)):
         ev = np.linalg.eigvalsh(0.5 * (Qh + np.swapaxes(Qh, -1, -2)))
-        pd = FLAG_Q_PD if bool(np.all(ev[..., 0] > 1e-8 * np.maximum(ev[..., -1], 1e-300))) else 0
+        pd = FLAG_Q_PD if bool(np.all(ev[..., 0] > Q_PD_MIN_EIG_RATIO * np.maximum(ev[..., -1], 1e-300))) else 0
 
     def is_diag(M):
         return bool(np.all(M[..., ~np.eye(D, dtype=bool)] == 0))

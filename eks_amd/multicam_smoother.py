@@ -319,11 +319,33 @@ def _linear_on_device(marker_array, keypoint_names, smooth_param, quantile_keep_
     return camera_dfs, s_finals, df_3d
 
 
-def _gram(x):
+_GRAM_TEMP_BYTES = 64 << 20
+
+
+def _gram(x, max_temp_bytes: int | None = None):
     """x^T x over the second-to-last axis of a tall (..., n, F) float64 tensor with a handful of columns, as an
     elementwise product and a sum: rocBLAS picks a 64 x 64 macro-tile float64 GEMM for these shapes - 1.3 ms for
-    47 500 x 3 (rocprofv3 on the configs[3] driver) where the reduction takes ~30 us."""
-    return (x.unsqueeze(-1) * x.unsqueeze(-2)).sum(dim=-3)
+    47 500 x 3 (rocprofv3 on the configs[3] driver) where the reduction takes ~30 us.
+
+    The (..., n, F, F) outer-product temporary is only formed while it stays under `max_temp_bytes` (64 MiB);
+    larger problems (long sessions, many cameras: K * n * F^2 * 8 bytes) are reduced one column at a time and,
+    where even an x-sized temporary is too large, in slabs of rows - the temporary never exceeds the cap (plus
+    one row slab), so a session that fitted before the elementwise form still fits."""
+    cap = _GRAM_TEMP_BYTES if max_temp_bytes is None else int(max_temp_bytes)
+    n, F = x.shape[-2], x.shape[-1]
+    lead = 1
+    for d in x.shape[:-2]:
+        lead *= int(d)
+    item = x.element_size()
+    if lead * n * F * F * item <= cap:
+        return (x.unsqueeze(-1) * x.unsqueeze(-2)).sum(dim=-3)
+    out = x.new_zeros(x.shape[:-2] + (F, F))
+    rows = max(1, min(n, cap // max(1, lead * F * item)))        # rows per slab: one x-sized temporary <= cap
+    for r0 in range(0, n, rows):
+        xs = x[..., r0:r0 + rows, :]
+        for j in range(F):
+            out[..., :, j] += (xs * xs[..., j:j + 1]).sum(dim=-2)
+    return out
 
 
 def _inflate_on_device(ys, evs, likes, n_latent, inflate_vars_kwargs, threshold: float = 5.0,

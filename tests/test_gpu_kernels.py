@@ -726,3 +726,59 @@ def test_order_stats_and_percentile_match_numpy_bit_for_bit(T, N):
         got = hip_ops.percentile(xd, q)
         ref = np.percentile(x, q, axis=0)
         assert got.dtype == ref.dtype and np.array_equal(got, ref, equal_nan=True), (q, got, ref)
+
+
+@pytest.mark.parametrize('dense', [False, True])
+def test_smooth_with_infinite_and_huge_variances_gives_those_frames_no_weight(dense):
+    """an infinite ensemble variance (a frame no member could place) used to poison the chain - the
+    fast reciprocals return NaN at inf, and r g = inf * 0 is NaN in every form of the update, the reference's
+    included.  Variances are clamped to 1e30 at load (eks_diag_lane.hpp: clip_var): such a frame gets zero weight.
+    Compared with the float64 oracle fed 1e30 in those places; every output must be finite."""
+    from eks_amd import hip_ops
+    if dense:
+        T, K, D, O = 1200, 3, 3, 4
+        arrs, y_tk, var_tk = _dense_problem(T, K, D, O, seed=5)
+    else:
+        T, K = 2500, 5
+        arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=93, unit=True)
+    var_tk = var_tk.copy()
+    var_tk[5::37, 0, :] = np.inf                     # whole frames of one keypoint
+    var_tk[11::53, 1, 0] = np.inf                    # single coordinates
+    var_tk[700:740, 2] = 3e38                        # a run of frames beyond the clamp, finite
+    var_tk[0, 0] = np.inf                            # the very first frame: the prior passes through
+    var_tk[T - 1, 1] = np.inf                        # and the last
+    s = np.full(K, 3.0)
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    ms, Vs = hip_ops.smooth(_dev(y_tk), _dev(var_tk), *_params_dev(arrs), _dev(s), flags=flags)
+    ms = np.transpose(ms.cpu().numpy().astype(np.float64), (1, 0, 2))
+    Vs = np.transpose(Vs.cpu().numpy().astype(np.float64), (1, 0, 2, 3))
+    assert np.isfinite(ms).all() and np.isfinite(Vs).all()
+    Rd = np.clip(np.swapaxes(var_tk.astype(np.float64), 0, 1), 1e-12, 1e30)
+    ms_o, Vs_o = orc.kalman_smoother(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], s, Rd)[:2]
+    assert _rel(ms, ms_o, axis_scale=(1, 2)) < 1e-5
+    assert (np.abs(Vs - Vs_o) / np.abs(Vs_o).max(axis=(2, 3), keepdims=True)).max() < 1e-5
+
+
+def test_score_gradient_at_the_conditioning_threshold():
+    """hip_ops.model_flags asserts EKS_FLAG_Q_PD up to cond(Q) = 1e6.  At that conditioning and
+    T = 50 000 the smoothing-distribution gradient - tr((sQ)^-1 E[w w']) - D summed over the frames - must still
+    agree with the dual-number kernels (which never invert Q) well inside what moves Adam's stop test."""
+    from eks_amd import _lib, hip_ops
+    T, K, D, O = 50_000, 4, 3, 4
+    arrs, y, var = _dense_problem(T, K, D, O, seed=123)
+    rng = np.random.default_rng(7)
+    U = np.linalg.qr(rng.standard_normal((K, D, D)))[0]
+    lam = np.array([1.0, 3e-3, 1.2e-6])              # cond 8e5: just inside the threshold
+    arrs['Qs'] = np.ascontiguousarray(U @ (lam[None, :, None] * np.swapaxes(U, 1, 2)))
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    assert flags == _lib.FLAG_Q_PD
+    rconst = hip_ops.const_r(_dev(var), 1e-4)
+    for u in (-6.0, 0.0, 5.0):
+        s = np.full(K, np.exp(u))
+        args = (_dev(y), rconst, *_params_dev(arrs), _dev(s[:, None]))
+        nll1, g1 = [a.cpu().numpy()[:, 0] for a in hip_ops.nll(*args, per_keypoint=True, want_grad=True, flags=flags)]
+        nll0, g0 = [a.cpu().numpy()[:, 0] for a in hip_ops.nll(*args, per_keypoint=True, want_grad=True, flags=0)]
+        assert (np.abs(nll1 - nll0) / np.abs(nll0)).max() < 1e-9
+        # the optimiser sees lr * g through Adam's normalisation; a relative 1e-5 of the gradient's own size (or of
+        # 1e-6 of the loss where the gradient vanishes) cannot move a step or the stop test
+        assert (np.abs(g1 - g0) / np.maximum(np.abs(g0), 1e-6 * np.abs(nll0))).max() < 1e-5, (u, g1, g0)

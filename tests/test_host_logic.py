@@ -358,6 +358,12 @@ def test_model_flags_diag_unit_and_positive_definite_q():
     Qz = Q.copy()
     Qz[0] = 0.0
     assert hip_ops.model_flags(eyeD, eyeD, C, Qz) == 0
+    # conditioning threshold: cond(Q) <= 1e6 for every keypoint, decided per batch
+    Qc = Q.copy()
+    Qc[1] = np.diag([1.0, 0.5, 2e-6])
+    assert hip_ops.model_flags(eyeD, eyeD, C, Qc) == _lib.FLAG_Q_PD
+    Qc[1] = np.diag([1.0, 0.5, 5e-7])
+    assert hip_ops.model_flags(eyeD, eyeD, C, Qc) == 0
     eye2 = np.tile(np.eye(2), (K, 1, 1))
     f = hip_ops.model_flags(eye2 * 3.0, eye2, eye2, eye2 * 0.5)
     assert f == _lib.FLAG_DIAG_MODEL | _lib.FLAG_UNIT_AC | _lib.FLAG_Q_PD
@@ -415,3 +421,38 @@ def test_initial_guesses_for_all_keypoints_equal_the_per_keypoint_calls_bit_for_
                     g = float(core.compute_initial_guesses(ev[:, k, :]) or 2.0)
                     loop[k] = g if (np.isfinite(g) and g > 0) else 2.0
             assert np.array_equal(loop, core._initial_guesses_per_keypoint(ev))
+
+
+def test_gram_never_builds_the_outer_product_tensor_beyond_its_cap():
+    """the PCA covariance / factor-analysis moments were reduced through a (..., n, F, F)
+    temporary - K * n * F^2 * 8 bytes, several GB for a long many-camera session.  Above the cap the reduction
+    goes column by column (and in row slabs), with the same result."""
+    import torch
+    from eks_amd import multicam_smoother as mc
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 5000, 12, dtype=torch.float64, generator=g)           # a 6-camera shape, 3 keypoints
+    ref = torch.einsum('kni,knj->kij', x, x)
+    small = mc._gram(x)                                                       # 3 * 5000 * 144 * 8 = 17 MB: direct form
+    assert torch.allclose(small, ref, rtol=1e-12, atol=1e-9)
+    peak = []
+    orig_sum = torch.Tensor.sum
+
+    def spy(self, *a, **k):
+        peak.append(self.numel() * self.element_size())
+        return orig_sum(self, *a, **k)
+    torch.Tensor.sum = spy
+    try:
+        for cap in (1 << 20, 100_000, 1):                                     # column form, row slabs, one row at a time
+            if cap == 1:
+                xx = x[:, :40]
+                got, want = mc._gram(xx, max_temp_bytes=cap), torch.einsum('kni,knj->kij', xx, xx)
+            else:
+                got, want = mc._gram(x, max_temp_bytes=cap), ref
+            assert torch.allclose(got, want, rtol=1e-12, atol=1e-9)
+            assert max(peak) <= max(cap, 3 * 12 * 8), (cap, max(peak))        # never more than the cap (or one row)
+            peak.clear()
+    finally:
+        torch.Tensor.sum = orig_sum
+    # 2-D input (the per-keypoint calls of the prior / process-noise set-up)
+    y = torch.randn(7000, 3, dtype=torch.float64, generator=g)
+    assert torch.allclose(mc._gram(y, max_temp_bytes=4096), y.T @ y, rtol=1e-12, atol=1e-9)
