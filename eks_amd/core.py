@@ -463,7 +463,8 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
                         blocks: list[list[int]] | None = None, lr: float = 0.25,
                         s_bounds_log: tuple = (-8.0, 8.0), tol: float = 1e-2, safety_cap: int = 300,
                         h_fn: Callable | None = None, *, s_mode: str = 'adam', n_grid: int = 64,
-                        vs_diag: bool = False, return_device: bool = False, x_init=None):
+                        vs_diag: bool = False, return_device: bool = False, x_init=None,
+                        return_info: bool = False):
     """Choose (or optimise) the process-noise scale s per keypoint, then run the Kalman filter +
     RTS smoother.  Drop-in for the reference's eks/core.py:159-302.
 
@@ -474,7 +475,8 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
 
     Extensions (keyword-only, not in the reference): s_mode 'adam' (reference behaviour) or 'grid'
     (n_grid candidates exp(linspace(*s_bounds_log)), BASELINE.json config 3); vs_diag returns only
-    the diagonal of Vs as (K,T,D); return_device keeps ms / Vs as device tensors.
+    the diagonal of Vs as (K,T,D); return_device keeps ms / Vs as device tensors; return_info appends the search's
+    record (mode, optimiser state / NLL table as device tensors, launches) as a fourth element.
 
     h_fn: the nonlinear observation model y_t = h_fn(x_t) + v_t (reference :188-190).  The
     accelerated path takes a `calibration.PinholeProjection` (what
@@ -486,9 +488,10 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
     if s_mode not in ('adam', 'grid'):
         raise ValueError("s_mode must be 'adam' or 'grid'")
     if h_fn is not None:
-        return _run_kalman_smoother_pinhole(ys, m0s, S0s, As, Qs, ensemble_vars, h_fn, s_frames,
-                                            smooth_param, blocks, lr, s_bounds_log, tol, safety_cap,
-                                            s_mode, n_grid, vs_diag, return_device, x_init)
+        res = _run_kalman_smoother_pinhole(ys, m0s, S0s, As, Qs, ensemble_vars, h_fn, s_frames,
+                                           smooth_param, blocks, lr, s_bounds_log, tol, safety_cap,
+                                           s_mode, n_grid, vs_diag, return_device, x_init)
+        return res + ({},) if return_info else res
     torch = _torch()
     t0 = time.perf_counter()
     P = _DeviceProblem(ys, m0s, S0s, As, Cs, Qs, ensemble_vars)
@@ -503,6 +506,7 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
     if P.T < 2:
         raise ValueError('Not enough frames to compute temporal differences.')
     s_finals = np.empty(K, dtype=float)
+    info = {}
     if smooth_param is not None:
         if isinstance(smooth_param, (int, float)):
             s_finals[:] = float(smooth_param)
@@ -530,4 +534,4 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
         ms_h, Vs_h = _to_host(ms, Vs)
         out = s_finals, np.swapaxes(ms_h, 0, 1), np.swapaxes(Vs_h, 0, 1)
     logger.debug(f'[profile]   final smoother pass ({K} keypoints): {time.perf_counter() - t2:.3f}s')
-    return out
+    return out + (info,) if return_info else out

@@ -2,8 +2,9 @@
 // pair of hipEvents recorded on the caller's stream (no synchronisation at record time).
 // eks_profile_drain() synchronises on the recorded events and returns (name, milliseconds) pairs.
 // Used by bench.py for the `roofline` object; off by default and then costs one branch per launch.
-// Level 2 brackets only the smoother's replay kernels (the HBM-roofline kernels): two event
-// records per step instead of twelve inside bench.py's timed region.
+// Level 2 brackets only the step's two roofline kernels - the smoother's replay kernels (HBM-bound) and the NLL
+// grid kernel (VALU-bound, the longest) - four event records per step instead of twelve inside bench.py's
+// timed region.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -69,8 +70,9 @@ static hipEvent_t take_event() {
 static bool scope_live(const char* name) {
   if (g_prof_level == 1) return true;
   if (g_prof_level != 2) return false;
+  // the roofline kernels of a step: the smoother's replay (HBM-bound) and the NLL grid (VALU-bound, the longest)
   const size_t n = strlen(name);
-  return n >= 7 && strcmp(name + n - 7, "_replay") == 0;
+  return (n >= 7 && strcmp(name + n - 7, "_replay") == 0) || strcmp(name, "diag_nll_summarize") == 0;
 }
 
 ProfScope::ProfScope(const char* name, hipStream_t st) : name_(name), st_(st), live_(scope_live(name)) {

@@ -116,6 +116,58 @@ def gather_session_results(local: dict[int, np.ndarray], n_sessions: int, group=
     return [merged[i] for i in range(n_sessions)]
 
 
+def rank_identity(group=None) -> dict:
+    """Who this rank is and which device it drives: rank, local rank, host, backend, device ordinal, device
+    name and PCI address (domain:bus:device) - what a multi-GPU run needs on record to show that N ranks
+    really ran on N distinct GPUs.  No device context is created for a process without a visible GPU."""
+    import os
+    import socket
+    import torch
+    dist = _dist()
+    rank, world = _rank_world(group)
+    ident = dict(rank=rank, world_size=world, local_rank=int(os.environ.get('LOCAL_RANK', 0)),
+                 host=socket.gethostname(), pid=os.getpid(),
+                 backend=dist.get_backend(group) if (dist.is_available() and dist.is_initialized()) else None,
+                 device=None, device_name=None, pci_bus_id=None)
+    if torch.cuda.is_available():
+        i = torch.cuda.current_device()
+        prop = torch.cuda.get_device_properties(i)
+        dom, bus, devid = (getattr(prop, a, None) for a in ('pci_domain_id', 'pci_bus_id', 'pci_device_id'))
+        ident.update(device=i, device_name=prop.name,
+                     pci_bus_id=None if bus is None else f'{int(dom or 0):04x}:{int(bus):02x}:{int(devid or 0):02x}',
+                     device_uuid=str(getattr(prop, 'uuid', '')) or None,
+                     visible_devices=torch.cuda.device_count())
+    return ident
+
+
+def gather_rank_identities(group=None) -> list[dict]:
+    """rank_identity() of every rank, on every rank (one all_gather_object: a few hundred bytes per rank,
+    outside any timed region)."""
+    dist = _dist()
+    me = rank_identity(group)
+    world = me['world_size']
+    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+        return [me]
+    out = [None] * world
+    dist.all_gather_object(out, me, group=group)
+    return sorted(out, key=lambda d: d['rank'])
+
+
+def check_distinct_devices(identities: list[dict]) -> None:
+    """Under RCCL (`nccl`) every rank must drive its own GPU: raise if two ranks of one host report the same
+    device (PCI address where the runtime exposes it, else the ordinal).  Under gloo ranks may share a GPU
+    (the CPU / one-GPU test configurations) and nothing is checked."""
+    if not identities or identities[0].get('backend') != 'nccl':
+        return
+    seen = {}
+    for d in identities:
+        key = (d['host'], d.get('pci_bus_id') or d.get('device_uuid') or d.get('device'))
+        if key in seen:
+            raise RuntimeError(f'ranks {seen[key]} and {d["rank"]} drive the same GPU {key}: RCCL needs one GPU per '
+                               'rank (launch with one process per device; LOCAL_RANK selects it)')
+        seen[key] = d['rank']
+
+
 # ------------------------------------------------------------------------------------------
 # drivers
 # ------------------------------------------------------------------------------------------

@@ -235,8 +235,8 @@ int eks_multicam_tables(int32_t n_views, int32_t n_frames, int32_t n_keypoints, 
                         eks_stream_t stream);
 
 /* ---- optional per-kernel timing (used by bench.py's roofline object).  on = 1: each kernel launch
- * (stage) is bracketed by hipEvents on the caller's stream; on = 2: only the smoother's replay
- * kernels (the HBM-roofline kernels); 0: off. eks_profile_drain waits for the
+ * (stage) is bracketed by hipEvents on the caller's stream; on = 2: only the roofline kernels - the
+ * smoother's replay kernels (HBM-bound) and the NLL grid kernel (VALU-bound); 0: off. eks_profile_drain waits for the
  * recorded events, writes up to max_n NUL-terminated kernel names back to back into `names` and
  * their durations in milliseconds into `ms`, clears the record and returns the count. -------- */
 int eks_profile_enable(int on);

@@ -185,3 +185,49 @@ def test_two_ranks_gloo_batched_sessions_and_keypoint_shards(tmp_path):
     assert k0['s_all'][1] == k0['s_all'][4]
     for k in (k0, k1):
         np.testing.assert_allclose(k['ms'], ms[k['own']], rtol=1e-10, atol=1e-12)
+
+
+def _worker_ws8(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    K = 250                                              # ragged: 250 keypoints do not divide by 8
+    big = _session(77, K=K, T=24)
+    blocks = [[3, 4, 5, 200], [17, 249]] + [[k] for k in range(K) if k not in (3, 4, 5, 200, 17, 249)]
+    s_all, own, ms, Vs = D.smooth_session_keypoint_sharded(**big, blocks=blocks, smooth_fn=_cpu_smooth, safety_cap=2)
+    ids = D.gather_rank_identities()
+    D.check_distinct_devices(ids)                        # gloo: ranks may share a device, nothing to check
+    np.savez(os.path.join(out_dir, f'w{rank}.npz'), s_all=s_all, own=own, ms=ms,
+             ranks=np.array([d['rank'] for d in ids]), pids=np.array([d['pid'] for d in ids]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_eight_ranks_gloo_ragged_keypoint_shards(tmp_path):
+    """World size 8 (the node the scaling bench runs on), K = 250 keypoints (not a multiple of 8) with two
+    multi-keypoint blocks: every keypoint is owned exactly once, blocks stay whole, every rank ends with the same
+    s_finals, the shards equal the single-process result; the ranks' identities are gathered and distinct."""
+    import torch.multiprocessing as mp
+    from oracle import eks_oracle as orc
+    world, K = 8, 250
+    mp.spawn(_worker_ws8, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(tmp_path / f'w{r}.npz') for r in range(world)]
+    owned = np.concatenate([r['own'] for r in res])
+    assert sorted(owned.tolist()) == list(range(K))
+    sizes = [len(r['own']) for r in res]
+    assert max(sizes) - min(sizes) <= 3, sizes           # greedy balance: blocks of 4 and 2 among singletons
+    for r in res:
+        np.testing.assert_array_equal(r['s_all'], res[0]['s_all'])
+        own = set(r['own'].tolist())
+        assert ({3, 4, 5, 200} <= own) or not ({3, 4, 5, 200} & own)
+        assert ({17, 249} <= own) or not ({17, 249} & own)
+        assert list(r['ranks']) == list(range(world)) and len(set(r['pids'].tolist())) == world
+    big = _session(77, K=K, T=24)
+    blocks = [[3, 4, 5, 200], [17, 249]] + [[k] for k in range(K) if k not in (3, 4, 5, 200, 17, 249)]
+    s, ms, _, _ = orc.run_kalman_smoother(**big, blocks=blocks, safety_cap=2)
+    np.testing.assert_allclose(res[0]['s_all'], s, rtol=1e-12)
+    assert s[3] == s[4] == s[5] == s[200] and s[17] == s[249]
+    for r in res:
+        np.testing.assert_allclose(r['ms'], ms[r['own']], rtol=1e-10, atol=1e-12)

@@ -45,6 +45,40 @@ def test_bench_two_rank_code_path():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
     out = json.loads(line)
     assert out['n_gpus'] == 2 and out['steps'] == 3 and out['scaling'] == 'weak' and out['value'] > 0
+    # who ran where is on record: two ranks, here sharing this box's one GPU over gloo
+    assert [d['rank'] for d in out['ranks']] == [0, 1] and all(d['backend'] == 'gloo' for d in out['ranks'])
+    assert all(d['device_name'] and d['pci_bus_id'] for d in out['ranks'])
+
+
+def test_bench_eight_ranks_self_launched():
+    """The node shape of the scaling bench - `python bench.py --gpus 8` - as far as a 1-GPU box can take it: eight
+    self-launched ranks share the GPU over gloo, every rank smooths its own configs[1] session, the s_finals
+    all-gather and the MAX-reduced regions run with a world of eight, and the line records all eight ranks."""
+    env = dict(os.environ, EKS_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '8', '--workload', 'c2', '--steps', '3', '--warmup', '1',
+                        '--regions', '2', '--no-cpu-baseline'], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert out['n_gpus'] == 8 and out['scaling'] == 'weak' and out['value'] > 0
+    assert [d['rank'] for d in out['ranks']] == list(range(8))
+    assert out['config']['parallelism'] == 'sessions x8'
+
+
+def test_rccl_distinct_device_check_refuses_two_ranks_on_one_gpu():
+    """Under RCCL the bench aborts before timing when two ranks report the same GPU (the check the first real
+    multi-GPU run relies on): unit-level, on fabricated identities plus this process's real one."""
+    from eks_amd import distributed as D
+    me = D.rank_identity()
+    assert me['device_name'] and me['pci_bus_id'] and me['visible_devices'] >= 1
+    a = dict(me, rank=0, backend='nccl')
+    b = dict(me, rank=1, backend='nccl')
+    with pytest.raises(RuntimeError, match='drive the same GPU'):
+        D.check_distinct_devices([a, b])
+    D.check_distinct_devices([a, dict(b, pci_bus_id='ffff:ff:1f', device=1)])
+    D.check_distinct_devices([dict(a, backend='gloo'), dict(b, backend='gloo')])
 
 
 def test_bench_launches_its_own_ranks():
