@@ -38,15 +38,17 @@ def rodrigues(rvec):
     return np.eye(3) + np.sin(theta) * Kx + (1.0 - np.cos(theta)) * (Kx @ Kx)
 
 
-def make_projection_fn(rot, tvec, Kmat, dist):
+def make_projection_fn(rot, tvec, Kmat, dist, dtype=np.float64):
     """world (...,3) -> pixels (...,2); accepts complex input (for the complex-step Jacobian).
-    `rot` is a rotation vector (3,) or matrix (3,3).  eks/multicam_smoother.py:799-868."""
+    `rot` is a rotation vector (3,) or matrix (3,3).  eks/multicam_smoother.py:799-868.
+    dtype=np.float32: constants rounded to float32, so that a float32 argument is projected in float32
+    arithmetic throughout (the reference's production precision; oracle/f32_forecast.py)."""
     rot = np.asarray(rot, dtype=np.float64)
-    R = rot if rot.shape == (3, 3) else rodrigues(rot)
-    t = np.asarray(tvec, dtype=np.float64).ravel()
-    Kmat = np.asarray(Kmat, dtype=np.float64)
+    R = (rot if rot.shape == (3, 3) else rodrigues(rot)).astype(dtype)
+    t = np.asarray(tvec, dtype=np.float64).ravel().astype(dtype)
+    Kmat = np.asarray(Kmat, dtype=np.float64).astype(dtype)
     fx, fy, cx, cy, skew = Kmat[0, 0], Kmat[1, 1], Kmat[0, 2], Kmat[1, 2], Kmat[0, 1]
-    dc = np.zeros(14)
+    dc = np.zeros(14, dtype=dtype)
     dist = np.asarray(dist, dtype=np.float64).ravel()
     dc[:len(dist)] = dist[:14]
     k1, k2, p1, p2, k3, k4, k5, k6, s1, s2, s3, s4 = dc[:12]

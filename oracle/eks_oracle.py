@@ -211,6 +211,118 @@ def filter_nll(y, m0, S0, A, C, Q, s, R, *, jitter=0.0, symmetrize=True, want_gr
 
 
 # --------------------------------------------------------------------------------------------
+# float32 EMULATION of the upstream recursion: what the reference's own numbers
+# look like.  The reference runs dynamax in float32 (jax's default; eks/ never enables x64: SURVEY.md
+# D5 / A.4), in the covariance form, with dynamax's operation order (recalled from
+# dynamax <= 1.0.1 `_condition_on` / `_predict` / `extended_kalman_smoother`):
+#     S = R + H P H^T ; ll += MVN(h(m), S).log_prob(y)   (tfp: Cholesky of S, triangular solve)
+#     K = psd_solve(S, H P)^T                            (Cholesky solve of sym(S) + 1e-9 I)
+#     P <- P - K S K^T ; m <- m + K (y - h(m)) ; P <- (P + P^T) / 2
+#     m <- A m ; P <- A P A^T + s Q
+#     backward: G = psd_solve(s Q + A P_f A^T, A P_f)^T ; m_s = m_f + G (m_s+ - A m_f) ;
+#               P_s = P_f + G (P_s+ - S_pred) G^T
+# Every array and every intermediate is float32 here (NumPy keeps float32 through matmul / Cholesky;
+# the triangular solves are written out so that nothing is silently promoted).  XLA's fusion and
+# FMA choices differ from NumPy's in the last bit of each operation, so this is an emulation of the
+# MAGNITUDE of upstream's rounding - the forecast of tests/test_f32_forecast.py - not a bitwise twin.
+# --------------------------------------------------------------------------------------------
+def _chol_solve_f32(S, B, jitter):
+    """psd_solve(S, B): X with (sym(S) + jitter I) X = B by Cholesky, float32 throughout.
+    S (K,n,n), B (K,n,m) -> (K,n,m)."""
+    f = np.float32
+    n = S.shape[-1]
+    Sj = (f(0.5) * (S + np.swapaxes(S, -1, -2)) + f(jitter) * np.eye(n, dtype=f)).astype(f)
+    L = np.linalg.cholesky(Sj).astype(f)
+    Z = np.empty_like(B)
+    for i in range(n):                                   # L Z = B
+        acc = B[:, i, :].copy()
+        for j in range(i):
+            acc = acc - L[:, i, j, None] * Z[:, j, :]
+        Z[:, i, :] = acc / L[:, i, i, None]
+    X = np.empty_like(B)
+    for i in range(n - 1, -1, -1):                       # L^T X = Z
+        acc = Z[:, i, :].copy()
+        for j in range(i + 1, n):
+            acc = acc - L[:, j, i, None] * X[:, j, :]
+        X[:, i, :] = acc / L[:, i, i, None]
+    return X
+
+
+def _mvn_logpdf_f32(e, S):
+    """tfp MultivariateNormalFullCovariance(loc, S).log_prob(y) with e = y - loc, float32: scale_tril =
+    cholesky(S), -0.5 |L^-1 e|^2 - sum log diag L - 0.5 n log 2 pi."""
+    f = np.float32
+    n = S.shape[-1]
+    L = np.linalg.cholesky(S).astype(f)
+    z = np.empty_like(e)
+    for i in range(n):
+        acc = e[:, i].copy()
+        for j in range(i):
+            acc = acc - L[:, i, j] * z[:, j]
+        z[:, i] = acc / L[:, i, i]
+    logdet_half = np.log(np.diagonal(L, axis1=-2, axis2=-1)).astype(f).sum(axis=-1, dtype=f)
+    return (f(-0.5) * (z * z).sum(axis=-1, dtype=f) - logdet_half - f(0.5 * n * LOG2PI)).astype(f)
+
+
+def kalman_smoother_f32(y, m0, S0, A, C, Q, s, R, *, jitter=1e-9, symmetrize=True, emission=None):
+    """The upstream recursion in float32 (see the block comment above).  Arguments as kalman_smoother (they are
+    rounded to float32 on entry, as `jnp.asarray` does upstream).  `emission(m (K,D) float32) -> (h(m) (K,O),
+    dh/dx (K,O,D))` in float32 replaces the linear C (the extended filter of eks/core.py:188-190 linearised at the
+    predicted mean; C is then ignored).  Returns (ms, Vs, nll) as float32 arrays."""
+    f = np.float32
+    y = np.asarray(y, f)
+    K, T, O = y.shape
+    m0 = np.asarray(m0, f)
+    D = m0.shape[-1]
+    A = np.asarray(A, f)
+    C = None if emission is not None else np.asarray(C, f)
+    At = _T(A)
+    sQ = (np.broadcast_to(np.asarray(s, f), (K,))[:, None, None] * np.asarray(Q, f)).astype(f)   # eks/core.py:152
+    R = np.asarray(R, f)
+    eyeO = np.eye(O, dtype=f)
+    if R.shape == (K, T, O):
+        Rt = lambda t: R[:, t, :, None] * eyeO
+    elif R.shape == (K, O):
+        Rc = R[:, :, None] * eyeO
+        Rt = lambda t: Rc
+    else:
+        raise ValueError(f'bad R shape {R.shape}')
+    mf = np.empty((K, T, D), f)
+    Pf = np.empty((K, T, D, D), f)
+    ll = np.zeros(K, f)
+    m, P = m0.copy(), np.asarray(S0, f).copy()
+    for t in range(T):
+        if emission is None:
+            H, yhat = C, np.einsum('kod,kd->ko', C, m)
+        else:
+            yhat, H = emission(m)
+            assert yhat.dtype == f and H.dtype == f
+        HP = np.matmul(H, P)                                        # (K,O,D)
+        S = (Rt(t) + np.matmul(HP, _T(H))).astype(f)
+        e = y[:, t] - yhat
+        ll = (ll + _mvn_logpdf_f32(e, S)).astype(f)
+        Kg = _T(_chol_solve_f32(S, HP, jitter))                     # (K,D,O)
+        P = P - _bmm(Kg, S, _T(Kg))
+        m = m + np.einsum('kdo,ko->kd', Kg, e)
+        if symmetrize:
+            P = f(0.5) * (P + _T(P))
+        mf[:, t], Pf[:, t] = m, P
+        m = np.einsum('kde,ke->kd', A, m)
+        P = _bmm(A, P, At) + sQ
+    ms, Vs = np.empty_like(mf), np.empty_like(Pf)
+    ms[:, -1], Vs[:, -1] = mf[:, -1], Pf[:, -1]
+    for t in range(T - 2, -1, -1):
+        m_pred = np.einsum('kde,ke->kd', A, mf[:, t])
+        AP = np.matmul(A, Pf[:, t])
+        S_pred = sQ + np.matmul(AP, At)
+        G = _T(_chol_solve_f32(S_pred, AP, jitter))
+        ms[:, t] = mf[:, t] + np.einsum('kde,ke->kd', G, ms[:, t + 1] - m_pred)
+        Vs[:, t] = Pf[:, t] + _bmm(G, Vs[:, t + 1] - S_pred, _T(G))
+    assert ms.dtype == f and Vs.dtype == f and ll.dtype == f
+    return ms, Vs, -ll
+
+
+# --------------------------------------------------------------------------------------------
 # independent formulation #2: information-form filter + two-filter smoother (diagonal R only)
 # --------------------------------------------------------------------------------------------
 def info_form_smoother(y, m0, S0, A, C, Q, s, Rdiag):
