@@ -648,6 +648,225 @@ __global__ __launch_bounds__(64 * kAsmWaves) void diag_nll_assemble_par_kernel(N
   nll[(size_t)k * G.n_cand + ci] = isfinite(v) ? v : 1e12;                // eks/core.py:650
 }
 
+// ---- grid search, round 4: head + lean roles in ONE launch ------------------------------------------------------
+// The 64-candidate grid is 2 FMAs per frame, chain and candidate; the general kernel above carries every regime's
+// state through the frame loop (256 VGPRs at 8 candidates per lane: 8 waves per (tile, chunk), 18 % of its VALU
+// instructions are not those FMAs and its chunk-0 blocks set the launch's length).  Here
+//   * blocks [0, nhead): HEAD role - chunk 0 of every chain (known entry state, transient regimes) through the
+//     general lane body at 4 candidates per lane: ntile x n_cand / 4 short waves that start first and run beside
+//     the rest;
+//   * the other blocks: LEAN role - block = (64-chain tile, chunk j >= 1), wave = 16 candidates: nll_lean_chunk,
+//     the converged-entry summary alone (~180 VGPRs: two waves per SIMD, half the row loads and shared dy per
+//     candidate-FMA, the candidates' constants parked in LDS).  A wave whose chunk does not qualify (wave-uniform:
+//     the filter variance has not converged that early in the sequence) summarises it with the exact-entry code, 4
+//     candidates at a time, and raises the (chunk, tile, group) flag; a pole so close to one that rho^t outlives
+//     the chunk keeps the lean form with A = rho^len (flag 2).  Flagged (tile, candidate)s are assembled in order.
+// Lean summaries are three planes (b, eta float32, ell float64: 16 B per chunk, chain and candidate instead of 28):
+// A = 0, C = -1 are implied and J is a constant of the (chain, candidate), written once by the head wave.
+constexpr int kLeanNC = 16;
+constexpr int kHeadNCL = 4;
+constexpr int kLeanWaves = 4;                // waves per block, both roles
+
+struct LeanGeom {
+  int nhead_blocks;      // head role: ceil(ntile * ngrp4 / kLeanWaves)
+  int ngrp4, ngrp16;     // candidate groups of the two roles
+  int32_t* flags;        // [ncn][ntile][ngrp16]: 1 = exact-entry summary (full planes valid)
+  float* Jc;             // [ncp][N]: J of a converged-entry summary
+};
+
+template <bool UNIT>
+__global__ __launch_bounds__(64 * kLeanWaves, 2) void diag_nll_grid_kernel(NllGeom G, LeanGeom LG, DiagModel M, NllWs W,
+                                                                         const float* __restrict__ y,
+                                                                         const double* __restrict__ rconst,
+                                                                         const double* __restrict__ s_cand) {
+  __shared__ float stash[kLeanWaves][4 * kLeanNC][64];
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  auto store_full = [&](int j, int ci, int n, const NllElem<float>& o) {
+    const size_t off = ((size_t)j * W.ncp + ci) * G.N + n;
+    W.A[off] = o.e.A;
+    W.b[off] = o.e.b;
+    W.C[off] = o.e.C;
+    W.eta[off] = o.e.eta;
+    W.J[off] = o.e.J;
+    W.ell[off] = o.ell;
+  };
+  if ((int)blockIdx.x < LG.nhead_blocks) {
+    // ---- head: chunk 0, kHeadNCL candidates per lane
+    const int hw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * kLeanWaves + w);
+    const int tile = hw / LG.ngrp4, g = hw - tile * LG.ngrp4;
+    if (tile >= G.ntile) return;
+    const int n = tile * 64 + lane;
+    if (n >= G.N) return;
+    const int k = n / G.D, d = n - k * G.D;
+    const size_t dd = (size_t)k * G.D * G.D + (size_t)d * (G.D + 1);
+    const double q = M.Q[dd], r_n = rconst[n], a_n = M.A[dd], c_n = M.C[dd];
+    double sq[kHeadNCL];
+#pragma unroll
+    for (int c = 0; c < kHeadNCL; ++c) {
+      const int ci = min(g * kHeadNCL + c, G.n_cand - 1);
+      sq[c] = (G.per_keypoint ? s_cand[(size_t)k * G.n_cand + ci] : s_cand[ci]) * q;
+    }
+    const int len = min(G.B0, G.T);
+    const BufferRows ld{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(y + tile * 64), 0, 0x7FFFFFFF, 0x00020000),
+                        (unsigned)(lane * 4), (unsigned)(G.N * 4)};
+    NllElem<float> out[kHeadNCL];
+    nll_summarize_chunk<float, kHeadNCL, UNIT>(ld, 0, len, r_n, a_n, c_n, sq, out, false);
+    if (g == 0) W.xr[n] = out[0].xref;
+#pragma unroll
+    for (int c = 0; c < kHeadNCL; ++c) {
+      const int ci = g * kHeadNCL + c;
+      if (ci >= G.n_cand) continue;
+      store_full(0, ci, n, out[c]);
+      // J of this candidate's converged-entry summaries: c cg / (1 - rho^2) as nll_lean_chunk forms it
+      const LeanConst lc = lean_const<UNIT>(r_n, a_n, c_n, sq[c]);
+      const float c_cg = UNIT ? lc.cg : (float)c_n * lc.cg;
+      LG.Jc[(size_t)ci * G.N + n] = c_cg / (1.f - lc.rho * lc.rho);
+    }
+    return;
+  }
+  // ---- lean: (tile, chunk j >= 1), wave = 16 candidates
+  const int lb = (int)blockIdx.x - LG.nhead_blocks;
+  const int tile = lb % G.ntile, j = 1 + lb / G.ntile;
+  if (w >= LG.ngrp16 || j >= G.ncn) return;
+  const int n_raw = tile * 64 + lane;
+  const bool chain_ok = n_raw < G.N;
+  const int n = chain_ok ? n_raw : G.N - 1;              // lanes past the last chain shadow it (nothing stored)
+  const int k = n / G.D, d = n - k * G.D;
+  const size_t dd = (size_t)k * G.D * G.D + (size_t)d * (G.D + 1);
+  const double q = M.Q[dd], r_n = rconst[n], a_n = M.A[dd], c_n = M.C[dd];
+  const int t0 = G.B0 + (j - 1) * G.BN, len = min(G.BN, G.T - t0);
+  const BufferRows ld{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(y + (size_t)t0 * G.N + tile * 64), 0,
+                                                        0x7FFFFFFF, 0x00020000),
+                      (unsigned)((n - tile * 64) * 4), (unsigned)(G.N * 4)};
+  const double* sc = G.per_keypoint ? s_cand + (size_t)k * G.n_cand : s_cand;
+  // the grid's candidates are dealt to the tile's waves round-robin: slot c of wave w is candidate c ngrp16 + w, so
+  // every wave holds the same mix of slow and fast candidates, slowest first (the staged alive phase of
+  // nll_lean_chunk then costs every wave the same, a few per cent; contiguous groups left the slowest group's
+  // waves 25 % longer than the rest of a launch whose blocks all run in one round)
+  const int ncand = G.n_cand, stride16 = LG.ngrp16;
+  auto cand_of = [&](int c) { return c * stride16 + w; };
+  auto sqf = [&](int c) { return sc[min(cand_of(c), ncand - 1)] * q; };
+  // the summary's fields go straight to the planes as the lane body produces them (nothing rides through the frame
+  // loops in registers)
+  struct Sink {
+    const NllWs& W;
+    size_t base, cstride;      // plane offset of candidate slot 0, distance between slots
+    size_t xr_off;
+    int nvalid;                // slots whose candidate exists
+    bool store, store_xr;
+    __device__ __forceinline__ void xref(float v) const { if (store_xr) W.xr[xr_off] = v; }
+    __device__ __forceinline__ void eta(int k, float v) const { if (store && k < nvalid) W.eta[base + k * cstride] = v; }
+    __device__ __forceinline__ void aj(int k, float a, float jv) const {
+      if (store && k < nvalid) {
+        W.A[base + k * cstride] = a;
+        W.J[base + k * cstride] = jv;
+      }
+    }
+    __device__ __forceinline__ void b(int k, float v) const { if (store && k < nvalid) W.b[base + k * cstride] = v; }
+    __device__ __forceinline__ void ell(int k, double v) const { if (store && k < nvalid) W.ell[base + k * cstride] = v; }
+  };
+  // slot c is candidate c stride16 + w: valid while c stride16 + w < n_cand
+  const int nvalid = ncand > w ? (ncand - w + stride16 - 1) / stride16 : 0;
+  Sink sink{W, ((size_t)j * W.ncp + w) * G.N + n, (size_t)stride16 * G.N, (size_t)j * G.N + n,
+            nvalid < kLeanNC ? nvalid : kLeanNC, chain_ok, chain_ok && w == 0};
+  const int lean = nll_lean_chunk<kLeanNC, UNIT>(ld, t0, len, r_n, a_n, c_n, sqf, &stash[w][0][lane], 64, sink);
+  // flag: 0 lean summary with A = 0 (the usual case) | 2 lean summary with A = rho^len != 0 (own A, J planes) |
+  // 1 exact-entry summary (full planes) - anything but 0 sends the (tile, candidate)'s assembly down the sequential walk
+  if (lane == 0) LG.flags[((size_t)j * G.ntile + tile) * LG.ngrp16 + w] = lean == 1 ? 0 : (lean == 2 ? 2 : 1);
+  if (lean) return;
+  // ---- the chunk does not qualify for the converged-entry summary: exact entry, kHeadNCL candidates at a time
+  for (int h = 0; h < kLeanNC / kHeadNCL; ++h) {
+    double sq[kHeadNCL];
+#pragma unroll
+    for (int c = 0; c < kHeadNCL; ++c) sq[c] = sqf(h * kHeadNCL + c);
+    NllElem<float> o4[kHeadNCL];
+    nll_summarize_chunk<float, kHeadNCL, UNIT>(ld, t0, len, r_n, a_n, c_n, sq, o4, false);
+    if (!chain_ok) continue;
+    if (w == 0 && h == 0) W.xr[(size_t)j * G.N + n] = o4[0].xref;
+#pragma unroll
+    for (int c = 0; c < kHeadNCL; ++c) {
+      const int ci = cand_of(h * kHeadNCL + c);
+      if (ci < G.n_cand) store_full(j, ci, n, o4[c]);
+    }
+  }
+}
+
+// assembly of the grid kernel's summaries: as diag_nll_assemble_par_kernel, reading the compact planes; a chain with
+// an exact-entry summary past chunk 0 (flagged) takes the sequential walk over a getter that knows both forms.
+__global__ __launch_bounds__(64 * kAsmWaves) void diag_nll_assemble_lean_kernel(NllGeom G, LeanGeom LG, DiagModel M,
+                                                                               NllWs W, double* __restrict__ nll) {
+  extern __shared__ double dyn[];                  // b_next[ncn][64] | part[kAsmWaves][64]
+  __shared__ int seq;                              // some chunk of this (tile, candidate) has an exact-entry summary
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tile = blockIdx.x % G.ntile, ci = blockIdx.x / G.ntile;
+  const int n = tile * 64 + lane;
+  const bool live = n < G.N;
+  double* bnext = dyn;
+  double* part = dyn + (size_t)G.ncn * 64;
+  const int g16 = ci % LG.ngrp16;                  // the lean wave that owns this candidate (dealt round-robin)
+  if (threadIdx.x == 0) seq = 0;
+  __syncthreads();
+  const int k = live ? n / G.D : 0, d = live ? n - k * G.D : 0;
+  const size_t dd = (size_t)k * G.D * G.D + (size_t)d * (G.D + 1);
+  double ll0 = 0.0;
+  for (int j = w; j < G.ncn; j += kAsmWaves) {
+    if (j > 0 && LG.flags[((size_t)j * G.ntile + tile) * LG.ngrp16 + g16] != 0) seq = 1;   // (wave-uniform)
+    if (!live) continue;
+    const size_t o = ((size_t)j * W.ncp + ci) * G.N + n;
+    if (j == 0) {
+      const double A = W.A[o], b = W.b[o], eta = W.eta[o], J = W.J[o], ell = W.ell[o];
+      const double xr = (double)W.xr[n];
+      const double m = M.m0[(size_t)k * G.D + d], P = M.S0[dd];
+      const double mr = m - xr, den = 1.0 + J * P, inv = 1.0 / den;
+      ll0 = ell - 0.5 * log(den) + (eta * mr + 0.5 * eta * eta * P - 0.5 * J * mr * mr) * inv;
+      bnext[lane] = A * inv * (mr + P * eta) + b;
+    } else {
+      bnext[(size_t)j * 64 + lane] = W.b[o];
+    }
+  }
+  __syncthreads();
+  const bool sequential = seq != 0;
+  double acc = (w == 0) ? ll0 : 0.0;
+  if (!sequential && live) {
+    const double J = (double)LG.Jc[(size_t)ci * G.N + n];
+    for (int j = (w == 0 ? kAsmWaves : w); j < G.ncn; j += kAsmWaves) {
+      const size_t o = ((size_t)j * W.ncp + ci) * G.N + n;
+      const double eta = W.eta[o], ell = W.ell[o];
+      const double mr = bnext[(size_t)(j - 1) * 64 + lane] - (double)W.xr[(size_t)j * G.N + n];
+      acc += ell + eta * mr - 0.5 * J * mr * mr;
+    }
+  }
+  part[w * 64 + lane] = acc;
+  __syncthreads();
+  if (w != 0) return;
+  double tot = 0.0;
+  if (live) {
+    if (sequential) {                              // rare: the generic sequential walk
+      auto get = [&](int j, Elem<double>& e, double& ell, double& xr) {
+        const size_t o = ((size_t)j * W.ncp + ci) * G.N + n;
+        xr = (double)W.xr[(size_t)j * G.N + n];
+        e.b = W.b[o]; e.eta = W.eta[o]; ell = W.ell[o];
+        const int fl = j == 0 ? 1 : LG.flags[((size_t)j * G.ntile + tile) * LG.ngrp16 + g16];
+        if (fl == 1) {
+          e.A = W.A[o]; e.C = W.C[o]; e.J = W.J[o];
+        } else if (fl == 2) {
+          e.A = W.A[o]; e.C = -1.0; e.J = W.J[o];
+        } else {
+          e.A = 0.0; e.C = -1.0; e.J = (double)LG.Jc[(size_t)ci * G.N + n];
+        }
+      };
+      tot = nll_assemble<double>(G.ncn, M.m0[(size_t)k * G.D + d], M.S0[dd], get);
+    } else {
+#pragma unroll
+      for (int q = 0; q < kAsmWaves; ++q) tot += part[q * 64 + lane];
+    }
+  }
+  for (int off = 1; off < G.D; off <<= 1) tot += __shfl_xor(tot, off);   // the keypoint's D chains
+  if (!live || d != 0) return;
+  const double v = -tot;
+  nll[(size_t)k * G.n_cand + ci] = isfinite(v) ? v : 1e12;                // eks/core.py:650
+}
+
 // may the gradient evaluation take the single-launch kernel (diag_nll_grad_fused_kernel)?  One value of s
 // per keypoint, whole 64-chain tiles addressed through 32-bit buffer offsets, the chains of a keypoint in
 // adjacent lanes of one wave.
@@ -669,6 +888,44 @@ static int grad_fused_chunk(int T, int N) {
   if (bn < kGfChunkMin) bn = kGfChunkMin;
   const int b = knob_int(KNOB_NLL_GRAD_CHUNK, (int)bn);
   return b < 8 ? 8 : b;
+}
+
+// may the grid search take diag_nll_grid_kernel?  Whole 64-chain tiles, the chains of a keypoint in adjacent lanes
+// of one wave, at least one lean wave's worth of candidates, a sequence long enough for chunks past the first, and
+// the assembly's chunk table within LDS.
+constexpr int kLeanChunk = 1600;       // target frames per lean chunk (C3: 62 chunks + chunk 0: one round of 512 blocks)
+constexpr int kLeanChunkMin = 1024;    // (shorter chunks: rho^t of the slow candidates outlives them - A != 0 summaries)
+// chunk geometry of the grid kernel: chunk 0 of b0 frames, then chunks of bn; blocks = head + tiles x chunks fill a
+// whole number of rounds of 2 blocks per CU.  Returns ncn (0: the sequence is too short for chunks past the first).
+static int lean_geometry(int T, int N, int n_cand, int* b0_out, int* bn_out) {
+  const int b0 = knob_int(KNOB_NLL_CHUNK0, kNllChunk0);
+  if (T < b0 + kLeanChunkMin) return 0;
+  const long ntile = (N + 63) / 64;
+  const long nhead = (ntile * ((n_cand + kHeadNCL - 1) / kHeadNCL) + kLeanWaves - 1) / kLeanWaves;
+  const long rest = T - b0;
+  const int target = knob_int(KNOB_NLL_CHUNK, kLeanChunk);
+  long rounds = (rest * ntile + 256L * target) / (512L * target);
+  if (rounds < 1) rounds = 1;
+  long nch = (512 * rounds - nhead) / ntile;
+  if (nch < 1) nch = 1;
+  long bn = (rest + nch - 1) / nch;
+  bn = (bn + 15) / 16 * 16;
+  if (bn < kLeanChunkMin) bn = kLeanChunkMin;
+  if (knob_set(KNOB_NLL_CHUNK)) bn = target < 64 ? 64 : (target + 15) / 16 * 16;      // (A/B runs and tests)
+  *b0_out = b0;
+  *bn_out = (int)bn;
+  return 1 + (int)((rest + bn - 1) / bn);
+}
+// may the grid search take diag_nll_grid_kernel?  Whole 64-chain tiles, the chains of a keypoint in adjacent lanes
+// of one wave, at least one lean wave's worth of candidates, a sequence long enough for chunks past the first, a
+// chunk within 32-bit buffer offsets, and the assembly's chunk table within LDS.
+static bool lean_grid_ok(int T, int N, int D, int n_cand) {
+  if (knob_int(KNOB_NLL_LEGACY, 0)) return false;
+  if (n_cand < kLeanNC || N <= 32 || (D & (D - 1)) != 0 || D > 64) return false;
+  int b0, bn;
+  const int ncn = lean_geometry(T, N, n_cand, &b0, &bn);
+  if (ncn < 2 || (long)(bn > b0 ? bn : b0) * N * 4 >= (1L << 31)) return false;
+  return ((size_t)ncn + kAsmWaves) * 64 * sizeof(double) <= 60 * 1024;
 }
 
 static NllGeom make_geom(int T, int N, int D, int n_cand, int per_keypoint, bool grad, int ncl) {
@@ -745,7 +1002,7 @@ bool diag_nll_grad_tree(int T, int K, int D) {
 size_t diag_nll_workspace_bytes(int T, int N, int n_cand) {
   // sized for the larger of the two modes (grad planes + smaller chunks)
   const int ncn = (T + kNllChunkGrad - 1) / kNllChunkGrad + 1;
-  const size_t ncp = align_up((size_t)n_cand, kNclGrid);
+  const size_t ncp = align_up((size_t)n_cand, 16);      // (kLeanNC: the grid kernel pads to whole lean waves)
   const size_t fl = align_up((size_t)ncn * ncp * N * sizeof(float), 256);
   const size_t db = align_up((size_t)ncn * ncp * N * sizeof(double), 256);
   // 10 element planes + the chunk references (one candidate's worth is used) + the Adam loop's
@@ -794,6 +1051,46 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
                            dnll, F);
       return hip_status(hipGetLastError());
     }
+  }
+  // ---- grid search on whole 64-chain tiles: head + lean roles in one launch (round 4)
+  if (!grad && !F.state && lean_grid_ok(T, N, D, n_cand)) {
+    G.nt_log2 = 6;
+    G.ntile = (N + 63) / 64;
+    G.ngrp = 0;
+    G.converged_entry = 1;
+    G.ncn = lean_geometry(T, N, n_cand, &G.B0, &G.BN);
+    LeanGeom LG;
+    LG.ngrp4 = (n_cand + kHeadNCL - 1) / kHeadNCL;
+    LG.ngrp16 = (n_cand + kLeanNC - 1) / kLeanNC;
+    LG.nhead_blocks = (G.ntile * LG.ngrp4 + kLeanWaves - 1) / kLeanWaves;
+    NllWs W;
+    W.ncp = (int)align_up((size_t)n_cand, kLeanNC);
+    const size_t fl = align_up((size_t)G.ncn * W.ncp * N * sizeof(float), 256);
+    const size_t db = align_up((size_t)G.ncn * W.ncp * N * sizeof(double), 256);
+    if (2 * db + 11 * fl + adam_extra_bytes(N) > ws_bytes) return EKS_ERR_WORKSPACE;
+    char* p = static_cast<char*>(ws);
+    W.ell = reinterpret_cast<double*>(p);
+    W.dell = nullptr;
+    LG.flags = reinterpret_cast<int32_t*>(p + db);          // (the gradient's plane: unused on this path)
+    p += 2 * db;
+    float** planes[7] = {&W.A, &W.b, &W.C, &W.eta, &W.J, &LG.Jc, &W.xr};
+    for (int i = 0; i < 7; ++i) *planes[i] = reinterpret_cast<float*>(p + i * fl);
+    W.dA = W.db = W.dC = W.deta = W.dJ = nullptr;
+    if ((size_t)G.ncn * G.ntile * LG.ngrp16 * sizeof(int32_t) > db || (long)G.BN * N * 4 >= (1L << 31))
+      return EKS_ERR_WORKSPACE;
+    {
+      ProfScope ps("diag_nll_summarize", st);
+      const dim3 grid((unsigned)(LG.nhead_blocks + G.ntile * (G.ncn - 1))), block(64 * kLeanWaves);
+      if (d.flags & EKS_FLAG_UNIT_AC)
+        hipLaunchKernelGGL(diag_nll_grid_kernel<true>, grid, block, 0, st, G, LG, M, W, y, rconst, s_cand);
+      else
+        hipLaunchKernelGGL(diag_nll_grid_kernel<false>, grid, block, 0, st, G, LG, M, W, y, rconst, s_cand);
+    }
+    ProfScope ps2("diag_nll_assemble", st);
+    const size_t shm = ((size_t)G.ncn + kAsmWaves) * 64 * sizeof(double);
+    hipLaunchKernelGGL(diag_nll_assemble_lean_kernel, dim3((unsigned)(G.ntile * n_cand)), dim3(64 * kAsmWaves), shm, st,
+                       G, LG, M, W, nll);
+    return hip_status(hipGetLastError());
   }
   // (the tree cannot take converged-entry summaries: they are only valid in sequential order)
   const bool tree = nll_uses_tree(K, D, n_cand, G.ncn);

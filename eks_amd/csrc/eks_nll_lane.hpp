@@ -28,8 +28,20 @@
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define EKS_WAVE_ALL(x) (__all(x) != 0)
+// no instruction moves across this point: keeps the machine scheduler from interleaving the frames of an unrolled
+// block (it otherwise holds 16 frames' worth of innovations live to cluster the FMAs, and spills)
+#define EKS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// ties values together at a point of the program (no instruction is emitted; they are opaque to the optimiser
+// from here on).  Without it the optimiser takes the frame loop of the alive phase apart: the data-independent
+// recurrence rho^t is run a whole unrolled block ahead, the accumulations are sunk to the block that flushes
+// them, and sixteen frames' worth of intermediates go through scratch memory
+#define EKS_OPAQUE4(x, y, z, u) asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(u))
+#define EKS_OPAQUE2(x, y) asm volatile("" : "+v"(x), "+v"(y))
 #else
+#define EKS_OPAQUE4(x, y, z, u) do { } while (0)
+#define EKS_OPAQUE2(x, y) do { } while (0)
 #define EKS_WAVE_ALL(x) (x)
+#define EKS_SCHED_FENCE() do { } while (0)
 #endif
 
 namespace eks {
@@ -632,6 +644,315 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
     L.template consume<1>(y1);
   }
   nll_lane_finish<R, NCL, UNIT>(L, len, xref, out);
+}
+
+// ---- lean form of the converged-entry summary (round 4) -----------------------------------------------------
+// The grid search evaluates 64 candidates per chain; every chunk past the first enters with the converged filter
+// variance (see nll_summarize_chunk), i.e. needs none of the transient-regime state above.  nll_lean_chunk is that
+// branch alone, written so that nothing but the loops' own state is live inside them: NC candidates per lane
+// paired in 64-bit registers (rho, d, sum d^2; while rho^t is alive also rho^t and sum d rho^t), float64 running
+// sums, 16 frames of y in flight - ~180 VGPRs at NC = 16 where the general lane body needs 256 at NC = 8.  The
+// steady-state constants of a candidate are functions of (r, s q) alone: they are formed in float64 when needed
+// (lean_const: before the loops for the pole, after them for the gains) instead of being carried through.
+// Arithmetic and operation order per candidate are those of nll_summarize_chunk's converged-entry branch: for the
+// same chunk boundaries the two agree to float32 rounding of the constants (tests/test_host_sim.py).
+template <int N>
+struct IntTag {
+  static constexpr int value = N;
+};
+struct LeanConst {
+  float rho, g, rg, cg, logS;     // pole of the innovation recursion, 1 / S_inf, r / S_inf, c / S_inf, log S_inf
+};
+// float64 reciprocal / square root for positive, well-scaled arguments: hardware seed + Newton steps on the device
+// (the library routines' scaling and fix-up sequences cost more than the rest of lean_const together, and it runs
+// once per candidate and chunk), the library routines on the host.  Within an ulp or two of them - rho is rounded
+// to float32 afterwards, so the float32 value differs from the exactly rounded one in at most its last bit in
+// rare cases (an absolute 6e-8 on a pole whose distance from 1 is >= 1e-2 on the grid's slowest candidates).
+EKS_HD double lean_rcp(double x) { return rcp(x); }
+EKS_HD double lean_sqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(x);                       // ~1 / sqrt(x)
+  double h = 0.5 * y, g = x * y;                            // g ~ sqrt(x), h ~ 1 / (2 sqrt(x))
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  return __builtin_fma(__builtin_fma(-g, g, x), h, g);      // one residual correction
+#else
+  return sqrt(x);
+#endif
+}
+template <bool UNIT>
+EKS_HD LeanConst lean_const(double r_d, double a_d, double c_d, double sq) {
+  // riccati_fixed_point's value branch (its derivative is not needed here)
+  const double a1 = UNIT ? 1.0 : a_d, c1 = UNIT ? 1.0 : c_d;
+  const double c2 = c1 * c1;
+  const double beta = r_d * (1.0 - a1 * a1) - sq * c2;
+  const double disc = lean_sqrt(beta * beta + 4.0 * c2 * sq * r_d);
+  const double Ci = beta > 0.0 ? (2.0 * sq * r_d) * lean_rcp(beta + disc) : (disc - beta) * lean_rcp(2.0 * c2);
+  const double S_d = r_d + Ci * c2;
+  const double g_d = lean_rcp(S_d);
+  const double cg_d = c1 * g_d;
+  const double t_d = Ci * cg_d;
+  LeanConst k;
+  k.g = (float)g_d;
+  k.rg = (float)(r_d * g_d);
+  k.cg = (float)cg_d;
+  k.logS = -fast_log(k.g);                                  // log S = -log g, float32 (|error| ~1e-7: 1e-9 of an NLL)
+  k.rho = UNIT ? k.rg : (float)(a1 * (1.0 - c1 * t_d));
+  return k;
+}
+
+// A lean summary leaves the lane through a SINK as soon as each field is known (the kernel's sink stores straight
+// to the summary planes; nothing is carried in registers across the frame loops):
+//   sink.xref(x) | sink.eta(k, v) | sink.aj(k, A, J) (only for a summary with A != 0) | sink.b(k, v) | sink.ell(k, v)
+template <int NC>
+struct LeanOut {                      // a sink that just keeps the fields (host simulator, micro-benchmarks)
+  float A[NC], B[NC], Eta[NC], J[NC];
+  double Ell[NC];
+  float xr;
+  EKS_HD void xref(float v) { xr = v; }
+  EKS_HD void eta(int k, float v) { Eta[k] = v; }
+  EKS_HD void aj(int k, float a, float j) { A[k] = a; J[k] = j; }
+  EKS_HD void b(int k, float v) { B[k] = v; }
+  EKS_HD void ell(int k, double v) { Ell[k] = v; }
+};
+
+// One lane: chunk [t0, t0 + len) of one chain for NC candidates, converged entry.  `sq(k)` returns s_k q of the
+// lane's chain (fetched on demand: nothing candidate-specific stays in registers across the loops but the loop
+// state).  `stash` parks the candidates' constants (g, rg, cg, log S: 4 NC floats per lane, element i at
+// stash[i * stride]) between the start of the chunk and its end - LDS on the device, a local array in the host
+// simulator.  Returns, wave-uniformly,
+//   0  the chunk does not qualify (the filter variance has not converged t0 frames in: rho^(2 t0) >= 1e-20 for
+//      some candidate of the wave) - nothing has been consumed, the caller summarises it with the exact-entry code;
+//   1  summary with A = 0: rho^t died inside the chunk for every candidate (the usual case) - the mean entering
+//      the next chunk is b whatever came before, J is the (chain, candidate) constant c cg / (1 - rho^2);
+//   2  summary with A = rho^len != 0 for some candidate (a pole so close to one that rho^t outlives the chunk):
+//      sink.aj carries the chunk's own values and the assembly has to walk the chunks in order.
+template <int NC, bool UNIT, typename LD, typename SQ, typename SINK>
+EKS_HD int nll_lean_chunk(const LD& ld, int t0, int len, double r_d, double a_d, double c_d, const SQ& sq,
+                          float* stash, int stride, SINK& out) {
+  static_assert(NC % 2 == 0, "candidates are paired");
+  constexpr int NP = NC / 2;
+  constexpr float kDeadA = 1e-5f;                       // NllLane<float>::kDeadA
+  const int nfull = len / 8;
+  const float af = (float)a_d;
+  f32x2 rho2[NP];
+  bool ok = t0 > 0;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    float rr[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = 2 * p + h;
+      const LeanConst c = lean_const<UNIT>(r_d, a_d, c_d, sq(k));
+      stash[(4 * k + 0) * stride] = c.g;
+      stash[(4 * k + 1) * stride] = c.rg;
+      stash[(4 * k + 2) * stride] = c.cg;
+      stash[(4 * k + 3) * stride] = c.logS;
+      rr[h] = c.rho;
+      const float nl = -logf(fmaxf(fabsf(c.rho), 1e-30f));
+      ok = ok && fabsf(c.rho) < 1.f && 2.f * (float)t0 * nl > 46.f;
+    }
+    rho2[p] = f32x2{rr[0], rr[1]};
+  }
+  if (!EKS_WAVE_ALL(ok)) return 0;
+  const float y0 = len > 0 ? ld(0) : 0.f;
+  out.xref(UNIT ? y0 : y0 / (float)c_d);
+  float yprev = UNIT ? y0 : y0 / af;                    // reference start: the first innovation is y_0 - c xref = 0
+  f32x2 dk2[NP], s22[NP];
+  double acc2[NC];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    dk2[p] = f32x2{0.f, 0.f};
+    s22[p] = f32x2{0.f, 0.f};
+  }
+#pragma unroll
+  for (int k = 0; k < NC; ++k) acc2[k] = 0.0;
+  // Rows travel through a ring of kRing 8-frame buffers: a buffer is requested again the moment it has been
+  // consumed, i.e. (kRing - 1) x 8 frames before it is needed (24 frames ~ 0.8 us of this loop at kRing = 4; the
+  // two-buffer form of the general lane body requests 8 frames ahead, ~0.27 us - less than a loaded HBM round trip,
+  // so its two waves per SIMD regularly both sat waiting).  An iteration of either loop is the ring's 32 frames:
+  // float32 partial sums are flushed to float64, and the alive set re-examined, once per iteration.
+  constexpr int kRing = 4;
+  int blk = 0;                                         // whole 8-frame blocks consumed; a multiple of kRing at every
+  float ring[kRing][8];                                // iteration boundary: ring[r] holds block blk + r
+  // (requests past the chunk's last whole block are redirected to it instead of being skipped: the loops stay
+  //  straight-line code - a conditional request made the compiler rotate the ring through register copies and wait
+  //  for every outstanding row at each iteration's end - and a row or two read twice costs nothing)
+  const int last_blk = nfull > 0 ? nfull - 1 : 0;
+#pragma unroll
+  for (int r = 0; r < kRing; ++r) {
+    const int b = r < last_blk ? r : last_blk;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ring[r][q] = nfull > 0 ? ld(b * 8 + q) : 0.f;
+  }
+  auto refill = [&](int r) {                           // ring[r] <- block blk + kRing + r (clamped to the last)
+    const int want = blk + kRing + r;
+    const int b = want < last_blk ? want : last_blk;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ring[r][q] = ld(b * 8 + q);
+  };
+  auto flush = [&]() {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      acc2[2 * p] += (double)s22[p][0];
+      acc2[2 * p + 1] += (double)s22[p][1];
+      s22[p] = f32x2{0.f, 0.f};
+    }
+  };
+  bool alive = true;
+  {
+    // ---- while rho^t is alive: d_t = d0_t - c m_in rho^t, so sum d0_t rho^t is needed beside sum d0_t^2
+    // (sum d0_t rho^t stays in float32: its terms decay geometrically and it multiplies m_in - xref, a few pixels -
+    //  what float32 loses there is 1e-7 of a term that is itself ~1e-5 of the chunk's log-likelihood).
+    // Staged: only the pairs p < NA still pay the two extra operations per frame; NA is halved as the pairs die
+    // (wave-uniform, checked every 32 frames).  With the candidates sorted by speed inside the lane (the grid
+    // kernel deals the grid's candidates to its waves round-robin, slowest first) the fast pairs drop out after
+    // the first check and only the lane's slowest pair runs the alive form for long; any order is correct.
+    f32x2 w2[NP], s12[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      w2[p] = f32x2{1.f, 1.f};
+      s12[p] = f32x2{0.f, 0.f};
+    }
+    auto frame4 = [&](float yy, auto na_tag) {
+      constexpr int NA = decltype(na_tag)::value;
+      const float dy = UNIT ? (yy - yprev) : (float)((double)yy - a_d * (double)yprev);
+      yprev = yy;
+      const f32x2 dy2 = f32x2{dy, dy};
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        dk2[p] = rho2[p] * dk2[p] + dy2;
+        s22[p] = s22[p] + dk2[p] * dk2[p];
+        if (p < NA) {
+          s12[p] = s12[p] + dk2[p] * w2[p];
+          w2[p] = w2[p] * rho2[p];
+          EKS_OPAQUE4(dk2[p], w2[p], s22[p], s12[p]);
+        } else {
+          EKS_OPAQUE2(dk2[p], s22[p]);
+        }
+      }
+      EKS_SCHED_FENCE();
+    };
+    auto run32 = [&](auto na_tag) {
+#pragma unroll
+      for (int r = 0; r < kRing; ++r) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) frame4(ring[r][q], na_tag);
+        refill(r);
+      }
+    };
+    using TagAll = IntTag<NP>;
+    int na = NP;                                   // pairs 0 .. na - 1 may still be alive
+    while (na > 0 && blk + kRing <= nfull) {
+#if defined(EKS_LEAN_NOSTAGE)
+      run32(TagAll());
+#else
+      if (NP >= 8 && na <= 1) run32(IntTag<1>());
+      else if (NP >= 8 && na <= 2) run32(IntTag<(NP >= 8 ? 2 : NP)>());
+      else if (NP >= 8 && na <= 4) run32(IntTag<(NP >= 8 ? 4 : NP)>());
+      else run32(TagAll());
+#endif
+      blk += kRing;
+      flush();
+      int top = 0;
+#pragma unroll
+      for (int p = NP - 1; p >= 0; --p) {
+        const bool dead = fabsf(w2[p][0]) < kDeadA && fabsf(w2[p][1]) < kDeadA;
+        if (top == 0 && !EKS_WAVE_ALL(dead)) top = p + 1;
+      }
+      na = top < na ? top : na;                   // (never grows: a dead pair's rho^t is no longer advanced)
+    }
+    alive = na > 0;
+    if (alive) {
+      // rho^t outlives the chunk's whole ring iterations (or the chunk has none): the remaining frames one at a
+      // time, still in the alive form - the summary keeps A = rho^len
+      for (int i = blk * 8; i < len; ++i) {
+        frame4(ld(i), TagAll());
+        if (((i + 1) & 31) == 0) flush();
+      }
+      flush();
+      blk = nfull;
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const float cg = stash[(4 * k + 2) * stride];
+      out.eta(k, s12[k / 2][k & 1] * cg);
+      if (alive) {
+        const float rho = rho2[k / 2][k & 1], w = w2[k / 2][k & 1];
+        const bool live_k = !(fabsf(w) < kDeadA);      // (a pair that left the alive set keeps a stale, dead rho^t)
+        const float c_cg = UNIT ? cg : (float)c_d * cg;
+        // sum rho^2t over the frames seen = (1 - rho^2n) / (1 - rho^2); rho^2n vanishes in float32 once rho^n is dead
+        out.aj(k, live_k ? w : 0.f, live_k ? c_cg * (1.f - w * w) / (1.f - rho * rho) : c_cg / (1.f - rho * rho));
+      }
+    }
+  }
+  // ---- steady state: d' = rho d + (y' - a y), two FMAs per frame and candidate
+  if (!alive) {
+    auto eat = [&](const float (&yy)[8]) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float dy = UNIT ? (yy[q] - yprev) : (float)((double)yy[q] - a_d * (double)yprev);
+        yprev = yy[q];
+        const f32x2 dy2 = f32x2{dy, dy};
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          dk2[p] = rho2[p] * dk2[p] + dy2;
+          s22[p] = s22[p] + dk2[p] * dk2[p];
+        }
+#if !defined(EKS_LEAN_STEADY_NOFENCE)
+        EKS_SCHED_FENCE();
+#endif
+      }
+    };
+    for (; blk + kRing <= nfull; blk += kRing) {
+#pragma unroll
+      for (int r = 0; r < kRing; ++r) {
+        eat(ring[r]);
+        refill(r);
+      }
+      flush();                                    // float32 partial sums span at most 32 frames
+    }
+#pragma unroll
+    for (int r = 0; r < kRing - 1; ++r) {         // the chunk's last whole blocks (fewer than a ring's worth)
+      if (blk + r < nfull) eat(ring[r]);
+    }
+    blk = nfull;
+    flush();
+    for (int i = blk * 8; i < len; ++i) {        // ragged tail of the sequence's last chunk: a frame at a time
+      const float yy = ld(i);
+      const float dy = UNIT ? (yy - yprev) : (float)((double)yy - a_d * (double)yprev);
+      yprev = yy;
+      const f32x2 dy2 = f32x2{dy, dy};
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        dk2[p] = rho2[p] * dk2[p] + dy2;
+        const f32x2 sq2 = dk2[p] * dk2[p];
+        acc2[2 * p] += (double)sq2[0];
+        acc2[2 * p + 1] += (double)sq2[1];
+      }
+    }
+  }
+  // ---- finish (nll_lane_finish / recover_mean of the general lane body, phase 2 throughout)
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const float g = stash[(4 * k + 0) * stride], rg = stash[(4 * k + 1) * stride], logS = stash[(4 * k + 3) * stride];
+    const float dl = dk2[k / 2][k & 1];
+    if (UNIT) {
+      out.b(k, yprev - rg * dl);
+    } else {
+      const float cf = (float)c_d;
+      const float ic = rcp(cf);
+      out.b(k, af * ((yprev - dl) * ic + (1.f - rg) * ic * dl));
+    }
+    const double q_v = (double)g * acc2[k];
+    const double l_v = (double)len * (double)logS;
+    out.ell(k, -0.5 * ((double)len * kLog2Pi + l_v + q_v));
+  }
+  return alive ? 2 : 1;
 }
 
 // Assemble the marginal log-likelihood of one chain for one candidate from its chunk summaries:

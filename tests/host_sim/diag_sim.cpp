@@ -135,3 +135,100 @@ extern "C" int sim_diag_nll(int T, int N, int D, int BN, int unit, int grad, con
   }
   return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// the grid kernel of round 4 (diag_nll_grid_kernel): chunk 0 through the general lane body at 4 candidates per
+// lane, chunks j >= 1 through nll_lean_chunk at 16 (falling back to the exact-entry summary when a chunk does not
+// qualify), the summaries assembled by the sequential walk over a getter that knows both forms.  `n_lean_out`
+// receives the number of (chain, chunk, group) units that took the lean path.
+// ---------------------------------------------------------------------------------------------
+template <bool UNIT>
+static void run_nll_lean(int T, int N, int D, int B0, int BN, const float* y, const double* rconst, const DiagModel& M,
+                         const double* s_cand, int n_cand, double* nll, int* n_lean_out) {
+  constexpr int NC = 16, NH = 4;
+  const int K = N / D;
+  const int ncn = T <= B0 ? 1 : 1 + (T - B0 + BN - 1) / BN;
+  const int ncp = (n_cand + NC - 1) / NC * NC, ng16 = ncp / NC;    // candidates dealt round-robin to ng16 waves
+  struct Sum { float A, b, C, eta, J, xr; double ell; };
+  std::vector<Sum> el((size_t)ncn * N * ncp);
+  std::vector<float> Jc((size_t)N * ncp);
+  int n_lean = 0;
+  for (int n = 0; n < N; ++n) {
+    const int k = n / D, d = n % D;
+    const size_t dd = (size_t)k * D * D + (size_t)d * (D + 1);
+    const double q = M.Q[dd], r = rconst[n], a = M.A[dd], c = M.C[dd];
+    auto put_full = [&](int j, int ci, const NllElem<float>& o) {
+      el[((size_t)j * N + n) * ncp + ci] = Sum{o.e.A, o.e.b, o.e.C, o.e.eta, o.e.J, o.xref, o.ell};
+    };
+    for (int g = 0; g * NH < n_cand; ++g) {                         // head: chunk 0
+      double sq[NH];
+      for (int cc = 0; cc < NH; ++cc) sq[cc] = s_cand[std::min(g * NH + cc, n_cand - 1)] * q;
+      NllElem<float> o[NH];
+      nll_summarize_chunk<float, NH, UNIT>(RowsByPointer{y + n, (size_t)N}, 0, std::min(B0, T), r, a, c, sq, o, false);
+      for (int cc = 0; cc < NH; ++cc) {
+        const int ci = g * NH + cc;
+        if (ci >= n_cand) continue;
+        put_full(0, ci, o[cc]);
+        const LeanConst lc = lean_const<UNIT>(r, a, c, sq[cc]);
+        const float c_cg = UNIT ? lc.cg : (float)c * lc.cg;
+        Jc[(size_t)n * ncp + ci] = c_cg / (1.f - lc.rho * lc.rho);
+      }
+    }
+    for (int j = 1; j < ncn; ++j)
+      for (int g = 0; g * NC < n_cand; ++g) {
+        const int t0 = B0 + (j - 1) * BN, len = std::min(BN, T - t0);
+        const RowsByPointer ld{y + (size_t)t0 * N + n, (size_t)N};
+        auto cand_of = [&](int cc) { return cc * ng16 + g; };
+        auto sqf = [&](int cc) { return s_cand[std::min(cand_of(cc), n_cand - 1)] * q; };
+        float stash[4 * NC];
+        LeanOut<NC> out;
+        const int res = nll_lean_chunk<NC, UNIT>(ld, t0, len, r, a, c, sqf, stash, 1, out);
+        if (res) {
+          ++n_lean;
+          for (int cc = 0; cc < NC; ++cc) {
+            const int ci = cand_of(cc);
+            if (ci < n_cand)
+              el[((size_t)j * N + n) * ncp + ci] =
+                  res == 2 ? Sum{out.A[cc], out.B[cc], -1.f, out.Eta[cc], out.J[cc], out.xr, out.Ell[cc]}
+                           : Sum{0.f, out.B[cc], -1.f, out.Eta[cc], Jc[(size_t)n * ncp + ci], out.xr, out.Ell[cc]};
+          }
+        } else {
+          for (int h = 0; h < NC / NH; ++h) {
+            double sq[NH];
+            for (int cc = 0; cc < NH; ++cc) sq[cc] = sqf(h * NH + cc);
+            NllElem<float> o[NH];
+            nll_summarize_chunk<float, NH, UNIT>(ld, t0, len, r, a, c, sq, o, false);
+            for (int cc = 0; cc < NH; ++cc)
+              if (cand_of(h * NH + cc) < n_cand) put_full(j, cand_of(h * NH + cc), o[cc]);
+          }
+        }
+      }
+  }
+  for (int k = 0; k < K; ++k)
+    for (int ci = 0; ci < n_cand; ++ci) {
+      double tot = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const int n = k * D + d;
+        const size_t dd = (size_t)k * D * D + (size_t)d * (D + 1);
+        auto get = [&](int j, Elem<double>& e, double& ell, double& xr) {
+          const Sum& s = el[((size_t)j * N + n) * ncp + ci];
+          xr = (double)s.xr;
+          e.A = s.A; e.b = s.b; e.C = s.C; e.eta = s.eta; e.J = s.J;
+          ell = s.ell;
+        };
+        tot += nll_assemble<double>(ncn, M.m0[(size_t)k * D + d], M.S0[dd], get);
+      }
+      nll[(size_t)k * n_cand + ci] = -tot;
+    }
+  if (n_lean_out) *n_lean_out = n_lean;
+}
+
+extern "C" int sim_diag_nll_lean(int T, int N, int D, int B0, int BN, int unit, const float* y, const double* rconst,
+                                 const double* m0, const double* S0, const double* A, const double* C, const double* Q,
+                                 const double* s_cand, int n_cand, double* nll, int* n_lean) {
+  DiagModel M{m0, S0, A, C, Q, nullptr, D};
+  if (unit) run_nll_lean<true>(T, N, D, B0, BN, y, rconst, M, s_cand, n_cand, nll, n_lean);
+  else run_nll_lean<false>(T, N, D, B0, BN, y, rconst, M, s_cand, n_cand, nll, n_lean);
+  return 0;
+}

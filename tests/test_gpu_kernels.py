@@ -396,12 +396,15 @@ def test_nll_grid_diag_matches_oracle(T, K, unit, n_cand):
     assert clear.all()
 
 
+@pytest.mark.parametrize('legacy', ['0', '1'])
 @pytest.mark.parametrize('T,K,unit', [(700, 40, True), (1300, 70, False), (4500, 33, True)])
-def test_nll_grid_staged_kernel_matches_c_oracle(T, K, unit):
-    """>= 64 chains and 64 candidates take the LDS-staged kernel (8 candidate groups per block,
-    ragged last chunk / tile / 8-frame block, partially filled last chain tile)."""
+def test_nll_grid_staged_kernel_matches_c_oracle(T, K, unit, legacy, set_knob):
+    """>= 64 chains and 64 candidates take the tile kernels (ragged last chunk / tile / 8-frame block, partially
+    filled last chain tile): the general kernel (8 candidate groups per block; EKS_NLL_LEGACY=1, and by itself on
+    sequences too short for chunks past the first) and the head + lean grid kernel of round 4."""
     from eks_amd import hip_ops
     from oracle import c_oracle
+    set_knob('EKS_NLL_LEGACY', legacy)
     arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=17 + T, unit=unit)
     cand = np.exp(np.linspace(-8, 8, 64))
     flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
@@ -415,10 +418,11 @@ def test_nll_grid_staged_kernel_matches_c_oracle(T, K, unit):
     np.testing.assert_array_equal(nll.argmin(axis=1)[clear], ref.argmin(axis=1)[clear])
     assert clear.mean() > 0.9
 
+@pytest.mark.parametrize('legacy', ['0', '1'])
 @pytest.mark.parametrize('T,K,unit,var_scale', [(40000, 32, True, 1.0), (26001, 40, False, 1.0),
                                                 (40000, 32, True, 60.0), (9000, 70, True, 0.05),
                                                 (20011, 70, False, 9.0), (20011, 70, True, 44.0)])
-def test_nll_grid_converged_entry_chunks_match_c_oracle(T, K, unit, var_scale):
+def test_nll_grid_converged_entry_chunks_match_c_oracle(T, K, unit, var_scale, legacy, set_knob):
     """Long sequences: chunks after the first are summarised for an entering belief N(m, P_inf)
     (no start-up transient), the first chunk is short, rows are read through buffer resources.
     var_scale moves the candidates' closed-loop poles: large R makes the slow candidates fall back
@@ -428,6 +432,7 @@ def test_nll_grid_converged_entry_chunks_match_c_oracle(T, K, unit, var_scale):
     once: bound 8e-6 there)."""
     from eks_amd import hip_ops
     from oracle import c_oracle
+    set_knob('EKS_NLL_LEGACY', legacy)       # 1: the general kernel; 0: the head + lean grid kernel (round 4)
     arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=5 + T, unit=unit)
     var_tk = (var_tk * var_scale).astype(np.float32)
     cand = np.exp(np.linspace(-8, 8, 64))
@@ -441,6 +446,66 @@ def test_nll_grid_converged_entry_chunks_match_c_oracle(T, K, unit, var_scale):
     clear = (srt[:, 1] - srt[:, 0]) > 2e-5 * np.abs(srt[:, 0])
     np.testing.assert_array_equal(nll.argmin(axis=1)[clear], ref.argmin(axis=1)[clear])
     assert clear.mean() > 0.9
+
+
+@pytest.mark.parametrize('T,K,D,unit,n_cand,per_kp,var_scale,chunk', [
+    (30000, 33, 2, True, 64, False, 1.0, 0),        # one ragged tile beside a full one
+    (9000, 40, 2, False, 40, False, 1.0, 0),        # candidates not a multiple of 16: the last lean wave is half used
+    (5000, 70, 2, True, 17, False, 1.0, 0),         # one full lean wave + one candidate
+    (12000, 36, 2, True, 64, True, 1.0, 0),         # a grid per keypoint
+    (16000, 17, 4, False, 32, False, 1.0, 0),       # four chains per keypoint (shuffle sum over 4 lanes)
+    (2100, 64, 2, True, 64, False, 1.0, 0),         # just past the shortest sequence the kernel takes
+    (30000, 40, 2, True, 64, False, 400.0, 0),      # poles at 0.999: the slow groups' chunks fall back to exact entry
+    (30000, 40, 2, False, 64, False, 30.0, 512),    # short chunks: rho^t outlives them for the slow groups
+    (20000, 64, 1, True, 64, False, 1.0, 800),      # one chain per keypoint, two rounds of blocks
+])
+def test_nll_grid_lean_kernel_shapes_and_fallbacks(T, K, D, unit, n_cand, per_kp, var_scale, chunk, set_knob):
+    """diag_nll_grid_kernel (round 4): head role (chunk 0 at 4 candidates per lane) + lean role (16 candidates per
+    lane, converged entry, constants in LDS) + the exact-entry fallback of a wave whose chunk does not qualify
+    (flagged: its (tile, candidate) blocks of the assembly take the sequential walk) - against the C oracle, and
+    against the general kernel (EKS_NLL_LEGACY=1) the two must agree far inside the bar."""
+    from eks_amd import hip_ops
+    from oracle import c_oracle
+    rng = np.random.default_rng(T + K)
+    if D == 2:
+        arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=3 + T, unit=unit)
+    else:
+        # K keypoints of D independent coordinates each (a diagonal model with D chains per keypoint)
+        sub = [_singlecam_problem(T, K, seed=3 + T + 7 * i, unit=unit) for i in range((D + 1) // 2)]
+        y_tk = np.concatenate([s_[1] for s_ in sub], axis=2)[:, :, :D].copy()
+        var_tk = np.concatenate([s_[2] for s_ in sub], axis=2)[:, :, :D].copy()
+        eye = np.eye(D)
+        diag = lambda lo, hi: eye * rng.uniform(lo, hi, (K, D))[:, :, None]
+        arrs = dict(m0s=np.zeros((K, D)), S0s=diag(1.0, 5.0), As=np.tile(eye, (K, 1, 1)) if unit else diag(0.93, 1.0),
+                    Cs=np.tile(eye, (K, 1, 1)) if unit else diag(0.6, 1.4),
+                    Qs=np.tile(eye, (K, 1, 1)) if unit else diag(0.5, 2.0))
+        arrs['ys'] = np.transpose(y_tk, (1, 0, 2)).astype(np.float64)
+    var_tk = (var_tk * var_scale).astype(np.float32)
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    rconst = hip_ops.const_r(_dev(var_tk), 1e-4)
+    if per_kp:
+        cand = np.exp(rng.uniform(-8, 8, (K, n_cand)))
+    else:
+        cand = np.exp(np.linspace(-8, 8, n_cand))
+    if chunk:
+        set_knob('EKS_NLL_CHUNK', str(chunk))
+    args = (_dev(y_tk), rconst, *_params_dev(arrs), _dev(cand))
+    nll = hip_ops.nll(*args, per_keypoint=per_kp, flags=flags).cpu().numpy()
+    Rc = rconst.cpu().numpy()
+    if per_kp:
+        ref = np.stack([c_oracle.nll_grid(arrs['ys'][k:k + 1], Rc[k:k + 1], arrs['m0s'][k:k + 1], arrs['S0s'][k:k + 1],
+                                          arrs['As'][k:k + 1], arrs['Cs'][k:k + 1], arrs['Qs'][k:k + 1], cand[k])[0]
+                        for k in range(K)])
+    else:
+        ref = c_oracle.nll_grid(arrs['ys'], Rc, arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], cand)
+    assert np.isfinite(nll).all()
+    assert (np.abs(nll - ref) / np.abs(ref)).max() < 1e-5
+    srt = np.sort(ref, axis=1)
+    clear = (srt[:, 1] - srt[:, 0]) > 2e-5 * np.abs(srt[:, 0])
+    np.testing.assert_array_equal(nll.argmin(axis=1)[clear], ref.argmin(axis=1)[clear])
+    set_knob('EKS_NLL_LEGACY', '1')
+    nll_old = hip_ops.nll(*args, per_keypoint=per_kp, flags=flags).cpu().numpy()
+    assert (np.abs(nll - nll_old) / np.abs(ref)).max() < 1e-5          # (each is within 1e-5 of the oracle)
 
 
 @pytest.mark.parametrize('T,K,unit', [(3000, 5, True), (1500, 3, False)])

@@ -84,6 +84,44 @@ def test_float32_three_regime_nll_and_dual_gradient(sim, T, BN):
             assert (np.abs(dn - ref_g) / np.abs(ref_g).max(axis=1, keepdims=True)).max() < 2e-5
 
 
+@pytest.mark.parametrize('T,B0,BN,unit,var_scale', [(9001, 1024, 1600, True, 1.0), (12500, 1024, 1600, False, 1.0),
+                                                    (7000, 1024, 512, True, 1.0), (4000, 512, 1600, True, 1.0),
+                                                    (20000, 1024, 3200, False, 1.0), (12000, 1024, 512, True, 20.0),
+                                                    (12000, 1024, 1600, False, 300.0)])
+def test_grid_kernel_lane_bodies_head_plus_lean_match_oracle(sim, T, B0, BN, unit, var_scale):
+    """diag_nll_grid_kernel's arithmetic on the host (round 4): chunk 0 through the general lane body at 4 candidates
+    per lane, chunks j >= 1 through nll_lean_chunk at 16 candidates per lane - converged entry, the constants from
+    lean_const - with the exact-entry fallback where a chunk does not qualify (the slowest candidates in short
+    chunks, or too early in the sequence), all 64 candidates of BASELINE's grid.  NLL within 1e-5 of the float64
+    oracle, argmin bit-exact; most units must really take the lean path."""
+    K, NC = 3, 64
+    arrs, y, var, ys64, ev64 = _problem(T, K, seed=6)
+    ev64 = ev64 * var_scale          # large R: poles near one - early chunks fall back to exact entry, rho^t outlives
+    if not unit:                     # short chunks (the lean summary then keeps A = rho^len)
+        rng = np.random.default_rng(3)
+        eye = np.eye(2)
+        arrs['As'] = np.ascontiguousarray(eye * rng.uniform(0.93, 1.0, (K, 2))[:, :, None])
+        arrs['Cs'] = np.ascontiguousarray(eye * rng.uniform(0.6, 1.4, (K, 2))[:, :, None])
+        arrs['Qs'] = np.ascontiguousarray(eye * rng.uniform(0.5, 2.0, (K, 2))[:, :, None])
+    Rc = orc.constant_R_from_timevarying(orc.build_R_from_vars(ev64))
+    cand = np.exp(np.linspace(-8, 8, NC))
+    from oracle import c_oracle          # the C twin: 64 candidates x 20 000 frames in NumPy would take minutes
+    ref = c_oracle.nll_grid(ys64, Rc, arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], cand)
+    spot = orc.filter_nll(ys64, arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], np.full(K, cand[5]), Rc)
+    assert (np.abs(ref[:, 5] - spot) / np.abs(spot)).max() < 1e-10
+    rconst = np.ascontiguousarray(Rc.reshape(-1))
+    f, d = ctypes.c_float, ctypes.c_double
+    nll = np.zeros((K, NC))
+    n_lean = ctypes.c_int(0)
+    sim.sim_diag_nll_lean(T, 2 * K, 2, B0, BN, int(unit), _p(y, f), _p(rconst, d), _p(arrs['m0s'], d),
+                          _p(arrs['S0s'], d), _p(arrs['As'], d), _p(arrs['Cs'], d), _p(arrs['Qs'], d), _p(cand, d), NC,
+                          _p(nll, d), ctypes.byref(n_lean))
+    assert (np.abs(nll - ref) / np.abs(ref)).max() < 1e-5
+    np.testing.assert_array_equal(nll.argmin(axis=1), ref.argmin(axis=1))
+    units = 2 * K * (NC // 16) * (0 if T <= B0 else (T - B0 + BN - 1) // BN)
+    assert n_lean.value >= (0.7 if var_scale == 1.0 else 0.3) * units, (n_lean.value, units)
+
+
 # ---------------------------------------------------------------------------------------------
 # general (D, O) smoother: chunk elements -> scan -> exact replay, from the kernels' own headers
 # ---------------------------------------------------------------------------------------------
