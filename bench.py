@@ -859,9 +859,9 @@ def main():
                 flops = 2.0 * 2.0 * local_units * 2 * n_cand
                 t_nll = float(np.mean(nll_live)) * 1e-3
                 nll_bytes = NLL_BYTES_PER_UNIT * local_units
-                ntraffic, ntraffic_src = measured_traffic('diag_nll_summarize_kernel') if headline else (None, None)
+                ntraffic, ntraffic_src = measured_traffic('diag_nll_grid_kernel') if headline else (None, None)
                 out['roofline'] = {
-                    'bound': 'valu', 'kernel': 'diag_nll_summarize_kernel', 'unit': 'TFLOP/s',
+                    'bound': 'valu', 'kernel': 'diag_nll_grid_kernel', 'unit': 'TFLOP/s',
                     'achieved': flops / t_nll / 1e12, 'peak': 157.3, 'frac': flops / t_nll / 1e12 / 157.3,
                     'kernel_avg_ms': float(np.mean(nll_live)), 'launches_timed': len(nll_live),
                     'kernel_avg_ms_source': 'HIP events on the launch stream, every launch inside the timed regions',

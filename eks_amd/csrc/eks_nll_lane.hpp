@@ -761,103 +761,76 @@ EKS_HD int nll_lean_chunk(const LD& ld, int t0, int len, double r_d, double a_d,
   if (!EKS_WAVE_ALL(ok)) return 0;
   const float y0 = len > 0 ? ld(0) : 0.f;
   out.xref(UNIT ? y0 : y0 / (float)c_d);
-  float yprev = UNIT ? y0 : y0 / af;                    // reference start: the first innovation is y_0 - c xref = 0
-  f32x2 dk2[NP], s22[NP];
-  double acc2[NC];
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    dk2[p] = f32x2{0.f, 0.f};
-    s22[p] = f32x2{0.f, 0.f};
-  }
-#pragma unroll
-  for (int k = 0; k < NC; ++k) acc2[k] = 0.0;
-  // Rows travel through a ring of kRing 8-frame buffers: a buffer is requested again the moment it has been
-  // consumed, i.e. (kRing - 1) x 8 frames before it is needed (24 frames ~ 0.8 us of this loop at kRing = 4; the
-  // two-buffer form of the general lane body requests 8 frames ahead, ~0.27 us - less than a loaded HBM round trip,
-  // so its two waves per SIMD regularly both sat waiting).  An iteration of either loop is the ring's 32 frames:
-  // float32 partial sums are flushed to float64, and the alive set re-examined, once per iteration.
-  constexpr int kRing = 4;
-  int blk = 0;                                         // whole 8-frame blocks consumed; a multiple of kRing at every
-  float ring[kRing][8];                                // iteration boundary: ring[r] holds block blk + r
-  // (requests past the chunk's last whole block are redirected to it instead of being skipped: the loops stay
-  //  straight-line code - a conditional request made the compiler rotate the ring through register copies and wait
-  //  for every outstanding row at each iteration's end - and a row or two read twice costs nothing)
+  const float ystart = UNIT ? y0 : y0 / af;            // reference start: the first innovation is y_0 - c xref = 0
+  // Rows travel through TWO sets of four 8-frame buffers: while one set (32 frames) is consumed, the other is in
+  // flight - requested at the top of the half-iteration before the one that consumes it, i.e. 32 frames (~1 us of
+  // the main loop) ahead.  (The two-buffer form of the general lane body requests 8 frames ahead, ~0.27 us - less
+  // than a loaded HBM round trip - so its two waves per SIMD regularly both sat waiting; and a ring refilled
+  // buffer by buffer ends, as the compiler counts outstanding loads across the back edge, in a wait for ALL of them
+  // at the loop top, the request just made included.  With whole sets that wait is for loads a half-iteration old.)
+  // Requests past the chunk's last whole block are redirected to it instead of being skipped: the loops stay
+  // straight-line code, and a row read twice costs nothing.
+  constexpr int kSet = 4;
   const int last_blk = nfull > 0 ? nfull - 1 : 0;
+  float ring[2][kSet][8];                              // (indexed by compile-time constants only: registers)
+  auto request = [&](auto set_tag, int first) {        // ring[S][r] <- block first + r (clamped to the last)
+    constexpr int S = decltype(set_tag)::value;
 #pragma unroll
-  for (int r = 0; r < kRing; ++r) {
-    const int b = r < last_blk ? r : last_blk;
+    for (int r = 0; r < kSet; ++r) {
+      const int b = first + r < last_blk ? first + r : last_blk;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) ring[r][q] = nfull > 0 ? ld(b * 8 + q) : 0.f;
-  }
-  auto refill = [&](int r) {                           // ring[r] <- block blk + kRing + r (clamped to the last)
-    const int want = blk + kRing + r;
-    const int b = want < last_blk ? want : last_blk;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) ring[r][q] = ld(b * 8 + q);
-  };
-  auto flush = [&]() {
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      acc2[2 * p] += (double)s22[p][0];
-      acc2[2 * p + 1] += (double)s22[p][1];
-      s22[p] = f32x2{0.f, 0.f};
+      for (int q = 0; q < 8; ++q) ring[S][r][q] = nfull > 0 ? ld(b * 8 + q) : 0.f;
     }
   };
-  bool alive = true;
+  const IntTag<0> setA;
+  const IntTag<1> setB;
+  int blk = 0;                                         // whole blocks consumed by the running pass
+  // ---- pass 1, while rho^t is alive: the true innovations are d_t = d0_t - c m_in rho^t (d0: zero-start), so the
+  // chunk's likelihood needs sum d0_t rho^t beside sum d0_t^2.  Its own short pass over the chunk's first frames:
+  // only (rho, d0, rho^t, the sum) of the pairs still alive are touched - NA is halved as the pairs die (wave-uniform,
+  // examined every 32 frames; the grid kernel deals candidates to its waves round-robin, slowest first, so after
+  // the first examinations only the lane's slowest pair is left and every wave pays the same few per cent; any
+  // order is correct).  The sum stays in float32: its terms decay geometrically and it multiplies m_in - xref, a few
+  // pixels - what float32 loses there is 1e-7 of a term that is itself ~1e-5 of the chunk's log-likelihood.
+  bool alive;
   {
-    // ---- while rho^t is alive: d_t = d0_t - c m_in rho^t, so sum d0_t rho^t is needed beside sum d0_t^2
-    // (sum d0_t rho^t stays in float32: its terms decay geometrically and it multiplies m_in - xref, a few pixels -
-    //  what float32 loses there is 1e-7 of a term that is itself ~1e-5 of the chunk's log-likelihood).
-    // Staged: only the pairs p < NA still pay the two extra operations per frame; NA is halved as the pairs die
-    // (wave-uniform, checked every 32 frames).  With the candidates sorted by speed inside the lane (the grid
-    // kernel deals the grid's candidates to its waves round-robin, slowest first) the fast pairs drop out after
-    // the first check and only the lane's slowest pair runs the alive form for long; any order is correct.
-    f32x2 w2[NP], s12[NP];
+    f32x2 d1[NP], w2[NP], s12[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
+      d1[p] = f32x2{0.f, 0.f};
       w2[p] = f32x2{1.f, 1.f};
       s12[p] = f32x2{0.f, 0.f};
     }
-    auto frame4 = [&](float yy, auto na_tag) {
+    float yprev = ystart;
+    auto frame1 = [&](float yy, auto na_tag) {
       constexpr int NA = decltype(na_tag)::value;
       const float dy = UNIT ? (yy - yprev) : (float)((double)yy - a_d * (double)yprev);
       yprev = yy;
       const f32x2 dy2 = f32x2{dy, dy};
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        dk2[p] = rho2[p] * dk2[p] + dy2;
-        s22[p] = s22[p] + dk2[p] * dk2[p];
-        if (p < NA) {
-          s12[p] = s12[p] + dk2[p] * w2[p];
-          w2[p] = w2[p] * rho2[p];
-          EKS_OPAQUE4(dk2[p], w2[p], s22[p], s12[p]);
-        } else {
-          EKS_OPAQUE2(dk2[p], s22[p]);
-        }
+      for (int p = 0; p < NA; ++p) {
+        d1[p] = rho2[p] * d1[p] + dy2;
+        s12[p] = s12[p] + d1[p] * w2[p];
+        w2[p] = w2[p] * rho2[p];
       }
       EKS_SCHED_FENCE();
     };
-    auto run32 = [&](auto na_tag) {
-#pragma unroll
-      for (int r = 0; r < kRing; ++r) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) frame4(ring[r][q], na_tag);
-        refill(r);
-      }
-    };
     using TagAll = IntTag<NP>;
     int na = NP;                                   // pairs 0 .. na - 1 may still be alive
-    while (na > 0 && blk + kRing <= nfull) {
-#if defined(EKS_LEAN_NOSTAGE)
-      run32(TagAll());
-#else
-      if (NP >= 8 && na <= 1) run32(IntTag<1>());
-      else if (NP >= 8 && na <= 2) run32(IntTag<(NP >= 8 ? 2 : NP)>());
-      else if (NP >= 8 && na <= 4) run32(IntTag<(NP >= 8 ? 4 : NP)>());
-      else run32(TagAll());
-#endif
-      blk += kRing;
-      flush();
+    auto run32 = [&](auto set_tag) {
+      constexpr int S = decltype(set_tag)::value;
+      auto go = [&](auto na_tag) {
+#pragma unroll
+        for (int r = 0; r < kSet; ++r) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) frame1(ring[S][r][q], na_tag);
+        }
+      };
+      if (NP >= 8 && na <= 1) go(IntTag<1>());
+      else if (NP >= 8 && na <= 2) go(IntTag<(NP >= 8 ? 2 : NP)>());
+      else if (NP >= 8 && na <= 4) go(IntTag<(NP >= 8 ? 4 : NP)>());
+      else go(TagAll());
+      blk += kSet;
       int top = 0;
 #pragma unroll
       for (int p = NP - 1; p >= 0; --p) {
@@ -865,17 +838,20 @@ EKS_HD int nll_lean_chunk(const LD& ld, int t0, int len, double r_d, double a_d,
         if (top == 0 && !EKS_WAVE_ALL(dead)) top = p + 1;
       }
       na = top < na ? top : na;                   // (never grows: a dead pair's rho^t is no longer advanced)
+    };
+    request(setA, 0);
+    while (na > 0 && blk + kSet <= nfull) {
+      request(setB, blk + kSet);
+      run32(setA);
+      if (!(na > 0 && blk + kSet <= nfull)) break;
+      request(setA, blk + kSet);
+      run32(setB);
     }
     alive = na > 0;
     if (alive) {
-      // rho^t outlives the chunk's whole ring iterations (or the chunk has none): the remaining frames one at a
-      // time, still in the alive form - the summary keeps A = rho^len
-      for (int i = blk * 8; i < len; ++i) {
-        frame4(ld(i), TagAll());
-        if (((i + 1) & 31) == 0) flush();
-      }
-      flush();
-      blk = nfull;
+      // rho^t outlives the chunk's whole 32-frame sets (or the chunk has none): the remaining frames one at a
+      // time - the summary keeps A = rho^len
+      for (int i = blk * 8; i < len; ++i) frame1(ld(i), TagAll());
     }
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
@@ -890,38 +866,73 @@ EKS_HD int nll_lean_chunk(const LD& ld, int t0, int len, double r_d, double a_d,
       }
     }
   }
-  // ---- steady state: d' = rho d + (y' - a y), two FMAs per frame and candidate
-  if (!alive) {
-    auto eat = [&](const float (&yy)[8]) {
+  // ---- pass 2, the whole chunk: d0' = rho d0 + (y' - a y) and the sum of its squares - two FMAs per frame and
+  // candidate.  The float32 partial sums go to float64 once per 32-frame set.
+  float yprev = ystart;
+  f32x2 dk2[NP], s22[NP];
+  double acc2[NC];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float dy = UNIT ? (yy[q] - yprev) : (float)((double)yy[q] - a_d * (double)yprev);
-        yprev = yy[q];
-        const f32x2 dy2 = f32x2{dy, dy};
+  for (int p = 0; p < NP; ++p) {
+    dk2[p] = f32x2{0.f, 0.f};
+    s22[p] = f32x2{0.f, 0.f};
+  }
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          dk2[p] = rho2[p] * dk2[p] + dy2;
-          s22[p] = s22[p] + dk2[p] * dk2[p];
-        }
-#if !defined(EKS_LEAN_STEADY_NOFENCE)
-        EKS_SCHED_FENCE();
-#endif
+  for (int k = 0; k < NC; ++k) acc2[k] = 0.0;
+  {
+    auto eat1 = [&](float yy) {
+      const float dy = UNIT ? (yy - yprev) : (float)((double)yy - a_d * (double)yprev);
+      yprev = yy;
+      const f32x2 dy2 = f32x2{dy, dy};
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        dk2[p] = rho2[p] * dk2[p] + dy2;
+        s22[p] = s22[p] + dk2[p] * dk2[p];
+      }
+      EKS_SCHED_FENCE();
+    };
+    auto flush = [&]() {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        acc2[2 * p] += (double)s22[p][0];
+        acc2[2 * p + 1] += (double)s22[p][1];
+        s22[p] = f32x2{0.f, 0.f};
       }
     };
-    for (; blk + kRing <= nfull; blk += kRing) {
+    auto eat_set = [&](auto set_tag, int n) {     // the first n (<= kSet) blocks of a set
+      constexpr int S = decltype(set_tag)::value;
 #pragma unroll
-      for (int r = 0; r < kRing; ++r) {
-        eat(ring[r]);
-        refill(r);
+      for (int r = 0; r < kSet; ++r) {
+        if (r < n) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) eat1(ring[S][r][q]);
+        }
       }
       flush();                                    // float32 partial sums span at most 32 frames
-    }
+    };
+    auto eat_full = [&](auto set_tag) {           // a whole set, no per-block predicate in the main loop
+      constexpr int S = decltype(set_tag)::value;
 #pragma unroll
-    for (int r = 0; r < kRing - 1; ++r) {         // the chunk's last whole blocks (fewer than a ring's worth)
-      if (blk + r < nfull) eat(ring[r]);
+      for (int r = 0; r < kSet; ++r) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) eat1(ring[S][r][q]);
+      }
+      flush();
+    };
+    blk = 0;
+    request(setA, 0);
+    for (; blk + 2 * kSet <= nfull; blk += 2 * kSet) {
+      request(setB, blk + kSet);
+      eat_full(setA);
+      request(setA, blk + 2 * kSet);
+      eat_full(setB);
     }
-    blk = nfull;
-    flush();
+    {
+      const int rem = nfull - blk;                 // 0 .. 2 kSet - 1 whole blocks left; set A holds the first kSet
+      if (rem > kSet) request(setB, blk + kSet);
+      eat_set(setA, rem < kSet ? rem : kSet);
+      if (rem > kSet) eat_set(setB, rem - kSet);
+      blk = nfull;
+    }
     for (int i = blk * 8; i < len; ++i) {        // ragged tail of the sequence's last chunk: a frame at a time
       const float yy = ld(i);
       const float dy = UNIT ? (yy - yprev) : (float)((double)yy - a_d * (double)yprev);

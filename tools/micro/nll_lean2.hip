@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cmath>
 #include <vector>
+#include <algorithm>
 #include "eks_nll_lane.hpp"
 using namespace eks;
 
@@ -21,8 +22,10 @@ struct BufferRows {
 template <int NC, bool RR>
 __global__ __launch_bounds__(256, 2) void k(const float* __restrict__ y, int N, int T, int B0, int BN, int ncn,
                                             const double* __restrict__ rc, const double* __restrict__ sc,
-                                            float* __restrict__ ob, double* __restrict__ oell, int* __restrict__ res) {
+                                            float* __restrict__ ob, double* __restrict__ oell, int* __restrict__ res,
+                                            unsigned long long* __restrict__ stamps) {
   __shared__ float stash[4][4 * NC][64];
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int ntile = N / 64;
   const int tile = blockIdx.x % ntile, j = 1 + blockIdx.x / ntile;
@@ -36,7 +39,12 @@ __global__ __launch_bounds__(256, 2) void k(const float* __restrict__ y, int N, 
   auto sqf = [&](int c) { return sc[RR ? c * ng + w : w * NC + c]; };
   LeanOut<NC> out;
   const int ok = nll_lean_chunk<NC, true>(ld, t0, len, r, 1.0, 1.0, sqf, &stash[w][0][lane], 64, out);
-  if (lane == 0) res[blockIdx.x * 4 + w] = ok;
+  if (lane == 0) {
+    res[blockIdx.x * 4 + w] = ok;
+    unsigned long long* st = stamps + (size_t)(blockIdx.x * 4 + w) * 4;
+    st[0] = r0; st[1] = __builtin_amdgcn_s_memrealtime(); st[2] = __builtin_amdgcn_s_memtime() - c0;
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); st[3] = xcc;
+  }
   if (!ok) return;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
@@ -49,25 +57,51 @@ __global__ __launch_bounds__(256, 2) void k(const float* __restrict__ y, int N, 
 template <int NC, bool RR>
 void run(const float* y, int T, int N, int nch, const double* rc, const double* sc, float* ob, double* oell, int* res,
          const char* what) {
+  static unsigned long long* stamps = nullptr;
+  if (!stamps) (void)hipMalloc(&stamps, sizeof(unsigned long long) * 4 * 4 * 8 * 140);
   const int B0 = 1024;
   int BN = ((T - B0 + nch - 1) / nch + 15) / 16 * 16;
   const int ncn = 1 + (T - B0 + BN - 1) / BN;
   const int blocks = (N / 64) * (ncn - 1);
   hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-  for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((k<NC, RR>), dim3(blocks), dim3(256), 0, 0, y, N, T, B0, BN, ncn, rc, sc, ob, oell, res);
+  for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((k<NC, RR>), dim3(blocks), dim3(256), 0, 0, y, N, T, B0, BN, ncn, rc, sc, ob, oell, res, stamps);
   (void)hipDeviceSynchronize();
   (void)hipEventRecord(a);
   const int reps = 20;
-  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k<NC, RR>), dim3(blocks), dim3(256), 0, 0, y, N, T, B0, BN, ncn, rc, sc, ob, oell, res);
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k<NC, RR>), dim3(blocks), dim3(256), 0, 0, y, N, T, B0, BN, ncn, rc, sc, ob, oell, res, stamps);
   (void)hipEventRecord(b); (void)hipEventSynchronize(b);
   float ms; (void)hipEventElapsedTime(&ms, a, b);
   std::vector<int> h(blocks * 4);
   (void)hipMemcpy(h.data(), res, sizeof(int) * h.size(), hipMemcpyDeviceToHost);
   int c1 = 0, c2 = 0, c0 = 0;
   for (int v : h) { c0 += v == 0; c1 += v == 1; c2 += v == 2; }
+  std::vector<unsigned long long> hs((size_t)blocks * 16);
+  (void)hipMemcpy(hs.data(), stamps, sizeof(unsigned long long) * hs.size(), hipMemcpyDeviceToHost);
+  unsigned long long tmin = ~0ull, tmax = 0; std::vector<double> dur; double clk = 0;
+  for (int i = 0; i < blocks * 4; ++i) { tmin = std::min(tmin, hs[i * 4]); tmax = std::max(tmax, hs[i * 4 + 1]); dur.push_back((hs[i * 4 + 1] - hs[i * 4]) * 0.01); clk += (double)hs[i * 4 + 2] / ((hs[i * 4 + 1] - hs[i * 4]) * 10.0); }
+  std::sort(dur.begin(), dur.end());
+  double start_spread = 0; for (int i = 0; i < blocks * 4; ++i) start_spread = std::max(start_spread, (hs[i * 4] - tmin) * 0.01);
   const double us = ms * 1e3 / reps, flops = 2.0 * 2.0 * (double)(T - B0) * N * 64;
   printf("%-44s BN=%5d %4d blocks: %7.1f us = %5.1f TFLOP/s useful  (waves: %d lean, %d lean A!=0, %d not qualified)\n", what, BN,
          blocks, us, flops / (us * 1e-6) / 1e12, c1, c2, c0);
+  {
+    double sx[8] = {0}, sw[4] = {0}; int nx[8] = {0}, nw[4] = {0};
+    for (int i = 0; i < blocks * 4; ++i) {
+      const double d = (hs[i * 4 + 1] - hs[i * 4]) * 0.01;
+      const int x = (int)(hs[i * 4 + 3] & 7);
+      sx[x] += d; nx[x]++; sw[i & 3] += d; nw[i & 3]++;
+    }
+    printf("    mean wave duration per XCD:");
+    for (int x = 0; x < 8; ++x) printf(" %.0f", nx[x] ? sx[x] / nx[x] : 0.0);
+    printf(" us; per wave slot of the block:");
+    for (int x = 0; x < 4; ++x) printf(" %.0f", sw[x] / nw[x]);
+    // first half of the grid (first block on each CU) vs second half
+    double h0 = 0, h1 = 0; int n0 = 0, n1 = 0;
+    for (int i = 0; i < blocks * 4; ++i) { const double d = (hs[i * 4 + 1] - hs[i * 4]) * 0.01; if (i < blocks * 2) { h0 += d; n0++; } else { h1 += d; n1++; } }
+    printf(" us; first / second half of the grid: %.0f / %.0f us\n", h0 / n0, h1 / n1);
+  }
+  printf("    last launch: first start -> last end %.1f us; wave durations min %.1f / median %.1f / p90 %.1f / max %.1f us; latest start +%.1f us; shader clock %.2f GHz\n",
+         (tmax - tmin) * 0.01, dur.front(), dur[dur.size() / 2], dur[dur.size() * 9 / 10], dur.back(), start_spread, clk / (blocks * 4));
 }
 
 int main() {
