@@ -458,13 +458,133 @@ def _log_opt(blocks, s_finals, info) -> None:
                      f'iters={int(st[b, 4])}, NLL={st[b, 3]:.6f}')
 
 
+_TILE_MIN_BYTES = int(os.environ.get('EKS_HOST_TILE_MIN_BYTES', 96 << 20))     # below this one untiled call is as fast
+_TILE_TARGET_BYTES = int(os.environ.get('EKS_HOST_TILE_BYTES', 80 << 20))      # transfer volume of one tile (in + out)
+
+
+_TILE_STREAMS: dict = {}
+
+
+def _tile_streams(dev):
+    """Three side streams per device, created once: torch's caching allocator keeps a pool per stream, so streams
+    made per call would hipMalloc every tile's buffers afresh (measured: 200 - 400 ms per call instead of 15)."""
+    key = dev.index if dev.index is not None else _torch().cuda.current_device()
+    if key not in _TILE_STREAMS:
+        _TILE_STREAMS[key] = [_torch().cuda.Stream(device=dev) for _ in range(3)]
+    return _TILE_STREAMS[key]
+
+
+_TILE_ADAM = False
+
+
+def _host_tiles(ys, ensemble_vars, K, T, O, D, vs_diag, blocks, h_fn, return_device, searching_adam=False):
+    """How to cut a host-array call into keypoint tiles for the pipelined boundary, or None.  Keypoints are
+    independent (reference eks/core.py:223-224, :293), so any partition gives the same numbers; tiling needs plain
+    NumPy inputs (a device tensor has nothing to upload), singleton blocks and enough bytes to be worth it."""
+    if return_device or h_fn is not None or os.environ.get('EKS_HOST_UNTILED'):
+        return None
+    # The Adam search is ~100 dependent launches of ~45 us whatever the number of keypoints: run per tile it is paid per
+    # tile (measured on BASELINE configs[2]: 88 ms tiled against 28.5 ms untiled), so that mode stays one call.
+    if searching_adam and not _TILE_ADAM:
+        return None
+    if hasattr(ys, 'detach') or hasattr(ensemble_vars, 'detach'):
+        return None
+    if blocks and any(len(b) != 1 for b in blocks):
+        return None
+    per_kp = T * (2 * O + D + (D if vs_diag else D * D)) * 4
+    if K * per_kp < _TILE_MIN_BYTES or K < 4:
+        return None
+    kt = max(1, min(K // 2, int(round(_TILE_TARGET_BYTES / per_kp))))
+    if kt >= 32:
+        kt = kt // 32 * 32                    # whole 64-chain tiles of the scalar-chain kernels (D = 2)
+    return [(k0, min(K, k0 + kt)) for k0 in range(0, K, kt)]
+
+
+def _run_tiled_from_host(tiles, ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames, smooth_param, lr, s_bounds_log,
+                         tol, safety_cap, s_mode, n_grid, vs_diag, return_info):
+    """run_kalman_smoother on HOST arrays as a three-stage pipeline over keypoint tiles: while tile i is in the
+    kernels, tile i + 1 is on its way up and tile i - 1's results are on their way down (PCIe is full duplex;
+    the untiled call moved 16 B per unit up, ran, then moved 24 B per unit down: 19.6 ms on BASELINE configs[2]
+    for 0.55 ms of kernels).  Each tile is an ordinary device-tensor call on one of three streams - upload, search,
+    smooth, transposition to the reference's (K, T, .) layout, download into its slab of ONE page-locked result
+    buffer - so the outputs are the untiled call's bit for bit (keypoints are independent, eks/core.py:293).
+    Measured on BASELINE configs[2] (tools/host_path_time.py): 19.4 -> see profiles/r04_*_host_path_time.txt."""
+    torch = _torch()
+    dev = hip_ops.require_gpu()
+    ys_h = np.asarray(ys)
+    ev_h = np.asarray(ensemble_vars)
+    K, T, O = ys_h.shape
+    par = {k: np.asarray(_to_numpy(v, np.float64)) for k, v in dict(m0=m0s, S0=S0s, A=As, C=Cs, Q=Qs).items()}
+    D = par['m0'].shape[1]
+    if tuple(ev_h.shape) != (T, K, O):
+        raise ValueError(f'ys must be (K,T,O) and ensemble_vars (T,K,O); got {tuple(ys_h.shape)} and {tuple(ev_h.shape)}')
+    if T < 2:
+        raise ValueError('Not enough frames to compute temporal differences.')
+    vshape = (K, T, D) if vs_diag else (K, T, D, D)
+    nbytes = (K * T * D + int(np.prod(vshape))) * 4
+    pinned = not os.environ.get('EKS_PAGEABLE_D2H') and nbytes <= (2 << 30) and _pinned_live[0] + nbytes <= _PINNED_CAP_BYTES
+    try:
+        ms_h = torch.empty((K, T, D), dtype=torch.float32, pin_memory=pinned)
+        Vs_h = torch.empty(vshape, dtype=torch.float32, pin_memory=pinned)
+    except RuntimeError:
+        pinned = False
+        ms_h = torch.empty((K, T, D), dtype=torch.float32)
+        Vs_h = torch.empty(vshape, dtype=torch.float32)
+    sp = None if smooth_param is None or isinstance(smooth_param, (int, float)) else \
+        np.broadcast_to(np.asarray(smooth_param, dtype=float), (K,))
+    # The ensemble variances arrive (T, K, O), frame-major: a keypoint tile of them is a strided view on the host
+    # (gathering one costs 1.6 - 5 ms of host time per 25 MB, three to ten times its transfer), so they go up whole,
+    # once, and are cut on the device.
+    cur = torch.cuda.current_stream(dev)
+    ev_d = torch.as_tensor(np.ascontiguousarray(ev_h), device=dev)
+    streams = _tile_streams(dev)
+    for st in streams:
+        st.wait_stream(cur)
+    s_parts, infos, keep = [], [], []
+    for i, (k0, k1) in enumerate(tiles):
+        st = streams[i % len(streams)]
+        with torch.cuda.stream(st):
+            y_t = torch.as_tensor(np.ascontiguousarray(ys_h[k0:k1]), device=dev)               # (Kt,T,O), caller's dtype
+            v_t = ev_d[:, k0:k1]                                                                # (T,Kt,O) view
+            res = run_kalman_smoother(
+                y_t, par['m0'][k0:k1], par['S0'][k0:k1], par['A'][k0:k1], par['C'][k0:k1], par['Q'][k0:k1], v_t,
+                s_frames=s_frames, smooth_param=(smooth_param if sp is None else list(sp[k0:k1])), blocks=None,
+                lr=lr, s_bounds_log=s_bounds_log, tol=tol, safety_cap=safety_cap, s_mode=s_mode, n_grid=n_grid,
+                vs_diag=vs_diag, return_device=True, return_info=True, _s_on_device=True)
+            s_dev, ms_d, Vs_d, info = res
+            ms_h[k0:k1].copy_(ms_d.contiguous(), non_blocking=True)      # (Kt,T,D) views of the frame-major buffers ->
+            Vs_h[k0:k1].copy_(Vs_d.contiguous(), non_blocking=True)      # the reference's layout on the device, then down
+            s_parts.append(s_dev)
+            infos.append(info)
+            keep.append((y_t, v_t, ms_d, Vs_d))
+            ev_d.record_stream(st)
+    for st in streams:
+        cur.wait_stream(st)
+    cur.synchronize()
+    s_finals = np.concatenate([np.asarray(s.cpu().numpy(), dtype=float) for s in s_parts])
+    out_ms, out_Vs = ms_h.numpy(), Vs_h.numpy()
+    if pinned:
+        import weakref
+        for arr, h in ((out_ms, ms_h), (out_Vs, Vs_h)):
+            n = h.numel() * h.element_size()
+            _pinned_live[0] += n
+            weakref.finalize(arr.base if arr.base is not None else h, _release_pinned, n)
+    out = (s_finals, out_ms, out_Vs)
+    if return_info:
+        out = out + (dict(mode='tiled', tiles=list(tiles), tile_info=infos),)
+    if infos and infos[0].get('mode') == 'adam':
+        _log_opt([[k] for k in range(K)], s_finals,
+                 dict(mode='adam', state=torch.cat([inf['state'] for inf in infos])))
+    return out
+
+
 def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list | None = None,
                         smooth_param: float | list | None = None,
                         blocks: list[list[int]] | None = None, lr: float = 0.25,
                         s_bounds_log: tuple = (-8.0, 8.0), tol: float = 1e-2, safety_cap: int = 300,
                         h_fn: Callable | None = None, *, s_mode: str = 'adam', n_grid: int = 64,
                         vs_diag: bool = False, return_device: bool = False, x_init=None,
-                        return_info: bool = False):
+                        return_info: bool = False, _s_on_device: bool = False):
     """Choose (or optimise) the process-noise scale s per keypoint, then run the Kalman filter +
     RTS smoother.  Drop-in for the reference's eks/core.py:159-302.
 
@@ -494,6 +614,14 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
         return res + ({},) if return_info else res
     torch = _torch()
     t0 = time.perf_counter()
+    if not return_device and not hasattr(ys, 'detach'):
+        shp = np.shape(ys)
+        if len(shp) == 3:
+            tiles = _host_tiles(ys, ensemble_vars, shp[0], shp[1], shp[2], np.shape(m0s)[1], vs_diag, blocks, h_fn,
+                                return_device, searching_adam=smooth_param is None and s_mode == 'adam')
+            if tiles and len(tiles) > 1:
+                return _run_tiled_from_host(tiles, ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames, smooth_param,
+                                            lr, s_bounds_log, tol, safety_cap, s_mode, n_grid, vs_diag, return_info)
     P = _DeviceProblem(ys, m0s, S0s, As, Cs, Qs, ensemble_vars)
     K = P.K
     if not blocks:
@@ -522,14 +650,15 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
             guesses = _initial_guesses_per_keypoint(ev_host)
         s_dev, info = _optimize_on_device(P, blocks, s_frames, guesses, lr, s_bounds_log, tol,
                                           safety_cap, 1e-4, s_mode, n_grid)
-        s_finals[:] = s_dev.cpu().numpy()
-        _log_opt(blocks, s_finals, info)
+        if not _s_on_device:                     # (the tiled boundary reads s once, after the last tile is enqueued)
+            s_finals[:] = s_dev.cpu().numpy()
+            _log_opt(blocks, s_finals, info)
         logger.debug(f'[profile]   optimize_smooth_param: {time.perf_counter() - t1:.3f}s')
 
     t2 = time.perf_counter()
     ms, Vs = hip_ops.smooth(P.y, P.var, *P.params, s_dev.contiguous(), flags=P.flags, vs_diag=vs_diag)
     if return_device:
-        out = s_finals, ms.transpose(0, 1), Vs.transpose(0, 1)
+        out = (s_dev if _s_on_device else s_finals), ms.transpose(0, 1), Vs.transpose(0, 1)
     else:
         ms_h, Vs_h = _to_host(ms, Vs)
         out = s_finals, np.swapaxes(ms_h, 0, 1), np.swapaxes(Vs_h, 0, 1)

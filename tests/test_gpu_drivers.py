@@ -424,3 +424,66 @@ def test_ibl_paw_wrapper_interpolates_flips_and_smooths(tmp_path):
         back = pd.read_csv(out / f"multicam_{['left', 'right'][c]}_results.csv", header=[0, 1, 2], index_col=0)
         np.testing.assert_allclose(back.values, dfs[c].values, rtol=1e-12)
     assert order  # (directory listing is what pairs the members, as upstream)
+
+
+@pytest.mark.parametrize('mode', ['fixed', 'fixed_list', 'grid', 'adam', 'dense_fixed'])
+def test_host_boundary_pipelined_over_keypoint_tiles_equals_the_untiled_call(mode, monkeypatch):
+    """run_kalman_smoother on HOST arrays runs as a pipeline over keypoint tiles (upload of
+    tile i + 1 | kernels of tile i | download of tile i - 1 on three streams).  Keypoints are independent
+    (reference eks/core.py:293), so the result must be the untiled call's: bit for bit at a given s (the smoother's
+    chunking does not depend on the number of chains), the same s from the searches (the grid's NLL geometry does
+    depend on the tile's width: an argmin may differ only at a near-tie, and then both candidates' losses agree)."""
+    import torch
+    from eks_amd import core, synth
+    from eks_amd.core import run_kalman_smoother
+    monkeypatch.setattr(core, '_TILE_MIN_BYTES', 1 << 20)
+    monkeypatch.setattr(core, '_TILE_TARGET_BYTES', 6 << 20)
+    monkeypatch.setattr(core, '_TILE_ADAM', True)          # (off by default: see _host_tiles)
+    rng = np.random.default_rng(0)
+    if mode == 'dense_fixed':
+        T, K, D, O = 6000, 36, 3, 4
+        x = np.cumsum(rng.standard_normal((K, T, D)) * 0.5, axis=1)
+        Cs = rng.standard_normal((K, O, D))
+        ev = (rng.gamma(2.0, 0.4, (T, K, O)) + 0.02).astype(np.float32)
+        ys = (np.einsum('kod,ktd->kto', Cs, x) + rng.standard_normal((K, T, O)) * np.sqrt(np.swapaxes(ev, 0, 1))).astype(np.float32)
+        L = rng.standard_normal((K, D, D)) * 0.3
+        Qs = L @ np.swapaxes(L, 1, 2) + 0.2 * np.eye(D)
+        args = (ys, np.zeros((K, D)), np.tile(np.eye(D) * 3.0, (K, 1, 1)), np.tile(np.eye(D), (K, 1, 1)), Cs, Qs, ev)
+        kw = dict(smooth_param=4.0)
+    else:
+        T, K = 12_000, 80
+        y, var = synth.singlecam_observations_torch(T, K, seed=21, device=torch.device('cuda', 0))
+        ys = np.ascontiguousarray(np.transpose(y.cpu().numpy(), (1, 0, 2)))
+        ev = var.cpu().numpy()
+        eye = np.tile(np.eye(2), (K, 1, 1))
+        args = (ys, np.zeros((K, 2)), eye * ys.var(axis=1)[:, :, None], eye, eye, eye, ev)
+        kw = {'fixed': dict(smooth_param=7.5), 'fixed_list': dict(smooth_param=list(np.exp(rng.uniform(-3, 3, K)))),
+              'grid': dict(s_mode='grid', n_grid=64), 'adam': dict(safety_cap=40)}[mode]
+    s1, ms1, Vs1, info = run_kalman_smoother(*args, **kw, return_info=True)
+    assert info.get('mode') == 'tiled' and len(info['tiles']) >= 3, info.get('mode')
+    assert ms1.shape == args[0].shape[:2] + (args[1].shape[1],) and ms1.flags['C_CONTIGUOUS']      # (K,T,D), K-major
+    monkeypatch.setenv('EKS_HOST_UNTILED', '1')
+    s0, ms0, Vs0, info0 = run_kalman_smoother(*args, **kw, return_info=True)
+    assert info0.get('mode') != 'tiled'
+    if mode in ('fixed', 'fixed_list', 'dense_fixed'):
+        np.testing.assert_array_equal(s1, s0)
+        np.testing.assert_array_equal(ms1, ms0)
+        np.testing.assert_array_equal(Vs1, Vs0)
+    elif mode == 'grid':
+        same = s1 == s0
+        assert same.mean() >= 0.95, same.mean()
+        assert np.abs(np.log(s1) - np.log(s0)).max() < 0.3
+        np.testing.assert_array_equal(ms1[same], ms0[same])
+        np.testing.assert_array_equal(Vs1[same], Vs0[same])
+    else:
+        # the gradient kernel's chunking depends on the tile's width: the float32 chunk summaries round differently
+        # and the trajectories agree to ~1e-6 in log s, not to the bit - and so do the outputs at those s
+        assert np.abs(np.log(s1) - np.log(s0)).max() < 1e-4
+        assert (np.abs(ms1 - ms0) / np.abs(ms0).max(axis=(1, 2), keepdims=True)).max() < 1e-5
+        assert (np.abs(Vs1 - Vs0) / np.abs(Vs0).max(axis=(1, 2, 3), keepdims=True)).max() < 1e-5
+    # float64 inputs and vs_diag take the same path
+    if mode == 'fixed':
+        s2, ms2, Vd2 = run_kalman_smoother(args[0].astype(np.float64), *args[1:6], args[6].astype(np.float64),
+                                           smooth_param=7.5, vs_diag=True)
+        np.testing.assert_array_equal(ms2, ms0)
+        np.testing.assert_array_equal(Vd2, np.diagonal(Vs0, axis1=2, axis2=3))
