@@ -14,6 +14,9 @@ FLAG_DIAG_MODEL = 1
 FLAG_VS_DIAG = 2
 FLAG_UNIT_AC = 4
 FLAG_Q_PD = 8
+# eks_warmup units (include/eks_hip.h: EKS_WARM_*)
+WARM = dict(misc=1, diag=2, diag_nll=4, dense=8, dense_wave=16, dense_wide=32, loss=64, loss_ar1=128, multicam=256)
+WARM_ALL = 511
 
 
 class EksDims(ctypes.Structure):
@@ -60,6 +63,7 @@ SIGNATURES = {
     'eks_maha_inflate': (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32] + [c_void_p] * 5
                          + [c_double, c_double, c_double, c_void_p, c_void_p, c_void_p]),
     'eks_multicam_tables': (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32] + [c_void_p] * 9),
+    'eks_warmup': (ctypes.c_int, [c_uint32, c_void_p]),
     'eks_profile_enable': (ctypes.c_int, [ctypes.c_int]),
     'eks_knobs_reload': (ctypes.c_int, []),
     'eks_profile_drain': (ctypes.c_int, [c_void_p, c_size_t, c_void_p, c_int32]),

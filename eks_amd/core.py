@@ -115,15 +115,30 @@ def compute_initial_guesses(ensemble_vars) -> float:
     return float(round(float(np.nanstd(ev[1:] - ev[:-1])), 5))
 
 
-def _initial_guesses_per_keypoint(ev_host: np.ndarray) -> np.ndarray:
+def _guess_rows_from_device(ev_dev) -> np.ndarray:
+    """The (K, (T' - 1) O) matrix of frame-to-frame differences _initial_guesses_per_keypoint reduces, prepared on the
+    device from a (T, K, O) tensor: the float32 subtraction is the same IEEE operation wherever it runs and the
+    transposition is a copy, so the rows are the host version's bit for bit - without its 2 ms of strided host copies
+    in front of the first optimiser launch."""
+    ev = ev_dev[:2000]
+    if ev.shape[0] < 2:
+        raise ValueError('Not enough frames to compute temporal differences.')
+    d = (ev[1:] - ev[:-1]).transpose(0, 1).contiguous()
+    return d.reshape(d.shape[0], -1).cpu().numpy()
+
+
+def _initial_guesses_per_keypoint(ev_host: np.ndarray = None, rows: np.ndarray | None = None) -> np.ndarray:
     """compute_initial_guesses for every keypoint of a (T', K, O) array at once (missing or non-positive guesses
     become 2.0, as in run_kalman_smoother's loop).  Each keypoint's differences are laid out as one contiguous
     row in the order the 2-D call reduces them, so the values are the per-keypoint calls' bit for bit; a loop of K
     nanstd calls cost 13 ms at K = 256 - twice the optimisation it seeds."""
-    ev = np.asarray(ev_host)[:2000]
-    if ev.shape[0] < 2:
-        raise ValueError('Not enough frames to compute temporal differences.')
-    d = np.ascontiguousarray(np.swapaxes(ev[1:] - ev[:-1], 0, 1)).reshape(ev.shape[1], -1)    # (K, (T'-1) O)
+    if rows is not None:
+        d = rows                                                 # (prepared on the device: _guess_rows_from_device)
+    else:
+        ev = np.asarray(ev_host)[:2000]
+        if ev.shape[0] < 2:
+            raise ValueError('Not enough frames to compute temporal differences.')
+        d = np.ascontiguousarray(np.swapaxes(ev[1:] - ev[:-1], 0, 1)).reshape(ev.shape[1], -1)    # (K, (T'-1) O)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore', RuntimeWarning)          # all-NaN keypoints: nan -> 2.0 below
         sd = np.nanstd(d, axis=1)
@@ -645,9 +660,12 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
         t1 = time.perf_counter()
         guesses = np.full(K, 2.0)
         if s_mode == 'adam':            # the starting point of the optimiser (reference :233-236)
-            ev_host = _to_numpy(ensemble_vars)[:2000] if not hasattr(ensemble_vars, 'detach') \
-                else ensemble_vars[:2000].detach().cpu().numpy()
-            guesses = _initial_guesses_per_keypoint(ev_host)
+            if hasattr(ensemble_vars, 'detach') and ensemble_vars.is_cuda and ensemble_vars.dtype == torch.float32:
+                guesses = _initial_guesses_per_keypoint(rows=_guess_rows_from_device(ensemble_vars.detach()))
+            else:
+                ev_host = _to_numpy(ensemble_vars)[:2000] if not hasattr(ensemble_vars, 'detach') \
+                    else ensemble_vars[:2000].detach().cpu().numpy()
+                guesses = _initial_guesses_per_keypoint(ev_host)
         s_dev, info = _optimize_on_device(P, blocks, s_frames, guesses, lr, s_bounds_log, tol,
                                           safety_cap, 1e-4, s_mode, n_grid)
         if not _s_on_device:                     # (the tiled boundary reads s once, after the last tile is enqueued)

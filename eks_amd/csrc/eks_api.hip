@@ -4,6 +4,8 @@
 
 #include "eks_adam.hpp"
 #include "eks_diag_lane.hpp"
+#include <chrono>
+
 #include "eks_internal.hpp"
 
 using namespace eks;
@@ -291,6 +293,23 @@ int eks_multicam_tables(int32_t n_views, int32_t n_frames, int32_t n_keypoints, 
   if (!stats || !ev || !ms || !Vs || !C || !mean || !tables) return EKS_ERR_NULL;
   return multicam_tables(n_views, n_frames, n_keypoints, state_dim, stats, ev, ms, Vs, C, mean, tables, latent,
                          reinterpret_cast<hipStream_t>(stream));
+}
+
+int eks_warmup(uint32_t units, float* ms_per_unit) {
+  // order = the bits of EKS_WARM_* (include/eks_hip.h)
+  static void (*const touch[])() = {eks::touch_misc,       eks::touch_diag,       eks::touch_diag_nll,
+                                    eks::touch_dense,      eks::touch_dense_wave, eks::touch_dense_wide,
+                                    eks::touch_loss,       eks::touch_loss_ar1,   eks::touch_multicam};
+  for (unsigned i = 0; i < sizeof(touch) / sizeof(touch[0]); ++i) {
+    if (ms_per_unit) ms_per_unit[i] = 0.f;
+    if (!(units & (1u << i))) continue;
+    const auto t0 = std::chrono::steady_clock::now();
+    touch[i]();
+    if (ms_per_unit)
+      ms_per_unit[i] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? EKS_OK : EKS_ERR_HIP_BASE - (int)e;
 }
 
 }  // extern "C"

@@ -602,3 +602,5 @@ int ekf_smooth(const eks_dims_t& d, int n_data_keypoints, const float* y, const 
 }
 
 }  // namespace eks
+
+EKS_DEFINE_TOUCH(dense)

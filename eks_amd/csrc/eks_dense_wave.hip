@@ -781,3 +781,5 @@ extern "C" int eks_debug_dw_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(eks::g_dw_stamps), sizeof(eks::g_dw_stamps));
 }
 #endif
+
+EKS_DEFINE_TOUCH(dense_wave)

@@ -736,3 +736,5 @@ int dense_wide_replay(int T, int K, int D, int O, int B, int nc, const DenseMode
 }
 
 }  // namespace eks
+
+EKS_DEFINE_TOUCH(dense_wide)

@@ -837,3 +837,5 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
 }
 
 }  // namespace eks
+
+EKS_DEFINE_TOUCH(diag)

@@ -1200,3 +1200,5 @@ extern "C" int eks_debug_gf_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(eks::g_gf_stamps), sizeof(eks::g_gf_stamps));
 }
 #endif
+
+EKS_DEFINE_TOUCH(diag_nll)

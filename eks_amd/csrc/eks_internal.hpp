@@ -26,6 +26,28 @@ enum Knob {
 bool knob_set(Knob k);               // the variable exists
 int knob_int(Knob k, int dflt);      // its integer value, or dflt when unset
 
+// First-call latency: HIP loads a translation unit's code object the first time one of its kernels is used (1-3 MB
+// each here).  Every unit defines an empty kernel and a `touch_<unit>()` that asks for its attributes - which loads
+// the unit's code object and nothing else - so that eks_warmup can load what a caller is going to need ahead of the
+// first real call (eks_api.hip).
+#define EKS_DEFINE_TOUCH(unit)                                                                              \
+  namespace eks {                                                                                           \
+  __global__ void touch_##unit##_kernel() {}                                                                \
+  void touch_##unit() {                                                                                     \
+    hipFuncAttributes a;                                                                                    \
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(touch_##unit##_kernel));                   \
+  }                                                                                                         \
+  }
+void touch_misc();
+void touch_diag();
+void touch_diag_nll();
+void touch_dense();
+void touch_dense_wave();
+void touch_dense_wide();
+void touch_loss();
+void touch_loss_ar1();
+void touch_multicam();
+
 // per-kernel timing scope (eks_profile.hip); a no-op unless eks_profile_enable(1) was called
 class ProfScope {
  public:

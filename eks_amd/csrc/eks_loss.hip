@@ -40,3 +40,5 @@ int dense_nll(const eks_dims_t& d, const float* y, const double* rconst, const D
 }
 
 }  // namespace eks
+
+EKS_DEFINE_TOUCH(loss)

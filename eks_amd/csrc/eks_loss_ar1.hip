@@ -41,3 +41,5 @@ int ar1_nll(const eks_dims_t& d, const float* y, const float* var, const double*
 }
 
 }  // namespace eks
+
+EKS_DEFINE_TOUCH(loss_ar1)

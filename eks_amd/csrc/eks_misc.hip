@@ -1144,3 +1144,5 @@ int ensemble_stats(int M, int V, int T, int K, const float* markers, int avg_mod
 }
 
 }  // namespace eks
+
+EKS_DEFINE_TOUCH(misc)

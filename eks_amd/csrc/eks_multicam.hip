@@ -267,3 +267,5 @@ int multicam_tables(int V, int T, int K, int D, const float* stats, const float*
 }
 
 }  // namespace eks
+
+EKS_DEFINE_TOUCH(multicam)

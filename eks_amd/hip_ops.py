@@ -16,11 +16,69 @@ from . import _lib
 from ._lib import FLAG_DIAG_MODEL, FLAG_Q_PD, FLAG_UNIT_AC, FLAG_VS_DIAG, EksDims
 
 
+_auto_warm = [False]
+
+
 def require_gpu() -> torch.device:
     if not torch.cuda.is_available():
         raise _lib.EksHipError('no ROCm device visible: eks_amd has no CPU fallback for the Kalman '
                                'path (the float64 oracle under oracle/ is test infrastructure only)')
+    if not _auto_warm[0]:
+        # first entry of the process into the accelerated path: start loading every unit's code object on a
+        # background thread (~20 ms in all) - it overlaps the caller's own set-up instead of being paid launch by
+        # launch inside the first smoothing call.  EKS_NO_AUTO_WARMUP=1 leaves loading to the first launches.
+        _auto_warm[0] = True
+        import os
+        if not os.environ.get('EKS_NO_AUTO_WARMUP'):
+            try:
+                warmup('all', background=True)
+            except Exception:           # warming is an optimisation: never the reason a call fails
+                pass
     return torch.device('cuda', torch.cuda.current_device())
+
+
+_WARM_SETS = {
+    # what the first call of each driver is going to launch
+    'diag': ('misc', 'diag', 'diag_nll'),                                   # singlecam: scalar chains
+    'dense': ('misc', 'dense', 'dense_wave', 'dense_wide', 'loss', 'multicam'),   # multicam, linear
+    'pupil': ('misc', 'dense', 'dense_wave', 'loss_ar1'),
+    'all': tuple(_lib.WARM),
+}
+_warm_done = set()
+_warm_thread = None
+
+
+def warmup(what: str = 'all', background: bool = False):
+    """eks_warmup: load the code objects the named path (`diag` = singlecam, `dense` = linear multicam, `pupil`,
+    `all`) is going to need, so that the first smoothing call of the process does not pay for it (tens of
+    milliseconds per translation unit: for a 2 000-frame recording that was the whole run time).  With
+    background=True the loading runs on a daemon thread - the drivers start it the moment they are entered, so it
+    overlaps their host-side set-up (CSV parsing, ensembling bookkeeping); calls into the library made meanwhile just
+    wait for the unit they need.  Returns {unit: milliseconds} (foreground) or the thread."""
+    import threading
+    global _warm_thread
+    require_gpu()
+    lib = _lib.load()
+    units = [u for u in _WARM_SETS[what] if u not in _warm_done]
+    mask = 0
+    for u in units:
+        mask |= _lib.WARM[u]
+        _warm_done.add(u)
+    if not mask:
+        return {} if not background else _warm_thread
+    dev = torch.cuda.current_device()
+
+    def work():
+        torch.cuda.set_device(dev)
+        ms = (ctypes.c_float * 9)()
+        _lib.check(lib.eks_warmup(mask, ms), 'eks_warmup')
+        return {u: float(ms[i]) for i, u in enumerate(_lib.WARM) if mask & _lib.WARM[u]}
+
+    if background:
+        _warm_thread = threading.Thread(target=work, name='eks-warmup', daemon=True)
+        _warm_thread.start()
+        return _warm_thread
+    return work()
 
 
 def _ptr(t: torch.Tensor | None):

@@ -242,6 +242,25 @@ int eks_multicam_tables(int32_t n_views, int32_t n_frames, int32_t n_keypoints, 
 int eks_profile_enable(int on);
 int eks_profile_drain(char* names, size_t names_bytes, float* ms, int32_t max_n);
 
+/* ---- first-call latency.  The HIP runtime loads a translation unit's code object (1-3 MB each here) the first
+ * time one of its kernels is launched, so the FIRST call of a process into each part of the library pays tens of
+ * milliseconds of loading on top of its kernels - for the reference's own 2 000-frame recordings that is the whole
+ * run time.  eks_warmup loads the units named in `units` now (no kernel runs, no device memory is touched; needs a
+ * current device) so that a caller - e.g. on a background thread while its CSV files parse - takes the cost off its
+ * first smoothing call.  ms_per_unit (optional, 9 floats, bit order) receives each unit's load time.  No reference
+ * counterpart (XLA compiles on first call instead: eks/core.py:585-588 mentions "28 separate XLA compilations"). */
+#define EKS_WARM_MISC 1u        /* eks_const_r, eks_ensemble, eks_order_stats, eks_argmin_s, eks_adam_step */
+#define EKS_WARM_DIAG 2u        /* eks_smooth on scalar chains (EKS_FLAG_DIAG_MODEL) */
+#define EKS_WARM_DIAG_NLL 4u    /* eks_nll / eks_adam_run on scalar chains */
+#define EKS_WARM_DENSE 8u       /* general (D, O): scan, generic summarize / replay, eks_ekf_smooth */
+#define EKS_WARM_DENSE_WAVE 16u /* general (D, O), narrow sessions (and their smoothing-distribution gradient) */
+#define EKS_WARM_DENSE_WIDE 32u /* general (D, O), wide sessions */
+#define EKS_WARM_LOSS 64u       /* eks_nll on the general path (dual numbers) */
+#define EKS_WARM_LOSS_AR1 128u  /* eks_ar1_nll (pupil) */
+#define EKS_WARM_MULTICAM 256u  /* eks_maha_inflate, eks_multicam_tables */
+#define EKS_WARM_ALL 511u
+int eks_warmup(uint32_t units, float* ms_per_unit);
+
 /* ---- measurement hook.  The EKS_* tuning variables (alternative kernel
  * organisations kept for A/B runs; none is needed in use) are read ONCE, on the first call into the
  * library, never per call.  eks_knobs_reload re-reads them (a test that flips a variable between two

@@ -456,3 +456,20 @@ def test_gram_never_builds_the_outer_product_tensor_beyond_its_cap():
     # 2-D input (the per-keypoint calls of the prior / process-noise set-up)
     y = torch.randn(7000, 3, dtype=torch.float64, generator=g)
     assert torch.allclose(mc._gram(y, max_temp_bytes=4096), y.T @ y, rtol=1e-12, atol=1e-9)
+
+
+def test_guess_rows_prepared_by_torch_equal_the_host_preparation_bit_for_bit():
+    """The optimiser's initial guesses from a device tensor: the differences and their transposition run in torch
+    (on the device in the drivers), the nanstd and the rounding stay numpy's - same bits as the all-host form."""
+    import torch
+    from eks_amd import core
+    rng = np.random.default_rng(3)
+    ev = rng.gamma(2.0, 0.3, (2600, 9, 2)).astype(np.float32)
+    ev[17, 2, 1] = np.nan
+    ev[:, 5] = 0.25                                            # a constant keypoint: std 0 -> the 2.0 fallback
+    a = core._initial_guesses_per_keypoint(ev)
+    b = core._initial_guesses_per_keypoint(rows=core._guess_rows_from_device(torch.as_tensor(ev)))
+    np.testing.assert_array_equal(a, b)
+    assert a[5] == 2.0
+    with pytest.raises(ValueError, match='Not enough frames'):
+        core._guess_rows_from_device(torch.as_tensor(ev[:1]))
