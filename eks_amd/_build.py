@@ -24,11 +24,24 @@ def hipcc() -> str:
     raise RuntimeError('hipcc not found (ROCm toolchain required to build libeks_hip.so)')
 
 
-def _newer(target: str, deps: list[str]) -> bool:
-    if not os.path.exists(target):
-        return False
-    t = os.path.getmtime(target)
-    return all(os.path.getmtime(d) <= t for d in deps)
+def _digest(paths: list[str], flags: list[str]) -> str:
+    """sha256 over the contents of `paths` and the compiler flags: what an object file was built FROM.  (Modification
+    times do not survive the copy to the GPU box and say nothing about contents; round 3 skipped by mtime.)"""
+    import hashlib
+    h = hashlib.sha256(' '.join(flags).encode())
+    for p in sorted(paths):
+        h.update(os.path.basename(p).encode())
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stamp(obj: str) -> str:
+    try:
+        with open(obj + '.sha256') as f:
+            return f.read().strip()
+    except OSError:
+        return ''
 
 
 # The SLP vectoriser packs adjacent scalar f32 operations of the candidate filters into v_pk_*_f32
@@ -39,8 +52,16 @@ def _newer(target: str, deps: list[str]) -> bool:
 PER_FILE_FLAGS = {'eks_diag_nll.hip': ['-fno-slp-vectorize'], 'eks_diag.hip': ['-fno-slp-vectorize']}
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, prove: bool = True) -> str:
+    """Compile what is out of date (by CONTENT: every object carries the sha256 of its source, the headers and the
+    flags it was built from) and link.  prove=True additionally compiles the smallest unit afresh into a temporary
+    file on every call - so that a box that was shipped up-to-date objects still shows that its hipcc builds this
+    tree - and the whole record goes to eks_amd/lib/BUILD_INFO.json.  EKS_FORCE_REBUILD=1 rebuilds everything."""
+    import json
+    import tempfile
+    import time
     os.makedirs(LIBDIR, exist_ok=True)
+    force = force or bool(os.environ.get('EKS_FORCE_REBUILD'))
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hpp')]
     headers.append(os.path.join(os.path.dirname(HERE), 'include', 'eks_hip.h'))
     cc = hipcc()
@@ -48,12 +69,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
              '-Wno-unused-result', '-I', CSRC] + os.environ.get('EKS_EXTRA_HIPCC_FLAGS', '').split()
     objs = []
     jobs = []
+    digests = {}
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(LIBDIR, src.replace('.hip', '.o'))
         objs.append(o)
-        if force or not _newer(o, [s] + headers):
-            jobs.append([cc, *flags, *PER_FILE_FLAGS.get(src, []), '-c', s, '-o', o])
+        fl = flags + PER_FILE_FLAGS.get(src, [])
+        digests[o] = _digest([s] + headers, fl)
+        if force or not os.path.exists(o) or _stamp(o) != digests[o]:
+            jobs.append((o, [cc, *fl, '-c', s, '-o', o]))
 
     def run(cmd):
         if verbose:
@@ -63,12 +87,42 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f'hipcc failed: {" ".join(cmd)}\n{r.stdout}\n{r.stderr}')
         return r
 
+    def compile_one(job):
+        o, cmd = job
+        run(cmd)
+        with open(o + '.sha256', 'w') as f:
+            f.write(digests[o])
+
+    t0 = time.time()
     with ThreadPoolExecutor(max_workers=min(7, max(1, len(jobs)))) as ex:
-        list(ex.map(run, jobs))
-    if jobs or force or not _newer(LIB, objs):
+        list(ex.map(compile_one, jobs))
+    link_digest = _digest(objs, [])
+    relinked = bool(jobs) or force or not os.path.exists(LIB) or _stamp(LIB) != link_digest
+    if relinked:
         run([cc, '-shared', '-fPIC', f'--offload-arch={ARCH}', *objs, '-o', LIB])
+        with open(LIB + '.sha256', 'w') as f:
+            f.write(link_digest)
+    proof = None
+    if prove:
+        src = os.path.join(CSRC, 'eks_profile.hip')
+        with tempfile.TemporaryDirectory() as tmp:
+            t1 = time.time()
+            run([cc, *flags, '-c', src, '-o', os.path.join(tmp, 'proof.o')])
+            proof = dict(unit='eks_profile.hip', seconds=round(time.time() - t1, 2),
+                         bytes=os.path.getsize(os.path.join(tmp, 'proof.o')))
+    info = dict(hipcc=cc, arch=ARCH, compiled=[os.path.basename(o) for o, _ in jobs], relinked=relinked,
+                reused=[os.path.basename(o) for o in objs if o not in {j[0] for j in jobs}],
+                seconds=round(time.time() - t0, 2), toolchain_proof=proof, library_bytes=os.path.getsize(LIB),
+                when=time.strftime('%Y-%m-%dT%H:%M:%S'))
+    try:
+        with open(os.path.join(LIBDIR, 'BUILD_INFO.json'), 'w') as f:
+            json.dump(info, f, indent=1)
+    except OSError:
+        pass
+    if verbose:
+        print(json.dumps(info))
     return LIB
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    print(build(force='--force' in sys.argv, verbose=True, prove='--no-proof' not in sys.argv))

@@ -77,6 +77,35 @@ def nll_grid(y, Rc, m0, S0, A, C, Q, s_cand, nthreads: int = 0):
     return out
 
 
+def smooth_diag(y, Rd, m0, S0, A, C, Q, s, nthreads: int = 0):
+    """The diagonal model (A, C, Q, S0 diagonal, D == O) as scalar chains: y (K,T,D), Rd (K,T,D) or (K,D).
+    Returns ms (K,T,D), Vd (K,T,D) (diagonal of the covariance), nll (K,)."""
+    lib = load()
+    y, Rd, m0, S0, A, C, Q = map(_c, (y, Rd, m0, S0, A, C, Q))
+    K, T, D = y.shape
+    s = _c(np.broadcast_to(s, (K,)))
+    ms = np.empty((K, T, D))
+    Vd = np.empty((K, T, D))
+    nll = np.empty(K)
+    rc = lib.eksc_smooth_diag(K, T, D, _p(y), _p(Rd), int(Rd.ndim == 2), _p(m0), _p(S0), _p(A), _p(C), _p(Q), _p(s),
+                              _p(ms), _p(Vd), _p(nll), int(nthreads))
+    if rc:
+        raise RuntimeError(f'eksc_smooth_diag rc={rc}')
+    return ms, Vd, nll
+
+
+def nll_grid_diag(y, Rc, m0, S0, A, C, Q, s_cand, nthreads: int = 0):
+    lib = load()
+    y, Rc, m0, S0, A, C, Q, s_cand = map(_c, (y, Rc, m0, S0, A, C, Q, s_cand))
+    K, T, D = y.shape
+    out = np.empty((K, len(s_cand)))
+    rc = lib.eksc_nll_grid_diag(K, T, D, _p(y), _p(Rc), _p(m0), _p(S0), _p(A), _p(C), _p(Q), _p(s_cand),
+                                len(s_cand), _p(out), int(nthreads))
+    if rc:
+        raise RuntimeError(f'eksc_nll_grid_diag rc={rc}')
+    return out
+
+
 def nll_directional(y, Rd, m0, S0, A, C, Q, dA, dQ):
     """One chain: y (T,O), Rd (T,O) or (O,), directions dA, dQ (n_dir,D,D).  Returns
     (nll, dnll (n_dir,)) - complex-step derivatives of the C filter."""

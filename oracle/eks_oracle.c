@@ -390,6 +390,103 @@ int eksc_nll_directional(int T, int D, int O, const double* y, const double* Rd,
   return 0;
 }
 
+/* ---- the DIAGONAL model as scalar chains (bench.py's like-for-like CPU baseline) --------------------------------
+ * With A, C, Q, S0 diagonal and D == O (singlecam: eks/singlecam_smoother.py:246-284) a keypoint is D independent
+ * scalar chains; the reference does not exploit this (it runs dynamax's general matrices), the GPU path does.  This
+ * is the same scalar recursion on the host: filter in the product forms P r / (P + r), RTS backwards, float64, the
+ * filtered beliefs kept in two T-long arrays per chain.  OpenMP over chains.  ms [K][T][D], Vd [K][T][D] (the
+ * diagonal of the covariance; the caller expands it), nll [K] (sum over the keypoint's chains).
+ * eksc_nll_grid_diag: the constant-R loss for n_cand candidates (the candidates of a chain advance side by side in the
+ * frame loop so that y is read once, as in the GPU kernel). */
+int eksc_smooth_diag(int K, int T, int D, const double* y, const double* Rd, int r_const, const double* m0,
+                     const double* S0, const double* A, const double* C, const double* Q, const double* s,
+                     double* ms, double* Vd, double* nll, int nthreads) {
+  if (K <= 0 || T <= 0 || D <= 0 || D > MAXD) return 1;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+  for (int k = 0; k < K; ++k) nll[k] = 0.0;
+  int fail = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int n = 0; n < K * D; ++n) {
+    const int k = n / D, d = n % D;
+    const size_t dd = (size_t)k * D * D + (size_t)d * (D + 1);
+    const double a = A[dd], c = C[dd], sq = s[k] * Q[dd];
+    double* mf = (double*)malloc(sizeof(double) * 2 * (size_t)T);
+    if (!mf) { fail = 1; continue; }
+    double* Pf = mf + T;
+    double m = m0[(size_t)k * D + d], P = S0[dd], ll = 0.0;
+    for (int t = 0; t < T; ++t) {
+      const double yt = y[((size_t)k * T + t) * D + d];
+      double r = r_const ? Rd[(size_t)k * D + d] : Rd[((size_t)k * T + t) * D + d];
+      if (!(r > 1e-12)) r = 1e-12;
+      const double S = c * c * P + r, g = 1.0 / S, e = yt - c * m;
+      ll += -0.5 * (LOG2PI + log(S) + e * e * g);
+      const double Kg = P * c * g;
+      m += Kg * e;
+      P = P * r * g;
+      mf[t] = m;
+      Pf[t] = P;
+      m = a * m;
+      P = a * a * P + sq;
+    }
+    double msn = mf[T - 1], Vsn = Pf[T - 1];
+    ms[((size_t)k * T + (T - 1)) * D + d] = msn;
+    Vd[((size_t)k * T + (T - 1)) * D + d] = Vsn;
+    for (int t = T - 2; t >= 0; --t) {
+      const double Pp = a * a * Pf[t] + sq, G = Pf[t] * a / Pp;
+      msn = mf[t] + G * (msn - a * mf[t]);
+      Vsn = Pf[t] * sq / Pp + G * G * Vsn;
+      ms[((size_t)k * T + t) * D + d] = msn;
+      Vd[((size_t)k * T + t) * D + d] = Vsn;
+    }
+    free(mf);
+#pragma omp atomic
+    nll[k] -= ll;
+  }
+  return fail;
+}
+
+int eksc_nll_grid_diag(int K, int T, int D, const double* y, const double* Rc, const double* m0, const double* S0,
+                       const double* A, const double* C, const double* Q, const double* s_cand, int n_cand,
+                       double* nll, int nthreads) {
+  if (K <= 0 || T <= 0 || D <= 0 || D > MAXD || n_cand <= 0 || n_cand > 256) return 1;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+  for (size_t i = 0; i < (size_t)K * n_cand; ++i) nll[i] = 0.0;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int n = 0; n < K * D; ++n) {
+    const int k = n / D, d = n % D;
+    const size_t dd = (size_t)k * D * D + (size_t)d * (D + 1);
+    const double a = A[dd], c = C[dd], q = Q[dd];
+    double r = Rc[(size_t)k * D + d];
+    if (!(r > 1e-12)) r = 1e-12;
+    double m[256], P[256], ll[256], sq[256];
+    for (int i = 0; i < n_cand; ++i) {
+      m[i] = m0[(size_t)k * D + d];
+      P[i] = S0[dd];
+      ll[i] = 0.0;
+      sq[i] = s_cand[i] * q;
+    }
+    for (int t = 0; t < T; ++t) {
+      const double yt = y[((size_t)k * T + t) * D + d];
+      for (int i = 0; i < n_cand; ++i) {
+        const double S = c * c * P[i] + r, g = 1.0 / S, e = yt - c * m[i];
+        ll[i] += log(S) + e * e * g;
+        m[i] = a * (m[i] + P[i] * c * g * e);
+        P[i] = a * a * P[i] * r * g + sq[i];
+      }
+    }
+    for (int i = 0; i < n_cand; ++i) {
+      const double v = 0.5 * ((double)T * LOG2PI + ll[i]);
+#pragma omp atomic
+      nll[(size_t)k * n_cand + i] += v;
+    }
+  }
+  return 0;
+}
+
 int eksc_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -256,3 +256,36 @@ def test_center_predictions_semantics():
     for k in range(3):
         np.testing.assert_array_equal(good[k], np.where(mask[:, k])[0][:nmin])
         np.testing.assert_allclose(means[0, :, 0, k], ens[0, :, good[k], k, 0:2].mean(axis=0))
+
+
+def test_c_port_scalar_chain_form_of_the_diagonal_model_equals_the_general_port():
+    """bench.py's like-for-like CPU baseline (eksc_smooth_diag / eksc_nll_grid_diag: the diagonal model as independent
+    scalar chains, product forms) against the general-matrix C port and the NumPy oracle: same numbers to 1e-10,
+    constant and time-varying R, the 1e-12 variance clip included."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(12)
+    K, T = 5, 700
+    y = np.cumsum(rng.standard_normal((K, T, 2)), axis=1) + rng.standard_normal((K, T, 2))
+    Rd = rng.gamma(2.0, 0.3, (K, T, 2)) + 0.05
+    Rd[::37, :, 0] = 1e-12
+    eye = np.tile(np.eye(2), (K, 1, 1))
+    A = eye * rng.uniform(0.9, 1.0, (K, 2))[:, :, None]
+    C = eye * rng.uniform(0.5, 1.5, (K, 2))[:, :, None]
+    Q = eye * rng.uniform(0.5, 2.0, (K, 2))[:, :, None]
+    m0, S0 = rng.standard_normal((K, 2)), eye * 3.0
+    s = np.exp(rng.uniform(-3, 3, K))
+    ms, Vs, nll = c_oracle.smooth(y, Rd, m0, S0, A, C, Q, s)
+    ms_d, Vd_d, nll_d = c_oracle.smooth_diag(y, Rd, m0, S0, A, C, Q, s)
+    Vd = np.diagonal(Vs, axis1=2, axis2=3)
+    assert np.abs(ms_d - ms).max() < 1e-10 * np.abs(ms).max()
+    # (at the clip the general port's P - K S K' cancels: 1e-4 of a 3e-12 variance; the product forms agree with the
+    #  information-form oracle below to 1e-8)
+    assert (np.abs(Vd_d - Vd) / Vd).max() < 1e-3 and (np.abs(Vd_d - Vd) / Vd)[1::37].max() < 1e-9
+    assert (np.abs(nll_d - nll) / np.abs(nll)).max() < 1e-10
+    ms_o, Vs_o, _ = orc.info_form_smoother(y, m0, S0, A, C, Q, s, Rd)[:3]
+    assert (np.abs(Vd_d - np.diagonal(Vs_o, axis1=2, axis2=3)) / Vd_d).max() < 1e-8
+    Rc = orc.constant_R_from_timevarying(Rd)
+    cand = np.exp(np.linspace(-8, 8, 17))
+    g1 = c_oracle.nll_grid(y, Rc, m0, S0, A, C, Q, cand)
+    g2 = c_oracle.nll_grid_diag(y, Rc, m0, S0, A, C, Q, cand)
+    assert (np.abs(g1 - g2) / np.abs(g1)).max() < 1e-10
