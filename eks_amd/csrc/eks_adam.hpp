@@ -66,4 +66,65 @@ struct AdamFuse {
   int32_t *n_active_cur, *n_active_next;
 };
 
+
+// ---- two-parameter optimiser of the pupil smoother (eks/ibl_pupil_smoother.py:560-604), one chain k of n.
+// state: {u_d, u_c, mom_d, mom_c, vel_d, vel_c, prev_loss, iters, done}.  nll == nullptr: initialisation only.
+// Always emits the AR(1) dynamics of the next evaluation and the tangents d/du_d, d/du_c; returns whether the chain
+// is still running afterwards.  Shared by the stand-alone step kernel (eks_misc.hip) and the fused finish + step at
+// the end of the pupil loss (eks_dense_wave.hip).
+__device__ __forceinline__ bool pupil_adam_step_chain(int k, int n, const double* __restrict__ latent_var,
+                                                      const double* __restrict__ nll,
+                                                      const double* __restrict__ dnll, double lr, double tol,
+                                                      int cap, double* __restrict__ state, double* __restrict__ a,
+                                                      double* __restrict__ q, double* __restrict__ da,
+                                                      double* __restrict__ dq) {
+  double* st = state + (size_t)k * 9;
+  double u[2] = {st[0], st[1]};
+  double prev = st[6], iters = st[7], done = st[8];
+  if (nll && done == 0.0 && iters < (double)cap) {
+    const double L = nll[k], cnt = iters + 1.0;
+    const double c1 = 1.0 - pow(0.9, cnt), c2 = 1.0 - pow(0.999, cnt);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const double g = dnll[(size_t)i * n + k];
+      const double mom = 0.9 * st[2 + i] + 0.1 * g;
+      const double vel = 0.999 * st[4 + i] + 0.001 * g * g;
+      u[i] -= lr * (mom / c1) / (sqrt(vel / c2) + 1e-8);
+      st[i] = u[i];
+      st[2 + i] = mom;
+      st[4 + i] = vel;
+    }
+    const bool stop = isfinite(prev) &&
+                      fabs(L - prev) < tol * fabs(log(fmax(prev, 1e-12))) + 1e-6;
+    prev = L;
+    iters = cnt;
+    done = stop ? 1.0 : 0.0;
+    st[6] = prev; st[7] = iters; st[8] = done;
+  }
+  // s = sigmoid(u) (1 - 2 eps) + eps, eps = 1e-3 (:506-508); A = diag(s_d, s_c, s_c),
+  // Q = diag(var (1 - s^2)) (:542-548)
+  constexpr double eps = 1e-3;
+  double s[2], ds[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double sig = 1.0 / (1.0 + exp(-u[i]));
+    s[i] = sig * (1.0 - 2.0 * eps) + eps;
+    ds[i] = sig * (1.0 - sig) * (1.0 - 2.0 * eps);
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int i = j == 0 ? 0 : 1;
+    const double lv = latent_var[(size_t)k * 3 + j];
+    const size_t p = (size_t)k * 3 + j;
+    a[p] = s[i];
+    q[p] = lv * (1.0 - s[i] * s[i]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      da[(size_t)t * n * 3 + p] = t == i ? ds[i] : 0.0;
+      dq[(size_t)t * n * 3 + p] = t == i ? -2.0 * s[i] * ds[i] * lv : 0.0;
+    }
+  }
+  return done == 0.0 && iters < (double)cap;
+}
+
 }  // namespace eks

@@ -233,9 +233,18 @@ int eks_pupil_adam_run(const eks_dims_t* d, const float* y, const float* var, co
   if (n_iters < 0) return EKS_ERR_SHAPE;
   if (d && d->state_dim != 3) return EKS_ERR_SHAPE;   // (diameter, com_x, com_y)
   if (!nll || !dnll) return EKS_ERR_NULL;
+  if (check_dims(d) != EKS_OK) return check_dims(d);
+  if (!y || !var || !m0 || !S0 || !C || !latent_var || !state || !a || !q || !da || !dq || !n_active) return EKS_ERR_NULL;
+  if (!workspace) return EKS_ERR_WORKSPACE;
   for (int it = 0; it < n_iters; ++it) {
-    int rc = eks_ar1_nll(d, y, var, m0, S0, C, a, q, da, dq, 2, nll, dnll, workspace, workspace_bytes,
-                         stream);
+    // loss + tangents + step in three launches where the smoothing-distribution form covers the shape (round 4)
+    int rc = dense_wave_ar1_score_step(*d, y, var, m0, S0, C, latent_var, lr, tol, safety_cap, state, a, q, da, dq, nll,
+                                       dnll, n_active, workspace, workspace_bytes,
+                                       reinterpret_cast<hipStream_t>(stream));
+    if (rc == EKS_OK) continue;
+    if (rc != EKS_ERR_UNSUPPORTED) return rc;
+    rc = eks_ar1_nll(d, y, var, m0, S0, C, a, q, da, dq, 2, nll, dnll, workspace, workspace_bytes,
+                     stream);
     if (rc != EKS_OK) return rc;
     rc = eks_pupil_adam_step(d->n_keypoints, latent_var, nll, dnll, lr, tol, safety_cap, state, a, q,
                              da, dq, n_active, stream);

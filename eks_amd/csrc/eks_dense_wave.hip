@@ -46,6 +46,7 @@
 
 #include <type_traits>
 
+#include "eks_adam.hpp"
 #include "eks_dense_lane.hpp"
 #include "eks_dense_shfl.hpp"
 #include "eks_internal.hpp"
@@ -656,10 +657,58 @@ __global__ __launch_bounds__(64) void dw_ar1_finish_kernel(int K, int nwb, int n
   }
 }
 
+// The pupil optimiser's iteration in THREE launches instead of five stream operations (round 4): the unit sums, the
+// loss / tangent derivatives AND the Adam step of eks/ibl_pupil_smoother.py:571-594 for all chains by one block -
+// thread (k, q) sums plane q of chain k, thread (k, 0) steps chain k and rewrites a, q, da, dq for the next
+// evaluation, the count of chains still running is a block reduction (no memset, no atomics).  K <= 64 chains.
+struct PupilStep {
+  const double* latent_var;
+  double* state;
+  double *a, *q, *da, *dq;       // (writable views of DwAr1's inputs)
+  int32_t* n_active;
+  double lr, tol;
+  int cap;
+};
+template <int D>
+__global__ __launch_bounds__(512) void dw_ar1_finish_step_kernel(int K, int nwb, const double* __restrict__ part,
+                                                                double* __restrict__ nll, double* __restrict__ dnll,
+                                                                PupilStep P) {
+  constexpr int NQ = 1 + 2 * D;
+  __shared__ double tot[64][NQ + 1];
+  __shared__ int running;
+  const int k = threadIdx.x >> 3, q = threadIdx.x & 7;
+  if (threadIdx.x == 0) running = 0;
+  if (k < K && q < NQ) {
+    double acc = 0.0;
+    for (int wb = 0; wb < nwb; ++wb) acc += part[((size_t)q * nwb + wb) * K + k];
+    tot[k][q] = acc;
+  }
+  __syncthreads();
+  if (k < K && q < 2) {                       // the two tangents of the pupil's parameters (read BEFORE the step rewrites them)
+    double g = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      const size_t p = ((size_t)q * K + k) * D + i;
+      g += tot[k][1 + i] * P.dq[p] + tot[k][1 + D + i] * P.da[p];
+    }
+    dnll[(size_t)q * K + k] = -g;
+    if (q == 0) nll[k] = -tot[k][0];
+  }
+  __syncthreads();
+  __threadfence_block();
+  if (k < K && q == 0) {
+    if (pupil_adam_step_chain(k, K, P.latent_var, nll, dnll, P.lr, P.tol, P.cap, P.state, P.a, P.q, P.da, P.dq))
+      atomicAdd(&running, 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *P.n_active = running;
+}
+
 // mode 0: the smoother (var, ms, Vs); 1: loss + d/d log s (rconst, nll, dnll); 2: pupil loss + tangents
 struct DwAr1 {
   const double *a, *q, *da, *dq;
   int n_tan;
+  const PupilStep* step = nullptr;       // mode 2: fold the finish and the optimiser step into one launch
 };
 static int dense_wave_run(const eks_dims_t& d, int mode, const float* y, const float* var, const double* rconst,
                           const DwAr1& ar, const DenseModel& Mm, float* ms, float* Vs, double* nll, double* dnll,
@@ -724,8 +773,11 @@ static int dense_wave_run(const eks_dims_t& d, int mode, const float* y, const f
       EKS_DW_S(3, 8, 2, 2)
     else
       EKS_DW_S(3, 8, 1, 2)
-    hipLaunchKernelGGL(dw_ar1_finish_kernel<3>, dim3(K), dim3(64), 0, st, K, G.nwb, ar.n_tan, part, ar.da, ar.dq, nll,
-                       dnll);
+    if (ar.step && K <= 64 && ar.n_tan == 2)
+      hipLaunchKernelGGL(dw_ar1_finish_step_kernel<3>, dim3(1), dim3(512), 0, st, K, G.nwb, part, nll, dnll, *ar.step);
+    else
+      hipLaunchKernelGGL(dw_ar1_finish_kernel<3>, dim3(K), dim3(64), 0, st, K, G.nwb, ar.n_tan, part, ar.da, ar.dq, nll,
+                         dnll);
     return hip_status(hipGetLastError());
   }
   if (D == 2) {
@@ -772,6 +824,21 @@ int dense_wave_ar1_score(const eks_dims_t& d, const float* y, const float* var, 
   const DenseModel Mm{m0, S0, nullptr, C, nullptr, nullptr};
   return dense_wave_run(d, 2, y, var, nullptr, DwAr1{a, q, da, dq, n_tan}, Mm, nullptr, nullptr, nll, dnll, ws,
                         ws_bytes, st);
+}
+// one iteration of the pupil optimiser: loss + two tangents + Adam step in three launches; returns EKS_ERR_UNSUPPORTED
+// when the shape is not covered (the caller then takes eks_ar1_nll + eks_pupil_adam_step)
+int dense_wave_ar1_score_step(const eks_dims_t& d, const float* y, const float* var, const double* m0, const double* S0,
+                              const double* C, const double* latent_var, double lr, double tol, int cap, double* state,
+                              double* a, double* q, double* da, double* dq, double* nll, double* dnll,
+                              int32_t* n_active, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int T = d.n_frames, K = d.n_keypoints;
+  if (!(d.flags & EKS_FLAG_Q_PD) || K > 64 || !dense_wave_ar1_covers(T, K, d.state_dim, d.obs_dim))
+    return EKS_ERR_UNSUPPORTED;
+  const PupilStep P{latent_var, state, a, q, da, dq, n_active, lr, tol, cap};
+  const DenseModel Mm{m0, S0, nullptr, C, nullptr, nullptr};
+  DwAr1 ar{a, q, da, dq, 2};
+  ar.step = &P;
+  return dense_wave_run(d, 2, y, var, nullptr, ar, Mm, nullptr, nullptr, nll, dnll, ws, ws_bytes, st);
 }
 
 }  // namespace eks

@@ -87,6 +87,10 @@ int dense_smooth(const eks_dims_t& d, const float* y, const float* var, const De
 bool dense_wave_covers(int T, int K, int D, int O);
 size_t dense_wave_workspace_bytes(int T, int K, int D);
 bool dense_wave_ar1_covers(int T, int K, int D, int O);
+int dense_wave_ar1_score_step(const eks_dims_t& d, const float* y, const float* var, const double* m0, const double* S0,
+                              const double* C, const double* latent_var, double lr, double tol, int cap, double* state,
+                              double* a, double* q, double* da, double* dq, double* nll, double* dnll,
+                              int32_t* n_active, void* ws, size_t ws_bytes, hipStream_t st);
 int dense_wave_ar1_score(const eks_dims_t& d, const float* y, const float* var, const double* m0, const double* S0,
                          const double* C, const double* a, const double* q, const double* da, const double* dq,
                          int n_tan, double* nll, double* dnll, void* ws, size_t ws_bytes, hipStream_t st);

@@ -945,53 +945,7 @@ __global__ void pupil_adam_step_kernel(int n, const double* __restrict__ latent_
                                        double* __restrict__ dq, int32_t* __restrict__ n_active) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
-  double* st = state + (size_t)k * 9;
-  double u[2] = {st[0], st[1]};
-  double prev = st[6], iters = st[7], done = st[8];
-  if (nll && done == 0.0 && iters < (double)cap) {
-    const double L = nll[k], cnt = iters + 1.0;
-    const double c1 = 1.0 - pow(0.9, cnt), c2 = 1.0 - pow(0.999, cnt);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const double g = dnll[(size_t)i * n + k];
-      const double mom = 0.9 * st[2 + i] + 0.1 * g;
-      const double vel = 0.999 * st[4 + i] + 0.001 * g * g;
-      u[i] -= lr * (mom / c1) / (sqrt(vel / c2) + 1e-8);
-      st[i] = u[i];
-      st[2 + i] = mom;
-      st[4 + i] = vel;
-    }
-    const bool stop = isfinite(prev) &&
-                      fabs(L - prev) < tol * fabs(log(fmax(prev, 1e-12))) + 1e-6;
-    prev = L;
-    iters = cnt;
-    done = stop ? 1.0 : 0.0;
-    st[6] = prev; st[7] = iters; st[8] = done;
-  }
-  // s = sigmoid(u) (1 - 2 eps) + eps, eps = 1e-3 (:506-508); A = diag(s_d, s_c, s_c),
-  // Q = diag(var (1 - s^2)) (:542-548)
-  constexpr double eps = 1e-3;
-  double s[2], ds[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const double sig = 1.0 / (1.0 + exp(-u[i]));
-    s[i] = sig * (1.0 - 2.0 * eps) + eps;
-    ds[i] = sig * (1.0 - sig) * (1.0 - 2.0 * eps);
-  }
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int i = j == 0 ? 0 : 1;
-    const double lv = latent_var[(size_t)k * 3 + j];
-    const size_t p = (size_t)k * 3 + j;
-    a[p] = s[i];
-    q[p] = lv * (1.0 - s[i] * s[i]);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      da[(size_t)t * n * 3 + p] = t == i ? ds[i] : 0.0;
-      dq[(size_t)t * n * 3 + p] = t == i ? -2.0 * s[i] * ds[i] * lv : 0.0;
-    }
-  }
-  if (done == 0.0 && iters < (double)cap) atomicAdd(n_active, 1);
+  if (pupil_adam_step_chain(k, n, latent_var, nll, dnll, lr, tol, cap, state, a, q, da, dq)) atomicAdd(n_active, 1);
 }
 
 int pupil_adam_step(int n, const double* latent_var, const double* nll, const double* dnll, double lr,

@@ -24,12 +24,13 @@ def require_gpu() -> torch.device:
         raise _lib.EksHipError('no ROCm device visible: eks_amd has no CPU fallback for the Kalman '
                                'path (the float64 oracle under oracle/ is test infrastructure only)')
     if not _auto_warm[0]:
-        # first entry of the process into the accelerated path: start loading every unit's code object on a
-        # background thread (~20 ms in all) - it overlaps the caller's own set-up instead of being paid launch by
-        # launch inside the first smoothing call.  EKS_NO_AUTO_WARMUP=1 leaves loading to the first launches.
+        # first entry of the process into the accelerated path.  EKS_AUTO_WARMUP=1 starts loading every unit's code
+        # object on a background thread here.  OFF by default: measured (tools/first_call.py, profiles/r04_*_first_call
+        # .txt) the units load in 0.7-2.6 ms each when their first launch needs them, and a thread loading all nine at
+        # once competes with the first call for the runtime's loader lock - 44 / 33 ms against 23 / 24 ms without it.
         _auto_warm[0] = True
         import os
-        if not os.environ.get('EKS_NO_AUTO_WARMUP'):
+        if os.environ.get('EKS_AUTO_WARMUP'):
             try:
                 warmup('all', background=True)
             except Exception:           # warming is an optimisation: never the reason a call fails

@@ -491,10 +491,11 @@ def test_host_boundary_pipelined_over_keypoint_tiles_equals_the_untiled_call(mod
 
 def test_first_call_of_a_fresh_process_is_bounded():
     """the first run_kalman_smoother of a process on the reference's own data size (2 000 frames x
-    4 keypoints).  The library's code objects are loaded by eks_warmup on a background thread the moment the
-    accelerated path is entered (hip_ops.require_gpu), torch's own first-use costs remain: the first call must stay
-    under 60 ms (tools/first_call.py measures 21 - 24 ms on an idle box; 65 - 240 ms in round 3), steady calls
-    under 5 ms."""
+    4 keypoints).  Measured (tools/first_call.py): the library's nine code objects load in 0.7 - 2.6 ms each at their
+    first launch; what is left of a first call is the process's first use of torch's allocator and kernels: 23 - 24 ms
+    on an idle box (65 - 240 ms in round 3's figures, which included the session's first large allocations), steady
+    calls 0.4 - 0.5 ms.  Bounds with room for a busy box: first < 60 ms, steady < 5 ms.  (eks_warmup / hip_ops.warmup
+    load units ahead of time for callers who want that; a background warm-up at first entry was measured SLOWER.)"""
     import re
     import subprocess
     import sys
