@@ -1,5 +1,5 @@
-O=gpurun_out/r03_fuzz2.txt; : > $O
-echo "## fuzz_parity 60 cases seed 401" >> $O; python tools/fuzz_parity.py 60 401 2>&1 | tail -2 >> $O
+O=${1:-gpurun_out/r04_fuzz.txt}; : > $O
+echo "## fuzz_parity 120 cases seed 411" >> $O; python tools/fuzz_parity.py 120 411 2>&1 | tail -2 >> $O
 echo "## fuzz_parity2 40 cases seed 402" >> $O; python tools/fuzz_parity2.py 40 402 2>&1 | tail -2 >> $O
 echo "## fuzz_drivers 30 cases seed 403" >> $O; python tools/fuzz_drivers.py 30 403 2>&1 | tail -2 >> $O
 echo "## fuzz_adam 20 cases seed 404" >> $O; python tools/fuzz_adam.py 20 404 2>&1 | tail -2 >> $O
