@@ -921,7 +921,8 @@ static int lean_geometry(int T, int N, int n_cand, int* b0_out, int* bn_out) {
 // chunk within 32-bit buffer offsets, and the assembly's chunk table within LDS.
 static bool lean_grid_ok(int T, int N, int D, int n_cand) {
   if (knob_int(KNOB_NLL_LEGACY, 0)) return false;
-  if (n_cand < kLeanNC || N <= 32 || (D & (D - 1)) != 0 || D > 64) return false;
+  // (a lean block is kLeanWaves waves of kLeanNC candidates: up to 64 candidates; longer grids keep the general kernel)
+  if (n_cand < kLeanNC || n_cand > kLeanNC * kLeanWaves || N <= 32 || (D & (D - 1)) != 0 || D > 64) return false;
   int b0, bn;
   const int ncn = lean_geometry(T, N, n_cand, &b0, &bn);
   if (ncn < 2 || (long)(bn > b0 ? bn : b0) * N * 4 >= (1L << 31)) return false;

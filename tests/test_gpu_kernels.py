@@ -458,6 +458,8 @@ def test_nll_grid_converged_entry_chunks_match_c_oracle(T, K, unit, var_scale, l
     (30000, 40, 2, True, 64, False, 400.0, 0),      # poles at 0.999: the slow groups' chunks fall back to exact entry
     (30000, 40, 2, False, 64, False, 30.0, 512),    # short chunks: rho^t outlives them for the slow groups
     (20000, 64, 1, True, 64, False, 1.0, 800),      # one chain per keypoint, two rounds of blocks
+    (9000, 40, 2, True, 96, False, 1.0, 0),         # more than 64 candidates: the general kernel takes the call
+    (6000, 33, 2, True, 16, False, 1.0, 0),         # exactly one lean wave of candidates
 ])
 def test_nll_grid_lean_kernel_shapes_and_fallbacks(T, K, D, unit, n_cand, per_kp, var_scale, chunk, set_knob):
     """diag_nll_grid_kernel (round 4): head role (chunk 0 at 4 candidates per lane) + lean role (16 candidates per
