@@ -539,7 +539,12 @@ __global__ __launch_bounds__(64 * CH) void diag_scan_groups_kernel(int N, int n0
   constexpr int NW = CH;                   // waves per block (64 slots x CH chains / 64 lanes)
   __shared__ float tot[2][5][NW][CH];      // [direction][field][wave][chain]
   const int c = threadIdx.x % CH, slot = threadIdx.x / CH, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int n = n0 + blockIdx.x * CH + c;   // n0: first chain of this launch (keypoint-tiled passes)
+  // Workgroups are dealt to the 8 XCDs round-robin and each XCD has its own L2: with CH = 4 the 16-byte pieces
+  // of one 64-byte line belong to four consecutive blocks, i.e. to four different L2s, and the launch fetched
+  // 64 MB for 8 MB of aggregates on the C3 shape (rocprofv3 FETCH_SIZE, profiles/r04_a_pmc_summary.txt).  Blocks
+  // of one XCD therefore take CONSECUTIVE chain groups (XCD x: the x-th eighth of the chains).
+  const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int n = n0 + lb * CH + c;           // n0: first chain of this launch (keypoint-tiled passes)
   const int per = (S.nblk + 63) / 64;      // <= PER, or the slot re-reads in batches of PER
   const int q0 = min(slot * per, S.nblk), q1 = min(q0 + per, S.nblk);
   const bool live = n < n1;                // chains [n0, n1) of the N whose planes these are

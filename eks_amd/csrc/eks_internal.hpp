@@ -14,6 +14,15 @@ struct DiagModel;
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int hip_status(hipError_t e) { return e == hipSuccess ? EKS_OK : EKS_ERR_HIP_BASE - (int)e; }
 
+// MI355X deals the workgroups of a launch to its 8 XCDs round-robin (block b runs on XCD b % 8) and every XCD
+// has its own L2.  Launches whose NEIGHBOURING blocks touch the same cache lines (pieces of one line, shared rows)
+// want those blocks on one XCD: this maps the hardware block index to a logical one such that XCD x works on the
+// x-th contiguous eighth of the logical range (a bijection for any grid size).
+__device__ __forceinline__ int xcd_contiguous_block(int b, int nb) {
+  const int x = b & 7, i = b >> 3, q = nb >> 3, r = nb & 7;
+  return x * q + (x < r ? x : r) + i;
+}
+
 // A/B tuning knobs: environment variables read ONCE, the first time any entry
 // point asks (thread-safe function-local static), never in the per-call host path - the library stays
 // re-entrant and a hot loop of eks_smooth calls does not walk the environment block.
