@@ -724,14 +724,22 @@ def main():
     gathered = [torch.empty(Kmax, dtype=torch.float64, device=dev) for _ in range(world)]
     gathered_host = [torch.empty(Kmax, dtype=torch.float64) for _ in range(world)]
 
+    # fixed s (configs[1]): a step is 16 us of GPU time - the call is prepared once (argument checks, workspace,
+    # ctypes argument list), so that the host's enqueue cost (19 us per plain hip_ops.smooth call, 12.5 us
+    # prepared; tools/c2_host_time.py) is not what the line reports
+    prepared = None if n_cand else hip_ops.PreparedSmooth(y, var, m0, S0, eye, eye, eye, s_fixed, flags=flags,
+                                                          out=(ms, Vs))
+
     def step(gather_outputs=False):
-        if n_cand:
+        if prepared is not None:
+            s = s_fixed
+            prepared()
+        elif n_cand:
             rc = hip_ops.const_r(var, 1e-4)
             nll = hip_ops.nll(y, rc, m0, S0, eye, eye, eye, cand, flags=flags)
             s, _ = hip_ops.argmin_s(nll, cand)
-        else:
-            s = s_fixed
-        hip_ops.smooth(y, var, m0, S0, eye, eye, eye, s, flags=flags, out=(ms, Vs))
+        if prepared is None:
+            hip_ops.smooth(y, var, m0, S0, eye, eye, eye, s, flags=flags, out=(ms, Vs))
         if use_dist:
             # the gather of s_finals (K float64 per rank) is asynchronous: it runs on the collective
             # stream while this rank's next step is being enqueued, and is waited for before the
@@ -764,7 +772,10 @@ def main():
     events_on = not args.no_kernel_events
     # inside the timed region only the roofline kernel (diag_replay) is bracketed by HIP events:
     # two event records per step; the stage breakdown comes from a short untimed pass afterwards
-    lib.eks_profile_enable(2 if events_on else 0)
+    # (not for the 16 us steps of a fixed-s small session: two event records per step would be a tenth of it -
+    # there the kernel time comes from the untimed pass below)
+    region_events = events_on and not (prepared is not None and T * K < 5_000_000)
+    lib.eks_profile_enable(2 if region_events else 0)
     # `--regions` back-to-back timed regions of exactly `--steps` steps, each closed by the barrier +
     # synchronize of sync(); the headline is the MEDIAN region (box-to-box and run-to-run spread of a
     # 12 ms region is larger than most kernel changes), min / max beside it
@@ -776,7 +787,7 @@ def main():
         sync()
         region_dt.append(time.perf_counter() - t0)
     lib.eks_profile_enable(0)
-    prof = drain_profile(lib) if events_on else {}
+    prof = drain_profile(lib) if region_events else {}
     stages = {}
     if events_on and rank == 0:
         lib.eks_profile_enable(1)
@@ -784,7 +795,10 @@ def main():
             step()
         sync()
         lib.eks_profile_enable(0)
-        stages = {k: float(np.mean(v)) for k, v in drain_profile(lib).items()}
+        raw = drain_profile(lib)
+        stages = {k: float(np.mean(v)) for k, v in raw.items()}
+        if not region_events:
+            prof = raw
     elif events_on and use_dist:
         for _ in range(5):          # keep the ranks' collectives matched
             step()
@@ -856,7 +870,10 @@ def main():
                                    'command (not measured in this run)') if traffic_src else None,
                 'algorithmic_bytes_per_launch': SMOOTH_BYTES_PER_UNIT * local_units,
                 'kernel_avg_ms': k3, 'launches_timed': len(prof.get('diag_replay', [])),
-                'kernel_avg_ms_source': 'HIP events on the launch stream, every launch inside the timed regions',
+                'kernel_avg_ms_source': ('HIP events on the launch stream, every launch inside the timed regions'
+                                         if region_events else
+                                         'HIP events on the launch stream, 5 untimed steps after the timed regions '
+                                         '(no event records inside the regions of a 16 us step)'),
             }
             stage_info = {
                 'stage_avg_ms': avg,

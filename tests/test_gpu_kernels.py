@@ -849,3 +849,24 @@ def test_score_gradient_at_the_conditioning_threshold():
         # the optimiser sees lr * g through Adam's normalisation; a relative 1e-5 of the gradient's own size (or of
         # 1e-6 of the loss where the gradient vanishes) cannot move a step or the stop test
         assert (np.abs(g1 - g0) / np.maximum(np.abs(g0), 1e-6 * np.abs(nll0))).max() < 1e-5, (u, g1, g0)
+
+
+def test_prepared_smooth_is_the_same_call_and_follows_changed_contents():
+    """hip_ops.PreparedSmooth (arguments checked and packed once, for callers that smooth small sessions in a loop)
+    enqueues exactly eks_smooth: bit-identical to hip_ops.smooth, and a second call after new smoothing parameters
+    were written INTO the prepared `s` tensor gives what a fresh call with them gives."""
+    from eks_amd import hip_ops
+    arrs, y_tk, var_tk = _singlecam_problem(3000, 9, seed=77)
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    y, var = _dev(y_tk), _dev(var_tk)
+    params = _params_dev(arrs)
+    s = _dev(np.full(9, 3.0))
+    call = hip_ops.PreparedSmooth(y, var, *params, s, flags=flags)
+    ms1, Vs1 = (t.clone() for t in call())
+    ref = hip_ops.smooth(y, var, *params, s, flags=flags)
+    assert torch.equal(ms1, ref[0]) and torch.equal(Vs1, ref[1])
+    s.copy_(_dev(np.linspace(0.1, 40.0, 9)))
+    ms2, Vs2 = call()
+    ref2 = hip_ops.smooth(y, var, *params, s.clone(), flags=flags)
+    assert torch.equal(ms2, ref2[0]) and torch.equal(Vs2, ref2[1])
+    assert not torch.equal(ms2, ms1)
