@@ -62,7 +62,7 @@ int eks_smooth(const eks_dims_t* d, const float* y, const float* var, const doub
 
 size_t eks_const_r_workspace_bytes(const eks_dims_t* d) {
   if (check_dims(d) != EKS_OK) return 0;
-  return const_r_workspace_bytes(d->n_keypoints * d->obs_dim);
+  return const_r_workspace_bytes(d->n_frames, d->n_keypoints * d->obs_dim);
 }
 
 int eks_const_r(const eks_dims_t* d, const float* var, double min_var, double* rconst,

@@ -580,6 +580,7 @@ __global__ __launch_bounds__(64 * kGfWaves) void diag_nll_grad_fused_kernel(NllG
 // falls back to the sequential walk, done by its lane of wave 0.  One round of loads instead of
 // ncn dependent ones: 17.6 -> ~6 us on the C3 shape.
 constexpr int kAsmWaves = 16;
+constexpr int kAsmPer = 8;                        // chunks per wave of the grid kernel's assembly (registers): ncn <= 128
 
 __global__ __launch_bounds__(64 * kAsmWaves) void diag_nll_assemble_par_kernel(NllGeom G, DiagModel M,
                                                                               NllWs W,
@@ -809,7 +810,19 @@ __global__ __launch_bounds__(64 * kAsmWaves) void diag_nll_assemble_lean_kernel(
   const int k = live ? n / G.D : 0, d = live ? n - k * G.D : 0;
   const size_t dd = (size_t)k * G.D * G.D + (size_t)d * (G.D + 1);
   double ll0 = 0.0;
-  for (int j = w; j < G.ncn; j += kAsmWaves) {
+  // everything a wave will need is requested BEFORE the block's barrier: the entry state of chunk j is the exit
+  // state b of chunk j - 1 (through LDS), the rest of chunk j's summary does not depend on it (the second round
+  // trip of loads behind the barrier was a quarter of this launch)
+  double ell_r[kAsmPer];
+  float eta_r[kAsmPer], xr_r[kAsmPer];
+  const double Jc = live ? (double)LG.Jc[(size_t)ci * G.N + n] : 0.0;
+#pragma unroll
+  for (int q = 0; q < kAsmPer; ++q) {
+    const int j = w + q * kAsmWaves;
+    ell_r[q] = 0.0;
+    eta_r[q] = 0.f;
+    xr_r[q] = 0.f;
+    if (j >= G.ncn) continue;                      // (wave-uniform)
     if (j > 0 && LG.flags[((size_t)j * G.ntile + tile) * LG.ngrp16 + g16] != 0) seq = 1;   // (wave-uniform)
     if (!live) continue;
     const size_t o = ((size_t)j * W.ncp + ci) * G.N + n;
@@ -822,18 +835,21 @@ __global__ __launch_bounds__(64 * kAsmWaves) void diag_nll_assemble_lean_kernel(
       bnext[lane] = A * inv * (mr + P * eta) + b;
     } else {
       bnext[(size_t)j * 64 + lane] = W.b[o];
+      eta_r[q] = W.eta[o];
+      ell_r[q] = W.ell[o];
+      xr_r[q] = W.xr[(size_t)j * G.N + n];
     }
   }
   __syncthreads();
   const bool sequential = seq != 0;
   double acc = (w == 0) ? ll0 : 0.0;
   if (!sequential && live) {
-    const double J = (double)LG.Jc[(size_t)ci * G.N + n];
-    for (int j = (w == 0 ? kAsmWaves : w); j < G.ncn; j += kAsmWaves) {
-      const size_t o = ((size_t)j * W.ncp + ci) * G.N + n;
-      const double eta = W.eta[o], ell = W.ell[o];
-      const double mr = bnext[(size_t)(j - 1) * 64 + lane] - (double)W.xr[(size_t)j * G.N + n];
-      acc += ell + eta * mr - 0.5 * J * mr * mr;
+#pragma unroll
+    for (int q = 0; q < kAsmPer; ++q) {
+      const int j = w + q * kAsmWaves;
+      if (j < 1 || j >= G.ncn) continue;
+      const double mr = bnext[(size_t)(j - 1) * 64 + lane] - (double)xr_r[q];
+      acc += ell_r[q] + (double)eta_r[q] * mr - 0.5 * Jc * mr * mr;
     }
   }
   part[w * 64 + lane] = acc;
@@ -926,7 +942,7 @@ static bool lean_grid_ok(int T, int N, int D, int n_cand) {
   int b0, bn;
   const int ncn = lean_geometry(T, N, n_cand, &b0, &bn);
   if (ncn < 2 || (long)(bn > b0 ? bn : b0) * N * 4 >= (1L << 31)) return false;
-  return ((size_t)ncn + kAsmWaves) * 64 * sizeof(double) <= 60 * 1024;
+  return ncn <= kAsmWaves * kAsmPer && ((size_t)ncn + kAsmWaves) * 64 * sizeof(double) <= 60 * 1024;
 }
 
 static NllGeom make_geom(int T, int N, int D, int n_cand, int per_keypoint, bool grad, int ncl) {

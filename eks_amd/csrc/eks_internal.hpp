@@ -30,7 +30,7 @@ enum Knob {
   KNOB_SMOOTH_UNFUSED, KNOB_SUMMARIZE_REVERSE, KNOB_REPLAY_FORWARD, KNOB_REPLAY_RECOMPUTE, KNOB_SCAN_CH,
   KNOB_SMOOTH_TILE, KNOB_DENSE_CHUNK, KNOB_NLL_NCL, KNOB_NLL_CHUNK, KNOB_NLL_CHUNK0, KNOB_NLL_WPB,
   KNOB_NLL_EXACT_ENTRY, KNOB_NLL_ASSEMBLE_SEQ, KNOB_DENSE_LEGACY, KNOB_NLL_GRAD_UNFUSED, KNOB_NLL_GRAD_CHUNK,
-  KNOB_DENSE_TREE_SCAN, KNOB_DENSE_DUAL_GRAD, KNOB_NLL_LEGACY, KNOB_COUNT
+  KNOB_DENSE_TREE_SCAN, KNOB_DENSE_DUAL_GRAD, KNOB_NLL_LEGACY, KNOB_MED_ROWS, KNOB_COUNT
 };
 bool knob_set(Knob k);               // the variable exists
 int knob_int(Knob k, int dflt);      // its integer value, or dflt when unset
@@ -145,7 +145,7 @@ int ar1_nll(const eks_dims_t& d, const float* y, const float* var, const double*
             hipStream_t st);
 
 // misc (eks_misc.hip)
-size_t const_r_workspace_bytes(int N);
+size_t const_r_workspace_bytes(int T, int N);
 int const_r(int T, int N, const float* var, double min_var, double* rconst, void* ws,
             size_t ws_bytes, hipStream_t st);
 int order_stats(int T, int N, const float* x, int r_lo, int r_hi, float* out, int32_t* nan_count,

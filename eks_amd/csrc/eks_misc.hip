@@ -27,7 +27,7 @@ __device__ __forceinline__ uint32_t var_key(float v, bool& valid) {
 //                (coalesced both ways; 4 % of the data).
 //   S2 bracket : per chain, the sample's order statistics 4.5 sigma either side of its median
 //                (two histogram passes in LDS) bracket the true median: [lo, hi] holds ~6 % of the frames.
-//   S3 collect : the full pass.  Lanes = chains, 64 rows per wave in two flights of 32 loads per
+//   S3 collect : the full pass.  Lanes = chains, 16 or 32 rows per wave in flights of 16 loads per
 //                lane; frames below lo and valid frames are counted in registers, frames inside
 //                [lo, hi] are staged per chain and wave in LDS (branch-free, register slot
 //                counters) and appended to the chain's list as one contiguous run per block
@@ -45,23 +45,20 @@ __device__ __forceinline__ uint32_t var_key(float v, bool& valid) {
 constexpr int kMedSmall = 1024;      // T up to here: one block per chain selects from the column
 constexpr int kMedSamples = 4096;    // sample rows per chain (fewer for short sequences)
 constexpr int kMedList = 16384;      // capacity of a chain's in-bracket list
-#ifndef EKS_COL_ROWS
-#define EKS_COL_ROWS 64
-#endif
 #ifndef EKS_COL_FLIGHT
-#define EKS_COL_FLIGHT 32
+#define EKS_COL_FLIGHT 16
 #endif
 #ifndef EKS_COL_SLOTS
 #define EKS_COL_SLOTS 16
 #endif
-constexpr int kColRows = EKS_COL_ROWS;        // rows per wave in the full pass
-constexpr int kColFlight = EKS_COL_FLIGHT;       // loads in flight per lane
+constexpr int kColFlight = EKS_COL_FLIGHT;       // loads in flight per lane; rows per wave (a launch parameter): a multiple of it
 constexpr int kColWaves = 8;         // waves per block of the full pass (same 64 chains)
 
 struct BracketWs {
   uint32_t *lo, *hi, *less, *valid, *cnt;   // [N]
   uint32_t* smp;                             // [N][S]
-  uint32_t* list;                            // [N][kMedList]
+  uint32_t* list;                            // [N][cap]
+  uint32_t cap;                              // list capacity per chain (list_capacity(T) >= kMedList)
   uint32_t* fallback;                        // [N] 1 -> too few valid samples: select from the column
 };
 
@@ -419,15 +416,15 @@ __global__ __launch_bounds__(256) void sample_bracket_kernel(int N, int S, Brack
   }
 }
 
-// S3: the full pass.  Block = 8 waves over the SAME 64 chains (8 consecutive 64-row slabs, two
-// flights of 32 loads per lane).  Every wave stages its in-bracket keys per chain in its OWN LDS
+// S3: the full pass.  Block = 8 waves over the SAME 64 chains (8 consecutive R-row slabs, flights
+// of 16 loads per lane; R: collect_rows_per_wave).  Every wave stages its in-bracket keys per chain in its OWN LDS
 // slots with the slot counter in a register - no atomics and no branches on the per-row path.
 // After the barrier the runs of the 8 waves are written out back to back, one global atomic per
 // chain and block.
-constexpr int kColSlots = EKS_COL_SLOTS;   // expected 64 rows x ~7 % = 4.5 in-bracket keys per lane and wave
+constexpr int kColSlots = EKS_COL_SLOTS;   // expected 32 rows x ~7 % = 2.3 in-bracket keys per lane and wave
 static_assert(kColWaves == 8, "the run write-out maps lanes to (8 source waves) x (8 slots)");
 
-__global__ __launch_bounds__(64 * kColWaves) void bracket_collect_kernel(int T, int N,
+__global__ __launch_bounds__(64 * kColWaves, 8) void bracket_collect_kernel(int T, int N, int R,
                                                                         const float* __restrict__ var,
                                                                         BracketWs B) {
   __shared__ uint32_t stage[kColWaves][kColSlots][65];   // [wave][slot][chain], padded
@@ -437,8 +434,8 @@ __global__ __launch_bounds__(64 * kColWaves) void bracket_collect_kernel(int T, 
   const int tile = blockIdx.x % ntile, slab = blockIdx.x / ntile;
   const int n = tile * 64 + lane;
   const bool live = n < N && !B.fallback[n];
-  const int t_begin = (slab * kColWaves + w) * kColRows;
-  const int t_end = min(T, t_begin + kColRows);
+  const int t_begin = (slab * kColWaves + w) * R;    // R rows per wave (a multiple of kColFlight, chosen by the launch)
+  const int t_end = min(T, t_begin + R);
   uint32_t less = 0, nvalid = 0, mine = 0;
   if (live && t_begin < T) {
     const uint32_t lo = B.lo[n], span = B.hi[n] - lo, cap = (uint32_t)kColSlots - 1u;
@@ -466,16 +463,40 @@ __global__ __launch_bounds__(64 * kColWaves) void bracket_collect_kernel(int T, 
         mine += in;
       }
     };
-    if (rows == kColRows) {          // whole slab: unconditional loads, kColFlight in flight
+    // The same for a flight WITHOUT a NaN in any lane (the rule): the clip is an integer maximum on the bit
+    // patterns (negative values and -0 are negative integers, everything else orders like its bits), validity
+    // needs no per-key work, and one v_cmp_u_f32 tests two keys for NaN at once - 8.5 vector instructions per
+    // key instead of 12 (the pass issues 13.5 M of them on the C3 shape: a quarter of its time at 4 cycles each).
+    auto eat_clean = [&](const float (&v)[kColFlight]) -> bool {
+      bool nan = false;
+#pragma unroll
+      for (int u = 0; u + 1 < kColFlight; u += 2) nan |= __builtin_isunordered(v[u], v[u + 1]);
+      if (kColFlight & 1) nan |= v[kColFlight - 1] != v[kColFlight - 1];
+      if (__any(nan)) return false;
+      constexpr int kClipBits = 0x2b8cbccc;                    // 1e-12f
+      static_assert(kColFlight > 0, "");
+#pragma unroll
+      for (int u = 0; u < kColFlight; ++u) {
+        const int bits = __builtin_bit_cast(int, v[u]);
+        const uint32_t key = (uint32_t)(bits > kClipBits ? bits : kClipBits);
+        less += key < lo;
+        const bool in = (key - lo) <= span;
+        stage[w][mine < cap ? mine : cap][lane] = key;
+        mine += in;
+      }
+      nvalid += kColFlight;
+      return true;
+    };
+    if (rows == R) {                 // whole slab: unconditional loads, kColFlight in flight
       // (requesting both flights up front - 64 loads per lane - changes nothing: 0.116 vs 0.114 ms
       // for the whole median on the C3 shape; the pass is not bound by a wave's own latency)
-      for (int t = 0; t < kColRows; t += kColFlight) {
+      for (int t = 0; t < R; t += kColFlight) {
         float v[kColFlight];
 #pragma unroll
         for (int u = 0; u < kColFlight; ++u)
           v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
               rsrc, voff, (unsigned)(t + u) * row_bytes, 0));
-        eat(v);
+        if (!eat_clean(v)) eat(v);
       }
     } else {                         // the ragged last slab: rows past the end count as NaN
       for (int t = 0; t < rows; t += kColFlight) {
@@ -495,7 +516,7 @@ __global__ __launch_bounds__(64 * kColWaves) void bracket_collect_kernel(int T, 
         const uint32_t key = var_key(var[(size_t)(t_begin + t) * N + n], valid);
         if (valid && (key - lo) <= span && seen++ >= cap) {
           const uint32_t g = atomicAdd(&B.cnt[n], 1u);
-          if (g < (uint32_t)kMedList) B.list[(size_t)n * kMedList + g] = key;
+          if (g < B.cap) B.list[(size_t)n * B.cap + g] = key;
         }
       }
       mine = cap;
@@ -533,8 +554,8 @@ __global__ __launch_bounds__(64 * kColWaves) void bracket_collect_kernel(int T, 
 #pragma unroll
     for (int q0 = 0; q0 < kColSlots; q0 += 8) {
       const uint32_t q = (uint32_t)(q0 + sq);
-      if (q < cnt && off + q < (uint32_t)kMedList)
-        B.list[(size_t)nn * kMedList + off + q] = stage[sw][q][c];
+      if (q < cnt && off + q < B.cap)
+        B.list[(size_t)nn * B.cap + off + q] = stage[sw][q][c];
     }
   }
 }
@@ -624,6 +645,63 @@ __device__ void median_column(int T, int N, const float* __restrict__ var, doubl
   }
 }
 
+// Ranks a <= b <= a + 1 (0-based) of the L keys of one chain's in-bracket list IN GLOBAL MEMORY (contiguous, so the
+// sweeps are coalesced and L2-resident): sequences so long that the ~7 % of their frames inside the bracket exceed
+// the LDS list of bracket_finish_kernel (T > ~230 000) - before round 4 such chains fell back to median_column's
+// five strided sweeps of the whole column (400 000 frames x 16 keypoints: 1.55 ms for the call instead of 0.1).
+// Same MSB-first radix select, 4 x 8 bits + one sweep for the successor.  Whole 256-thread block; hist: 256
+// counters, sc: 6 words.
+__device__ void select_two_from_list(const uint32_t* __restrict__ keys, uint32_t L, uint32_t a, uint32_t b,
+                                     uint32_t* hist, uint32_t* sc, uint32_t& v_lo, uint32_t& v_hi) {
+  uint32_t &sh_prefix = sc[0], &sh_rank = sc[1], &sh_less = sc[3], &sh_eq = sc[4], &sh_next = sc[5];
+  uint32_t prefix = 0, rank = a, less = 0;
+  for (int pass = 0; pass < 4; ++pass) {
+    hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const int shift = 24 - 8 * pass;
+    for (uint32_t i = threadIdx.x; i < L; i += 256) {
+      const uint32_t key = keys[i];
+      if (pass > 0 && (key >> (shift + 8)) != prefix) continue;
+      atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t cum = 0;
+      int bin = 255;
+      for (int q = 0; q < 256; ++q) {
+        if (cum + hist[q] > rank) {
+          bin = q;
+          break;
+        }
+        cum += hist[q];
+      }
+      less += cum;
+      rank -= cum;
+      prefix = (prefix << 8) | (uint32_t)bin;
+      sh_prefix = prefix;
+      sh_rank = rank;
+      sh_less = less;
+      sh_eq = hist[bin];
+      sh_next = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    prefix = sh_prefix;
+    rank = sh_rank;
+    less = sh_less;
+  }
+  const uint32_t eq = sh_eq, key_lo = prefix;
+  uint32_t best = 0xFFFFFFFFu;
+  for (uint32_t i = threadIdx.x; i < L; i += 256) {
+    const uint32_t key = keys[i];
+    if (key > key_lo && key < best) best = key;
+  }
+  if (best != 0xFFFFFFFFu) atomicMin(&sh_next, best);
+  __syncthreads();
+  v_lo = key_lo;
+  v_hi = (b < less + eq) ? key_lo : sh_next;
+  __syncthreads();
+}
+
 // S4: one block per chain
 __global__ __launch_bounds__(256) void bracket_finish_kernel(int T, int N, const float* __restrict__ var,
                                                             double min_var, BracketWs B,
@@ -636,12 +714,20 @@ __global__ __launch_bounds__(256) void bracket_finish_kernel(int T, int N, const
   const uint32_t r_lo = cnt ? (cnt - 1) / 2 : 0, r_hi = cnt / 2;
   // too few valid samples, the bracket missed the median, or heavy duplicates overflowed the
   // list: this block selects from the chain's whole column instead (block-uniform branch)
-  if (B.fallback[n] || cnt == 0 || inside > (uint32_t)kMedList || r_lo < less ||
-      r_hi >= less + inside) {
+  if (B.fallback[n] || cnt == 0 || inside > B.cap || r_lo < less || r_hi >= less + inside) {
     median_column(T, N, var, min_var, n, rconst, hist, sc);
     return;
   }
-  for (int i = threadIdx.x; i < (int)inside; i += 256) vals[i] = B.list[(size_t)n * kMedList + i];
+  if (inside > (uint32_t)kMedList) {    // a long sequence: the list does not fit LDS, select in place (block-uniform)
+    uint32_t v_lo, v_hi;
+    select_two_from_list(B.list + (size_t)n * B.cap, inside, r_lo - less, r_hi - less, hist, sc, v_lo, v_hi);
+    if (threadIdx.x == 0) {
+      const double med = 0.5 * (double)__uint_as_float(v_lo) + 0.5 * (double)__uint_as_float(v_hi);
+      rconst[n] = med > min_var ? med : min_var;
+    }
+    return;
+  }
+  for (int i = threadIdx.x; i < (int)inside; i += 256) vals[i] = B.list[(size_t)n * B.cap + i];
   __syncthreads();
   const uint32_t blo = B.lo[n], bhi = B.hi[n];          // every listed key lies in [blo, bhi]
   const int lsh = bhi > blo ? __clz((int)(bhi - blo)) : 0;
@@ -685,13 +771,39 @@ __global__ __launch_bounds__(256) void bracket_finish_kernel(int T, int N, const
 
 static inline size_t arr_bytes(size_t n) { return align_up(n * 4, 256); }
 
-size_t const_r_workspace_bytes(int N) {
-  return 8 * arr_bytes(N) + arr_bytes((size_t)N * kMedSamples) + arr_bytes((size_t)N * kMedList) + 256;
+// Rows per wave of the full pass (a multiple of kColFlight).  Measured on MI355X, whole eks_const_r call
+// (tools/med_rows_sweep.py; 16 / 32 / 48 / 64 rows): 100 000 x 256 keypoints 81.7 / 71.6 / 70.6 / 80.2 us (the
+// pass itself 42.9 us at 32 rows against 51.5 at the 64 of rounds 2-3, and 58 / 66 at 80 / 96: a block holds its
+// LDS and wave slots until its slowest wave has finished, and long waves leave a long, thin tail), 50 000 x 4 096:
+// 675 / 642 / 646 / 648, 10 000 x 64: 29.4 / 29.5 / 30.0 / 30.8, 3 000 x 30: 24.5 / 25.2 / 26.3 / 36.4.
+// Hence 32 rows, or 16 while that leaves CUs without a block.  EKS_MED_ROWS overrides (A/B runs).
+static int collect_rows_per_wave(int T, int ntile) {
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n;
+  }();
+  const int forced = knob_int(KNOB_MED_ROWS, 0);
+  if (forced >= kColFlight && forced <= 128) return forced / kColFlight * kColFlight;
+  const long blocks32 = (long)((T + 32 * kColWaves - 1) / (32 * kColWaves)) * ntile;
+  return blocks32 >= cus ? 32 : 16;
+}
+
+// capacity of a chain's in-bracket list: the LDS list of the finish kernel, or - for sequences whose bracket
+// (4.5 sigma of the 4096-row sample's median rank either side: ~7.1 % of the frames) outgrows it - 9 % of T
+static inline uint32_t list_capacity(int T) {
+  const size_t want = (size_t)T * 9 / 100 + 1024;
+  return want <= (size_t)kMedList ? (uint32_t)kMedList : (uint32_t)align_up(want, 64);
+}
+
+size_t const_r_workspace_bytes(int T, int N) {
+  return 8 * arr_bytes(N) + arr_bytes((size_t)N * kMedSamples) + arr_bytes((size_t)N * list_capacity(T)) + 256;
 }
 
 int const_r(int T, int N, const float* var, double min_var, double* rconst, void* ws,
             size_t ws_bytes, hipStream_t st) {
-  if (ws_bytes < const_r_workspace_bytes(N)) return EKS_ERR_WORKSPACE;
+  if (ws_bytes < const_r_workspace_bytes(T, N)) return EKS_ERR_WORKSPACE;
   ProfScope ps("const_r_select", st);
   if (T <= kMedSmall) {
     hipLaunchKernelGGL(median_small_kernel, dim3(N), dim3(256), 0, st, T, N, var, min_var, rconst);
@@ -707,15 +819,17 @@ int const_r(int T, int N, const float* var, double min_var, double* rconst, void
   B.smp = reinterpret_cast<uint32_t*>(p);
   p += arr_bytes((size_t)N * kMedSamples);
   B.list = reinterpret_cast<uint32_t*>(p);
+  B.cap = list_capacity(T);
 
   const int S = sample_count(T);
   const int ntile = (N + 63) / 64;
   hipLaunchKernelGGL(sample_transpose_kernel, dim3(ntile, (S + 63) / 64), dim3(256), 0, st, T, N, S,
                      var, B);
   hipLaunchKernelGGL(sample_bracket_kernel, dim3(N), dim3(256), 0, st, N, S, B);
-  const int nslab = (T + kColRows * kColWaves - 1) / (kColRows * kColWaves);
+  const int R = collect_rows_per_wave(T, ntile);
+  const int nslab = (T + R * kColWaves - 1) / (R * kColWaves);
   hipLaunchKernelGGL(bracket_collect_kernel, dim3((unsigned)(ntile * nslab)), dim3(64 * kColWaves), 0, st,
-                     T, N, var, B);
+                     T, N, R, var, B);
   hipLaunchKernelGGL(bracket_finish_kernel, dim3(N), dim3(256), 0, st, T, N, var, min_var, B, rconst);
   return hip_status(hipGetLastError());
 }

@@ -364,6 +364,26 @@ def test_const_r_is_exact_median(T, N):
     np.testing.assert_allclose(got[:, 0], ref, rtol=1e-15, atol=0)
 
 
+@pytest.mark.parametrize('T', [400_000, 1_000_003])
+def test_const_r_long_sequences_select_from_the_list_in_global_memory(T):
+    """Sequences whose bracket (~7 % of the frames) outgrows the finish kernel's LDS list (T > ~230 000): the exact
+    median comes from a radix select over the chain's list in global memory (round 4; before, from five strided
+    sweeps of the whole column).  Bit-exact against numpy on continuous, NaN-carrying, quantised (the list overflows
+    its capacity too: whole-column fallback) and constant columns."""
+    from eks_amd import hip_ops
+    rng = np.random.default_rng(T)
+    N = 6
+    var = rng.gamma(2.0, 0.3, (T, N, 1)).astype(np.float32)
+    var[rng.random(T) < 0.2, 1, 0] = np.nan
+    var[:, 2, 0] = np.round(var[:, 2, 0], 1)                   # ~13 % of the frames share the median's value
+    var[:, 3, 0] = 0.5
+    var[: T // 2, 4, 0] *= 1e-3                                # bimodal: the median sits in a gap
+    var[rng.random(T) < 0.05, 5, 0] = 0.0                      # below the 1e-12 clip
+    got = hip_ops.const_r(_dev(var), 1e-4).cpu().numpy()[:, 0]
+    ref = np.maximum(np.nanmedian(np.clip(var[:, :, 0].astype(np.float64), 1e-12, None), axis=0), 1e-4)
+    np.testing.assert_array_equal(got, ref)
+
+
 def test_const_r_all_nan_column():
     from eks_amd import hip_ops
     var = np.full((50, 2, 1), np.nan, np.float32)
