@@ -1,9 +1,10 @@
-O=${1:-gpurun_out/r04_fuzz.txt}; : > $O
-echo "## fuzz_parity 120 cases seed 411" >> $O; python tools/fuzz_parity.py 120 411 2>&1 | tail -2 >> $O
-echo "## fuzz_parity2 40 cases seed 402" >> $O; python tools/fuzz_parity2.py 40 402 2>&1 | tail -2 >> $O
-echo "## fuzz_drivers 30 cases seed 403" >> $O; python tools/fuzz_drivers.py 30 403 2>&1 | tail -2 >> $O
-echo "## fuzz_adam 20 cases seed 404" >> $O; python tools/fuzz_adam.py 20 404 2>&1 | tail -2 >> $O
-echo "## fuzz_pupil 12 cases seed 405" >> $O; python tools/fuzz_pupil.py 12 405 2>&1 | tail -2 >> $O
-echo "## fuzz_median seed 406, 120 cases" >> $O; python tools/fuzz_median.py 406 120 2>&1 | tail -1 >> $O
-echo "## fuzz_ekf 30 rigs seed 407" >> $O; python tools/fuzz_ekf.py 30 407 2>&1 | tail -2 >> $O
+# Runs ON THE GPU BOX: the seven parity fuzzers (oracles as the checker).  usage: tools/fuzz_all.sh [output file] [seed base]
+O=${1:-gpurun_out/r04_fuzz.txt}; B=${2:-400}; : > $O
+echo "## fuzz_parity 120 cases seed $((B+11))" >> $O; FUZZ_DETAIL=1 python tools/fuzz_parity.py 120 $((B+11)) 2>&1 | grep -E "detail|^worst" | cut -c1-420 >> $O
+echo "## fuzz_parity2 40 cases seed $((B+2))" >> $O; python tools/fuzz_parity2.py 40 $((B+2)) 2>&1 | tail -1 >> $O
+echo "## fuzz_drivers 30 cases seed $((B+3))" >> $O; python tools/fuzz_drivers.py 30 $((B+3)) 2>&1 | tail -1 >> $O
+echo "## fuzz_adam 20 cases seed $((B+4))" >> $O; python tools/fuzz_adam.py 20 $((B+4)) 2>&1 | tail -1 >> $O
+echo "## fuzz_pupil 12 cases seed $((B+5))" >> $O; python tools/fuzz_pupil.py 12 $((B+5)) 2>&1 | tail -1 >> $O
+echo "## fuzz_median seed $((B+6)), 200 cases" >> $O; python tools/fuzz_median.py $((B+6)) 200 2>&1 | tail -1 >> $O
+echo "## fuzz_ekf 30 rigs seed $((B+7))" >> $O; python tools/fuzz_ekf.py 30 $((B+7)) 2>&1 | tail -1 >> $O
 cat $O
