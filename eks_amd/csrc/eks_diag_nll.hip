@@ -794,6 +794,7 @@ __global__ __launch_bounds__(64 * kLeanWaves, 2) void diag_nll_grid_kernel(NllGe
 
 // assembly of the grid kernel's summaries: as diag_nll_assemble_par_kernel, reading the compact planes; a chain with
 // an exact-entry summary past chunk 0 (flagged) takes the sequential walk over a getter that knows both forms.
+template <int kAsmWaves, int kAsmPer>
 __global__ __launch_bounds__(64 * kAsmWaves) void diag_nll_assemble_lean_kernel(NllGeom G, LeanGeom LG, DiagModel M,
                                                                                NllWs W, double* __restrict__ nll) {
   extern __shared__ double dyn[];                  // b_next[ncn][64] | part[kAsmWaves][64]
@@ -1104,9 +1105,18 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
         hipLaunchKernelGGL(diag_nll_grid_kernel<false>, grid, block, 0, st, G, LG, M, W, y, rconst, s_cand);
     }
     ProfScope ps2("diag_nll_assemble", st);
-    const size_t shm = ((size_t)G.ncn + kAsmWaves) * 64 * sizeof(double);
-    hipLaunchKernelGGL(diag_nll_assemble_lean_kernel, dim3((unsigned)(G.ntile * n_cand)), dim3(64 * kAsmWaves), shm, st,
-                       G, LG, M, W, nll);
+    // waves per assembly block (measured on C3: 16 waves 13.9 us, 8: 11.9, 4: 15.8)
+    const int aw = knob_int(KNOB_NLL_ASM_WAVES, 8);
+#define EKS_ASM_LEAN(WV)                                                                                         \
+  hipLaunchKernelGGL((diag_nll_assemble_lean_kernel<WV, 128 / WV>), dim3((unsigned)(G.ntile * n_cand)), dim3(64 * WV), \
+                     ((size_t)G.ncn + WV) * 64 * sizeof(double), st, G, LG, M, W, nll)
+    if (aw == 4)
+      EKS_ASM_LEAN(4);
+    else if (aw == 8)
+      EKS_ASM_LEAN(8);
+    else
+      EKS_ASM_LEAN(16);
+#undef EKS_ASM_LEAN
     return hip_status(hipGetLastError());
   }
   // (the tree cannot take converged-entry summaries: they are only valid in sequential order)
