@@ -53,10 +53,29 @@
 
 namespace eks {
 
-#ifndef EKS_DW_B
-#define EKS_DW_B 8
-#endif
-constexpr int kDwB = EKS_DW_B;   // frames per lane (measured on configs[3]: 16 -> 94 us, 8 -> see DESIGN.md)
+// Frames per lane, a template parameter of the kernels chosen per problem by dw_chunk_frames (round 4): the DEPTH of
+// these launches is what a chunk costs (B element steps, B filter steps, B smoother steps) plus what its scan costs
+// (six shuffle levels per 64 chunks and a walk over the units' aggregates), so short sessions want short chunks and
+// long ones long chunks.  Measured (tools/pupil_time.py, the pupil optimiser on one chain; B = 2 / 4 / 8):
+// T = 2 000: 160 / 174 / 224 ms, T = 20 000: 217 / 216 / 250 ms, T = 200 000: - / 833 / 495 ms; configs[3]
+// (4 chains x 50 000 frames): - / 99.6 / 68.2 us per smooth (16 frames: 94 us, round 3).
+constexpr int kDwBMax = 8;
+// the smallest chunk whose (keypoint, 64-chunk) units still number at most kDwUnitsShort
+constexpr int kDwUnitsShort = 160;
+static inline long dw_units(int T, int K, int B) {
+  const long nc = ((long)T + B - 1) / B;
+  return (long)K * ((nc + 63) / 64);
+}
+// (O > 8 - five and six cameras - keeps 8 frames: only that form is instantiated for them.  EKS_DW_CHUNK = 2 / 4 / 8
+// forces a choice for A/B runs; O = 0 asks for the choice that needs the largest workspace.)
+static inline int dw_chunk_frames(int T, int K, int O) {
+  if (O > 8) return kDwBMax;
+  const int forced = knob_int(KNOB_DW_CHUNK, 0);
+  if (forced == 2 || forced == 4 || forced == 8) return forced;
+  if (dw_units(T, K, 2) <= kDwUnitsShort) return 2;
+  if (dw_units(T, K, 4) <= kDwUnitsShort) return 4;
+  return kDwBMax;
+}
 
 // Diagnostic build only (-DEKS_DW_STAMPS, tools/dw_stamps.py): wave 0's lane 0 of the first 64 blocks
 // stamps the 100 MHz real-time counter at the phase boundaries; nothing reads the stamps but the tool.
@@ -71,7 +90,7 @@ __device__ unsigned long long g_dw_stamps[2][64][16];
 #endif
 
 struct DwGeom {
-  int K, T, nc, nwb;         // keypoints, frames, chunks (ceil(T / kDwB)), blocks per keypoint (ceil(nc / 64))
+  int K, T, nc, nwb;         // keypoints, frames, chunks (ceil(T / B)), blocks per keypoint (ceil(nc / 64))
 };
 
 // observation rows of ONE keypoint (the block's keypoint is uniform: these live in scalar registers)
@@ -95,29 +114,29 @@ __device__ __forceinline__ ObsRows<D, O> load_obs_rows(const DenseModelPtrs& M, 
   return R;
 }
 
-// A lane's chunk: all kDwB rows (O floats of y, O of var each) are requested at once - one memory latency
+// A lane's chunk: all B rows (O floats of y, O of var each) are requested at once - one memory latency
 // per chunk - and parked in LDS as [frame][lane][O], so the frame loops below stay ROLLED: these kernels run
 // their code once per wave, and straight-line code for 16 frames x O observations (38 KB at O = 4) was
 // fetched cold from L2 at ~7 cycles per instruction (in-kernel stamps, profiles/r03_probes.txt).
-template <int O>
+template <int O, int B>
 struct DwRows {
   static constexpr int W = O % 4 == 0 ? 4 : 2;
   typedef float fw __attribute__((ext_vector_type(W)));
-  fw a[kDwB][O / W], b[kDwB][O / W];
+  fw a[B][O / W], b[B][O / W];
 };
 // request: all loads of the chunk in flight (nothing waits here - the caller issues its model loads next);
 // park: into LDS, [frame][lane][O]
-template <int O>
+template <int O, int B>
 __device__ __forceinline__ void dw_request_rows(const float* __restrict__ y, const float* __restrict__ var,
-                                                size_t row0, size_t row_stride, int nrows, DwRows<O>& R) {
+                                                size_t row0, size_t row_stride, int nrows, DwRows<O, B>& R) {
   // a keypoint's O values of one frame are contiguous: 8- / 16-byte pieces.  The pieces are naturally aligned
   // when y / var come from the allocator; the load type only promises 4 bytes (global loads may be misaligned),
   // so an oddly offset view of a larger array works too
-  constexpr int W = DwRows<O>::W;
-  typedef typename DwRows<O>::fw fw;
+  constexpr int W = DwRows<O, B>::W;
+  typedef typename DwRows<O, B>::fw fw;
   typedef float fwu __attribute__((ext_vector_type(W), aligned(4)));
 #pragma unroll
-  for (int i = 0; i < kDwB; ++i) {
+  for (int i = 0; i < B; ++i) {
     const size_t r = row0 + (size_t)i * row_stride;
 #pragma unroll
     for (int o = 0; o < O / W; ++o) {
@@ -131,13 +150,13 @@ __device__ __forceinline__ void dw_request_rows(const float* __restrict__ y, con
     }
   }
 }
-template <int O>
-__device__ __forceinline__ void dw_park_rows(const DwRows<O>& R, float* __restrict__ ly, float* __restrict__ lv,
+template <int O, int B>
+__device__ __forceinline__ void dw_park_rows(const DwRows<O, B>& R, float* __restrict__ ly, float* __restrict__ lv,
                                              int lane) {
-  constexpr int W = DwRows<O>::W;
-  typedef typename DwRows<O>::fw fw;
+  constexpr int W = DwRows<O, B>::W;
+  typedef typename DwRows<O, B>::fw fw;
 #pragma unroll
-  for (int i = 0; i < kDwB; ++i)
+  for (int i = 0; i < B; ++i)
 #pragma unroll
     for (int o = 0; o < O / W; ++o) {
       *reinterpret_cast<fw*>(ly + ((size_t)i * 64 + lane) * O + o * W) = R.a[i][o];
@@ -168,7 +187,7 @@ __device__ __forceinline__ void dw_load_dynamics(const DenseModelPtrs& M, const 
 // SUBS wave pairs per workgroup (each pair = one (keypoint, 64 chunks) unit): with more units than CUs, two
 // 2-wave workgroups on one CU could land on the same SIMDs and halve each other's float64 rate (measured:
 // 392 units of 2 waves 45 us, their own lifetime 28 us); a 4-wave workgroup spreads over the CU's four SIMDs.
-template <int D, int O, int SUBS, int MODE>
+template <int D, int O, int SUBS, int MODE, int B>
 __global__ __launch_bounds__(128 * SUBS) void dw_summarize_kernel(DwGeom G, DenseModelPtrs M,
                                                           const double* __restrict__ s,
                                                           const float* __restrict__ y,
@@ -183,7 +202,7 @@ __global__ __launch_bounds__(128 * SUBS) void dw_summarize_kernel(DwGeom G, Dens
   constexpr bool SCORE = MODE == 1;                   // constant R instead of rows of var
   constexpr int NV = delem_doubles<D>();
   // each wave parks its own copy of its rows (SCORE reads no variances: constant R)
-  __shared__ float ly[2 * SUBS][kDwB * 64 * O], lv[SCORE ? 1 : 2 * SUBS][SCORE ? 1 : kDwB * 64 * O];
+  __shared__ float ly[2 * SUBS][B * 64 * O], lv[SCORE ? 1 : 2 * SUBS][SCORE ? 1 : B * 64 * O];
   const int unit = blockIdx.x * SUBS + (threadIdx.x >> 7);
   if (unit >= G.K * G.nwb) return;                    // (no barrier in this kernel)
   const int k = unit % G.K, wb = unit / G.K;
@@ -192,11 +211,11 @@ __global__ __launch_bounds__(128 * SUBS) void dw_summarize_kernel(DwGeom G, Dens
   const int j = wb * 64 + lane;
   const bool live = j < G.nc;
   DW_STAMP(0, 0);
-  const int t0 = live ? j * kDwB : 0, len = live ? min(kDwB, G.T - t0) : 0;
+  const int t0 = live ? j * B : 0, len = live ? min(B, G.T - t0) : 0;
   float* my_y = ly[threadIdx.x >> 6];
   float* my_v = SCORE ? nullptr : lv[threadIdx.x >> 6];
-  DwRows<O> rows;
-  dw_request_rows<O>(y, var, ((size_t)t0 * G.K + k) * O, (size_t)G.K * O, len, rows);
+  DwRows<O, B> rows;
+  dw_request_rows<O, B>(y, var, ((size_t)t0 * G.K + k) * O, (size_t)G.K * O, len, rows);
   Mat<double, D> F, sQ;                               // (the model's loads go out behind the rows': one round trip)
   bool fid;
   dw_load_dynamics<D, MODE>(M, s, ar_a, ar_q, k, F, sQ, fid);
@@ -204,7 +223,7 @@ __global__ __launch_bounds__(128 * SUBS) void dw_summarize_kernel(DwGeom G, Dens
   double rk[O];                                       // SCORE: the keypoint's constant variances
 #pragma unroll
   for (int o = 0; o < O; ++o) rk[o] = SCORE ? rconst[(size_t)k * O + o] : 0.0;
-  dw_park_rows<O>(rows, my_y, my_v, lane);
+  dw_park_rows<O, B>(rows, my_y, my_v, lane);
   DElem<double, D> e = delem_identity<double, D>();
   DW_STAMP(0, 1);
 #pragma unroll 1
@@ -304,7 +323,7 @@ __device__ __forceinline__ DElem<double, D> dw_compose_range(const double* __res
   return x;
 }
 
-template <int D, int O, int SUBS, int MODE>
+template <int D, int O, int SUBS, int MODE, int B>
 __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseModelPtrs M,
                                                        const double* __restrict__ s,
                                                        const float* __restrict__ y,
@@ -324,9 +343,9 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
   constexpr int NV = delem_doubles<D>();
   constexpr int NF = D + D * (D + 1) / 2;             // filtered mean + upper triangle of the covariance
   constexpr int REC = D + D * D;
-  __shared__ double recs_all[SUBS][kDwB * NF * 64];   // [frame][field][lane]
+  __shared__ double recs_all[SUBS][B * NF * 64];   // [frame][field][lane]
   __shared__ double xch_all[SUBS][REC];
-  __shared__ float ly_all[SUBS][kDwB * 64 * O], lv_all[SCORE ? 1 : SUBS][SCORE ? 1 : kDwB * 64 * O];
+  __shared__ float ly_all[SUBS][B * 64 * O], lv_all[SCORE ? 1 : SUBS][SCORE ? 1 : B * 64 * O];
   const int sub = threadIdx.x >> 7;
   double* recs = recs_all[sub];
   double* xch = xch_all[sub];
@@ -363,17 +382,17 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
   }
   // ---- wave 0: everything this lane will need is requested before the reduction starts
   DW_STAMP(1, 0);
-  DwRows<O> rows;
+  DwRows<O, B> rows;
   {
     const int jj = wb * 64 + lane;
-    const int tt0 = jj < G.nc ? jj * kDwB : 0, ll = jj < G.nc ? min(kDwB, G.T - tt0) : 0;
-    dw_request_rows<O>(y, var, ((size_t)tt0 * G.K + k) * O, (size_t)G.K * O, ll, rows);
+    const int tt0 = jj < G.nc ? jj * B : 0, ll = jj < G.nc ? min(B, G.T - tt0) : 0;
+    dw_request_rows<O, B>(y, var, ((size_t)tt0 * G.K + k) * O, (size_t)G.K * O, ll, rows);
   }
   Mat<double, D> F, sQ;
   bool fid;
   dw_load_dynamics<D, MODE>(M, s, ar_a, ar_q, k, F, sQ, fid);
   const ObsRows<D, O> H = load_obs_rows<D, O>(M, k);
-  const int t0 = live ? j * kDwB : 0, len = live ? min(kDwB, G.T - t0) : 0;
+  const int t0 = live ? j * B : 0, len = live ? min(B, G.T - t0) : 0;
   DElem<double, D> pe = delem_identity<double, D>(), se = delem_identity<double, D>();
   if (live) {
     pe = load_delem<double, D>(pre_ex + ((size_t)j * G.K + k) * NV);
@@ -391,7 +410,7 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
       for (int b = 0; b < D; ++b) P.a[a][b] = f0[D + a * D + b];
     }
   }
-  dw_park_rows<O>(rows, ly, lv, lane);
+  dw_park_rows<O, B>(rows, ly, lv, lane);
   DW_STAMP(1, 1);
   if (wb > 0) {
     const DElem<double, D> tot = dw_compose_range<D>(agg, G.K, k, 0, wb, lane);
@@ -618,12 +637,12 @@ bool dense_wave_covers(int T, int K, int D, int O) {
   // calibration) for D = 3, one wave pair per workgroup (their rows take 2 x 24 KB of LDS per pair)
   if (!(((D == 2 || D == 3) && (O == 2 || O == 4 || O == 6 || O == 8)) || (D == 3 && (O == 10 || O == 12))))
     return false;
-  const long nc = ((long)T + kDwB - 1) / kDwB, nwb = (nc + 63) / 64;
-  return (long)K * nwb <= 1024;                       // depth-bound problems: every block resident at once
+  return dw_units(T, K, dw_chunk_frames(T, K, O)) <= 1024;                       // depth-bound problems: every block resident at once
 }
 
 size_t dense_wave_workspace_bytes(int T, int K, int D) {
-  const size_t nc = ((size_t)T + kDwB - 1) / kDwB, nwb = (nc + 63) / 64;
+  const size_t cb = (size_t)dw_chunk_frames(T, K, 0);   // (an upper bound for O > 8, which keeps 8 frames)
+  const size_t nc = ((size_t)T + cb - 1) / cb, nwb = (nc + 63) / 64;
   const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
   return 2 * align_up(nc * K * nv * 8, 256) + align_up(nwb * K * nv * 8, 256) + align_up((size_t)K * rec * 8, 256) +
          align_up(nwb * K * (1 + 2 * (size_t)D) * 8, 256);   // partial sums: up to 1 + 2 D planes (MODE 2)
@@ -714,7 +733,8 @@ static int dense_wave_run(const eks_dims_t& d, int mode, const float* y, const f
                           const DwAr1& ar, const DenseModel& Mm, float* ms, float* Vs, double* nll, double* dnll,
                           void* ws, size_t ws_bytes, hipStream_t st) {
   const int T = d.n_frames, K = d.n_keypoints, D = d.state_dim, O = d.obs_dim;
-  DwGeom G{K, T, (T + kDwB - 1) / kDwB, 0};
+  const int cb = dw_chunk_frames(T, K, O);            // frames per lane: 2 / 4 for short sessions, else 8
+  DwGeom G{K, T, (T + cb - 1) / cb, 0};
   G.nwb = (G.nc + 63) / 64;
   const size_t nv = 3 * D * D + 2 * D + 1, rec = D + D * D;
   const size_t need = dense_wave_workspace_bytes(T, K, D);
@@ -734,16 +754,27 @@ static int dense_wave_run(const eks_dims_t& d, int mode, const float* y, const f
   const int units = K * G.nwb;
   const bool two = units > 256 && O <= 8;             // more (keypoint, 64-chunk) units than CUs: 4-wave workgroups
   const dim3 grid((unsigned)(two ? (units + 1) / 2 : units)), block(two ? 256 : 128);
-#define EKS_DW_S(DD, OO, SS, MD)                                                                         \
+#define EKS_DW_SB(DD, OO, SS, MD, BB)                                                                    \
   {                                                                                                      \
     {                                                                                                    \
       ProfScope ps(MD ? "dense_score_summarize" : "dense_summarize", st);                                \
-      hipLaunchKernelGGL((dw_summarize_kernel<DD, OO, SS, MD>), grid, block, 0, st, G, M, Mm.s, y, var,   \
-                         rconst, ar.a, ar.q, pre_ex, suf_ex, agg, first);                                \
+      hipLaunchKernelGGL((dw_summarize_kernel<DD, OO, SS, MD, BB>), grid, block, 0, st, G, M, Mm.s, y,    \
+                         var, rconst, ar.a, ar.q, pre_ex, suf_ex, agg, first);                           \
     }                                                                                                    \
     ProfScope ps(MD ? "dense_score_replay" : "dense_replay", st);                                        \
-    hipLaunchKernelGGL((dw_replay_kernel<DD, OO, SS, MD>), grid, block, 0, st, G, M, Mm.s, y, var,        \
+    hipLaunchKernelGGL((dw_replay_kernel<DD, OO, SS, MD, BB>), grid, block, 0, st, G, M, Mm.s, y, var,    \
                        rconst, ar.a, ar.q, part, pre_ex, suf_ex, agg, first, ms, Vs, vs_diag);           \
+  }
+  // short chunks exist for one wave pair per workgroup only (they are chosen while the units are few) and up to
+  // four cameras
+#define EKS_DW_S(DD, OO, SS, MD)                     \
+  {                                                  \
+    if (SS == 1 && OO <= 8 && cb == 2)               \
+      EKS_DW_SB(DD, (OO <= 8 ? OO : 8), 1, MD, 2)    \
+    else if (SS == 1 && OO <= 8 && cb == 4)          \
+      EKS_DW_SB(DD, (OO <= 8 ? OO : 8), 1, MD, 4)    \
+    else                                             \
+      EKS_DW_SB(DD, OO, SS, MD, kDwBMax)             \
   }
 #define EKS_DW(DD, OO)            \
   if (two && mode == 1)           \
@@ -795,6 +826,7 @@ static int dense_wave_run(const eks_dims_t& d, int mode, const float* y, const f
 #undef EKS_DW_O
 #undef EKS_DW
 #undef EKS_DW_S
+#undef EKS_DW_SB
   if (mode == 1) return dense_score_finish(K, G.nwb, part, part + (size_t)K * G.nwb, nll, dnll, st);
   return hip_status(hipGetLastError());
 }

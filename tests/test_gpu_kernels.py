@@ -262,6 +262,37 @@ def test_smooth_dense_matches_oracle(T, K, D, O, general_A):
             ref = Vs_o
         assert _rel(Vk, ref, axis_scale=tuple(range(1, ref.ndim))) < 1e-5
 
+@pytest.mark.parametrize('chunk', ['2', '4', '8'])
+@pytest.mark.parametrize('T,K,D,O,general_A', [(1201, 4, 3, 4, False), (515, 2, 2, 6, True), (131, 3, 3, 8, False),
+                                               (3, 2, 3, 4, False)])
+def test_dense_wave_kernels_at_every_chunk_length_match_oracle(T, K, D, O, general_A, chunk, set_knob):
+    """The narrow-session kernels choose 2, 4 or 8 frames per lane from the problem's size (round 4: short sessions
+    are depth-bound and want short chunks); here every choice is forced (EKS_DW_CHUNK) on ragged shapes: the
+    smoother against the oracle at 1e-5, the loss and its smoothing-distribution gradient at the float64 bars."""
+    from eks_amd import _lib, hip_ops
+    set_knob('EKS_DW_CHUNK', chunk)
+    arrs, y, var = _dense_problem(T, K, D, O, seed=31 + T)
+    if general_A:
+        arrs['As'] = arrs['As'] * 0.97 + 0.02 * np.random.default_rng(9).standard_normal((K, D, D))
+    s = np.exp(np.random.default_rng(3).uniform(-3, 4, K))
+    ms, Vs = hip_ops.smooth(_dev(y), _dev(var), *_params_dev(arrs), _dev(s), flags=0)
+    ms = np.transpose(ms.cpu().numpy().astype(np.float64), (1, 0, 2))
+    Vs = np.transpose(Vs.cpu().numpy().astype(np.float64), (1, 0, 2, 3))
+    Rd = orc.build_R_from_vars(np.swapaxes(arrs['ensemble_vars'], 0, 1))
+    ms_o, Vs_o, _ = orc.kalman_smoother(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], s, Rd)
+    assert _rel(ms, ms_o, axis_scale=(1, 2)) < 1e-5
+    assert _rel(Vs, Vs_o, axis_scale=(1, 2, 3)) < 1e-5
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    assert flags == _lib.FLAG_Q_PD
+    rconst = hip_ops.const_r(_dev(var), 1e-4)
+    nll1, g1 = [a.cpu().numpy()[:, 0] for a in hip_ops.nll(_dev(y), rconst, *_params_dev(arrs), _dev(s[:, None]),
+                                                           per_keypoint=True, want_grad=True, flags=flags)]
+    ref, gref = orc.filter_nll(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], s,
+                               rconst.cpu().numpy(), want_grad=True)
+    assert (np.abs(nll1 - ref) / np.abs(ref)).max() < 1e-8
+    assert (np.abs(g1 - gref) / np.abs(gref).max()).max() < 1e-7
+
+
 @pytest.mark.parametrize('T,K,D,O,general_A', [
     (100, 1200, 3, 4, False),   # 1 200 (keypoint, 64-chunk) units > 1 024: keypoint-major kernels, 16-frame chunks
     (8000, 600, 3, 4, False),   # K T / 16 > 2^18: 32-frame chunks, eight checkpoints per lane, scan over 250 chunks
