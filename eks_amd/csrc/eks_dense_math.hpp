@@ -268,6 +268,127 @@ EKS_HD Mat<S, D> chol_solve_mat(const CholF<S, D>& F, const Mat<S, D>& Z) {
   return X;
 }
 
+// ---- triangular and symmetric forms (round 4).  A composition of two scan elements is ~650 dependent-ish float64
+// instructions in the general forms above, and the narrow-session kernels run ONE wave per SIMD through ten of them
+// per launch: their time IS this instruction count (in-kernel stamps: ~2 us per composition).  With C = L L^T,
+// G = I + L^T J L = Lg Lg^T and the two D x D matrices
+//     W = L Lg^-T,   Z = (J L) Lg^-T          (rows solved against the lower factor: right_solve_lt)
+// every term of the composition is a product with W or Z:
+//     M = (I + C J)^-1 = I - W Z^T,   M C = W W^T,   M^T J = J - Z Z^T
+// - no D x D solve against G at all, symmetric results by construction (computed once per pair), and products with
+// L skip its zeros.  ~370 instructions for D = 3.
+// X L for lower-triangular L (entries above the diagonal are not read)
+template <typename S, int D>
+EKS_HD Mat<S, D> mat_mul_lower(const Mat<S, D>& x, const Mat<S, D>& L) {
+  Mat<S, D> o;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      S acc = x.a[i][j] * L.a[j][j];
+#pragma unroll
+      for (int k = 0; k < D; ++k)
+        if (k > j) acc = acc + x.a[i][k] * L.a[k][j];
+      o.a[i][j] = acc;
+    }
+  return o;
+}
+// lower triangle of I + L^T Y (the rest is zero: what chol_factor reads)
+template <typename S, int D>
+EKS_HD Mat<S, D> eye_plus_lt_y_lower(const Mat<S, D>& L, const Mat<S, D>& y) {
+  Mat<S, D> o = mat_zero<S, D>();
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+      if (j <= i) {
+        S acc = L.a[i][i] * y.a[i][j];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+          if (k > i) acc = acc + L.a[k][i] * y.a[k][j];
+        o.a[i][j] = i == j ? acc + S(1.0) : acc;
+      }
+  return o;
+}
+// X = B Lg^-T: row r of X solves Lg x = (row r of B)^T by forward substitution.  lower: B is lower-triangular.
+template <typename S, int D, bool LOWER = false>
+EKS_HD Mat<S, D> right_solve_lt(const CholF<S, D>& F, const Mat<S, D>& B) {
+  Mat<S, D> X;
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      S t = (LOWER && i > r) ? S(0.0) : B.a[r][i];
+#pragma unroll
+      for (int k = 0; k < D; ++k)
+        if (k < i) t = t - F.L.a[i][k] * X.a[r][k];
+      X.a[r][i] = t * F.invd.a[i];
+    }
+  return X;
+}
+// W W^T: every pair computed once, exactly symmetric
+template <typename S, int D>
+EKS_HD Mat<S, D> mat_aat(const Mat<S, D>& w) {
+  Mat<S, D> o;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+      if (j >= i) {
+        S acc = w.a[i][0] * w.a[j][0];
+#pragma unroll
+        for (int k = 1; k < D; ++k) acc = acc + w.a[i][k] * w.a[j][k];
+        o.a[i][j] = acc;
+        o.a[j][i] = acc;
+      }
+  return o;
+}
+// A^T X A + Y for symmetric X, Y (every pair computed once)
+template <typename S, int D>
+EKS_HD Mat<S, D> mat_sandwich_tn_plus(const Mat<S, D>& a, const Mat<S, D>& x, const Mat<S, D>& y) {
+  const Mat<S, D> xa = mat_mul(x, a);
+  Mat<S, D> o;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+      if (j >= i) {
+        S acc = S(0.5) * (y.a[i][j] + y.a[j][i]);
+#pragma unroll
+        for (int k = 0; k < D; ++k) acc = acc + a.a[k][i] * xa.a[k][j];
+        o.a[i][j] = acc;
+        o.a[j][i] = acc;
+      }
+  return o;
+}
+// Lg^-1 (L^T x): L lower (zeros skipped), then forward substitution against the factor
+template <typename S, int D>
+EKS_HD Vec<S, D> lg_inv_lt_vec(const CholF<S, D>& F, const Mat<S, D>& L, const Vec<S, D>& x) {
+  Vec<S, D> u;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    S t = L.a[i][i] * x.a[i];
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+      if (k > i) t = t + L.a[k][i] * x.a[k];
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+      if (k < i) t = t - F.L.a[i][k] * u.a[k];
+    u.a[i] = t * F.invd.a[i];
+  }
+  return u;
+}
+// x - W (Z^T x)
+template <typename S, int D>
+EKS_HD Vec<S, D> vec_minus_w_zt(const Vec<S, D>& x, const Mat<S, D>& w, const Mat<S, D>& z) {
+  const Vec<S, D> t = mat_t_vec(z, x);
+  const Vec<S, D> wt = mat_vec(w, t);
+  Vec<S, D> o;
+#pragma unroll
+  for (int i = 0; i < D; ++i) o.a[i] = x.a[i] - wt.a[i];
+  return o;
+}
+
 template <typename S, int D>
 struct DElem {
   Mat<S, D> A, C, J;
@@ -378,27 +499,19 @@ template <typename S, int D>
 EKS_HD void condition_on_info(const Vec<S, D>& m, const Mat<S, D>& P, const Vec<S, D>& eta,
                               const Mat<S, D>& J, Vec<S, D>& m_in, Mat<S, D>& P_in, S& logdet) {
   const Mat<S, D> L = chol_psd(P);
-  Mat<S, D> G = mat_mul_tn(L, mat_mul(J, L));
-#pragma unroll
-  for (int i = 0; i < D; ++i) G.a[i][i] = G.a[i][i] + S(1.0);
-  const CholF<S, D> Lg = chol_factor(mat_symmetrize(G));
+  const CholF<S, D> Lg = chol_factor(eye_plus_lt_y_lower(L, mat_mul_lower(J, L)));
   logdet = S(0.0);
 #pragma unroll
   for (int i = 0; i < D; ++i) logdet = logdet + S(2.0) * log_s(Lg.L.a[i][i]);
   Vec<S, D> w = mat_vec(P, eta);
 #pragma unroll
   for (int i = 0; i < D; ++i) w.a[i] = w.a[i] + m.a[i];
-  const Vec<S, D> x = chol_solve(Lg, mat_t_vec(L, mat_vec(J, w)));
-  const Vec<S, D> Lx = mat_vec(L, x);
+  // W = L Lg^-T:  P_in = W W^T,  m_in = w - W Lg^-1 L^T J w
+  const Mat<S, D> W = right_solve_lt<S, D, true>(Lg, L);
+  const Vec<S, D> Wu = mat_vec(W, lg_inv_lt_vec(Lg, L, mat_vec(J, w)));
 #pragma unroll
-  for (int i = 0; i < D; ++i) m_in.a[i] = w.a[i] - Lx.a[i];
-  // X = G^-1 L^T  ->  P_in = L X
-  Mat<S, D> Lt;
-#pragma unroll
-  for (int i = 0; i < D; ++i)
-#pragma unroll
-    for (int j = 0; j < D; ++j) Lt.a[i][j] = L.a[j][i];
-  P_in = mat_symmetrize(mat_mul(L, chol_solve_mat(Lg, Lt)));
+  for (int i = 0; i < D; ++i) m_in.a[i] = w.a[i] - Wu.a[i];
+  P_in = mat_aat(W);
 }
 
 // Push N(m, P) through an element; returns the element's log marginal likelihood under it.
@@ -426,30 +539,22 @@ EKS_HD S delem_apply(const DElem<S, D>& e, Vec<S, D>& m, Mat<S, D>& P) {
 template <typename S, int D>
 EKS_HD void delem_back(const DElem<S, D>& e, Vec<S, D>& eta, Mat<S, D>& J) {
   const Mat<S, D> L = chol_psd(e.C);
-  const Mat<S, D> JL = mat_mul(J, L);
-  Mat<S, D> G = mat_mul_tn(L, JL);
-#pragma unroll
-  for (int i = 0; i < D; ++i) G.a[i][i] = G.a[i][i] + S(1.0);
-  const CholF<S, D> Lg = chol_factor(mat_symmetrize(G));
+  const Mat<S, D> JL = mat_mul_lower(J, L);
+  const CholF<S, D> Lg = chol_factor(eye_plus_lt_y_lower(L, JL));
+  const Mat<S, D> Z = right_solve_lt<S, D>(Lg, JL);           // J L Lg^-T
   const Vec<S, D> Jb = mat_vec(J, e.b);
   Vec<S, D> v;
 #pragma unroll
   for (int i = 0; i < D; ++i) v.a[i] = eta.a[i] - Jb.a[i];
-  const Vec<S, D> x = chol_solve(Lg, mat_t_vec(L, v));
-  const Vec<S, D> JLx = mat_vec(JL, x);
+  // M^T v = v - Z Lg^-1 L^T v
+  const Vec<S, D> Zu = mat_vec(Z, lg_inv_lt_vec(Lg, L, v));
 #pragma unroll
-  for (int i = 0; i < D; ++i) v.a[i] = v.a[i] - JLx.a[i];
+  for (int i = 0; i < D; ++i) v.a[i] = v.a[i] - Zu.a[i];
   const Vec<S, D> Atv = mat_t_vec(e.A, v);
 #pragma unroll
   for (int i = 0; i < D; ++i) eta.a[i] = Atv.a[i] + e.eta.a[i];
-  // J' = J - J L G^-1 L^T J  (symmetric), then A^T J' A + J_e
-  Mat<S, D> JLt;
-#pragma unroll
-  for (int i = 0; i < D; ++i)
-#pragma unroll
-    for (int j = 0; j < D; ++j) JLt.a[i][j] = JL.a[j][i];
-  const Mat<S, D> Jp = mat_symmetrize(mat_sub(J, mat_mul(JL, chol_solve_mat(Lg, JLt))));
-  J = mat_symmetrize(mat_add(mat_mul_tn(e.A, mat_mul(Jp, e.A)), e.J));
+  // J' = J - Z Z^T, then A^T J' A + J_e
+  J = mat_sandwich_tn_plus(e.A, mat_sub(mat_symmetrize(J), mat_aat(Z)), e.J);
 }
 
 // Compose two elements, `i` (earlier frames) then `j` (later frames):
@@ -462,52 +567,54 @@ EKS_HD void delem_back(const DElem<S, D>& e, Vec<S, D>& eta, Mat<S, D>& J) {
 template <typename S, int D, bool ELL = true>
 EKS_HD DElem<S, D> delem_combine(const DElem<S, D>& ei, const DElem<S, D>& ej) {
   const Mat<S, D> L = chol_psd(ei.C);
-  const Mat<S, D> JL = mat_mul(ej.J, L);
-  Mat<S, D> G = mat_mul_tn(L, JL);
-#pragma unroll
-  for (int i = 0; i < D; ++i) G.a[i][i] = G.a[i][i] + S(1.0);
-  const CholF<S, D> Lg = chol_factor(mat_symmetrize(G));
-  Mat<S, D> JLt;
-#pragma unroll
-  for (int i = 0; i < D; ++i)
-#pragma unroll
-    for (int j = 0; j < D; ++j) JLt.a[i][j] = JL.a[j][i];
-  // M X = X - L G^-1 (JL)^T X
-  const Mat<S, D> MA = mat_sub(ei.A, mat_mul(L, chol_solve_mat(Lg, mat_mul(JLt, ei.A))));
-  const Mat<S, D> MC = mat_symmetrize(mat_sub(ei.C, mat_mul(L, chol_solve_mat(Lg, mat_mul(JLt, ei.C)))));
+  const Mat<S, D> JL = mat_mul_lower(ej.J, L);
+  const CholF<S, D> Lg = chol_factor(eye_plus_lt_y_lower(L, JL));
+  const Mat<S, D> W = right_solve_lt<S, D, true>(Lg, L);      // L Lg^-T
+  const Mat<S, D> Z = right_solve_lt<S, D>(Lg, JL);           // J L Lg^-T
+  DElem<S, D> o;
+  // A = A_j (A_i - W Z^T A_i)
+  o.A = mat_mul(ej.A, mat_sub(ei.A, mat_mul(W, mat_mul_tn(Z, ei.A))));
+  // b = A_j M (b_i + C_i eta_j) + b_j
   Vec<S, D> w = mat_vec(ei.C, ej.eta);
 #pragma unroll
   for (int i = 0; i < D; ++i) w.a[i] = w.a[i] + ei.b.a[i];
-  const Vec<S, D> Lx = mat_vec(L, chol_solve(Lg, mat_vec(JLt, w)));
-  Vec<S, D> Mw;
-#pragma unroll
-  for (int i = 0; i < D; ++i) Mw.a[i] = w.a[i] - Lx.a[i];
-  DElem<S, D> o;
-  o.A = mat_mul(ej.A, MA);
-  const Vec<S, D> AMw = mat_vec(ej.A, Mw);
+  const Vec<S, D> AMw = mat_vec(ej.A, vec_minus_w_zt(w, W, Z));
 #pragma unroll
   for (int i = 0; i < D; ++i) o.b.a[i] = AMw.a[i] + ej.b.a[i];
-  o.C = mat_symmetrize(mat_add(mat_mul_nt(mat_mul(ej.A, MC), ej.A), ej.C));
-  // M^T x = x - JL G^-1 L^T x
+  // C = A_j (W W^T) A_j^T + C_j = (A_j W)(A_j W)^T + C_j
+  {
+    const Mat<S, D> AW = mat_aat(mat_mul(ej.A, W));
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int k = 0; k < D; ++k)
+        if (k >= i) {
+          const S c = AW.a[i][k] + S(0.5) * (ej.C.a[i][k] + ej.C.a[k][i]);
+          o.C.a[i][k] = c;
+          o.C.a[k][i] = c;
+        }
+  }
+  // eta = A_i^T M^T (eta_j - J_j b_i) + eta_i,   M^T = I - Z W^T
   const Vec<S, D> Jb = mat_vec(ej.J, ei.b);
   Vec<S, D> v;
 #pragma unroll
   for (int i = 0; i < D; ++i) v.a[i] = ej.eta.a[i] - Jb.a[i];
-  const Vec<S, D> JLx = mat_vec(JL, chol_solve(Lg, mat_t_vec(L, v)));
+  const Vec<S, D> Wtv = mat_t_vec(W, v);
+  const Vec<S, D> ZWtv = mat_vec(Z, Wtv);
   Vec<S, D> Mtv;
 #pragma unroll
-  for (int i = 0; i < D; ++i) Mtv.a[i] = v.a[i] - JLx.a[i];
+  for (int i = 0; i < D; ++i) Mtv.a[i] = v.a[i] - ZWtv.a[i];
   const Vec<S, D> AtMtv = mat_t_vec(ei.A, Mtv);
 #pragma unroll
   for (int i = 0; i < D; ++i) o.eta.a[i] = AtMtv.a[i] + ei.eta.a[i];
-  const Mat<S, D> MtJ = mat_symmetrize(mat_sub(ej.J, mat_mul(JL, chol_solve_mat(Lg, JLt))));
-  o.J = mat_symmetrize(mat_add(mat_mul_tn(ei.A, mat_mul(MtJ, ei.A)), ei.J));
+  // J = A_i^T (J_j - Z Z^T) A_i + J_i
+  o.J = mat_sandwich_tn_plus(ei.A, mat_sub(mat_symmetrize(ej.J), mat_aat(Z)), ei.J);
   if constexpr (ELL) {
     S logdet = S(0.0);
 #pragma unroll
     for (int i = 0; i < D; ++i) logdet = logdet + S(2.0) * log_s(Lg.L.a[i][i]);
-    o.ell = ei.ell + ej.ell - S(0.5) * logdet + dot(ei.b, ej.eta) - S(0.5) * dot(ei.b, Jb) +
-            S(0.5) * dot(v, mat_vec(MC, v));
+    // v^T (M C_i) v = |W^T v|^2
+    o.ell = ei.ell + ej.ell - S(0.5) * logdet + dot(ei.b, ej.eta) - S(0.5) * dot(ei.b, Jb) + S(0.5) * dot(Wtv, Wtv);
   } else {
     o.ell = S(0.0);
   }
