@@ -473,11 +473,17 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
       const double dv = (double)py[o] - dot(h, m);
       const double gd = g * dv;
       if constexpr (SUMS) ll -= 0.5 * (kLog2Pi + log(sigma) + dv * gd);    // log N(y_o; h.m, sigma)
+      // (the gain folded into one factor, the symmetric pairs of P computed once: P stays exactly symmetric)
 #pragma unroll
       for (int a = 0; a < D; ++a) {
         m.a[a] += u.a[a] * gd;
+        const double ug = u.a[a] * g;
 #pragma unroll
-        for (int b = 0; b < D; ++b) P.a[a][b] -= u.a[a] * u.a[b] * g;
+        for (int b = a; b < D; ++b) {
+          const double pv = P.a[a][b] - ug * u.a[b];
+          P.a[a][b] = pv;
+          P.a[b][a] = pv;
+        }
       }
     }
     double* rc = mine + (size_t)i * NF * 64;
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(128 * SUBS) void dw_replay_kernel(DwGeom G, DenseMo
     const Mat<double, D> P_next = P_s;
 #pragma unroll
     for (int a = 0; a < D; ++a) m_s.a[a] = mf.a[a] + Gdm.a[a];
-    P_s = mat_symmetrize(mat_add(Pf, mat_mul(mat_mul_tn(Z, mat_sub(P_s, Pp)), Z)));
+    P_s = mat_sandwich_tn_plus(Z, mat_sub(P_s, Pp), Pf);            // Pf + G (P_s - Pp) G^T, every pair once
     if constexpr (MODE == 2) {
       // per coordinate (F = diag a, Q = diag q): E[w^2] and E[w x_i] from the same smoothed moments
       const Mat<double, D> Cx = mat_mul_tn(Z, P_next);            // Cov(x_i, x_{i+1} | y)
