@@ -235,8 +235,13 @@ EKS_HD double belief_update_obs(const Obs& obs, int k, int t, const double* xl, 
 #pragma unroll
     for (int a = 0; a < D; ++a) {
       m.a[a] += u.a[a] * gd;
+      const double ug = u.a[a] * g;                  // (gain folded in; symmetric pairs once: P stays symmetric)
 #pragma unroll
-      for (int b = 0; b < D; ++b) P.a[a][b] -= u.a[a] * u.a[b] * g;
+      for (int b = a; b < D; ++b) {
+        const double pv = P.a[a][b] - ug * u.a[b];
+        P.a[a][b] = pv;
+        P.a[b][a] = pv;
+      }
     }
   });
   return ll;
@@ -410,7 +415,7 @@ EKS_HD void dense_replay_chunk_obs(const Obs& obs, int K, int k, int t0, int len
     for (int a = 0; a < D; ++a) m_s.a[a] = mf.a[a] + Gdm.a[a];
     // P_s = Pf + G (P_s - Pp) G^T,  G = Z^T
     const Mat<double, D> dP = mat_sub(P_s, Pp);
-    P_s = mat_symmetrize(mat_add(Pf, mat_mul(mat_mul_tn(Z, dP), Z)));
+    P_s = mat_sandwich_tn_plus(Z, dP, Pf);
     if constexpr (SCORE) {
       const Vec<double, D> Fm = f_identity ? m_s : mat_vec(F, m_s);
       Vec<double, D> dw;

@@ -121,8 +121,13 @@ __device__ __forceinline__ void wide_filter_frame(const WideRowsC<D, O>& H, cons
 #pragma unroll
     for (int a = 0; a < D; ++a) {
       m.a[a] += u.a[a] * gd;
+      const double ug = u.a[a] * g;                  // (gain folded in; symmetric pairs once: P stays symmetric)
 #pragma unroll
-      for (int b = 0; b < D; ++b) P.a[a][b] -= u.a[a] * u.a[b] * g;
+      for (int b = a; b < D; ++b) {
+        const double pv = P.a[a][b] - ug * u.a[b];
+        P.a[a][b] = pv;
+        P.a[b][a] = pv;
+      }
     }
   }
 }
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(64) void dwide_replay_kernel(WideGeom G, DenseModel
     const Mat<double, D> P_next = P_s;
 #pragma unroll
     for (int a = 0; a < D; ++a) m_s.a[a] = mf.a[a] + Gdm.a[a];
-    P_s = mat_symmetrize(mat_add(Pf, mat_mul(mat_mul_tn(Z, mat_sub(P_s, Pp)), Z)));
+    P_s = mat_sandwich_tn_plus(Z, mat_sub(P_s, Pp), Pf);            // Pf + G (P_s - Pp) G^T, every pair once
     if constexpr (SCORE) {
       const Vec<double, D> Fm = fid ? m_s : mat_vec(F, m_s);
       Vec<double, D> dw;
