@@ -39,6 +39,8 @@ SIGNATURES = {
                                                                     c_void_p]),
     'eks_argmin_s': (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p]),
+    'eks_np_nanstd_rows': (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p,
+                                          c_void_p]),
     'eks_order_stats': (ctypes.c_int, [c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                        c_void_p]),
     'eks_adam_step': (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_double,

@@ -127,21 +127,41 @@ def _guess_rows_from_device(ev_dev) -> np.ndarray:
     return d.reshape(d.shape[0], -1).cpu().numpy()
 
 
-def _initial_guesses_per_keypoint(ev_host: np.ndarray = None, rows: np.ndarray | None = None) -> np.ndarray:
+def _guess_std_on_device(ev_dev):
+    """numpy.nanstd of every keypoint's frame-to-frame differences, computed ON THE DEVICE with numpy's own summation
+    order (hip_ops.np_nanstd_rows: bit for bit) - K floats come back instead of the (K, (T' - 1) O) rows, and the
+    2 ms the host reduction cost at 256 keypoints are gone from in front of the optimiser's first launch.  None
+    when the rows are not float32 or too long for the kernel (the host reduces then)."""
+    torch = _torch()
+    ev = ev_dev[:2000]
+    if ev.shape[0] < 2:
+        raise ValueError('Not enough frames to compute temporal differences.')
+    if ev.dtype != torch.float32 or not ev.is_cuda:
+        return None
+    d = (ev[1:] - ev[:-1]).transpose(0, 1).contiguous()
+    sd = hip_ops.np_nanstd_rows(d.reshape(d.shape[0], -1))
+    return None if sd is None else sd.cpu().numpy()
+
+
+def _initial_guesses_per_keypoint(ev_host: np.ndarray = None, rows: np.ndarray | None = None,
+                                  sd: np.ndarray | None = None) -> np.ndarray:
     """compute_initial_guesses for every keypoint of a (T', K, O) array at once (missing or non-positive guesses
     become 2.0, as in run_kalman_smoother's loop).  Each keypoint's differences are laid out as one contiguous
     row in the order the 2-D call reduces them, so the values are the per-keypoint calls' bit for bit; a loop of K
     nanstd calls cost 13 ms at K = 256 - twice the optimisation it seeds."""
-    if rows is not None:
+    if sd is not None:
+        d = None                                                 # (reduced on the device: _guess_std_on_device)
+    elif rows is not None:
         d = rows                                                 # (prepared on the device: _guess_rows_from_device)
     else:
         ev = np.asarray(ev_host)[:2000]
         if ev.shape[0] < 2:
             raise ValueError('Not enough frames to compute temporal differences.')
         d = np.ascontiguousarray(np.swapaxes(ev[1:] - ev[:-1], 0, 1)).reshape(ev.shape[1], -1)    # (K, (T'-1) O)
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore', RuntimeWarning)          # all-NaN keypoints: nan -> 2.0 below
-        sd = np.nanstd(d, axis=1)
+    if sd is None:
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', RuntimeWarning)      # all-NaN keypoints: nan -> 2.0 below
+            sd = np.nanstd(d, axis=1)
     g = np.array([round(float(v), 5) for v in sd])               # Python's round on a Python float, as the scalar form
     g = np.where(g == 0.0, 2.0, g)                               # (`or 2.0` of the loop form)
     return np.where(np.isfinite(g) & (g > 0.0), g, 2.0)
@@ -661,7 +681,10 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
         guesses = np.full(K, 2.0)
         if s_mode == 'adam':            # the starting point of the optimiser (reference :233-236)
             if hasattr(ensemble_vars, 'detach') and ensemble_vars.is_cuda and ensemble_vars.dtype == torch.float32:
-                guesses = _initial_guesses_per_keypoint(rows=_guess_rows_from_device(ensemble_vars.detach()))
+                ev_d = ensemble_vars.detach()
+                sd = _guess_std_on_device(ev_d)
+                guesses = (_initial_guesses_per_keypoint(sd=sd) if sd is not None else
+                           _initial_guesses_per_keypoint(rows=_guess_rows_from_device(ev_d)))
             else:
                 ev_host = _to_numpy(ensemble_vars)[:2000] if not hasattr(ensemble_vars, 'detach') \
                     else ensemble_vars[:2000].detach().cpu().numpy()

@@ -7,6 +7,7 @@
 
 #include "eks_adam.hpp"
 #include "eks_internal.hpp"
+#include "eks_np_sum.hpp"
 
 namespace eks {
 
@@ -831,6 +832,73 @@ int const_r(int T, int N, const float* var, double min_var, double* rconst, void
   hipLaunchKernelGGL(bracket_collect_kernel, dim3((unsigned)(ntile * nslab)), dim3(64 * kColWaves), 0, st,
                      T, N, R, var, B);
   hipLaunchKernelGGL(bracket_finish_kernel, dim3(N), dim3(256), 0, st, T, N, var, min_var, B, rconst);
+  return hip_status(hipGetLastError());
+}
+
+// ==========================================================================================
+// numpy.nanstd of every row of a [K][n] float32 matrix, bit for bit (eks_np_sum.hpp).  Block = row: the row sits
+// in LDS, thread i sums leaf i of numpy's pairwise recursion, thread 0 walks the combine program - both tables are
+// a function of n alone and come from the caller (hip_ops.np_nanstd_rows builds them once per n).
+// ==========================================================================================
+__global__ __launch_bounds__(256) void np_nanstd_rows_kernel(int K, int n, const float* __restrict__ d,
+                                                            const int32_t* __restrict__ leaves, int n_leaves,
+                                                            const int32_t* __restrict__ ops, int n_ops,
+                                                            float* __restrict__ out) {
+  extern __shared__ float npl[];             // row[n] | slots[n_leaves + n_ops]
+  __shared__ int nan_count;
+  __shared__ float avg_sh;
+  float* row = npl;
+  float* slot = npl + n;
+  const int k = blockIdx.x;
+  if (threadIdx.x == 0) nan_count = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float v = d[(size_t)k * n + i];
+    row[i] = v;
+    mine += v != v;
+  }
+  if (mine) atomicAdd(&nan_count, mine);
+  __syncthreads();
+  const int cnt = n - nan_count;
+  if (cnt == 0) {                            // numpy: nan (and a RuntimeWarning)
+    if (threadIdx.x == 0) out[k] = __uint_as_float(0x7FC00000u);
+    return;
+  }
+  auto reduce = [&](auto&& value) -> float {  // the pairwise sum of value(0 .. n - 1); result valid in thread 0
+    for (int l = threadIdx.x; l < n_leaves; l += 256) {
+      const int s0 = leaves[2 * l], len = leaves[2 * l + 1];
+      slot[l] = np_leaf_sum(len, [&](int i) { return value(s0 + i); });
+    }
+    __syncthreads();
+    float res = 0.f;
+    if (threadIdx.x == 0) {
+      for (int q = 0; q < n_ops; ++q) slot[ops[3 * q]] = np_add(slot[ops[3 * q + 1]], slot[ops[3 * q + 2]]);
+      res = np_add(0.f, slot[n_leaves + n_ops - 1]);
+    }
+    __syncthreads();
+    return res;
+  };
+  const float s = reduce([&](int i) {
+    const float v = row[i];
+    return v != v ? 0.f : v;
+  });
+  if (threadIdx.x == 0) avg_sh = np_divide_by_count(s, cnt);
+  __syncthreads();
+  const float avg = avg_sh;
+  const float v2 = reduce([&](int i) {
+    const float v = row[i];
+    const float x = v != v ? 0.f : np_sub(v, avg);
+    return np_mul(x, x);
+  });
+  if (threadIdx.x == 0) out[k] = (float)sqrt((double)np_divide_by_count(v2, cnt));
+}
+
+int np_nanstd_rows(int K, int n, const float* d, const int32_t* leaves, int n_leaves, const int32_t* ops, int n_ops,
+                   float* out, hipStream_t st) {
+  const size_t shm = ((size_t)n + n_leaves + n_ops) * sizeof(float);
+  if (shm > 64 * 1024) return EKS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(np_nanstd_rows_kernel, dim3(K), dim3(256), shm, st, K, n, d, leaves, n_leaves, ops, n_ops, out);
   return hip_status(hipGetLastError());
 }
 

@@ -200,6 +200,60 @@ def const_r(var, min_var: float = 1e-4):
     return out
 
 
+_NP_SUM_PROGRAMS: dict = {}
+
+
+def np_sum_program(n: int):
+    """Leaves and combine order of numpy's pairwise float32 summation of n contiguous values
+    (numpy/_core/src/umath/loops_utils.h.src): leaves (L, 2) int32 = (start, length <= 128) left to right, ops
+    (L - 1, 3) int32 = (dst, a, b) in evaluation order over slots 0 .. L - 1 (leaf sums) and L .. (internal nodes);
+    the root is the last slot.  A function of n alone: cached."""
+    if n not in _NP_SUM_PROGRAMS:
+        leaves, ops = [], []
+
+        def node(start, m):
+            if m <= 128:
+                leaves.append((start, m))
+                return ('leaf', len(leaves) - 1)
+            h = m // 2
+            h -= h % 8
+            a, b = node(start, h), node(start + h, m - h)
+            ops.append([None, a, b])
+            return ('op', len(ops) - 1)
+
+        node(0, int(n))
+        L = len(leaves)
+        slot = lambda ref: ref[1] if ref[0] == 'leaf' else L + ref[1]
+        prog = np.array([[L + i, slot(a), slot(b)] for i, (_, a, b) in enumerate(ops)], dtype=np.int32).reshape(-1, 3)
+        _NP_SUM_PROGRAMS[n] = (np.array(leaves, dtype=np.int32), prog)
+    return _NP_SUM_PROGRAMS[n]
+
+
+_NP_SUM_DEVICE: dict = {}
+
+
+def np_nanstd_rows(x):
+    """eks_np_nanstd_rows: numpy.nanstd(x, axis=1) of a device float32 matrix (K, n), bit for bit, as a float32 device
+    tensor (K,); None when the row does not fit the kernel's LDS (the caller reduces on the host then)."""
+    lib = _lib.load()
+    x = _chk(x, torch.float32, 'x')
+    K, n = x.shape
+    leaves, ops = np_sum_program(n)
+    # (beyond 8 192 elements numpy reduces in buffered pieces of that size - another order; such rows, e.g. three
+    #  cameras' 6 x 1 999 differences, go to the host's own numpy)
+    if n > 8192 or (n + 2 * len(leaves)) * 4 > 64 * 1024:
+        return None
+    key = (n, x.device)
+    if key not in _NP_SUM_DEVICE:
+        _NP_SUM_DEVICE[key] = (torch.as_tensor(leaves, device=x.device), torch.as_tensor(ops, device=x.device))
+    lv, op = _NP_SUM_DEVICE[key]
+    out = torch.empty(K, dtype=torch.float32, device=x.device)
+    rc = lib.eks_np_nanstd_rows(K, n, _ptr(x), _ptr(lv), len(leaves), _ptr(op) if len(ops) else None, len(ops),
+                                _ptr(out), _stream())
+    _lib.check(rc, 'eks_np_nanstd_rows')
+    return out
+
+
 def order_stats(x, rank_lo: int, rank_hi: int):
     """eks_order_stats: x (T, N) float32 -> (vals (N, 2) float32 = the order statistics rank_lo and rank_hi of
     every column with NaNs sorted last, nan_count (N,) int32), device tensors."""

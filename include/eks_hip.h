@@ -99,6 +99,17 @@ int eks_nll(const eks_dims_t* dims, const float* y, const double* rconst, const 
 int eks_order_stats(int32_t n_rows, int32_t n_cols, const float* x, int32_t rank_lo, int32_t rank_hi,
                     float* out, int32_t* nan_count, eks_stream_t stream);
 
+/* ---- numpy.nanstd(x, axis=1) of a [n_rows][n_cols] float32 matrix, BIT FOR BIT: the optimiser's initial guess
+ * (reference eks/core.py:104-133, compute_initial_guesses: round(nanstd(differences of the ensemble variances), 5))
+ * seeds the Adam trajectory through a float32, so it has to be numpy's value, and numpy's value is a function of
+ * its summation order (pairwise, eks_amd/csrc/eks_np_sum.hpp).  leaves: n_leaves pairs (start, length <= 128) of
+ * that recursion's leaves left to right; ops: n_leaves - 1 triples (dst, a, b) in evaluation order over slots
+ * 0 .. n_leaves - 1 = leaf sums, n_leaves .. = internal nodes, the last one the root (both tables depend on n_cols
+ * only; eks_amd/hip_ops.py: np_sum_program builds them).  out[r] float32; a row without a finite value gives NaN.
+ * (n_cols + 2 n_leaves) * 4 bytes must fit 64 KB of LDS: EKS_ERR_UNSUPPORTED otherwise. ---------------------- */
+int eks_np_nanstd_rows(int32_t n_rows, int32_t n_cols, const float* x, const int32_t* leaves, int32_t n_leaves,
+                       const int32_t* ops, int32_t n_ops, float* out, eks_stream_t stream);
+
 /* ---- argmin over candidates + gather: s_out[k] = s_cand[argmin_c nll[k][c]] (first minimum,
  * like numpy.argmin).  idx_out (optional) receives the int32 indices. ---------------------- */
 int eks_argmin_s(int32_t n_keypoints, int32_t n_cand, const double* nll, const double* s_cand,

@@ -921,3 +921,42 @@ def test_prepared_smooth_is_the_same_call_and_follows_changed_contents():
     ref2 = hip_ops.smooth(y, var, *params, s.clone(), flags=flags)
     assert torch.equal(ms2, ref2[0]) and torch.equal(Vs2, ref2[1])
     assert not torch.equal(ms2, ms1)
+
+
+@pytest.mark.parametrize('K,n', [(5, 1), (3, 7), (4, 130), (256, 3998), (40, 7996), (2, 8192)])
+def test_np_nanstd_rows_is_numpys_value_bit_for_bit(K, n):
+    """eks_np_nanstd_rows against numpy.nanstd(x, axis=1) on float32 rows with NaNs, an all-NaN row, a constant row
+    and values over four decades: identical bits (the optimiser's initial guess is this number rounded to five
+    decimals and cast to float32, reference eks/core.py:104-133, :612-613)."""
+    import warnings
+    from eks_amd import hip_ops
+    rng = np.random.default_rng(K * 100003 + n)
+    x = (rng.standard_normal((K, n)) * np.exp(rng.uniform(-4, 5, (K, 1)))).astype(np.float32)
+    x[rng.random((K, n)) < 0.03] = np.nan
+    if K > 3:
+        x[1] = np.nan
+        x[2] = 0.75
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        ref = np.nanstd(x, axis=1)
+    got = hip_ops.np_nanstd_rows(_dev(x)).cpu().numpy()
+    assert got.dtype == np.float32 and np.array_equal(got, ref, equal_nan=True)
+
+
+def test_np_nanstd_rows_declines_rows_numpy_would_reduce_in_buffered_pieces():
+    from eks_amd import hip_ops
+    assert hip_ops.np_nanstd_rows(_dev(np.ones((2, 8193), np.float32))) is None
+
+
+def test_initial_guesses_reduced_on_the_device_equal_the_host_reduction():
+    """core._guess_std_on_device + _initial_guesses_per_keypoint(sd=...) - what run_kalman_smoother uses for device
+    tensors - against the host form on the same float32 variances (NaNs, an all-NaN keypoint, a constant one)."""
+    from eks_amd import core
+    rng = np.random.default_rng(5)
+    ev = rng.gamma(2, 1, (2500, 70, 2)).astype(np.float32)
+    ev[rng.random(ev.shape) < 0.02] = np.nan
+    ev[:, 2, :] = np.nan
+    ev[:, 3, :] = 1.0
+    sd = core._guess_std_on_device(_dev(ev))
+    assert sd is not None
+    assert np.array_equal(core._initial_guesses_per_keypoint(sd=sd), core._initial_guesses_per_keypoint(ev))

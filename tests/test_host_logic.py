@@ -473,3 +473,41 @@ def test_guess_rows_prepared_by_torch_equal_the_host_preparation_bit_for_bit():
     assert a[5] == 2.0
     with pytest.raises(ValueError, match='Not enough frames'):
         core._guess_rows_from_device(torch.as_tensor(ev[:1]))
+
+
+def test_np_sum_program_is_numpys_pairwise_summation_order():
+    """hip_ops.np_sum_program(n) - the leaves and combine order eks_np_nanstd_rows is given - interpreted in float32
+    on the host reproduces numpy.sum of n contiguous float32 values bit for bit (numpy sums pairwise:
+    numpy/_core/src/umath/loops_utils.h.src); the device kernel follows the same tables (GPU test)."""
+    from eks_amd.hip_ops import np_sum_program
+    f = np.float32
+
+    def leaf(a):
+        n = len(a)
+        if n < 8:
+            r = f(0.0)
+            for x in a:
+                r = f(r + x)
+            return r
+        r = [f(a[j]) for j in range(8)]
+        i = 8
+        while i < n - (n % 8):
+            for j in range(8):
+                r[j] = f(r[j] + a[i + j])
+            i += 8
+        res = f(f(f(r[0] + r[1]) + f(r[2] + r[3])) + f(f(r[4] + r[5]) + f(r[6] + r[7])))
+        while i < n:
+            res = f(res + a[i])
+            i += 1
+        return res
+
+    rng = np.random.default_rng(0)
+    for n in (1, 7, 8, 9, 128, 129, 255, 256, 257, 1000, 3998, 7996, 8192):
+        leaves, ops = np_sum_program(n)
+        assert leaves[:, 1].sum() == n and (leaves[:, 1] <= 128).all() and len(ops) == len(leaves) - 1
+        for _ in range(4):
+            a = (rng.standard_normal(n) * 30).astype(f)
+            slot = [leaf(a[s0:s0 + ln]) for s0, ln in leaves] + [None] * len(ops)
+            for dst, x, y in ops:
+                slot[dst] = f(slot[x] + slot[y])
+            assert f(0.0) + slot[-1] == np.sum(a), n
