@@ -205,6 +205,13 @@ int eks_adam_run(const eks_dims_t* d, const float* y, const double* rconst, cons
     }
     const bool in_kernel = n_blocks == K && diag_nll_grad_tree(d->n_frames, K, d->state_dim);
     const DiagModel M{m0, S0, A, C, Q, nullptr, d->state_dim};
+    if (diag_nll_adam_persist_ok(d->n_frames, K, d->state_dim, n_blocks)) {
+      // short sessions, one keypoint per optimiser block: all n_iters iterations in ONE launch, a workgroup per
+      // keypoint (eks_diag_nll.hip: diag_nll_adam_persist_kernel); n_active counts the keypoints still running
+      const AdamFuse F{block_offsets, block_members, kp_block, lr, lo, hi, tol, safety_cap, 1, state, s_keypoint,
+                       n_active, counter_b};
+      return diag_nll_adam_persist(*d, y, rconst, M, n_iters, nll, dnll, F, n_active, st);
+    }
     for (int it = 0; it < n_iters; ++it) {
       // the LAST iteration of the call counts into n_active, the one before into the spare counter, ...
       const bool last_parity = ((n_iters - 1 - it) & 1) == 0;

@@ -366,6 +366,148 @@ __global__ void diag_nll_assemble_tree_kernel(NllGeom G, DiagModel M, NllWs W, i
   }
 }
 
+// The WHOLE optimiser loop of a short session in one launch (round 4).  With one keypoint per optimiser block - the
+// reference's default, blocks = [] (eks/core.py:223-224) - keypoints do not interact at all (the vmapped
+// lax.while_loop of eks/core.py:654-681 masks finished lanes, nothing else), so a workgroup can own a keypoint for
+// all iterations of an eks_adam_run call: thread (i, d) summarises chunk i of chain d (64 ... 256 chunks of 8+ frames,
+// value + d/d log s in float32 duals as everywhere on this path), the summaries are composed by the LDS tree of
+// diag_nll_assemble_tree_kernel in float64 duals, thread (0, 0) finishes, applies the Adam step and the stop
+// rule, and the block goes round again with the new s - no launch, no global exchange, no other block.  Sessions
+// of the reference's own size (2 000 frames, a handful of keypoints) spent 32 us per iteration in two launches
+// whose lanes each walked 512 frames; here a lane walks 32 - 64.  Up to kPersistMaxT frames; longer sessions keep the
+// per-iteration kernels, whose chunks spread over the chip.
+constexpr int kPersistMaxT = 16384;
+
+template <bool UNIT>
+__global__ __launch_bounds__(512) void diag_nll_adam_persist_kernel(int T, int N, int D, int cl, int n_iters, DiagModel M,
+                                             const float* __restrict__ y, const double* __restrict__ rconst,
+                                             double* __restrict__ nll, double* __restrict__ dnll, AdamFuse F,
+                                             int32_t* __restrict__ n_active) {
+  constexpr int NF = 13;                           // 6 element fields + derivatives + reference
+  extern __shared__ double lds[];                  // [D][NF][LN] | tot[D][2] | flag
+  const int i = threadIdx.x, d = threadIdx.y;
+  const int LN = blockDim.x;                       // lanes (= chunks) per chain: 64 ... 256
+  const int k = blockIdx.x;
+  const int kb = F.kp_block[k];
+  const int n = k * D + d;
+  double* my = lds + (size_t)d * NF * LN;
+  double* tot = lds + (size_t)D * NF * LN;
+  int* running = reinterpret_cast<int*>(tot + 2 * D);
+  const size_t dd = (size_t)k * D * D + (size_t)d * (D + 1);
+  const double r_n = rconst[n], a_n = M.A[dd], c_n = M.C[dd], q_n = M.Q[dd];
+  const int t0 = i * cl, len = max(0, min(cl, T - t0));
+  const int nlive = (T + cl - 1) / cl;             // lanes that own a chunk
+  const RowsByPointer ld{y + (size_t)t0 * N + n, (size_t)N};
+  auto put = [&](int slot, const NllAcc<DualD>& a) {
+    const DualD f[6] = {a.e.A, a.e.b, a.e.C, a.e.eta, a.e.J, a.ell};
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      my[q * LN + slot] = f[q].v;
+      my[(6 + q) * LN + slot] = f[q].d;
+    }
+    my[(NF - 1) * LN + slot] = a.xr;
+  };
+  auto take = [&](int slot) {
+    DualD f[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) f[q] = DualD(my[q * LN + slot], my[(6 + q) * LN + slot]);
+    NllAcc<DualD> a;
+    a.e.A = f[0]; a.e.b = f[1]; a.e.C = f[2]; a.e.eta = f[3]; a.e.J = f[4]; a.ell = f[5];
+    a.xr = my[(NF - 1) * LN + slot];
+    return a;
+  };
+  bool alive = adam_block_running(F.state, kb, F.cap);               // block-uniform
+  for (int it = 0; it < n_iters && alive; ++it) {
+    NllAcc<DualD> acc;
+    if (len > 0) {
+      double sq[1] = {F.s_keypoint[k] * q_n};
+      NllElem<Dual> out[1];
+      nll_summarize_chunk<Dual, 1, UNIT>(ld, t0, len, r_n, a_n, c_n, sq, out, false);
+      acc.e.A = DualD(out[0].e.A.v, out[0].e.A.d);
+      acc.e.b = DualD(out[0].e.b.v, out[0].e.b.d);
+      acc.e.C = DualD(out[0].e.C.v, out[0].e.C.d);
+      acc.e.eta = DualD(out[0].e.eta.v, out[0].e.eta.d);
+      acc.e.J = DualD(out[0].e.J.v, out[0].e.J.d);
+      acc.ell = DualD(out[0].ell, out[0].dell);
+      acc.xr = (double)out[0].xref;
+    }
+    for (int half = 1; half < nlive; half <<= 1) {
+      const int span = half << 1;
+      const bool send = (i & (span - 1)) == half && i < nlive;
+      const bool recv = (i & (span - 1)) == 0 && i + half < nlive;
+      if (send) put(i, acc);
+      __syncthreads();
+      if (recv) acc = nll_acc_combine(acc, take(i + half));
+      __syncthreads();                            // (the slots are written again at the next level / iteration)
+    }
+    if (i == 0) {
+      const DualD m = DualD(M.m0[(size_t)k * D + d] - acc.xr), P = DualD(M.S0[dd]);   // relative to the reference
+      const DualD den = DualD(1.0) + acc.e.J * P;
+      const DualD inv = rcp(den);
+      const DualD ll = acc.ell - DualD(0.5) * log_with_rcp(den, inv) +
+                       (acc.e.eta * m + DualD(0.5) * acc.e.eta * acc.e.eta * P - DualD(0.5) * acc.e.J * m * m) * inv;
+      tot[2 * d] = ll.v;
+      tot[2 * d + 1] = ll.d;
+    }
+    __syncthreads();
+    if (i == 0 && d == 0) {
+      double v = 0.0, g = 0.0;
+      for (int q = 0; q < D; ++q) {
+        v += tot[2 * q];
+        g += tot[2 * q + 1];
+      }
+      v = -v;
+      const bool fin = isfinite(v);                // eks/core.py:650
+      nll[k] = fin ? v : 1e12;
+      dnll[k] = fin ? -g : 0.0;
+      *running = adam_step_block(kb, F.offs, F.members, nll, dnll, F.lr, F.lo, F.hi, F.tol, F.cap, F.state,
+                                 F.s_keypoint)
+                     ? 1
+                     : 0;
+    }
+    __syncthreads();                               // the new s (global, written by this block) and the verdict
+    alive = *running != 0;
+  }
+  if (i == 0 && d == 0 && alive) atomicAdd(n_active, 1);
+}
+
+// may eks_adam_run hand a whole call (n_iters iterations) to diag_nll_adam_persist_kernel?
+bool diag_nll_adam_persist_ok(int T, int K, int D, int n_blocks) {
+  return n_blocks == K && T >= 2 && T <= kPersistMaxT && D >= 1 && D <= 8 && !knob_int(KNOB_ADAM_PER_ITERATION, 0);   // (64 lanes x D <= 512 threads)
+}
+
+int diag_nll_adam_persist(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M, int n_iters,
+                          double* nll, double* dnll, const AdamFuse& F, int32_t* n_active, hipStream_t st) {
+  const int T = d.n_frames, K = d.n_keypoints, D = d.state_dim, N = K * D;
+  // lanes per chain: 64, doubled while a lane's chunk would exceed 64 frames (measured on 2 000 x 4: 64 lanes of 32
+  // frames 2.0 ms for the whole run_kalman_smoother call, 256 lanes of 8 frames 2.5 ms - every lane pays the set-up of
+  // its chunk's recursion and every doubling a tree level with two workgroup barriers), up to what the workgroup
+  // (512 threads) and its LDS (13 doubles per lane and chain) hold
+  int LN = 64;
+  // (512 threads: the lane body wants ~200 VGPRs - at 1 024 threads it spilled 400 bytes per lane)
+  while (LN < 256 && LN * 64 < T && 2 * LN * D <= 512 && (size_t)2 * LN * D * 13 * sizeof(double) <= 140 * 1024) LN *= 2;
+  int cl = ((T + LN - 1) / LN + 7) / 8 * 8;
+  if (cl < 8) cl = 8;
+  const size_t shm = ((size_t)D * 13 * LN + 2 * D + 2) * sizeof(double);
+  if (shm > 64 * 1024) {
+    static const bool raised = [] {
+      const int lim = 150 * 1024;
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(diag_nll_adam_persist_kernel<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess &&
+             hipFuncSetAttribute(reinterpret_cast<const void*>(diag_nll_adam_persist_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    }();
+    if (!raised) return EKS_ERR_UNSUPPORTED;
+  }
+  if (d.flags & EKS_FLAG_UNIT_AC)
+    hipLaunchKernelGGL(diag_nll_adam_persist_kernel<true>, dim3(K), dim3(LN, D), shm, st, T, N, D, cl, n_iters, M, y,
+                       rconst, nll, dnll, F, n_active);
+  else
+    hipLaunchKernelGGL(diag_nll_adam_persist_kernel<false>, dim3(K), dim3(LN, D), shm, st, T, N, D, cl, n_iters, M, y,
+                       rconst, nll, dnll, F, n_active);
+  return hip_status(hipGetLastError());
+}
+
 // N1+N2 in ONE launch for the Adam loop (one value of s per keypoint, value + d/d log s; round 3).  The
 // two-launch form above spent 36 us in the chunk summaries and 21 us + a launch gap composing them: the
 // tree kernel is one block per keypoint whose lanes gather 13 planes x ~200 chunks with a stride of a whole

@@ -30,7 +30,7 @@ enum Knob {
   KNOB_SMOOTH_UNFUSED, KNOB_SUMMARIZE_REVERSE, KNOB_REPLAY_FORWARD, KNOB_REPLAY_RECOMPUTE, KNOB_SCAN_CH,
   KNOB_SMOOTH_TILE, KNOB_DENSE_CHUNK, KNOB_NLL_NCL, KNOB_NLL_CHUNK, KNOB_NLL_CHUNK0, KNOB_NLL_WPB,
   KNOB_NLL_EXACT_ENTRY, KNOB_NLL_ASSEMBLE_SEQ, KNOB_DENSE_LEGACY, KNOB_NLL_GRAD_UNFUSED, KNOB_NLL_GRAD_CHUNK,
-  KNOB_DENSE_TREE_SCAN, KNOB_DENSE_DUAL_GRAD, KNOB_NLL_LEGACY, KNOB_MED_ROWS, KNOB_NLL_ASM_WAVES, KNOB_DW_CHUNK, KNOB_COUNT
+  KNOB_DENSE_TREE_SCAN, KNOB_DENSE_DUAL_GRAD, KNOB_NLL_LEGACY, KNOB_MED_ROWS, KNOB_NLL_ASM_WAVES, KNOB_DW_CHUNK, KNOB_ADAM_PER_ITERATION, KNOB_COUNT
 };
 bool knob_set(Knob k);               // the variable exists
 int knob_int(Knob k, int dflt);      // its integer value, or dflt when unset
@@ -80,6 +80,9 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
              const double* s_cand, int n_cand, int per_keypoint, double* nll, double* dnll,
              void* ws, size_t ws_bytes, hipStream_t st, const AdamFuse* fuse = nullptr);
 bool diag_nll_grad_tree(int T, int K, int D);
+bool diag_nll_adam_persist_ok(int T, int K, int D, int n_blocks);
+int diag_nll_adam_persist(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M, int n_iters,
+                          double* nll, double* dnll, const AdamFuse& F, int32_t* n_active, hipStream_t st);
 size_t adam_extra_bytes(int N);     // tail of the NLL workspace: keypoint -> block map, tile tickets, counter
 int32_t* nll_ws_tickets(void* ws, int T, int N, int n_cand);   // the tile tickets inside that tail
 int adam_prepare(int n_blocks, int K, const int32_t* offs, const int32_t* members, int32_t* kp_block,

@@ -960,3 +960,63 @@ def test_initial_guesses_reduced_on_the_device_equal_the_host_reduction():
     sd = core._guess_std_on_device(_dev(ev))
     assert sd is not None
     assert np.array_equal(core._initial_guesses_per_keypoint(sd=sd), core._initial_guesses_per_keypoint(ev))
+
+
+@pytest.mark.parametrize('T,K,unit', [(2000, 4, True), (700, 3, False), (9000, 20, True), (16384, 2, False),
+                                      (130, 5, True), (2, 2, True)])
+def test_adam_whole_loop_in_one_launch_reproduces_the_per_iteration_loop(T, K, unit, set_knob):
+    """Sessions of up to 16 384 frames with one keypoint per optimiser block run all iterations of an eks_adam_run
+    call in ONE launch, a workgroup per keypoint (diag_nll_adam_persist_kernel).  Against the per-iteration kernels
+    (EKS_ADAM_PER_ITERATION=1) on the same problem: the same number of iterations per keypoint and log s within
+    2e-6 (the chunking differs - 64 chunks of T / 64 frames instead of 512-frame chunks - so the float32 summaries
+    round differently), and against the oracle's Adam (oracle/eks_oracle.py: adam_optimize_s on the C port's
+    complex-step gradient) with the same stopping iteration and log s within 1e-5."""
+    from eks_amd import hip_ops
+    arrs, y_tk, var_tk = _singlecam_problem(max(T, 2), K, seed=900 + T, unit=unit)
+    y_tk, var_tk = y_tk[:T], var_tk[:T]
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    y, rc = _dev(y_tk), hip_ops.const_r(_dev(var_tk), 1e-4)
+    params = _params_dev(arrs)
+    offs = torch.arange(K + 1, dtype=torch.int32, device='cuda')
+    mem = torch.arange(K, dtype=torch.int32, device='cuda')
+    u0 = np.log(np.random.default_rng(T).uniform(0.05, 20.0, K))
+
+    def run():
+        state = np.zeros((K, 6))
+        state[:, 0] = u0
+        state[:, 3] = np.inf
+        state = _dev(state)
+        s_kp = _dev(np.exp(u0))
+        loop = hip_ops.AdamLoop(y, rc, *params, offs, mem, state, s_kp, 0.25, -8.0, 8.0, 1e-2, 300, flags=flags)
+        for _ in range(40):
+            loop.run(8)
+            if int(loop.n_active.item()) == 0:
+                break
+        return state.cpu().numpy(), s_kp.cpu().numpy()
+
+    st_p, s_p = run()
+    set_knob('EKS_ADAM_PER_ITERATION', '1')
+    st_i, s_i = run()
+    assert np.array_equal(st_p[:, 4], st_i[:, 4]), (st_p[:, 4], st_i[:, 4])          # iterations taken
+    assert np.array_equal(st_p[:, 5], st_i[:, 5])
+    assert np.abs(np.log(s_p) - np.log(s_i)).max() < 2e-6
+    if T >= 100:
+        from oracle import c_oracle
+        ks = list(range(min(K, 4)))
+        ys = np.transpose(y_tk, (1, 0, 2)).astype(np.float64)
+        Rc = rc.cpu().numpy()
+        zero = np.zeros((1, 2, 2))
+
+        def loss_and_grad(u):
+            out = []
+            for j, k in enumerate(ks):
+                sQ = np.exp(u[j]) * arrs['Qs'][k]
+                L, g = c_oracle.nll_directional(ys[k], Rc[k], arrs['m0s'][k], arrs['S0s'][k], arrs['As'][k],
+                                                arrs['Cs'][k], sQ, zero, sQ[None])
+                out.append((L, g[0]))
+            return np.array([o[0] for o in out]), np.array([o[1] for o in out])
+
+        u_o, _, it_o = orc.adam_optimize_s(loss_and_grad, u0[ks], tol=1e-2, safety_cap=300)
+        s_o = np.exp(np.clip(u_o, -8.0, 8.0))
+        assert np.array_equal(st_p[ks, 4].astype(int), it_o)
+        assert np.abs(np.log(s_p[ks]) - np.log(s_o)).max() < 1e-5
