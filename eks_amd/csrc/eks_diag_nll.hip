@@ -473,7 +473,10 @@ __global__ __launch_bounds__(512) void diag_nll_adam_persist_kernel(int T, int N
 
 // may eks_adam_run hand a whole call (n_iters iterations) to diag_nll_adam_persist_kernel?
 bool diag_nll_adam_persist_ok(int T, int K, int D, int n_blocks) {
-  return n_blocks == K && T >= 2 && T <= kPersistMaxT && D >= 1 && D <= 8 && !knob_int(KNOB_ADAM_PER_ITERATION, 0);   // (64 lanes x D <= 512 threads)
+  // (64 lanes x D <= 512 threads; up to 512 keypoints every workgroup is resident and the keypoints advance side by
+  //  side - wider sessions go round by round and the chip-wide single-launch kernel streams them faster)
+  return n_blocks == K && K <= 512 && T >= 2 && T <= kPersistMaxT && D >= 1 && D <= 8 &&
+         !knob_int(KNOB_ADAM_PER_ITERATION, 0);
 }
 
 int diag_nll_adam_persist(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M, int n_iters,
