@@ -475,8 +475,12 @@ __global__ __launch_bounds__(512) void diag_nll_adam_persist_kernel(int T, int N
 bool diag_nll_adam_persist_ok(int T, int K, int D, int n_blocks) {
   // (64 lanes x D <= 512 threads; up to 512 keypoints every workgroup is resident and the keypoints advance side by
   //  side - wider sessions go round by round and the chip-wide single-launch kernel streams them faster)
-  return n_blocks == K && K <= 512 && T >= 2 && T <= kPersistMaxT && D >= 1 && D <= 8 &&
-         !knob_int(KNOB_ADAM_PER_ITERATION, 0);
+  //  Measured (tools/small_session_time.py, tools/adam_time.py; per-iteration kernels -> whole loop): 2 000 frames x
+  //  4 / 16 / 64 keypoints 3.3 / 3.7 / 5.1 -> 1.9 / 2.3 / 3.1 ms, 10 000 x 16 4.4 -> 4.1 ms, but 10 000 x 64 - which the
+  //  chip-wide single-launch kernel serves - 2.8 -> 3.9 ms: beyond 4 096 frames only sessions of at most 32 chains.
+  if (n_blocks != K || K > 512 || T < 2 || T > kPersistMaxT || D < 1 || D > 8 || knob_int(KNOB_ADAM_PER_ITERATION, 0))
+    return false;
+  return T <= 4096 || K * D <= 32;
 }
 
 int diag_nll_adam_persist(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M, int n_iters,
