@@ -186,7 +186,15 @@ class _DeviceProblem:
         self.K, self.D = host['m0'].shape
         self.O = host['C'].shape[1]
         self.flags = hip_ops.model_flags(host['S0'], host['A'], host['C'], host['Q'])
-        self.params = [torch.as_tensor(host[k], device=self.dev) for k in ('m0', 'S0', 'A', 'C', 'Q')]
+        # the five parameter arrays go up as ONE copy (an upload of a few hundred bytes costs ~19 us of host time
+        # whatever its size: five of them were a fifth of a 2 000-frame session's whole call)
+        keys = ('m0', 'S0', 'A', 'C', 'Q')
+        flat = torch.as_tensor(np.concatenate([host[k].ravel() for k in keys]), device=self.dev)
+        self.params, at = [], 0
+        for k in keys:
+            n = host[k].size
+            self.params.append(flat[at:at + n].view(host[k].shape))
+            at += n
         # ys arrives (K,T,O) like upstream; a torch tensor that is a transposed view of a
         # frame-major buffer is taken zero-copy, anything else is transposed once
         if hasattr(ys, 'detach'):
