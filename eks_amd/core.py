@@ -295,6 +295,11 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
     # round issued after the last block stopped costs a round of full evaluations - so its rounds are short.
     if sync_every is None:
         sync_every = 16 if (P.flags & hip_ops.FLAG_DIAG_MODEL) else 4
+        # short scalar-chain sessions with one keypoint per block run a whole call in ONE launch whose workgroups
+        # stop by themselves (eks_diag_nll.hip: diag_nll_adam_persist_kernel): longer rounds cost nothing on the
+        # device and spare host round trips
+        if (P.flags & hip_ops.FLAG_DIAG_MODEL) and nb == P.K and y_c.shape[0] <= 4096 and P.K <= 512:
+            sync_every = 64
     rounds = (cap + sync_every - 1) // sync_every
     try:
         snap = _pinned_empty((max(rounds, 1),), torch.int32)
