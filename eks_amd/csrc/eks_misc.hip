@@ -161,13 +161,14 @@ __device__ uint32_t lds_radix_select(const uint32_t* vals, int L, uint32_t rank,
 // hist: 256 counters, sh: 6 words, small: kSelSmall words of LDS.
 constexpr int kSelSmall = 256;
 
+template <int NT>
 __device__ uint32_t lds_select_compact(const uint32_t* vals, int L, uint32_t rank, uint32_t base, int lsh,
                                        uint32_t* hist, uint32_t* sh, uint32_t* small, uint32_t* next,
                                        bool* has_next) {
-  hist[threadIdx.x] = 0u;
+  if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
   if (threadIdx.x == 0) sh[3] = 0u;
   __syncthreads();
-  for (int i = threadIdx.x; i < L; i += 256) atomicAdd(&hist[radix_norm(vals[i], base, lsh) >> 24], 1u);
+  for (int i = threadIdx.x; i < L; i += NT) atomicAdd(&hist[radix_norm(vals[i], base, lsh) >> 24], 1u);
   __syncthreads();
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
@@ -201,9 +202,9 @@ __device__ uint32_t lds_select_compact(const uint32_t* vals, int L, uint32_t ran
     uint32_t r = q_in;
     for (int pass = 1; pass < 4; ++pass) {
       const int shift = 24 - 8 * pass;
-      hist[threadIdx.x] = 0u;
+      if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
       __syncthreads();
-      for (int i = threadIdx.x; i < L; i += 256) {
+      for (int i = threadIdx.x; i < L; i += NT) {
         const uint32_t key = radix_norm(vals[i], base, lsh);
         if ((key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
       }
@@ -237,7 +238,7 @@ __device__ uint32_t lds_select_compact(const uint32_t* vals, int L, uint32_t ran
     }
     return (prefix >> lsh) + base;
   }
-  for (int i = threadIdx.x; i < L; i += 256) {
+  for (int i = threadIdx.x; i < L; i += NT) {
     const uint32_t key = radix_norm(vals[i], base, lsh);
     if ((key >> 24) == bin) small[atomicAdd(&sh[3], 1u)] = key;
   }
@@ -264,6 +265,7 @@ __device__ uint32_t lds_select_compact(const uint32_t* vals, int L, uint32_t ran
 // histogram passes (the second one refines the two first-pass bins at once) instead of two exact
 // radix selects.  Returns the low edge of r_lo's cell and the high edge of r_hi's: every key of
 // rank r_lo..r_hi lies inside.  hist: 512 counters, sh: 4 words.
+template <int NT>
 __device__ void lds_bracket(const uint32_t* vals, int L, uint32_t r_lo, uint32_t r_hi, uint32_t base,
                             int lsh, uint32_t* hist, uint32_t* sh, uint32_t& lo, uint32_t& hi) {
   // wave 0 / wave 1 locate rank r in hist[off .. off + 256): bin -> sh[slot], rank inside -> sh[slot + 1]
@@ -289,20 +291,20 @@ __device__ void lds_bracket(const uint32_t* vals, int L, uint32_t r_lo, uint32_t
       cum += c[q];
     }
   };
-  hist[threadIdx.x] = 0u;
-  hist[256 + threadIdx.x] = 0u;
+  if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
+  if (threadIdx.x < 256) hist[256 + threadIdx.x] = 0u;
   __syncthreads();
-  for (int i = threadIdx.x; i < L; i += 256) atomicAdd(&hist[radix_norm(vals[i], base, lsh) >> 24], 1u);
+  for (int i = threadIdx.x; i < L; i += NT) atomicAdd(&hist[radix_norm(vals[i], base, lsh) >> 24], 1u);
   __syncthreads();
   if (threadIdx.x < 64) find(r_lo, 0, 0);
   else if (threadIdx.x < 128) find(r_hi, 0, 2);
   __syncthreads();
   const uint32_t b_lo = sh[0], q_lo = sh[1], b_hi = sh[2], q_hi = sh[3];
   __syncthreads();
-  hist[threadIdx.x] = 0u;
-  hist[256 + threadIdx.x] = 0u;
+  if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
+  if (threadIdx.x < 256) hist[256 + threadIdx.x] = 0u;
   __syncthreads();
-  for (int i = threadIdx.x; i < L; i += 256) {
+  for (int i = threadIdx.x; i < L; i += NT) {
     const uint32_t k = radix_norm(vals[i], base, lsh);
     if ((k >> 24) == b_lo) atomicAdd(&hist[(k >> 16) & 255u], 1u);
     if ((k >> 24) == b_hi) atomicAdd(&hist[256 + ((k >> 16) & 255u)], 1u);
@@ -318,6 +320,7 @@ __device__ void lds_bracket(const uint32_t* vals, int L, uint32_t r_lo, uint32_t
 }
 
 // min / max over the valid keys of vals[0..L) (block-wide, through LDS scratch mm[2])
+template <int NT>
 __device__ void lds_key_range(const uint32_t* vals, int L, uint32_t* mm, uint32_t& lo, uint32_t& hi) {
   if (threadIdx.x == 0) {
     mm[0] = 0xFFFFFFFFu;
@@ -325,7 +328,7 @@ __device__ void lds_key_range(const uint32_t* vals, int L, uint32_t* mm, uint32_
   }
   __syncthreads();
   uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-  for (int i = threadIdx.x; i < L; i += 256) {
+  for (int i = threadIdx.x; i < L; i += NT) {
     const uint32_t k = vals[i];
     if (k != 0xFFFFFFFFu) {
       mn = min(mn, k);
@@ -379,7 +382,8 @@ __global__ __launch_bounds__(256) void sample_transpose_kernel(int T, int N, int
 }
 
 // S2: one block per chain
-__global__ __launch_bounds__(256) void sample_bracket_kernel(int N, int S, BracketWs B) {
+template <int NT>
+__global__ __launch_bounds__(NT) void sample_bracket_kernel(int N, int S, BracketWs B) {
   __shared__ uint32_t vals[kMedSamples];
   __shared__ uint32_t hist[512];
   __shared__ uint32_t sh[4], nvalid;
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(256) void sample_bracket_kernel(int N, int S, Brack
   if (threadIdx.x == 0) nvalid = 0;
   __syncthreads();
   uint32_t mine = 0;
-  for (int i = threadIdx.x; i < S; i += 256) {
+  for (int i = threadIdx.x; i < S; i += NT) {
     const uint32_t k = B.smp[(size_t)n * S + i];
     vals[i] = k;
     mine += k != 0xFFFFFFFFu;
@@ -405,12 +409,12 @@ __global__ __launch_bounds__(256) void sample_bracket_kernel(int N, int S, Brack
   const int mid = ((int)nv - 1) / 2;
   const int r_lo = max(0, mid - delta), r_hi = min((int)nv - 1, mid + 1 + delta);
   uint32_t kmin, kmax;
-  lds_key_range(vals, S, sh, kmin, kmax);
+  lds_key_range<NT>(vals, S, sh, kmin, kmax);
   const int lsh = kmax > kmin ? __clz((int)(kmax - kmin)) : 0;
   // the bracket only has to CONTAIN the sample's order statistics r_lo .. r_hi: 1/65536 of the
   // sample's key range is resolution enough (the exact selection happens in S4)
   uint32_t lo, hi;
-  lds_bracket(vals, S, (uint32_t)r_lo, (uint32_t)r_hi, kmin, lsh, hist, sh, lo, hi);
+  lds_bracket<NT>(vals, S, (uint32_t)r_lo, (uint32_t)r_hi, kmin, lsh, hist, sh, lo, hi);
   if (threadIdx.x == 0) {
     B.lo[n] = lo;
     B.hi[n] = min(hi, kmax);
@@ -563,6 +567,7 @@ __global__ __launch_bounds__(64 * kColWaves, 8) void bracket_collect_kernel(int 
 
 // exact median of one chain's column by radix select inside one block (fallback path)
 // (called by the whole 256-thread block of bracket_finish_kernel; hist: 256 counters, sc: 6 words)
+template <int NT>
 __device__ void median_column(int T, int N, const float* __restrict__ var, double min_var, int n,
                               double* __restrict__ rconst, uint32_t* hist, uint32_t* sc) {
   uint32_t &sh_prefix = sc[0], &sh_rank = sc[1], &sh_cnt = sc[2], &sh_less = sc[3], &sh_eq = sc[4],
@@ -571,11 +576,11 @@ __device__ void median_column(int T, int N, const float* __restrict__ var, doubl
   // bound by T / 256 dependent memory latencies per sweep)
   auto sweep = [&](auto&& f) {
     constexpr int kU = 16;
-    for (int t0 = threadIdx.x; t0 < T; t0 += 256 * kU) {
+    for (int t0 = threadIdx.x; t0 < T; t0 += NT * kU) {
       float v[kU];
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
-        const int t = t0 + 256 * u;
+        const int t = t0 + NT * u;
         v[u] = t < T ? var[(size_t)t * N + n] : __uint_as_float(0x7FC00000u);
       }
 #pragma unroll
@@ -588,7 +593,7 @@ __device__ void median_column(int T, int N, const float* __restrict__ var, doubl
   };
   uint32_t prefix = 0, rank = 0, less = 0;
   for (int pass = 0; pass < 4; ++pass) {
-    hist[threadIdx.x] = 0u;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
     __syncthreads();
     const int shift = 24 - 8 * pass;
     sweep([&](uint32_t key) {
@@ -652,15 +657,16 @@ __device__ void median_column(int T, int N, const float* __restrict__ var, doubl
 // five strided sweeps of the whole column (400 000 frames x 16 keypoints: 1.55 ms for the call instead of 0.1).
 // Same MSB-first radix select, 4 x 8 bits + one sweep for the successor.  Whole 256-thread block; hist: 256
 // counters, sc: 6 words.
+template <int NT>
 __device__ void select_two_from_list(const uint32_t* __restrict__ keys, uint32_t L, uint32_t a, uint32_t b,
                                      uint32_t* hist, uint32_t* sc, uint32_t& v_lo, uint32_t& v_hi) {
   uint32_t &sh_prefix = sc[0], &sh_rank = sc[1], &sh_less = sc[3], &sh_eq = sc[4], &sh_next = sc[5];
   uint32_t prefix = 0, rank = a, less = 0;
   for (int pass = 0; pass < 4; ++pass) {
-    hist[threadIdx.x] = 0u;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
     __syncthreads();
     const int shift = 24 - 8 * pass;
-    for (uint32_t i = threadIdx.x; i < L; i += 256) {
+    for (uint32_t i = threadIdx.x; i < L; i += NT) {
       const uint32_t key = keys[i];
       if (pass > 0 && (key >> (shift + 8)) != prefix) continue;
       atomicAdd(&hist[(key >> shift) & 255u], 1u);
@@ -692,7 +698,7 @@ __device__ void select_two_from_list(const uint32_t* __restrict__ keys, uint32_t
   }
   const uint32_t eq = sh_eq, key_lo = prefix;
   uint32_t best = 0xFFFFFFFFu;
-  for (uint32_t i = threadIdx.x; i < L; i += 256) {
+  for (uint32_t i = threadIdx.x; i < L; i += NT) {
     const uint32_t key = keys[i];
     if (key > key_lo && key < best) best = key;
   }
@@ -704,7 +710,8 @@ __device__ void select_two_from_list(const uint32_t* __restrict__ keys, uint32_t
 }
 
 // S4: one block per chain
-__global__ __launch_bounds__(256) void bracket_finish_kernel(int T, int N, const float* __restrict__ var,
+template <int NT>
+__global__ __launch_bounds__(NT) void bracket_finish_kernel(int T, int N, const float* __restrict__ var,
                                                             double min_var, BracketWs B,
                                                             double* __restrict__ rconst) {
   __shared__ uint32_t vals[kMedList];
@@ -716,25 +723,25 @@ __global__ __launch_bounds__(256) void bracket_finish_kernel(int T, int N, const
   // too few valid samples, the bracket missed the median, or heavy duplicates overflowed the
   // list: this block selects from the chain's whole column instead (block-uniform branch)
   if (B.fallback[n] || cnt == 0 || inside > B.cap || r_lo < less || r_hi >= less + inside) {
-    median_column(T, N, var, min_var, n, rconst, hist, sc);
+    median_column<NT>(T, N, var, min_var, n, rconst, hist, sc);
     return;
   }
   if (inside > (uint32_t)kMedList) {    // a long sequence: the list does not fit LDS, select in place (block-uniform)
     uint32_t v_lo, v_hi;
-    select_two_from_list(B.list + (size_t)n * B.cap, inside, r_lo - less, r_hi - less, hist, sc, v_lo, v_hi);
+    select_two_from_list<NT>(B.list + (size_t)n * B.cap, inside, r_lo - less, r_hi - less, hist, sc, v_lo, v_hi);
     if (threadIdx.x == 0) {
       const double med = 0.5 * (double)__uint_as_float(v_lo) + 0.5 * (double)__uint_as_float(v_hi);
       rconst[n] = med > min_var ? med : min_var;
     }
     return;
   }
-  for (int i = threadIdx.x; i < (int)inside; i += 256) vals[i] = B.list[(size_t)n * B.cap + i];
+  for (int i = threadIdx.x; i < (int)inside; i += NT) vals[i] = B.list[(size_t)n * B.cap + i];
   __syncthreads();
   const uint32_t blo = B.lo[n], bhi = B.hi[n];          // every listed key lies in [blo, bhi]
   const int lsh = bhi > blo ? __clz((int)(bhi - blo)) : 0;
   uint32_t nxt_in_bin = 0;
   bool has_next = false;
-  const uint32_t v_lo = lds_select_compact(vals, (int)inside, r_lo - less, blo, lsh, hist, sc, small,
+  const uint32_t v_lo = lds_select_compact<NT>(vals, (int)inside, r_lo - less, blo, lsh, hist, sc, small,
                                            &nxt_in_bin, &has_next);
   uint32_t v_hi = v_lo;
   if (r_hi != r_lo && has_next) {
@@ -747,7 +754,7 @@ __global__ __launch_bounds__(256) void bracket_finish_kernel(int T, int N, const
     }
     __syncthreads();
     uint32_t le = 0, nxt = 0xFFFFFFFFu;
-    for (int i = threadIdx.x; i < (int)inside; i += 256) {
+    for (int i = threadIdx.x; i < (int)inside; i += NT) {
       const uint32_t k = vals[i];
       le += k <= v_lo;
       if (k > v_lo) nxt = min(nxt, k);
@@ -826,12 +833,22 @@ int const_r(int T, int N, const float* var, double min_var, double* rconst, void
   const int ntile = (N + 63) / 64;
   hipLaunchKernelGGL(sample_transpose_kernel, dim3(ntile, (S + 63) / 64), dim3(256), 0, st, T, N, S,
                      var, B);
-  hipLaunchKernelGGL(sample_bracket_kernel, dim3(N), dim3(256), 0, st, N, S, B);
+  if (knob_int(KNOB_MED_BRACKET_THREADS, 256) == 512)
+    hipLaunchKernelGGL(sample_bracket_kernel<512>, dim3(N), dim3(512), 0, st, N, S, B);
+  else
+    hipLaunchKernelGGL(sample_bracket_kernel<256>, dim3(N), dim3(256), 0, st, N, S, B);
   const int R = collect_rows_per_wave(T, ntile);
   const int nslab = (T + R * kColWaves - 1) / (R * kColWaves);
   hipLaunchKernelGGL(bracket_collect_kernel, dim3((unsigned)(ntile * nslab)), dim3(64 * kColWaves), 0, st,
                      T, N, R, var, B);
-  hipLaunchKernelGGL(bracket_finish_kernel, dim3(N), dim3(256), 0, st, T, N, var, min_var, B, rconst);
+  // (the block's helpers stride by blockDim.x: any multiple of 256 threads; EKS_MED_FINISH_THREADS for A/B runs)
+  // measured on C3 (512 chains, ~7 000 listed keys each): 256 threads 16.1 us, 512: 13.6, 1 024: 16.9
+  int ft = knob_int(KNOB_MED_FINISH_THREADS, 512);
+  if (ft != 256 && ft != 512) ft = 512;
+  if (ft == 512)
+    hipLaunchKernelGGL(bracket_finish_kernel<512>, dim3(N), dim3(512), 0, st, T, N, var, min_var, B, rconst);
+  else
+    hipLaunchKernelGGL(bracket_finish_kernel<256>, dim3(N), dim3(256), 0, st, T, N, var, min_var, B, rconst);
   return hip_status(hipGetLastError());
 }
 
