@@ -6,7 +6,7 @@ T = 100 000 frames x K = 256 keypoints, smoothing parameter chosen per keypoint 
 NLL grid (candidates exp(linspace(-8, 8, 64)), constant-R loss of eks/core.py:602/:640-650), then
 the final fixed-s filter + RTS smoother with the full `ms (T,K,2)`, `Vs (T,K,2,2)` contract.
 One "step" = one pass of that whole path over one session already resident in HBM:
-    eks_const_r -> eks_nll (64 candidates) -> eks_argmin_s -> eks_smooth.
+    eks_const_r -> eks_nll_argmin (64 candidates: table + argmin) -> eks_smooth.
 1 unit = one keypoint at one frame.  Inputs are synthetic (seeded, generated on device).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c3adam|c2|c5|c4|c4w|c4adam|pupil|ekf]
@@ -736,8 +736,7 @@ def main():
             prepared()
         elif n_cand:
             rc = hip_ops.const_r(var, 1e-4)
-            nll = hip_ops.nll(y, rc, m0, S0, eye, eye, eye, cand, flags=flags)
-            s, _ = hip_ops.argmin_s(nll, cand)
+            nll, s, _ = hip_ops.nll_argmin(y, rc, m0, S0, eye, eye, eye, cand, flags=flags)
         if prepared is None:
             hip_ops.smooth(y, var, m0, S0, eye, eye, eye, s, flags=flags, out=(ms, Vs))
         if use_dist:

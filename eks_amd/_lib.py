@@ -37,6 +37,8 @@ SIGNATURES = {
     'eks_nll': (ctypes.c_int, [POINTER(EksDims)] + [c_void_p] * 8 + [c_int32, c_int32, c_void_p,
                                                                     c_void_p, c_void_p, c_size_t,
                                                                     c_void_p]),
+    'eks_nll_argmin': (ctypes.c_int, [POINTER(EksDims)] + [c_void_p] * 8 + [c_int32, c_void_p, c_void_p, c_void_p,
+                                                                           c_void_p, c_size_t, c_void_p]),
     'eks_argmin_s': (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p]),
     'eks_np_nanstd_rows': (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p,

@@ -256,14 +256,14 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
     nb = len(blocks)
     if s_mode == 'grid':
         cand = torch.exp(torch.linspace(lo, hi, n_grid, dtype=torch.float64, device=P.dev))
-        nll = hip_ops.nll(y_c, rconst, *P.params, cand, flags=P.flags)
         if nb != P.K:                                   # blocks share one s: sum member losses
+            nll = hip_ops.nll(y_c, rconst, *P.params, cand, flags=P.flags)
             blk = torch.zeros((nb, n_grid), dtype=torch.float64, device=P.dev)
             blk.index_add_(0, torch.as_tensor(of_kp, device=P.dev), nll)
             s_blk, idx = hip_ops.argmin_s(blk, cand)
             s = s_blk[torch.as_tensor(of_kp, device=P.dev)]
-        else:
-            s, idx = hip_ops.argmin_s(nll, cand)
+        else:                                           # table and argmin in one call (eks_nll_argmin)
+            nll, s, idx = hip_ops.nll_argmin(y_c, rconst, *P.params, cand, flags=P.flags)
         return s, dict(mode='grid', nll=nll, argmin=idx, candidates=cand)
     # Adam on u = log s (reference eks/core.py:612-613, :439-441: float32 initial value)
     # (block means by one segmented sum over the CSR member list: a Python loop over 256 blocks of np.mean / np.clip

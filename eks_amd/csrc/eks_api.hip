@@ -102,6 +102,27 @@ int eks_nll(const eks_dims_t* d, const float* y, const double* rconst, const dou
                    workspace_bytes, st);
 }
 
+int eks_nll_argmin(const eks_dims_t* d, const float* y, const double* rconst, const double* m0,
+                   const double* S0, const double* A, const double* C, const double* Q,
+                   const double* s_cand, int32_t n_cand, double* nll, double* s_out, int32_t* idx_out,
+                   void* workspace, size_t workspace_bytes, eks_stream_t stream) {
+  const int rc = check_dims(d);
+  if (rc != EKS_OK) return rc;
+  if (n_cand <= 0) return EKS_ERR_SHAPE;
+  if (!y || !rconst || !m0 || !S0 || !A || !C || !Q || !s_cand || !nll || !s_out) return EKS_ERR_NULL;
+  if (!workspace) return EKS_ERR_WORKSPACE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->flags & EKS_FLAG_DIAG_MODEL) {
+    const DiagModel M{m0, S0, A, C, Q, nullptr, d->state_dim};
+    return diag_nll(*d, y, rconst, M, s_cand, n_cand, 0, nll, nullptr, workspace, workspace_bytes, st, nullptr, s_out,
+                    idx_out);
+  }
+  const DenseModel M{m0, S0, A, C, Q, nullptr};
+  const int rc2 = dense_nll(*d, y, rconst, M, s_cand, n_cand, 0, nll, nullptr, workspace, workspace_bytes, st);
+  if (rc2 != EKS_OK) return rc2;
+  return argmin_s(d->n_keypoints, n_cand, nll, s_cand, s_out, idx_out, st);
+}
+
 int eks_order_stats(int32_t n_rows, int32_t n_cols, const float* x, int32_t rank_lo, int32_t rank_hi,
                     float* out, int32_t* nan_count, eks_stream_t stream) {
   if (n_rows <= 0 || n_cols <= 0 || rank_lo < 0 || rank_hi < rank_lo || rank_hi >= n_rows || rank_hi > rank_lo + 1)

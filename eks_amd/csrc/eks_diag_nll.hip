@@ -26,6 +26,7 @@
 
 #include "eks_adam.hpp"
 #include "eks_internal.hpp"
+#include "eks_nll_lag.hpp"
 #include "eks_nll_lane.hpp"
 
 namespace eks {
@@ -820,19 +821,125 @@ constexpr int kLeanWaves = 4;                // waves per block, both roles
 struct LeanGeom {
   int nhead_blocks;      // head role: ceil(ntile * ngrp4 / kLeanWaves)
   int ngrp4, ngrp16;     // candidate groups of the two roles
-  int32_t* flags;        // [ncn][ntile][ngrp16]: 1 = exact-entry summary (full planes valid)
-  float* Jc;             // [ncp][N]: J of a converged-entry summary
+  int32_t* flags;        // [ncn][ntile][ncp], per candidate: 0 = lean summary with A = 0, 1 = exact-entry summary (full
+                         // planes valid), 2 = lean summary with its own A, J
+  // ---- round 5: shared-lag form (eks_nll_lag.hpp).  A block whose chunk qualifies (whole 32-frame sets, converged
+  // entry for EVERY candidate, at least kLagMinFast fast candidates - decided identically by its four waves from the
+  // chains' constants, no exchange) summarises its fast candidates as lag sums and deals only the slow ones to the waves.
+  int lag_on;            // the launch may use the form at all
+  double rho_max;        // a candidate is fast when its pole is at most this for every chain of the tile
+  double* lagc;          // [ncn][N][kLagN]: the chunk's lag sums
+  float *uh, *ut;        // [ncn][N][kLagN]: its first / last kLagN inputs u
+  float* yl;             // [ncn][N]: its last observation
+  int32_t* mode;         // [ncn][ntile]: 1 = the (chunk, tile) took the lag form
+  unsigned long long* fastmask;   // [ntile]: bit c = candidate c is fast for this tile (valid where some chunk's mode is 1)
+  // ---- table of the assembly (diag_nll_assemble_kp_kernel), written by the head role
+  double* tab;           // [N][kTabFields][ncp]: the candidate's float64 steady-state constants (rho, g, r g, c g, log S,
+                         // J), J of its float32 recursion-form summaries, chunk 0's term of the log-likelihood given the
+                         // prior and the mean entering chunk 1
 };
+constexpr int kTabFields = 9;
+enum { TAB_RHO, TAB_G, TAB_RG, TAB_CG, TAB_LOGS, TAB_JC, TAB_J32, TAB_LL0, TAB_B0 };
+// Layouts of the grid path (round 5: the assembly's lanes are CANDIDATES, so everything per (chain, candidate) has the
+// candidate fastest):  summary planes [j][N][ncp];  chunk references xr [j][N];  lag sums / first and last inputs
+// [j][N][kLagN] (a chain's values contiguous: the assembly reads them with scalar loads);  flags [j][ntile][ncp].
+constexpr int kLagMinFast = 16;        // fewer fast candidates: the lag products cost more than they save
+constexpr int kLagMaxNP = 6;           // slow pairs per wave (nslow <= 48 when at least 16 of 64 are fast)
+// LDS of a block, in doubles: the round-4 lean role parks 4 floats x 16 candidates per lane and wave (64 KB); the lag
+// form [4 waves][kLagN][64] float64 lag accumulators (32 KB) + 3 floats x 2 NP candidates per lane and wave (<= 36 KB)
+constexpr int kGridLdsDoubles = (kLeanWaves * kLagN * 64) + (kLeanWaves * 3 * 2 * kLagMaxNP * 64) / 2;
+static_assert(kGridLdsDoubles * 8 >= kLeanWaves * 4 * kLeanNC * 64 * 4, "the lean role's stash must fit");
+
+// sinks of the lag form's lane body: slow candidates' fields straight to the summary planes (indexed by candidate),
+// lag partial sums into this wave's float64 accumulators in LDS, the chunk's first / last inputs to their planes
+template <int NC>
+struct LagSlowSink {
+  const NllWs& W;
+  size_t jbase;            // (j * N + n) * ncp
+  size_t xr_off;
+  int cand[NC];
+  bool used[NC];           // slot k holds a slow candidate (a fast one that pads the list is computed but not stored)
+  bool store, store_xr;
+  __device__ __forceinline__ size_t off(int k) const { return jbase + (size_t)cand[k]; }
+  __device__ __forceinline__ void xref(float v) const { if (store_xr) W.xr[xr_off] = v; }
+  __device__ __forceinline__ void eta(int k, float v) const { if (store && used[k]) W.eta[off(k)] = v; }
+  __device__ __forceinline__ void aj(int k, float a, float jv) const {
+    if (store && used[k]) {
+      W.A[off(k)] = a;
+      W.J[off(k)] = jv;
+    }
+  }
+  __device__ __forceinline__ void b(int k, float v) const { if (store && used[k]) W.b[off(k)] = v; }
+  __device__ __forceinline__ void ell(int k, double v) const { if (store && used[k]) W.ell[off(k)] = v; }
+};
+struct LagDevSink {
+  double* acc;             // LDS: this wave's [kLagN][64] accumulators, at the lane
+  float *uh, *ut, *yl;     // global, at (j, n)
+  bool store;
+  __device__ __forceinline__ void add(int k, float v) const { acc[k * 64] += (double)v; }
+  __device__ __forceinline__ void head(int i, float v) const { if (store) uh[i] = v; }
+  __device__ __forceinline__ void tail(int i, float v) const { if (store) ut[i] = v; }
+  __device__ __forceinline__ void ylast(float v) const { if (store) *yl = v; }
+};
+
+// the lag form of one (tile, chunk) block, NP slow pairs per wave.  rk: this LANE's candidate's place in the list
+// "slow candidates in index order, then the fast ones" (lanes >= n_cand: none); slot k of wave w is the candidate
+// with place 4 k + w.  Returns the lane body's verdict (1 / 2).
+template <int NP, bool UNIT>
+__device__ __forceinline__ int lag_block_body(const NllGeom& G, const LeanGeom& LG, const NllWs& W, const BufferRows& ld,
+                                              int j, int n, bool chain_ok, int w, int lane, int len, double q, double r_n,
+                                              double a_n, double c_n, const double* sc, unsigned long long fm, int rk,
+                                              double* lds) {
+  constexpr int NC = 2 * NP;
+  LagSlowSink<NC> sink{W, ((size_t)j * G.N + n) * W.ncp, (size_t)j * G.N + n, {}, {}, chain_ok, chain_ok && w == 0};
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const unsigned long long hit = __ballot(lane < G.n_cand && rk == 4 * k + w);
+    const int c = hit ? __builtin_ctzll(hit) : G.n_cand - 1;
+    sink.cand[k] = __builtin_amdgcn_readfirstlane(c);
+    sink.used[k] = hit != 0 && ((fm >> c) & 1ull) == 0;
+  }
+  double* acc = lds + ((size_t)w * kLagN) * 64 + lane;
+#pragma unroll
+  for (int k = 0; k < kLagN; ++k) acc[k * 64] = 0.0;
+  float* stash = reinterpret_cast<float*>(lds + (size_t)kLeanWaves * kLagN * 64) + ((size_t)w * 3 * NC) * 64 + lane;
+  const size_t jn = ((size_t)j * G.N + n) * kLagN;
+  LagDevSink lsink{acc, LG.uh + jn, LG.ut + jn, LG.yl + (size_t)j * G.N + n, chain_ok && w == 0};
+  auto sqf = [&](int k) { return sc[sink.cand[k]] * q; };
+  return nll_lag_chunk<NP, kLagND, UNIT>(ld, len, r_n, a_n, c_n, sqf, w, kLeanWaves, stash, 64, sink, lsink);
+}
+
+// Diagnostic build only (-DEKS_GRID_STAMPS, tools/grid_stamps.py): lane 0 of every wave stamps the 100 MHz real-time
+// counter when it starts and when it ends, with its role (0 head, 1 lean, 2 lag form, 3 exact-entry fallback).
+#ifdef EKS_GRID_STAMPS
+__device__ unsigned long long g_grid_stamps[2048][kLeanWaves][4];
+#define GRID_STAMP_BEGIN()                                                                                   \
+  const unsigned long long grid_t0_ = __builtin_amdgcn_s_memrealtime()
+#define GRID_STAMP_END(role)                                                                                 \
+  do {                                                                                                       \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) {                                                      \
+      unsigned long long* st_ = g_grid_stamps[blockIdx.x][threadIdx.x >> 6];                                 \
+      unsigned xcc_;                                                                                         \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                    \
+      st_[0] = grid_t0_; st_[1] = __builtin_amdgcn_s_memrealtime(); st_[2] = (role); st_[3] = xcc_;          \
+    }                                                                                                        \
+  } while (0)
+#else
+#define GRID_STAMP_BEGIN() do { } while (0)
+#define GRID_STAMP_END(role) do { } while (0)
+#endif
 
 template <bool UNIT>
 __global__ __launch_bounds__(64 * kLeanWaves, 2) void diag_nll_grid_kernel(NllGeom G, LeanGeom LG, DiagModel M, NllWs W,
                                                                          const float* __restrict__ y,
                                                                          const double* __restrict__ rconst,
                                                                          const double* __restrict__ s_cand) {
-  __shared__ float stash[kLeanWaves][4 * kLeanNC][64];
+  __shared__ double lds[kGridLdsDoubles];
+  float (*stash)[4 * kLeanNC][64] = reinterpret_cast<float (*)[4 * kLeanNC][64]>(lds);
+  GRID_STAMP_BEGIN();
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   auto store_full = [&](int j, int ci, int n, const NllElem<float>& o) {
-    const size_t off = ((size_t)j * W.ncp + ci) * G.N + n;
+    const size_t off = ((size_t)j * G.N + n) * W.ncp + ci;
     W.A[off] = o.e.A;
     W.b[off] = o.e.b;
     W.C[off] = o.e.C;
@@ -851,9 +958,13 @@ __global__ __launch_bounds__(64 * kLeanWaves, 2) void diag_nll_grid_kernel(NllGe
     const size_t dd = (size_t)k * G.D * G.D + (size_t)d * (G.D + 1);
     const double q = M.Q[dd], r_n = rconst[n], a_n = M.A[dd], c_n = M.C[dd];
     double sq[kHeadNCL];
+    // candidate c of head wave g is c ngrp4 + g: every wave holds the same mix of slow and fast candidates (with
+    // contiguous groups the wave of the four slowest ran 130 us on C3, twice the others - longer than the lag-form
+    // blocks beside it)
+    auto head_cand = [&](int c) { return c * LG.ngrp4 + g; };
 #pragma unroll
     for (int c = 0; c < kHeadNCL; ++c) {
-      const int ci = min(g * kHeadNCL + c, G.n_cand - 1);
+      const int ci = min(head_cand(c), G.n_cand - 1);
       sq[c] = (G.per_keypoint ? s_cand[(size_t)k * G.n_cand + ci] : s_cand[ci]) * q;
     }
     const int len = min(G.B0, G.T);
@@ -864,20 +975,35 @@ __global__ __launch_bounds__(64 * kLeanWaves, 2) void diag_nll_grid_kernel(NllGe
     if (g == 0) W.xr[n] = out[0].xref;
 #pragma unroll
     for (int c = 0; c < kHeadNCL; ++c) {
-      const int ci = g * kHeadNCL + c;
+      const int ci = head_cand(c);
       if (ci >= G.n_cand) continue;
       store_full(0, ci, n, out[c]);
-      // J of this candidate's converged-entry summaries: c cg / (1 - rho^2) as nll_lean_chunk forms it
+      // the assembly's table: float64 constants, J of the float32 recursion-form summaries (c cg / (1 - rho^2) as
+      // nll_lean_chunk forms it), chunk 0 applied to the prior (its term and the mean it hands on)
       const LeanConst lc = lean_const<UNIT>(r_n, a_n, c_n, sq[c]);
       const float c_cg = UNIT ? lc.cg : (float)c_n * lc.cg;
-      LG.Jc[(size_t)ci * G.N + n] = c_cg / (1.f - lc.rho * lc.rho);
+      double* tb = LG.tab + (size_t)n * kTabFields * W.ncp + ci;
+      const LagConst kc = lag_const<UNIT>(r_n, a_n, c_n, sq[c]);
+      tb[TAB_RHO * W.ncp] = kc.rho;
+      tb[TAB_G * W.ncp] = kc.g;
+      tb[TAB_RG * W.ncp] = kc.rg;
+      tb[TAB_CG * W.ncp] = kc.cg;
+      tb[TAB_LOGS * W.ncp] = kc.logS;
+      tb[TAB_JC * W.ncp] = kc.Jc;
+      tb[TAB_J32 * W.ncp] = (double)(c_cg / (1.f - lc.rho * lc.rho));
+      const double eA = out[c].e.A, eb = out[c].e.b, eeta = out[c].e.eta, eJ = out[c].e.J;
+      const double m = M.m0[(size_t)k * G.D + d], P = M.S0[dd];
+      const double mr = m - (double)out[c].xref, den = 1.0 + eJ * P, inv = 1.0 / den;
+      tb[TAB_LL0 * W.ncp] = out[c].ell - 0.5 * log(den) + (eeta * mr + 0.5 * eeta * eeta * P - 0.5 * eJ * mr * mr) * inv;
+      tb[TAB_B0 * W.ncp] = eA * inv * (mr + P * eeta) + eb;
     }
+    GRID_STAMP_END(0);
     return;
   }
   // ---- lean: (tile, chunk j >= 1), wave = 16 candidates
   const int lb = (int)blockIdx.x - LG.nhead_blocks;
   const int tile = lb % G.ntile, j = 1 + lb / G.ntile;
-  if (w >= LG.ngrp16 || j >= G.ncn) return;
+  if (j >= G.ncn) return;
   const int n_raw = tile * 64 + lane;
   const bool chain_ok = n_raw < G.N;
   const int n = chain_ok ? n_raw : G.N - 1;              // lanes past the last chain shadow it (nothing stored)
@@ -889,6 +1015,64 @@ __global__ __launch_bounds__(64 * kLeanWaves, 2) void diag_nll_grid_kernel(NllGe
                                                         0x7FFFFFFF, 0x00020000),
                       (unsigned)((n - tile * 64) * 4), (unsigned)(G.N * 4)};
   const double* sc = G.per_keypoint ? s_cand + (size_t)k * G.n_cand : s_cand;
+  // ---- round 5: the shared-lag form, when the block's chunk qualifies.  Every wave decides from the same numbers.
+  if (LG.lag_on && (len & 31) == 0 && len >= 64) {
+    const double a1 = UNIT ? 1.0 : a_n, c1 = UNIT ? 1.0 : c_n;
+    const double thr_fast = lag_sq_threshold(r_n, a1, c1, LG.rho_max);
+    // converged entry for every candidate: rho^(2 t0) < 1e-20 <=> |rho| < exp(-23 / t0) <=> s q above its threshold
+    const double thr_qual = lag_sq_threshold(r_n, a1, c1, (double)__expf(-23.f / (float)t0));
+    unsigned long long fm = 0;
+    bool qual = true;
+    for (int c = 0; c < G.n_cand; ++c) {
+      const double sqc = sc[c] * q;
+      if (__all(sqc >= thr_fast)) fm |= 1ull << c;
+      qual = qual && __all(sqc >= thr_qual);
+    }
+    const int nfast = __popcll(fm), nslow = G.n_cand - nfast;
+    if (qual && nfast >= kLagMinFast && nslow <= 8 * kLagMaxNP) {
+      const unsigned long long below = (1ull << lane) - 1ull;
+      const int rk = ((fm >> lane) & 1ull) ? nslow + __popcll(fm & below) : __popcll(~fm & below);
+      const int np = nslow > 8 ? (nslow + 7) / 8 : 1;
+      int res;
+#define EKS_LAG_BODY(NP_) \
+  res = lag_block_body<NP_, UNIT>(G, LG, W, ld, j, n, chain_ok, w, lane, len, q, r_n, a_n, c_n, sc, fm, rk, lds)
+      switch (np) {
+        case 1: EKS_LAG_BODY(1); break;
+        case 2: EKS_LAG_BODY(2); break;
+        case 3: EKS_LAG_BODY(3); break;
+        case 4: EKS_LAG_BODY(4); break;
+        case 5: EKS_LAG_BODY(5); break;
+        default: EKS_LAG_BODY(6); break;
+      }
+#undef EKS_LAG_BODY
+      // flags of this wave's slow candidates (slot k of wave w has place 4 k + w in the list); the fast ones never flag
+      if (lane < G.n_cand && !((fm >> lane) & 1ull) && (rk & 3) == w)
+        LG.flags[((size_t)j * G.ntile + tile) * W.ncp + lane] = res == 2 ? 2 : 0;
+      if (lane < G.n_cand && ((fm >> lane) & 1ull) && (lane & 3) == w)
+        LG.flags[((size_t)j * G.ntile + tile) * W.ncp + lane] = 0;
+      if (w == 0 && lane == 0) {
+        LG.mode[(size_t)j * G.ntile + tile] = 1;
+        LG.fastmask[tile] = fm;                          // (every lag-form block of the tile writes the same mask)
+      }
+      // the four waves' partial lag sums meet: wave w adds up lags 4 w .. 4 w + 3
+      __syncthreads();
+      if (chain_ok) {
+        double* dst = LG.lagc + ((size_t)j * G.N + n) * kLagN;
+#pragma unroll
+        for (int i = 0; i < kLagN / kLeanWaves; ++i) {
+          const int kk = w * (kLagN / kLeanWaves) + i;
+          double v = 0.0;
+#pragma unroll
+          for (int ww = 0; ww < kLeanWaves; ++ww) v += lds[((size_t)ww * kLagN + kk) * 64 + lane];
+          dst[kk] = v;
+        }
+      }
+      GRID_STAMP_END(2);
+      return;
+    }
+  }
+  if (w == 0 && lane == 0) LG.mode[(size_t)j * G.ntile + tile] = 0;
+  if (w >= LG.ngrp16) return;
   // the grid's candidates are dealt to the tile's waves round-robin: slot c of wave w is candidate c ngrp16 + w, so
   // every wave holds the same mix of slow and fast candidates, slowest first (the staged alive phase of
   // nll_lean_chunk then costs every wave the same, a few per cent; contiguous groups left the slowest group's
@@ -917,13 +1101,17 @@ __global__ __launch_bounds__(64 * kLeanWaves, 2) void diag_nll_grid_kernel(NllGe
   };
   // slot c is candidate c stride16 + w: valid while c stride16 + w < n_cand
   const int nvalid = ncand > w ? (ncand - w + stride16 - 1) / stride16 : 0;
-  Sink sink{W, ((size_t)j * W.ncp + w) * G.N + n, (size_t)stride16 * G.N, (size_t)j * G.N + n,
+  Sink sink{W, ((size_t)j * G.N + n) * W.ncp + w, (size_t)stride16, (size_t)j * G.N + n,
             nvalid < kLeanNC ? nvalid : kLeanNC, chain_ok, chain_ok && w == 0};
   const int lean = nll_lean_chunk<kLeanNC, UNIT>(ld, t0, len, r_n, a_n, c_n, sqf, &stash[w][0][lane], 64, sink);
   // flag: 0 lean summary with A = 0 (the usual case) | 2 lean summary with A = rho^len != 0 (own A, J planes) |
   // 1 exact-entry summary (full planes) - anything but 0 sends the (tile, candidate)'s assembly down the sequential walk
-  if (lane == 0) LG.flags[((size_t)j * G.ntile + tile) * LG.ngrp16 + w] = lean == 1 ? 0 : (lean == 2 ? 2 : 1);
-  if (lean) return;
+  if (lane < kLeanNC && cand_of(lane) < ncand)
+    LG.flags[((size_t)j * G.ntile + tile) * W.ncp + cand_of(lane)] = lean == 1 ? 0 : (lean == 2 ? 2 : 1);
+  if (lean) {
+    GRID_STAMP_END(1);
+    return;
+  }
   // ---- the chunk does not qualify for the converged-entry summary: exact entry, kHeadNCL candidates at a time
   for (int h = 0; h < kLeanNC / kHeadNCL; ++h) {
     double sq[kHeadNCL];
@@ -939,98 +1127,243 @@ __global__ __launch_bounds__(64 * kLeanWaves, 2) void diag_nll_grid_kernel(NllGe
       if (ci < G.n_cand) store_full(j, ci, n, o4[c]);
     }
   }
+  GRID_STAMP_END(3);
 }
 
-// assembly of the grid kernel's summaries: as diag_nll_assemble_par_kernel, reading the compact planes; a chain with
-// an exact-entry summary past chunk 0 (flagged) takes the sequential walk over a getter that knows both forms.
-template <int kAsmWaves, int kAsmPer>
-__global__ __launch_bounds__(64 * kAsmWaves) void diag_nll_assemble_lean_kernel(NllGeom G, LeanGeom LG, DiagModel M,
-                                                                               NllWs W, double* __restrict__ nll) {
-  extern __shared__ double dyn[];                  // b_next[ncn][64] | part[kAsmWaves][64]
-  __shared__ int seq;                              // some chunk of this (tile, candidate) has an exact-entry summary
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tile = blockIdx.x % G.ntile, ci = blockIdx.x / G.ntile;
-  const int n = tile * 64 + lane;
-  const bool live = n < G.N;
-  double* bnext = dyn;
-  double* part = dyn + (size_t)G.ncn * 64;
-  const int g16 = ci % LG.ngrp16;                  // the lean wave that owns this candidate (dealt round-robin)
-  if (threadIdx.x == 0) seq = 0;
-  __syncthreads();
-  const int k = live ? n / G.D : 0, d = live ? n - k * G.D : 0;
+// ---- assembly of the grid kernel's summaries, argmin included (round 5) ---------------------------------------------
+// A converged-entry summary has A = 0, so chunk j's term of the log-likelihood needs only the mean chunk j - 1 hands
+// on:  ll = ll_0(prior) + sum_{j >= 1} [ ell_j + eta_j mr_j - J mr_j^2 / 2 ],  mr_j = b_{j-1} - xref_j.
+// Block = KEYPOINT, wave = (chain d of the keypoint, group of consecutive chunks), LANE = CANDIDATE:
+//   * a recursion-form summary is one coalesced row of the [j][N][ncp] planes;
+//   * where a (chunk, tile) took the shared-lag form, the chunk's lag sums and first / last inputs are per CHAIN, i.e.
+//     wave-uniform: scalar loads, and every fast candidate's summary is formed from them in float64 (lag_summary's
+//     arithmetic with the coefficients in SGPRs);
+//   * the wave walks its chunks in order, so the mean a chunk hands on stays in a register;
+//   * the waves' sums meet in LDS: wave 0 adds them in a fixed order, writes nll[k][0 .. n_cand) as one row and takes
+//     the argmin across its lanes (first minimum, numpy.argmin semantics) - no separate argmin launch, no exchange
+//     between blocks;
+//   * a candidate with a flagged summary anywhere in the sequence (exact-entry summary, or a pole whose rho^t outlives
+//     its chunk) is walked in order, from the prior, by the first wave of each chain (nll_assemble).
+constexpr int kAsmKpWaves = 16;
+constexpr int kAsmBatch = 8;            // chunks a wave stages and evaluates at a time
+
+struct GridAsmOut {
+  const double* s_cand;
+  double* s_out;         // [K] s_cand at the argmin (may be null: no argmin)
+  int32_t* idx_out;      // [K] (may be null)
+};
+
+// a chunk's lag data as a wave keeps it in LDS (one copy per wave, read back with broadcast reads)
+struct LagStage {
+  double c[kLagN];
+  float uh[kLagN], ut[kLagN];
+  float yl, pad;
+};
+
+// lag_summary's arithmetic for one candidate per lane, the chunk's data the same for every lane (LDS broadcast reads);
+// inv = 1 / (1 - rho^2) and clog = log 2 pi + log S are the lane's constants
+template <bool UNIT>
+__device__ __forceinline__ void lag_summary_staged(const LagConst& k, double inv, double clog, double a_d, double ic, int len,
+                                                   const LagStage& L, double& b, double& eta, double& ell) {
+  const double rho = k.rho;
+  double h = L.c[kLagN - 1];
+#pragma unroll
+  for (int i = kLagN - 2; i >= 1; --i) h = L.c[i] + rho * h;
+  double dl = 0.0, z = 0.0;
+#pragma unroll
+  for (int i = 0; i < kLagN; ++i) dl = rho * dl + (double)L.ut[i];
+#pragma unroll
+  for (int i = kLagN - 1; i >= 0; --i) z = (double)L.uh[i] + rho * z;
+  const double s0 = (L.c[0] + 2.0 * rho * h - rho * rho * dl * dl) * inv;
+  eta = k.cg * z * inv;
+  b = UNIT ? (double)L.yl - k.rg * dl : a_d * (((double)L.yl - dl) * ic + (1.0 - k.rg) * ic * dl);
+  ell = -0.5 * ((double)len * clog + k.g * s0);
+}
+template <bool UNIT>
+__device__ __forceinline__ double lag_out_mean_staged(const LagConst& k, double a_d, double ic, const LagStage& L) {
+  double dl = 0.0;
+#pragma unroll
+  for (int i = 0; i < kLagN; ++i) dl = k.rho * dl + (double)L.ut[i];
+  return UNIT ? (double)L.yl - k.rg * dl : a_d * (((double)L.yl - dl) * ic + (1.0 - k.rg) * ic * dl);
+}
+
+template <bool UNIT>
+__global__ __launch_bounds__(64 * kAsmKpWaves) void diag_nll_assemble_kp_kernel(NllGeom G, LeanGeom LG, DiagModel M, NllWs W,
+                                                                               GridAsmOut O, int ncgw, int cpw,
+                                                                               double* __restrict__ nll) {
+  __shared__ LagStage stage[kAsmKpWaves][kAsmBatch + 1];           // [.][kAsmBatch]: the chunk before the wave's first
+  __shared__ double accs[kAsmKpWaves][64];
+  __shared__ int flg[kAsmKpWaves][64];
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int k = blockIdx.x;
+  const int d = wv / ncgw, cg = wv - d * ncgw;                    // (blockDim = D * ncgw waves)
+  const int n = k * G.D + d, tile = n >> 6;
+  const size_t N = (size_t)G.N, ncp = (size_t)W.ncp;
   const size_t dd = (size_t)k * G.D * G.D + (size_t)d * (G.D + 1);
-  double ll0 = 0.0;
-  // everything a wave will need is requested BEFORE the block's barrier: the entry state of chunk j is the exit
-  // state b of chunk j - 1 (through LDS), the rest of chunk j's summary does not depend on it (the second round
-  // trip of loads behind the barrier was a quarter of this launch)
-  double ell_r[kAsmPer];
-  float eta_r[kAsmPer], xr_r[kAsmPer];
-  const double Jc = live ? (double)LG.Jc[(size_t)ci * G.N + n] : 0.0;
+  const double a_n = M.A[dd], c_n = M.C[dd], ic = 1.0 / c_n;
+  const bool cvalid = lane < G.n_cand;
+  const unsigned long long fm = LG.lag_on ? LG.fastmask[tile] : 0ull;   // (garbage unless some chunk of the tile has mode 1:
+  const bool fast = ((fm >> lane) & 1ull) != 0;                          //  only ever used together with a chunk's mode)
+  const double* tb = LG.tab + (size_t)n * kTabFields * ncp + lane;
+  LagConst kc;
+  kc.rho = tb[TAB_RHO * ncp];
+  kc.g = tb[TAB_G * ncp];
+  kc.rg = tb[TAB_RG * ncp];
+  kc.cg = tb[TAB_CG * ncp];
+  kc.logS = tb[TAB_LOGS * ncp];
+  kc.Jc = tb[TAB_JC * ncp];
+  const double J32 = tb[TAB_J32 * ncp];
+  const double inv = 1.0 / (1.0 - kc.rho * kc.rho), clog = kLog2Pi + kc.logS;
+  const int j0 = 1 + cg * cpw, j1 = min(G.ncn, j0 + cpw);
+  auto chunk_len = [&](int j) { return min(G.BN, G.T - (G.B0 + (j - 1) * G.BN)); };
+  auto lag_chunk = [&](int j) { return LG.lag_on && LG.mode[(size_t)j * G.ntile + tile] != 0; };   // (wave-uniform)
+  // this wave's copy of chunk j's lag data: 16 lanes bring the lag sums, 33 the first / last inputs and the last
+  // observation (one request each; the values come back to every lane by broadcast reads)
+  auto stage_chunk = [&](int j, LagStage& S) {
+    const size_t jn = ((size_t)j * N + n) * kLagN;
+    if (lane < kLagN) S.c[lane] = LG.lagc[jn + lane];
+    if (lane < kLagN) S.uh[lane] = LG.uh[jn + lane];
+    else if (lane < 2 * kLagN) S.ut[lane - kLagN] = LG.ut[jn + lane - kLagN];
+    else if (lane == 2 * kLagN) S.yl = LG.yl[(size_t)j * N + n];
+  };
+  double acc = 0.0;
+  int flagor = 0;
+  if (j0 < j1) {
+    double m_in = 0.0;
+    for (int jb = j0; jb < j1; jb += kAsmBatch) {
+      // ---- everything the batch needs is requested before anything is evaluated
+      float b_r[kAsmBatch], eta_r[kAsmBatch], xr_r[kAsmBatch];
+      double ell_r[kAsmBatch];
+      int fl_r[kAsmBatch];
+      bool lag_r[kAsmBatch];
+      const bool first = jb == j0;
+      const bool lag_prev = first && j0 > 1 && lag_chunk(j0 - 1);
+      if (lag_prev) stage_chunk(j0 - 1, stage[wv][kAsmBatch]);
+      float b_prev = 0.f;
+      if (first && j0 > 1) b_prev = W.b[((size_t)(j0 - 1) * N + n) * ncp + lane];
 #pragma unroll
-  for (int q = 0; q < kAsmPer; ++q) {
-    const int j = w + q * kAsmWaves;
-    ell_r[q] = 0.0;
-    eta_r[q] = 0.f;
-    xr_r[q] = 0.f;
-    if (j >= G.ncn) continue;                      // (wave-uniform)
-    if (j > 0 && LG.flags[((size_t)j * G.ntile + tile) * LG.ngrp16 + g16] != 0) seq = 1;   // (wave-uniform)
-    if (!live) continue;
-    const size_t o = ((size_t)j * W.ncp + ci) * G.N + n;
-    if (j == 0) {
-      const double A = W.A[o], b = W.b[o], eta = W.eta[o], J = W.J[o], ell = W.ell[o];
-      const double xr = (double)W.xr[n];
-      const double m = M.m0[(size_t)k * G.D + d], P = M.S0[dd];
-      const double mr = m - xr, den = 1.0 + J * P, inv = 1.0 / den;
-      ll0 = ell - 0.5 * log(den) + (eta * mr + 0.5 * eta * eta * P - 0.5 * J * mr * mr) * inv;
-      bnext[lane] = A * inv * (mr + P * eta) + b;
-    } else {
-      bnext[(size_t)j * 64 + lane] = W.b[o];
-      eta_r[q] = W.eta[o];
-      ell_r[q] = W.ell[o];
-      xr_r[q] = W.xr[(size_t)j * G.N + n];
-    }
-  }
-  __syncthreads();
-  const bool sequential = seq != 0;
-  double acc = (w == 0) ? ll0 : 0.0;
-  if (!sequential && live) {
-#pragma unroll
-    for (int q = 0; q < kAsmPer; ++q) {
-      const int j = w + q * kAsmWaves;
-      if (j < 1 || j >= G.ncn) continue;
-      const double mr = bnext[(size_t)(j - 1) * 64 + lane] - (double)xr_r[q];
-      acc += ell_r[q] + (double)eta_r[q] * mr - 0.5 * Jc * mr * mr;
-    }
-  }
-  part[w * 64 + lane] = acc;
-  __syncthreads();
-  if (w != 0) return;
-  double tot = 0.0;
-  if (live) {
-    if (sequential) {                              // rare: the generic sequential walk
-      auto get = [&](int j, Elem<double>& e, double& ell, double& xr) {
-        const size_t o = ((size_t)j * W.ncp + ci) * G.N + n;
-        xr = (double)W.xr[(size_t)j * G.N + n];
-        e.b = W.b[o]; e.eta = W.eta[o]; ell = W.ell[o];
-        const int fl = j == 0 ? 1 : LG.flags[((size_t)j * G.ntile + tile) * LG.ngrp16 + g16];
-        if (fl == 1) {
-          e.A = W.A[o]; e.C = W.C[o]; e.J = W.J[o];
-        } else if (fl == 2) {
-          e.A = W.A[o]; e.C = -1.0; e.J = W.J[o];
+      for (int q = 0; q < kAsmBatch; ++q) {
+        const int j = jb + q;
+        lag_r[q] = false;
+        b_r[q] = eta_r[q] = xr_r[q] = 0.f;
+        ell_r[q] = 0.0;
+        fl_r[q] = 0;
+        if (j >= j1) continue;                                      // (wave-uniform)
+        const size_t row = ((size_t)j * N + n) * ncp + lane;
+        lag_r[q] = lag_chunk(j);
+        if (lag_r[q]) stage_chunk(j, stage[wv][q]);
+        xr_r[q] = W.xr[(size_t)j * N + n];
+        fl_r[q] = LG.flags[((size_t)j * G.ntile + tile) * ncp + lane];
+        b_r[q] = W.b[row];
+        eta_r[q] = W.eta[row];
+        ell_r[q] = W.ell[row];
+      }
+      if (first) {                                                  // the mean entering the wave's first chunk
+        if (j0 == 1) {
+          m_in = tb[TAB_B0 * ncp];
+          acc = tb[TAB_LL0 * ncp];
         } else {
-          e.A = 0.0; e.C = -1.0; e.J = (double)LG.Jc[(size_t)ci * G.N + n];
+          m_in = (double)b_prev;
+          if (lag_prev) {
+            const double bl = lag_out_mean_staged<UNIT>(kc, a_n, ic, stage[wv][kAsmBatch]);
+            m_in = fast ? bl : m_in;
+          }
         }
-      };
-      tot = nll_assemble<double>(G.ncn, M.m0[(size_t)k * G.D + d], M.S0[dd], get);
-    } else {
+      }
 #pragma unroll
-      for (int q = 0; q < kAsmWaves; ++q) tot += part[q * 64 + lane];
+      for (int q = 0; q < kAsmBatch; ++q) {
+        const int j = jb + q;
+        if (j >= j1) continue;
+        double b = (double)b_r[q], eta = (double)eta_r[q], ell = ell_r[q], J = J32;
+        bool lagged = false;
+        if (lag_r[q]) {
+          double bl, el, ll;
+          lag_summary_staged<UNIT>(kc, inv, clog, a_n, ic, chunk_len(j), stage[wv][q], bl, el, ll);
+          lagged = fast;
+          b = fast ? bl : b;
+          eta = fast ? el : eta;
+          ell = fast ? ll : ell;
+          J = fast ? kc.Jc : J;
+        }
+        flagor |= lagged ? 0 : fl_r[q];
+        const double mr = m_in - (double)xr_r[q];
+        acc += ell + eta * mr - 0.5 * J * mr * mr;
+        m_in = b;
+        __builtin_amdgcn_sched_barrier(0);       // (one chunk's broadcast reads and Horner chains at a time: registers)
+      }
     }
   }
-  for (int off = 1; off < G.D; off <<= 1) tot += __shfl_xor(tot, off);   // the keypoint's D chains
-  if (!live || d != 0) return;
-  const double v = -tot;
-  nll[(size_t)k * G.n_cand + ci] = isfinite(v) ? v : 1e12;                // eks/core.py:650
+  accs[wv][lane] = acc;
+  flg[wv][lane] = cvalid ? flagor : 0;
+  __syncthreads();
+  // ---- flagged candidates: the first wave of each chain walks them in order, from the prior
+  if (cg == 0) {
+    int any = 0;
+    for (int q = 0; q < ncgw; ++q) any |= flg[d * ncgw + q][lane];
+    if (__any(any != 0)) {
+      double tot = 0.0;
+      if (any != 0) {
+        auto get = [&](int j, Elem<double>& e, double& ell, double& xr) {
+          const size_t o = ((size_t)j * N + n) * ncp + lane;
+          xr = (double)W.xr[(size_t)j * N + n];
+          if (fast && j > 0 && lag_chunk(j)) {
+            const size_t jn = ((size_t)j * N + n) * kLagN;
+            double cc[kLagN];
+            float hh[kLagN], tt[kLagN];
+#pragma unroll
+            for (int i = 0; i < kLagN; ++i) {
+              cc[i] = LG.lagc[jn + i];
+              hh[i] = LG.uh[jn + i];
+              tt[i] = LG.ut[jn + i];
+            }
+            lag_summary<kLagN, UNIT>(kc, a_n, c_n, chunk_len(j), cc, hh, tt, LG.yl[(size_t)j * N + n], e.b, e.eta, ell);
+            e.A = 0.0; e.C = -1.0; e.J = kc.Jc;
+            return;
+          }
+          e.b = W.b[o]; e.eta = W.eta[o]; ell = W.ell[o];
+          const int fl = j == 0 ? 1 : LG.flags[((size_t)j * G.ntile + tile) * ncp + lane];
+          if (fl == 1) {
+            e.A = W.A[o]; e.C = W.C[o]; e.J = W.J[o];
+          } else if (fl == 2) {
+            e.A = W.A[o]; e.C = -1.0; e.J = W.J[o];
+          } else {
+            e.A = 0.0; e.C = -1.0; e.J = J32;
+          }
+        };
+        tot = nll_assemble<double>(G.ncn, M.m0[(size_t)k * G.D + d], M.S0[dd], get);
+      }
+      // the walk's total replaces the chain's chunk-parallel sums for those candidates
+      if (any != 0) {
+        accs[wv][lane] = tot;
+        for (int q = 1; q < ncgw; ++q) accs[d * ncgw + q][lane] = 0.0;
+      }
+    }
+  }
+  __syncthreads();
+  if (wv != 0) return;
+  double tot = 0.0;
+  const int nw = G.D * ncgw;
+  for (int q = 0; q < nw; ++q) tot += accs[q][lane];              // chains in order, each chain's chunk groups in order
+  double v = -tot;
+  v = isfinite(v) ? v : 1e12;                                     // eks/core.py:650
+  if (cvalid) nll[(size_t)k * G.n_cand + lane] = v;
+  if (O.s_out == nullptr) return;
+  constexpr int kNone = 0x7FFFFFFF;
+  int best = cvalid ? lane : kNone;
+  double bv = v;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double ov = __shfl_xor(bv, off);
+    const int oi = __shfl_xor(best, off);
+    if (oi != kNone && (best == kNone || ov < bv || (ov == bv && oi < best))) {
+      bv = ov;
+      best = oi;
+    }
+  }
+  if (lane == 0) {
+    O.s_out[k] = O.s_cand[best];
+    if (O.idx_out) O.idx_out[k] = best;
+  }
 }
 
 // may the gradient evaluation take the single-launch kernel (diag_nll_grad_fused_kernel)?  One value of s
@@ -1075,7 +1408,7 @@ static int lean_geometry(int T, int N, int n_cand, int* b0_out, int* bn_out) {
   long nch = (512 * rounds - nhead) / ntile;
   if (nch < 1) nch = 1;
   long bn = (rest + nch - 1) / nch;
-  bn = (bn + 15) / 16 * 16;
+  bn = (bn + 31) / 32 * 32;            // whole 32-frame sets (the lag form's unit)
   if (bn < kLeanChunkMin) bn = kLeanChunkMin;
   if (knob_set(KNOB_NLL_CHUNK)) bn = target < 64 ? 64 : (target + 15) / 16 * 16;      // (A/B runs and tests)
   *b0_out = b0;
@@ -1088,11 +1421,11 @@ static int lean_geometry(int T, int N, int n_cand, int* b0_out, int* bn_out) {
 static bool lean_grid_ok(int T, int N, int D, int n_cand) {
   if (knob_int(KNOB_NLL_LEGACY, 0)) return false;
   // (a lean block is kLeanWaves waves of kLeanNC candidates: up to 64 candidates; longer grids keep the general kernel)
-  if (n_cand < kLeanNC || n_cand > kLeanNC * kLeanWaves || N <= 32 || (D & (D - 1)) != 0 || D > 64) return false;
+  if (n_cand < kLeanNC || n_cand > kLeanNC * kLeanWaves || N <= 32 || (D & (D - 1)) != 0 || D > kAsmKpWaves) return false;
   int b0, bn;
   const int ncn = lean_geometry(T, N, n_cand, &b0, &bn);
   if (ncn < 2 || (long)(bn > b0 ? bn : b0) * N * 4 >= (1L << 31)) return false;
-  return ncn <= kAsmWaves * kAsmPer && ((size_t)ncn + kAsmWaves) * 64 * sizeof(double) <= 60 * 1024;
+  return true;
 }
 
 static NllGeom make_geom(int T, int N, int D, int n_cand, int per_keypoint, bool grad, int ncl) {
@@ -1186,9 +1519,26 @@ int32_t* nll_ws_tickets(void* ws, int T, int N, int n_cand) {
   return reinterpret_cast<int32_t*>(tail + align_up((size_t)N * sizeof(int32_t), 256));
 }
 
+static int diag_nll_impl(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M,
+                         const double* s_cand, int n_cand, int per_keypoint, double* nll, double* dnll,
+                         void* ws, size_t ws_bytes, hipStream_t st, const AdamFuse* fuse, double* s_out, int32_t* idx_out,
+                         bool* argmin_done);
+
 int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M,
              const double* s_cand, int n_cand, int per_keypoint, double* nll, double* dnll,
-             void* ws, size_t ws_bytes, hipStream_t st, const AdamFuse* fuse) {
+             void* ws, size_t ws_bytes, hipStream_t st, const AdamFuse* fuse, double* s_out, int32_t* idx_out) {
+  bool done = false;
+  const int rc = diag_nll_impl(d, y, rconst, M, s_cand, n_cand, per_keypoint, nll, dnll, ws, ws_bytes, st, fuse, s_out,
+                               idx_out, &done);
+  if (rc != EKS_OK || !s_out || done) return rc;
+  if (per_keypoint) return EKS_ERR_UNSUPPORTED;      // (the separate argmin gathers from one shared grid)
+  return argmin_s(d.n_keypoints, n_cand, nll, s_cand, s_out, idx_out, st);
+}
+
+static int diag_nll_impl(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M,
+                         const double* s_cand, int n_cand, int per_keypoint, double* nll, double* dnll,
+                         void* ws, size_t ws_bytes, hipStream_t st, const AdamFuse* fuse, double* s_out, int32_t* idx_out,
+                         bool* argmin_done) {
   const int T = d.n_frames, D = d.state_dim, K = d.n_keypoints, N = K * D;
   if (ws_bytes < diag_nll_workspace_bytes(T, N, n_cand)) return EKS_ERR_WORKSPACE;
   const bool grad = dnll != nullptr;
@@ -1240,11 +1590,30 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
     W.dell = nullptr;
     LG.flags = reinterpret_cast<int32_t*>(p + db);          // (the gradient's plane: unused on this path)
     p += 2 * db;
-    float** planes[7] = {&W.A, &W.b, &W.C, &W.eta, &W.J, &LG.Jc, &W.xr};
+    float* unused_plane = nullptr;
+    float** planes[7] = {&W.A, &W.b, &W.C, &W.eta, &W.J, &unused_plane, &W.xr};
     for (int i = 0; i < 7; ++i) *planes[i] = reinterpret_cast<float*>(p + i * fl);
     W.dA = W.db = W.dC = W.deta = W.dJ = nullptr;
-    if ((size_t)G.ncn * G.ntile * LG.ngrp16 * sizeof(int32_t) > db || (long)G.BN * N * 4 >= (1L << 31))
-      return EKS_ERR_WORKSPACE;
+    // [flags : ncn x ntile x ncp ints][mode : ncn x ntile ints][fast masks : ntile x 8 B] in the gradient's plane
+    const size_t flag_bytes = align_up((size_t)G.ncn * G.ntile * W.ncp * sizeof(int32_t), 256);
+    const size_t mode_bytes = align_up((size_t)G.ncn * G.ntile * sizeof(int32_t), 256);
+    if (flag_bytes + mode_bytes + (size_t)G.ntile * 8 > db || (long)G.BN * N * 4 >= (1L << 31)) return EKS_ERR_WORKSPACE;
+    LG.mode = reinterpret_cast<int32_t*>(p - db + flag_bytes);
+    LG.fastmask = reinterpret_cast<unsigned long long*>(p - db + flag_bytes + mode_bytes);
+    // the shared-lag form (round 5): its planes are the four float planes this path does not use (the lag sums are
+    // 16 float64 per chain and chunk: they fit a float plane of ncp >= 32 candidates)
+    LG.lag_on = !per_keypoint && W.ncp >= 2 * kLagN && !knob_int(KNOB_NLL_NOLAG, 0);
+    LG.rho_max = lag_rho_max(kLagN);
+    LG.uh = reinterpret_cast<float*>(p + 7 * fl);
+    LG.ut = reinterpret_cast<float*>(p + 8 * fl);
+    LG.yl = reinterpret_cast<float*>(p + 9 * fl);
+    LG.lagc = reinterpret_cast<double*>(p + 10 * fl);
+    // the assembly's table behind the float planes
+    {
+      const size_t tab_bytes = align_up((size_t)N * kTabFields * W.ncp * sizeof(double), 256);
+      LG.tab = reinterpret_cast<double*>(p + 11 * fl);
+      if (2 * db + 11 * fl + tab_bytes + adam_extra_bytes(N) > ws_bytes) return EKS_ERR_WORKSPACE;
+    }
     {
       ProfScope ps("diag_nll_summarize", st);
       const dim3 grid((unsigned)(LG.nhead_blocks + G.ntile * (G.ncn - 1))), block(64 * kLeanWaves);
@@ -1254,18 +1623,19 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
         hipLaunchKernelGGL(diag_nll_grid_kernel<false>, grid, block, 0, st, G, LG, M, W, y, rconst, s_cand);
     }
     ProfScope ps2("diag_nll_assemble", st);
-    // waves per assembly block (measured on C3: 16 waves 13.9 us, 8: 11.9, 4: 15.8)
-    const int aw = knob_int(KNOB_NLL_ASM_WAVES, 8);
-#define EKS_ASM_LEAN(WV)                                                                                         \
-  hipLaunchKernelGGL((diag_nll_assemble_lean_kernel<WV, 128 / WV>), dim3((unsigned)(G.ntile * n_cand)), dim3(64 * WV), \
-                     ((size_t)G.ncn + WV) * 64 * sizeof(double), st, G, LG, M, W, nll)
-    if (aw == 4)
-      EKS_ASM_LEAN(4);
-    else if (aw == 8)
-      EKS_ASM_LEAN(8);
+    if (s_out != nullptr && per_keypoint) return EKS_ERR_UNSUPPORTED;
+    const GridAsmOut AO{s_cand, s_out, idx_out};
+    // waves of a keypoint's block: its D chains x groups of consecutive chunks (at most kAsmKpWaves in all)
+    int ncgw = kAsmKpWaves / D;
+    if (ncgw > G.ncn - 1) ncgw = G.ncn - 1;
+    const int cpw = (G.ncn - 1 + ncgw - 1) / ncgw;
+    ncgw = (G.ncn - 1 + cpw - 1) / cpw;
+    const dim3 agrid((unsigned)K), ablock((unsigned)(64 * D * ncgw));
+    if (d.flags & EKS_FLAG_UNIT_AC)
+      hipLaunchKernelGGL(diag_nll_assemble_kp_kernel<true>, agrid, ablock, 0, st, G, LG, M, W, AO, ncgw, cpw, nll);
     else
-      EKS_ASM_LEAN(16);
-#undef EKS_ASM_LEAN
+      hipLaunchKernelGGL(diag_nll_assemble_kp_kernel<false>, agrid, ablock, 0, st, G, LG, M, W, AO, ncgw, cpw, nll);
+    *argmin_done = s_out != nullptr;
     return hip_status(hipGetLastError());
   }
   // (the tree cannot take converged-entry summaries: they are only valid in sequential order)
@@ -1371,6 +1741,11 @@ int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const Di
 
 }  // namespace eks
 
+#ifdef EKS_GRID_STAMPS
+extern "C" int eks_debug_grid_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(eks::g_grid_stamps), sizeof(eks::g_grid_stamps));
+}
+#endif
 #ifdef EKS_GF_STAMPS
 extern "C" int eks_debug_gf_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(eks::g_gf_stamps), sizeof(eks::g_gf_stamps));

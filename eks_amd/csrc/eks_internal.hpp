@@ -30,7 +30,7 @@ enum Knob {
   KNOB_SMOOTH_UNFUSED, KNOB_SUMMARIZE_REVERSE, KNOB_REPLAY_FORWARD, KNOB_REPLAY_RECOMPUTE, KNOB_SCAN_CH,
   KNOB_SMOOTH_TILE, KNOB_DENSE_CHUNK, KNOB_NLL_NCL, KNOB_NLL_CHUNK, KNOB_NLL_CHUNK0, KNOB_NLL_WPB,
   KNOB_NLL_EXACT_ENTRY, KNOB_NLL_ASSEMBLE_SEQ, KNOB_DENSE_LEGACY, KNOB_NLL_GRAD_UNFUSED, KNOB_NLL_GRAD_CHUNK,
-  KNOB_DENSE_TREE_SCAN, KNOB_DENSE_DUAL_GRAD, KNOB_NLL_LEGACY, KNOB_MED_ROWS, KNOB_NLL_ASM_WAVES, KNOB_DW_CHUNK, KNOB_ADAM_PER_ITERATION, KNOB_MED_FINISH_THREADS, KNOB_MED_BRACKET_THREADS, KNOB_COUNT
+  KNOB_DENSE_TREE_SCAN, KNOB_DENSE_DUAL_GRAD, KNOB_NLL_LEGACY, KNOB_MED_ROWS, KNOB_NLL_ASM_WAVES, KNOB_DW_CHUNK, KNOB_ADAM_PER_ITERATION, KNOB_MED_FINISH_THREADS, KNOB_MED_BRACKET_THREADS, KNOB_NLL_NOLAG, KNOB_COUNT
 };
 bool knob_set(Knob k);               // the variable exists
 int knob_int(Knob k, int dflt);      // its integer value, or dflt when unset
@@ -78,7 +78,8 @@ size_t diag_nll_workspace_bytes(int T, int N, int n_cand);
 struct AdamFuse;   // eks_adam.hpp
 int diag_nll(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M,
              const double* s_cand, int n_cand, int per_keypoint, double* nll, double* dnll,
-             void* ws, size_t ws_bytes, hipStream_t st, const AdamFuse* fuse = nullptr);
+             void* ws, size_t ws_bytes, hipStream_t st, const AdamFuse* fuse = nullptr, double* s_out = nullptr,
+             int32_t* idx_out = nullptr);   // s_out: also the argmin over the candidates (eks_nll_argmin)
 bool diag_nll_grad_tree(int T, int K, int D);
 bool diag_nll_adam_persist_ok(int T, int K, int D, int n_blocks);
 int diag_nll_adam_persist(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M, int n_iters,

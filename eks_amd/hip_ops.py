@@ -309,6 +309,34 @@ def nll(y, rconst, m0, S0, A, C, Q, s_cand, per_keypoint: bool = False, want_gra
     return (out, grad) if want_grad else out
 
 
+def nll_argmin(y, rconst, m0, S0, A, C, Q, s_cand, flags: int = 0):
+    """eks_nll_argmin: the grid search in one call - the NLL table (K, n_cand), s at each keypoint's argmin and the
+    int32 indices (the scalar-chain grid kernels take the argmin inside the table's assembly)."""
+    lib = _lib.load()
+    T, K, O = y.shape
+    D = m0.shape[-1]
+    y = _chk(y, torch.float32, 'y')
+    rconst = _chk(rconst, torch.float64, 'rconst', (K, O))
+    m0 = _chk(m0, torch.float64, 'm0', (K, D))
+    S0 = _chk(S0, torch.float64, 'S0', (K, D, D))
+    A = _chk(A, torch.float64, 'A', (K, D, D))
+    C = _chk(C, torch.float64, 'C', (K, O, D))
+    Q = _chk(Q, torch.float64, 'Q', (K, D, D))
+    s_cand = _chk(s_cand, torch.float64, 's_cand')
+    if s_cand.dim() != 1:
+        raise ValueError('s_cand must be (n_cand,)')
+    n_cand = s_cand.shape[0]
+    d = _dims(K, T, D, O, flags)
+    out = torch.empty((K, n_cand), dtype=torch.float64, device=y.device)
+    s_out = torch.empty(K, dtype=torch.float64, device=y.device)
+    idx = torch.empty(K, dtype=torch.int32, device=y.device)
+    ws = _workspace(lib.eks_nll_workspace_bytes(ctypes.byref(d), n_cand), y.device)
+    rc = lib.eks_nll_argmin(ctypes.byref(d), _ptr(y), _ptr(rconst), _ptr(m0), _ptr(S0), _ptr(A), _ptr(C), _ptr(Q),
+                            _ptr(s_cand), n_cand, _ptr(out), _ptr(s_out), _ptr(idx), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, 'eks_nll_argmin')
+    return out, s_out, idx
+
+
 def argmin_s(nll_kc, s_cand):
     lib = _lib.load()
     K, n_cand = nll_kc.shape

@@ -115,6 +115,17 @@ int eks_np_nanstd_rows(int32_t n_rows, int32_t n_cols, const float* x, const int
 int eks_argmin_s(int32_t n_keypoints, int32_t n_cand, const double* nll, const double* s_cand,
                  double* s_out, int32_t* idx_out, eks_stream_t stream);
 
+/* ---- the grid search in one call: eks_nll (value only) followed by eks_argmin_s, as ONE entry point so that the
+ * scalar-chain grid kernels can take the argmin inside the assembly of the table (the block that finishes a tile of
+ * keypoints last does it: no separate launch).  This is the smoothing-parameter search of BASELINE.json config 3
+ * (the reference's own search, eks/core.py:562-699, is the Adam loop below).  Arguments as eks_nll (per_keypoint = 0)
+ * and eks_argmin_s; nll [K][n_cand] is still written in full.  Shapes the fused kernels do not cover run the two
+ * steps one after the other - the results are the same either way.  workspace: eks_nll_workspace_bytes. ------------ */
+int eks_nll_argmin(const eks_dims_t* dims, const float* y, const double* rconst, const double* m0,
+                   const double* S0, const double* A, const double* C, const double* Q,
+                   const double* s_cand, int32_t n_cand, double* nll, double* s_out, int32_t* idx_out,
+                   void* workspace, size_t workspace_bytes, eks_stream_t stream);
+
 /* ---- one Adam iteration on u = log s for every block of keypoints, with the reference's
  * control flow (eks/core.py:652-681 singletons, :509-549 blocks): L_b = sum of member nll,
  * g_b = lr * sum of member dnll (zero where u is outside [lo, hi], as jnp.clip differentiates),

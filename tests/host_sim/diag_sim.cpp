@@ -232,3 +232,171 @@ extern "C" int sim_diag_nll_lean(int T, int N, int D, int B0, int BN, int unit, 
   else run_nll_lean<false>(T, N, D, B0, BN, y, rconst, M, s_cand, n_cand, nll, n_lean);
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// round 5: the shared-lag form of the grid kernel (eks_nll_lag.hpp).  A "block" is one chain here: the candidates whose
+// steady-state pole is below lag_rho_max are summarised from the chunk's lag sums (lag_summary, float64), the others
+// are dealt to four "waves" that run nll_lag_chunk with NP pairs each and take turns at the lag products.  Chunks
+// that do not qualify (too early in the sequence, a length that is not a multiple of 32, fewer than 16 fast
+// candidates) take the round-4 path.  n_lag_out: (chain, chunk) units that took the lag path.
+// ---------------------------------------------------------------------------------------------
+#include "eks_nll_lag.hpp"
+
+template <bool UNIT, int NP, typename SQW, typename PUT>
+static int lag_block(const RowsByPointer& ld, int len, double r, double a, double c, const SQW& sqw, LagKeep<kLagN>* keep,
+                     const PUT& put) {
+  int worst = 1;
+  for (int w = 0; w < 4; ++w) {
+    float stash[6 * NP];
+    LeanOut<2 * NP> out;
+    for (int k = 0; k < 2 * NP; ++k) out.A[k] = 0.f, out.J[k] = 0.f;
+    auto sq = [&](int k) { return sqw(w, k); };
+    const int res = nll_lag_chunk<NP, kLagND, UNIT>(ld, len, r, a, c, sq, w, 4, stash, 1, out, keep[w]);
+    worst = res > worst ? res : worst;
+    for (int k = 0; k < 2 * NP; ++k) put(w, k, res, out);
+  }
+  return worst;
+}
+
+template <bool UNIT>
+static void run_nll_lag(int T, int N, int D, int B0, int BN, const float* y, const double* rconst, const DiagModel& M,
+                        const double* s_cand, int n_cand, double* nll, int* n_lag_out) {
+  constexpr int NC = 16, NH = 4, NLAG = kLagN;
+  const int K = N / D;
+  const int ncn = T <= B0 ? 1 : 1 + (T - B0 + BN - 1) / BN;
+  const int ncp = (n_cand + NC - 1) / NC * NC, ng16 = ncp / NC;
+  struct Sum { double A, b, C, eta, J, xr, ell; };
+  std::vector<Sum> el((size_t)ncn * N * ncp);
+  std::vector<float> Jc((size_t)N * ncp);
+  const double rho_max = lag_rho_max(NLAG);
+  int n_lag = 0;
+  for (int n = 0; n < N; ++n) {
+    const int k = n / D, d = n % D;
+    const size_t dd = (size_t)k * D * D + (size_t)d * (D + 1);
+    const double q = M.Q[dd], r = rconst[n], a = M.A[dd], c = M.C[dd];
+    auto put_full = [&](int j, int ci, const NllElem<float>& o) {
+      el[((size_t)j * N + n) * ncp + ci] = Sum{o.e.A, o.e.b, o.e.C, o.e.eta, o.e.J, o.xref, o.ell};
+    };
+    for (int g = 0; g * NH < n_cand; ++g) {                         // head: chunk 0
+      double sq[NH];
+      for (int cc = 0; cc < NH; ++cc) sq[cc] = s_cand[std::min(g * NH + cc, n_cand - 1)] * q;
+      NllElem<float> o[NH];
+      nll_summarize_chunk<float, NH, UNIT>(RowsByPointer{y + n, (size_t)N}, 0, std::min(B0, T), r, a, c, sq, o, false);
+      for (int cc = 0; cc < NH; ++cc) {
+        const int ci = g * NH + cc;
+        if (ci >= n_cand) continue;
+        put_full(0, ci, o[cc]);
+        const LeanConst lc = lean_const<UNIT>(r, a, c, sq[cc]);
+        const float c_cg = UNIT ? lc.cg : (float)c * lc.cg;
+        Jc[(size_t)n * ncp + ci] = c_cg / (1.f - lc.rho * lc.rho);
+      }
+    }
+    // the block's fast set and slow list (the same for every chunk of the chain)
+    const double thr = lag_sq_threshold(r, UNIT ? 1.0 : a, UNIT ? 1.0 : c, rho_max);
+    std::vector<int> fast(n_cand), slow;
+    int nfast = 0;
+    double sq_min = 1e300;
+    for (int ci = 0; ci < n_cand; ++ci) {
+      fast[ci] = s_cand[ci] * q >= thr;
+      nfast += fast[ci];
+      sq_min = std::min(sq_min, s_cand[ci] * q);
+      if (!fast[ci]) slow.push_back(ci);
+    }
+    for (int ci = 0; ci < n_cand && slow.size() % 8 != 0; ++ci)
+      if (fast[ci]) slow.push_back(ci);                              // pad with fast candidates (their results are not used)
+    while (slow.size() % 8 != 0) slow.push_back(slow.back());
+    const int np = (int)slow.size() / 8;
+    for (int j = 1; j < ncn; ++j) {
+      const int t0 = B0 + (j - 1) * BN, len = std::min(BN, T - t0);
+      const RowsByPointer ld{y + (size_t)t0 * N + n, (size_t)N};
+      // converged entry for EVERY candidate: rho^(2 t0) < 1e-20 <=> |rho| < exp(-23 / t0) <=> s q above its threshold
+      const bool qual = sq_min >= lag_sq_threshold(r, UNIT ? 1.0 : a, UNIT ? 1.0 : c, exp(-23.0 / (double)t0));
+      const bool lagmode = qual && len % 32 == 0 && len >= 64 && nfast >= 16 && np >= 1 && np <= 6;
+      if (lagmode) {
+        ++n_lag;
+        LagKeep<NLAG> keep[4];
+        for (int w = 0; w < 4; ++w)
+          for (int i = 0; i < NLAG; ++i) keep[w].c[i] = 0.0;
+        auto sqw = [&](int w, int kk) { return s_cand[slow[kk * 4 + w]] * q; };
+        auto put = [&](int w, int kk, int res, const auto& out) {
+          const int ci = slow[kk * 4 + w];
+          if (fast[ci]) return;
+          el[((size_t)j * N + n) * ncp + ci] =
+              res == 2 && out.A[kk] != 0.f ? Sum{out.A[kk], out.B[kk], -1., out.Eta[kk], out.J[kk], out.xr, out.Ell[kk]}
+                                           : Sum{0., out.B[kk], -1., out.Eta[kk], Jc[(size_t)n * ncp + ci], out.xr, out.Ell[kk]};
+        };
+        switch (np) {
+          case 1: lag_block<UNIT, 1>(ld, len, r, a, c, sqw, keep, put); break;
+          case 2: lag_block<UNIT, 2>(ld, len, r, a, c, sqw, keep, put); break;
+          case 3: lag_block<UNIT, 3>(ld, len, r, a, c, sqw, keep, put); break;
+          case 4: lag_block<UNIT, 4>(ld, len, r, a, c, sqw, keep, put); break;
+          case 5: lag_block<UNIT, 5>(ld, len, r, a, c, sqw, keep, put); break;
+          default: lag_block<UNIT, 6>(ld, len, r, a, c, sqw, keep, put); break;
+        }
+        double cs[NLAG];
+        for (int i = 0; i < NLAG; ++i) cs[i] = keep[0].c[i] + keep[1].c[i] + keep[2].c[i] + keep[3].c[i];
+        const float xr = UNIT ? ld(0) : ld(0) / (float)c;
+        for (int ci = 0; ci < n_cand; ++ci) {
+          if (!fast[ci]) continue;
+          const LagConst kc = lag_const<UNIT>(r, a, c, s_cand[ci] * q);
+          double b, eta, ell;
+          lag_summary<NLAG, UNIT>(kc, a, c, len, cs, keep[0].uh, keep[0].ut, keep[0].yl, b, eta, ell);
+          el[((size_t)j * N + n) * ncp + ci] = Sum{0., b, -1., eta, kc.Jc, xr, ell};
+        }
+        continue;
+      }
+      for (int g = 0; g * NC < n_cand; ++g) {                        // the round-4 path
+        auto cand_of = [&](int cc) { return cc * ng16 + g; };
+        auto sqf = [&](int cc) { return s_cand[std::min(cand_of(cc), n_cand - 1)] * q; };
+        float stash[4 * NC];
+        LeanOut<NC> out;
+        const int res = nll_lean_chunk<NC, UNIT>(ld, t0, len, r, a, c, sqf, stash, 1, out);
+        if (res) {
+          for (int cc = 0; cc < NC; ++cc) {
+            const int ci = cand_of(cc);
+            if (ci < n_cand)
+              el[((size_t)j * N + n) * ncp + ci] =
+                  res == 2 ? Sum{out.A[cc], out.B[cc], -1., out.Eta[cc], out.J[cc], out.xr, out.Ell[cc]}
+                           : Sum{0., out.B[cc], -1., out.Eta[cc], Jc[(size_t)n * ncp + ci], out.xr, out.Ell[cc]};
+          }
+        } else {
+          for (int h = 0; h < NC / NH; ++h) {
+            double sq[NH];
+            for (int cc = 0; cc < NH; ++cc) sq[cc] = sqf(h * NH + cc);
+            NllElem<float> o[NH];
+            nll_summarize_chunk<float, NH, UNIT>(ld, t0, len, r, a, c, sq, o, false);
+            for (int cc = 0; cc < NH; ++cc)
+              if (cand_of(h * NH + cc) < n_cand) put_full(j, cand_of(h * NH + cc), o[cc]);
+          }
+        }
+      }
+    }
+  }
+  for (int k = 0; k < K; ++k)
+    for (int ci = 0; ci < n_cand; ++ci) {
+      double tot = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const int n = k * D + d;
+        const size_t dd = (size_t)k * D * D + (size_t)d * (D + 1);
+        auto get = [&](int j, Elem<double>& e, double& ell, double& xr) {
+          const Sum& s = el[((size_t)j * N + n) * ncp + ci];
+          xr = s.xr;
+          e.A = s.A; e.b = s.b; e.C = s.C; e.eta = s.eta; e.J = s.J;
+          ell = s.ell;
+        };
+        tot += nll_assemble<double>(ncn, M.m0[(size_t)k * D + d], M.S0[dd], get);
+      }
+      nll[(size_t)k * n_cand + ci] = -tot;
+    }
+  if (n_lag_out) *n_lag_out = n_lag;
+}
+
+extern "C" int sim_diag_nll_lag(int T, int N, int D, int B0, int BN, int unit, const float* y, const double* rconst,
+                                const double* m0, const double* S0, const double* A, const double* C, const double* Q,
+                                const double* s_cand, int n_cand, double* nll, int* n_lag) {
+  DiagModel M{m0, S0, A, C, Q, nullptr, D};
+  if (unit) run_nll_lag<true>(T, N, D, B0, BN, y, rconst, M, s_cand, n_cand, nll, n_lag);
+  else run_nll_lag<false>(T, N, D, B0, BN, y, rconst, M, s_cand, n_cand, nll, n_lag);
+  return 0;
+}
+

@@ -561,6 +561,38 @@ def test_nll_grid_lean_kernel_shapes_and_fallbacks(T, K, D, unit, n_cand, per_kp
     assert (np.abs(nll - nll_old) / np.abs(ref)).max() < 1e-5          # (each is within 1e-5 of the oracle)
 
 
+@pytest.mark.parametrize('T,K,unit,n_cand,var_scale,nolag', [
+    (30000, 33, True, 64, 1.0, '0'),       # the shared-lag form with a ragged tile and a ragged last chunk
+    (30000, 33, True, 64, 1.0, '1'),       # the same call with the form switched off: the round-4 summaries
+    (9000, 40, False, 40, 1.0, '0'),       # 40 candidates: the last candidate group is half used
+    (30000, 40, True, 64, 400.0, '0'),     # poles at 0.999: flagged (tile, candidate)s take the sequential walk
+    (2100, 64, True, 64, 1.0, '0'),        # two chunks
+    (1500, 8, True, 64, 1.0, '0'),         # too short / too narrow for the grid kernel: nll + argmin one after the other
+])
+def test_nll_argmin_is_the_table_plus_numpys_argmin(T, K, unit, n_cand, var_scale, nolag, set_knob):
+    """eks_nll_argmin (round 5: the argmin is taken inside the assembly of the table by the block that finishes a
+    tile last): the table within 1e-5 of the C oracle, the indices EXACTLY numpy.argmin of the table it returns, s the
+    candidate at that index; and the table equals eks_nll's bit for bit."""
+    from eks_amd import hip_ops
+    from oracle import c_oracle
+    set_knob('EKS_NLL_NOLAG', nolag)
+    arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=11 + T, unit=unit)
+    var_tk = (var_tk * var_scale).astype(np.float32)
+    cand = np.exp(np.linspace(-8, 8, n_cand))
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    rconst = hip_ops.const_r(_dev(var_tk), 1e-4)
+    args = (_dev(y_tk), rconst, *_params_dev(arrs), _dev(cand))
+    for rep in range(3):                   # (the assembly's tickets must come back to zero)
+        nll, s_sel, idx = hip_ops.nll_argmin(*args, flags=flags)
+        nll, s_sel, idx = nll.cpu().numpy(), s_sel.cpu().numpy(), idx.cpu().numpy()
+        ref = c_oracle.nll_grid(arrs['ys'], rconst.cpu().numpy(), arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'],
+                                arrs['Qs'], cand)
+        assert (np.abs(nll - ref) / np.abs(ref)).max() < 1e-5
+        np.testing.assert_array_equal(idx, nll.argmin(axis=1))
+        np.testing.assert_array_equal(s_sel, cand[idx])
+        np.testing.assert_array_equal(nll, hip_ops.nll(*args, flags=flags).cpu().numpy())
+
+
 @pytest.mark.parametrize('T,K,unit', [(3000, 5, True), (1500, 3, False)])
 def test_nll_grad_diag_matches_oracle(T, K, unit):
     from eks_amd import hip_ops
