@@ -825,24 +825,18 @@ struct LeanGeom {
                          // planes valid), 2 = lean summary with its own A, J
   // ---- round 5: shared-lag form (eks_nll_lag.hpp).  A block whose chunk qualifies (whole 32-frame sets, converged
   // entry for EVERY candidate, at least kLagMinFast fast candidates - decided identically by its four waves from the
-  // chains' constants, no exchange) summarises its fast candidates as lag sums and deals only the slow ones to the waves.
+  // chains' constants, no exchange) deals only the slow candidates to its waves, accumulates the chunk's lag sums beside
+  // them and forms the fast candidates' summaries from those at the end - into the same planes.
   int lag_on;            // the launch may use the form at all
   double rho_max;        // a candidate is fast when its pole is at most this for every chain of the tile
-  double* lagc;          // [ncn][N][kLagN]: the chunk's lag sums
-  float *uh, *ut;        // [ncn][N][kLagN]: its first / last kLagN inputs u
-  float* yl;             // [ncn][N]: its last observation
-  int32_t* mode;         // [ncn][ntile]: 1 = the (chunk, tile) took the lag form
-  unsigned long long* fastmask;   // [ntile]: bit c = candidate c is fast for this tile (valid where some chunk's mode is 1)
   // ---- table of the assembly (diag_nll_assemble_kp_kernel), written by the head role
-  double* tab;           // [N][kTabFields][ncp]: the candidate's float64 steady-state constants (rho, g, r g, c g, log S,
-                         // J), J of its float32 recursion-form summaries, chunk 0's term of the log-likelihood given the
-                         // prior and the mean entering chunk 1
+  double* tab;           // [N][kTabFields][ncp]: J of the candidate's converged-entry summaries, chunk 0's term of the
+                         // log-likelihood given the prior, the mean entering chunk 1
 };
-constexpr int kTabFields = 9;
-enum { TAB_RHO, TAB_G, TAB_RG, TAB_CG, TAB_LOGS, TAB_JC, TAB_J32, TAB_LL0, TAB_B0 };
+constexpr int kTabFields = 3;
+enum { TAB_J32, TAB_LL0, TAB_B0 };
 // Layouts of the grid path (round 5: the assembly's lanes are CANDIDATES, so everything per (chain, candidate) has the
-// candidate fastest):  summary planes [j][N][ncp];  chunk references xr [j][N];  lag sums / first and last inputs
-// [j][N][kLagN] (a chain's values contiguous: the assembly reads them with scalar loads);  flags [j][ntile][ncp].
+// candidate fastest):  summary planes [j][N][ncp];  chunk references xr [j][N];  flags [j][ntile][ncp].
 constexpr int kLagMinFast = 16;        // fewer fast candidates: the lag products cost more than they save
 constexpr int kLagMaxNP = 6;           // slow pairs per wave (nslow <= 48 when at least 16 of 64 are fast)
 // LDS of a block, in doubles: the round-4 lean role parks 4 floats x 16 candidates per lane and wave (64 KB); the lag
@@ -850,63 +844,147 @@ constexpr int kLagMaxNP = 6;           // slow pairs per wave (nslow <= 48 when 
 constexpr int kGridLdsDoubles = (kLeanWaves * kLagN * 64) + (kLeanWaves * 3 * 2 * kLagMaxNP * 64) / 2;
 static_assert(kGridLdsDoubles * 8 >= kLeanWaves * 4 * kLeanNC * 64 * 4, "the lean role's stash must fit");
 
-// sinks of the lag form's lane body: slow candidates' fields straight to the summary planes (indexed by candidate),
-// lag partial sums into this wave's float64 accumulators in LDS, the chunk's first / last inputs to their planes
-template <int NC>
-struct LagSlowSink {
-  const NllWs& W;
-  size_t jbase;            // (j * N + n) * ncp
-  size_t xr_off;
-  int cand[NC];
-  bool used[NC];           // slot k holds a slow candidate (a fast one that pads the list is computed but not stored)
-  bool store, store_xr;
-  __device__ __forceinline__ size_t off(int k) const { return jbase + (size_t)cand[k]; }
-  __device__ __forceinline__ void xref(float v) const { if (store_xr) W.xr[xr_off] = v; }
-  __device__ __forceinline__ void eta(int k, float v) const { if (store && used[k]) W.eta[off(k)] = v; }
-  __device__ __forceinline__ void aj(int k, float a, float jv) const {
-    if (store && used[k]) {
-      W.A[off(k)] = a;
-      W.J[off(k)] = jv;
-    }
-  }
-  __device__ __forceinline__ void b(int k, float v) const { if (store && used[k]) W.b[off(k)] = v; }
-  __device__ __forceinline__ void ell(int k, double v) const { if (store && used[k]) W.ell[off(k)] = v; }
-};
+// ---- the lag form of one (tile, chunk) block ---------------------------------------------------------------------------
+// LDS of the block (kGridLdsDoubles doubles), in time order:
+//   main loop   [4 waves][kLagN][64] float64 lag accumulators | the waves' stashes of constants
+//   after A     the stash region holds the block's totals: lag sums [kLagN][64] float64, first / last inputs
+//               [2 kLagN][64] float32 and the last observation [64] float32 (the lead wave's)
+//   after C     the whole array is the output tile: b, eta [64 chains][kTilePitch] float32, ell [64][kTilePitch] float64
+//               (candidate fastest, odd pitch: lanes = chains write it, lanes = candidates read it, both without
+//               bank conflicts) - the block's 64 x 64 results leave as whole rows of the [j][N][ncp] planes.
+//               With lanes = chains storing straight to those planes every store instruction touched 64 different
+//               lines: 48 such instructions per wave at the END of every wave's chunk, all at once - measured as 15 us
+//               on the C3 launch.
+constexpr int kTilePitch = 65;
+constexpr int kLagTotDoubles = kLagN * 64;                                   // lag totals
+constexpr int kLagLdsLagAcc = kLeanWaves * kLagN * 64;                       // (doubles) the stash region starts here
+static_assert((2 * 64 * kTilePitch * 4 + 64 * kTilePitch * 8 + 7) / 8 <= kGridLdsDoubles, "the output tile must fit");
+static_assert(kLagTotDoubles + (2 * kLagN + 1) * 64 / 2 + 64 <= kGridLdsDoubles - kLagLdsLagAcc, "totals behind the accumulators");
+
 struct LagDevSink {
   double* acc;             // LDS: this wave's [kLagN][64] accumulators, at the lane
-  float *uh, *ut, *yl;     // global, at (j, n)
-  bool store;
+  float uh[kLagN], ut[kLagN], yl;   // (the lead wave's: the chunk's first / last inputs, its last observation)
   __device__ __forceinline__ void add(int k, float v) const { acc[k * 64] += (double)v; }
-  __device__ __forceinline__ void head(int i, float v) const { if (store) uh[i] = v; }
-  __device__ __forceinline__ void tail(int i, float v) const { if (store) ut[i] = v; }
-  __device__ __forceinline__ void ylast(float v) const { if (store) *yl = v; }
+  __device__ __forceinline__ void head(int i, float v) { uh[i] = v; }
+  __device__ __forceinline__ void tail(int i, float v) { ut[i] = v; }
+  __device__ __forceinline__ void ylast(float v) { yl = v; }
 };
 
-// the lag form of one (tile, chunk) block, NP slow pairs per wave.  rk: this LANE's candidate's place in the list
-// "slow candidates in index order, then the fast ones" (lanes >= n_cand: none); slot k of wave w is the candidate
-// with place 4 k + w.  Returns the lane body's verdict (1 / 2).
+// NP slow pairs per wave.  rk: this LANE's candidate's place in the list "slow candidates in index order, then the
+// fast ones" (lanes >= n_cand: none); slot k of wave w is the candidate with place 4 k + w.  Returns the lane
+// body's verdict (1 / 2).  Every wave of the block runs this (the barriers inside are the block's).
 template <int NP, bool UNIT>
 __device__ __forceinline__ int lag_block_body(const NllGeom& G, const LeanGeom& LG, const NllWs& W, const BufferRows& ld,
-                                              int j, int n, bool chain_ok, int w, int lane, int len, double q, double r_n,
-                                              double a_n, double c_n, const double* sc, unsigned long long fm, int rk,
-                                              double* lds) {
+                                              int j, int tile, int n, bool chain_ok, int w, int lane, int len, double q,
+                                              double r_n, double a_n, double c_n, const double* sc, unsigned long long fm,
+                                              int rk, double* lds) {
   constexpr int NC = 2 * NP;
-  LagSlowSink<NC> sink{W, ((size_t)j * G.N + n) * W.ncp, (size_t)j * G.N + n, {}, {}, chain_ok, chain_ok && w == 0};
+  int cand[NC];
+  bool used[NC];           // slot k holds a slow candidate (a fast one that pads the list is computed but not kept)
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
     const unsigned long long hit = __ballot(lane < G.n_cand && rk == 4 * k + w);
     const int c = hit ? __builtin_ctzll(hit) : G.n_cand - 1;
-    sink.cand[k] = __builtin_amdgcn_readfirstlane(c);
-    sink.used[k] = hit != 0 && ((fm >> c) & 1ull) == 0;
+    cand[k] = __builtin_amdgcn_readfirstlane(c);
+    used[k] = hit != 0 && ((fm >> c) & 1ull) == 0;
   }
   double* acc = lds + ((size_t)w * kLagN) * 64 + lane;
 #pragma unroll
   for (int k = 0; k < kLagN; ++k) acc[k * 64] = 0.0;
-  float* stash = reinterpret_cast<float*>(lds + (size_t)kLeanWaves * kLagN * 64) + ((size_t)w * 3 * NC) * 64 + lane;
-  const size_t jn = ((size_t)j * G.N + n) * kLagN;
-  LagDevSink lsink{acc, LG.uh + jn, LG.ut + jn, LG.yl + (size_t)j * G.N + n, chain_ok && w == 0};
-  auto sqf = [&](int k) { return sc[sink.cand[k]] * q; };
-  return nll_lag_chunk<NP, kLagND, UNIT>(ld, len, r_n, a_n, c_n, sqf, w, kLeanWaves, stash, 64, sink, lsink);
+  float* stash = reinterpret_cast<float*>(lds + kLagLdsLagAcc) + ((size_t)w * 3 * NC) * 64 + lane;
+  LagDevSink lsink;
+  lsink.acc = acc;
+  LeanOut<NC> out;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) out.A[k] = out.J[k] = 0.f;
+  auto sqf = [&](int k) { return sc[cand[k]] * q; };
+  const int res = nll_lag_chunk<NP, kLagND, UNIT>(ld, len, r_n, a_n, c_n, sqf, 1u << w, kLeanWaves, w == 0, stash, 64, out, lsink);
+  if (chain_ok && w == 0) W.xr[(size_t)j * G.N + n] = out.xr;
+  if (res == 2 && chain_ok) {                          // (wave-uniform, rare: the summaries carry their own A, J)
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      if (!used[k]) continue;
+      const size_t o = ((size_t)j * G.N + n) * W.ncp + cand[k];
+      W.A[o] = out.A[k];
+      W.J[o] = out.J[k];
+    }
+  }
+  // ---- A: every wave's partial lag sums are complete and its stash is dead
+  __syncthreads();
+  double* tot = lds + kLagLdsLagAcc;                                   // [kLagN][64]
+  float* uu = reinterpret_cast<float*>(tot + kLagTotDoubles);          // [2 kLagN + 1][64]
+#pragma unroll
+  for (int i = 0; i < kLagN / kLeanWaves; ++i) {
+    const int kk = w * (kLagN / kLeanWaves) + i;
+    double v = 0.0;
+#pragma unroll
+    for (int ww = 0; ww < kLeanWaves; ++ww) v += lds[((size_t)ww * kLagN + kk) * 64 + lane];
+    tot[kk * 64 + lane] = v;
+  }
+  if (w == 0) {
+#pragma unroll
+    for (int i = 0; i < kLagN; ++i) {
+      uu[i * 64 + lane] = lsink.uh[i];
+      uu[(kLagN + i) * 64 + lane] = lsink.ut[i];
+    }
+    uu[2 * kLagN * 64 + lane] = lsink.yl;
+  }
+  // ---- B: totals in LDS; every wave takes its own copy
+  __syncthreads();
+  double cs[kLagN];
+  float uh[kLagN], ut[kLagN];
+#pragma unroll
+  for (int i = 0; i < kLagN; ++i) {
+    cs[i] = tot[i * 64 + lane];
+    uh[i] = uu[i * 64 + lane];
+    ut[i] = uu[(kLagN + i) * 64 + lane];
+  }
+  const float yl = uu[2 * kLagN * 64 + lane];
+  // ---- C: LDS is free - the output tile
+  __syncthreads();
+  float* tb = reinterpret_cast<float*>(lds);                           // b   [64][kTilePitch]
+  float* te = tb + 64 * kTilePitch;                                    // eta [64][kTilePitch]
+  double* tl = lds + (2 * 64 * kTilePitch * 4 + 7) / 8;                // ell [64][kTilePitch]
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    if (!used[k]) continue;
+    tb[lane * kTilePitch + cand[k]] = out.B[k];
+    te[lane * kTilePitch + cand[k]] = out.Eta[k];
+    tl[lane * kTilePitch + cand[k]] = out.Ell[k];
+  }
+  // the fast candidates, dealt to the waves round-robin: each from the chunk's lag sums, in float64
+  {
+    const int nfast = __popcll(fm);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const bool isfast = ((fm >> lane) & 1ull) != 0;
+    const int frank = __popcll(fm & below);
+#pragma unroll 1
+    for (int r = w; r < nfast; r += kLeanWaves) {
+      const unsigned long long hit = __ballot(isfast && frank == r);
+      const int c = __builtin_amdgcn_readfirstlane(__builtin_ctzll(hit));
+      const LagConst kc = lag_const_fast<UNIT>(r_n, a_n, c_n, sc[c] * q);
+      double b, eta, ell;
+      lag_summary<kLagN, UNIT>(kc, a_n, c_n, len, cs, uh, ut, yl, b, eta, ell);
+      tb[lane * kTilePitch + c] = (float)b;
+      te[lane * kTilePitch + c] = (float)eta;
+      tl[lane * kTilePitch + c] = ell;
+    }
+  }
+  // ---- D: the tile is complete: whole rows out (wave w: chains 16 w .. 16 w + 15; lane = candidate)
+  __syncthreads();
+  if (lane < W.ncp) {
+#pragma unroll 4
+    for (int i = 0; i < 64 / kLeanWaves; ++i) {
+      const int ch = w * (64 / kLeanWaves) + i;
+      const int nn = tile * 64 + ch;
+      if (nn >= G.N) break;                            // (wave-uniform)
+      const size_t o = ((size_t)j * G.N + nn) * W.ncp + lane;
+      W.b[o] = tb[ch * kTilePitch + lane];
+      W.eta[o] = te[ch * kTilePitch + lane];
+      W.ell[o] = tl[ch * kTilePitch + lane];
+    }
+  }
+  return res;
 }
 
 // Diagnostic build only (-DEKS_GRID_STAMPS, tools/grid_stamps.py): lane 0 of every wave stamps the 100 MHz real-time
@@ -978,18 +1056,11 @@ __global__ __launch_bounds__(64 * kLeanWaves, 2) void diag_nll_grid_kernel(NllGe
       const int ci = head_cand(c);
       if (ci >= G.n_cand) continue;
       store_full(0, ci, n, out[c]);
-      // the assembly's table: float64 constants, J of the float32 recursion-form summaries (c cg / (1 - rho^2) as
-      // nll_lean_chunk forms it), chunk 0 applied to the prior (its term and the mean it hands on)
+      // the assembly's table: J of the converged-entry summaries (c cg / (1 - rho^2) as nll_lean_chunk forms it),
+      // chunk 0 applied to the prior (its term and the mean it hands on)
       const LeanConst lc = lean_const<UNIT>(r_n, a_n, c_n, sq[c]);
       const float c_cg = UNIT ? lc.cg : (float)c_n * lc.cg;
       double* tb = LG.tab + (size_t)n * kTabFields * W.ncp + ci;
-      const LagConst kc = lag_const<UNIT>(r_n, a_n, c_n, sq[c]);
-      tb[TAB_RHO * W.ncp] = kc.rho;
-      tb[TAB_G * W.ncp] = kc.g;
-      tb[TAB_RG * W.ncp] = kc.rg;
-      tb[TAB_CG * W.ncp] = kc.cg;
-      tb[TAB_LOGS * W.ncp] = kc.logS;
-      tb[TAB_JC * W.ncp] = kc.Jc;
       tb[TAB_J32 * W.ncp] = (double)(c_cg / (1.f - lc.rho * lc.rho));
       const double eA = out[c].e.A, eb = out[c].e.b, eeta = out[c].e.eta, eJ = out[c].e.J;
       const double m = M.m0[(size_t)k * G.D + d], P = M.S0[dd];
@@ -1035,7 +1106,7 @@ __global__ __launch_bounds__(64 * kLeanWaves, 2) void diag_nll_grid_kernel(NllGe
       const int np = nslow > 8 ? (nslow + 7) / 8 : 1;
       int res;
 #define EKS_LAG_BODY(NP_) \
-  res = lag_block_body<NP_, UNIT>(G, LG, W, ld, j, n, chain_ok, w, lane, len, q, r_n, a_n, c_n, sc, fm, rk, lds)
+  res = lag_block_body<NP_, UNIT>(G, LG, W, ld, j, tile, n, chain_ok, w, lane, len, q, r_n, a_n, c_n, sc, fm, rk, lds)
       switch (np) {
         case 1: EKS_LAG_BODY(1); break;
         case 2: EKS_LAG_BODY(2); break;
@@ -1050,28 +1121,10 @@ __global__ __launch_bounds__(64 * kLeanWaves, 2) void diag_nll_grid_kernel(NllGe
         LG.flags[((size_t)j * G.ntile + tile) * W.ncp + lane] = res == 2 ? 2 : 0;
       if (lane < G.n_cand && ((fm >> lane) & 1ull) && (lane & 3) == w)
         LG.flags[((size_t)j * G.ntile + tile) * W.ncp + lane] = 0;
-      if (w == 0 && lane == 0) {
-        LG.mode[(size_t)j * G.ntile + tile] = 1;
-        LG.fastmask[tile] = fm;                          // (every lag-form block of the tile writes the same mask)
-      }
-      // the four waves' partial lag sums meet: wave w adds up lags 4 w .. 4 w + 3
-      __syncthreads();
-      if (chain_ok) {
-        double* dst = LG.lagc + ((size_t)j * G.N + n) * kLagN;
-#pragma unroll
-        for (int i = 0; i < kLagN / kLeanWaves; ++i) {
-          const int kk = w * (kLagN / kLeanWaves) + i;
-          double v = 0.0;
-#pragma unroll
-          for (int ww = 0; ww < kLeanWaves; ++ww) v += lds[((size_t)ww * kLagN + kk) * 64 + lane];
-          dst[kk] = v;
-        }
-      }
       GRID_STAMP_END(2);
       return;
     }
   }
-  if (w == 0 && lane == 0) LG.mode[(size_t)j * G.ntile + tile] = 0;
   if (w >= LG.ngrp16) return;
   // the grid's candidates are dealt to the tile's waves round-robin: slot c of wave w is candidate c ngrp16 + w, so
   // every wave holds the same mix of slow and fast candidates, slowest first (the staged alive phase of
@@ -1134,10 +1187,8 @@ __global__ __launch_bounds__(64 * kLeanWaves, 2) void diag_nll_grid_kernel(NllGe
 // A converged-entry summary has A = 0, so chunk j's term of the log-likelihood needs only the mean chunk j - 1 hands
 // on:  ll = ll_0(prior) + sum_{j >= 1} [ ell_j + eta_j mr_j - J mr_j^2 / 2 ],  mr_j = b_{j-1} - xref_j.
 // Block = KEYPOINT, wave = (chain d of the keypoint, group of consecutive chunks), LANE = CANDIDATE:
-//   * a recursion-form summary is one coalesced row of the [j][N][ncp] planes;
-//   * where a (chunk, tile) took the shared-lag form, the chunk's lag sums and first / last inputs are per CHAIN, i.e.
-//     wave-uniform: scalar loads, and every fast candidate's summary is formed from them in float64 (lag_summary's
-//     arithmetic with the coefficients in SGPRs);
+//   * a chunk's summaries of one chain are one coalesced row of the [j][N][ncp] planes (however they were formed:
+//     recursion or lag sums), all rows of a batch requested before any is used;
 //   * the wave walks its chunks in order, so the mean a chunk hands on stays in a register;
 //   * the waves' sums meet in LDS: wave 0 adds them in a fixed order, writes nll[k][0 .. n_cand) as one row and takes
 //     the argmin across its lanes (first minimum, numpy.argmin semantics) - no separate argmin launch, no exchange
@@ -1145,7 +1196,7 @@ __global__ __launch_bounds__(64 * kLeanWaves, 2) void diag_nll_grid_kernel(NllGe
 //   * a candidate with a flagged summary anywhere in the sequence (exact-entry summary, or a pole whose rho^t outlives
 //     its chunk) is walked in order, from the prior, by the first wave of each chain (nll_assemble).
 constexpr int kAsmKpWaves = 16;
-constexpr int kAsmBatch = 8;            // chunks a wave stages and evaluates at a time
+constexpr int kAsmBatch = 8;            // chunks whose rows a wave requests at a time
 
 struct GridAsmOut {
   const double* s_cand;
@@ -1153,45 +1204,10 @@ struct GridAsmOut {
   int32_t* idx_out;      // [K] (may be null)
 };
 
-// a chunk's lag data as a wave keeps it in LDS (one copy per wave, read back with broadcast reads)
-struct LagStage {
-  double c[kLagN];
-  float uh[kLagN], ut[kLagN];
-  float yl, pad;
-};
-
-// lag_summary's arithmetic for one candidate per lane, the chunk's data the same for every lane (LDS broadcast reads);
-// inv = 1 / (1 - rho^2) and clog = log 2 pi + log S are the lane's constants
-template <bool UNIT>
-__device__ __forceinline__ void lag_summary_staged(const LagConst& k, double inv, double clog, double a_d, double ic, int len,
-                                                   const LagStage& L, double& b, double& eta, double& ell) {
-  const double rho = k.rho;
-  double h = L.c[kLagN - 1];
-#pragma unroll
-  for (int i = kLagN - 2; i >= 1; --i) h = L.c[i] + rho * h;
-  double dl = 0.0, z = 0.0;
-#pragma unroll
-  for (int i = 0; i < kLagN; ++i) dl = rho * dl + (double)L.ut[i];
-#pragma unroll
-  for (int i = kLagN - 1; i >= 0; --i) z = (double)L.uh[i] + rho * z;
-  const double s0 = (L.c[0] + 2.0 * rho * h - rho * rho * dl * dl) * inv;
-  eta = k.cg * z * inv;
-  b = UNIT ? (double)L.yl - k.rg * dl : a_d * (((double)L.yl - dl) * ic + (1.0 - k.rg) * ic * dl);
-  ell = -0.5 * ((double)len * clog + k.g * s0);
-}
-template <bool UNIT>
-__device__ __forceinline__ double lag_out_mean_staged(const LagConst& k, double a_d, double ic, const LagStage& L) {
-  double dl = 0.0;
-#pragma unroll
-  for (int i = 0; i < kLagN; ++i) dl = k.rho * dl + (double)L.ut[i];
-  return UNIT ? (double)L.yl - k.rg * dl : a_d * (((double)L.yl - dl) * ic + (1.0 - k.rg) * ic * dl);
-}
-
 template <bool UNIT>
 __global__ __launch_bounds__(64 * kAsmKpWaves) void diag_nll_assemble_kp_kernel(NllGeom G, LeanGeom LG, DiagModel M, NllWs W,
                                                                                GridAsmOut O, int ncgw, int cpw,
                                                                                double* __restrict__ nll) {
-  __shared__ LagStage stage[kAsmKpWaves][kAsmBatch + 1];           // [.][kAsmBatch]: the chunk before the wave's first
   __shared__ double accs[kAsmKpWaves][64];
   __shared__ int flg[kAsmKpWaves][64];
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1200,96 +1216,43 @@ __global__ __launch_bounds__(64 * kAsmKpWaves) void diag_nll_assemble_kp_kernel(
   const int n = k * G.D + d, tile = n >> 6;
   const size_t N = (size_t)G.N, ncp = (size_t)W.ncp;
   const size_t dd = (size_t)k * G.D * G.D + (size_t)d * (G.D + 1);
-  const double a_n = M.A[dd], c_n = M.C[dd], ic = 1.0 / c_n;
   const bool cvalid = lane < G.n_cand;
-  const unsigned long long fm = LG.lag_on ? LG.fastmask[tile] : 0ull;   // (garbage unless some chunk of the tile has mode 1:
-  const bool fast = ((fm >> lane) & 1ull) != 0;                          //  only ever used together with a chunk's mode)
   const double* tb = LG.tab + (size_t)n * kTabFields * ncp + lane;
-  LagConst kc;
-  kc.rho = tb[TAB_RHO * ncp];
-  kc.g = tb[TAB_G * ncp];
-  kc.rg = tb[TAB_RG * ncp];
-  kc.cg = tb[TAB_CG * ncp];
-  kc.logS = tb[TAB_LOGS * ncp];
-  kc.Jc = tb[TAB_JC * ncp];
   const double J32 = tb[TAB_J32 * ncp];
-  const double inv = 1.0 / (1.0 - kc.rho * kc.rho), clog = kLog2Pi + kc.logS;
   const int j0 = 1 + cg * cpw, j1 = min(G.ncn, j0 + cpw);
-  auto chunk_len = [&](int j) { return min(G.BN, G.T - (G.B0 + (j - 1) * G.BN)); };
-  auto lag_chunk = [&](int j) { return LG.lag_on && LG.mode[(size_t)j * G.ntile + tile] != 0; };   // (wave-uniform)
-  // this wave's copy of chunk j's lag data: 16 lanes bring the lag sums, 33 the first / last inputs and the last
-  // observation (one request each; the values come back to every lane by broadcast reads)
-  auto stage_chunk = [&](int j, LagStage& S) {
-    const size_t jn = ((size_t)j * N + n) * kLagN;
-    if (lane < kLagN) S.c[lane] = LG.lagc[jn + lane];
-    if (lane < kLagN) S.uh[lane] = LG.uh[jn + lane];
-    else if (lane < 2 * kLagN) S.ut[lane - kLagN] = LG.ut[jn + lane - kLagN];
-    else if (lane == 2 * kLagN) S.yl = LG.yl[(size_t)j * N + n];
-  };
   double acc = 0.0;
   int flagor = 0;
   if (j0 < j1) {
-    double m_in = 0.0;
+    // the mean entering the wave's first chunk
+    double m_in;
+    if (j0 == 1) {
+      m_in = tb[TAB_B0 * ncp];
+      acc = tb[TAB_LL0 * ncp];
+    } else {
+      m_in = (double)W.b[((size_t)(j0 - 1) * N + n) * ncp + lane];
+    }
     for (int jb = j0; jb < j1; jb += kAsmBatch) {
-      // ---- everything the batch needs is requested before anything is evaluated
+      // every row of the batch is requested before anything is evaluated
       float b_r[kAsmBatch], eta_r[kAsmBatch], xr_r[kAsmBatch];
       double ell_r[kAsmBatch];
       int fl_r[kAsmBatch];
-      bool lag_r[kAsmBatch];
-      const bool first = jb == j0;
-      const bool lag_prev = first && j0 > 1 && lag_chunk(j0 - 1);
-      if (lag_prev) stage_chunk(j0 - 1, stage[wv][kAsmBatch]);
-      float b_prev = 0.f;
-      if (first && j0 > 1) b_prev = W.b[((size_t)(j0 - 1) * N + n) * ncp + lane];
 #pragma unroll
       for (int q = 0; q < kAsmBatch; ++q) {
-        const int j = jb + q;
-        lag_r[q] = false;
-        b_r[q] = eta_r[q] = xr_r[q] = 0.f;
-        ell_r[q] = 0.0;
-        fl_r[q] = 0;
-        if (j >= j1) continue;                                      // (wave-uniform)
+        const int j = jb + q < j1 ? jb + q : j1 - 1;              // (past the end: the last chunk again, unused)
         const size_t row = ((size_t)j * N + n) * ncp + lane;
-        lag_r[q] = lag_chunk(j);
-        if (lag_r[q]) stage_chunk(j, stage[wv][q]);
         xr_r[q] = W.xr[(size_t)j * N + n];
         fl_r[q] = LG.flags[((size_t)j * G.ntile + tile) * ncp + lane];
         b_r[q] = W.b[row];
         eta_r[q] = W.eta[row];
         ell_r[q] = W.ell[row];
       }
-      if (first) {                                                  // the mean entering the wave's first chunk
-        if (j0 == 1) {
-          m_in = tb[TAB_B0 * ncp];
-          acc = tb[TAB_LL0 * ncp];
-        } else {
-          m_in = (double)b_prev;
-          if (lag_prev) {
-            const double bl = lag_out_mean_staged<UNIT>(kc, a_n, ic, stage[wv][kAsmBatch]);
-            m_in = fast ? bl : m_in;
-          }
-        }
-      }
 #pragma unroll
       for (int q = 0; q < kAsmBatch; ++q) {
-        const int j = jb + q;
-        if (j >= j1) continue;
-        double b = (double)b_r[q], eta = (double)eta_r[q], ell = ell_r[q], J = J32;
-        bool lagged = false;
-        if (lag_r[q]) {
-          double bl, el, ll;
-          lag_summary_staged<UNIT>(kc, inv, clog, a_n, ic, chunk_len(j), stage[wv][q], bl, el, ll);
-          lagged = fast;
-          b = fast ? bl : b;
-          eta = fast ? el : eta;
-          ell = fast ? ll : ell;
-          J = fast ? kc.Jc : J;
-        }
-        flagor |= lagged ? 0 : fl_r[q];
+        if (jb + q >= j1) continue;                                // (wave-uniform)
+        flagor |= fl_r[q];
         const double mr = m_in - (double)xr_r[q];
-        acc += ell + eta * mr - 0.5 * J * mr * mr;
-        m_in = b;
-        __builtin_amdgcn_sched_barrier(0);       // (one chunk's broadcast reads and Horner chains at a time: registers)
+        acc += ell_r[q] + (double)eta_r[q] * mr - 0.5 * J32 * mr * mr;
+        m_in = (double)b_r[q];
       }
     }
   }
@@ -1306,20 +1269,6 @@ __global__ __launch_bounds__(64 * kAsmKpWaves) void diag_nll_assemble_kp_kernel(
         auto get = [&](int j, Elem<double>& e, double& ell, double& xr) {
           const size_t o = ((size_t)j * N + n) * ncp + lane;
           xr = (double)W.xr[(size_t)j * N + n];
-          if (fast && j > 0 && lag_chunk(j)) {
-            const size_t jn = ((size_t)j * N + n) * kLagN;
-            double cc[kLagN];
-            float hh[kLagN], tt[kLagN];
-#pragma unroll
-            for (int i = 0; i < kLagN; ++i) {
-              cc[i] = LG.lagc[jn + i];
-              hh[i] = LG.uh[jn + i];
-              tt[i] = LG.ut[jn + i];
-            }
-            lag_summary<kLagN, UNIT>(kc, a_n, c_n, chunk_len(j), cc, hh, tt, LG.yl[(size_t)j * N + n], e.b, e.eta, ell);
-            e.A = 0.0; e.C = -1.0; e.J = kc.Jc;
-            return;
-          }
           e.b = W.b[o]; e.eta = W.eta[o]; ell = W.ell[o];
           const int fl = j == 0 ? 1 : LG.flags[((size_t)j * G.ntile + tile) * ncp + lane];
           if (fl == 1) {
@@ -1594,25 +1543,17 @@ static int diag_nll_impl(const eks_dims_t& d, const float* y, const double* rcon
     float** planes[7] = {&W.A, &W.b, &W.C, &W.eta, &W.J, &unused_plane, &W.xr};
     for (int i = 0; i < 7; ++i) *planes[i] = reinterpret_cast<float*>(p + i * fl);
     W.dA = W.db = W.dC = W.deta = W.dJ = nullptr;
-    // [flags : ncn x ntile x ncp ints][mode : ncn x ntile ints][fast masks : ntile x 8 B] in the gradient's plane
+    // [flags : ncn x ntile x ncp ints] in the gradient's plane
     const size_t flag_bytes = align_up((size_t)G.ncn * G.ntile * W.ncp * sizeof(int32_t), 256);
-    const size_t mode_bytes = align_up((size_t)G.ncn * G.ntile * sizeof(int32_t), 256);
-    if (flag_bytes + mode_bytes + (size_t)G.ntile * 8 > db || (long)G.BN * N * 4 >= (1L << 31)) return EKS_ERR_WORKSPACE;
-    LG.mode = reinterpret_cast<int32_t*>(p - db + flag_bytes);
-    LG.fastmask = reinterpret_cast<unsigned long long*>(p - db + flag_bytes + mode_bytes);
-    // the shared-lag form (round 5): its planes are the four float planes this path does not use (the lag sums are
-    // 16 float64 per chain and chunk: they fit a float plane of ncp >= 32 candidates)
-    LG.lag_on = !per_keypoint && W.ncp >= 2 * kLagN && !knob_int(KNOB_NLL_NOLAG, 0);
+    if (flag_bytes > db || (long)G.BN * N * 4 >= (1L << 31)) return EKS_ERR_WORKSPACE;
+    // the shared-lag form (round 5)
+    LG.lag_on = !per_keypoint && n_cand >= 2 * kLagMinFast && !knob_int(KNOB_NLL_NOLAG, 0);
     LG.rho_max = lag_rho_max(kLagN);
-    LG.uh = reinterpret_cast<float*>(p + 7 * fl);
-    LG.ut = reinterpret_cast<float*>(p + 8 * fl);
-    LG.yl = reinterpret_cast<float*>(p + 9 * fl);
-    LG.lagc = reinterpret_cast<double*>(p + 10 * fl);
     // the assembly's table behind the float planes
     {
       const size_t tab_bytes = align_up((size_t)N * kTabFields * W.ncp * sizeof(double), 256);
-      LG.tab = reinterpret_cast<double*>(p + 11 * fl);
-      if (2 * db + 11 * fl + tab_bytes + adam_extra_bytes(N) > ws_bytes) return EKS_ERR_WORKSPACE;
+      LG.tab = reinterpret_cast<double*>(p + 7 * fl);
+      if (2 * db + 7 * fl + tab_bytes + adam_extra_bytes(N) > ws_bytes) return EKS_ERR_WORKSPACE;
     }
     {
       ProfScope ps("diag_nll_summarize", st);

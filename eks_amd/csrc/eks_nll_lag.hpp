@@ -67,6 +67,26 @@ EKS_HD LagConst lag_const(double r_d, double a_d, double c_d, double sq) {
   return k;
 }
 
+// the same constants with hardware-seeded float64 square root / reciprocals and log S = -log g in float32 (as
+// lean_const): what the gfx950 kernel forms per (chain, fast candidate) and chunk - ~40 instructions instead of the
+// library routines' ~250.  J is not needed there (the assembly has it from the head role's table).
+template <bool UNIT>
+EKS_HD LagConst lag_const_fast(double r_d, double a_d, double c_d, double sq) {
+  const double a1 = UNIT ? 1.0 : a_d, c1 = UNIT ? 1.0 : c_d;
+  const double c2 = c1 * c1;
+  const double beta = r_d * (1.0 - a1 * a1) - sq * c2;
+  const double disc = lean_sqrt(beta * beta + 4.0 * c2 * sq * r_d);
+  const double Ci = beta > 0.0 ? (2.0 * sq * r_d) * lean_rcp(beta + disc) : (disc - beta) * lean_rcp(2.0 * c2);
+  LagConst k;
+  k.g = lean_rcp(r_d + Ci * c2);
+  k.rg = r_d * k.g;
+  k.cg = c1 * k.g;
+  k.logS = (double)(-fast_log((float)k.g));
+  k.rho = UNIT ? k.rg : a1 * (1.0 - c1 * (Ci * k.cg));
+  k.Jc = 0.0;
+  return k;
+}
+
 // One fast candidate's converged-entry summary of one chunk of `len` frames from the chunk's lag sums c[NLAG], its
 // first NLAG inputs uh[] and last NLAG inputs ut[] (time order) and its last observation: the outgoing mean b of
 // the reference trajectory, eta and the run-local log-likelihood ell (A = 0, J = k.Jc; see nll_lean_chunk).
@@ -82,13 +102,13 @@ EKS_HD void lag_summary(const LagConst& k, double a_d, double c_d, int len, cons
   for (int i = 0; i < NLAG; ++i) dl = rho * dl + (double)ut[i];            // the recursion over the last NLAG frames
 #pragma unroll
   for (int i = NLAG - 1; i >= 0; --i) z = (double)uh[i] + rho * z;         // sum_i rho^i u_i
-  const double inv = 1.0 / (1.0 - rho * rho);
+  const double inv = lean_rcp(1.0 - rho * rho);
   const double s0 = (c[0] + 2.0 * rho * h - rho * rho * dl * dl) * inv;
   eta = k.cg * z * inv;
   if (UNIT) {
     b = (double)ylast - k.rg * dl;
   } else {
-    const double ic = 1.0 / c_d;
+    const double ic = lean_rcp(c_d);
     b = a_d * (((double)ylast - dl) * ic + (1.0 - k.rg) * ic * dl);
   }
   ell = -0.5 * ((double)len * kLog2Pi + (double)len * k.logS + k.g * s0);
@@ -107,14 +127,15 @@ struct LagKeep {
 
 // One lane: a chunk of len (a multiple of 32) frames of one chain, converged entry (the CALLER has checked that the
 // filter variance has converged at the chunk's first frame for every candidate), NP pairs of slow candidates by the
-// recursion, plus the lag products of the 32-frame sets s with s % nturn == turn (wave-uniform: the waves of a block
-// share the chunk's lag work by time; every wave computes the inputs u of every frame anyway).  `sq(k)` returns
-// s_k q of slow candidate k of this lane's wave, slowest first; `stash` as nll_lean_chunk with 3 floats per candidate.  The wave with turn 0
+// recursion, plus the lag products of the 32-frame sets s with bit s % period of turn_mask set (wave-uniform: the waves
+// of a block share the chunk's lag work by time - their masks partition the period; every wave computes the inputs u
+// of every frame anyway).  `sq(k)` returns
+// s_k q of slow candidate k of this lane's wave, slowest first; `stash` as nll_lean_chunk with 3 floats per candidate.  The `lead` wave
 // also hands the chunk's first / last NLAG inputs and its last observation to `lags`.
 // Returns 1 (A = 0 for every candidate) or 2 (rho^t of some candidate outlives the chunk: sink.aj has its A, J).
 template <int NP, int ND, bool UNIT, typename LD, typename SQ, typename SINK, typename LAGS>
-EKS_HD int nll_lag_chunk(const LD& ld, int len, double r_d, double a_d, double c_d, const SQ& sq, int turn, int nturn,
-                         float* stash, int stride, SINK& out, LAGS& lags) {
+EKS_HD int nll_lag_chunk(const LD& ld, int len, double r_d, double a_d, double c_d, const SQ& sq, unsigned turn_mask,
+                         int period, bool lead, float* stash, int stride, SINK& out, LAGS& lags) {
   static_assert(ND >= 1 && ND <= 15, "the inputs of 32 frames are kept: lags up to 30");
   constexpr int NC = 2 * NP, NLAG = 2 * ND;
   const int nsets = len / 32;
@@ -194,7 +215,7 @@ EKS_HD int nll_lag_chunk(const LD& ld, int len, double r_d, double a_d, double c
         X[a] = f32x2{input(ya, yprev), input(yb, ya)};
         yprev = yb;
       }
-      if (s == 0 && turn == 0) {
+      if (s == 0 && lead) {
 #pragma unroll
         for (int i = 0; i < NLAG; ++i) lags.head(i, X[i / 2][i & 1]);
       }
@@ -303,17 +324,22 @@ EKS_HD int nll_lag_chunk(const LD& ld, int len, double r_d, double a_d, double c
     };
     const IntTag<0> plain;
     const IntTag<1> lagset;
-    int next_turn = turn;                              // the next set that is this wave's
+    int ph = 0;                                        // s % period
+    auto mine = [&]() {
+      const bool m = ((turn_mask >> ph) & 1u) != 0;
+      ph = ph + 1 == period ? 0 : ph + 1;
+      return m;
+    };
     request(setA, 0);
     for (int s = 0; s < nsets; s += 2) {
       request(setB, s + 1);
-      if (s == next_turn) { eat_set(setA, lagset); next_turn += nturn; } else eat_set(setA, plain);
+      if (mine()) eat_set(setA, lagset); else eat_set(setA, plain);
       if (s + 1 >= nsets) break;
       request(setA, s + 2);
-      if (s + 1 == next_turn) { eat_set(setB, lagset); next_turn += nturn; } else eat_set(setB, plain);
+      if (mine()) eat_set(setB, lagset); else eat_set(setB, plain);
     }
   }
-  if (turn == 0) {
+  if (lead) {
 #pragma unroll
     for (int i = 0; i < NLAG; ++i) lags.tail(i, X[(32 - NLAG + i) / 2][(32 - NLAG + i) & 1]);
     lags.ylast(yprev);

@@ -251,7 +251,7 @@ static int lag_block(const RowsByPointer& ld, int len, double r, double a, doubl
     LeanOut<2 * NP> out;
     for (int k = 0; k < 2 * NP; ++k) out.A[k] = 0.f, out.J[k] = 0.f;
     auto sq = [&](int k) { return sqw(w, k); };
-    const int res = nll_lag_chunk<NP, kLagND, UNIT>(ld, len, r, a, c, sq, w, 4, stash, 1, out, keep[w]);
+    const int res = nll_lag_chunk<NP, kLagND, UNIT>(ld, len, r, a, c, sq, 1u << w, 4, w == 0, stash, 1, out, keep[w]);
     worst = res > worst ? res : worst;
     for (int k = 0; k < 2 * NP; ++k) put(w, k, res, out);
   }

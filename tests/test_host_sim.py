@@ -122,6 +122,65 @@ def test_grid_kernel_lane_bodies_head_plus_lean_match_oracle(sim, T, B0, BN, uni
     assert n_lean.value >= (0.7 if var_scale == 1.0 else 0.3) * units, (n_lean.value, units)
 
 
+@pytest.mark.parametrize('T,B0,BN,unit,var_scale,min_lag', [
+    (9001, 1024, 1600, True, 1.0, 0.7), (12500, 1024, 1600, False, 1.0, 0.7), (20000, 1024, 3200, False, 1.0, 0.7),
+    (12000, 1024, 512, True, 20.0, 0.5), (12000, 1024, 1600, False, 300.0, 0.1), (7000, 1024, 1024, True, 0.05, 0.7)])
+def test_grid_kernel_shared_lag_form_matches_oracle(sim, T, B0, BN, unit, var_scale, min_lag):
+    """The shared-lag form of the grid kernel (round 5, eks_nll_lag.hpp) on the host: the candidates whose steady-state
+    pole is below lag_rho_max (0.345 for 16 lags) are summarised from the chunk's 16 lag sums and its first / last 16
+    inputs in float64 (lag_summary), the others run nll_lag_chunk's recursion in four "waves" that take turns at the
+    lag products; chunks that do not qualify keep the round-4 lane bodies.  NLL within 1e-5 of the float64 oracle on
+    all 64 candidates, argmin bit-exact, the FAST candidates (grid indices 40 and up: poles below 0.2 at these
+    variances) within 1e-7 - the lag form is the more accurate of the two; most chunks must really take it."""
+    K, NC = 3, 64
+    arrs, y, var, ys64, ev64 = _problem(T, K, seed=6)
+    ev64 = ev64 * var_scale
+    if not unit:
+        rng = np.random.default_rng(3)
+        eye = np.eye(2)
+        arrs['As'] = np.ascontiguousarray(eye * rng.uniform(0.93, 1.0, (K, 2))[:, :, None])
+        arrs['Cs'] = np.ascontiguousarray(eye * rng.uniform(0.6, 1.4, (K, 2))[:, :, None])
+        arrs['Qs'] = np.ascontiguousarray(eye * rng.uniform(0.5, 2.0, (K, 2))[:, :, None])
+    Rc = orc.constant_R_from_timevarying(orc.build_R_from_vars(ev64))
+    cand = np.exp(np.linspace(-8, 8, NC))
+    from oracle import c_oracle
+    ref = c_oracle.nll_grid(ys64, Rc, arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], cand)
+    rconst = np.ascontiguousarray(Rc.reshape(-1))
+    f, d = ctypes.c_float, ctypes.c_double
+    nll = np.zeros((K, NC))
+    n_lag = ctypes.c_int(0)
+    sim.sim_diag_nll_lag(T, 2 * K, 2, B0, BN, int(unit), _p(y, f), _p(rconst, d), _p(arrs['m0s'], d),
+                         _p(arrs['S0s'], d), _p(arrs['As'], d), _p(arrs['Cs'], d), _p(arrs['Qs'], d), _p(cand, d), NC,
+                         _p(nll, d), ctypes.byref(n_lag))
+    err = np.abs(nll - ref) / np.abs(ref)
+    assert err.max() < 1e-5
+    np.testing.assert_array_equal(nll.argmin(axis=1), ref.argmin(axis=1))
+    units = 2 * K * (0 if T <= B0 else (T - B0 + BN - 1) // BN)
+    assert n_lag.value >= min_lag * units, (n_lag.value, units)
+    if var_scale <= 1.0:
+        assert err[:, 48:].max() < 1e-7, err[:, 48:].max()
+
+
+def test_lag_sum_identity_is_exact_with_all_lags():
+    """sum_t d_t^2 of the zero-start recursion d_t = rho d_{t-1} + u_t equals
+    [c_0 + 2 sum_k rho^k c_k - rho^2 d_last^2] / (1 - rho^2) with c_k the lag sums of u - the identity the lag form
+    truncates at 16 lags (eks_nll_lag.hpp); and sum_t d_t rho^t = [sum_i rho^i u_i - rho^(L+1) d_last] / (1 - rho^2)."""
+    rng = np.random.default_rng(0)
+    L = 300
+    u = rng.normal(size=L)
+    for rho in (0.05, 0.3, 0.7, 0.95):
+        dd = np.zeros(L)
+        acc = 0.0
+        for t in range(L):
+            acc = rho * acc + u[t]
+            dd[t] = acc
+        c = np.array([np.dot(u[k:], u[:L - k]) for k in range(L)])
+        s0 = (c[0] + 2 * np.sum(rho ** np.arange(1, L) * c[1:]) - rho ** 2 * dd[-1] ** 2) / (1 - rho ** 2)
+        assert abs(s0 - np.sum(dd ** 2)) < 1e-9 * np.sum(dd ** 2)
+        s1 = (np.sum(rho ** np.arange(L) * u) - rho ** (L + 1) * dd[-1]) / (1 - rho ** 2)
+        assert abs(s1 - np.sum(dd * rho ** np.arange(L))) < 1e-9 * max(1.0, abs(s1))
+
+
 # ---------------------------------------------------------------------------------------------
 # general (D, O) smoother: chunk elements -> scan -> exact replay, from the kernels' own headers
 # ---------------------------------------------------------------------------------------------
