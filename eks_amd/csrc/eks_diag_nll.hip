@@ -870,20 +870,21 @@ struct LagDevSink {
   __device__ __forceinline__ void ylast(float v) { yl = v; }
 };
 
-// NP slow pairs per wave.  rk: this LANE's candidate's place in the list "slow candidates in index order, then the
-// fast ones" (lanes >= n_cand: none); slot k of wave w is the candidate with place 4 k + w.  Returns the lane
+// NP slow pairs in this wave.  rk: this LANE's candidate's place in the list "slow candidates in index order, then the
+// fast ones" (lanes >= n_cand: none); the pairs of consecutive places go to the waves round-robin: slot k of wave w
+// is place 2 (4 (k / 2) + w) + k % 2.  turn_mask: this wave's lag sets of every 16.  Returns the lane
 // body's verdict (1 / 2).  Every wave of the block runs this (the barriers inside are the block's).
 template <int NP, bool UNIT>
 __device__ __forceinline__ int lag_block_body(const NllGeom& G, const LeanGeom& LG, const NllWs& W, const BufferRows& ld,
                                               int j, int tile, int n, bool chain_ok, int w, int lane, int len, double q,
                                               double r_n, double a_n, double c_n, const double* sc, unsigned long long fm,
-                                              int rk, double* lds) {
+                                              int rk, unsigned turn_mask, double* lds) {
   constexpr int NC = 2 * NP;
   int cand[NC];
   bool used[NC];           // slot k holds a slow candidate (a fast one that pads the list is computed but not kept)
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
-    const unsigned long long hit = __ballot(lane < G.n_cand && rk == 4 * k + w);
+    const unsigned long long hit = __ballot(lane < G.n_cand && rk == 2 * ((k >> 1) * kLeanWaves + w) + (k & 1));
     const int c = hit ? __builtin_ctzll(hit) : G.n_cand - 1;
     cand[k] = __builtin_amdgcn_readfirstlane(c);
     used[k] = hit != 0 && ((fm >> c) & 1ull) == 0;
@@ -891,14 +892,14 @@ __device__ __forceinline__ int lag_block_body(const NllGeom& G, const LeanGeom& 
   double* acc = lds + ((size_t)w * kLagN) * 64 + lane;
 #pragma unroll
   for (int k = 0; k < kLagN; ++k) acc[k * 64] = 0.0;
-  float* stash = reinterpret_cast<float*>(lds + kLagLdsLagAcc) + ((size_t)w * 3 * NC) * 64 + lane;
+  float* stash = reinterpret_cast<float*>(lds + kLagLdsLagAcc) + ((size_t)w * 3 * 2 * kLagMaxNP) * 64 + lane;   // (NP differs between waves)
   LagDevSink lsink;
   lsink.acc = acc;
   LeanOut<NC> out;
 #pragma unroll
   for (int k = 0; k < NC; ++k) out.A[k] = out.J[k] = 0.f;
   auto sqf = [&](int k) { return sc[cand[k]] * q; };
-  const int res = nll_lag_chunk<NP, kLagND, UNIT>(ld, len, r_n, a_n, c_n, sqf, 1u << w, kLeanWaves, w == 0, stash, 64, out, lsink);
+  const int res = nll_lag_chunk<NP, kLagND, UNIT>(ld, len, r_n, a_n, c_n, sqf, turn_mask, 16, w == 0, stash, 64, out, lsink);
   if (chain_ok && w == 0) W.xr[(size_t)j * G.N + n] = out.xr;
   if (res == 2 && chain_ok) {                          // (wave-uniform, rare: the summaries carry their own A, J)
 #pragma unroll
@@ -1103,10 +1104,21 @@ __global__ __launch_bounds__(64 * kLeanWaves, 2) void diag_nll_grid_kernel(NllGe
     if (qual && nfast >= kLagMinFast && nslow <= 8 * kLagMaxNP) {
       const unsigned long long below = (1ull << lane) - 1ull;
       const int rk = ((fm >> lane) & 1ull) ? nslow + __popcll(fm & below) : __popcll(~fm & below);
-      const int np = nslow > 8 ? (nslow + 7) / 8 : 1;
+      // The slow candidates go to the waves in PAIRS, round-robin, slowest first: P pairs -> P / 4 per wave and one more
+      // for the first P % 4 waves (padding every wave to the same count cost 32 recursions for C3's 28 slow candidates,
+      // and the kernel is bound by the FMAs it issues).  The waves with fewer pairs take more of the lag sets: with a
+      // lag set at ~4.25 pair-sets of FMAs, `rem` turns of 16 for the waves with the extra pair and rem + 4 for the
+      // others level the work (rem = 0: four each).
+      int npairs = (nslow + 1) / 2;
+      if (npairs < kLeanWaves) npairs = kLeanWaves;
+      const int base = npairs / kLeanWaves, rem = npairs % kLeanWaves;
+      const int np = base + (w < rem ? 1 : 0);
+      const int turns = rem == 0 ? 4 : (w < rem ? rem : rem + 4);
+      const int first = rem == 0 ? 4 * w : (w < rem ? rem * w : rem * rem + (rem + 4) * (w - rem));
+      const unsigned turn_mask = ((1u << turns) - 1u) << first;
       int res;
 #define EKS_LAG_BODY(NP_) \
-  res = lag_block_body<NP_, UNIT>(G, LG, W, ld, j, tile, n, chain_ok, w, lane, len, q, r_n, a_n, c_n, sc, fm, rk, lds)
+  res = lag_block_body<NP_, UNIT>(G, LG, W, ld, j, tile, n, chain_ok, w, lane, len, q, r_n, a_n, c_n, sc, fm, rk, turn_mask, lds)
       switch (np) {
         case 1: EKS_LAG_BODY(1); break;
         case 2: EKS_LAG_BODY(2); break;
@@ -1116,8 +1128,8 @@ __global__ __launch_bounds__(64 * kLeanWaves, 2) void diag_nll_grid_kernel(NllGe
         default: EKS_LAG_BODY(6); break;
       }
 #undef EKS_LAG_BODY
-      // flags of this wave's slow candidates (slot k of wave w has place 4 k + w in the list); the fast ones never flag
-      if (lane < G.n_cand && !((fm >> lane) & 1ull) && (rk & 3) == w)
+      // flags of this wave's slow candidates (the pair of place rk / 2 is wave (rk / 2) % 4's); the fast ones never flag
+      if (lane < G.n_cand && !((fm >> lane) & 1ull) && ((rk >> 1) & 3) == w)
         LG.flags[((size_t)j * G.ntile + tile) * W.ncp + lane] = res == 2 ? 2 : 0;
       if (lane < G.n_cand && ((fm >> lane) & 1ull) && (lane & 3) == w)
         LG.flags[((size_t)j * G.ntile + tile) * W.ncp + lane] = 0;

@@ -23,6 +23,34 @@
 
 namespace eks {
 
+// a * b + {c.hi, c.hi} / {c.lo, c.lo}: the inputs u of two consecutive frames share a 64-bit register pair, and the
+// recursion adds one of them to both candidates of a pair.  The compiler folds the low-half splat into the
+// instruction's op_sel_hi field but copies the high half to another register first (one v_mov per odd frame, 4 % of the
+// frame loop): the high-half form is spelled out.
+EKS_HD f32x2 fma_splat_lo(f32x2 a, f32x2 b, f32x2 c) { return a * b + f32x2{c[0], c[0]}; }
+EKS_HD f32x2 fma_splat_hi(f32x2 a, f32x2 b, f32x2 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+#else
+  return a * b + f32x2{c[1], c[1]};
+#endif
+}
+// One wait for a whole 32-frame set of rows: row loads return in order, so once the set's LAST row has arrived all of
+// it has.  Touching that register first (an empty statement the optimiser cannot see through, and nothing may be
+// scheduled across) makes the compiler wait once - for all but the 32 requests of the other set - instead of in front
+// of every one of the 32 uses.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EKS_ROWS_ARRIVED(last)              \
+  do {                                      \
+    asm volatile("" : "+v"(last));          \
+    __builtin_amdgcn_sched_barrier(0);      \
+  } while (0)
+#else
+#define EKS_ROWS_ARRIVED(last) do { } while (0)
+#endif
+
 constexpr int kLagND = 8;                 // lag PAIRS: the lag sums c_0 .. c_{2 kLagND - 1}
 constexpr int kLagN = 2 * kLagND;
 // a pole is "fast" when rho^NLAG <= 6e-8 (1 - rho): truncating the series above at NLAG lags then moves the chunk's
@@ -209,6 +237,7 @@ EKS_HD int nll_lag_chunk(const LD& ld, int len, double r_d, double a_d, double c
     float yprev = ystart;
     auto run_set = [&](auto set_tag, int s) {
       constexpr int S = decltype(set_tag)::value;
+      EKS_ROWS_ARRIVED(ring[S][kSet - 1][7]);
 #pragma unroll
       for (int a = 0; a < 16; ++a) {
         const float ya = ring[S][a / 4][(2 * a) % 8], yb = ring[S][a / 4][(2 * a + 1) % 8];
@@ -230,9 +259,9 @@ EKS_HD int nll_lag_chunk(const LD& ld, int len, double r_d, double a_d, double c
 #pragma unroll
         for (int a = 15; a >= 0; --a) {
 #pragma unroll
-          for (int p = 0; p < NA; ++p) zs[p] = rho2[p] * zs[p] + f32x2{X[a][1], X[a][1]};
+          for (int p = 0; p < NA; ++p) zs[p] = fma_splat_hi(rho2[p], zs[p], X[a]);
 #pragma unroll
-          for (int p = 0; p < NA; ++p) zs[p] = rho2[p] * zs[p] + f32x2{X[a][0], X[a][0]};
+          for (int p = 0; p < NA; ++p) zs[p] = fma_splat_lo(rho2[p], zs[p], X[a]);
           EKS_SCHED_FENCE();
         }
 #pragma unroll
@@ -285,12 +314,12 @@ EKS_HD int nll_lag_chunk(const LD& ld, int len, double r_d, double a_d, double c
         yprev = yb;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          dk2[p] = rho2[p] * dk2[p] + f32x2{X[a][0], X[a][0]};
+          dk2[p] = fma_splat_lo(rho2[p], dk2[p], X[a]);
           s22[p] = s22[p] + dk2[p] * dk2[p];
         }
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          dk2[p] = rho2[p] * dk2[p] + f32x2{X[a][1], X[a][1]};
+          dk2[p] = fma_splat_hi(rho2[p], dk2[p], X[a]);
           s22[p] = s22[p] + dk2[p] * dk2[p];
         }
         if constexpr (LT) {
@@ -333,9 +362,11 @@ EKS_HD int nll_lag_chunk(const LD& ld, int len, double r_d, double a_d, double c
     request(setA, 0);
     for (int s = 0; s < nsets; s += 2) {
       request(setB, s + 1);
+      EKS_ROWS_ARRIVED(ring[0][kSet - 1][7]);          // (ahead of the branch: what its arms share is hoisted to here)
       if (mine()) eat_set(setA, lagset); else eat_set(setA, plain);
       if (s + 1 >= nsets) break;
       request(setA, s + 2);
+      EKS_ROWS_ARRIVED(ring[1][kSet - 1][7]);
       if (mine()) eat_set(setB, lagset); else eat_set(setB, plain);
     }
   }

@@ -242,20 +242,17 @@ extern "C" int sim_diag_nll_lean(int T, int N, int D, int B0, int BN, int unit, 
 // ---------------------------------------------------------------------------------------------
 #include "eks_nll_lag.hpp"
 
+// one "wave" of the lag block: NP pairs, its turn mask over 16 sets
 template <bool UNIT, int NP, typename SQW, typename PUT>
-static int lag_block(const RowsByPointer& ld, int len, double r, double a, double c, const SQW& sqw, LagKeep<kLagN>* keep,
-                     const PUT& put) {
-  int worst = 1;
-  for (int w = 0; w < 4; ++w) {
-    float stash[6 * NP];
-    LeanOut<2 * NP> out;
-    for (int k = 0; k < 2 * NP; ++k) out.A[k] = 0.f, out.J[k] = 0.f;
-    auto sq = [&](int k) { return sqw(w, k); };
-    const int res = nll_lag_chunk<NP, kLagND, UNIT>(ld, len, r, a, c, sq, 1u << w, 4, w == 0, stash, 1, out, keep[w]);
-    worst = res > worst ? res : worst;
-    for (int k = 0; k < 2 * NP; ++k) put(w, k, res, out);
-  }
-  return worst;
+static int lag_wave(const RowsByPointer& ld, int len, double r, double a, double c, int w, unsigned mask, const SQW& sqw,
+                    LagKeep<kLagN>& keep, const PUT& put) {
+  float stash[6 * NP];
+  LeanOut<2 * NP> out;
+  for (int k = 0; k < 2 * NP; ++k) out.A[k] = 0.f, out.J[k] = 0.f;
+  auto sq = [&](int k) { return sqw(w, k); };
+  const int res = nll_lag_chunk<NP, kLagND, UNIT>(ld, len, r, a, c, sq, mask, 16, w == 0, stash, 1, out, keep);
+  for (int k = 0; k < 2 * NP; ++k) put(w, k, res, out);
+  return res;
 }
 
 template <bool UNIT>
@@ -302,36 +299,48 @@ static void run_nll_lag(int T, int N, int D, int B0, int BN, const float* y, con
       sq_min = std::min(sq_min, s_cand[ci] * q);
       if (!fast[ci]) slow.push_back(ci);
     }
-    for (int ci = 0; ci < n_cand && slow.size() % 8 != 0; ++ci)
-      if (fast[ci]) slow.push_back(ci);                              // pad with fast candidates (their results are not used)
-    while (slow.size() % 8 != 0) slow.push_back(slow.back());
-    const int np = (int)slow.size() / 8;
+    // pairs of consecutive places of the slow list go to the four waves round-robin (diag_nll_grid_kernel): P pairs ->
+    // P / 4 per wave and one more for the first P % 4; the list is padded with fast candidates (results unused)
+    const int nslow = (int)slow.size();
+    int npairs = (nslow + 1) / 2;
+    if (npairs < 4) npairs = 4;
+    for (int ci = 0; ci < n_cand && (int)slow.size() < 2 * npairs; ++ci)
+      if (fast[ci]) slow.push_back(ci);
+    while ((int)slow.size() < 2 * npairs) slow.push_back(slow.back());
+    const int base = npairs / 4, rem = npairs % 4;
     for (int j = 1; j < ncn; ++j) {
       const int t0 = B0 + (j - 1) * BN, len = std::min(BN, T - t0);
       const RowsByPointer ld{y + (size_t)t0 * N + n, (size_t)N};
       // converged entry for EVERY candidate: rho^(2 t0) < 1e-20 <=> |rho| < exp(-23 / t0) <=> s q above its threshold
       const bool qual = sq_min >= lag_sq_threshold(r, UNIT ? 1.0 : a, UNIT ? 1.0 : c, exp(-23.0 / (double)t0));
-      const bool lagmode = qual && len % 32 == 0 && len >= 64 && nfast >= 16 && np >= 1 && np <= 6;
+      const bool lagmode = qual && len % 32 == 0 && len >= 64 && nfast >= 16 && nslow <= 48;
       if (lagmode) {
         ++n_lag;
         LagKeep<NLAG> keep[4];
         for (int w = 0; w < 4; ++w)
           for (int i = 0; i < NLAG; ++i) keep[w].c[i] = 0.0;
-        auto sqw = [&](int w, int kk) { return s_cand[slow[kk * 4 + w]] * q; };
+        auto place = [&](int w, int kk) { return 2 * ((kk / 2) * 4 + w) + (kk & 1); };
+        auto sqw = [&](int w, int kk) { return s_cand[slow[place(w, kk)]] * q; };
         auto put = [&](int w, int kk, int res, const auto& out) {
-          const int ci = slow[kk * 4 + w];
+          const int ci = slow[place(w, kk)];
           if (fast[ci]) return;
           el[((size_t)j * N + n) * ncp + ci] =
               res == 2 && out.A[kk] != 0.f ? Sum{out.A[kk], out.B[kk], -1., out.Eta[kk], out.J[kk], out.xr, out.Ell[kk]}
                                            : Sum{0., out.B[kk], -1., out.Eta[kk], Jc[(size_t)n * ncp + ci], out.xr, out.Ell[kk]};
         };
-        switch (np) {
-          case 1: lag_block<UNIT, 1>(ld, len, r, a, c, sqw, keep, put); break;
-          case 2: lag_block<UNIT, 2>(ld, len, r, a, c, sqw, keep, put); break;
-          case 3: lag_block<UNIT, 3>(ld, len, r, a, c, sqw, keep, put); break;
-          case 4: lag_block<UNIT, 4>(ld, len, r, a, c, sqw, keep, put); break;
-          case 5: lag_block<UNIT, 5>(ld, len, r, a, c, sqw, keep, put); break;
-          default: lag_block<UNIT, 6>(ld, len, r, a, c, sqw, keep, put); break;
+        for (int w = 0; w < 4; ++w) {
+          const int np = base + (w < rem ? 1 : 0);
+          const int turns = rem == 0 ? 4 : (w < rem ? rem : rem + 4);
+          const int first = rem == 0 ? 4 * w : (w < rem ? rem * w : rem * rem + (rem + 4) * (w - rem));
+          const unsigned mask = ((1u << turns) - 1u) << first;
+          switch (np) {
+            case 1: lag_wave<UNIT, 1>(ld, len, r, a, c, w, mask, sqw, keep[w], put); break;
+            case 2: lag_wave<UNIT, 2>(ld, len, r, a, c, w, mask, sqw, keep[w], put); break;
+            case 3: lag_wave<UNIT, 3>(ld, len, r, a, c, w, mask, sqw, keep[w], put); break;
+            case 4: lag_wave<UNIT, 4>(ld, len, r, a, c, w, mask, sqw, keep[w], put); break;
+            case 5: lag_wave<UNIT, 5>(ld, len, r, a, c, w, mask, sqw, keep[w], put); break;
+            default: lag_wave<UNIT, 6>(ld, len, r, a, c, w, mask, sqw, keep[w], put); break;
+          }
         }
         double cs[NLAG];
         for (int i = 0; i < NLAG; ++i) cs[i] = keep[0].c[i] + keep[1].c[i] + keep[2].c[i] + keep[3].c[i];
