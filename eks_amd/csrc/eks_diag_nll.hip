@@ -1101,7 +1101,8 @@ __global__ __launch_bounds__(64 * kLeanWaves, 2) void diag_nll_grid_kernel(NllGe
       qual = qual && __all(sqc >= thr_qual);
     }
     const int nfast = __popcll(fm), nslow = G.n_cand - nfast;
-    if (qual && nfast >= kLagMinFast && nslow <= 8 * kLagMaxNP) {
+    // (general diagonal models form every input u in float64: with 5 or 6 pairs per wave their frame loops spill)
+    if (qual && nfast >= kLagMinFast && nslow <= 8 * (UNIT ? kLagMaxNP : 4)) {
       const unsigned long long below = (1ull << lane) - 1ull;
       const int rk = ((fm >> lane) & 1ull) ? nslow + __popcll(fm & below) : __popcll(~fm & below);
       // The slow candidates go to the waves in PAIRS, round-robin, slowest first: P pairs -> P / 4 per wave and one more
@@ -1116,7 +1117,7 @@ __global__ __launch_bounds__(64 * kLeanWaves, 2) void diag_nll_grid_kernel(NllGe
       const int turns = rem == 0 ? 4 : (w < rem ? rem : rem + 4);
       const int first = rem == 0 ? 4 * w : (w < rem ? rem * w : rem * rem + (rem + 4) * (w - rem));
       const unsigned turn_mask = ((1u << turns) - 1u) << first;
-      int res;
+      int res = 1;
 #define EKS_LAG_BODY(NP_) \
   res = lag_block_body<NP_, UNIT>(G, LG, W, ld, j, tile, n, chain_ok, w, lane, len, q, r_n, a_n, c_n, sc, fm, rk, turn_mask, lds)
       switch (np) {
@@ -1124,8 +1125,8 @@ __global__ __launch_bounds__(64 * kLeanWaves, 2) void diag_nll_grid_kernel(NllGe
         case 2: EKS_LAG_BODY(2); break;
         case 3: EKS_LAG_BODY(3); break;
         case 4: EKS_LAG_BODY(4); break;
-        case 5: EKS_LAG_BODY(5); break;
-        default: EKS_LAG_BODY(6); break;
+        case 5: if constexpr (UNIT) EKS_LAG_BODY(5); break;
+        default: if constexpr (UNIT) EKS_LAG_BODY(6); break;
       }
 #undef EKS_LAG_BODY
       // flags of this wave's slow candidates (the pair of place rk / 2 is wave (rk / 2) % 4's); the fast ones never flag
@@ -1137,62 +1138,98 @@ __global__ __launch_bounds__(64 * kLeanWaves, 2) void diag_nll_grid_kernel(NllGe
       return;
     }
   }
-  if (w >= LG.ngrp16) return;
+  // ---- the round-4 form: every candidate by the recursion, 16 per wave
   // the grid's candidates are dealt to the tile's waves round-robin: slot c of wave w is candidate c ngrp16 + w, so
   // every wave holds the same mix of slow and fast candidates, slowest first (the staged alive phase of
   // nll_lean_chunk then costs every wave the same, a few per cent; contiguous groups left the slowest group's
   // waves 25 % longer than the rest of a launch whose blocks all run in one round)
+  __shared__ int tile_valid[kLeanWaves];
   const int ncand = G.n_cand, stride16 = LG.ngrp16;
   auto cand_of = [&](int c) { return c * stride16 + w; };
   auto sqf = [&](int c) { return sc[min(cand_of(c), ncand - 1)] * q; };
-  // the summary's fields go straight to the planes as the lane body produces them (nothing rides through the frame
-  // loops in registers)
-  struct Sink {
+  // slot c is candidate c stride16 + w: valid while c stride16 + w < n_cand
+  const int nvalid = min(kLeanNC, ncand > w ? (ncand - w + stride16 - 1) / stride16 : 0);
+  // the summaries stay in registers from the end of the lane body to the block's output tile (as the lag form: whole
+  // rows of the [j][N][ncp] planes instead of 48 scattered store instructions per wave); a summary with A != 0 stores
+  // its A, J at once (rare)
+  struct Keep {
     const NllWs& W;
-    size_t base, cstride;      // plane offset of candidate slot 0, distance between slots
-    size_t xr_off;
-    int nvalid;                // slots whose candidate exists
+    size_t base, cstride, xr_off;
+    int nvalid;
     bool store, store_xr;
+    float B[kLeanNC], Eta[kLeanNC];
+    double Ell[kLeanNC];
     __device__ __forceinline__ void xref(float v) const { if (store_xr) W.xr[xr_off] = v; }
-    __device__ __forceinline__ void eta(int k, float v) const { if (store && k < nvalid) W.eta[base + k * cstride] = v; }
+    __device__ __forceinline__ void eta(int k, float v) { Eta[k] = v; }
     __device__ __forceinline__ void aj(int k, float a, float jv) const {
       if (store && k < nvalid) {
         W.A[base + k * cstride] = a;
         W.J[base + k * cstride] = jv;
       }
     }
-    __device__ __forceinline__ void b(int k, float v) const { if (store && k < nvalid) W.b[base + k * cstride] = v; }
-    __device__ __forceinline__ void ell(int k, double v) const { if (store && k < nvalid) W.ell[base + k * cstride] = v; }
+    __device__ __forceinline__ void b(int k, float v) { B[k] = v; }
+    __device__ __forceinline__ void ell(int k, double v) { Ell[k] = v; }
   };
-  // slot c is candidate c stride16 + w: valid while c stride16 + w < n_cand
-  const int nvalid = ncand > w ? (ncand - w + stride16 - 1) / stride16 : 0;
-  Sink sink{W, ((size_t)j * G.N + n) * W.ncp + w, (size_t)stride16, (size_t)j * G.N + n,
-            nvalid < kLeanNC ? nvalid : kLeanNC, chain_ok, chain_ok && w == 0};
-  const int lean = nll_lean_chunk<kLeanNC, UNIT>(ld, t0, len, r_n, a_n, c_n, sqf, &stash[w][0][lane], 64, sink);
-  // flag: 0 lean summary with A = 0 (the usual case) | 2 lean summary with A = rho^len != 0 (own A, J planes) |
-  // 1 exact-entry summary (full planes) - anything but 0 sends the (tile, candidate)'s assembly down the sequential walk
-  if (lane < kLeanNC && cand_of(lane) < ncand)
-    LG.flags[((size_t)j * G.ntile + tile) * W.ncp + cand_of(lane)] = lean == 1 ? 0 : (lean == 2 ? 2 : 1);
-  if (lean) {
-    GRID_STAMP_END(1);
-    return;
-  }
-  // ---- the chunk does not qualify for the converged-entry summary: exact entry, kHeadNCL candidates at a time
-  for (int h = 0; h < kLeanNC / kHeadNCL; ++h) {
-    double sq[kHeadNCL];
+  Keep keep{W, ((size_t)j * G.N + n) * W.ncp + w, (size_t)stride16, (size_t)j * G.N + n, nvalid, chain_ok, chain_ok && w == 0,
+            {}, {}, {}};
+  int lean = 0;
+  if (w < LG.ngrp16) {
+    lean = nll_lean_chunk<kLeanNC, UNIT>(ld, t0, len, r_n, a_n, c_n, sqf, &stash[w][0][lane], 64, keep);
+    // flag: 0 lean summary with A = 0 (the usual case) | 2 lean summary with A = rho^len != 0 (own A, J planes) |
+    // 1 exact-entry summary (full planes) - anything but 0 sends the (tile, candidate)'s assembly down the sequential walk
+    if (lane < kLeanNC && cand_of(lane) < ncand)
+      LG.flags[((size_t)j * G.ntile + tile) * W.ncp + cand_of(lane)] = lean == 1 ? 0 : (lean == 2 ? 2 : 1);
+    if (!lean) {
+      // ---- the chunk does not qualify for the converged-entry summary: exact entry, kHeadNCL candidates at a time,
+      // stored field by field (these waves put nothing into the tile)
+      for (int h = 0; h < kLeanNC / kHeadNCL; ++h) {
+        double sq[kHeadNCL];
 #pragma unroll
-    for (int c = 0; c < kHeadNCL; ++c) sq[c] = sqf(h * kHeadNCL + c);
-    NllElem<float> o4[kHeadNCL];
-    nll_summarize_chunk<float, kHeadNCL, UNIT>(ld, t0, len, r_n, a_n, c_n, sq, o4, false);
-    if (!chain_ok) continue;
-    if (w == 0 && h == 0) W.xr[(size_t)j * G.N + n] = o4[0].xref;
+        for (int c = 0; c < kHeadNCL; ++c) sq[c] = sqf(h * kHeadNCL + c);
+        NllElem<float> o4[kHeadNCL];
+        nll_summarize_chunk<float, kHeadNCL, UNIT>(ld, t0, len, r_n, a_n, c_n, sq, o4, false);
+        if (!chain_ok) continue;
+        if (w == 0 && h == 0) W.xr[(size_t)j * G.N + n] = o4[0].xref;
 #pragma unroll
-    for (int c = 0; c < kHeadNCL; ++c) {
-      const int ci = cand_of(h * kHeadNCL + c);
-      if (ci < G.n_cand) store_full(j, ci, n, o4[c]);
+        for (int c = 0; c < kHeadNCL; ++c) {
+          const int ci = cand_of(h * kHeadNCL + c);
+          if (ci < G.n_cand) store_full(j, ci, n, o4[c]);
+        }
+      }
     }
   }
-  GRID_STAMP_END(3);
+  // ---- the block's output tile (every wave of the block arrives here)
+  __syncthreads();                                                     // the stashes are dead
+  {
+    float* tb = reinterpret_cast<float*>(lds);                         // b   [64][kTilePitch]
+    float* te = tb + 64 * kTilePitch;                                  // eta [64][kTilePitch]
+    double* tl = lds + (2 * 64 * kTilePitch * 4 + 7) / 8;              // ell [64][kTilePitch]
+    if (lean) {
+#pragma unroll
+      for (int c = 0; c < kLeanNC; ++c) {
+        if (c >= nvalid) continue;
+        tb[lane * kTilePitch + cand_of(c)] = keep.B[c];
+        te[lane * kTilePitch + cand_of(c)] = keep.Eta[c];
+        tl[lane * kTilePitch + cand_of(c)] = keep.Ell[c];
+      }
+    }
+    if (lane == 0) tile_valid[w] = lean != 0;
+    __syncthreads();
+    // whole rows out (wave w: chains 16 w .. 16 w + 15; lane = candidate, whose wave is candidate % ngrp16)
+    if (lane < ncand && tile_valid[lane % stride16]) {
+#pragma unroll 4
+      for (int i = 0; i < 64 / kLeanWaves; ++i) {
+        const int ch = w * (64 / kLeanWaves) + i;
+        const int nn = tile * 64 + ch;
+        if (nn >= G.N) break;                                          // (wave-uniform)
+        const size_t o = ((size_t)j * G.N + nn) * W.ncp + lane;
+        W.b[o] = tb[ch * kTilePitch + lane];
+        W.eta[o] = te[ch * kTilePitch + lane];
+        W.ell[o] = tl[ch * kTilePitch + lane];
+      }
+    }
+  }
+  GRID_STAMP_END(lean ? 1 : 3);
 }
 
 // ---- assembly of the grid kernel's summaries, argmin included (round 5) ---------------------------------------------

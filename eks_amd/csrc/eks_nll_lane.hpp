@@ -705,9 +705,9 @@ EKS_HD LeanConst lean_const(double r_d, double a_d, double c_d, double sq) {
   return k;
 }
 
-// A lean summary leaves the lane through a SINK as soon as each field is known (the kernel's sink stores straight
-// to the summary planes; nothing is carried in registers across the frame loops):
-//   sink.xref(x) | sink.eta(k, v) | sink.aj(k, A, J) (only for a summary with A != 0) | sink.b(k, v) | sink.ell(k, v)
+// A lean summary leaves the lane through a SINK; nothing is carried in registers across the frame loops (eta, known
+// after pass 1, waits in the stash):
+//   sink.xref(x) | sink.aj(k, A, J) (only for a summary with A != 0) | at the end: sink.eta(k, v), sink.b(k, v), sink.ell(k, v)
 template <int NC>
 struct LeanOut {                      // a sink that just keeps the fields (host simulator, micro-benchmarks)
   float A[NC], B[NC], Eta[NC], J[NC];
@@ -750,9 +750,8 @@ EKS_HD int nll_lean_chunk(const LD& ld, int t0, int len, double r_d, double a_d,
       const LeanConst c = lean_const<UNIT>(r_d, a_d, c_d, sq(k));
       stash[(4 * k + 0) * stride] = c.g;
       stash[(4 * k + 1) * stride] = c.rg;
-      stash[(4 * k + 2) * stride] = c.cg;
-      stash[(4 * k + 3) * stride] = c.logS;
-      rr[h] = c.rho;
+      stash[(4 * k + 2) * stride] = c.cg;        // (row 4 k + 3 parks eta from the end of pass 1 to the end of the chunk;
+      rr[h] = c.rho;                             //  log S_inf = -log g is formed again there)
       const float nl = -logf(fmaxf(fabsf(c.rho), 1e-30f));
       ok = ok && fabsf(c.rho) < 1.f && 2.f * (float)t0 * nl > 46.f;
     }
@@ -856,7 +855,7 @@ EKS_HD int nll_lean_chunk(const LD& ld, int t0, int len, double r_d, double a_d,
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
       const float cg = stash[(4 * k + 2) * stride];
-      out.eta(k, s12[k / 2][k & 1] * cg);
+      stash[(4 * k + 3) * stride] = s12[k / 2][k & 1] * cg;
       if (alive) {
         const float rho = rho2[k / 2][k & 1], w = w2[k / 2][k & 1];
         const bool live_k = !(fabsf(w) < kDeadA);      // (a pair that left the alive set keeps a stale, dead rho^t)
@@ -950,7 +949,9 @@ EKS_HD int nll_lean_chunk(const LD& ld, int t0, int len, double r_d, double a_d,
   // ---- finish (nll_lane_finish / recover_mean of the general lane body, phase 2 throughout)
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
-    const float g = stash[(4 * k + 0) * stride], rg = stash[(4 * k + 1) * stride], logS = stash[(4 * k + 3) * stride];
+    const float g = stash[(4 * k + 0) * stride], rg = stash[(4 * k + 1) * stride];
+    const float logS = -fast_log(g);
+    out.eta(k, stash[(4 * k + 3) * stride]);
     const float dl = dk2[k / 2][k & 1];
     if (UNIT) {
       out.b(k, yprev - rg * dl);
