@@ -19,8 +19,9 @@ ONE session of the workload's shape, its keypoints dealt to the GPUs (configs[2]
 per GPU on 8 GPUs); `--gather-outputs` adds a second timed loop that also all-gathers ms / Vs to
 every rank (compute + gather beside compute only).  Rank 0 prints ONE JSON line: `value` is the
 whole-job rate with inputs resident in HBM; `roofline` is the step's DOMINANT (longest) kernel - on the
-headline workload the VALU-bound NLL grid kernel, with its HBM view and counter traffic beside it -
-`roofline_hbm_kernel` the smoother's HBM-bound replay kernel, `cpu_baseline` the C port of the reference
+headline workload since round 5 the smoother's HBM-bound replay kernel (`frac` = `frac_hbm` = achieved / 8 TB/s, counter
+traffic beside it), with the VALU-bound NLL grid kernel as `roofline_valu_kernel` (whichever of the two is longer on
+the run is `roofline`; the other keeps its own key) and `whole_step_frac` for the step - `cpu_baseline` the C port of the reference
 recursion on the host cores, `cpu_baseline_numpy` the NumPy restatement, `host_boundary` the same
 step through host arrays (PCIe included; never `value`), `ranks` who ran where (rank, device, PCI address,
 backend: under RCCL the ranks must sit on distinct GPUs or the run aborts).  A `parity_vs_cpu_port` figure
@@ -892,9 +893,10 @@ def main():
                 t_nll = float(np.mean(nll_live)) * 1e-3
                 nll_bytes = NLL_BYTES_PER_UNIT * local_units
                 ntraffic, ntraffic_src = measured_traffic('diag_nll_grid_kernel') if headline else (None, None)
-                out['roofline'] = {
+                valu_roof = {
                     'bound': 'valu', 'kernel': 'diag_nll_grid_kernel', 'unit': 'TFLOP/s',
                     'achieved': flops / t_nll / 1e12, 'peak': 157.3, 'frac': flops / t_nll / 1e12 / 157.3,
+                    'frac_hbm': nll_bytes / t_nll / 1e9 / HBM_PEAK_GBS,
                     'kernel_avg_ms': float(np.mean(nll_live)), 'launches_timed': len(nll_live),
                     'kernel_avg_ms_source': 'HIP events on the launch stream, every launch inside the timed regions',
                     'algorithmic_flops_per_launch': flops,
@@ -905,13 +907,22 @@ def main():
                                  'achieved_GBps': nll_bytes / t_nll / 1e9,
                                  'frac_of_hbm_peak': nll_bytes / t_nll / 1e9 / HBM_PEAK_GBS},
                     'share_of_step': float(np.mean(nll_live)) / (1e3 * dt / args.steps),
-                    'note': 'the longest kernel of the step; useful FMA flops only (2 per frame x chain x candidate) '
-                            'against the fp32 vector peak (157.3 TFLOP/s = 2 cycles per v_fma_f32 at 2.4 GHz); '
-                            'tools/micro/fma_rate.hip sustains 89 (2 waves per SIMD) to 113 (6 waves) TFLOP/s on this '
-                            'dependency structure at the 2.04-2.17 GHz the chip holds under it',
-                    **stage_info}
-                out['roofline_hbm_kernel'] = hbm_roof
+                    'note': 'ALGORITHMIC FMA flops (2 per frame x chain x candidate: what the loss of 64 candidates costs '
+                            'by the recursion) against the fp32 vector peak (157.3 TFLOP/s = 2 cycles per v_fma_f32 at '
+                            '2.4 GHz).  Round 5: the kernel ISSUES fewer - the candidates whose pole is below 0.345 share 16 '
+                            'lag sums per chain and chunk (36 of 64 on this shape: ~81 FMAs per chain-frame instead of '
+                            '128); it stays bound by the packed FMAs it issues at the 1.7-1.9 GHz the chip holds under them'}
+                hbm_roof['frac_hbm'] = hbm_roof['frac']
+                hbm_roof['share_of_step'] = k3 / (1e3 * dt / args.steps)
+                # `roofline` is the step's DOMINANT (longest) kernel, whichever that is on this run
+                if k3 >= float(np.mean(nll_live)):
+                    out['roofline'] = {**hbm_roof, **stage_info}
+                    out['roofline_valu_kernel'] = valu_roof
+                else:
+                    out['roofline'] = {**valu_roof, **stage_info}
+                    out['roofline_hbm_kernel'] = hbm_roof
             else:
+                hbm_roof['frac_hbm'] = hbm_roof['frac']
                 out['roofline'] = {**hbm_roof, **stage_info}
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libeks_hip.so')
 SOURCES = ['eks_api.hip', 'eks_diag.hip', 'eks_diag_nll.hip', 'eks_dense.hip', 'eks_dense_wave.hip', 'eks_dense_wide.hip', 'eks_loss.hip',
-           'eks_loss_ar1.hip', 'eks_misc.hip', 'eks_multicam.hip', 'eks_profile.hip']
+           'eks_loss_ar1.hip', 'eks_misc.hip', 'eks_multicam.hip', 'eks_profile.hip', 'eks_host.hip']
 ARCH = 'gfx950'
 
 
@@ -99,7 +99,7 @@ def build(force: bool = False, verbose: bool = False, prove: bool = True) -> str
     link_digest = _digest(objs, [])
     relinked = bool(jobs) or force or not os.path.exists(LIB) or _stamp(LIB) != link_digest
     if relinked:
-        run([cc, '-shared', '-fPIC', f'--offload-arch={ARCH}', *objs, '-o', LIB])
+        run([cc, '-shared', '-fPIC', f'--offload-arch={ARCH}', *objs, '-lpthread', '-o', LIB])
         with open(LIB + '.sha256', 'w') as f:
             f.write(link_digest)
     proof = None

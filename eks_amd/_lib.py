@@ -70,6 +70,10 @@ SIGNATURES = {
     'eks_warmup': (ctypes.c_int, [c_uint32, c_void_p]),
     'eks_profile_enable': (ctypes.c_int, [ctypes.c_int]),
     'eks_knobs_reload': (ctypes.c_int, []),
+    'eks_csv_read_numeric': (ctypes.c_int, [c_char_p, c_int32, c_void_p, ctypes.c_int64, c_void_p, c_void_p, c_void_p,
+                                            c_int32, c_int32]),
+    'eks_host_gather_cols': (ctypes.c_int, [c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                            c_void_p, c_int32]),
     'eks_profile_drain': (ctypes.c_int, [c_void_p, c_size_t, c_void_p, c_int32]),
     'eks_ensemble': (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32,
                                     c_float, c_void_p, c_void_p]),

@@ -37,10 +37,25 @@ def _torch():
 
 _PINNED_CAP_BYTES = int(os.environ.get('EKS_PINNED_CAP_BYTES', 1 << 30))
 _pinned_live = [0]          # bytes of page-locked result buffers callers still hold
+# The host layer's process-wide state (this counter - also touched from finalisers, on whatever thread the garbage
+# collector runs - and the per-device side streams below) is guarded: several threads may drive sessions, each on its own
+# torch stream (INTEGRATION.md "Threads"; tests/test_gpu_drivers.py::test_two_threads_two_streams...).
+import threading
+_state_lock = threading.Lock()
 
 
 def _release_pinned(nbytes: int) -> None:
-    _pinned_live[0] -= nbytes
+    with _state_lock:
+        _pinned_live[0] -= nbytes
+
+
+def _pinned_reserve(nbytes: int) -> bool:
+    """Count nbytes of page-locked results against the cap; False (nothing counted) beyond it."""
+    with _state_lock:
+        if _pinned_live[0] + nbytes > _PINNED_CAP_BYTES:
+            return False
+        _pinned_live[0] += nbytes
+        return True
 
 
 def _pinned_empty(shape, dtype):
@@ -62,11 +77,12 @@ def _to_host(*tensors, pinned: bool | None = None):
     nbytes = sum(t.numel() * t.element_size() for t in tensors)
     if pinned is None:
         pinned = not os.environ.get('EKS_PAGEABLE_D2H')
-    if not pinned or nbytes > (2 << 30) or _pinned_live[0] + nbytes > _PINNED_CAP_BYTES:
+    if not pinned or nbytes > (2 << 30) or not _pinned_reserve(nbytes):
         return tuple(t.cpu().numpy() for t in tensors)
     try:
         host = [_pinned_empty(t.shape, t.dtype) for t in tensors]
     except RuntimeError:            # page-locked memory exhausted or unavailable: plain copies
+        _release_pinned(nbytes)
         return tuple(t.cpu().numpy() for t in tensors)
     for h, t in zip(host, tensors):
         h.copy_(t, non_blocking=True)
@@ -77,8 +93,7 @@ def _to_host(*tensors, pinned: bool | None = None):
         arr = h.numpy()
         n = h.numel() * h.element_size()
         owner = arr.base if arr.base is not None else h
-        _pinned_live[0] += n
-        weakref.finalize(owner, _release_pinned, n)
+        weakref.finalize(owner, _release_pinned, n)            # (reserved above)
         out.append(arr)
     return tuple(out)
 
@@ -178,14 +193,16 @@ def constant_R_from_timevarying(R_t_np: np.ndarray, min_var: float = 1e-4) -> np
 class _DeviceProblem:
     """Inputs of run_kalman_smoother on the device, frame-major."""
 
-    def __init__(self, ys, m0s, S0s, As, Cs, Qs, ensemble_vars):
+    def __init__(self, ys, m0s, S0s, As, Cs, Qs, ensemble_vars, flags=None):
         torch = _torch()
         self.dev = hip_ops.require_gpu()
         host = {k: np.ascontiguousarray(_to_numpy(v, np.float64))
                 for k, v in dict(m0=m0s, S0=S0s, A=As, C=Cs, Q=Qs).items()}
         self.K, self.D = host['m0'].shape
         self.O = host['C'].shape[1]
-        self.flags = hip_ops.model_flags(host['S0'], host['A'], host['C'], host['Q'])
+        # (the tiled host path decides the model's flags ONCE, over all keypoints: a session of which only some keypoints
+        #  are diagonal or well conditioned must not take different kernels in different tiles)
+        self.flags = hip_ops.model_flags(host['S0'], host['A'], host['C'], host['Q']) if flags is None else int(flags)
         # the five parameter arrays go up as ONE copy (an upload of a few hundred bytes costs ~19 us of host time
         # whatever its size: five of them were a fifth of a 2 000-frame session's whole call)
         keys = ('m0', 'S0', 'A', 'C', 'Q')
@@ -514,12 +531,13 @@ _TILE_STREAMS: dict = {}
 
 
 def _tile_streams(dev):
-    """Three side streams per device, created once: torch's caching allocator keeps a pool per stream, so streams
+    """Four side streams per device and calling thread (three for the tiles' pipeline, one for the variances' upload), created once: torch's caching allocator keeps a pool per stream, so streams
     made per call would hipMalloc every tile's buffers afresh (measured: 200 - 400 ms per call instead of 15)."""
-    key = dev.index if dev.index is not None else _torch().cuda.current_device()
-    if key not in _TILE_STREAMS:
-        _TILE_STREAMS[key] = [_torch().cuda.Stream(device=dev) for _ in range(3)]
-    return _TILE_STREAMS[key]
+    key = (dev.index if dev.index is not None else _torch().cuda.current_device(), threading.get_ident())
+    with _state_lock:                      # (a set per device AND calling thread: two threads' pipelines do not share)
+        if key not in _TILE_STREAMS:
+            _TILE_STREAMS[key] = [_torch().cuda.Stream(device=dev) for _ in range(4)]
+        return _TILE_STREAMS[key]
 
 
 _TILE_ADAM = False
@@ -539,6 +557,9 @@ def _host_tiles(ys, ensemble_vars, K, T, O, D, vs_diag, blocks, h_fn, return_dev
         return None
     if blocks and any(len(b) != 1 for b in blocks):
         return None
+    if blocks:
+        _block_csr(blocks, K)                 # (what the untiled call would refuse - a list that does not partition the
+                                              #  keypoints - is refused here too, before anything is cut)
     per_kp = T * (2 * O + D + (D if vs_diag else D * D)) * 4
     if K * per_kp < _TILE_MIN_BYTES or K < 4:
         return None
@@ -570,44 +591,66 @@ def _run_tiled_from_host(tiles, ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frame
         raise ValueError('Not enough frames to compute temporal differences.')
     vshape = (K, T, D) if vs_diag else (K, T, D, D)
     nbytes = (K * T * D + int(np.prod(vshape))) * 4
-    pinned = not os.environ.get('EKS_PAGEABLE_D2H') and nbytes <= (2 << 30) and _pinned_live[0] + nbytes <= _PINNED_CAP_BYTES
+    pinned = not os.environ.get('EKS_PAGEABLE_D2H') and nbytes <= (2 << 30) and _pinned_reserve(nbytes)
     try:
         ms_h = torch.empty((K, T, D), dtype=torch.float32, pin_memory=pinned)
         Vs_h = torch.empty(vshape, dtype=torch.float32, pin_memory=pinned)
     except RuntimeError:
+        if pinned:
+            _release_pinned(nbytes)
         pinned = False
         ms_h = torch.empty((K, T, D), dtype=torch.float32)
         Vs_h = torch.empty(vshape, dtype=torch.float32)
     sp = None if smooth_param is None or isinstance(smooth_param, (int, float)) else \
         np.broadcast_to(np.asarray(smooth_param, dtype=float), (K,))
+    flags = hip_ops.model_flags(par['S0'], par['A'], par['C'], par['Q'])      # once, for every tile
     # The ensemble variances arrive (T, K, O), frame-major: a keypoint tile of them is a strided view on the host
-    # (gathering one costs 1.6 - 5 ms of host time per 25 MB, three to ten times its transfer), so they go up whole,
-    # once, and are cut on the device.
+    # (gathering one costs 1.6 - 5 ms of host time per 25 MB, three to ten times its transfer) - but a TIME slab of them
+    # is contiguous.  They go up in slabs on their own stream while the first keypoint tiles of ys go up on theirs,
+    # into one frame-major device array that is cut per keypoint tile on the device; a tile's kernels wait for the
+    # last slab (round 4 sent the whole array up before the first tile started: 3.6 ms of BASELINE configs[2]'s 16.6).
     cur = torch.cuda.current_stream(dev)
-    ev_d = torch.as_tensor(np.ascontiguousarray(ev_h), device=dev)
     streams = _tile_streams(dev)
+    up = streams[-1]
     for st in streams:
         st.wait_stream(cur)
-    s_parts, infos, keep = [], [], []
-    for i, (k0, k1) in enumerate(tiles):
-        st = streams[i % len(streams)]
-        with torch.cuda.stream(st):
-            y_t = torch.as_tensor(np.ascontiguousarray(ys_h[k0:k1]), device=dev)               # (Kt,T,O), caller's dtype
-            v_t = ev_d[:, k0:k1]                                                                # (T,Kt,O) view
-            res = run_kalman_smoother(
-                y_t, par['m0'][k0:k1], par['S0'][k0:k1], par['A'][k0:k1], par['C'][k0:k1], par['Q'][k0:k1], v_t,
-                s_frames=s_frames, smooth_param=(smooth_param if sp is None else list(sp[k0:k1])), blocks=None,
-                lr=lr, s_bounds_log=s_bounds_log, tol=tol, safety_cap=safety_cap, s_mode=s_mode, n_grid=n_grid,
-                vs_diag=vs_diag, return_device=True, return_info=True, _s_on_device=True)
-            s_dev, ms_d, Vs_d, info = res
-            ms_h[k0:k1].copy_(ms_d.contiguous(), non_blocking=True)      # (Kt,T,D) views of the frame-major buffers ->
-            Vs_h[k0:k1].copy_(Vs_d.contiguous(), non_blocking=True)      # the reference's layout on the device, then down
-            s_parts.append(s_dev)
-            infos.append(info)
-            keep.append((y_t, v_t, ms_d, Vs_d))
-            ev_d.record_stream(st)
-    for st in streams:
-        cur.wait_stream(st)
+    ev_c = ev_h if ev_h.flags['C_CONTIGUOUS'] else np.ascontiguousarray(ev_h)
+    ev_d = torch.empty((T, K, O), dtype=torch.as_tensor(ev_c[:1]).dtype, device=dev)
+    n_slabs = max(1, min(8, (ev_c.nbytes + (24 << 20) - 1) // (24 << 20)))
+    slab = (T + n_slabs - 1) // n_slabs
+    with torch.cuda.stream(up):
+        for t0 in range(0, T, slab):
+            ev_d[t0:t0 + slab].copy_(torch.as_tensor(ev_c[t0:t0 + slab]), non_blocking=True)
+        ev_ready = torch.cuda.Event()
+        ev_ready.record(up)
+    work = streams[:-1]
+    s_parts, infos = [], []
+    try:
+        for i, (k0, k1) in enumerate(tiles):
+            st = work[i % len(work)]
+            with torch.cuda.stream(st):
+                y_t = torch.as_tensor(np.ascontiguousarray(ys_h[k0:k1]), device=dev)           # (Kt,T,O), caller's dtype
+                st.wait_event(ev_ready)
+                v_t = ev_d[:, k0:k1]                                                            # (T,Kt,O) view
+                res = run_kalman_smoother(
+                    y_t, par['m0'][k0:k1], par['S0'][k0:k1], par['A'][k0:k1], par['C'][k0:k1], par['Q'][k0:k1], v_t,
+                    s_frames=s_frames, smooth_param=(smooth_param if sp is None else list(sp[k0:k1])), blocks=None,
+                    lr=lr, s_bounds_log=s_bounds_log, tol=tol, safety_cap=safety_cap, s_mode=s_mode, n_grid=n_grid,
+                    vs_diag=vs_diag, return_device=True, return_info=True, _s_on_device=True, _model_flags=flags)
+                s_dev, ms_d, Vs_d, info = res
+                ms_c, Vs_c = ms_d.contiguous(), Vs_d.contiguous()    # (Kt,T,D) views of the frame-major buffers ->
+                ms_h[k0:k1].copy_(ms_c, non_blocking=True)           # the reference's layout on the device, then down
+                Vs_h[k0:k1].copy_(Vs_c, non_blocking=True)
+                s_parts.append(s_dev)
+                infos.append({k: v for k, v in info.items()})
+                # nothing of the tile is kept alive past this point: the copies above are enqueued on `st`, and the
+                # caching allocator hands a block back only to work enqueued on the same stream later (a call just over
+                # the tiling threshold then peaks at a few tiles' worth of device memory, not at the untiled footprint)
+                del y_t, v_t, res, ms_d, Vs_d, ms_c, Vs_c
+                ev_d.record_stream(st)
+    finally:
+        for st in streams:                       # (also when a tile raised: the side streams rejoin the caller's)
+            cur.wait_stream(st)
     cur.synchronize()
     s_finals = np.concatenate([np.asarray(s.cpu().numpy(), dtype=float) for s in s_parts])
     out_ms, out_Vs = ms_h.numpy(), Vs_h.numpy()
@@ -615,8 +658,7 @@ def _run_tiled_from_host(tiles, ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frame
         import weakref
         for arr, h in ((out_ms, ms_h), (out_Vs, Vs_h)):
             n = h.numel() * h.element_size()
-            _pinned_live[0] += n
-            weakref.finalize(arr.base if arr.base is not None else h, _release_pinned, n)
+            weakref.finalize(arr.base if arr.base is not None else h, _release_pinned, n)     # (reserved above)
     out = (s_finals, out_ms, out_Vs)
     if return_info:
         out = out + (dict(mode='tiled', tiles=list(tiles), tile_info=infos),)
@@ -632,7 +674,7 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
                         s_bounds_log: tuple = (-8.0, 8.0), tol: float = 1e-2, safety_cap: int = 300,
                         h_fn: Callable | None = None, *, s_mode: str = 'adam', n_grid: int = 64,
                         vs_diag: bool = False, return_device: bool = False, x_init=None,
-                        return_info: bool = False, _s_on_device: bool = False):
+                        return_info: bool = False, _s_on_device: bool = False, _model_flags: int | None = None):
     """Choose (or optimise) the process-noise scale s per keypoint, then run the Kalman filter +
     RTS smoother.  Drop-in for the reference's eks/core.py:159-302.
 
@@ -670,7 +712,7 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
             if tiles and len(tiles) > 1:
                 return _run_tiled_from_host(tiles, ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames, smooth_param,
                                             lr, s_bounds_log, tol, safety_cap, s_mode, n_grid, vs_diag, return_info)
-    P = _DeviceProblem(ys, m0s, S0s, As, Cs, Qs, ensemble_vars)
+    P = _DeviceProblem(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, flags=_model_flags)
     K = P.K
     if not blocks:
         blocks = [[k] for k in range(K)]

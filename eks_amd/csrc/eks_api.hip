@@ -31,6 +31,8 @@ const char* eks_status_string(int status) {
     case EKS_ERR_SHAPE: return "bad shape";
     case EKS_ERR_UNSUPPORTED: return "unsupported (D, O) / flag combination";
     case EKS_ERR_WORKSPACE: return "workspace missing or too small";
+    case EKS_CSV_IO: return "file cannot be opened or mapped";
+    case EKS_CSV_FALLBACK: return "not a purely numeric table: read it with pandas";
     default: return status <= EKS_ERR_HIP_BASE ? hipGetErrorString((hipError_t)(EKS_ERR_HIP_BASE - status))
                                                : "unknown status";
   }

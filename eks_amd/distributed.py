@@ -161,7 +161,12 @@ def check_distinct_devices(identities: list[dict]) -> None:
         return
     seen = {}
     for d in identities:
-        key = (d['host'], d.get('pci_bus_id') or d.get('device_uuid') or d.get('device'))
+        ident = d.get('pci_bus_id') or d.get('device_uuid')
+        if not ident:
+            # neither a PCI address nor a uuid: ranks isolated with HIP_VISIBLE_DEVICES all report ordinal 0 - nothing
+            # here positively identifies a duplicate, so nothing is refused
+            continue
+        key = (d['host'], ident)
         if key in seen:
             raise RuntimeError(f'ranks {seen[key]} and {d["rank"]} drive the same GPU {key}: RCCL needs one GPU per '
                                'rank (launch with one process per device; LOCAL_RANK selects it)')

@@ -64,7 +64,6 @@ def warmup(what: str = 'all', background: bool = False):
     mask = 0
     for u in units:
         mask |= _lib.WARM[u]
-        _warm_done.add(u)
     if not mask:
         return {} if not background else _warm_thread
     dev = torch.cuda.current_device()
@@ -73,6 +72,7 @@ def warmup(what: str = 'all', background: bool = False):
         torch.cuda.set_device(dev)
         ms = (ctypes.c_float * 9)()
         _lib.check(lib.eks_warmup(mask, ms), 'eks_warmup')
+        _warm_done.update(units)                     # (only once the units really are loaded)
         return {u: float(ms[i]) for i, u in enumerate(_lib.WARM) if mask & _lib.WARM[u]}
 
     if background:
@@ -244,13 +244,30 @@ def np_nanstd_rows(x):
     if n > 8192 or (n + 2 * len(leaves)) * 4 > 64 * 1024:
         return None
     key = (n, x.device)
-    if key not in _NP_SUM_DEVICE:
+    first = key not in _NP_SUM_DEVICE
+    if first:
         _NP_SUM_DEVICE[key] = (torch.as_tensor(leaves, device=x.device), torch.as_tensor(ops, device=x.device))
     lv, op = _NP_SUM_DEVICE[key]
+    if lv is None:
+        return None
     out = torch.empty(K, dtype=torch.float32, device=x.device)
     rc = lib.eks_np_nanstd_rows(K, n, _ptr(x), _ptr(lv), len(leaves), _ptr(op) if len(ops) else None, len(ops),
                                 _ptr(out), _stream())
     _lib.check(rc, 'eks_np_nanstd_rows')
+    if first:
+        # The kernel hard-codes THIS numpy's pairwise float32 summation (block of 128, eight accumulators): a numpy
+        # build that reduces in another order would seed the optimiser differently from the host path without anything
+        # failing.  Once per (row length, device): one row against numpy itself; on a mismatch the host reduces.
+        import numpy as np
+        import warnings
+        row = x[:1].cpu().numpy()
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', RuntimeWarning)
+            ref = np.nanstd(row, axis=1)
+        got = out[:1].cpu().numpy()
+        if not (np.array_equal(got, ref) or (np.isnan(got).all() and np.isnan(ref).all())):
+            _NP_SUM_DEVICE[key] = (None, None)
+            return None
     return out
 
 

@@ -21,7 +21,7 @@ import pandas as pd
 
 from .marker_array import MarkerArray, input_dfs_to_markerArray
 from .multicam_smoother import ensemble_kalman_smoother_multicam
-from .utils import convert_lp_dlc
+from .utils import convert_lp_dlc, write_prediction_csv
 
 __all__ = ['fit_eks_multicam_ibl_paw', 'remove_camera_means', 'add_camera_means', 'pca']
 
@@ -116,5 +116,5 @@ def fit_eks_multicam_ibl_paw(input_source: str, save_dir: str, smooth_param: flo
         inflate_vars_kwargs={'likelihoods': None})
     os.makedirs(save_dir, exist_ok=True)
     for cam, df in zip(CAMERAS, camera_dfs):
-        df.to_csv(os.path.join(save_dir, f'multicam_{cam}_results.csv'))
+        write_prediction_csv(df, os.path.join(save_dir, f'multicam_{cam}_results.csv'))
     return camera_dfs, s_finals, per_cam, BODYPARTS

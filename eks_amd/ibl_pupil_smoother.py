@@ -27,7 +27,7 @@ import pandas as pd
 from . import hip_ops
 from .core import _to_numpy, _torch, ensemble
 from .marker_array import MarkerArray, input_dfs_to_markerArray
-from .utils import format_data, frame_spans, make_dlc_pandas_index
+from .utils import format_data, frame_spans, make_dlc_pandas_index, write_prediction_csv
 
 __all__ = ['fit_eks_pupil', 'ensemble_kalman_smoother_ibl_pupil', 'get_pupil_location',
            'get_pupil_diameter', 'add_mean_to_array', 'run_pupil_kalman_smoother',
@@ -110,7 +110,7 @@ def fit_eks_pupil(input_source, save_file: str, smooth_params: list | None = Non
         marker_array=marker_array, keypoint_names=bodypart_list, smooth_params=smooth_params,
         s_frames=s_frames, avg_mode=avg_mode, var_mode=var_mode)
     os.makedirs(os.path.dirname(save_file), exist_ok=True)
-    df.to_csv(save_file)
+    write_prediction_csv(df, save_file)
     logger.info('dataframes successfully converted to CSV')
     return df, s_finals, input_dfs, bodypart_list
 

@@ -28,7 +28,7 @@ from .marker_array import (MarkerArray, input_dfs_to_markerArray, mA_to_stacked_
                            stacked_array_to_mA)
 from .stats import (compute_mahalanobis, compute_pca, factor_analysis_from_moments, pca_from_moments,
                     pca_sign_rule)
-from .utils import center_predictions, format_data, make_dlc_pandas_index
+from .utils import center_predictions, format_data, make_dlc_pandas_index, write_prediction_csv
 
 __all__ = ['fit_eks_mirrored_multicam', 'fit_eks_multicam', 'ensemble_kalman_smoother_multicam']
 
@@ -70,7 +70,7 @@ def fit_eks_mirrored_multicam(input_source, save_file: str, bodypart_list: list 
             names=df.columns.names)
     final_df = pd.concat(camera_dfs, axis=1) if len(camera_dfs) > 1 else camera_dfs[0]
     os.makedirs(os.path.dirname(save_file), exist_ok=True)
-    final_df.to_csv(f'{save_file}')
+    write_prediction_csv(final_df, f'{save_file}')
     return final_df, s_finals, input_dfs, bodypart_list
 
 
@@ -102,9 +102,9 @@ def fit_eks_multicam(input_source, save_dir: str, bodypart_list: list | None = N
         camgroup=camgroup)
     os.makedirs(save_dir, exist_ok=True)
     for cam, df in zip(camera_names, camera_dfs):
-        df.to_csv(os.path.join(save_dir, f'multicam_{cam}_results.csv'))
+        write_prediction_csv(df, os.path.join(save_dir, f'multicam_{cam}_results.csv'))
     if save_3d_outputs and calibration is not None:
-        df_3d.to_csv(os.path.join(save_dir, 'multicam_3d_results.csv'))
+        write_prediction_csv(df_3d, os.path.join(save_dir, 'multicam_3d_results.csv'))
     return camera_dfs, s_finals, input_dfs, bodypart_list, df_3d
 
 

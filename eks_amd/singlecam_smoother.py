@@ -16,7 +16,7 @@ import pandas as pd
 
 from .core import ensemble, run_kalman_smoother
 from .marker_array import MarkerArray, input_dfs_to_markerArray
-from .utils import center_predictions, format_data, make_dlc_pandas_index
+from .utils import center_predictions, format_data, make_dlc_pandas_index, write_prediction_csv
 
 __all__ = ['fit_eks_singlecam', 'ensemble_kalman_smoother_singlecam']
 
@@ -41,7 +41,7 @@ def fit_eks_singlecam(input_source, save_file: str, bodypart_list: list | None =
         marker_array=marker_array, keypoint_names=bodypart_list, smooth_param=smooth_param,
         s_frames=s_frames, blocks=blocks, avg_mode=avg_mode, var_mode=var_mode)
     os.makedirs(os.path.dirname(save_file), exist_ok=True)
-    df.to_csv(save_file)
+    write_prediction_csv(df, save_file)
     logger.info('dataframes successfully converted to CSV')
     return df, s_finals, input_dfs, bodypart_list
 

@@ -46,12 +46,81 @@ def convert_lp_dlc(df_lp: pd.DataFrame, keypoint_names, model_name=None) -> pd.D
     return pd.DataFrame(flat, index=df_lp.index)
 
 
+def read_prediction_csv(path: str, n_threads: int | None = None) -> pd.DataFrame:
+    """`pd.read_csv(path, header=[0, 1, 2], index_col=0)` (reference eks/utils.py:188) with the numeric body parsed by
+    the library's own reader (`eks_csv_read_numeric`: mmap, one thread per block of lines, pandas' own decimal ->
+    double conversion restated - the values are pandas' bit for bit, tests/test_csv_ingest.py).  The three header rows
+    still go through pandas (three lines).  Files that hold anything but numbers and missing values, and any file when
+    EKS_PANDAS_CSV is set or the library is not built, are read by pandas as before."""
+    if os.environ.get('EKS_PANDAS_CSV'):
+        return pd.read_csv(path, header=[0, 1, 2], index_col=0)
+    try:
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+    except Exception:                       # no library here (a CPU-only checkout): pandas
+        return pd.read_csv(path, header=[0, 1, 2], index_col=0)
+    if n_threads is None:
+        n_threads = max(1, min(16, os.cpu_count() or 1))
+    n_rows, n_cols = ctypes.c_int64(0), ctypes.c_int32(0)
+    bpath = os.fsencode(path)
+    rc = lib.eks_csv_read_numeric(bpath, 3, None, 0, ctypes.byref(n_rows), ctypes.byref(n_cols), None, 0, n_threads)
+    if rc != 0 or n_cols.value < 2:
+        return pd.read_csv(path, header=[0, 1, 2], index_col=0)
+    head = pd.read_csv(path, header=[0, 1, 2], index_col=0, nrows=0)
+    if len(head.columns) != n_cols.value - 1:
+        return pd.read_csv(path, header=[0, 1, 2], index_col=0)
+    body = np.empty((n_rows.value, n_cols.value), dtype=np.float64)
+    is_int = np.zeros(n_cols.value, dtype=np.uint8)
+    rc = lib.eks_csv_read_numeric(bpath, 3, body.ctypes.data_as(ctypes.c_void_p), body.size, ctypes.byref(n_rows),
+                                  ctypes.byref(n_cols), is_int.ctypes.data_as(ctypes.c_void_p), is_int.size, n_threads)
+    if rc != 0 or not is_int[0]:            # (text somewhere, ragged lines, a non-integer index column: pandas' call)
+        return pd.read_csv(path, header=[0, 1, 2], index_col=0)
+    index = pd.Index(body[:, 0].astype(np.int64), name=head.index.name)
+    df = pd.DataFrame(body[:, 1:], index=index, columns=head.columns)
+    ints = np.flatnonzero(is_int[1:])
+    if ints.size:                           # columns written as integers throughout: int64, as pandas infers
+        df = df.astype({df.columns[i]: np.int64 for i in ints})
+    return df
+
+
+def write_prediction_csv(df: pd.DataFrame, path) -> None:
+    """`df.to_csv(path)` (reference eks/singlecam_smoother.py:98-99, eks/multicam_smoother.py:151-152, :270-275) for
+    the result tables, byte for byte: the header comes from pandas itself (the empty slice's to_csv), every number is
+    Python's own `repr` - the shortest string that reads back as the same double, which is what pandas writes - and a
+    missing value is the empty field.  pandas spends 2.2 us per number in its object-array formatter (13 s for BASELINE
+    configs[1]'s 10 000 x 576 table); `map(repr, row)` does the same text in a quarter of that.  Tables that are not
+    plain float64 / int64 with a plain integer index, and any table when EKS_PANDAS_CSV is set, go through pandas
+    (tests/test_csv_ingest.py compares the bytes)."""
+    plain = (not os.environ.get('EKS_PANDAS_CSV') and len(df) > 0 and df.shape[1] > 0
+             and all(dt == np.float64 or dt == np.int64 for dt in df.dtypes)
+             and df.index.nlevels == 1 and df.index.dtype == np.int64)
+    if not plain:
+        df.to_csv(path)
+        return
+    head = df.iloc[:0].to_csv()
+    idx = df.index.tolist()
+    if all(dt == np.float64 for dt in df.dtypes):
+        vals = df.to_numpy()
+        fmt = (lambda x: '' if x != x else repr(x)) if np.isnan(vals).any() else repr
+        rows = vals.tolist()
+        body = '\n'.join([str(i) + ',' + ','.join(map(fmt, r)) for i, r in zip(idx, rows)])
+    else:
+        cols = [df.iloc[:, c].tolist() for c in range(df.shape[1])]
+        fmt = lambda x: '' if x != x else repr(x)          # (repr of a Python int is its decimal string)
+        body = '\n'.join([str(i) + ',' + ','.join(map(fmt, r)) for i, r in zip(idx, zip(*cols))])
+    with open(path, 'w', newline='') as f:
+        f.write(head)
+        f.write(body)
+        f.write('\n')
+
+
 def _read_prediction_file(path: str):
     if path.endswith('.slp'):
         raise NotImplementedError(
             'SLEAP .slp input needs the sleap_io reader (reference eks/utils.py:72-122); '
             'convert to CSV first - it is outside the accelerated path')
-    raw = pd.read_csv(path, header=[0, 1, 2], index_col=0)
+    raw = read_prediction_csv(path)
     names = get_keypoint_names(raw)
     return convert_lp_dlc(raw, names), names
 

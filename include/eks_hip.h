@@ -35,6 +35,9 @@ typedef struct ihipStream_t* eks_stream_t; /* == hipStream_t */
 #define EKS_ERR_SHAPE (-2)       /* non-positive or inconsistent dimension */
 #define EKS_ERR_UNSUPPORTED (-3) /* (D,O)/flag combination not built */
 #define EKS_ERR_WORKSPACE (-4)   /* workspace missing or too small */
+#define EKS_CSV_IO (-5)          /* eks_csv_read_numeric: the file cannot be opened / mapped */
+#define EKS_CSV_FALLBACK 1       /* eks_csv_read_numeric: not an error - the file holds something other than numbers and
+                                    missing values (quotes, text, ragged lines): let pandas read it */
 #define EKS_ERR_HIP_BASE (-1000) /* -1000 - hipError_t */
 
 /* flags */
@@ -289,6 +292,25 @@ int eks_warmup(uint32_t units, float* ms_per_unit);
  * calls of one process); not to be called while another thread is inside the library.  Returns the
  * number of EKS_* variables found set.  No reference counterpart. ------------------------------ */
 int eks_knobs_reload(void);
+
+/* ---- HOST-side helpers of the boundary (no device code, no stream: they return when done) ------------------------
+ * eks_csv_read_numeric: the numeric body of a prediction CSV - what `pd.read_csv(path, header=[0, 1, 2], index_col=0)`
+ * (reference eks/utils.py:188; the 3 header rows are skip_lines) parses field by field - into out[n_rows][n_cols]
+ * float64, EVERY column including the index column, blank lines skipped, empty fields and pandas' default NA strings
+ * -> NaN, [+-]inf / infinity accepted.  The decimal -> double conversion is pandas' own default (its tokenizer's
+ * precise_xstrtod: <= 17 significant digits, one multiplication / division by a power of ten), so the values are the
+ * ones pandas returns, bit for bit.  out == NULL: size query (n_rows_out, n_cols_out only).  col_is_int (optional,
+ * n_cols bytes): 1 where every field of the column was written as an integer (pandas gives such a column dtype int64).
+ * n_threads: blocks of lines parsed concurrently (std::thread).  Returns EKS_OK, EKS_CSV_FALLBACK (see above; also for
+ * integers beyond 2^53), EKS_CSV_IO, EKS_ERR_NULL, EKS_ERR_WORKSPACE (capacity < n_rows * n_cols). ------------------- */
+int eks_csv_read_numeric(const char* path, int32_t skip_lines, double* out, int64_t capacity, int64_t* n_rows_out,
+                         int32_t* n_cols_out, uint8_t* col_is_int, int32_t col_capacity, int32_t n_threads);
+
+/* eks_host_gather_cols: dst[r][0 .. width) = src[r][col_offset .. col_offset + width) (bytes) for n_rows rows of a
+ * row-major HOST matrix with rows of src_row_bytes, on n_threads threads: a keypoint tile of the frame-major ensemble
+ * variances (T, K, O) (reference eks/core.py:159-177 takes them in that layout) made contiguous for its upload. ---- */
+int eks_host_gather_cols(const void* src, int64_t n_rows, int64_t src_row_bytes, int64_t col_offset_bytes,
+                         int64_t width_bytes, void* dst, int32_t n_threads);
 
 #ifdef __cplusplus
 }

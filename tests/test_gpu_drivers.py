@@ -489,6 +489,57 @@ def test_host_boundary_pipelined_over_keypoint_tiles_equals_the_untiled_call(mod
         np.testing.assert_array_equal(Vd2, np.diagonal(Vs0, axis1=2, axis2=3))
 
 
+@pytest.mark.parametrize('host_arrays', [False, True])
+def test_two_threads_two_streams_equal_the_serial_runs(host_arrays, monkeypatch):
+    """The host layer's threading contract (INTEGRATION.md "Threads"): several threads may drive sessions at once, each
+    on its own torch stream - the C ABI takes the stream per call and owns no state, the host layer's process-wide
+    pieces (the count of page-locked result bytes, the tiled boundary's side streams) are locked / per thread.  Two
+    threads, two sessions (grid search + smooth), through device tensors and through the tiled NumPy boundary: bit
+    for bit the serial results."""
+    import threading
+    import torch
+    from eks_amd import core, synth
+    from eks_amd.core import run_kalman_smoother
+    if host_arrays:
+        monkeypatch.setattr(core, '_TILE_MIN_BYTES', 1 << 20)
+        monkeypatch.setattr(core, '_TILE_TARGET_BYTES', 6 << 20)
+    dev = torch.device('cuda', 0)
+    sessions = []
+    for seed, K in ((41, 80), (42, 72)):
+        y, var = synth.singlecam_observations_torch(9_000, K, seed=seed, device=dev)
+        ys = y.transpose(0, 1).contiguous()
+        eye = np.tile(np.eye(2), (K, 1, 1))
+        S0 = eye * ys.cpu().numpy().var(axis=1)[:, :, None]
+        if host_arrays:
+            sessions.append((ys.cpu().numpy(), np.zeros((K, 2)), S0, eye, eye, eye, var.cpu().numpy()))
+        else:
+            sessions.append((ys, np.zeros((K, 2)), S0, eye, eye, eye, var))
+    kw = dict(s_mode='grid', n_grid=64)
+    serial = [run_kalman_smoother(*a, **kw) for a in sessions]
+    results = [None, None]
+    errors = []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                for _ in range(3):
+                    results[i] = run_kalman_smoother(*sessions[i], **kw)
+            st.synchronize()
+        except Exception as e:            # noqa: BLE001 - reported below
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for got, ref in zip(results, serial):
+        for g, r in zip(got, ref):
+            np.testing.assert_array_equal(np.asarray(g), np.asarray(r))
+
+
 def test_first_call_of_a_fresh_process_is_bounded():
     """the first run_kalman_smoother of a process on the reference's own data size (2 000 frames x
     4 keypoints).  Measured (tools/first_call.py): the library's nine code objects load in 0.7 - 2.6 ms each at their

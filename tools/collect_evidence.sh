@@ -26,7 +26,7 @@ python bench.py --workload ekf > $O/bench_ekf.json 2>/dev/null
 python tools/ekf_time.py > $O/ekf_time.txt 2>&1
 python tools/driver_time.py 2>&1 | grep -E " ms" > $O/driver_time.txt
 python tools/host_path_time.py 2>&1 | grep -v amdgpu > $O/host_path_time.txt
-for m in diag dense; do python tools/first_call.py $m 2>&1 | grep -v amdgpu; EKS_NO_AUTO_WARMUP=1 python tools/first_call.py $m 2>&1 | grep -v amdgpu | sed 's/^/no auto warm-up: /'; done > $O/first_call.txt
+for m in diag dense; do python tools/first_call.py $m 2>&1 | grep -v amdgpu; EKS_AUTO_WARMUP=1 python tools/first_call.py $m 2>&1 | grep -v amdgpu | sed 's/^/auto warm-up (EKS_AUTO_WARMUP=1): /'; done > $O/first_call.txt
 tools/micro/bin/nll_lean2 > $O/nll_lean2.txt 2>&1
 python tools/adam_time.py > $O/adam_time.txt 2>&1
 python tools/dense_adam_time.py > $O/dense_adam_time.txt 2>&1

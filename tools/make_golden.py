@@ -193,8 +193,35 @@ def fly():
     print('fly: T', T, 'K', K, 'V', V, 'M', M, 's_adam', s_a, 'iters', info['iters'])
 
 
+def csv_samples():
+    """The first 40 and last 5 lines of every recording under the reference's data/ (data files of its own tests) and
+    what pandas reads from them: tests/test_csv_ingest.py holds the library's reader to pandas' values on the GPU box,
+    where neither the reference nor its data exist."""
+    import glob
+    import pandas as pd
+    import tempfile
+    texts, names, values = [], [], []
+    for f in sorted(glob.glob(os.path.join(REF, '**', '*.csv'), recursive=True)):
+        lines = open(f).read().split('\n')
+        body = [ln for ln in lines[3:] if ln]
+        keep = lines[:3] + body[:40] + body[-5:]
+        txt = '\n'.join(keep) + '\n'
+        with tempfile.NamedTemporaryFile('w', suffix='.csv', delete=False) as t:
+            t.write(txt)
+        df = pd.read_csv(t.name, header=[0, 1, 2], index_col=0)
+        os.unlink(t.name)
+        texts.append(txt)
+        names.append(os.path.relpath(f, REF))
+        values.append(df.to_numpy(dtype=np.float64))
+    np.savez_compressed(os.path.join(OUT, 'csv_samples.npz'), names=np.array(names), texts=np.array(texts, dtype=object),
+                        **{f'values_{i}': v for i, v in enumerate(values)})
+    print('csv_samples:', len(names), 'files')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ['csv']:
+        return csv_samples()
     if sys.argv[1:] == ['fly']:
         return fly()
     if sys.argv[1:] == ['pupil']:
