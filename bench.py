@@ -115,10 +115,10 @@ def self_launch(args):
     return child.wait()
 
 
-TRAFFIC_FILES = ('r04_traffic.json', 'r03_traffic.json')
+TRAFFIC_FILES = ('r05_traffic.json', 'r04_traffic.json')
 # the sources whose kernels the traffic summary describes: a summary taken before any of them changed
 # is STALE and is not reported (tests/test_abi_surface.py fails on a stale committed summary)
-TRAFFIC_SOURCES = ('eks_diag.hip', 'eks_diag_lane.hpp', 'eks_math.hpp', 'eks_diag_nll.hip', 'eks_nll_lane.hpp')
+TRAFFIC_SOURCES = ('eks_diag.hip', 'eks_diag_lane.hpp', 'eks_math.hpp', 'eks_diag_nll.hip', 'eks_nll_lane.hpp', 'eks_nll_lag.hpp')
 
 
 def kernel_sources_sha16():

@@ -72,6 +72,10 @@ SIGNATURES = {
     'eks_knobs_reload': (ctypes.c_int, []),
     'eks_csv_read_numeric': (ctypes.c_int, [c_char_p, c_int32, c_void_p, ctypes.c_int64, c_void_p, c_void_p, c_void_p,
                                             c_int32, c_int32]),
+    'eks_csv_write_table': (ctypes.c_int, [c_char_p, c_char_p, ctypes.c_int64, c_void_p, c_void_p, ctypes.c_int64, c_int32,
+                                           c_int32]),
+    'eks_format_repr': (ctypes.c_int, [c_void_p, ctypes.c_int64, c_void_p, ctypes.c_int64, c_void_p]),
+    'eks_host_thread_speedup': (c_double, [c_int32]),
     'eks_host_gather_cols': (ctypes.c_int, [c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                             c_void_p, c_int32]),
     'eks_profile_drain': (ctypes.c_int, [c_void_p, c_size_t, c_void_p, c_int32]),

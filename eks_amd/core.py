@@ -524,7 +524,7 @@ def _log_opt(blocks, s_finals, info) -> None:
 
 
 _TILE_MIN_BYTES = int(os.environ.get('EKS_HOST_TILE_MIN_BYTES', 96 << 20))     # below this one untiled call is as fast
-_TILE_TARGET_BYTES = int(os.environ.get('EKS_HOST_TILE_BYTES', 80 << 20))      # transfer volume of one tile (in + out)
+_TILE_TARGET_BYTES = int(os.environ.get('EKS_HOST_TILE_BYTES', 128 << 20))     # transfer volume of one tile (in + out)
 
 
 _TILE_STREAMS: dict = {}
@@ -566,6 +566,13 @@ def _host_tiles(ys, ensemble_vars, K, T, O, D, vs_diag, blocks, h_fn, return_dev
     kt = max(1, min(K // 2, int(round(_TILE_TARGET_BYTES / per_kp))))
     if kt >= 32:
         kt = kt // 32 * 32                    # whole 64-chain tiles of the scalar-chain kernels (D = 2)
+    if os.environ.get('EKS_HOST_TILE_KP'):
+        kt = int(os.environ['EKS_HOST_TILE_KP'])
+        return [(k0, min(K, k0 + kt)) for k0 in range(0, K, kt)]
+    # (measured on BASELINE configs[2], tools/host_boundary_ab.py: equal tiles of 8 / 16 / 32 / 43 / 64 keypoints 30 / 21 /
+    #  14.6 / 15.6 / 15.2 ms - every tile costs ~1 ms of Python and launches on the host, and a first tile twice as large
+    #  delays the first download by what it takes to bring it up; tiles that grow 1.3x from 32: 17.6 ms - the three
+    #  streams then serialise a large tile behind the download of the third before it)
     return [(k0, min(K, k0 + kt)) for k0 in range(0, K, kt)]
 
 
@@ -604,34 +611,78 @@ def _run_tiled_from_host(tiles, ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frame
     sp = None if smooth_param is None or isinstance(smooth_param, (int, float)) else \
         np.broadcast_to(np.asarray(smooth_param, dtype=float), (K,))
     flags = hip_ops.model_flags(par['S0'], par['A'], par['C'], par['Q'])      # once, for every tile
-    # The ensemble variances arrive (T, K, O), frame-major: a keypoint tile of them is a strided view on the host
-    # (gathering one costs 1.6 - 5 ms of host time per 25 MB, three to ten times its transfer) - but a TIME slab of them
-    # is contiguous.  They go up in slabs on their own stream while the first keypoint tiles of ys go up on theirs,
-    # into one frame-major device array that is cut per keypoint tile on the device; a tile's kernels wait for the
-    # last slab (round 4 sent the whole array up before the first tile started: 3.6 ms of BASELINE configs[2]'s 16.6).
+    # The ensemble variances arrive (T, K, O), frame-major: a keypoint tile of them is a strided view on the host.
+    # numpy gathers one in 1.6 - 5 ms per 25 MB (three to ten times its transfer), so round 4 sent the whole array up
+    # before the first tile started (3.6 ms of BASELINE configs[2]'s 16.6); the library's own threaded gather
+    # (eks_host_gather_cols) makes a tile contiguous in a page-locked buffer in a fraction of that, and the variances
+    # travel tile by tile like the observations - the first kernels start after ONE tile's uploads.
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
     cur = torch.cuda.current_stream(dev)
     streams = _tile_streams(dev)
-    up = streams[-1]
     for st in streams:
         st.wait_stream(cur)
     ev_c = ev_h if ev_h.flags['C_CONTIGUOUS'] else np.ascontiguousarray(ev_h)
-    ev_d = torch.empty((T, K, O), dtype=torch.as_tensor(ev_c[:1]).dtype, device=dev)
-    n_slabs = max(1, min(8, (ev_c.nbytes + (24 << 20) - 1) // (24 << 20)))
-    slab = (T + n_slabs - 1) // n_slabs
-    with torch.cuda.stream(up):
-        for t0 in range(0, T, slab):
-            ev_d[t0:t0 + slab].copy_(torch.as_tensor(ev_c[t0:t0 + slab]), non_blocking=True)
-        ev_ready = torch.cuda.Event()
-        ev_ready.record(up)
+    ev_dtype = torch.as_tensor(ev_c[:1, :1]).dtype
+    n_thr = max(1, min(32, (os.cpu_count() or 1) // 2))
+    row_bytes = K * O * ev_c.itemsize
+
+    def var_tile(k0, k1):
+        """ensemble_vars[:, k0:k1] as a contiguous host tensor (page-locked when possible)"""
+        try:
+            buf = torch.empty((T, k1 - k0, O), dtype=ev_dtype, pin_memory=True)
+        except RuntimeError:
+            buf = torch.empty((T, k1 - k0, O), dtype=ev_dtype)
+        rc = lib.eks_host_gather_cols(ctypes.c_void_p(ev_c.ctypes.data), T, row_bytes, k0 * O * ev_c.itemsize,
+                                      (k1 - k0) * O * ev_c.itemsize, ctypes.c_void_p(buf.data_ptr()), n_thr)
+        _lib.check(rc, 'eks_host_gather_cols')
+        return buf
+
     work = streams[:-1]
+    # EKS_HOST_VAR_WHOLE=1: round 4's form (the whole array up before the first tile), kept for A/B runs
+    whole = bool(os.environ.get('EKS_HOST_VAR_WHOLE'))
+    trace = [] if os.environ.get('EKS_HOST_TILE_TRACE') else None
+    if whole:
+        with torch.cuda.stream(streams[-1]):
+            ev_d = torch.as_tensor(ev_c, device=dev)
+            ev_ready = torch.cuda.Event()
+            ev_ready.record(streams[-1])
+    import time as _time
+    # the variance tiles are made contiguous AHEAD of the loop below, on a helper thread (the gather releases the GIL):
+    # the calling thread's own per-tile work - the pageable upload of ys, the launches - does not wait for it
+    import queue
+    vq: queue.Queue = queue.Queue(maxsize=3)
+
+    def produce():
+        try:
+            for (a, b) in tiles:
+                vq.put(var_tile(a, b))
+        except BaseException as e:          # noqa: BLE001 - handed to the consumer
+            vq.put(e)
+
+    if not whole:
+        threading.Thread(target=produce, name='eks-var-tiles', daemon=True).start()
     s_parts, infos = [], []
     try:
         for i, (k0, k1) in enumerate(tiles):
             st = work[i % len(work)]
             with torch.cuda.stream(st):
+                t_a = _time.perf_counter()
                 y_t = torch.as_tensor(np.ascontiguousarray(ys_h[k0:k1]), device=dev)           # (Kt,T,O), caller's dtype
-                st.wait_event(ev_ready)
-                v_t = ev_d[:, k0:k1]                                                            # (T,Kt,O) view
+                t_b = _time.perf_counter()
+                if whole:
+                    st.wait_event(ev_ready)
+                    v_t = ev_d[:, k0:k1]
+                    ev_d.record_stream(st)
+                else:
+                    v_host = vq.get()
+                    if isinstance(v_host, BaseException):
+                        raise v_host
+                    t_c = _time.perf_counter()
+                    v_t = v_host.to(dev, non_blocking=True)                                     # (T,Kt,O)
+                    if trace is not None:
+                        trace.append((k0, k1, (t_b - t_a) * 1e3, (t_c - t_b) * 1e3, (_time.perf_counter() - t_c) * 1e3))
                 res = run_kalman_smoother(
                     y_t, par['m0'][k0:k1], par['S0'][k0:k1], par['A'][k0:k1], par['C'][k0:k1], par['Q'][k0:k1], v_t,
                     s_frames=s_frames, smooth_param=(smooth_param if sp is None else list(sp[k0:k1])), blocks=None,
@@ -647,11 +698,13 @@ def _run_tiled_from_host(tiles, ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frame
                 # caching allocator hands a block back only to work enqueued on the same stream later (a call just over
                 # the tiling threshold then peaks at a few tiles' worth of device memory, not at the untiled footprint)
                 del y_t, v_t, res, ms_d, Vs_d, ms_c, Vs_c
-                ev_d.record_stream(st)
     finally:
         for st in streams:                       # (also when a tile raised: the side streams rejoin the caller's)
             cur.wait_stream(st)
     cur.synchronize()
+    if trace:
+        logger.warning('tiled boundary, per tile (k0, k1, ys upload ms, variance gather ms, variance upload enqueue ms): '
+                       + '; '.join(f'{a}-{b}: {u:.2f} {g:.2f} {e:.2f}' for a, b, u, g, e in trace))
     s_finals = np.concatenate([np.asarray(s.cpu().numpy(), dtype=float) for s in s_parts])
     out_ms, out_Vs = ms_h.numpy(), Vs_h.numpy()
     if pinned:

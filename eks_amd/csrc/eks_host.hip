@@ -20,7 +20,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cerrno>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -450,4 +452,284 @@ extern "C" int eks_host_gather_cols(const void* src, int64_t n_rows, int64_t src
   work(0);
   for (auto& x : th) x.join();
   return EKS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// eks_csv_write_table: `DataFrame.to_csv` of a float64 table with an integer index (the result tables of fit_eks_*:
+// reference eks/singlecam_smoother.py:98-99, eks/multicam_smoother.py:151-152, :270-275), byte for byte.  pandas writes
+// every number as Python's repr: the SHORTEST decimal string that reads back as the same double (closest to it among
+// those), fixed notation for decimal exponents -4 .. 15, otherwise d.ddde+XX with a two-digit exponent; a missing
+// value is the empty field.  The digits are found with the C library's correctly rounded printf / strtod: the smallest
+// precision whose correctly rounded decimal reads back is the shortest one (for a power of two, whose rounding interval is
+// lopsided, the neighbouring decimals are tried as well).  Row blocks are formatted concurrently and written in order.
+// tests/test_csv_ingest.py holds the text to pandas' and the number formatting to Python's repr on millions of doubles.
+// ---------------------------------------------------------------------------------------------------------------
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+namespace {
+
+// digits (no leading / trailing zeros beyond the first) and decimal point position of the shortest repr: value =
+// 0.d1d2... x 10^decpt.  Returns the number of digits.
+// the exact search: the smallest precision whose correctly rounded decimal (the C library's printf) reads back
+int shortest_digits_exact(double v, char* digits, int* decpt) {
+  char buf[40];
+  auto probe = [&](int prec) {
+    snprintf(buf, sizeof buf, "%.*e", prec - 1, v);
+    return strtod(buf, nullptr) == v;
+  };
+  int prec;
+  if (probe(15)) {
+    int lo = 1, hi = 15;                          // (monotone in the precision)
+    while (lo < hi) {
+      const int mid = (lo + hi) / 2;
+      if (probe(mid)) hi = mid; else lo = mid + 1;
+    }
+    prec = lo;
+  } else {
+    prec = probe(16) ? 16 : 17;
+  }
+  snprintf(buf, sizeof buf, "%.*e", prec - 1, v);
+  // a power of two: one decimal SHORTER may still lie in the (wider) upper half of the rounding interval
+  {
+    uint64_t bits;
+    memcpy(&bits, &v, 8);
+    if ((bits & 0xFFFFFFFFFFFFFull) == 0 && prec > 1) {
+      char b2[40];
+      snprintf(b2, sizeof b2, "%.*e", prec - 2, v);          // correctly rounded, one digit fewer
+      char* e = strchr(b2, 'e');
+      std::string mant(b2, (size_t)(e - b2));
+      std::string ex(e);
+      int i = (int)mant.size() - 1;                // its upper neighbour in the last place
+      while (i >= 0) {
+        if (mant[(size_t)i] == '.') { --i; continue; }
+        if (mant[(size_t)i] == '9') { mant[(size_t)i] = '0'; --i; continue; }
+        ++mant[(size_t)i];
+        break;
+      }
+      if (i >= 0) {
+        const std::string cand = mant + ex;
+        if (strtod(cand.c_str(), nullptr) == v) snprintf(buf, sizeof buf, "%s", cand.c_str());
+      }
+    }
+  }
+  int n = 0;
+  const char* p = buf;
+  for (; *p && *p != 'e'; ++p)
+    if (*p >= '0' && *p <= '9') digits[n++] = *p;
+  const int ex = atoi(p + 1);
+  while (n > 1 && digits[n - 1] == '0') --n;
+  digits[n] = 0;
+  *decpt = ex + 1;
+  return n;
+}
+
+// digits (no trailing zeros) and decimal point position of the shortest repr: value = 0.d1d2... x 10^decpt.
+// ONE 17-digit conversion; shorter candidates are cut from its digits (round half up) and checked by reading them back.
+// Cutting rounds twice, which differs from the correctly rounded short decimal only when what is cut is exactly 5000...
+// within the 17 digits - then, and for powers of two, the exact search above decides.
+int shortest_digits(double v, char* digits, int* decpt) {
+  uint64_t bits;
+  memcpy(&bits, &v, 8);
+  if ((bits & 0xFFFFFFFFFFFFFull) == 0) return shortest_digits_exact(v, digits, decpt);
+  char buf[40];
+  snprintf(buf, sizeof buf, "%.16e", v);           // d.dddddddddddddddde[+-]XX
+  char m[18];
+  m[0] = buf[0];
+  memcpy(m + 1, buf + 2, 16);
+  const int ex = atoi(buf + 19);
+  char cand[40];
+  int cn = 0, cex = 0;
+  auto cut = [&](int prec, bool* ambiguous) {      // the first prec digits of m, rounded half up -> cand / cn / cex
+    bool tail_zero = true;
+    for (int i = prec + 1; i < 17; ++i) tail_zero = tail_zero && m[i] == '0';
+    *ambiguous = prec < 17 && m[prec] == '5' && tail_zero;
+    char d[18];
+    memcpy(d, m, (size_t)prec);
+    cex = ex;
+    if (prec < 17 && m[prec] >= '5') {
+      int i = prec - 1;
+      while (i >= 0 && d[i] == '9') d[i--] = '0';
+      if (i >= 0) {
+        ++d[i];
+      } else {                                    // 99..9 -> 100..0
+        d[0] = '1';
+        ++cex;
+      }
+    }
+    cn = prec;
+    memcpy(cand, d, (size_t)prec);
+  };
+  auto reads_back = [&]() {
+    char t[48];
+    int o = 0;
+    t[o++] = cand[0];
+    t[o++] = '.';
+    memcpy(t + o, cand + 1, (size_t)(cn - 1));
+    o += cn - 1;
+    o += snprintf(t + o, 8, "e%d", cex);
+    return strtod(t, nullptr) == v;
+  };
+  bool amb;
+  auto probe = [&](int prec, bool* any_amb) {
+    cut(prec, &amb);
+    *any_amb = *any_amb || amb;
+    return reads_back();
+  };
+  bool any_amb = false;
+  int prec;
+  if (probe(15, &any_amb)) {
+    int lo = 1, hi = 15;
+    while (lo < hi) {
+      const int mid = (lo + hi) / 2;
+      if (probe(mid, &any_amb)) hi = mid; else lo = mid + 1;
+    }
+    prec = lo;
+  } else {
+    prec = probe(16, &any_amb) ? 16 : 17;
+  }
+  if (any_amb) return shortest_digits_exact(v, digits, decpt);
+  cut(prec, &amb);
+  int n = cn;
+  memcpy(digits, cand, (size_t)n);
+  while (n > 1 && digits[n - 1] == '0') --n;
+  digits[n] = 0;
+  *decpt = cex + 1;
+  return n;
+}
+
+// Python's repr(float) / what DataFrame.to_csv writes (na_rep = ''); returns the length
+int format_repr(double v, char* out) {
+  if (v != v) return 0;
+  if (v == HUGE_VAL) { memcpy(out, "inf", 3); return 3; }
+  if (v == -HUGE_VAL) { memcpy(out, "-inf", 4); return 4; }
+  char* o = out;
+  if (std::signbit(v)) {
+    *o++ = '-';
+    v = -v;
+  }
+  if (v == 0.0) {
+    memcpy(o, "0.0", 3);
+    return (int)(o - out) + 3;
+  }
+  char d[24];
+  int decpt;
+  const int n = shortest_digits(v, d, &decpt);
+  if (decpt > -4 && decpt <= 16) {                 // fixed notation (float_repr_style 'short', format code 'r')
+    if (decpt <= 0) {
+      *o++ = '0';
+      *o++ = '.';
+      for (int i = 0; i < -decpt; ++i) *o++ = '0';
+      memcpy(o, d, (size_t)n);
+      o += n;
+    } else if (decpt >= n) {
+      memcpy(o, d, (size_t)n);
+      o += n;
+      for (int i = 0; i < decpt - n; ++i) *o++ = '0';
+      *o++ = '.';
+      *o++ = '0';
+    } else {
+      memcpy(o, d, (size_t)decpt);
+      o += decpt;
+      *o++ = '.';
+      memcpy(o, d + decpt, (size_t)(n - decpt));
+      o += n - decpt;
+    }
+  } else {
+    *o++ = d[0];
+    if (n > 1) {
+      *o++ = '.';
+      memcpy(o, d + 1, (size_t)(n - 1));
+      o += n - 1;
+    }
+    *o++ = 'e';
+    int ex = decpt - 1;
+    *o++ = ex < 0 ? '-' : '+';
+    if (ex < 0) ex = -ex;
+    o += snprintf(o, 8, "%02d", ex);
+  }
+  return (int)(o - out);
+}
+
+}  // namespace
+
+extern "C" int eks_format_repr(const double* values, int64_t n, char* out, int64_t capacity, int64_t* offsets) {
+  // test hook: the text of n doubles, concatenated; offsets[i] .. offsets[i + 1] is number i
+  if (!values || !out || !offsets) return EKS_ERR_NULL;
+  int64_t at = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    offsets[i] = at;
+    if (at + 32 > capacity) return EKS_ERR_WORKSPACE;
+    at += format_repr(values[i], out + at);
+  }
+  offsets[n] = at;
+  return EKS_OK;
+}
+
+extern "C" int eks_csv_write_table(const char* path, const char* header, int64_t header_bytes, const int64_t* index,
+                                   const double* values, int64_t n_rows, int32_t n_cols, int32_t n_threads) {
+  if (!path || !values || (n_rows > 0 && !index) || (header_bytes > 0 && !header)) return EKS_ERR_NULL;
+  if (n_rows < 0 || n_cols <= 0) return EKS_ERR_SHAPE;
+  if (n_threads < 1) n_threads = 1;
+  if (n_rows * (int64_t)n_cols < 20000) n_threads = 1;
+  FILE* f = fopen(path, "wb");
+  if (!f) return EKS_CSV_IO;
+  bool ok = header_bytes == 0 || fwrite(header, 1, (size_t)header_bytes, f) == (size_t)header_bytes;
+  // row blocks: formatted concurrently n_threads at a time, written in order (bounded memory: ~26 bytes per number)
+  const int64_t rows_per_block = std::max<int64_t>(1, std::min<int64_t>(n_rows, (int64_t)(4 << 20) / (26 * (int64_t)n_cols) + 1));
+  std::vector<std::string> text((size_t)n_threads);
+  for (int64_t r0 = 0; ok && r0 < n_rows; r0 += rows_per_block * n_threads) {
+    auto work = [&](int t) {
+      const int64_t a = r0 + (int64_t)t * rows_per_block, b = std::min(n_rows, a + rows_per_block);
+      std::string& s = text[(size_t)t];
+      s.clear();
+      if (a >= b) return;
+      s.reserve((size_t)((b - a) * (26 * (int64_t)n_cols + 24)));
+      char num[48];
+      for (int64_t r = a; r < b; ++r) {
+        s.append(num, (size_t)snprintf(num, sizeof num, "%lld", (long long)index[r]));
+        const double* row = values + r * (int64_t)n_cols;
+        for (int c = 0; c < n_cols; ++c) {
+          s.push_back(',');
+          s.append(num, (size_t)format_repr(row[c], num));
+        }
+        s.push_back('\n');
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    for (int t = 0; ok && t < n_threads; ++t)
+      ok = text[(size_t)t].empty() || fwrite(text[(size_t)t].data(), 1, text[(size_t)t].size(), f) == text[(size_t)t].size();
+  }
+  ok = (fclose(f) == 0) && ok;
+  return ok ? EKS_OK : EKS_CSV_IO;
+}
+
+// How much faster do n_threads threads of this process get a fixed amount of independent work done than one?
+// (A sandbox may give a process several CPUs and still run its threads one at a time; the writer above only pays
+// when they run side by side - its per-number cost on ONE thread is several times Python's own repr.)
+extern "C" double eks_host_thread_speedup(int32_t n_threads) {
+  if (n_threads < 1) n_threads = 1;
+  auto spin = [](double* out) {
+    double x = 1.0;
+    for (int i = 0; i < 400000; ++i) x = x * 1.0000001 + 1e-9;
+    *out = x;
+  };
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  std::vector<double> sink((size_t)n_threads * 16);
+  double t0 = now();
+  spin(&sink[0]);
+  const double one = now() - t0;
+  t0 = now();
+  {
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(spin, &sink[(size_t)t * 16]);
+    spin(&sink[0]);
+    for (auto& x : th) x.join();
+  }
+  const double many = now() - t0;
+  return many > 0.0 ? one * n_threads / many : 1.0;
 }

@@ -46,6 +46,25 @@ def convert_lp_dlc(df_lp: pd.DataFrame, keypoint_names, model_name=None) -> pd.D
     return pd.DataFrame(flat, index=df_lp.index)
 
 
+_HEADER_CACHE: dict = {}
+
+
+def _header_frame(path):
+    """The column index and index name pandas builds from the file's three header rows (an empty frame), cached by the
+    rows' text: the members of an ensemble share their header, and pandas takes 20 ms to read three lines."""
+    try:
+        with open(path, 'rb') as f:
+            rows = [f.readline() for _ in range(3)]
+    except OSError:
+        return None
+    key = b''.join(rows)
+    if key not in _HEADER_CACHE:
+        if len(_HEADER_CACHE) > 64:
+            _HEADER_CACHE.clear()
+        _HEADER_CACHE[key] = pd.read_csv(path, header=[0, 1, 2], index_col=0, nrows=0)
+    return _HEADER_CACHE[key]
+
+
 def read_prediction_csv(path: str, n_threads: int | None = None) -> pd.DataFrame:
     """`pd.read_csv(path, header=[0, 1, 2], index_col=0)` (reference eks/utils.py:188) with the numeric body parsed by
     the library's own reader (`eks_csv_read_numeric`: mmap, one thread per block of lines, pandas' own decimal ->
@@ -67,8 +86,8 @@ def read_prediction_csv(path: str, n_threads: int | None = None) -> pd.DataFrame
     rc = lib.eks_csv_read_numeric(bpath, 3, None, 0, ctypes.byref(n_rows), ctypes.byref(n_cols), None, 0, n_threads)
     if rc != 0 or n_cols.value < 2:
         return pd.read_csv(path, header=[0, 1, 2], index_col=0)
-    head = pd.read_csv(path, header=[0, 1, 2], index_col=0, nrows=0)
-    if len(head.columns) != n_cols.value - 1:
+    head = _header_frame(path)
+    if head is None or len(head.columns) != n_cols.value - 1:
         return pd.read_csv(path, header=[0, 1, 2], index_col=0)
     body = np.empty((n_rows.value, n_cols.value), dtype=np.float64)
     is_int = np.zeros(n_cols.value, dtype=np.uint8)
@@ -82,6 +101,26 @@ def read_prediction_csv(path: str, n_threads: int | None = None) -> pd.DataFrame
     if ints.size:                           # columns written as integers throughout: int64, as pandas infers
         df = df.astype({df.columns[i]: np.int64 for i in ints})
     return df
+
+
+_WRITER_THREADS = [None]
+
+
+def _writer_threads() -> int:
+    """Threads for the library's table writer, or 0 = format in Python.  One number costs the C library's printf /
+    strtod pair ~2 us on one thread against 0.3 us for Python's repr, so the threaded writer only pays where the
+    process's threads really run side by side (measured once, ~1 ms: eks_host_thread_speedup)."""
+    if _WRITER_THREADS[0] is None:
+        n = 0
+        try:
+            from . import _lib
+            want = max(1, min(64, (os.cpu_count() or 1) // 2))
+            if want >= 8 and _lib.load().eks_host_thread_speedup(8) >= 6.0 and not os.environ.get('EKS_PY_CSV_WRITER'):
+                n = want
+        except Exception:
+            n = 0
+        _WRITER_THREADS[0] = n
+    return _WRITER_THREADS[0]
 
 
 def write_prediction_csv(df: pd.DataFrame, path) -> None:
@@ -99,8 +138,21 @@ def write_prediction_csv(df: pd.DataFrame, path) -> None:
         df.to_csv(path)
         return
     head = df.iloc[:0].to_csv()
+    all_float = all(dt == np.float64 for dt in df.dtypes)
+    n_thr = _writer_threads() if all_float and df.size >= 200_000 else 0
+    if n_thr:
+        # the library's own writer (eks_csv_write_table): the same text, row blocks formatted on n_thr threads
+        import ctypes
+        from . import _lib
+        vals = np.ascontiguousarray(df.to_numpy(), dtype=np.float64)
+        idx64 = np.ascontiguousarray(df.index.to_numpy(), dtype=np.int64)
+        hb = head.encode()
+        rc = _lib.load().eks_csv_write_table(os.fsencode(os.fspath(path)), hb, len(hb), idx64.ctypes.data_as(ctypes.c_void_p),
+                                             vals.ctypes.data_as(ctypes.c_void_p), vals.shape[0], vals.shape[1], n_thr)
+        _lib.check(rc, 'eks_csv_write_table')
+        return
     idx = df.index.tolist()
-    if all(dt == np.float64 for dt in df.dtypes):
+    if all_float:
         vals = df.to_numpy()
         fmt = (lambda x: '' if x != x else repr(x)) if np.isnan(vals).any() else repr
         rows = vals.tolist()

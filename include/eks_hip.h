@@ -306,6 +306,22 @@ int eks_knobs_reload(void);
 int eks_csv_read_numeric(const char* path, int32_t skip_lines, double* out, int64_t capacity, int64_t* n_rows_out,
                          int32_t* n_cols_out, uint8_t* col_is_int, int32_t col_capacity, int32_t n_threads);
 
+/* eks_csv_write_table: `DataFrame.to_csv(path)` of a float64 table with an int64 index, byte for byte (the result
+ * tables of fit_eks_*: reference eks/singlecam_smoother.py:98-99, eks/multicam_smoother.py:151-152, :270-275): `header`
+ * (header_bytes of text, newline included: the caller takes it from pandas - the empty slice's to_csv) followed by one
+ * line per row, "index,v0,v1,...": every number as Python's repr (the shortest decimal string that reads back as the
+ * same double; fixed notation for decimal exponents -4 .. 15, d.ddde+XX otherwise), a NaN as the empty field, inf /
+ * -inf as such.  values [n_rows][n_cols] row-major.  Row blocks are formatted on n_threads threads and written in
+ * order.  eks_format_repr (test hook): the text of n doubles concatenated into out, offsets [n + 1]. --------------- */
+int eks_csv_write_table(const char* path, const char* header, int64_t header_bytes, const int64_t* index,
+                        const double* values, int64_t n_rows, int32_t n_cols, int32_t n_threads);
+int eks_format_repr(const double* values, int64_t n, char* out, int64_t capacity, int64_t* offsets);
+
+/* eks_host_thread_speedup: how many times faster n_threads threads of this process finish n_threads units of work than
+ * one thread finishes one (a ~1 ms measurement; a sandbox may expose several CPUs and still run a process's threads
+ * one at a time).  The Python wrapper asks once and takes the threaded writer only where threads run side by side. -- */
+double eks_host_thread_speedup(int32_t n_threads);
+
 /* eks_host_gather_cols: dst[r][0 .. width) = src[r][col_offset .. col_offset + width) (bytes) for n_rows rows of a
  * row-major HOST matrix with rows of src_row_bytes, on n_threads threads: a keypoint tile of the frame-major ensemble
  * variances (T, K, O) (reference eks/core.py:159-177 takes them in that layout) made contiguous for its upload. ---- */

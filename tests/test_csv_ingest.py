@@ -142,6 +142,45 @@ def test_writer_writes_pandas_bytes(tmp_path, with_nan):
         assert open(a, 'rb').read() == open(b, 'rb').read()
 
 
+def test_library_writer_is_pandas_bytes_and_pythons_repr(tmp_path, monkeypatch):
+    """eks_csv_write_table (threads; taken where a process's threads run side by side): forced on here, the file is
+    DataFrame.to_csv's byte for byte; and its number formatting is Python's repr on a corpus that covers what the search
+    for the shortest digits can get wrong - every power of two (lopsided rounding interval), their neighbours, random
+    bit patterns, float32 values, short decimals, halves (double rounding), subnormals, the notation thresholds."""
+    import ctypes
+    from eks_amd import utils
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    p2 = np.array([2.0 ** e for e in range(-1074, 1024)])
+    bits = rng.integers(0, 2 ** 63, size=60000, dtype=np.int64).view(np.float64)
+    corpus = np.concatenate([
+        p2, -p2[::5], np.nextafter(p2[500:1600], np.inf), np.nextafter(p2[500:1600], -np.inf), bits[np.isfinite(bits)],
+        (rng.normal(size=60000) * 10.0 ** rng.integers(-6, 6, size=60000)).astype(np.float32).astype(np.float64),
+        rng.normal(size=60000) * 10.0 ** rng.integers(-6, 6, size=60000),
+        np.round(rng.normal(size=30000) * 100, 3), np.arange(4000) / 8.0,
+        np.array([float(f'{a}.{b}5') for a in range(40) for b in range(100)]),
+        np.array([0.0, -0.0, 1e16, 1e15, 9999999999999998.0, 1e-5, 1e-4, 123456789012345680.0, 5e-324,
+                  1.7976931348623157e308, np.inf, -np.inf, np.nan, 1.0, 0.1, 1 / 3, 1e22, 1e23, 9.999999999999999e22,
+                  0.9999999999999999, 2.675, 1e-7])])
+    n = len(corpus)
+    out = ctypes.create_string_buffer(n * 32 + 64)
+    offs = np.zeros(n + 1, np.int64)
+    assert lib.eks_format_repr(corpus.ctypes.data_as(ctypes.c_void_p), n, out, len(out), offs.ctypes.data_as(ctypes.c_void_p)) == 0
+    raw = out.raw
+    for i, v in enumerate(corpus.tolist()):
+        assert raw[offs[i]:offs[i + 1]].decode() == ('' if v != v else repr(v)), (v, raw[offs[i]:offs[i + 1]])
+    # the table writer, forced on
+    monkeypatch.setattr(utils, '_WRITER_THREADS', [3])
+    T, K = 3000, 8
+    labels = ['x', 'y', 'likelihood', 'x_ens_median', 'y_ens_median', 'x_ens_var', 'y_ens_var', 'x_posterior_var', 'y_posterior_var']
+    arr = corpus[rng.integers(0, n, size=T * K * 9)].reshape(T, K * 9)
+    df = pd.DataFrame(arr, columns=make_dlc_pandas_index([f'kp{i}' for i in range(K)], labels))
+    a, b = str(tmp_path / 'a.csv'), str(tmp_path / 'b.csv')
+    df.to_csv(a)
+    write_prediction_csv(df, b)
+    assert open(a, 'rb').read() == open(b, 'rb').read()
+
+
 def test_host_gather_cols_is_the_strided_copy():
     import ctypes
     lib = _lib.load()
