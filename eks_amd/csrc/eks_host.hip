@@ -715,7 +715,7 @@ extern "C" double eks_host_thread_speedup(int32_t n_threads) {
   if (n_threads < 1) n_threads = 1;
   auto spin = [](double* out) {
     double x = 1.0;
-    for (int i = 0; i < 400000; ++i) x = x * 1.0000001 + 1e-9;
+    for (int i = 0; i < 2000000; ++i) x = x * 1.0000001 + 1e-9;      // (~5 ms: well above the cost of starting the threads)
     *out = x;
   };
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

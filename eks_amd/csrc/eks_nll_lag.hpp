@@ -168,22 +168,26 @@ EKS_HD int nll_lag_chunk(const LD& ld, int len, double r_d, double a_d, double c
   constexpr int NC = 2 * NP, NLAG = 2 * ND;
   const int nsets = len / 32;
   const float af = (float)a_d;
-  f32x2 rho2[NP];
+  f32x2 rho2[NP], nk2[NP];                   // pole; minus its complement (kKappaRho)
+  bool slow_pole = false;
   int nset_alive[NP];                      // 32-frame sets while rho^t of the pair is alive (wave-uniform)
   bool end_alive[NP];                      // ... and it still is when the chunk ends
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
-    float rr[2];
+    float rr[2], kk[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int k = 2 * p + h;
       const LeanConst c = lean_const<UNIT>(r_d, a_d, c_d, sq(k));
+      kk[h] = -c.kap;
+      slow_pole = slow_pole || fabsf(c.rho) > kKappaRho;
       stash[(3 * k + 0) * stride] = c.g;          // (log S_inf = -log g is formed again at the end)
       stash[(3 * k + 1) * stride] = c.rg;
       stash[(3 * k + 2) * stride] = c.cg;
       rr[h] = c.rho;
     }
     rho2[p] = f32x2{rr[0], rr[1]};
+    nk2[p] = f32x2{kk[0], kk[1]};
     // frames until rho^t < 1e-5 (NllLane<float>::kDeadA; ln 1e5 = 11.52), the slower pole of the pair, the slowest lane
     const float rm = fmaxf(fabsf(rr[0]), fabsf(rr[1]));
     const float nl = -logf(fminf(fmaxf(rm, 1e-30f), 0.99999994f));
@@ -297,7 +301,9 @@ EKS_HD int nll_lag_chunk(const LD& ld, int len, double r_d, double a_d, double c
 #pragma unroll
   for (int a = 0; a < 16; ++a) X[a] = f32x2{0.f, 0.f};
   float yprev = ystart;
-  {
+  const bool use_kappa = EKS_WAVE_ANY(slow_pole);      // (wave-uniform: the recursion's complement form, kKappaRho)
+  auto pass2 = [&](auto kap_tag) {
+    constexpr bool KAP = decltype(kap_tag)::value != 0;
     auto eat_set = [&](auto set_tag, auto lag_tag) {
       constexpr int S = decltype(set_tag)::value;
       constexpr bool LT = decltype(lag_tag)::value != 0;
@@ -314,12 +320,14 @@ EKS_HD int nll_lag_chunk(const LD& ld, int len, double r_d, double a_d, double c
         yprev = yb;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          dk2[p] = fma_splat_lo(rho2[p], dk2[p], X[a]);
+          if constexpr (KAP) dk2[p] = dk2[p] + fma_splat_lo(nk2[p], dk2[p], X[a]);      // d + (u - kappa d)
+          else dk2[p] = fma_splat_lo(rho2[p], dk2[p], X[a]);
           s22[p] = s22[p] + dk2[p] * dk2[p];
         }
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          dk2[p] = fma_splat_hi(rho2[p], dk2[p], X[a]);
+          if constexpr (KAP) dk2[p] = dk2[p] + fma_splat_hi(nk2[p], dk2[p], X[a]);
+          else dk2[p] = fma_splat_hi(rho2[p], dk2[p], X[a]);
           s22[p] = s22[p] + dk2[p] * dk2[p];
         }
         if constexpr (LT) {
@@ -369,7 +377,9 @@ EKS_HD int nll_lag_chunk(const LD& ld, int len, double r_d, double a_d, double c
       EKS_ROWS_ARRIVED(ring[1][kSet - 1][7]);
       if (mine()) eat_set(setB, lagset); else eat_set(setB, plain);
     }
-  }
+  };
+  if (use_kappa) pass2(IntTag<1>());
+  else pass2(IntTag<0>());
   if (lead) {
 #pragma unroll
     for (int i = 0; i < NLAG; ++i) lags.tail(i, X[(32 - NLAG + i) / 2][(32 - NLAG + i) & 1]);

@@ -67,7 +67,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((vector_size(8)));
 #endif
 
+template <int N>
+struct IntTag {
+  static constexpr int value = N;
+};
+
 constexpr double kLog2Pi = 1.8378770664093454835606594728112;
+// poles above this run the recursion in the complement form d' = d + (u - (1 - rho) d): see LeanConst below
+constexpr float kKappaRho = 0.98f;
 
 // ---- dual numbers: value and derivative w.r.t. u = log s ---------------------------------
 template <typename F>
@@ -160,10 +167,16 @@ struct NllLane {
   R CinfR[NCL], gI[NCL], rgI[NCL], cgI[NCL], logSinf[NCL];
   R rhoI[NCL];        // steady-state pole a r g = a (1 - c t) of the innovation recursion when a != 1
                       // (with a = c = 1 it IS r g: pole() reads rgI and this array is never live)
+  R kapI[NCL];        // 1 - pole, rounded once from float64; used where slow_pole (kKappaRho)
+  bool slow_pole;     // some candidate of the WAVE has a pole above kKappaRho: complement form of the recursion
   EKS_HD R pole(int k) const { return UNIT ? rgI[k] : rhoI[k]; }
+  // d' = pole d + u, in the form that keeps the pole's distance from one to float32's RELATIVE precision when it is small
+  EKS_HD R advance(int k, R d, R u) const { return slow_pole ? d + (u - kapI[k] * d) : pole(k) * d + u; }
   Elem<R> e[NCL];
   R dl[NCL];          // innovation of the last consumed frame
   R rg_last[NCL];     // r g = 1 - c K of the last consumed frame
+  R kap_last[NCL];    // 1 - a (1 - c K) of the last consumed frame, formed without cancellation (regime 0 only)
+  float oma;          // 1 - a, from float64
   float y_last;       // last consumed observation
   bool any_frame;
   // y' - a y is formed with a in float64: rounding a to float32 (6e-8) shifts every prediction
@@ -193,13 +206,12 @@ struct NllLane {
       float yp = y_last;
       if (phase[k] == 2) {
         // ---- regime 2: only the squared innovations advance
-        const R rho = pole(k);
         R s2 = R(0.f), d = dl[k];
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
           const float dy = UNIT ? (yb[q] - yp) : (float)((double)yb[q] - a_dbl * (double)yp);
           yp = yb[q];
-          d = rho * d + R(dy);
+          d = advance(k, d, R(dy));
           s2 = s2 + d * d;
         }
         dl[k] = d;
@@ -207,13 +219,12 @@ struct NllLane {
         n_post[k] += NB;
       } else if (phase[k] == 1) {
         // ---- regime 1: C frozen; A still decays, eta / J still accumulate
-        const R rho = pole(k);
         R s2 = R(0.f), d = dl[k];
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
           const float dy = UNIT ? (yb[q] - yp) : (float)((double)yb[q] - a_dbl * (double)yp);
           yp = yb[q];
-          d = rho * d + R(dy);
+          d = advance(k, d, R(dy));
           s2 = s2 + d * d;
           const R Acg = e[k].A * cgI[k];
           e[k].eta = e[k].eta + Acg * d;
@@ -231,30 +242,43 @@ struct NllLane {
       } else {
         // ---- regime 0: full recursion until C sits on its fixed point
         const R c = UNIT ? R(1.f) : pc[k].c, a = UNIT ? R(1.f) : pc[k].a;
-        R qs = R(0.f), ls = R(0.f), d = dl[k], rg = rg_last[k];
+        // The variance advances as its DEVIATION from the fixed point: C' - C_inf = (C - C_inf) a^2 (r g) (r g_inf)
+        // exactly (the Riccati map minus itself at C_inf), a product of factors below one - it decays with float32's
+        // RELATIVE precision, where C' = a^2 C r g + s q stalls ~ulp / (1 - rho^2) away from C_inf: for poles at 0.999
+        // that was 1e-4 of C_inf, the snap below had to be that coarse, and its decaying transient cost 3e-6 to 5e-6 on
+        // the NLL of the slowest candidates at variances in the hundreds (round 5).
+        // The innovation is carried over in the complement form d' = d + (u - kappa d), kappa = 1 - a (1 - c K) =
+        // (1 - a) + a c^2 C g of the PREVIOUS frame, a sum of positive terms: as the gain settles, a pole a r g rounded
+        // to float32 is a BIASED pole (up to 3e-8 / (1 - rho) of the gain), and with the variance now tracked to 1e-6
+        // this regime lasts ~7 / (1 - rho) frames.
+        R qs = R(0.f), ls = R(0.f), d = dl[k], rg = rg_last[k], kp = kap_last[k];
+        R dC = e[k].C - CinfR[k];
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
           const float dy = UNIT ? (yb[q] - yp) : (float)((double)yb[q] - a_dbl * (double)yp);
           yp = yb[q];
-          d = (UNIT ? rg : a * rg) * d + R(dy);        // gain of the PREVIOUS frame carries d over
-          const R S = UNIT ? (rR + e[k].C) : (rR + e[k].C * c * c);
+          d = d + (R(dy) - kp * d);
+          const R Cq = CinfR[k] + dC;
+          const R S = UNIT ? (rR + Cq) : (rR + Cq * c * c);
           const R g = rcp(S);
           rg = rR * g;                                 // 1 - c K of this frame
           const R Acg = UNIT ? e[k].A * g : e[k].A * c * g;
           e[k].eta = e[k].eta + Acg * d;
           e[k].J = e[k].J + (UNIT ? Acg * e[k].A : Acg * e[k].A * c);
           e[k].A = UNIT ? e[k].A * rg : a * e[k].A * rg;
-          e[k].C = UNIT ? (e[k].C * rg + pc[k].q_s) : (a * a * e[k].C * rg + pc[k].q_s);
+          dC = UNIT ? (dC * rg) * rgI[k] : (a * a * dC * rg) * rgI[k];
+          kp = UNIT ? Cq * g : R(oma) + a * c * c * Cq * g;
           qs = qs + d * d * g;
           ls = ls + log_with_rcp(S, g);
         }
+        e[k].C = CinfR[k] + dC;
         dl[k] = d;
         rg_last[k] = rg;
+        kap_last[k] = kp;
         quad[k].add(qs);
         logacc[k].add(ls);
-        const bool ok = fabsf(val(e[k].C) - val(CinfR[k])) <= tolC[k] * val(CinfR[k]) &&
-                        fabsf(der(e[k].C) - der(CinfR[k])) <=
-                            4.f * tolC[k] * fabsf(der(CinfR[k])) + 1e-30f;
+        const bool ok = fabsf(val(dC)) <= tolC[k] * val(CinfR[k]) &&
+                        fabsf(der(dC)) <= 4.f * tolC[k] * fabsf(der(CinfR[k])) + 1e-30f;
         if (EKS_WAVE_ALL(ok)) {
           phase[k] = 1;
           e[k].C = CinfR[k];
@@ -297,7 +321,9 @@ EKS_HD void nll_lane_init(NllLane<R, NCL, UNIT>& L, double r_d, double a_d, doub
   L.y_last = 0.f;
   L.any_frame = false;
   L.a_dbl = a_d;
+  L.oma = (float)(1.0 - a_d);
   const float af = (float)a_d, cf = (float)c_d;
+  bool slow = false;
 #pragma unroll
   for (int k = 0; k < NCL; ++k) {
     L.pc[k].a = R(af);
@@ -323,10 +349,15 @@ EKS_HD void nll_lane_init(NllLane<R, NCL, UNIT>& L, double r_d, double a_d, doub
       L.cgI[k] = make_real(R(), (float)cg_d, (float)dcg_d);
       L.logSinf[k] = make_real(R(), (float)log(S_d), (float)(dS_d * g_d));
       L.rhoI[k] = make_real(R(), (float)(a1 * (1.0 - c1 * t_d)), (float)(-a1 * c1 * dt_d));
+      // 1 - pole: with a = c = 1 it is C g = t (no cancellation), otherwise 1 - a + a c t; d / d log s = -d pole
+      const double kap_d = UNIT ? t_d : 1.0 - a1 * (1.0 - c1 * t_d);
+      L.kapI[k] = make_real(R(), (float)kap_d, (float)(a1 * c1 * dt_d));
+      slow = slow || fabs(a1 * (1.0 - c1 * t_d)) > (double)kKappaRho;
     }
     L.e[k] = elem_identity<R>();
     L.dl[k] = R(0.f);
     L.rg_last[k] = R(0.f);
+    L.kap_last[k] = R(1.f);            // (the first innovation is u itself: d starts at zero)
     L.phase[k] = 0;
     L.n_post[k] = 0;
     // the float32 recursion stalls within ~ulp / (1 - rho) of the true fixed point, rho = (a r g)^2
@@ -334,8 +365,11 @@ EKS_HD void nll_lane_init(NllLane<R, NCL, UNIT>& L, double r_d, double a_d, doub
     // Snapping C onto the fixed point when it is `tol` away perturbs the NLL by a decaying
     // transient (measured against the oracle: 2e-6 relative in total at 1e-4, 1e-5 at 1e-3); the
     // gradient path keeps the strict threshold.
-    L.tolC[k] = (sizeof(R) == sizeof(float) ? 1e-5f : 1e-6f) + 2.4e-7f / fmaxf(1.0f - rho, 1e-6f);
+    // (round 5: the variance's deviation decays exactly - see consume - so no allowance for a stall distance any more)
+    (void)rho;
+    L.tolC[k] = 1e-6f;
   }
+  L.slow_pole = !EKS_WAVE_ALL(!slow);                    // (wave-uniform)
 }
 
 template <typename R, int NCL, bool UNIT>
@@ -546,10 +580,11 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
   if (steady && blk < nfull) {
     constexpr bool PK = EKS_NLL_PACKED && sizeof(R) == sizeof(float) && (NCL % 2 == 0);
     constexpr int NP = PK ? NCL / 2 : 1;
+    // (pole form, or - where the wave has a pole above kKappaRho - the complement form with rho standing for -(1 - pole))
     R rho[NCL], dk[NCL], s2[NCL];
 #pragma unroll
     for (int k = 0; k < NCL; ++k) {
-      rho[k] = L.pole(k);
+      rho[k] = L.slow_pole ? R(0.f) - L.kapI[k] : L.pole(k);
       dk[k] = L.dl[k];
       s2[k] = R(0.f);
     }
@@ -567,7 +602,8 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
 #pragma unroll
     for (int q = 0; q < 8; ++q) ya[q] = ld((blk * 8 + q));
     const int first = blk;
-    auto eat = [&](const float (&yy)[8]) {
+    auto eat_as = [&](const float (&yy)[8], auto kap_tag) {
+      constexpr bool KAP = decltype(kap_tag)::value != 0;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const float dy = UNIT ? (yy[q] - yprev) : (float)((double)yy[q] - a_d * (double)yprev);
@@ -576,17 +612,24 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
           const f32x2 dy2 = f32x2{dy, dy};
 #pragma unroll
           for (int p = 0; p < NP; ++p) {
-            dk2[p] = rho2[p] * dk2[p] + dy2;
+            if constexpr (KAP) dk2[p] = dk2[p] + (rho2[p] * dk2[p] + dy2);      // d + (u - kappa d)
+            else dk2[p] = rho2[p] * dk2[p] + dy2;
             s22[p] = s22[p] + dk2[p] * dk2[p];
           }
         } else {
 #pragma unroll
           for (int k = 0; k < NCL; ++k) {
-            dk[k] = rho[k] * dk[k] + R(dy);
+            if constexpr (KAP) dk[k] = dk[k] + (rho[k] * dk[k] + R(dy));
+            else dk[k] = rho[k] * dk[k] + R(dy);
             s2[k] = s2[k] + dk[k] * dk[k];
           }
         }
       }
+    };
+    const bool kap_form = L.slow_pole;
+    auto eat = [&](const float (&yy)[8]) {
+      if (kap_form) eat_as(yy, IntTag<1>());
+      else eat_as(yy, IntTag<0>());
     };
     auto flush = [&]() {
       if constexpr (PK) {
@@ -656,13 +699,15 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
 // (lean_const: before the loops for the pole, after them for the gains) instead of being carried through.
 // Arithmetic and operation order per candidate are those of nll_summarize_chunk's converged-entry branch: for the
 // same chunk boundaries the two agree to float32 rounding of the constants (tests/test_host_sim.py).
-template <int N>
-struct IntTag {
-  static constexpr int value = N;
-};
 struct LeanConst {
   float rho, g, rg, cg, logS;     // pole of the innovation recursion, 1 / S_inf, r / S_inf, c / S_inf, log S_inf
+  float kap;                      // 1 - rho, rounded ONCE from float64 (the pole's complement: see kKappaRho)
 };
+// A float32 pole is off by up to 3e-8, i.e. by 3e-8 / (1 - rho) of its distance from one - and that is what the filter's
+// gain, and with it the NLL of a slow candidate, is off by (measured 4e-6 at 1 - rho ~ 2e-3: variances in the hundreds).
+// Where some pole of a wave's candidates lies above kKappaRho the recursion runs in the complement form
+//     d' = d + (u - kappa d),   kappa = 1 - rho rounded once from float64 (6e-8 of ITSELF),
+// one more operation per frame and candidate; below it the pole form's error is at most 3e-8 / 0.02 = 1.5e-6.
 // float64 reciprocal / square root for positive, well-scaled arguments: hardware seed + Newton steps on the device
 // (the library routines' scaling and fix-up sequences cost more than the rest of lean_const together, and it runs
 // once per candidate and chunk), the library routines on the host.  Within an ulp or two of them - rho is rounded
@@ -702,6 +747,7 @@ EKS_HD LeanConst lean_const(double r_d, double a_d, double c_d, double sq) {
   k.cg = (float)cg_d;
   k.logS = -fast_log(k.g);                                  // log S = -log g, float32 (|error| ~1e-7: 1e-9 of an NLL)
   k.rho = UNIT ? k.rg : (float)(a1 * (1.0 - c1 * t_d));
+  k.kap = UNIT ? (float)(Ci * g_d) : (float)(1.0 - a1 * (1.0 - c1 * t_d));      // (unit model: 1 - r g = C g, no cancellation)
   return k;
 }
 
@@ -739,15 +785,18 @@ EKS_HD int nll_lean_chunk(const LD& ld, int t0, int len, double r_d, double a_d,
   constexpr float kDeadA = 1e-5f;                       // NllLane<float>::kDeadA
   const int nfull = len / 8;
   const float af = (float)a_d;
-  f32x2 rho2[NP];
+  f32x2 rho2[NP], nk2[NP];                             // pole; minus its complement
   bool ok = t0 > 0;
+  bool slow_pole = false;
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
-    float rr[2];
+    float rr[2], kk[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int k = 2 * p + h;
       const LeanConst c = lean_const<UNIT>(r_d, a_d, c_d, sq(k));
+      kk[h] = -c.kap;
+      slow_pole = slow_pole || fabsf(c.rho) > kKappaRho;
       stash[(4 * k + 0) * stride] = c.g;
       stash[(4 * k + 1) * stride] = c.rg;
       stash[(4 * k + 2) * stride] = c.cg;        // (row 4 k + 3 parks eta from the end of pass 1 to the end of the chunk;
@@ -756,8 +805,10 @@ EKS_HD int nll_lean_chunk(const LD& ld, int t0, int len, double r_d, double a_d,
       ok = ok && fabsf(c.rho) < 1.f && 2.f * (float)t0 * nl > 46.f;
     }
     rho2[p] = f32x2{rr[0], rr[1]};
+    nk2[p] = f32x2{kk[0], kk[1]};
   }
   if (!EKS_WAVE_ALL(ok)) return 0;
+  const bool use_kappa = !EKS_WAVE_ALL(!slow_pole);      // (wave-uniform)
   const float y0 = len > 0 ? ld(0) : 0.f;
   out.xref(UNIT ? y0 : y0 / (float)c_d);
   const float ystart = UNIT ? y0 : y0 / af;            // reference start: the first innovation is y_0 - c xref = 0
@@ -877,14 +928,19 @@ EKS_HD int nll_lean_chunk(const LD& ld, int t0, int len, double r_d, double a_d,
   }
 #pragma unroll
   for (int k = 0; k < NC; ++k) acc2[k] = 0.0;
-  {
+  auto pass2 = [&](auto kap_tag) {
+    constexpr bool KAP = decltype(kap_tag)::value != 0;
+    auto step = [&](int p, f32x2 dy2) {
+      if constexpr (KAP) dk2[p] = dk2[p] + (nk2[p] * dk2[p] + dy2);      // d + (u - kappa d)
+      else dk2[p] = rho2[p] * dk2[p] + dy2;
+    };
     auto eat1 = [&](float yy) {
       const float dy = UNIT ? (yy - yprev) : (float)((double)yy - a_d * (double)yprev);
       yprev = yy;
       const f32x2 dy2 = f32x2{dy, dy};
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        dk2[p] = rho2[p] * dk2[p] + dy2;
+        step(p, dy2);
         s22[p] = s22[p] + dk2[p] * dk2[p];
       }
       EKS_SCHED_FENCE();
@@ -939,13 +995,15 @@ EKS_HD int nll_lean_chunk(const LD& ld, int t0, int len, double r_d, double a_d,
       const f32x2 dy2 = f32x2{dy, dy};
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        dk2[p] = rho2[p] * dk2[p] + dy2;
+        step(p, dy2);
         const f32x2 sq2 = dk2[p] * dk2[p];
         acc2[2 * p] += (double)sq2[0];
         acc2[2 * p + 1] += (double)sq2[1];
       }
     }
-  }
+  };
+  if (use_kappa) pass2(IntTag<1>());
+  else pass2(IntTag<0>());
   // ---- finish (nll_lane_finish / recover_mean of the general lane body, phase 2 throughout)
 #pragma unroll
   for (int k = 0; k < NC; ++k) {

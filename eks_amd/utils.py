@@ -109,13 +109,16 @@ _WRITER_THREADS = [None]
 def _writer_threads() -> int:
     """Threads for the library's table writer, or 0 = format in Python.  One number costs the C library's printf /
     strtod pair ~2 us on one thread against 0.3 us for Python's repr, so the threaded writer only pays where the
-    process's threads really run side by side (measured once, ~1 ms: eks_host_thread_speedup)."""
+    process's threads really run side by side (measured once, ~20 ms: eks_host_thread_speedup; on the MI355X box's 256
+    cores 32 threads write BASELINE configs[1]'s table in 0.31 s - Python's repr 1.57 s, pandas 5.9 s)."""
     if _WRITER_THREADS[0] is None:
         n = 0
         try:
             from . import _lib
-            want = max(1, min(64, (os.cpu_count() or 1) // 2))
-            if want >= 8 and _lib.load().eks_host_thread_speedup(8) >= 6.0 and not os.environ.get('EKS_PY_CSV_WRITER'):
+            want = max(1, min(32, (os.cpu_count() or 1) // 2))
+            lib = _lib.load()
+            if want >= 8 and not os.environ.get('EKS_PY_CSV_WRITER') and \
+                    max(lib.eks_host_thread_speedup(8), lib.eks_host_thread_speedup(8)) >= 4.5:
                 n = want
         except Exception:
             n = 0
