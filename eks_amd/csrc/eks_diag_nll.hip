@@ -553,6 +553,7 @@ struct GradFuseWs {
   double* grp;          // [ntile][ngroups][kGfFields][64]
   int32_t* tickets;     // [ntile], zero between evaluations (the last block of a tile resets its own)
   int ngroups;
+  int conv_allowed;     // converged-entry chunk terms where the poles allow (EKS_NLL_GRAD_TREE=1: always the tree)
 };
 
 __device__ __forceinline__ void gf_put(double* slot, const NllAcc<DualD>& a) {
@@ -620,6 +621,135 @@ __device__ __forceinline__ void gf_stores_acknowledged() {
   __builtin_amdgcn_s_waitcnt(0);
 }
 
+
+// a chain's log-likelihood and derivative (wave 0 of the tile's last block) -> the keypoint's loss, gradient and step
+__device__ __forceinline__ void gf_finish(const NllGeom& G, const AdamFuse& F, int lane, int k, int d, int kb, bool running,
+                                          double v, double g, double* __restrict__ nll, double* __restrict__ dnll) {
+  for (int off = 1; off < G.D; off <<= 1) {          // the D chains of a keypoint sit in adjacent lanes
+    v += __shfl_xor(v, off);
+    g += __shfl_xor(g, off);
+  }
+  bool still = false;
+  if (running && d == 0) {
+    v = -v;
+    const bool fin = isfinite(v);                    // eks/core.py:650
+    nll[k] = fin ? v : 1e12;
+    dnll[k] = fin ? -g : 0.0;
+    if (F.state != nullptr && F.step_in_kernel)
+      still = adam_step_block(kb, F.offs, F.members, nll, dnll, F.lr, F.lo, F.hi, F.tol, F.cap, F.state,
+                              F.s_keypoint);
+  }
+  if (F.state != nullptr && F.step_in_kernel) {
+    const int cnt = __popcll(__ballot(still));
+    if (lane == 0 && cnt) atomicAdd(F.n_active_cur, cnt);
+  }
+}
+
+// ---- round 5: the evaluation without compositions.  With every chunk past the first summarised from a converged
+// entry (nll_conv_chunk_dual: A = 0), chunk j's term of the log-likelihood needs only chunk j - 1's outgoing mean:
+//     ll = ll_0(prior) + sum_{j >= 1} [ ell_j + eta_j mr_j - J_j mr_j^2 / 2 ],   mr_j = b_{j-1} - xref_j
+// (diag_nll_assemble_par_kernel's identity, here with d / d log s riding along in float64).  Inside a block the b's
+// meet in LDS; the term of a block's FIRST chunk needs the previous block's last b, so each block publishes
+// (sum of its finished terms, its last b, its first chunk's eta, J, xref: 9 doubles per lane instead of 13) and the
+// tile's last block adds the deferred terms - independent loads and a sum where the tree had log-depth compositions.
+constexpr int kGcSum = 0, kGcB = 2, kGcEta = 4, kGcJ = 6, kGcXr = 8;      // field rows of a group's slot ([field][64])
+
+template <bool UNIT, typename LD>
+__device__ __forceinline__ void gf_conv_body(const NllGeom& G, const DiagModel& M, const GradFuseWs& W, const AdamFuse& F,
+                                             double* lds, int* last_flag, const LD& ld, const ConvConst& KC, int w, int lane,
+                                             int tile, int grp, int j, int nvalid, int t0, int len, double r_n, double a_n,
+                                             double c_n, double sq_n, int k, int d, size_t dd, int kb, bool running,
+                                             double* mine, double* __restrict__ nll, double* __restrict__ dnll) {
+  double* bx = lds;                                  // [kGfWaves][2][64]: the mean each chunk hands on
+  double* part = lds + kGfWaves * 2 * 64;            // [kGfWaves][2][64]: the waves' terms
+  DualD term(0.0), eta(0.0), Jc(0.0);
+  double xr = 0.0;
+  if (j == 0) {                                      // chunk 0: known entry state, applied to the prior here
+    double sq[1] = {sq_n};
+    NllElem<Dual> out[1];
+    nll_summarize_chunk<Dual, 1, UNIT>(ld, t0, len, r_n, a_n, c_n, sq, out, false);
+    const DualD A(out[0].e.A.v, out[0].e.A.d), b(out[0].e.b.v, out[0].e.b.d), e0(out[0].e.eta.v, out[0].e.eta.d),
+        J0(out[0].e.J.v, out[0].e.J.d), ell(out[0].ell, out[0].dell);
+    const DualD mr = DualD(M.m0[(size_t)k * G.D + d] - (double)out[0].xref), P = DualD(M.S0[dd]);
+    const DualD den = DualD(1.0) + J0 * P;
+    const DualD inv = rcp(den);
+    term = ell - DualD(0.5) * log_with_rcp(den, inv) + (e0 * mr + DualD(0.5) * e0 * e0 * P - DualD(0.5) * J0 * mr * mr) * inv;
+    const DualD bn = A * inv * (mr + P * e0) + b;     // (b is absolute, mr relative to xref)
+    bx[(w * 2 + 0) * 64 + lane] = bn.v;
+    bx[(w * 2 + 1) * 64 + lane] = bn.d;
+  } else if (j < G.ncn) {
+    ConvDual o;
+    nll_conv_chunk_dual<UNIT>(ld, len, KC, a_n, c_n, o);
+    term = DualD(o.ell, o.dell);
+    eta = DualD(o.eta, o.deta);
+    Jc = DualD(o.J, o.dJ);
+    xr = (double)o.xref;
+    bx[(w * 2 + 0) * 64 + lane] = o.b;
+    bx[(w * 2 + 1) * 64 + lane] = o.db;
+  }
+  GF_STAMP(1);
+  __syncthreads();
+  if (w > 0 && j < G.ncn) {
+    const DualD mr = DualD(bx[((w - 1) * 2 + 0) * 64 + lane], bx[((w - 1) * 2 + 1) * 64 + lane]) - DualD(xr);
+    term = term + eta * mr - DualD(0.5) * Jc * mr * mr;
+  }
+  part[(w * 2 + 0) * 64 + lane] = term.v;
+  part[(w * 2 + 1) * 64 + lane] = term.d;
+  __syncthreads();
+  GF_STAMP(2);
+  if (w == 0) {
+    double sv = 0.0, sd = 0.0;
+#pragma unroll
+    for (int q = 0; q < kGfWaves; ++q) {
+      sv += part[(q * 2 + 0) * 64 + lane];
+      sd += part[(q * 2 + 1) * 64 + lane];
+    }
+    gf_publish(mine + (kGcSum + 0) * 64, sv);
+    gf_publish(mine + (kGcSum + 1) * 64, sd);
+    gf_publish(mine + (kGcB + 0) * 64, bx[((nvalid - 1) * 2 + 0) * 64 + lane]);
+    gf_publish(mine + (kGcB + 1) * 64, bx[((nvalid - 1) * 2 + 1) * 64 + lane]);
+    gf_publish(mine + (kGcEta + 0) * 64, eta.v);
+    gf_publish(mine + (kGcEta + 1) * 64, eta.d);
+    gf_publish(mine + (kGcJ + 0) * 64, Jc.v);
+    gf_publish(mine + (kGcJ + 1) * 64, Jc.d);
+    gf_publish(mine + kGcXr * 64, xr);
+    gf_stores_acknowledged();
+    if (lane == 0) *last_flag = atomicAdd(W.tickets + tile, 1) == W.ngroups - 1;
+  }
+  __syncthreads();
+  GF_STAMP(3);
+  if (!*last_flag) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other blocks' slots
+  // ---- the tile's last block: every group's sum and deferred first term at once, wave w taking groups w, w + 8, ...
+  const double* base = W.grp + (size_t)tile * W.ngroups * kGfFields * 64 + lane;
+  DualD tot(0.0);
+  for (int g = w; g < W.ngroups; g += kGfWaves) {
+    const double* sl = base + (size_t)g * kGfFields * 64;
+    tot = tot + DualD(sl[(kGcSum + 0) * 64], sl[(kGcSum + 1) * 64]);
+    if (g > 0) {
+      const double* pv = sl - (size_t)kGfFields * 64;
+      const DualD mr = DualD(pv[(kGcB + 0) * 64], pv[(kGcB + 1) * 64]) - DualD(sl[kGcXr * 64]);
+      const DualD e(sl[(kGcEta + 0) * 64], sl[(kGcEta + 1) * 64]), Jg(sl[(kGcJ + 0) * 64], sl[(kGcJ + 1) * 64]);
+      tot = tot + e * mr - DualD(0.5) * Jg * mr * mr;
+    }
+  }
+  GF_STAMP(4);
+  part[(w * 2 + 0) * 64 + lane] = tot.v;             // (every wave is past its reads of `part`: the barrier above)
+  part[(w * 2 + 1) * 64 + lane] = tot.d;
+  __syncthreads();
+  GF_STAMP(5);
+  if (w != 0) return;
+  if (lane == 0) W.tickets[tile] = 0;                // ready for the next evaluation (stream order)
+  double v = 0.0, g = 0.0;
+#pragma unroll
+  for (int q = 0; q < kGfWaves; ++q) {
+    v += part[(q * 2 + 0) * 64 + lane];
+    g += part[(q * 2 + 1) * 64 + lane];
+  }
+  gf_finish(G, F, lane, k, d, kb, running, v, g, nll, dnll);
+  GF_STAMP(6);
+}
+
 template <bool UNIT>
 __global__ __launch_bounds__(64 * kGfWaves) void diag_nll_grad_fused_kernel(NllGeom G, DiagModel M, GradFuseWs W,
                                                                            const float* __restrict__ y,
@@ -653,6 +783,16 @@ __global__ __launch_bounds__(64 * kGfWaves) void diag_nll_grad_fused_kernel(NllG
     if (!__any(running)) return;                     // the same answer in every wave of the tile's blocks
   }
   GF_STAMP(0);
+  // ---- round 5: every chunk past the first by its converged-entry summary when the tile's poles allow it (the
+  // ---- same answer in every block of the tile: it depends on the chains' constants alone)
+  if (W.conv_allowed && G.ncn > 1) {
+    const ConvConst KC = conv_const<UNIT>(r_n, a_n, c_n, s_kp[k] * q_n);
+    if (__all(conv_chunk_ok(KC, G.BN))) {
+      gf_conv_body<UNIT>(G, M, W, F, lds, &last_flag, ld, KC, w, lane, tile, grp, j, nvalid, t0, len, r_n, a_n, c_n,
+                         s_kp[k] * q_n, k, d, dd, kb, running, mine, nll, dnll);
+      return;
+    }
+  }
   NllAcc<DualD> acc;
   if (j < G.ncn) {
     double sq[1] = {s_kp[k] * q_n};
@@ -697,25 +837,7 @@ __global__ __launch_bounds__(64 * kGfWaves) void diag_nll_grad_fused_kernel(NllG
   const DualD inv = rcp(den);
   const DualD ll = acc.ell - DualD(0.5) * log_with_rcp(den, inv) +
                    (acc.e.eta * m + DualD(0.5) * acc.e.eta * acc.e.eta * P - DualD(0.5) * acc.e.J * m * m) * inv;
-  double v = ll.v, g = ll.d;
-  for (int off = 1; off < G.D; off <<= 1) {          // the D chains of a keypoint sit in adjacent lanes
-    v += __shfl_xor(v, off);
-    g += __shfl_xor(g, off);
-  }
-  bool still = false;
-  if (running && d == 0) {
-    v = -v;
-    const bool fin = isfinite(v);                    // eks/core.py:650
-    nll[k] = fin ? v : 1e12;
-    dnll[k] = fin ? -g : 0.0;
-    if (F.state != nullptr && F.step_in_kernel)
-      still = adam_step_block(kb, F.offs, F.members, nll, dnll, F.lr, F.lo, F.hi, F.tol, F.cap, F.state,
-                              F.s_keypoint);
-  }
-  if (F.state != nullptr && F.step_in_kernel) {
-    const int cnt = __popcll(__ballot(still));
-    if (lane == 0 && cnt) atomicAdd(F.n_active_cur, cnt);
-  }
+  gf_finish(G, F, lane, k, d, kb, running, ll.v, ll.d, nll, dnll);
   GF_STAMP(6);
 }
 
@@ -1549,6 +1671,7 @@ static int diag_nll_impl(const eks_dims_t& d, const float* y, const double* rcon
     FW.ngroups = (G.ncn + kGfWaves - 1) / kGfWaves;
     FW.grp = static_cast<double*>(ws);
     FW.tickets = nll_ws_tickets(ws, T, N, n_cand);
+    FW.conv_allowed = !knob_int(KNOB_NLL_GRAD_TREE, 0);
     const size_t grp_bytes = (size_t)G.ntile * FW.ngroups * kGfFields * 64 * sizeof(double);
     if (grp_bytes > diag_nll_workspace_bytes(T, N, n_cand) - adam_extra_bytes(N)) return EKS_ERR_WORKSPACE;
     {

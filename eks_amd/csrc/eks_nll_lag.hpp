@@ -414,4 +414,134 @@ EKS_HD int nll_lag_chunk(const LD& ld, int len, double r_d, double a_d, double c
   return any_alive ? 2 : 1;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Converged-entry chunk summary WITH d / d log s (round 5: the Adam loop, one value of s per keypoint).
+// nll_summarize_chunk<Dual, 1> starts every chunk from a known state and the chunks' elements then have to be
+// COMPOSED in order (float64 dual-number compositions: 12.5 of an iteration's 41 us on C3).  A chunk that starts after
+// the filter variance has converged (rho^(2 t0) < 1e-20: the true filter's predicted variance does not depend on the
+// data) needs none of that: its summary has A = 0, so its term of the log-likelihood
+//     ell + eta mr - J mr^2 / 2,     mr = (mean the previous chunk hands on) - xref
+// and its derivative need only the previous chunk's b and db - every chunk's term can be formed at once.
+// One candidate per lane; value and derivative ride through the frame loop as float32 pairs (as in the exact-entry
+// code), the sums go to float64 every 32 frames.  conv_chunk_ok() says whether a chunk length qualifies.
+// ---------------------------------------------------------------------------------------------------------------
+struct ConvDual {                 // the summary: every field a (value, d / d log s) pair in float64
+  double b, db, eta, deta, J, dJ, ell, dell;
+  float xref;
+};
+struct ConvConst {                // steady-state constants of one (chain, s) and their d / d log s (nll_lane_init's formulas)
+  double rho, drho, g, dg, cg, dcg, rg, drg, S, dS;
+  float nl;                       // -log |rho|
+};
+template <bool UNIT>
+EKS_HD ConvConst conv_const(double r_d, double a_d, double c_d, double sq) {
+  const double a1 = UNIT ? 1.0 : a_d, c1 = UNIT ? 1.0 : c_d;
+  double Ci, dCi;
+  riccati_fixed_point(a1, c1, r_d, sq, Ci, dCi);
+  ConvConst k;
+  k.S = r_d + Ci * c1 * c1;
+  k.dS = dCi * c1 * c1;
+  k.g = 1.0 / k.S;
+  k.dg = -k.g * k.g * k.dS;
+  k.cg = c1 * k.g;
+  k.dcg = c1 * k.dg;
+  const double t = Ci * k.cg, dt = dCi * k.cg + Ci * k.dcg;
+  k.rho = a1 * (1.0 - c1 * t);
+  k.drho = -a1 * c1 * dt;
+  k.rg = r_d * k.g;
+  k.drg = r_d * k.dg;
+  k.nl = -logf(fminf(fmaxf(fabsf((float)k.rho), 1e-30f), 0.99999994f));
+  return k;
+}
+// may every chunk of `bn` frames past the first be summarised this way?  rho^bn < 1e-10: the variance has converged
+// when chunk 1 starts (rho^(2 bn) < 1e-20) and no chunk's outgoing mean remembers the incoming one (A = rho^bn)
+EKS_HD bool conv_chunk_ok(const ConvConst& k, int bn) { return (float)bn * k.nl > 23.1f; }
+
+template <bool UNIT, typename LD>
+EKS_HD void nll_conv_chunk_dual(const LD& ld, int len, const ConvConst& K, double a_d, double c_d, ConvDual& out) {
+  const Dual rho((float)K.rho, (float)K.drho);
+  const float y0 = ld(0);
+  out.xref = UNIT ? y0 : (float)((double)y0 / c_d);
+  float yprev = UNIT ? y0 : (float)((double)y0 / a_d);
+  Dual dk(0.f), w(1.f, 0.f), s1(0.f), s2(0.f);
+  double s1v = 0.0, s1d = 0.0, s2v = 0.0, s2d = 0.0;
+  bool alive = true;
+  const int nfull = len / 8;
+  float ya[8], yb[8];
+  if (nfull > 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ya[q] = ld(q);
+  }
+  auto eat = [&](const float (&yy)[8], auto alive_tag) {
+    constexpr bool AL = decltype(alive_tag)::value != 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float dy = UNIT ? (yy[q] - yprev) : (float)((double)yy[q] - a_d * (double)yprev);
+      yprev = yy[q];
+      dk = rho * dk + Dual(dy);
+      s2 = s2 + dk * dk;
+      if constexpr (AL) {
+        s1 = s1 + dk * w;
+        w = w * rho;
+      }
+    }
+  };
+  int blk = 0;
+  for (; blk + 2 <= nfull; blk += 2) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) yb[q] = ld((blk + 1) * 8 + q);
+    if (alive) eat(ya, IntTag<1>()); else eat(ya, IntTag<0>());
+    if (blk + 2 < nfull) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) ya[q] = ld((blk + 2) * 8 + q);
+    }
+    if (alive) eat(yb, IntTag<1>()); else eat(yb, IntTag<0>());
+    if ((blk & 2) != 0 || blk + 4 > nfull) {         // float32 partial sums span at most 32 frames
+      s2v += (double)s2.v; s2d += (double)s2.d;
+      s2 = Dual(0.f);
+      if (alive) {
+        s1v += (double)s1.v; s1d += (double)s1.d;
+        s1 = Dual(0.f);
+        const bool dead = fabsf(w.v) < 1e-9f && fabsf(w.d) < 1e-9f;
+        alive = !EKS_WAVE_ALL(dead);
+      }
+    }
+  }
+  if (blk < nfull) {
+    if (alive) eat(ya, IntTag<1>()); else eat(ya, IntTag<0>());
+    ++blk;
+  }
+  for (int i = blk * 8; i < len; ++i) {              // ragged tail
+    const float yy = ld(i);
+    const float dy = UNIT ? (yy - yprev) : (float)((double)yy - a_d * (double)yprev);
+    yprev = yy;
+    dk = rho * dk + Dual(dy);
+    s2 = s2 + dk * dk;
+    s1 = s1 + dk * w;
+    w = w * rho;
+  }
+  s2v += (double)s2.v; s2d += (double)s2.d;
+  s1v += (double)s1.v; s1d += (double)s1.d;
+  // finish (float64 duals): b = a ((y - d) / c + K d), K = (1 - r g) / c; eta = c g S1; J = c^2 g / (1 - rho^2)
+  const double dl = (double)dk.v, ddl = (double)dk.d;
+  if (UNIT) {
+    out.b = (double)yprev - K.rg * dl;
+    out.db = -(K.drg * dl + K.rg * ddl);
+  } else {
+    const double ic = 1.0 / c_d;
+    out.b = a_d * ic * ((double)yprev - K.rg * dl);
+    out.db = -a_d * ic * (K.drg * dl + K.rg * ddl);
+  }
+  const double c1 = UNIT ? 1.0 : c_d;
+  out.eta = s1v * K.cg;
+  out.deta = s1d * K.cg + s1v * K.dcg;
+  const double iom = 1.0 / (1.0 - K.rho * K.rho);
+  const double ccg = c1 * K.cg, dccg = c1 * K.dcg;
+  out.J = ccg * iom;
+  out.dJ = dccg * iom + ccg * iom * iom * 2.0 * K.rho * K.drho;
+  out.ell = -0.5 * ((double)len * (kLog2Pi + log(K.S)) + K.g * s2v);
+  out.dell = -0.5 * ((double)len * K.dS * K.g + K.dg * s2v + K.g * s2d);
+}
+
 }  // namespace eks

@@ -132,6 +132,7 @@ template <>
 struct Acc64<float> {
   double v = 0.0;
   EKS_HD void add(float x) { v += (double)x; }
+  EKS_HD float rounded() const { return (float)v; }
 };
 template <>
 struct Acc64<Dual> {
@@ -140,6 +141,7 @@ struct Acc64<Dual> {
     v += (double)x.v;
     d += (double)x.d;
   }
+  EKS_HD Dual rounded() const { return Dual((float)v, (float)d); }
 };
 
 // chunk summary for one (chain, candidate): element + run-local log-likelihood (and derivatives)
@@ -184,6 +186,12 @@ struct NllLane {
   // NLL at |y| ~ 1000); one float64 FMA per frame and lane, shared by the lane's candidates
   double a_dbl;
   Acc64<R> quad[NCL], logacc[NCL], acc2[NCL];
+  // eta and J of the summary: float32 partial sums of one 8-frame block, added up in float64.  The summary describes
+  // the chunk for an entering state known EXACTLY (x_in = xref): with a slow candidate on a short, fast-moving
+  // sequence its ell is far below the sequence's log-likelihood and eta^2 / 2J, applied with the prior, brings it
+  // back - each of them 10x the result (T = 64, s = 5e-4: 5e4 against 8e3), and a running float32 sum of eta put
+  // 1.3e-5 on that NLL (fuzz seed 911, case 64; round 5).
+  Acc64<R> eta64[NCL], J64[NCL];
   int phase[NCL], n_post[NCL];
   float tolC[NCL];
   R rR;
@@ -219,7 +227,7 @@ struct NllLane {
         n_post[k] += NB;
       } else if (phase[k] == 1) {
         // ---- regime 1: C frozen; A still decays, eta / J still accumulate
-        R s2 = R(0.f), d = dl[k];
+        R s2 = R(0.f), d = dl[k], es = R(0.f), js = R(0.f);
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
           const float dy = UNIT ? (yb[q] - yp) : (float)((double)yb[q] - a_dbl * (double)yp);
@@ -227,12 +235,14 @@ struct NllLane {
           d = advance(k, d, R(dy));
           s2 = s2 + d * d;
           const R Acg = e[k].A * cgI[k];
-          e[k].eta = e[k].eta + Acg * d;
-          e[k].J = e[k].J + (UNIT ? Acg * e[k].A : Acg * e[k].A * pc[k].c);
+          es = es + Acg * d;
+          js = js + (UNIT ? Acg * e[k].A : Acg * e[k].A * pc[k].c);
           e[k].A = UNIT ? e[k].A * rgI[k] : pc[k].a * e[k].A * rgI[k];
         }
         dl[k] = d;
         acc2[k].add(s2);
+        eta64[k].add(es);
+        J64[k].add(js);
         n_post[k] += NB;
         const bool dead = fabsf(val(e[k].A)) < kDeadA && fabsf(der(e[k].A)) < kDeadA;
         if (EKS_WAVE_ALL(dead)) {
@@ -251,7 +261,7 @@ struct NllLane {
         // (1 - a) + a c^2 C g of the PREVIOUS frame, a sum of positive terms: as the gain settles, a pole a r g rounded
         // to float32 is a BIASED pole (up to 3e-8 / (1 - rho) of the gain), and with the variance now tracked to 1e-6
         // this regime lasts ~7 / (1 - rho) frames.
-        R qs = R(0.f), ls = R(0.f), d = dl[k], rg = rg_last[k], kp = kap_last[k];
+        R qs = R(0.f), ls = R(0.f), d = dl[k], rg = rg_last[k], kp = kap_last[k], es = R(0.f), js = R(0.f);
         R dC = e[k].C - CinfR[k];
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
@@ -263,8 +273,8 @@ struct NllLane {
           const R g = rcp(S);
           rg = rR * g;                                 // 1 - c K of this frame
           const R Acg = UNIT ? e[k].A * g : e[k].A * c * g;
-          e[k].eta = e[k].eta + Acg * d;
-          e[k].J = e[k].J + (UNIT ? Acg * e[k].A : Acg * e[k].A * c);
+          es = es + Acg * d;
+          js = js + (UNIT ? Acg * e[k].A : Acg * e[k].A * c);
           e[k].A = UNIT ? e[k].A * rg : a * e[k].A * rg;
           dC = UNIT ? (dC * rg) * rgI[k] : (a * a * dC * rg) * rgI[k];
           kp = UNIT ? Cq * g : R(oma) + a * c * c * Cq * g;
@@ -277,6 +287,8 @@ struct NllLane {
         kap_last[k] = kp;
         quad[k].add(qs);
         logacc[k].add(ls);
+        eta64[k].add(es);
+        J64[k].add(js);
         const bool ok = fabsf(val(dC)) <= tolC[k] * val(CinfR[k]) &&
                         fabsf(der(dC)) <= 4.f * tolC[k] * fabsf(der(CinfR[k])) + 1e-30f;
         if (EKS_WAVE_ALL(ok)) {
@@ -293,6 +305,11 @@ struct NllLane {
   // the run-local mean after the last consumed frame (see consume): b = a ((y - d) / c + K d),
   // K = C c g = (1 - r g) / c of that frame
   EKS_HD void recover_mean() {
+#pragma unroll
+    for (int k = 0; k < NCL; ++k) {
+      e[k].eta = eta64[k].rounded();
+      e[k].J = J64[k].rounded();
+    }
     if (!any_frame) return;
 #pragma unroll
     for (int k = 0; k < NCL; ++k) {
@@ -555,9 +572,9 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
         L.rg_last[k] = L.rgI[k];
         L.e[k].A = 0.f;
         L.e[k].C = -1.f;                                           // converged-entry marker
-        L.e[k].eta = (float)(s1acc[k] * (double)L.cgI[k]);
+        L.eta64[k].v = s1acc[k] * (double)L.cgI[k];
         const float c_cg = UNIT ? L.cgI[k] : L.pc[k].c * L.cgI[k];
-        L.e[k].J = c_cg / (1.f - rho[k] * rho[k]);
+        L.J64[k].v = (double)(c_cg / (1.f - rho[k] * rho[k]));
       }
       L.y_last = yprev;
       L.any_frame = true;

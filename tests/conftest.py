@@ -48,7 +48,10 @@ def set_knob(monkeypatch):
     lib = _lib.load()
 
     def _set(name, value):
-        monkeypatch.setenv(name, value)
+        if value is None:
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, value)
         lib.eks_knobs_reload()
 
     yield _set

@@ -409,3 +409,62 @@ extern "C" int sim_diag_nll_lag(int T, int N, int D, int B0, int BN, int unit, c
   return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// round 5: the gradient evaluation without compositions (gf_conv_body of diag_nll_grad_fused_kernel): chunk 0 from a
+// known entry state applied to the prior, every later chunk by nll_conv_chunk_dual, chunk j's term from chunk j - 1's b.
+// Returns the number of (chain) evaluations that qualified (the others are skipped: nll = dnll = NaN).
+// ---------------------------------------------------------------------------------------------
+#include "eks_nll_lag.hpp"
+
+template <bool UNIT>
+static int run_nll_conv_grad(int T, int N, int D, int BN, const float* y, const double* rconst, const DiagModel& M,
+                             const double* s_kp, double* nll, double* dnll) {
+  const int K = N / D, ncn = (T + BN - 1) / BN;
+  int n_ok = 0;
+  for (int k = 0; k < K; ++k) {
+    DualD tot(0.0);
+    bool ok = ncn > 1;
+    for (int d = 0; d < D && ok; ++d) {
+      const int n = k * D + d;
+      const size_t dd = (size_t)k * D * D + (size_t)d * (D + 1);
+      const double r = rconst[n], a = M.A[dd], c = M.C[dd], sq = s_kp[k] * M.Q[dd];
+      const ConvConst KC = conv_const<UNIT>(r, a, c, sq);
+      if (!conv_chunk_ok(KC, BN)) { ok = false; break; }
+      double sqv[1] = {sq};
+      NllElem<Dual> o0[1];
+      nll_summarize_chunk<Dual, 1, UNIT>(RowsByPointer{y + n, (size_t)N}, 0, std::min(BN, T), r, a, c, sqv, o0, false);
+      const DualD A(o0[0].e.A.v, o0[0].e.A.d), b(o0[0].e.b.v, o0[0].e.b.d), e0(o0[0].e.eta.v, o0[0].e.eta.d),
+          J0(o0[0].e.J.v, o0[0].e.J.d), ell(o0[0].ell, o0[0].dell);
+      const DualD mr = DualD(M.m0[(size_t)k * D + d] - (double)o0[0].xref), P = DualD(M.S0[dd]);
+      const DualD den = DualD(1.0) + J0 * P;
+      const DualD inv = rcp(den);
+      tot = tot + ell - DualD(0.5) * log_with_rcp(den, inv) + (e0 * mr + DualD(0.5) * e0 * e0 * P - DualD(0.5) * J0 * mr * mr) * inv;
+      DualD bprev = A * inv * (mr + P * e0) + b;
+      for (int j = 1; j < ncn; ++j) {
+        const int t0 = j * BN, len = std::min(BN, T - t0);
+        ConvDual o;
+        nll_conv_chunk_dual<UNIT>(RowsByPointer{y + (size_t)t0 * N + n, (size_t)N}, len, KC, a, c, o);
+        const DualD m2 = bprev - DualD((double)o.xref);
+        tot = tot + DualD(o.ell, o.dell) + DualD(o.eta, o.deta) * m2 - DualD(0.5) * DualD(o.J, o.dJ) * m2 * m2;
+        bprev = DualD(o.b, o.db);
+      }
+    }
+    if (ok) {
+      nll[k] = -tot.v;
+      dnll[k] = -tot.d;
+      ++n_ok;
+    } else {
+      nll[k] = dnll[k] = std::nan("");
+    }
+  }
+  return n_ok;
+}
+
+extern "C" int sim_diag_nll_conv_grad(int T, int N, int D, int BN, int unit, const float* y, const double* rconst,
+                                      const double* m0, const double* S0, const double* A, const double* C, const double* Q,
+                                      const double* s_kp, double* nll, double* dnll) {
+  DiagModel M{m0, S0, A, C, Q, nullptr, D};
+  return unit ? run_nll_conv_grad<true>(T, N, D, BN, y, rconst, M, s_kp, nll, dnll)
+              : run_nll_conv_grad<false>(T, N, D, BN, y, rconst, M, s_kp, nll, dnll);
+}

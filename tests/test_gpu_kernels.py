@@ -656,6 +656,35 @@ def test_nll_grad_single_launch_matches_oracle_and_two_launch_form(T, K, unit, s
     nll2, g2 = [a.cpu().numpy()[:, 0] for a in hip_ops.nll(*args, per_keypoint=True, want_grad=True, flags=flags)]
     assert (np.abs(nll - nll2) / np.abs(ref)).max() < 2e-6
     assert (np.abs(g - g2) / np.abs(gref).max()).max() < 2e-5
+    # round 5: where a tile's poles allow, the launch sums converged-entry chunk terms instead of composing chunk
+    # summaries (gf_conv_body); EKS_NLL_GRAD_TREE=1 keeps the compositions everywhere
+    set_knob('EKS_NLL_GRAD_UNFUSED', None)
+    set_knob('EKS_NLL_GRAD_TREE', '1')
+    nll3, g3 = [a.cpu().numpy()[:, 0] for a in hip_ops.nll(*args, per_keypoint=True, want_grad=True, flags=flags)]
+    assert (np.abs(nll - nll3) / np.abs(ref)).max() < 2e-6
+    assert (np.abs(g - g3) / np.abs(gref).max()).max() < 2e-5
+
+
+@pytest.mark.parametrize('unit', [True, False])
+def test_nll_grad_sum_of_chunk_terms_matches_oracle_on_fast_poles(unit, set_knob):
+    """Every keypoint's pole dies within a chunk (s >= 0.05 at R ~ 0.3: rho < 0.8): all tiles take gf_conv_body.
+    Against the oracle and against the tree form (which must differ in the low bits - or the new path did not run)."""
+    from eks_amd import hip_ops
+    T, K = 30_000, 70
+    arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=77, unit=unit)
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    rconst = hip_ops.const_r(_dev(var_tk), 1e-4)
+    s = np.exp(np.random.default_rng(2).uniform(-3, 6, K))
+    args = (_dev(y_tk), rconst, *_params_dev(arrs), _dev(s[:, None]))
+    nll, g = [a.cpu().numpy()[:, 0] for a in hip_ops.nll(*args, per_keypoint=True, want_grad=True, flags=flags)]
+    ref, gref = orc.filter_nll(arrs['ys'], arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], s,
+                               rconst.cpu().numpy(), want_grad=True)
+    assert (np.abs(nll - ref) / np.abs(ref)).max() < 3e-6
+    assert (np.abs(g - gref) / np.maximum(np.abs(gref), 1e-3 * np.abs(ref))).max() < 3e-5
+    set_knob('EKS_NLL_GRAD_TREE', '1')
+    nll3, g3 = [a.cpu().numpy()[:, 0] for a in hip_ops.nll(*args, per_keypoint=True, want_grad=True, flags=flags)]
+    assert (np.abs(nll3 - ref) / np.abs(ref)).max() < 3e-6
+    assert not np.array_equal(nll, nll3)
 
 
 def test_nll_grad_single_launch_is_bit_reproducible():

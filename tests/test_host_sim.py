@@ -161,6 +161,36 @@ def test_grid_kernel_shared_lag_form_matches_oracle(sim, T, B0, BN, unit, var_sc
         assert err[:, 48:].max() < 1e-7, err[:, 48:].max()
 
 
+@pytest.mark.parametrize('T,BN,unit', [(6000, 392, True), (6000, 392, False), (3001, 256, True), (5000, 1000, False)])
+def test_gradient_without_compositions_matches_oracle(sim, T, BN, unit):
+    """gf_conv_body of diag_nll_grad_fused_kernel (round 5): chunk 0 applied to the prior, every later chunk by its
+    converged-entry summary with d / d log s (nll_conv_chunk_dual), the terms summed - against the oracle's value and
+    gradient.  Keypoints whose poles outlive a chunk do not qualify and are skipped (the kernel keeps the tree)."""
+    K = 12
+    arrs, y, var, ys64, ev64 = _problem(T, K, seed=9)
+    rng = np.random.default_rng(4)
+    if not unit:
+        eye = np.eye(2)
+        arrs['As'] = np.ascontiguousarray(eye * rng.uniform(0.9, 1.0, (K, 2))[:, :, None])
+        arrs['Cs'] = np.ascontiguousarray(eye * rng.uniform(0.5, 1.5, (K, 2))[:, :, None])
+        arrs['Qs'] = np.ascontiguousarray(eye * rng.uniform(0.5, 2.0, (K, 2))[:, :, None])
+        arrs['m0s'] = np.ascontiguousarray(rng.standard_normal((K, 2)))
+    Rc = orc.constant_R_from_timevarying(orc.build_R_from_vars(ev64))
+    rconst = np.ascontiguousarray(Rc.reshape(-1))
+    s = np.exp(np.linspace(-5.5, 6, K))
+    ref_nll, ref_g = orc.filter_nll(ys64, arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], s, Rc, want_grad=True)
+    f, d = ctypes.c_float, ctypes.c_double
+    nll = np.zeros(K)
+    dn = np.zeros(K)
+    n_ok = sim.sim_diag_nll_conv_grad(T, 2 * K, 2, BN, int(unit), _p(y, f), _p(rconst, d), _p(arrs['m0s'], d),
+                                      _p(arrs['S0s'], d), _p(arrs['As'], d), _p(arrs['Cs'], d), _p(arrs['Qs'], d),
+                                      _p(s, d), _p(nll, d), _p(dn, d))
+    ok = ~np.isnan(nll)
+    assert n_ok == ok.sum() and n_ok >= K - 4, n_ok
+    assert (np.abs(nll[ok] - ref_nll[ok]) / np.abs(ref_nll[ok])).max() < 3e-6
+    assert (np.abs(dn[ok] - ref_g[ok]) / np.maximum(np.abs(ref_g[ok]), 1e-3 * np.abs(ref_nll[ok]))).max() < 2e-5
+
+
 def test_lag_sum_identity_is_exact_with_all_lags():
     """sum_t d_t^2 of the zero-start recursion d_t = rho d_{t-1} + u_t equals
     [c_0 + 2 sum_k rho^k c_k - rho^2 d_last^2] / (1 - rho^2) with c_k the lag sums of u - the identity the lag form

@@ -13,6 +13,7 @@ python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke
 python bench.py > $O/bench_c3.json 2> $O/bench_c3.err
 python bench.py --workload c3adam > $O/bench_c3adam.json 2> $O/bench_c3adam.err
 EKS_NLL_LEGACY=1 python bench.py --no-cpu-baseline > $O/bench_c3_legacy_nll.json 2>/dev/null
+EKS_NLL_NOLAG=1 python bench.py --no-cpu-baseline > $O/bench_c3_nolag.json 2>/dev/null
 python bench.py --workload c4 --no-cpu-baseline > $O/bench_c4.json 2>/dev/null
 python bench.py --workload c4w --no-cpu-baseline > $O/bench_c4w.json 2>/dev/null
 python bench.py --workload c4adam --no-cpu-baseline > $O/bench_c4adam.json 2>/dev/null
@@ -27,7 +28,10 @@ python tools/ekf_time.py > $O/ekf_time.txt 2>&1
 python tools/driver_time.py 2>&1 | grep -E " ms" > $O/driver_time.txt
 python tools/host_path_time.py 2>&1 | grep -v amdgpu > $O/host_path_time.txt
 for m in diag dense; do python tools/first_call.py $m 2>&1 | grep -v amdgpu; EKS_AUTO_WARMUP=1 python tools/first_call.py $m 2>&1 | grep -v amdgpu | sed 's/^/auto warm-up (EKS_AUTO_WARMUP=1): /'; done > $O/first_call.txt
-tools/micro/bin/nll_lean2 > $O/nll_lean2.txt 2>&1
+tools/micro/bin/nll_lag > $O/nll_lag.txt 2>&1
+python tools/fit_time.py 2>&1 | grep -v amdgpu > $O/fit_time.txt
+python tools/host_boundary_ab.py 2>&1 | grep -v amdgpu > $O/host_boundary_ab.txt
+EKS_HIP_LIB=build_alt/gridstamps/libeks_hip.so python tools/grid_stamps.py 2>&1 | grep -v amdgpu > $O/grid_stamps.txt
 python tools/adam_time.py > $O/adam_time.txt 2>&1
 python tools/dense_adam_time.py > $O/dense_adam_time.txt 2>&1
 python tools/dense_adam_time_d.py 2>&1 | grep adam > $O/dense_adam_time_d.txt

@@ -60,12 +60,13 @@ json.dump({'source': f'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate p
                          'coalesced stream, MI355X_MICROARCH.md HBM section)',
            'kernel_sources_sha16': open(os.path.join(ev, 'kernel_sources_sha16.txt')).read().strip(),
            'hbm_bytes_per_launch': traffic}, open(os.path.join(prof, f"{tag.split('_')[0]}_traffic.json"), 'w'), indent=1)
-for name in ('c3', 'c3adam', 'c3_legacy_nll', 'c4', 'c4w', 'c4adam', 'c5', 'c2', 'pupil', 'ekf', 'c3_2ranks_gloo', 'c3_2ranks_gloo_strong'):
+for name in ('c3', 'c3adam', 'c3_legacy_nll', 'c3_nolag', 'c4', 'c4w', 'c4adam', 'c5', 'c2', 'pupil', 'ekf', 'c3_2ranks_gloo', 'c3_2ranks_gloo_strong'):
     src = os.path.join(ev, f'bench_{name}.json')
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(prof, f'{tag}_bench_{name}.json'))
 for name in ('pytest_gpu.txt', 'smoke.txt', 'adam_time.txt', 'dense_adam_time.txt', 'dense_adam_time_d.txt',
-             'pupil_time.txt', 'ekf_time.txt', 'driver_time.txt', 'host_path_time.txt', 'first_call.txt', 'nll_lean2.txt'):
+             'pupil_time.txt', 'ekf_time.txt', 'driver_time.txt', 'host_path_time.txt', 'first_call.txt', 'nll_lean2.txt', 'nll_lag.txt',
+             'fit_time.txt', 'host_boundary_ab.txt', 'grid_stamps.txt'):
     src = os.path.join(ev, name)
     if os.path.exists(src):
         shutil.copy(src, os.path.join(prof, f'{tag}_{name}'))
