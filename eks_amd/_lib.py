@@ -78,6 +78,7 @@ SIGNATURES = {
     'eks_host_thread_speedup': (c_double, [c_int32]),
     'eks_host_gather_cols': (ctypes.c_int, [c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                             c_void_p, c_int32]),
+    'eks_adam_run_stride': (c_int32, [c_void_p, c_int32]),
     'eks_profile_drain': (ctypes.c_int, [c_void_p, c_size_t, c_void_p, c_int32]),
     'eks_ensemble': (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32,
                                     c_float, c_void_p, c_void_p]),

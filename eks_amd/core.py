@@ -262,6 +262,11 @@ def _block_csr(blocks, K):
     return offs, members.astype(np.int32), of_kp
 
 
+_ADAM_LOOP_FAILED = ('eks_adam_run: a workgroup of the in-launch optimiser loop gave up waiting for its tile\'s step '
+                     '(eks_diag_nll.hip: GfLoop); results are invalid.  EKS_ADAM_PER_ITERATION=1 runs one launch per '
+                     'iteration instead')
+
+
 def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, s_bounds_log, tol,
                         safety_cap, min_R_var, s_mode, n_grid, sync_every: int | None = None):
     """Returns (s per keypoint as a device float64 tensor, info dict)."""
@@ -311,12 +316,12 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
     # launch that returns at once), the general path evaluates every keypoint whatever the optimiser state - a
     # round issued after the last block stopped costs a round of full evaluations - so its rounds are short.
     if sync_every is None:
-        sync_every = 16 if (P.flags & hip_ops.FLAG_DIAG_MODEL) else 4
-        # short scalar-chain sessions with one keypoint per block run a whole call in ONE launch whose workgroups
-        # stop by themselves (eks_diag_nll.hip: diag_nll_adam_persist_kernel): longer rounds cost nothing on the
-        # device and spare host round trips
-        if (P.flags & hip_ops.FLAG_DIAG_MODEL) and nb == P.K and y_c.shape[0] <= 4096 and P.K <= 512:
-            sync_every = 64
+        # the library knows which form the loop takes here (eks_adam_run_stride, include/eks_hip.h): one launch per
+        # call where the loss kernel keeps its workgroups (long calls cost nothing on the device and spare host round
+        # trips), one launch per iteration otherwise
+        sync_every = loop.stride()
+    if os.environ.get('EKS_ADAM_SYNC_EVERY'):            # (A/B runs)
+        sync_every = max(1, int(os.environ['EKS_ADAM_SYNC_EVERY']))
     rounds = (cap + sync_every - 1) // sync_every
     try:
         snap = _pinned_empty((max(rounds, 1),), torch.int32)
@@ -329,7 +334,10 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
         loop.run(n)
         iters += n
         if snap is None:
-            if int(loop.n_active.item()) == 0:
+            left = int(loop.n_active.item())
+            if left < 0:
+                raise RuntimeError(_ADAM_LOOP_FAILED)
+            if left == 0:
                 break
             continue
         snap[r:r + 1].copy_(loop.n_active, non_blocking=True)
@@ -337,7 +345,10 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
         ev.record()
         if pending is not None:
             pending[1].synchronize()
-            if int(snap[pending[0]]) == 0:
+            left = int(snap[pending[0]])
+            if left < 0:
+                raise RuntimeError(_ADAM_LOOP_FAILED)
+            if left == 0:
                 break
         pending = (r, ev)
         r += 1

@@ -12,6 +12,19 @@ namespace eks {
 // state of one optimiser block (a set of keypoints sharing one s): {u, mom, vel, prev_loss, iters, done}
 constexpr int kAdamState = 6;
 
+// base^n for the bias corrections 1 - 0.9^t, 1 - 0.999^t (t = the iteration count, a whole number): by squaring, ~20
+// dependent multiplications where the library's pow() was most of the step's 2.8 us on the loss kernel's critical path
+__device__ __forceinline__ double adam_pow_count(double base, double cnt) {
+  unsigned n = (unsigned)cnt;
+  double r = 1.0;
+  while (n) {
+    if (n & 1u) r *= base;
+    base *= base;
+    n >>= 1;
+  }
+  return r;
+}
+
 __device__ __forceinline__ bool adam_block_running(const double* __restrict__ state, int b, int cap) {
   return state[(size_t)b * kAdamState + 5] == 0.0 && state[(size_t)b * kAdamState + 4] < (double)cap;
 }
@@ -21,8 +34,9 @@ __device__ __forceinline__ bool adam_step_block(int b, const int32_t* __restrict
                                                 const int32_t* __restrict__ members,
                                                 const double* __restrict__ nll,
                                                 const double* __restrict__ dnll, double lr, double lo,
-                                                double hi, double tol, int cap, double* __restrict__ state,
-                                                double* __restrict__ s_keypoint) {
+                                                double hi, double tol, int cap, double* state,
+                                                double* s_keypoint) {
+  auto put = [](double* p, double v) { *p = v; };
   double* st = state + (size_t)b * kAdamState;
   double u = st[0], mom = st[1], vel = st[2], prev = st[3], iters = st[4], done = st[5];
   if (done == 0.0 && iters < (double)cap) {
@@ -36,19 +50,57 @@ __device__ __forceinline__ bool adam_step_block(int b, const int32_t* __restrict
     const double cnt = iters + 1.0;
     mom = 0.9 * mom + 0.1 * g;
     vel = 0.999 * vel + 0.001 * g * g;
-    const double mhat = mom / (1.0 - pow(0.9, cnt));
-    const double vhat = vel / (1.0 - pow(0.999, cnt));
+    const double mhat = mom / (1.0 - adam_pow_count(0.9, cnt));
+    const double vhat = vel / (1.0 - adam_pow_count(0.999, cnt));
     u = u - mhat / (sqrt(vhat) + 1e-8);
     const bool stop = isfinite(prev) &&
                       fabs(L - prev) < tol * fabs(log(fmax(prev, 1e-12))) + 1e-6;
     prev = L;
     iters = cnt;
     done = stop ? 1.0 : 0.0;
-    st[0] = u; st[1] = mom; st[2] = vel; st[3] = prev; st[4] = iters; st[5] = done;
+    put(st + 0, u); put(st + 1, mom); put(st + 2, vel); put(st + 3, prev); put(st + 4, iters); put(st + 5, done);
   }
   const double s = exp(fmin(fmax(u, lo), hi));
-  for (int i = offs[b]; i < offs[b + 1]; ++i) s_keypoint[members[i]] = s;
+  for (int i = offs[b]; i < offs[b + 1]; ++i) put(s_keypoint + members[i], s);
   return done == 0.0 && iters < (double)cap;
+}
+
+// The same step for an optimiser block that is ONE keypoint, its state, loss and gradient already in registers (the
+// fused form at the end of the scalar-chain loss kernel: no dependent loads of offs / members / nll on its critical path).
+struct AdamRegs {
+  double u, mom, vel, prev, iters, done;
+};
+__device__ __forceinline__ AdamRegs adam_load(const double* state, int b) {
+  const double* st = state + (size_t)b * kAdamState;
+  return AdamRegs{st[0], st[1], st[2], st[3], st[4], st[5]};
+}
+template <bool AGENT>
+__device__ __forceinline__ bool adam_step_single(int b, int k, AdamRegs a, double L, double g, double lr, double lo, double hi,
+                                                 double tol, int cap, double* state, double* s_keypoint, double* s_out) {
+  auto put = [](double* p, double v) {
+    if (AGENT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+  };
+  double* st = state + (size_t)b * kAdamState;
+  if (a.done == 0.0 && a.iters < (double)cap) {
+    if (a.u < lo || a.u > hi) g = 0.0;
+    g *= lr;
+    const double cnt = a.iters + 1.0;
+    a.mom = 0.9 * a.mom + 0.1 * g;
+    a.vel = 0.999 * a.vel + 0.001 * g * g;
+    const double mhat = a.mom / (1.0 - adam_pow_count(0.9, cnt));
+    const double vhat = a.vel / (1.0 - adam_pow_count(0.999, cnt));
+    a.u = a.u - mhat / (sqrt(vhat) + 1e-8);
+    const bool stop = isfinite(a.prev) && fabs(L - a.prev) < tol * fabs(log(fmax(a.prev, 1e-12))) + 1e-6;
+    a.prev = L;
+    a.iters = cnt;
+    a.done = stop ? 1.0 : 0.0;
+    put(st + 0, a.u); put(st + 1, a.mom); put(st + 2, a.vel); put(st + 3, a.prev); put(st + 4, a.iters); put(st + 5, a.done);
+  }
+  const double s = exp(fmin(fmax(a.u, lo), hi));
+  put(s_keypoint + k, s);
+  *s_out = s;
+  return a.done == 0.0 && a.iters < (double)cap;
 }
 
 // What the loss kernels of one Adam iteration need to (a) skip the keypoints whose optimiser block has

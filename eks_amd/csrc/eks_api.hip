@@ -235,6 +235,13 @@ int eks_adam_run(const eks_dims_t* d, const float* y, const double* rconst, cons
                        n_active, counter_b};
       return diag_nll_adam_persist(*d, y, rconst, M, n_iters, nll, dnll, F, n_active, st);
     }
+    if (in_kernel) {
+      // long sessions: the chip-wide loss kernel keeps its workgroups for all n_iters iterations (round 5: GfLoop)
+      const AdamFuse F{block_offsets, block_members, kp_block, lr, lo, hi, tol, safety_cap, 1, state, s_keypoint,
+                       n_active, counter_b};
+      rc = diag_nll_adam_loop(*d, y, rconst, M, n_iters, nll, dnll, F, workspace, workspace_bytes, st);
+      if (rc != EKS_ERR_UNSUPPORTED) return rc;
+    }
     for (int it = 0; it < n_iters; ++it) {
       // the LAST iteration of the call counts into n_active, the one before into the spare counter, ...
       const bool last_parity = ((n_iters - 1 - it) & 1) == 0;
@@ -259,6 +266,14 @@ int eks_adam_run(const eks_dims_t* d, const float* y, const double* rconst, cons
     if (rc != EKS_OK) return rc;
   }
   return EKS_OK;
+}
+
+int32_t eks_adam_run_stride(const eks_dims_t* d, int32_t n_blocks) {
+  if (check_dims(d) != EKS_OK || n_blocks <= 0) return 4;
+  if (!(d->flags & EKS_FLAG_DIAG_MODEL)) return 4;
+  if (diag_nll_adam_persist_ok(d->n_frames, d->n_keypoints, d->state_dim, n_blocks)) return 64;
+  if (diag_nll_adam_loop_ok(d->n_frames, d->n_keypoints, d->state_dim, n_blocks)) return 128;
+  return 16;
 }
 
 int eks_pupil_adam_run(const eks_dims_t* d, const float* y, const float* var, const double* m0,

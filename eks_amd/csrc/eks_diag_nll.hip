@@ -540,21 +540,33 @@ constexpr int kGfChunkMin = 256;      // (shorter chunks never leave the full re
 // stamps the 100 MHz real-time counter at the phase boundaries.
 #ifdef EKS_GF_STAMPS
 __device__ unsigned long long g_gf_stamps[256][kGfWaves][8];
+__device__ unsigned long long g_gf_iter[256][48][8];     // loop mode: wave 0 of every block, per iteration
 #define GF_STAMP(ph)                                                                                         \
   do {                                                                                                       \
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 256)                                                         \
       g_gf_stamps[blockIdx.x][threadIdx.x >> 6][ph] = __builtin_amdgcn_s_memrealtime();                      \
+    if (threadIdx.x == 0 && blockIdx.x < 256 && gf_it < 48)                                                  \
+      g_gf_iter[blockIdx.x][gf_it][ph] = __builtin_amdgcn_s_memrealtime();                                   \
   } while (0)
+#define GF_IT_DECL int gf_it = 0
+#define GF_IT_ARG , int gf_it
+#define GF_IT_PASS , gf_it
+#define GF_IT_SET(v) gf_it = (v)
 #else
 #define GF_STAMP(ph) do { } while (0)
+#define GF_IT_DECL
+#define GF_IT_ARG
+#define GF_IT_PASS
+#define GF_IT_SET(v)
 #endif
 
 struct GradFuseWs {
   double* grp;          // [ntile][ngroups][kGfFields][64]
-  int32_t* tickets;     // [ntile], zero between evaluations (the last block of a tile resets its own)
+  int32_t* tickets;     // [ntile], a multiple of ngroups between evaluations (every evaluation of a tile adds ngroups)
   int ngroups;
   int conv_allowed;     // converged-entry chunk terms where the poles allow (EKS_NLL_GRAD_TREE=1: always the tree)
 };
+struct GfLoop;
 
 __device__ __forceinline__ void gf_put(double* slot, const NllAcc<DualD>& a) {
   const DualD f[6] = {a.e.A, a.e.b, a.e.C, a.e.eta, a.e.J, a.ell};
@@ -622,27 +634,84 @@ __device__ __forceinline__ void gf_stores_acknowledged() {
 }
 
 
-// a chain's log-likelihood and derivative (wave 0 of the tile's last block) -> the keypoint's loss, gradient and step
+// ---- round 5: several optimiser iterations in one launch (eks_adam_run, the step applied in the kernel) -------------
+// An iteration's launch ends ~6 us after its last wave (dispatch of 256 workgroups, end-of-kernel cache maintenance:
+// the kernel trace shows 42 us per launch for 36 us of in-kernel timeline), 118 times on C3.  In loop mode the launch's
+// workgroups stay: the tile's last block applies the step, stores the new s and optimiser state through to memory
+// (agent-scope stores, like the group slots) and hands s to the tile's other blocks (gf_hand_put), which
+// poll for it and start the next evaluation from the new s.  Tiles are independent - each runs until all of its
+// keypoints have stopped or the call's iterations are used up.  The launch is cooperative (all ntile x ngroups
+// workgroups resident; the runtime runs one cooperative launch at a time, so two host threads' loops cannot wait on
+// each other's unscheduled workgroups), and the poll is bounded: a workgroup that never sees its tile's counter move
+// gives up and marks the call as failed (n_active < 0, checked by the caller); the tile's other blocks follow.
+struct GfLoop {
+  int n_iters;            // iterations of this launch
+  unsigned long long* hand;   // [ntile][64][2], zero when the launch starts: the hand-off words (below)
+};
+constexpr int kGfSpinLimit = 1 << 17;       // polls (each a trip to memory, ~1 us)
+constexpr int kGfFailed = -(1 << 30);
+// The step's hand-off to the tile's other blocks: s as two 64-bit words per lane, each (tag << 32) | half of s's bits
+// with tag = iteration + 1 (bit 31: the keypoint is still running).  A 64-bit store is indivisible, so a word whose tag
+// matches carries this iteration's half whatever order the stores land in: no acknowledgement wait between data and
+// flag on the writer's side, no second trip to memory after the flag on the readers'.
+__device__ __forceinline__ void gf_hand_put(unsigned long long* slot, int it, bool run, double s) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
+  const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) | (run ? 0x80000000u : 0u)) << 32;
+  __hip_atomic_store(slot + 0, tag | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(slot + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool gf_hand_poll(const unsigned long long* slot, int it, bool& run, double& s) {
+  const unsigned long long w0 = __hip_atomic_load(slot + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long w1 = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned want = (unsigned)(it + 1);
+  const unsigned t0 = (unsigned)(w0 >> 32), t1 = (unsigned)(w1 >> 32);
+  if ((t0 & 0x7FFFFFFFu) != want || (t1 & 0x7FFFFFFFu) != want) return false;
+  run = (t0 >> 31) != 0;
+  s = __longlong_as_double((long long)((w0 & 0xFFFFFFFFull) | (w1 << 32)));
+  return true;
+}
+
+// a chain's log-likelihood and derivative (wave 0 of the tile's last block) -> the keypoint's loss, gradient and step.
+// `st`: the optimiser state of the lane's keypoint, requested beside the group slots.  Loop mode: also the lane's s for
+// the next evaluation and whether its keypoint is still running.
+template <bool LOOP>
 __device__ __forceinline__ void gf_finish(const NllGeom& G, const AdamFuse& F, int lane, int k, int d, int kb, bool running,
-                                          double v, double g, double* __restrict__ nll, double* __restrict__ dnll) {
+                                          double v, double g, const AdamRegs& st, double* __restrict__ nll,
+                                          double* __restrict__ dnll, bool count_now, double& s_next, bool& run_next) {
   for (int off = 1; off < G.D; off <<= 1) {          // the D chains of a keypoint sit in adjacent lanes
     v += __shfl_xor(v, off);
     g += __shfl_xor(g, off);
   }
   bool still = false;
+  double s_new = s_next;
   if (running && d == 0) {
     v = -v;
     const bool fin = isfinite(v);                    // eks/core.py:650
-    nll[k] = fin ? v : 1e12;
-    dnll[k] = fin ? -g : 0.0;
+    const double L = fin ? v : 1e12, dL = fin ? -g : 0.0;
+    if (LOOP) {      // (another XCD's block wrote them an iteration ago: written through, or its stale line could land last)
+      gf_publish(nll + k, L);
+      gf_publish(dnll + k, dL);
+    } else {
+      nll[k] = L;
+      dnll[k] = dL;
+    }
     if (F.state != nullptr && F.step_in_kernel)
-      still = adam_step_block(kb, F.offs, F.members, nll, dnll, F.lr, F.lo, F.hi, F.tol, F.cap, F.state,
-                              F.s_keypoint);
+      still = adam_step_single<LOOP>(kb, k, st, L, dL, F.lr, F.lo, F.hi, F.tol, F.cap, F.state, F.s_keypoint, &s_new);
   }
-  if (F.state != nullptr && F.step_in_kernel) {
+  if (F.state != nullptr && F.step_in_kernel && count_now) {
     const int cnt = __popcll(__ballot(still));
     if (lane == 0 && cnt) atomicAdd(F.n_active_cur, cnt);
   }
+  if (LOOP) {
+    const int lead = lane & ~(G.D - 1);              // the keypoint's first chain holds its step
+    s_next = __shfl(s_new, lead);
+    run_next = __shfl((int)still, lead) != 0;
+  }
+}
+// (wave 0 of the last block, behind the acquire fence) the state gf_finish will need
+__device__ __forceinline__ AdamRegs gf_state_request(const AdamFuse& F, int w, int d, int kb, bool running) {
+  if (w == 0 && d == 0 && running && F.state != nullptr && F.step_in_kernel) return adam_load(F.state, kb);
+  return AdamRegs{0, 0, 0, 0, 0, 1.0};
 }
 
 // ---- round 5: the evaluation without compositions.  With every chunk past the first summarised from a converged
@@ -652,152 +721,163 @@ __device__ __forceinline__ void gf_finish(const NllGeom& G, const AdamFuse& F, i
 // meet in LDS; the term of a block's FIRST chunk needs the previous block's last b, so each block publishes
 // (sum of its finished terms, its last b, its first chunk's eta, J, xref: 9 doubles per lane instead of 13) and the
 // tile's last block adds the deferred terms - independent loads and a sum where the tree had log-depth compositions.
+#ifndef EKS_GF_ROWS
+#define EKS_GF_ROWS 8
+#endif
+constexpr int kGfRows = EKS_GF_ROWS;                // frames per row buffer of the converged-entry chunk body (two buffers)
 constexpr int kGcSum = 0, kGcB = 2, kGcEta = 4, kGcJ = 6, kGcXr = 8;      // field rows of a group's slot ([field][64])
 
-template <bool UNIT, typename LD>
-__device__ __forceinline__ void gf_conv_body(const NllGeom& G, const DiagModel& M, const GradFuseWs& W, const AdamFuse& F,
-                                             double* lds, int* last_flag, const LD& ld, const ConvConst& KC, int w, int lane,
-                                             int tile, int grp, int j, int nvalid, int t0, int len, double r_n, double a_n,
-                                             double c_n, double sq_n, int k, int d, size_t dd, int kb, bool running,
-                                             double* mine, double* __restrict__ nll, double* __restrict__ dnll) {
-  double* bx = lds;                                  // [kGfWaves][2][64]: the mean each chunk hands on
-  double* part = lds + kGfWaves * 2 * 64;            // [kGfWaves][2][64]: the waves' terms
-  DualD term(0.0), eta(0.0), Jc(0.0);
-  double xr = 0.0;
-  if (j == 0) {                                      // chunk 0: known entry state, applied to the prior here
+// everything one evaluation needs that does not change between iterations
+template <typename LD>
+struct GfCtx {
+  const NllGeom& G;
+  const DiagModel& M;
+  const GradFuseWs& W;
+  const AdamFuse& F;
+  const LD& ld;
+  double* lds;
+  int* last_flag;
+  double* mine;
+  double* __restrict__ nll;
+  double* __restrict__ dnll;
+  int w, lane, tile, grp, j, nvalid, t0, len, k, d, kb;
+  size_t dd;
+  double r_n, a_n, c_n, q_n;
+};
+
+// one evaluation at s_now.  Returns whether this block was its tile's last (block-uniform); in that block wave 0 has
+// written the keypoints' loss and gradient and applied the step (s_next / run_next: wave 0, loop mode).
+template <bool UNIT, bool LOOP, typename LD>
+__device__ __forceinline__ bool gf_evaluate(const GfCtx<LD>& X, double s_now, bool running, bool count_now,
+                                            const float (&pre)[kGfRows], double& s_next, bool& run_next GF_IT_ARG) {
+  const NllGeom& G = X.G;
+  const GradFuseWs& W = X.W;
+  const int w = X.w, lane = X.lane;
+  const double sq_n = s_now * X.q_n;
+  // every chunk past the first by its converged-entry summary when the tile's poles allow it (the same answer in
+  // every block of the tile: it depends on the chains' constants alone)
+  bool conv = false;
+  ConvConst KC;
+  if (W.conv_allowed && G.ncn > 1) {
+    KC = conv_const<UNIT>(X.r_n, X.a_n, X.c_n, sq_n);
+    conv = __all(conv_chunk_ok(KC, min(G.B0, G.BN)));
+  }
+  if (conv) {
+    double* bx = X.lds;                                // [kGfWaves][2][64]: the mean each chunk hands on
+    double* part = X.lds + kGfWaves * 2 * 64;          // [kGfWaves][2][64]: the waves' terms
+    DualD term(0.0), eta(0.0), Jc(0.0);
+    double xr = 0.0;
+    if (X.j == 0) {                                    // chunk 0: known entry state, applied to the prior here
+      double sq[1] = {sq_n};
+      NllElem<Dual> out[1];
+      nll_summarize_chunk<Dual, 1, UNIT>(X.ld, X.t0, X.len, X.r_n, X.a_n, X.c_n, sq, out, false, G.T);
+      const DualD A(out[0].e.A.v, out[0].e.A.d), b(out[0].e.b.v, out[0].e.b.d), e0(out[0].e.eta.v, out[0].e.eta.d),
+          J0(out[0].e.J.v, out[0].e.J.d), ell(out[0].ell, out[0].dell);
+      const DualD mr = DualD(X.M.m0[(size_t)X.k * G.D + X.d] - (double)out[0].xref), P = DualD(X.M.S0[X.dd]);
+      const DualD den = DualD(1.0) + J0 * P;
+      const DualD inv = rcp(den);
+      term = ell - DualD(0.5) * log_with_rcp(den, inv) +
+             (e0 * mr + DualD(0.5) * e0 * e0 * P - DualD(0.5) * J0 * mr * mr) * inv;
+      const DualD bn = A * inv * (mr + P * e0) + b;     // (b is absolute, mr relative to xref)
+      bx[(w * 2 + 0) * 64 + lane] = bn.v;
+      bx[(w * 2 + 1) * 64 + lane] = bn.d;
+    } else if (X.j < G.ncn) {
+      ConvDual o;
+      nll_conv_chunk_dual<UNIT, kGfRows>(X.ld, X.len, KC, X.a_n, X.c_n, o, X.len >= kGfRows ? pre : nullptr);
+      term = DualD(o.ell, o.dell);
+      eta = DualD(o.eta, o.deta);
+      Jc = DualD(o.J, o.dJ);
+      xr = (double)o.xref;
+      bx[(w * 2 + 0) * 64 + lane] = o.b;
+      bx[(w * 2 + 1) * 64 + lane] = o.db;
+    }
+    GF_STAMP(1);
+    __syncthreads();
+    if (w > 0 && X.j < G.ncn) {
+      const DualD mr = DualD(bx[((w - 1) * 2 + 0) * 64 + lane], bx[((w - 1) * 2 + 1) * 64 + lane]) - DualD(xr);
+      term = term + eta * mr - DualD(0.5) * Jc * mr * mr;
+    }
+    part[(w * 2 + 0) * 64 + lane] = term.v;
+    part[(w * 2 + 1) * 64 + lane] = term.d;
+    __syncthreads();
+    GF_STAMP(2);
+    if (w == 0) {
+      double sv = 0.0, sd = 0.0;
+#pragma unroll
+      for (int q = 0; q < kGfWaves; ++q) {
+        sv += part[(q * 2 + 0) * 64 + lane];
+        sd += part[(q * 2 + 1) * 64 + lane];
+      }
+      double* mine = X.mine;
+      gf_publish(mine + (kGcSum + 0) * 64, sv);
+      gf_publish(mine + (kGcSum + 1) * 64, sd);
+      gf_publish(mine + (kGcB + 0) * 64, bx[((X.nvalid - 1) * 2 + 0) * 64 + lane]);
+      gf_publish(mine + (kGcB + 1) * 64, bx[((X.nvalid - 1) * 2 + 1) * 64 + lane]);
+      gf_publish(mine + (kGcEta + 0) * 64, eta.v);
+      gf_publish(mine + (kGcEta + 1) * 64, eta.d);
+      gf_publish(mine + (kGcJ + 0) * 64, Jc.v);
+      gf_publish(mine + (kGcJ + 1) * 64, Jc.d);
+      gf_publish(mine + kGcXr * 64, xr);
+      gf_stores_acknowledged();
+      if (lane == 0) *X.last_flag = (atomicAdd(W.tickets + X.tile, 1) + 1) % W.ngroups == 0;
+    }
+    __syncthreads();
+    GF_STAMP(3);
+    if (!*X.last_flag) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other blocks' slots (and, loop mode, the optimiser state)
+    // ---- the tile's last block: every group's sum and deferred first term at once, wave w taking groups w, w + 8, ...
+    // (four groups' fields - and the keypoints' optimiser state - requested together: one trip to memory, not four)
+    const AdamRegs st = gf_state_request(X.F, w, X.d, X.kb, running);
+    const double* base = W.grp + (size_t)X.tile * W.ngroups * kGfFields * 64 + lane;
+    DualD tot(0.0);
+    for (int gb = w; gb < W.ngroups; gb += 4 * kGfWaves) {
+      double f[4][9];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int g = min(gb + q * kGfWaves, W.ngroups - 1);
+        const double* sl = base + (size_t)g * kGfFields * 64;
+        const double* pv = g > 0 ? sl - (size_t)kGfFields * 64 : sl;
+        f[q][0] = sl[(kGcSum + 0) * 64]; f[q][1] = sl[(kGcSum + 1) * 64];
+        f[q][2] = pv[(kGcB + 0) * 64];   f[q][3] = pv[(kGcB + 1) * 64];
+        f[q][4] = sl[(kGcEta + 0) * 64]; f[q][5] = sl[(kGcEta + 1) * 64];
+        f[q][6] = sl[(kGcJ + 0) * 64];   f[q][7] = sl[(kGcJ + 1) * 64];
+        f[q][8] = sl[kGcXr * 64];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int g = gb + q * kGfWaves;
+        if (g < W.ngroups) {
+          tot = tot + DualD(f[q][0], f[q][1]);
+          if (g > 0) {
+            const DualD mr = DualD(f[q][2], f[q][3]) - DualD(f[q][8]);
+            tot = tot + DualD(f[q][4], f[q][5]) * mr - DualD(0.5) * DualD(f[q][6], f[q][7]) * mr * mr;
+          }
+        }
+      }
+    }
+    GF_STAMP(4);
+    part[(w * 2 + 0) * 64 + lane] = tot.v;             // (every wave is past its reads of `part`: the barrier above)
+    part[(w * 2 + 1) * 64 + lane] = tot.d;
+    __syncthreads();
+    GF_STAMP(5);
+    if (w == 0) {
+      double v = 0.0, g = 0.0;
+#pragma unroll
+      for (int q = 0; q < kGfWaves; ++q) {
+        v += part[(q * 2 + 0) * 64 + lane];
+        g += part[(q * 2 + 1) * 64 + lane];
+      }
+      gf_finish<LOOP>(G, X.F, lane, X.k, X.d, X.kb, running, v, g, st, X.nll, X.dnll, count_now, s_next, run_next);
+      GF_STAMP(6);
+    }
+    return true;
+  }
+  // ---- exact-entry summaries composed in order: block tree, group slots, the last block's walk and tree (round 3)
+  NllAcc<DualD> acc;
+  if (X.j < G.ncn) {
     double sq[1] = {sq_n};
     NllElem<Dual> out[1];
-    nll_summarize_chunk<Dual, 1, UNIT>(ld, t0, len, r_n, a_n, c_n, sq, out, false);
-    const DualD A(out[0].e.A.v, out[0].e.A.d), b(out[0].e.b.v, out[0].e.b.d), e0(out[0].e.eta.v, out[0].e.eta.d),
-        J0(out[0].e.J.v, out[0].e.J.d), ell(out[0].ell, out[0].dell);
-    const DualD mr = DualD(M.m0[(size_t)k * G.D + d] - (double)out[0].xref), P = DualD(M.S0[dd]);
-    const DualD den = DualD(1.0) + J0 * P;
-    const DualD inv = rcp(den);
-    term = ell - DualD(0.5) * log_with_rcp(den, inv) + (e0 * mr + DualD(0.5) * e0 * e0 * P - DualD(0.5) * J0 * mr * mr) * inv;
-    const DualD bn = A * inv * (mr + P * e0) + b;     // (b is absolute, mr relative to xref)
-    bx[(w * 2 + 0) * 64 + lane] = bn.v;
-    bx[(w * 2 + 1) * 64 + lane] = bn.d;
-  } else if (j < G.ncn) {
-    ConvDual o;
-    nll_conv_chunk_dual<UNIT>(ld, len, KC, a_n, c_n, o);
-    term = DualD(o.ell, o.dell);
-    eta = DualD(o.eta, o.deta);
-    Jc = DualD(o.J, o.dJ);
-    xr = (double)o.xref;
-    bx[(w * 2 + 0) * 64 + lane] = o.b;
-    bx[(w * 2 + 1) * 64 + lane] = o.db;
-  }
-  GF_STAMP(1);
-  __syncthreads();
-  if (w > 0 && j < G.ncn) {
-    const DualD mr = DualD(bx[((w - 1) * 2 + 0) * 64 + lane], bx[((w - 1) * 2 + 1) * 64 + lane]) - DualD(xr);
-    term = term + eta * mr - DualD(0.5) * Jc * mr * mr;
-  }
-  part[(w * 2 + 0) * 64 + lane] = term.v;
-  part[(w * 2 + 1) * 64 + lane] = term.d;
-  __syncthreads();
-  GF_STAMP(2);
-  if (w == 0) {
-    double sv = 0.0, sd = 0.0;
-#pragma unroll
-    for (int q = 0; q < kGfWaves; ++q) {
-      sv += part[(q * 2 + 0) * 64 + lane];
-      sd += part[(q * 2 + 1) * 64 + lane];
-    }
-    gf_publish(mine + (kGcSum + 0) * 64, sv);
-    gf_publish(mine + (kGcSum + 1) * 64, sd);
-    gf_publish(mine + (kGcB + 0) * 64, bx[((nvalid - 1) * 2 + 0) * 64 + lane]);
-    gf_publish(mine + (kGcB + 1) * 64, bx[((nvalid - 1) * 2 + 1) * 64 + lane]);
-    gf_publish(mine + (kGcEta + 0) * 64, eta.v);
-    gf_publish(mine + (kGcEta + 1) * 64, eta.d);
-    gf_publish(mine + (kGcJ + 0) * 64, Jc.v);
-    gf_publish(mine + (kGcJ + 1) * 64, Jc.d);
-    gf_publish(mine + kGcXr * 64, xr);
-    gf_stores_acknowledged();
-    if (lane == 0) *last_flag = atomicAdd(W.tickets + tile, 1) == W.ngroups - 1;
-  }
-  __syncthreads();
-  GF_STAMP(3);
-  if (!*last_flag) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other blocks' slots
-  // ---- the tile's last block: every group's sum and deferred first term at once, wave w taking groups w, w + 8, ...
-  const double* base = W.grp + (size_t)tile * W.ngroups * kGfFields * 64 + lane;
-  DualD tot(0.0);
-  for (int g = w; g < W.ngroups; g += kGfWaves) {
-    const double* sl = base + (size_t)g * kGfFields * 64;
-    tot = tot + DualD(sl[(kGcSum + 0) * 64], sl[(kGcSum + 1) * 64]);
-    if (g > 0) {
-      const double* pv = sl - (size_t)kGfFields * 64;
-      const DualD mr = DualD(pv[(kGcB + 0) * 64], pv[(kGcB + 1) * 64]) - DualD(sl[kGcXr * 64]);
-      const DualD e(sl[(kGcEta + 0) * 64], sl[(kGcEta + 1) * 64]), Jg(sl[(kGcJ + 0) * 64], sl[(kGcJ + 1) * 64]);
-      tot = tot + e * mr - DualD(0.5) * Jg * mr * mr;
-    }
-  }
-  GF_STAMP(4);
-  part[(w * 2 + 0) * 64 + lane] = tot.v;             // (every wave is past its reads of `part`: the barrier above)
-  part[(w * 2 + 1) * 64 + lane] = tot.d;
-  __syncthreads();
-  GF_STAMP(5);
-  if (w != 0) return;
-  if (lane == 0) W.tickets[tile] = 0;                // ready for the next evaluation (stream order)
-  double v = 0.0, g = 0.0;
-#pragma unroll
-  for (int q = 0; q < kGfWaves; ++q) {
-    v += part[(q * 2 + 0) * 64 + lane];
-    g += part[(q * 2 + 1) * 64 + lane];
-  }
-  gf_finish(G, F, lane, k, d, kb, running, v, g, nll, dnll);
-  GF_STAMP(6);
-}
-
-template <bool UNIT>
-__global__ __launch_bounds__(64 * kGfWaves) void diag_nll_grad_fused_kernel(NllGeom G, DiagModel M, GradFuseWs W,
-                                                                           const float* __restrict__ y,
-                                                                           const double* __restrict__ rconst,
-                                                                           const double* __restrict__ s_kp,
-                                                                           double* __restrict__ nll,
-                                                                           double* __restrict__ dnll, AdamFuse F) {
-  __shared__ double lds[kGfWaves * kGfFields * 64];
-  __shared__ int last_flag;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int tile = blockIdx.x % G.ntile, grp = blockIdx.x / G.ntile;
-  if (F.state != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *F.n_active_next = 0;
-  const int n_raw = tile * 64 + lane;
-  const bool chain_ok = n_raw < G.N;
-  const int n = chain_ok ? n_raw : G.N - 1;          // lanes past the last chain shadow it (results unused)
-  const int k = n / G.D, d = n - k * G.D;
-  const size_t dd = (size_t)k * G.D * G.D + (size_t)d * (G.D + 1);
-  const int j = grp * kGfWaves + w;
-  const int nvalid = min(kGfWaves, G.ncn - grp * kGfWaves);
-  const int t0 = j * G.BN, len = j < G.ncn ? min(G.BN, G.T - t0) : 0;
-  const double r_n = rconst[n], a_n = M.A[dd], c_n = M.C[dd], q_n = M.Q[dd];
-  const BufferRows ld{__builtin_amdgcn_make_buffer_rsrc(
-                          const_cast<float*>(y + (size_t)(j < G.ncn ? t0 : 0) * G.N + tile * 64), 0, 0x7FFFFFFF,
-                          0x00020000),
-                      (unsigned)((n - tile * 64) * 4), (unsigned)(G.N * 4)};
-  double* mine = W.grp + ((size_t)tile * W.ngroups + grp) * kGfFields * 64 + lane;
-  const int kb = F.state != nullptr ? F.kp_block[k] : 0;
-  bool running = chain_ok;
-  if (F.state != nullptr) {
-    running = chain_ok && adam_block_running(F.state, kb, F.cap);
-    if (!__any(running)) return;                     // the same answer in every wave of the tile's blocks
-  }
-  GF_STAMP(0);
-  // ---- round 5: every chunk past the first by its converged-entry summary when the tile's poles allow it (the
-  // ---- same answer in every block of the tile: it depends on the chains' constants alone)
-  if (W.conv_allowed && G.ncn > 1) {
-    const ConvConst KC = conv_const<UNIT>(r_n, a_n, c_n, s_kp[k] * q_n);
-    if (__all(conv_chunk_ok(KC, G.BN))) {
-      gf_conv_body<UNIT>(G, M, W, F, lds, &last_flag, ld, KC, w, lane, tile, grp, j, nvalid, t0, len, r_n, a_n, c_n,
-                         s_kp[k] * q_n, k, d, dd, kb, running, mine, nll, dnll);
-      return;
-    }
-  }
-  NllAcc<DualD> acc;
-  if (j < G.ncn) {
-    double sq[1] = {s_kp[k] * q_n};
-    NllElem<Dual> out[1];
-    nll_summarize_chunk<Dual, 1, UNIT>(ld, t0, len, r_n, a_n, c_n, sq, out, false);
+    nll_summarize_chunk<Dual, 1, UNIT>(X.ld, X.t0, X.len, X.r_n, X.a_n, X.c_n, sq, out, false, G.T);
     acc.e.A = DualD(out[0].e.A.v, out[0].e.A.d);
     acc.e.b = DualD(out[0].e.b.v, out[0].e.b.d);
     acc.e.C = DualD(out[0].e.C.v, out[0].e.C.d);
@@ -807,38 +887,137 @@ __global__ __launch_bounds__(64 * kGfWaves) void diag_nll_grad_fused_kernel(NllG
     acc.xr = (double)out[0].xref;
   }
   GF_STAMP(1);
-  gf_block_tree(lds, w, lane, nvalid, acc);
+  gf_block_tree(X.lds, w, lane, X.nvalid, acc);
   GF_STAMP(2);
   if (w == 0) {
-    gf_put_published(mine, acc);
+    gf_put_published(X.mine, acc);
     gf_stores_acknowledged();
-    if (lane == 0) last_flag = atomicAdd(W.tickets + tile, 1) == W.ngroups - 1;
+    if (lane == 0) *X.last_flag = (atomicAdd(W.tickets + X.tile, 1) + 1) % W.ngroups == 0;
   }
   __syncthreads();
   GF_STAMP(3);
-  if (!last_flag) return;
+  if (!*X.last_flag) return false;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other blocks' group summaries
   // ---- the tile's last block: compose its groups (a contiguous run per wave), finish, step
+  const AdamRegs st = gf_state_request(X.F, w, X.d, X.kb, running);
   const int per = (W.ngroups + kGfWaves - 1) / kGfWaves;
   const int g0 = w * per, g1 = min(W.ngroups, g0 + per);
   const int nlive = (W.ngroups + per - 1) / per;
-  const double* base = W.grp + (size_t)tile * W.ngroups * kGfFields * 64 + lane;
+  const double* base = W.grp + (size_t)X.tile * W.ngroups * kGfFields * 64 + lane;
   if (g0 < g1) {
     acc = gf_take(base + (size_t)g0 * kGfFields * 64);
     for (int g = g0 + 1; g < g1; ++g) acc = nll_acc_combine(acc, gf_take(base + (size_t)g * kGfFields * 64));
   }
   GF_STAMP(4);
-  gf_block_tree(lds, w, lane, nlive, acc);
+  gf_block_tree(X.lds, w, lane, nlive, acc);
   GF_STAMP(5);
-  if (w != 0) return;
-  if (lane == 0) W.tickets[tile] = 0;                // ready for the next evaluation (stream order)
-  const DualD m = DualD(M.m0[(size_t)k * G.D + d] - acc.xr), P = DualD(M.S0[dd]);   // relative to the reference
-  const DualD den = DualD(1.0) + acc.e.J * P;
-  const DualD inv = rcp(den);
-  const DualD ll = acc.ell - DualD(0.5) * log_with_rcp(den, inv) +
-                   (acc.e.eta * m + DualD(0.5) * acc.e.eta * acc.e.eta * P - DualD(0.5) * acc.e.J * m * m) * inv;
-  gf_finish(G, F, lane, k, d, kb, running, ll.v, ll.d, nll, dnll);
-  GF_STAMP(6);
+  if (w == 0) {
+    const DualD m = DualD(X.M.m0[(size_t)X.k * G.D + X.d] - acc.xr), P = DualD(X.M.S0[X.dd]);   // relative to the reference
+    const DualD den = DualD(1.0) + acc.e.J * P;
+    const DualD inv = rcp(den);
+    const DualD ll = acc.ell - DualD(0.5) * log_with_rcp(den, inv) +
+                     (acc.e.eta * m + DualD(0.5) * acc.e.eta * acc.e.eta * P - DualD(0.5) * acc.e.J * m * m) * inv;
+    gf_finish<LOOP>(G, X.F, lane, X.k, X.d, X.kb, running, ll.v, ll.d, st, X.nll, X.dnll, count_now, s_next, run_next);
+    GF_STAMP(6);
+  }
+  return true;
+}
+
+template <bool UNIT, bool LOOP>
+__global__ __launch_bounds__(64 * kGfWaves) void diag_nll_grad_fused_kernel(NllGeom G, DiagModel M, GradFuseWs W,
+                                                                           const float* __restrict__ y,
+                                                                           const double* __restrict__ rconst,
+                                                                           const double* s_kp,
+                                                                           double* __restrict__ nll,
+                                                                           double* __restrict__ dnll, AdamFuse F, GfLoop L) {
+  __shared__ double lds[kGfWaves * kGfFields * 64];
+  __shared__ int last_flag;
+  __shared__ double next_s[64];
+  __shared__ int next_run[64];
+  __shared__ int wait_failed;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int tile = blockIdx.x % G.ntile, grp = blockIdx.x / G.ntile;
+  // (a launch of its own counts into alternating counters and zeroes the next one; a longer call's is zeroed by the host)
+  if ((!LOOP || L.hand == nullptr) && F.state != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *F.n_active_next = 0;
+  const int n_raw = tile * 64 + lane;
+  const bool chain_ok = n_raw < G.N;
+  const int n = chain_ok ? n_raw : G.N - 1;          // lanes past the last chain shadow it (results unused)
+  const int k = n / G.D, d = n - k * G.D;
+  const size_t dd = (size_t)k * G.D * G.D + (size_t)d * (G.D + 1);
+  const int j = grp * kGfWaves + w;
+  const int t0 = j == 0 ? 0 : G.B0 + (j - 1) * G.BN;     // chunk 0 is the short one (its transient is the expensive part)
+  const BufferRows ld{__builtin_amdgcn_make_buffer_rsrc(
+                          const_cast<float*>(y + (size_t)(j < G.ncn ? t0 : 0) * G.N + tile * 64), 0, 0x7FFFFFFF,
+                          0x00020000),
+                      (unsigned)((n - tile * 64) * 4), (unsigned)(G.N * 4)};
+  const int kb = F.state != nullptr ? F.kp_block[k] : 0;
+  const GfCtx<BufferRows> X{G, M, W, F, ld, lds, &last_flag,
+                            W.grp + ((size_t)tile * W.ngroups + grp) * kGfFields * 64 + lane, nll, dnll,
+                            w, lane, tile, grp, j, min(kGfWaves, G.ncn - grp * kGfWaves), t0,
+                            j < G.ncn ? min(j == 0 ? G.B0 : G.BN, G.T - t0) : 0, k, d, kb, dd,
+                            rconst[n], M.A[dd], M.C[dd], M.Q[dd]};
+  double s_now = s_kp[k];
+  bool running = chain_ok;
+  if (F.state != nullptr) running = chain_ok && adam_block_running(F.state, kb, F.cap);
+#ifdef EKS_GF_STAGGER
+  if (LOOP) {                                          // (experiment) tiles start EKS_GF_STAGGER x 10 ns apart
+    const unsigned long long t_go = __builtin_amdgcn_s_memrealtime() + (unsigned long long)tile * EKS_GF_STAGGER;
+    while (__builtin_amdgcn_s_memrealtime() < t_go) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
+  // the first rows of a converged-entry chunk do not depend on s: they are requested before the step is waited for
+  float pre[kGfRows];
+  auto request_first_rows = [&]() {
+    if (j >= 1 && X.len >= kGfRows) {
+#pragma unroll
+      for (int q = 0; q < kGfRows; ++q) pre[q] = ld(q);
+    } else {
+#pragma unroll
+      for (int q = 0; q < kGfRows; ++q) pre[q] = 0.f;
+    }
+  };
+  request_first_rows();
+  GF_IT_DECL;
+  for (int it = 0;; ++it) {
+    if (F.state != nullptr && !__any(running)) return;   // the same answer in every wave of the tile's blocks
+    GF_IT_SET(it);
+    GF_STAMP(0);
+    double s_next = s_now;
+    bool run_next = false;
+    const bool was_last = gf_evaluate<UNIT, LOOP>(X, s_now, running, !LOOP || it == L.n_iters - 1, pre, s_next, run_next GF_IT_PASS);
+    if (!LOOP || it + 1 >= L.n_iters) return;
+    request_first_rows();
+    if (was_last) {
+      // this block applied the step: s and the running flags to the tile's other blocks and to its own other waves
+      if (w == 0) {
+        gf_hand_put(L.hand + ((size_t)tile * 64 + lane) * 2, it, run_next && chain_ok, s_next);
+        next_s[lane] = s_next;
+        next_run[lane] = run_next && chain_ok;
+      }
+    } else if (w == 0) {
+      const unsigned long long* slot = L.hand + ((size_t)tile * 64 + lane) * 2;
+      bool got = false, r = false;
+      double sv = s_now;
+      int spins = 0;
+      for (;;) {
+        if (!got) got = gf_hand_poll(slot, it, r, sv);
+        if (__all(got) || ++spins >= kGfSpinLimit) break;
+        __builtin_amdgcn_s_sleep(4);
+      }
+      const bool all_got = __all(got);
+      next_s[lane] = sv;
+      next_run[lane] = r;
+      if (lane == 0) wait_failed = all_got ? 0 : 1;
+    }
+    __syncthreads();
+    if (!was_last && wait_failed) {
+      if (threadIdx.x == 0) atomicAdd(F.n_active_cur, kGfFailed);
+      return;
+    }
+    s_now = next_s[lane];
+    running = next_run[lane] != 0;
+    GF_STAMP(7);
+  }
 }
 
 // N2'' chunk-parallel assembly for the grid search (value only, converged-entry summaries): a
@@ -1554,10 +1733,19 @@ static NllGeom make_geom(int T, int N, int D, int n_cand, int per_keypoint, bool
   G.T = T;
   G.D = D;
   G.BN = grad ? kNllChunkGrad : kNllChunk;
+  G.B0 = G.BN;
   if (grad && grad_fused_ok(T, N, D, n_cand, per_keypoint)) {
     G.BN = grad_fused_chunk(T, N);
+    // Chunk 0 starts from a known state and pays the transient regimes (the dual-number recursion in full until the
+    // variance has converged): at the others' length its wave was the one every iteration waited for (C3, mid-search:
+    // 38 us against 24; with 128 frames the tiles whose poles are above 0.84 mid-search lose the converged-entry form,
+    // 128 / 200 / 256 / 392 frames: 5.06 / 4.98 / 4.93 / 5.08 ms for the whole search).  Round 5: two thirds of BN.
+    G.B0 = G.BN >= 192 ? (G.BN * 2 / 3) / 8 * 8 : G.BN;
+    if (knob_set(KNOB_NLL_CHUNK0)) {
+      const int b0 = knob_int(KNOB_NLL_CHUNK0, 128) / 8 * 8;
+      G.B0 = b0 < 8 ? 8 : (b0 > G.BN ? G.BN : b0);
+    }
   }
-  G.B0 = G.BN;
   if (!grad) {
     // one block per (64-chain tile, chunk): pick the chunk length so that the grid is a whole
     // number of 256-CU rounds (C3: 8 tiles x 32 chunks = 256 blocks)
@@ -1630,13 +1818,113 @@ size_t diag_nll_workspace_bytes(int T, int N, int n_cand) {
   return 11 * fl + 2 * db + adam_extra_bytes(N);
 }
 
-// [keypoint -> block map : N ints][tile tickets : ceil(N / 64) ints][second counter : 256 B]
+// [keypoint -> block map : N ints][tile tickets : ceil(N / 64) ints][hand-off words : ceil(N / 64) x 64 x 2 x 8 B]
+// [second counter : 256 B]
 size_t adam_extra_bytes(int N) {
-  return align_up((size_t)N * sizeof(int32_t), 256) + align_up((size_t)((N + 63) / 64) * sizeof(int32_t), 256) + 256;
+  return align_up((size_t)N * sizeof(int32_t), 256) + align_up((size_t)((N + 63) / 64) * sizeof(int32_t), 256) +
+         (size_t)((N + 63) / 64) * 1024 + 256;
+}
+static void* nll_ws_hand(void* ws, int T, int N) {
+  char* tail = static_cast<char*>(ws) + diag_nll_workspace_bytes(T, N, 1) - adam_extra_bytes(N);
+  return tail + align_up((size_t)N * sizeof(int32_t), 256) + align_up((size_t)((N + 63) / 64) * sizeof(int32_t), 256);
 }
 int32_t* nll_ws_tickets(void* ws, int T, int N, int n_cand) {
   char* tail = static_cast<char*>(ws) + diag_nll_workspace_bytes(T, N, n_cand) - adam_extra_bytes(N);
   return reinterpret_cast<int32_t*>(tail + align_up((size_t)N * sizeof(int32_t), 256));
+}
+
+// how many workgroups of the loop-mode kernel the current device holds at once (0: no cooperative launches)
+static long gf_resident_blocks(bool unit) {
+  const void* fn = unit ? reinterpret_cast<const void*>(&diag_nll_grad_fused_kernel<true, true>)
+                        : reinterpret_cast<const void*>(&diag_nll_grad_fused_kernel<false, true>);
+  int dev = 0, coop = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * kGfWaves, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return (long)per_cu * cus;
+}
+
+// the single-launch gradient evaluation (loop_iters == 0) or loop_iters optimiser iterations in one cooperative launch
+static int grad_fused_launch(const eks_dims_t& d, const NllGeom& G, const float* y, const double* rconst, const DiagModel& M,
+                             const double* s_kp, double* nll, double* dnll, void* ws, hipStream_t st, const AdamFuse& F,
+                             bool tickets_zeroed, int loop_iters) {
+  const int T = d.n_frames, N = d.n_keypoints * d.state_dim;
+  GradFuseWs FW;
+  FW.ngroups = (G.ncn + kGfWaves - 1) / kGfWaves;
+  FW.grp = static_cast<double*>(ws);
+  FW.tickets = nll_ws_tickets(ws, T, N, 1);
+  FW.conv_allowed = !knob_int(KNOB_NLL_GRAD_TREE, 0);
+  const size_t grp_bytes = (size_t)G.ntile * FW.ngroups * kGfFields * 64 * sizeof(double);
+  if (grp_bytes > diag_nll_workspace_bytes(T, N, 1) - adam_extra_bytes(N)) return EKS_ERR_WORKSPACE;
+  const dim3 grid((unsigned)(G.ntile * FW.ngroups)), block(64 * kGfWaves);
+  const bool unit = (d.flags & EKS_FLAG_UNIT_AC) != 0;
+  if (loop_iters <= 0) {
+    if (!tickets_zeroed) {   // (eks_adam_run zeroes the tickets once; every evaluation leaves them zero)
+      const hipError_t e = hipMemsetAsync(FW.tickets, 0, (size_t)G.ntile * sizeof(int32_t), st);
+      if (e != hipSuccess) return hip_status(e);
+    }
+    ProfScope ps("diag_nll_grad_fused", st);
+    const GfLoop L{1, nullptr};
+    // (an optimiser iteration as its own launch runs the loop-mode code for one iteration: the same instructions as
+    //  inside a longer call, so the two forms of eks_adam_run agree bit for bit - tests/test_gpu_kernels.py)
+    const bool step = F.state != nullptr && F.step_in_kernel;
+    if (unit && step)
+      hipLaunchKernelGGL((diag_nll_grad_fused_kernel<true, true>), grid, block, 0, st, G, M, FW, y, rconst, s_kp, nll,
+                         dnll, F, L);
+    else if (unit)
+      hipLaunchKernelGGL((diag_nll_grad_fused_kernel<true, false>), grid, block, 0, st, G, M, FW, y, rconst, s_kp, nll,
+                         dnll, F, L);
+    else if (step)
+      hipLaunchKernelGGL((diag_nll_grad_fused_kernel<false, true>), grid, block, 0, st, G, M, FW, y, rconst, s_kp, nll,
+                         dnll, F, L);
+    else
+      hipLaunchKernelGGL((diag_nll_grad_fused_kernel<false, false>), grid, block, 0, st, G, M, FW, y, rconst, s_kp, nll,
+                         dnll, F, L);
+    return hip_status(hipGetLastError());
+  }
+  // ---- loop mode: every workgroup resident, hand-off words and the running count zeroed behind the stream
+  const void* fn = unit ? reinterpret_cast<const void*>(&diag_nll_grad_fused_kernel<true, true>)
+                        : reinterpret_cast<const void*>(&diag_nll_grad_fused_kernel<false, true>);
+  if (gf_resident_blocks(unit) < (long)grid.x) return EKS_ERR_UNSUPPORTED;
+  GfLoop L{loop_iters, reinterpret_cast<unsigned long long*>(nll_ws_hand(ws, T, N))};
+  hipError_t e = hipMemsetAsync(L.hand, 0, (size_t)G.ntile * 64 * 2 * sizeof(unsigned long long), st);
+  if (e == hipSuccess) e = hipMemsetAsync(F.n_active_cur, 0, sizeof(int32_t), st);
+  if (e != hipSuccess) return hip_status(e);
+  ProfScope ps("diag_nll_grad_fused", st);
+  NllGeom Gc = G;
+  DiagModel Mc = M;
+  AdamFuse Fc = F;
+  void* args[] = {&Gc, &Mc, &FW, &y, &rconst, &s_kp, &nll, &dnll, &Fc, &L};
+  e = hipLaunchCooperativeKernel(fn, grid, block, args, 0, st);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return EKS_ERR_UNSUPPORTED;
+  }
+  return EKS_OK;
+}
+
+bool diag_nll_adam_loop_ok(int T, int K, int D, int n_blocks) {
+  const int N = K * D;
+  if (n_blocks != K || !diag_nll_grad_tree(T, K, D) || !grad_fused_ok(T, N, D, 1, 1) || knob_int(KNOB_ADAM_PER_ITERATION, 0))
+    return false;
+  const NllGeom G = make_geom(T, N, D, 1, 1, true, pick_ncl(1, true));
+  const long blocks = (long)G.ntile * ((G.ncn + kGfWaves - 1) / kGfWaves);
+  return gf_resident_blocks(true) >= blocks && gf_resident_blocks(false) >= blocks;
+}
+
+// eks_adam_run's n_iters iterations in one launch (see GfLoop); EKS_ERR_UNSUPPORTED: take the per-iteration launches
+int diag_nll_adam_loop(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M, int n_iters,
+                       double* nll, double* dnll, const AdamFuse& F, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int T = d.n_frames, D = d.state_dim, N = d.n_keypoints * D;
+  if (n_iters < 2 || !F.state || !F.step_in_kernel || !grad_fused_ok(T, N, D, 1, 1) ||
+      knob_int(KNOB_ADAM_PER_ITERATION, 0) || ws_bytes < diag_nll_workspace_bytes(T, N, 1))
+    return EKS_ERR_UNSUPPORTED;
+  const NllGeom G = make_geom(T, N, D, 1, 1, true, pick_ncl(1, true));
+  return grad_fused_launch(d, G, y, rconst, M, F.s_keypoint, nll, dnll, ws, st, F, true, n_iters);
 }
 
 static int diag_nll_impl(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M,
@@ -1666,30 +1954,8 @@ static int diag_nll_impl(const eks_dims_t& d, const float* y, const double* rcon
   if (fuse) F = *fuse;
   const int ncl = pick_ncl(n_cand, grad);
   NllGeom G = make_geom(T, N, D, n_cand, per_keypoint, grad, ncl);
-  if (grad && grad_fused_ok(T, N, D, n_cand, per_keypoint)) {
-    GradFuseWs FW;
-    FW.ngroups = (G.ncn + kGfWaves - 1) / kGfWaves;
-    FW.grp = static_cast<double*>(ws);
-    FW.tickets = nll_ws_tickets(ws, T, N, n_cand);
-    FW.conv_allowed = !knob_int(KNOB_NLL_GRAD_TREE, 0);
-    const size_t grp_bytes = (size_t)G.ntile * FW.ngroups * kGfFields * 64 * sizeof(double);
-    if (grp_bytes > diag_nll_workspace_bytes(T, N, n_cand) - adam_extra_bytes(N)) return EKS_ERR_WORKSPACE;
-    {
-      if (!fuse) {   // (eks_adam_run zeroes the tickets once; every evaluation leaves them zero)
-        const hipError_t e = hipMemsetAsync(FW.tickets, 0, (size_t)G.ntile * sizeof(int32_t), st);
-        if (e != hipSuccess) return hip_status(e);
-      }
-      ProfScope ps("diag_nll_grad_fused", st);
-      const dim3 grid((unsigned)(G.ntile * FW.ngroups)), block(64 * kGfWaves);
-      if (d.flags & EKS_FLAG_UNIT_AC)
-        hipLaunchKernelGGL(diag_nll_grad_fused_kernel<true>, grid, block, 0, st, G, M, FW, y, rconst, s_cand, nll,
-                           dnll, F);
-      else
-        hipLaunchKernelGGL(diag_nll_grad_fused_kernel<false>, grid, block, 0, st, G, M, FW, y, rconst, s_cand, nll,
-                           dnll, F);
-      return hip_status(hipGetLastError());
-    }
-  }
+  if (grad && grad_fused_ok(T, N, D, n_cand, per_keypoint))
+    return grad_fused_launch(d, G, y, rconst, M, s_cand, nll, dnll, ws, st, F, fuse != nullptr, 0);
   // ---- grid search on whole 64-chain tiles: head + lean roles in one launch (round 4)
   if (!grad && !F.state && lean_grid_ok(T, N, D, n_cand)) {
     G.nt_log2 = 6;
@@ -1862,6 +2128,9 @@ extern "C" int eks_debug_grid_stamps(unsigned long long* out) {
 #ifdef EKS_GF_STAMPS
 extern "C" int eks_debug_gf_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(eks::g_gf_stamps), sizeof(eks::g_gf_stamps));
+}
+extern "C" int eks_debug_gf_iter_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(eks::g_gf_iter), sizeof(eks::g_gf_iter));
 }
 #endif
 

@@ -84,6 +84,9 @@ bool diag_nll_grad_tree(int T, int K, int D);
 bool diag_nll_adam_persist_ok(int T, int K, int D, int n_blocks);
 int diag_nll_adam_persist(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M, int n_iters,
                           double* nll, double* dnll, const AdamFuse& F, int32_t* n_active, hipStream_t st);
+int diag_nll_adam_loop(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M, int n_iters,
+                       double* nll, double* dnll, const AdamFuse& F, void* ws, size_t ws_bytes, hipStream_t st);
+bool diag_nll_adam_loop_ok(int T, int K, int D, int n_blocks);   // would eks_adam_run take the in-launch loop?
 size_t adam_extra_bytes(int N);     // tail of the NLL workspace: keypoint -> block map, tile tickets, counter
 int32_t* nll_ws_tickets(void* ws, int T, int N, int n_cand);   // the tile tickets inside that tail
 int adam_prepare(int n_blocks, int K, const int32_t* offs, const int32_t* members, int32_t* kp_block,

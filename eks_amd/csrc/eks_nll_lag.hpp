@@ -458,52 +458,70 @@ EKS_HD ConvConst conv_const(double r_d, double a_d, double c_d, double sq) {
 // when chunk 1 starts (rho^(2 bn) < 1e-20) and no chunk's outgoing mean remembers the incoming one (A = rho^bn)
 EKS_HD bool conv_chunk_ok(const ConvConst& k, int bn) { return (float)bn * k.nl > 23.1f; }
 
-template <bool UNIT, typename LD>
-EKS_HD void nll_conv_chunk_dual(const LD& ld, int len, const ConvConst& K, double a_d, double c_d, ConvDual& out) {
-  const Dual rho((float)K.rho, (float)K.drho);
-  const float y0 = ld(0);
-  out.xref = UNIT ? y0 : (float)((double)y0 / c_d);
-  float yprev = UNIT ? y0 : (float)((double)y0 / a_d);
-  Dual dk(0.f), w(1.f, 0.f), s1(0.f), s2(0.f);
-  double s1v = 0.0, s1d = 0.0, s2v = 0.0, s2d = 0.0;
-  bool alive = true;
-  const int nfull = len / 8;
-  float ya[8], yb[8];
+// NB: frames per row buffer; two buffers, so 2 NB rows are requested ahead of the arithmetic.
+// The recursion on (value, derivative) pairs in packed float32 (v_pk_fma_f32: both halves in one issue slot):
+//     X = (d, d')            X  <- (rho, rho) X + (u, rho' d)                        sub, mul, pk_fma
+//     S2 = (sum d^2, sum d d')   S2 <- (d, d) X + S2          (d / d log s of sum d^2 is twice its second half)   pk_fma
+// and while rho^t is alive  W = (rho^t, (rho^t)'),  S1 <- (d, d) W + S1,  S1' += d' rho^t,  W <- (w, w)(rho, rho') + (0, w' rho).
+// Four issue slots per frame once rho^t has died; written with the dual-number operators the compiler spent 15
+// (measured: the frame loop was VALU-bound at 25 us of a 39 us iteration on C3).
+// `pre`: the chunk's first NB rows, requested by the caller ahead of time (they do not depend on s: the loop-mode kernel
+// asks for them before it waits for the step); nullptr: requested here.
+template <bool UNIT, int NB = 8, typename LD>
+EKS_HD void nll_conv_chunk_dual(const LD& ld, int len, const ConvConst& K, double a_d, double c_d, ConvDual& out,
+                                const float* pre = nullptr) {
+  const float rho = (float)K.rho, rhod = (float)K.drho;
+  const f32x2 R = f32x2{rho, rho}, RD = f32x2{rho, rhod};
+  const int nfull = len / NB;
+  float ya[NB], yb[NB];
   if (nfull > 0) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) ya[q] = ld(q);
+    for (int q = 0; q < NB; ++q) ya[q] = pre ? pre[q] : ld(q);
   }
-  auto eat = [&](const float (&yy)[8], auto alive_tag) {
+  const float y0 = nfull > 0 ? ya[0] : ld(0);
+  out.xref = UNIT ? y0 : (float)((double)y0 / c_d);
+  float yprev = UNIT ? y0 : (float)((double)y0 / a_d);
+  f32x2 X = f32x2{0.f, 0.f}, W = f32x2{1.f, 0.f}, S1 = f32x2{0.f, 0.f}, S2 = f32x2{0.f, 0.f};
+  double s1v = 0.0, s1d = 0.0, s2v = 0.0, s2d = 0.0;
+  bool alive = true;
+  auto frame = [&](float yy, auto alive_tag) {
     constexpr bool AL = decltype(alive_tag)::value != 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float dy = UNIT ? (yy[q] - yprev) : (float)((double)yy[q] - a_d * (double)yprev);
-      yprev = yy[q];
-      dk = rho * dk + Dual(dy);
-      s2 = s2 + dk * dk;
-      if constexpr (AL) {
-        s1 = s1 + dk * w;
-        w = w * rho;
-      }
+    const float u = UNIT ? (yy - yprev) : (float)((double)yy - a_d * (double)yprev);
+    yprev = yy;
+    X = R * X + f32x2{u, rhod * X[0]};
+    S2 = f32x2{X[0], X[0]} * X + S2;
+    if constexpr (AL) {
+      S1 = f32x2{X[0], X[0]} * W + S1;
+      S1[1] += X[1] * W[0];
+      W = f32x2{W[0], W[0]} * RD + f32x2{0.f, W[1] * rho};
     }
   };
-  int blk = 0;
+  auto eat = [&](const float (&yy)[NB], auto alive_tag) {
+#pragma unroll
+    for (int q = 0; q < NB; ++q) frame(yy[q], alive_tag);
+  };
+  auto flush = [&]() {
+    s2v += (double)S2[0]; s2d += 2.0 * (double)S2[1];
+    S2 = f32x2{0.f, 0.f};
+    s1v += (double)S1[0]; s1d += (double)S1[1];
+    S1 = f32x2{0.f, 0.f};
+  };
+  constexpr int kPairsPerFlush = NB >= 16 ? 1 : 16 / NB;      // float32 partial sums span at most 32 frames
+  int blk = 0, since = 0;
   for (; blk + 2 <= nfull; blk += 2) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) yb[q] = ld((blk + 1) * 8 + q);
+    for (int q = 0; q < NB; ++q) yb[q] = ld((blk + 1) * NB + q);
     if (alive) eat(ya, IntTag<1>()); else eat(ya, IntTag<0>());
     if (blk + 2 < nfull) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) ya[q] = ld((blk + 2) * 8 + q);
+      for (int q = 0; q < NB; ++q) ya[q] = ld((blk + 2) * NB + q);
     }
     if (alive) eat(yb, IntTag<1>()); else eat(yb, IntTag<0>());
-    if ((blk & 2) != 0 || blk + 4 > nfull) {         // float32 partial sums span at most 32 frames
-      s2v += (double)s2.v; s2d += (double)s2.d;
-      s2 = Dual(0.f);
+    if (++since == kPairsPerFlush || blk + 4 > nfull) {
+      since = 0;
+      flush();
       if (alive) {
-        s1v += (double)s1.v; s1d += (double)s1.d;
-        s1 = Dual(0.f);
-        const bool dead = fabsf(w.v) < 1e-9f && fabsf(w.d) < 1e-9f;
+        const bool dead = fabsf(W[0]) < 1e-9f && fabsf(W[1]) < 1e-9f;
         alive = !EKS_WAVE_ALL(dead);
       }
     }
@@ -512,19 +530,18 @@ EKS_HD void nll_conv_chunk_dual(const LD& ld, int len, const ConvConst& K, doubl
     if (alive) eat(ya, IntTag<1>()); else eat(ya, IntTag<0>());
     ++blk;
   }
-  for (int i = blk * 8; i < len; ++i) {              // ragged tail
-    const float yy = ld(i);
-    const float dy = UNIT ? (yy - yprev) : (float)((double)yy - a_d * (double)yprev);
-    yprev = yy;
-    dk = rho * dk + Dual(dy);
-    s2 = s2 + dk * dk;
-    s1 = s1 + dk * w;
-    w = w * rho;
+  const int ntail = len - blk * NB;                  // ragged tail: its rows requested together
+  if (ntail > 0) {
+#pragma unroll
+    for (int q = 0; q < NB - 1; ++q) ya[q] = ld(blk * NB + (q < ntail ? q : ntail - 1));
+#pragma unroll
+    for (int q = 0; q < NB - 1; ++q) {
+      if (q < ntail) frame(ya[q], IntTag<1>());
+    }
   }
-  s2v += (double)s2.v; s2d += (double)s2.d;
-  s1v += (double)s1.v; s1d += (double)s1.d;
+  flush();
+  const double dl = (double)X[0], ddl = (double)X[1];
   // finish (float64 duals): b = a ((y - d) / c + K d), K = (1 - r g) / c; eta = c g S1; J = c^2 g / (1 - rho^2)
-  const double dl = (double)dk.v, ddl = (double)dk.d;
   if (UNIT) {
     out.b = (double)yprev - K.rg * dl;
     out.db = -(K.drg * dl + K.rg * ddl);

@@ -433,13 +433,13 @@ struct RowsByPointer {
 template <typename R, int NCL, bool UNIT, typename LD>
 EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, double a_d, double c_d,
                                 const double* sq_d, NllElem<R>* out,
-                                bool allow_converged_entry = false) {
+                                bool allow_converged_entry = false, int sequence_len = -1) {
   NllLane<R, NCL, UNIT> L;
   nll_lane_init<R, NCL, UNIT>(L, r_d, a_d, c_d, sq_d);
   // Snapping C onto the fixed point costs a one-off ~1e-5 of a frame's terms: nothing against a
   // chunk of thousands of frames, the whole error budget of a sequence of three.  Short chunks
-  // stay in the full recursion.
-  if (len < 256) {
+  // stay in the full recursion (a caller that cuts a long sequence into short chunks says how long it is).
+  if ((sequence_len < 0 ? len : sequence_len) < 256) {
 #pragma unroll
     for (int k = 0; k < NCL; ++k) L.tolC[k] = -1.f;
   }
@@ -619,13 +619,24 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
 #pragma unroll
     for (int q = 0; q < 8; ++q) ya[q] = ld((blk * 8 + q));
     const int first = blk;
+    // one candidate with its derivative (the gradient path): (d, d') and (sum d^2, sum d d') as packed pairs - four
+    // issue slots per frame where the dual-number operators compile to 15 (round 5; see nll_conv_chunk_dual)
+    constexpr bool PKD = EKS_NLL_PACKED && sizeof(R) == sizeof(Dual) && NCL == 1;
+    f32x2 Xd = f32x2{val(dk[0]), der(dk[0])}, S2d = f32x2{0.f, 0.f};
+    const f32x2 Rd = f32x2{val(rho[0]), val(rho[0])};
+    const float rhod = der(rho[0]);
     auto eat_as = [&](const float (&yy)[8], auto kap_tag) {
       constexpr bool KAP = decltype(kap_tag)::value != 0;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const float dy = UNIT ? (yy[q] - yprev) : (float)((double)yy[q] - a_d * (double)yprev);
         yprev = yy[q];
-        if constexpr (PK) {
+        if constexpr (PKD) {
+          const f32x2 step = Rd * Xd + f32x2{dy, rhod * Xd[0]};
+          if constexpr (KAP) Xd = Xd + step;                                  // d + (u - kappa d)
+          else Xd = step;
+          S2d = f32x2{Xd[0], Xd[0]} * Xd + S2d;
+        } else if constexpr (PK) {
           const f32x2 dy2 = f32x2{dy, dy};
 #pragma unroll
           for (int p = 0; p < NP; ++p) {
@@ -649,7 +660,10 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
       else eat_as(yy, IntTag<0>());
     };
     auto flush = [&]() {
-      if constexpr (PK) {
+      if constexpr (PKD) {
+        L.acc2[0].add(make_real(R(), S2d[0], 2.f * S2d[1]));
+        S2d = f32x2{0.f, 0.f};
+      } else if constexpr (PK) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
           L.acc2[2 * p].add(make_real(R(), s22[p].x, 0.f));
@@ -682,6 +696,7 @@ EKS_HD void nll_summarize_chunk(const LD& ld, int t0, int len, double r_d, doubl
     flush();
     // back to the (d, y) state of the transient code so a ragged tail can continue
     const int eaten = (blk - first) * 8;
+    if constexpr (PKD) dk[0] = make_real(R(), Xd[0], Xd[1]);
     if constexpr (PK) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {

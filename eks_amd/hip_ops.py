@@ -402,6 +402,11 @@ class AdamLoop:
         self.dims = _dims(K, T, D, O, flags)
         self.ws = _workspace(self.lib.eks_nll_workspace_bytes(ctypes.byref(self.dims), 1), dev)
 
+    def stride(self) -> int:
+        """eks_adam_run_stride: iterations to ask for per run() on this problem (the spacing of the caller's reads of
+        n_active)."""
+        return int(self.lib.eks_adam_run_stride(ctypes.byref(self.dims), self.nb))
+
     def run(self, n_iters: int) -> None:
         rc = self.lib.eks_adam_run(ctypes.byref(self.dims), *[_ptr(b) for b in self.bufs], self.nb,
                                    _ptr(self.offs), _ptr(self.members), *self.opt, int(n_iters),

@@ -156,6 +156,16 @@ int eks_adam_run(const eks_dims_t* dims, const float* y, const double* rconst, c
                  double* state, double* s_keypoint, double* nll, double* dnll, int32_t* n_active,
                  void* workspace, size_t workspace_bytes, eks_stream_t stream);
 
+/* ---- how many iterations one eks_adam_run call should ask for on this problem, device and library build: the calls
+ * are what the caller's host round trips (reading *n_active) are spaced by, and what they cost differs by the form the
+ * loop takes - 128 where the chip-wide loss kernel keeps its workgroups for the whole call (one cooperative launch,
+ * ~70 us to start, an over-issued call returns at once), 64 for short sessions (one launch, a workgroup per keypoint),
+ * 16 where every iteration is its own launch on scalar chains (an over-issued iteration is a launch that returns at
+ * once), 4 on the general (D, O) path (an over-issued iteration is a full evaluation).  *n_active < 0 after a call:
+ * the in-launch loop gave up waiting (the call's results are invalid).  No reference counterpart (the reference's
+ * loop is one XLA while_loop, eks/core.py:654-681). */
+int32_t eks_adam_run_stride(const eks_dims_t* dims, int32_t n_blocks);
+
 /* ---- IBL pupil smoother, eks/ibl_pupil_smoother.py:363-607.
  * Independent chains k < n_keypoints (one per session), AR(1) dynamics A_k = diag(a[k][:]),
  * process noise diag(q[k][:]), observation matrix C [K][O][D], TIME-VARYING R_t = diag(max(var,

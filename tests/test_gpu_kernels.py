@@ -1050,6 +1050,51 @@ def test_initial_guesses_reduced_on_the_device_equal_the_host_reduction():
     assert np.array_equal(core._initial_guesses_per_keypoint(sd=sd), core._initial_guesses_per_keypoint(ev))
 
 
+@pytest.mark.parametrize('T,K,unit,stride', [(30_000, 70, True, 24), (20_011, 33, False, 7), (50_000, 128, True, 128)])
+def test_adam_chip_wide_loop_in_one_launch_is_the_per_iteration_loop_bit_for_bit(T, K, unit, stride, set_knob):
+    """Long sessions, one keypoint per optimiser block: an eks_adam_run call keeps the chip-wide loss kernel's
+    workgroups for all of its iterations (round 5: GfLoop in eks_diag_nll.hip - the tile's last block applies the step
+    and hands s to the tile's other blocks through tagged words).  The arithmetic of an iteration is that of a launch
+    per iteration (EKS_ADAM_PER_ITERATION=1), so the optimiser state, s, and the last loss and gradient must agree
+    bit for bit - also when calls end mid-search (stride 7 / 24) and with a partial last tile (K = 70 / 33)."""
+    from eks_amd import hip_ops
+    arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=31 + T, unit=unit)
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    y, rc = _dev(y_tk), hip_ops.const_r(_dev(var_tk), 1e-4)
+    params = _params_dev(arrs)
+    offs = torch.arange(K + 1, dtype=torch.int32, device='cuda')
+    mem = torch.arange(K, dtype=torch.int32, device='cuda')
+    u0 = np.log(np.random.default_rng(T).uniform(0.05, 50.0, K))
+
+    def run():
+        state = np.zeros((K, 6))
+        state[:, 0] = u0
+        state[:, 3] = np.inf
+        state = _dev(state)
+        s_kp = _dev(np.exp(u0))
+        loop = hip_ops.AdamLoop(y, rc, *params, offs, mem, state, s_kp, 0.25, -8.0, 8.0, 1e-2, 300, flags=flags)
+        left = []
+        for _ in range((300 + stride - 1) // stride):
+            loop.run(stride)
+            left.append(int(loop.n_active.item()))
+            assert left[-1] >= 0
+            if left[-1] == 0:
+                break
+        return loop.stride(), state.cpu().numpy(), s_kp.cpu().numpy(), loop.nll.cpu().numpy(), loop.dnll.cpu().numpy(), left
+
+    n_loop, st_l, s_l, nll_l, g_l, left_l = run()
+    assert n_loop == 128                     # (the in-launch loop is what ran)
+    set_knob('EKS_ADAM_PER_ITERATION', '1')
+    n_it, st_i, s_i, nll_i, g_i, left_i = run()
+    assert n_it == 16
+    assert st_l[:, 4].max() > 20 and np.all(st_l[:, 5] == 1.0)
+    np.testing.assert_array_equal(st_l, st_i)
+    np.testing.assert_array_equal(s_l, s_i)
+    np.testing.assert_array_equal(nll_l, nll_i)
+    np.testing.assert_array_equal(g_l, g_i)
+    assert left_l == left_i                   # keypoints still running after every call
+
+
 @pytest.mark.parametrize('T,K,unit', [(2000, 4, True), (700, 3, False), (9000, 20, True), (16384, 2, False),
                                       (130, 5, True), (2, 2, True)])
 def test_adam_whole_loop_in_one_launch_reproduces_the_per_iteration_loop(T, K, unit, set_knob):
