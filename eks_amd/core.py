@@ -142,7 +142,7 @@ def _guess_rows_from_device(ev_dev) -> np.ndarray:
     return d.reshape(d.shape[0], -1).cpu().numpy()
 
 
-def _guess_std_on_device(ev_dev):
+def _guess_std_on_device(ev_dev, lazy: bool = False):
     """numpy.nanstd of every keypoint's frame-to-frame differences, computed ON THE DEVICE with numpy's own summation
     order (hip_ops.np_nanstd_rows: bit for bit) - K floats come back instead of the (K, (T' - 1) O) rows, and the
     2 ms the host reduction cost at 256 keypoints are gone from in front of the optimiser's first launch.  None
@@ -155,7 +155,9 @@ def _guess_std_on_device(ev_dev):
         return None
     d = (ev[1:] - ev[:-1]).transpose(0, 1).contiguous()
     sd = hip_ops.np_nanstd_rows(d.reshape(d.shape[0], -1))
-    return None if sd is None else sd.cpu().numpy()
+    if sd is None or not lazy:
+        return None if sd is None else sd.cpu().numpy()
+    return lambda: sd.cpu().numpy()        # (the caller enqueues more work before it waits for these K floats)
 
 
 def _initial_guesses_per_keypoint(ev_host: np.ndarray = None, rows: np.ndarray | None = None,
@@ -267,6 +269,44 @@ _ADAM_LOOP_FAILED = ('eks_adam_run: a workgroup of the in-launch optimiser loop 
                      'iteration instead')
 
 
+def _finish_search(info) -> None:
+    """Waits for a search whose calls were all enqueued without looking at their counts and raises if one of them
+    reported that the in-launch loop gave up."""
+    un = info.pop('_unchecked', None) if isinstance(info, dict) else None
+    if un is None:
+        return
+    snap, r, ev = un
+    ev.synchronize()
+    if any(int(snap[i]) < 0 for i in range(r)):
+        raise _AdamLoopGaveUp(_ADAM_LOOP_FAILED)
+
+
+class _AdamLoopGaveUp(RuntimeError):
+    pass
+
+
+def _without_in_launch_loop(fn):
+    """The in-launch optimiser loop needs all of its workgroups on the device at once; something else holding compute
+    units for as long as it waits (another PROCESS's loop on the same GPU) makes it give up instead of hanging.  The
+    search is then repeated with a launch per iteration - for the rest of the process - and a warning."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*a, **kw):
+        try:
+            return fn(*a, **kw)
+        except _AdamLoopGaveUp:
+            if kw.get('_s_on_device'):               # (a tile of a tiled call: the whole call is repeated)
+                raise
+            logger.warning('eks_adam_run: the in-launch optimiser loop gave up waiting (is another process using this '
+                           'GPU?); repeating the search with one launch per iteration, as will later calls')
+            os.environ['EKS_ADAM_PER_ITERATION'] = '1'
+            from . import _lib
+            _lib.load().eks_knobs_reload()
+            return fn(*a, **kw)
+    return wrapper
+
+
 def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, s_bounds_log, tol,
                         safety_cap, min_R_var, s_mode, n_grid, sync_every: int | None = None):
     """Returns (s per keypoint as a device float64 tensor, info dict)."""
@@ -290,6 +330,8 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
     # Adam on u = log s (reference eks/core.py:612-613, :439-441: float32 initial value)
     # (block means by one segmented sum over the CSR member list: a Python loop over 256 blocks of np.mean / np.clip
     #  calls held the first launch back by 2 ms)
+    if callable(s_guess_per_k):
+        s_guess_per_k = s_guess_per_k()
     g = np.asarray(s_guess_per_k, dtype=np.float64)[np.asarray(members, dtype=np.int64)]
     offs64 = np.asarray(offs, dtype=np.int64)
     if np.all(np.diff(offs64) == 1):
@@ -297,13 +339,20 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
     else:
         means = np.array([np.mean(g[offs64[b]:offs64[b + 1]]) for b in range(nb)])
     u0 = np.log(np.clip(means, 1e-6, 1e3)).astype(np.float32).astype(np.float64)
-    state = np.zeros((nb, 6))
-    state[:, 0] = u0
-    state[:, 3] = np.inf
-    state = torch.as_tensor(state, device=P.dev)
-    offs_d = torch.as_tensor(offs, device=P.dev)
-    mem_d = torch.as_tensor(members, device=P.dev)
-    s_kp = torch.as_tensor(np.exp(np.clip(u0, lo, hi))[of_kp], device=P.dev)
+    # optimiser state and starting point in ONE upload (four small pageable copies cost ~25 us each in front of the
+    # first launch), the block lists generated on the device when every block is a keypoint in order
+    packed = np.zeros(nb * 6 + P.K)
+    packed[0:nb * 6:6] = u0
+    packed[3:nb * 6:6] = np.inf
+    packed[nb * 6:] = np.exp(np.clip(u0, lo, hi))[of_kp]
+    packed = torch.as_tensor(packed, device=P.dev)
+    state, s_kp = packed[:nb * 6].view(nb, 6), packed[nb * 6:]
+    if nb == P.K and np.array_equal(members, np.arange(P.K)):
+        offs_d = torch.arange(P.K + 1, dtype=torch.int32, device=P.dev)
+        mem_d = torch.arange(P.K, dtype=torch.int32, device=P.dev)
+    else:
+        offs_d = torch.as_tensor(offs, device=P.dev)
+        mem_d = torch.as_tensor(members, device=P.dev)
     loop = hip_ops.AdamLoop(y_c, rconst, *P.params, offs_d, mem_d, state, s_kp, lr, lo, hi, tol,
                             safety_cap, flags=P.flags)
     iters, cap = 0, int(safety_cap)
@@ -327,6 +376,21 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
         snap = _pinned_empty((max(rounds, 1),), torch.int32)
     except RuntimeError:          # page-locked memory exhausted or unavailable (as _to_host): blocking reads
         snap = None
+    if sync_every >= 64 and snap is not None:
+        # One launch per call, and a call issued after the last block has stopped returns at once (~40 us on the device):
+        # every call the cap allows is enqueued now, nothing is waited for, and whatever the caller enqueues next (the
+        # final smoothing pass) follows the search without a host round trip in between.  The counts are looked at
+        # later (_finish_search): only a negative one matters - the in-launch loop gave up (eks_adam_run_stride).
+        r = 0
+        while iters < cap:
+            n = min(sync_every, cap - iters)
+            loop.run(n)
+            iters += n
+            snap[r:r + 1].copy_(loop.n_active, non_blocking=True)
+            r += 1
+        ev = torch.cuda.Event()
+        ev.record()
+        return s_kp, dict(mode='adam', state=state, launches=iters, calls=r, deferred_count=True, _unchecked=(snap, r, ev))
     pending = None                                        # (round index, event) of the newest unread count
     r = 0
     while iters < cap:
@@ -336,7 +400,7 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
         if snap is None:
             left = int(loop.n_active.item())
             if left < 0:
-                raise RuntimeError(_ADAM_LOOP_FAILED)
+                raise _AdamLoopGaveUp(_ADAM_LOOP_FAILED)
             if left == 0:
                 break
             continue
@@ -347,7 +411,7 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
             pending[1].synchronize()
             left = int(snap[pending[0]])
             if left < 0:
-                raise RuntimeError(_ADAM_LOOP_FAILED)
+                raise _AdamLoopGaveUp(_ADAM_LOOP_FAILED)
             if left == 0:
                 break
         pending = (r, ev)
@@ -357,6 +421,7 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
     return s_kp, dict(mode='adam', state=state, launches=iters, deferred_count=snap is not None)
 
 
+@_without_in_launch_loop
 def optimize_smooth_param(ys, m0s, S0s, As, Cs, Qs, Rs, blocks, s_finals, s_frames, s_guess_per_k,
                           lr: float = 0.25, s_bounds_log=(-8.0, 8.0), tol: float = 1e-3,
                           safety_cap: int = 300, min_R_var: float = 1e-4,
@@ -378,6 +443,7 @@ def optimize_smooth_param(ys, m0s, S0s, As, Cs, Qs, Rs, blocks, s_finals, s_fram
     P = _DeviceProblem(ys, m0s, S0s, As, Cs, Qs, np.swapaxes(Rd, 0, 1))
     s, info = _optimize_on_device(P, blocks, s_frames, np.asarray(s_guess_per_k, float), lr,
                                   s_bounds_log, tol, safety_cap, min_R_var, 'adam', 0)
+    _finish_search(info)
     s_finals[:] = s.cpu().numpy()
     _log_opt(blocks, s_finals, info)
 
@@ -713,6 +779,8 @@ def _run_tiled_from_host(tiles, ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frame
         for st in streams:                       # (also when a tile raised: the side streams rejoin the caller's)
             cur.wait_stream(st)
     cur.synchronize()
+    for inf in infos:
+        _finish_search(inf)
     if trace:
         logger.warning('tiled boundary, per tile (k0, k1, ys upload ms, variance gather ms, variance upload enqueue ms): '
                        + '; '.join(f'{a}-{b}: {u:.2f} {g:.2f} {e:.2f}' for a, b, u, g, e in trace))
@@ -732,6 +800,7 @@ def _run_tiled_from_host(tiles, ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frame
     return out
 
 
+@_without_in_launch_loop
 def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list | None = None,
                         smooth_param: float | list | None = None,
                         blocks: list[list[int]] | None = None, lr: float = 0.25,
@@ -801,9 +870,11 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
         if s_mode == 'adam':            # the starting point of the optimiser (reference :233-236)
             if hasattr(ensemble_vars, 'detach') and ensemble_vars.is_cuda and ensemble_vars.dtype == torch.float32:
                 ev_d = ensemble_vars.detach()
-                sd = _guess_std_on_device(ev_d)
-                guesses = (_initial_guesses_per_keypoint(sd=sd) if sd is not None else
-                           _initial_guesses_per_keypoint(rows=_guess_rows_from_device(ev_d)))
+                sd = _guess_std_on_device(ev_d, lazy=True)
+                if sd is None:
+                    guesses = _initial_guesses_per_keypoint(rows=_guess_rows_from_device(ev_d))
+                else:       # read back (and rounded, on the host) once eks_const_r has been enqueued behind the reduction
+                    guesses = lambda: _initial_guesses_per_keypoint(sd=sd())      # noqa: E731
             else:
                 ev_host = _to_numpy(ensemble_vars)[:2000] if not hasattr(ensemble_vars, 'detach') \
                     else ensemble_vars[:2000].detach().cpu().numpy()
@@ -811,12 +882,27 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
         s_dev, info = _optimize_on_device(P, blocks, s_frames, guesses, lr, s_bounds_log, tol,
                                           safety_cap, 1e-4, s_mode, n_grid)
         if not _s_on_device:                     # (the tiled boundary reads s once, after the last tile is enqueued)
-            s_finals[:] = s_dev.cpu().numpy()
-            _log_opt(blocks, s_finals, info)
-        logger.debug(f'[profile]   optimize_smooth_param: {time.perf_counter() - t1:.3f}s')
+            # s travels to page-locked memory behind the search and is read after the final pass has been enqueued:
+            # the device goes from the search straight into the smoother, the host wakes up beside it
+            try:
+                s_host = _pinned_empty((K,), torch.float64)
+                s_host.copy_(s_dev, non_blocking=True)
+                s_ready = torch.cuda.Event()
+                s_ready.record()
+            except RuntimeError:
+                s_host = None
+        logger.debug(f'[profile]   optimize_smooth_param (enqueued): {time.perf_counter() - t1:.3f}s')
 
     t2 = time.perf_counter()
     ms, Vs = hip_ops.smooth(P.y, P.var, *P.params, s_dev.contiguous(), flags=P.flags, vs_diag=vs_diag)
+    if smooth_param is None and not _s_on_device:
+        _finish_search(info)
+        if s_host is not None:
+            s_ready.synchronize()
+            s_finals[:] = s_host.numpy()
+        else:
+            s_finals[:] = s_dev.cpu().numpy()
+        _log_opt(blocks, s_finals, info)
     if return_device:
         out = (s_dev if _s_on_device else s_finals), ms.transpose(0, 1), Vs.transpose(0, 1)
     else:

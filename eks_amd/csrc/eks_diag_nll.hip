@@ -647,6 +647,7 @@ __device__ __forceinline__ void gf_stores_acknowledged() {
 struct GfLoop {
   int n_iters;            // iterations of this launch
   unsigned long long* hand;   // [ntile][64][2], zero when the launch starts: the hand-off words (below)
+  int spin_limit;         // polls before a waiting workgroup gives up (kGfSpinLimit; EKS_ADAM_LOOP_SPINS for tests)
 };
 constexpr int kGfSpinLimit = 1 << 17;       // polls (each a trip to memory, ~1 us)
 constexpr int kGfFailed = -(1 << 30);
@@ -1001,7 +1002,7 @@ __global__ __launch_bounds__(64 * kGfWaves) void diag_nll_grad_fused_kernel(NllG
       int spins = 0;
       for (;;) {
         if (!got) got = gf_hand_poll(slot, it, r, sv);
-        if (__all(got) || ++spins >= kGfSpinLimit) break;
+        if (__all(got) || ++spins >= L.spin_limit) break;
         __builtin_amdgcn_s_sleep(4);
       }
       const bool all_got = __all(got);
@@ -1868,7 +1869,7 @@ static int grad_fused_launch(const eks_dims_t& d, const NllGeom& G, const float*
       if (e != hipSuccess) return hip_status(e);
     }
     ProfScope ps("diag_nll_grad_fused", st);
-    const GfLoop L{1, nullptr};
+    const GfLoop L{1, nullptr, kGfSpinLimit};
     // (an optimiser iteration as its own launch runs the loop-mode code for one iteration: the same instructions as
     //  inside a longer call, so the two forms of eks_adam_run agree bit for bit - tests/test_gpu_kernels.py)
     const bool step = F.state != nullptr && F.step_in_kernel;
@@ -1890,7 +1891,8 @@ static int grad_fused_launch(const eks_dims_t& d, const NllGeom& G, const float*
   const void* fn = unit ? reinterpret_cast<const void*>(&diag_nll_grad_fused_kernel<true, true>)
                         : reinterpret_cast<const void*>(&diag_nll_grad_fused_kernel<false, true>);
   if (gf_resident_blocks(unit) < (long)grid.x) return EKS_ERR_UNSUPPORTED;
-  GfLoop L{loop_iters, reinterpret_cast<unsigned long long*>(nll_ws_hand(ws, T, N))};
+  GfLoop L{loop_iters, reinterpret_cast<unsigned long long*>(nll_ws_hand(ws, T, N)),
+           knob_int(KNOB_ADAM_LOOP_SPINS, kGfSpinLimit)};
   hipError_t e = hipMemsetAsync(L.hand, 0, (size_t)G.ntile * 64 * 2 * sizeof(unsigned long long), st);
   if (e == hipSuccess) e = hipMemsetAsync(F.n_active_cur, 0, sizeof(int32_t), st);
   if (e != hipSuccess) return hip_status(e);
@@ -1898,6 +1900,18 @@ static int grad_fused_launch(const eks_dims_t& d, const NllGeom& G, const float*
   NllGeom Gc = G;
   DiagModel Mc = M;
   AdamFuse Fc = F;
+  if (getenv("ROCP_TOOL_LIBRARIES") != nullptr) {
+    // Under a rocprofiler-sdk tool (rocprofv3) a process that made a cooperative launch crashes when it EXITS (ROCm
+    // 7.2: SIGSEGV in the tool's finalisation, after the run itself completed).  The same kernel as an ordinary launch:
+    // its workgroups fit the device (checked above) and a profiled process runs its kernels one stream at a time.
+    if (unit)
+      hipLaunchKernelGGL((diag_nll_grad_fused_kernel<true, true>), grid, block, 0, st, Gc, Mc, FW, y, rconst, s_kp, nll,
+                         dnll, Fc, L);
+    else
+      hipLaunchKernelGGL((diag_nll_grad_fused_kernel<false, true>), grid, block, 0, st, Gc, Mc, FW, y, rconst, s_kp, nll,
+                         dnll, Fc, L);
+    return hip_status(hipGetLastError());
+  }
   void* args[] = {&Gc, &Mc, &FW, &y, &rconst, &s_kp, &nll, &dnll, &Fc, &L};
   e = hipLaunchCooperativeKernel(fn, grid, block, args, 0, st);
   if (e != hipSuccess) {

@@ -540,6 +540,72 @@ def test_two_threads_two_streams_equal_the_serial_runs(host_arrays, monkeypatch)
             np.testing.assert_array_equal(np.asarray(g), np.asarray(r))
 
 
+def _adam_session(T, K, seed):
+    import torch
+    from eks_amd import synth
+    dev = torch.device('cuda', 0)
+    y, var = synth.singlecam_observations_torch(T, K, seed=seed, device=dev)
+    ys = y.transpose(0, 1).contiguous()
+    eye = np.tile(np.eye(2), (K, 1, 1))
+    S0 = eye * ys.cpu().numpy().var(axis=1)[:, :, None]
+    return ys, np.zeros((K, 2)), S0, eye, eye, eye, var
+
+
+def test_adam_sessions_from_two_threads_share_the_device(set_knob):
+    """The in-launch optimiser loop (round 5) is a cooperative launch whose workgroups wait for each other: two threads
+    searching at once on two streams must neither hang nor change a bit of either result."""
+    import threading
+    import torch
+    from eks_amd.core import run_kalman_smoother
+    sessions = [_adam_session(40_000, 96, 51), _adam_session(30_000, 128, 52)]
+    serial = [run_kalman_smoother(*a) for a in sessions]
+    results, errors = [None, None], []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream(device=torch.device('cuda', 0))
+            with torch.cuda.stream(st):
+                for _ in range(3):
+                    results[i] = run_kalman_smoother(*sessions[i])
+            st.synchronize()
+        except Exception as e:            # noqa: BLE001 - reported below
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads)
+    assert not errors, errors
+    for got, ref in zip(results, serial):
+        for g, r in zip(got, ref):
+            np.testing.assert_array_equal(np.asarray(g), np.asarray(r))
+
+
+def test_adam_loop_that_gives_up_is_repeated_with_a_launch_per_iteration(set_knob, caplog):
+    """A workgroup of the in-launch loop that never sees its tile's step gives up instead of hanging (bounded polls) and
+    marks the call (n_active < 0); the host layer repeats the search with one launch per iteration and says so.
+    EKS_ADAM_LOOP_SPINS=1 makes every waiting workgroup give up at once."""
+    import logging
+    from eks_amd import hip_ops
+    from eks_amd.core import run_kalman_smoother
+    sess = _adam_session(30_000, 64, 53)
+    ref = run_kalman_smoother(*sess)
+    set_knob('EKS_ADAM_PER_ITERATION', None)
+    set_knob('EKS_ADAM_LOOP_SPINS', '1')
+    try:
+        with caplog.at_level(logging.WARNING):
+            got = run_kalman_smoother(*sess)
+        assert any('gave up' in r.getMessage() for r in caplog.records)
+        assert os.environ.get('EKS_ADAM_PER_ITERATION') == '1'
+        for g, r in zip(got, ref):
+            np.testing.assert_array_equal(np.asarray(g), np.asarray(r))
+    finally:
+        os.environ.pop('EKS_ADAM_PER_ITERATION', None)
+        hip_ops._lib.load().eks_knobs_reload()
+
+
 def test_first_call_of_a_fresh_process_is_bounded():
     """the first run_kalman_smoother of a process on the reference's own data size (2 000 frames x
     4 keypoints).  Measured (tools/first_call.py): the library's nine code objects load in 0.7 - 2.6 ms each at their
