@@ -12,6 +12,8 @@ python -m pytest tests -q -m gpu 2>&1 | tail -3 > $O/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 python bench.py > $O/bench_c3.json 2> $O/bench_c3.err
 python bench.py --workload c3adam > $O/bench_c3adam.json 2> $O/bench_c3adam.err
+EKS_ADAM_PER_ITERATION=1 python bench.py --workload c3adam --no-cpu-baseline > $O/bench_c3adam_per_iteration.json 2>/dev/null
+EKS_NLL_GRAD_TREE=1 EKS_ADAM_PER_ITERATION=1 python bench.py --workload c3adam --no-cpu-baseline > $O/bench_c3adam_per_iteration_tree.json 2>/dev/null
 EKS_NLL_LEGACY=1 python bench.py --no-cpu-baseline > $O/bench_c3_legacy_nll.json 2>/dev/null
 EKS_NLL_NOLAG=1 python bench.py --no-cpu-baseline > $O/bench_c3_nolag.json 2>/dev/null
 python bench.py --workload c4 --no-cpu-baseline > $O/bench_c4.json 2>/dev/null
@@ -32,6 +34,7 @@ tools/micro/bin/nll_lag > $O/nll_lag.txt 2>&1
 python tools/fit_time.py 2>&1 | grep -v amdgpu > $O/fit_time.txt
 python tools/host_boundary_ab.py 2>&1 | grep -v amdgpu > $O/host_boundary_ab.txt
 EKS_HIP_LIB=build_alt/gridstamps/libeks_hip.so python tools/grid_stamps.py 2>&1 | grep -v amdgpu > $O/grid_stamps.txt
+EKS_HIP_LIB=build_alt/gfstamps/libeks_hip.so python tools/gf_loop_stamps.py 2>&1 | grep -v "amdgpu\|Warning\|print(" > $O/gf_loop_stamps.txt
 python tools/adam_time.py > $O/adam_time.txt 2>&1
 python tools/dense_adam_time.py > $O/dense_adam_time.txt 2>&1
 python tools/dense_adam_time_d.py 2>&1 | grep adam > $O/dense_adam_time_d.txt
@@ -39,6 +42,7 @@ python tools/pupil_time.py 2>&1 | grep -v amdgpu > $O/pupil_time.txt
 cd /tmp; export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-events"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3adam -- python3 $R/bench.py --workload c3adam --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > /dev/null 2>&1
 B3="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B3 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B3 > /dev/null 2>&1
