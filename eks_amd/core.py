@@ -673,21 +673,7 @@ def _run_tiled_from_host(tiles, ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frame
         raise ValueError(f'ys must be (K,T,O) and ensemble_vars (T,K,O); got {tuple(ys_h.shape)} and {tuple(ev_h.shape)}')
     if T < 2:
         raise ValueError('Not enough frames to compute temporal differences.')
-    vshape = (K, T, D) if vs_diag else (K, T, D, D)
-    nbytes = (K * T * D + int(np.prod(vshape))) * 4
-    pinned = not os.environ.get('EKS_PAGEABLE_D2H') and nbytes <= (2 << 30) and _pinned_reserve(nbytes)
-    try:
-        ms_h = torch.empty((K, T, D), dtype=torch.float32, pin_memory=pinned)
-        Vs_h = torch.empty(vshape, dtype=torch.float32, pin_memory=pinned)
-    except RuntimeError:
-        if pinned:
-            _release_pinned(nbytes)
-        pinned = False
-        ms_h = torch.empty((K, T, D), dtype=torch.float32)
-        Vs_h = torch.empty(vshape, dtype=torch.float32)
-    sp = None if smooth_param is None or isinstance(smooth_param, (int, float)) else \
-        np.broadcast_to(np.asarray(smooth_param, dtype=float), (K,))
-    flags = hip_ops.model_flags(par['S0'], par['A'], par['C'], par['Q'])      # once, for every tile
+    t_entry = time.perf_counter()
     # The ensemble variances arrive (T, K, O), frame-major: a keypoint tile of them is a strided view on the host.
     # numpy gathers one in 1.6 - 5 ms per 25 MB (three to ten times its transfer), so round 4 sent the whole array up
     # before the first tile started (3.6 ms of BASELINE configs[2]'s 16.6); the library's own threaded gather
@@ -740,7 +726,23 @@ def _run_tiled_from_host(tiles, ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frame
 
     if not whole:
         threading.Thread(target=produce, name='eks-var-tiles', daemon=True).start()
+    vshape = (K, T, D) if vs_diag else (K, T, D, D)
+    nbytes = (K * T * D + int(np.prod(vshape))) * 4
+    pinned = not os.environ.get('EKS_PAGEABLE_D2H') and nbytes <= (2 << 30) and _pinned_reserve(nbytes)
+    try:
+        ms_h = torch.empty((K, T, D), dtype=torch.float32, pin_memory=pinned)
+        Vs_h = torch.empty(vshape, dtype=torch.float32, pin_memory=pinned)
+    except RuntimeError:
+        if pinned:
+            _release_pinned(nbytes)
+        pinned = False
+        ms_h = torch.empty((K, T, D), dtype=torch.float32)
+        Vs_h = torch.empty(vshape, dtype=torch.float32)
+    sp = None if smooth_param is None or isinstance(smooth_param, (int, float)) else \
+        np.broadcast_to(np.asarray(smooth_param, dtype=float), (K,))
+    flags = hip_ops.model_flags(par['S0'], par['A'], par['C'], par['Q'])      # once, for every tile
     s_parts, infos = [], []
+    t_loop = time.perf_counter()
     try:
         for i, (k0, k1) in enumerate(tiles):
             st = work[i % len(work)]
@@ -782,7 +784,8 @@ def _run_tiled_from_host(tiles, ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frame
     for inf in infos:
         _finish_search(inf)
     if trace:
-        logger.warning('tiled boundary, per tile (k0, k1, ys upload ms, variance gather ms, variance upload enqueue ms): '
+        logger.warning(f'tiled boundary: {(t_loop - t_entry) * 1e3:.2f} ms before the first tile, {(time.perf_counter() - t_loop) * 1e3:.2f} ms '
+                       'to the end of the downloads; per tile (k0, k1, ys upload ms, variance gather ms, variance upload enqueue ms): '
                        + '; '.join(f'{a}-{b}: {u:.2f} {g:.2f} {e:.2f}' for a, b, u, g, e in trace))
     s_finals = np.concatenate([np.asarray(s.cpu().numpy(), dtype=float) for s in s_parts])
     out_ms, out_Vs = ms_h.numpy(), Vs_h.numpy()
