@@ -107,6 +107,10 @@ EKS_HD F val(DualT<F> x) { return x.v; }
 template <typename F>
 EKS_HD F der(DualT<F> x) { return x.d; }
 
+EKS_HD DualT<float> make_dual(float x) { return DualT<float>(x, 0.f); }
+EKS_HD DualT<float> make_dual(DualT<float> x) { return x; }
+EKS_HD float from_dual(float, DualT<float> x) { return x.v; }
+EKS_HD DualT<float> from_dual(DualT<float>, DualT<float> x) { return x; }
 EKS_HD float make_real(float, float v, float) { return v; }
 EKS_HD Dual make_real(Dual, float v, float d) { return Dual(v, d); }
 EKS_HD double make_real(double, double v, double) { return v; }
@@ -225,6 +229,43 @@ struct NllLane {
         dl[k] = d;
         acc2[k].add(s2);
         n_post[k] += NB;
+      } else if (phase[k] == 1 && EKS_NLL_PACKED && sizeof(R) == sizeof(Dual) && NCL == 1) {
+        // ---- regime 1 of the gradient path on packed (value, derivative) pairs (round 5: the dual-number operators
+        //      below compile to ~35 issue slots per frame, this to 13; chunk 0 of the Adam loss kernel spends ~130
+        //      frames here mid-search and was the wave every iteration waited for)
+        const Dual pl = make_dual(slow_pole ? R(0.f) - kapI[k] : pole(k)), cgd = make_dual(cgI[k]), rgd = make_dual(rgI[k]);
+        const Dual d0 = make_dual(dl[k]), A0 = make_dual(e[k].A);
+        const f32x2 P2 = f32x2{pl.v, pl.v}, CG = f32x2{cgd.v, cgd.d}, RG = f32x2{rgd.v, rgd.d};
+        const float cN = UNIT ? 1.f : val(pc[k].c), aN = UNIT ? 1.f : val(pc[k].a);
+        f32x2 X = f32x2{d0.v, d0.d}, Ap = f32x2{A0.v, A0.d};
+        f32x2 S2 = f32x2{0.f, 0.f}, ES = f32x2{0.f, 0.f}, JS = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          const float dy = UNIT ? (yb[q] - yp) : (float)((double)yb[q] - a_dbl * (double)yp);
+          yp = yb[q];
+          const f32x2 step = P2 * X + f32x2{dy, pl.d * X[0]};
+          X = slow_pole ? X + step : step;
+          S2 = f32x2{X[0], X[0]} * X + S2;
+          const f32x2 Acg = f32x2{Ap[0], Ap[0]} * CG + f32x2{0.f, Ap[1] * cgd.v};
+          ES = f32x2{Acg[0], Acg[0]} * X + ES;
+          ES[1] += Acg[1] * X[0];
+          f32x2 AA = f32x2{Acg[0], Acg[0]} * Ap + f32x2{0.f, Acg[1] * Ap[0]};
+          if (!UNIT) AA = AA * f32x2{cN, cN};
+          JS = JS + AA;
+          Ap = f32x2{Ap[0], Ap[0]} * RG + f32x2{0.f, Ap[1] * rgd.v};
+          if (!UNIT) Ap = Ap * f32x2{aN, aN};
+        }
+        dl[k] = from_dual(R(), Dual(X[0], X[1]));
+        e[k].A = from_dual(R(), Dual(Ap[0], Ap[1]));
+        acc2[k].add(from_dual(R(), Dual(S2[0], 2.f * S2[1])));
+        eta64[k].add(from_dual(R(), Dual(ES[0], ES[1])));
+        J64[k].add(from_dual(R(), Dual(JS[0], JS[1])));
+        n_post[k] += NB;
+        const bool dead = fabsf(val(e[k].A)) < kDeadA && fabsf(der(e[k].A)) < kDeadA;
+        if (EKS_WAVE_ALL(dead)) {
+          phase[k] = 2;
+          e[k].A = R(0.f);
+        }
       } else if (phase[k] == 1) {
         // ---- regime 1: C frozen; A still decays, eta / J still accumulate
         R s2 = R(0.f), d = dl[k], es = R(0.f), js = R(0.f);

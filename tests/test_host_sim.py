@@ -191,6 +191,57 @@ def test_gradient_without_compositions_matches_oracle(sim, T, BN, unit):
     assert (np.abs(dn[ok] - ref_g[ok]) / np.maximum(np.abs(ref_g[ok]), 1e-3 * np.abs(ref_nll[ok]))).max() < 2e-5
 
 
+@pytest.fixture(scope='module')
+def sim_packed():
+    """The same simulator with the lane bodies' PACKED forms (what the GPU runs: float32 pairs in 64-bit registers) - they
+    are written with clang's vector extensions, so this build needs ROCm's clang++ (it is host code: no GPU involved)."""
+    cxx = '/opt/rocm/lib/llvm/bin/clang++'
+    if not os.path.exists(cxx):
+        pytest.skip('no clang++ under /opt/rocm')
+    src = os.path.join(ROOT, 'tests', 'host_sim', 'diag_sim.cpp')
+    lib = os.path.join(ROOT, 'tests', 'host_sim', 'libdiag_sim_packed.so')
+    subprocess.run([cxx, '-O2', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=fast', '-DEKS_NLL_PACKED=1', '-I',
+                    os.path.join(ROOT, 'eks_amd', 'csrc'), src, '-o', lib], check=True)
+    return ctypes.CDLL(lib)
+
+
+@pytest.mark.parametrize('unit', [True, False])
+def test_packed_dual_lane_bodies_match_the_oracle_like_the_scalar_ones(sim, sim_packed, unit):
+    """Round 5's packed (value, derivative) forms - regime 1 and the steady loop of the gradient lane, the converged-entry
+    chunk with d / d log s - built for the host: against the oracle at the scalar forms' bars, and within float32 rounding
+    of the scalar forms themselves (same operations, possibly contracted differently by the two compilers)."""
+    T, BN, K = 6000, 392, 6
+    arrs, y, var, ys64, ev64 = _problem(T, K, seed=21)
+    rng = np.random.default_rng(8)
+    if not unit:
+        eye = np.eye(2)
+        arrs['As'] = np.ascontiguousarray(eye * rng.uniform(0.9, 1.0, (K, 2))[:, :, None])
+        arrs['Cs'] = np.ascontiguousarray(eye * rng.uniform(0.5, 1.5, (K, 2))[:, :, None])
+        arrs['Qs'] = np.ascontiguousarray(eye * rng.uniform(0.5, 2.0, (K, 2))[:, :, None])
+    Rc = orc.constant_R_from_timevarying(orc.build_R_from_vars(ev64))
+    rconst = np.ascontiguousarray(Rc.reshape(-1))
+    s = np.exp(np.linspace(-6.5, 5, K))           # slow poles (regime 1 lasts hundreds of frames) to fast ones
+    ref_nll, ref_g = orc.filter_nll(ys64, arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], s, Rc, want_grad=True)
+    f, d = ctypes.c_float, ctypes.c_double
+    out = {}
+    for name, lib in (('scalar', sim), ('packed', sim_packed)):
+        nll, dn = np.zeros((K, 1)), np.zeros((K, 1))
+        sk = np.ascontiguousarray(s[:, None])
+        lib.sim_diag_nll(T, 2 * K, 2, BN, int(unit), 1, _p(y, f), _p(rconst, d), _p(arrs['m0s'], d), _p(arrs['S0s'], d),
+                         _p(arrs['As'], d), _p(arrs['Cs'], d), _p(arrs['Qs'], d), _p(sk, d), 1, 1, _p(nll, d), _p(dn, d))
+        nll2, dn2 = np.zeros(K), np.zeros(K)
+        lib.sim_diag_nll_conv_grad(T, 2 * K, 2, BN, int(unit), _p(y, f), _p(rconst, d), _p(arrs['m0s'], d),
+                                   _p(arrs['S0s'], d), _p(arrs['As'], d), _p(arrs['Cs'], d), _p(arrs['Qs'], d),
+                                   _p(s, d), _p(nll2, d), _p(dn2, d))
+        out[name] = (nll[:, 0], dn[:, 0], nll2, dn2)
+        assert (np.abs(nll[:, 0] - ref_nll) / np.abs(ref_nll)).max() < 3e-6
+        assert (np.abs(dn[:, 0] - ref_g) / np.maximum(np.abs(ref_g), 1e-3 * np.abs(ref_nll))).max() < 3e-5
+    for a, b in zip(out['scalar'], out['packed']):
+        ok = ~np.isnan(a)
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        assert (np.abs(a[ok] - b[ok]) / np.maximum(np.abs(a[ok]), 1e-3 * np.abs(ref_nll[ok]))).max() < 2e-6
+
+
 def test_lag_sum_identity_is_exact_with_all_lags():
     """sum_t d_t^2 of the zero-start recursion d_t = rho d_{t-1} + u_t equals
     [c_0 + 2 sum_k rho^k c_k - rho^2 d_last^2] / (1 - rho^2) with c_k the lag sums of u - the identity the lag form
