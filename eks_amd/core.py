@@ -879,9 +879,17 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
                 else:       # read back (and rounded, on the host) once eks_const_r has been enqueued behind the reduction
                     guesses = lambda: _initial_guesses_per_keypoint(sd=sd())      # noqa: E731
             else:
-                ev_host = _to_numpy(ensemble_vars)[:2000] if not hasattr(ensemble_vars, 'detach') \
-                    else ensemble_vars[:2000].detach().cpu().numpy()
-                guesses = _initial_guesses_per_keypoint(ev_host)
+                src_f32 = (ensemble_vars.dtype == torch.float32) if hasattr(ensemble_vars, 'detach') \
+                    else (getattr(ensemble_vars, 'dtype', None) == np.float32)
+                sd = _guess_std_on_device(P.var, lazy=True) if src_f32 else None
+                if sd is not None:
+                    # float32 variances from the host: the copy on the device holds the same values, and the device
+                    # reduction is numpy's float32 summation bit for bit (np.nanstd over 256 x 4 000 cost 2-3 ms here)
+                    guesses = lambda: _initial_guesses_per_keypoint(sd=sd())      # noqa: E731
+                else:
+                    ev_host = _to_numpy(ensemble_vars)[:2000] if not hasattr(ensemble_vars, 'detach') \
+                        else ensemble_vars[:2000].detach().cpu().numpy()
+                    guesses = _initial_guesses_per_keypoint(ev_host)
         s_dev, info = _optimize_on_device(P, blocks, s_frames, guesses, lr, s_bounds_log, tol,
                                           safety_cap, 1e-4, s_mode, n_grid)
         if not _s_on_device:                     # (the tiled boundary reads s once, after the last tile is enqueued)

@@ -1050,7 +1050,8 @@ def test_initial_guesses_reduced_on_the_device_equal_the_host_reduction():
     assert np.array_equal(core._initial_guesses_per_keypoint(sd=sd), core._initial_guesses_per_keypoint(ev))
 
 
-@pytest.mark.parametrize('T,K,unit,stride', [(30_000, 70, True, 24), (20_011, 33, False, 7), (50_000, 128, True, 128)])
+@pytest.mark.parametrize('T,K,unit,stride', [(30_000, 70, True, 24), (20_011, 33, False, 7), (50_000, 128, True, 128),
+                                             (12_345, 300, False, 50), (4_500, 40, True, 9)])
 def test_adam_chip_wide_loop_in_one_launch_is_the_per_iteration_loop_bit_for_bit(T, K, unit, stride, set_knob):
     """Long sessions, one keypoint per optimiser block: an eks_adam_run call keeps the chip-wide loss kernel's
     workgroups for all of its iterations (round 5: GfLoop in eks_diag_nll.hip - the tile's last block applies the step
