@@ -525,13 +525,17 @@ int diag_nll_adam_persist(const eks_dims_t& d, const float* y, const double* rco
 //     in time order by a 3-level tree through LDS; wave 0 stores ONE group summary (13 doubles per chain,
 //     [tile][group][field][lane]: coalesced);
 //   * the block that takes the LAST ticket of its tile (agent-scope release / acquire around an atomic
-//     counter - no spinning, so no co-residency assumption) reads the tile's group summaries back
+//     counter - nobody waits for anybody inside one evaluation, so no co-residency assumption; the loop
+//     mode of round 5, GfLoop below, does wait and is launched cooperatively) reads the tile's group summaries back
 //     (coalesced, a contiguous run of groups per wave), composes them the same way, pushes the prior
 //     through the result, sums the D chains of a keypoint with wave shuffles, writes nll / dnll and - when
 //     every optimiser block is one keypoint - applies the Adam step of its 64 / D keypoints on the spot;
 //   * all blocks of a tile share its chains, so the "every keypoint of the tile has stopped" exit is
 //     block-uniform and the ticket count of a tile is all or nothing.
 // The chunk length is chosen so that the grid is a whole number of 256-CU rounds (C3: 8 tiles x 32 groups).
+// Round 5: where the tile's poles allow, the chunks past the first are summarised from a converged entry and their
+// terms SUMMED (gf_evaluate's first branch: no compositions at all); and all iterations of an eks_adam_run call run
+// inside one launch (GfLoop).  The form described above is what remains for slow poles and single evaluations.
 constexpr int kGfWaves = 8;
 constexpr int kGfFields = 13;          // (A, b, C, eta, J, ell) x (value, derivative) + reference state
 constexpr int kGfChunkMin = 256;      // (shorter chunks never leave the full recursion: nll_summarize_chunk)
@@ -566,7 +570,6 @@ struct GradFuseWs {
   int ngroups;
   int conv_allowed;     // converged-entry chunk terms where the poles allow (EKS_NLL_GRAD_TREE=1: always the tree)
 };
-struct GfLoop;
 
 __device__ __forceinline__ void gf_put(double* slot, const NllAcc<DualD>& a) {
   const DualD f[6] = {a.e.A, a.e.b, a.e.C, a.e.eta, a.e.J, a.ell};
@@ -960,12 +963,6 @@ __global__ __launch_bounds__(64 * kGfWaves) void diag_nll_grad_fused_kernel(NllG
   double s_now = s_kp[k];
   bool running = chain_ok;
   if (F.state != nullptr) running = chain_ok && adam_block_running(F.state, kb, F.cap);
-#ifdef EKS_GF_STAGGER
-  if (LOOP) {                                          // (experiment) tiles start EKS_GF_STAGGER x 10 ns apart
-    const unsigned long long t_go = __builtin_amdgcn_s_memrealtime() + (unsigned long long)tile * EKS_GF_STAGGER;
-    while (__builtin_amdgcn_s_memrealtime() < t_go) __builtin_amdgcn_s_sleep(16);
-  }
-#endif
   // the first rows of a converged-entry chunk do not depend on s: they are requested before the step is waited for
   float pre[kGfRows];
   auto request_first_rows = [&]() {

@@ -148,7 +148,12 @@ int eks_adam_step(int32_t n_blocks, const int32_t* block_offsets, const int32_t*
  * a host round trip per iteration.  Arguments as in eks_nll / eks_adam_step; s_keypoint [K] is
  * both the evaluation point and the step's output; nll, dnll [K] hold the last evaluation.
  * Iterations enqueued after a block has stopped leave it untouched, so the caller may issue
- * n_iters at a time and read *n_active in between.  workspace: eks_nll_workspace_bytes(dims, 1). */
+ * n_iters at a time and read *n_active in between.  workspace: eks_nll_workspace_bytes(dims, 1).
+ * Scalar chains with one keypoint per block: all n_iters iterations are ONE launch - a workgroup per keypoint for
+ * short sessions, the chip-wide loss kernel launched cooperatively for long ones (its workgroups wait for each other:
+ * one that waits in vain - e.g. another process holds the compute units - gives up after a bounded number of polls
+ * and the call reports *n_active < 0: its results are invalid; EKS_ADAM_PER_ITERATION=1 selects a launch per
+ * iteration, with identical results). */
 int eks_adam_run(const eks_dims_t* dims, const float* y, const double* rconst, const double* m0,
                  const double* S0, const double* A, const double* C, const double* Q,
                  int32_t n_blocks, const int32_t* block_offsets, const int32_t* block_members,
