@@ -1050,14 +1050,16 @@ def test_initial_guesses_reduced_on_the_device_equal_the_host_reduction():
     assert np.array_equal(core._initial_guesses_per_keypoint(sd=sd), core._initial_guesses_per_keypoint(ev))
 
 
-@pytest.mark.parametrize('T,K,unit,stride', [(30_000, 70, True, 24), (20_011, 33, False, 7), (50_000, 128, True, 128),
-                                             (12_345, 300, False, 50), (4_500, 40, True, 9)])
-def test_adam_chip_wide_loop_in_one_launch_is_the_per_iteration_loop_bit_for_bit(T, K, unit, stride, set_knob):
+@pytest.mark.parametrize('T,K,unit,stride,cap', [(30_000, 70, True, 24, 300), (20_011, 33, False, 7, 300),
+                                                 (50_000, 128, True, 128, 300), (12_345, 300, False, 50, 300),
+                                                 (4_500, 40, True, 9, 300), (30_000, 70, True, 5, 13)])
+def test_adam_chip_wide_loop_in_one_launch_is_the_per_iteration_loop_bit_for_bit(T, K, unit, stride, cap, set_knob):
     """Long sessions, one keypoint per optimiser block: an eks_adam_run call keeps the chip-wide loss kernel's
     workgroups for all of its iterations (round 5: GfLoop in eks_diag_nll.hip - the tile's last block applies the step
     and hands s to the tile's other blocks through tagged words).  The arithmetic of an iteration is that of a launch
     per iteration (EKS_ADAM_PER_ITERATION=1), so the optimiser state, s, and the last loss and gradient must agree
-    bit for bit - also when calls end mid-search (stride 7 / 24) and with a partial last tile (K = 70 / 33)."""
+    bit for bit - also when calls end mid-search (stride 7 / 24), with a partial last tile (K = 70 / 33), and when the
+    safety cap ends the search (cap 13: nobody has stopped by the rule)."""
     from eks_amd import hip_ops
     arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=31 + T, unit=unit)
     flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
@@ -1073,9 +1075,9 @@ def test_adam_chip_wide_loop_in_one_launch_is_the_per_iteration_loop_bit_for_bit
         state[:, 3] = np.inf
         state = _dev(state)
         s_kp = _dev(np.exp(u0))
-        loop = hip_ops.AdamLoop(y, rc, *params, offs, mem, state, s_kp, 0.25, -8.0, 8.0, 1e-2, 300, flags=flags)
+        loop = hip_ops.AdamLoop(y, rc, *params, offs, mem, state, s_kp, 0.25, -8.0, 8.0, 1e-2, cap, flags=flags)
         left = []
-        for _ in range((300 + stride - 1) // stride):
+        for _ in range((cap + stride - 1) // stride):
             loop.run(stride)
             left.append(int(loop.n_active.item()))
             assert left[-1] >= 0
@@ -1088,7 +1090,10 @@ def test_adam_chip_wide_loop_in_one_launch_is_the_per_iteration_loop_bit_for_bit
     set_knob('EKS_ADAM_PER_ITERATION', '1')
     n_it, st_i, s_i, nll_i, g_i, left_i = run()
     assert n_it == 16
-    assert st_l[:, 4].max() > 20 and np.all(st_l[:, 5] == 1.0)
+    if cap == 300:
+        assert st_l[:, 4].max() > 20 and np.all(st_l[:, 5] == 1.0)
+    else:
+        assert np.all(st_l[:, 4] == cap) and np.all(st_l[:, 5] == 0.0) and left_l[-1] == 0
     np.testing.assert_array_equal(st_l, st_i)
     np.testing.assert_array_equal(s_l, s_i)
     np.testing.assert_array_equal(nll_l, nll_i)
