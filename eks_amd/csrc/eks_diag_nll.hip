@@ -725,10 +725,14 @@ __device__ __forceinline__ AdamRegs gf_state_request(const AdamFuse& F, int w, i
 // meet in LDS; the term of a block's FIRST chunk needs the previous block's last b, so each block publishes
 // (sum of its finished terms, its last b, its first chunk's eta, J, xref: 9 doubles per lane instead of 13) and the
 // tile's last block adds the deferred terms - independent loads and a sum where the tree had log-depth compositions.
-#ifndef EKS_GF_ROWS
-#define EKS_GF_ROWS 8
+// frames per row buffer of the converged-entry chunk body (two buffers: 2 ROWS rows requested ahead per wave).  8 where the
+// launch fills the chip (C3: the streaming phase runs at the HBM peak, 16 measured slower); 16 for small launches - a
+// single-tile session has ~50 workgroups, each limited by what it keeps in flight
+constexpr int kGfRowsFull = 8, kGfRowsFew = 16;
+#ifndef EKS_GF_FEW_BLOCKS
+#define EKS_GF_FEW_BLOCKS 128
 #endif
-constexpr int kGfRows = EKS_GF_ROWS;                // frames per row buffer of the converged-entry chunk body (two buffers)
+constexpr int kGfFewBlocks = EKS_GF_FEW_BLOCKS;     // launches of at most this many workgroups take kGfRowsFew (A/B builds: 0 / 100000)
 constexpr int kGcSum = 0, kGcB = 2, kGcEta = 4, kGcJ = 6, kGcXr = 8;      // field rows of a group's slot ([field][64])
 
 // everything one evaluation needs that does not change between iterations
@@ -751,9 +755,9 @@ struct GfCtx {
 
 // one evaluation at s_now.  Returns whether this block was its tile's last (block-uniform); in that block wave 0 has
 // written the keypoints' loss and gradient and applied the step (s_next / run_next: wave 0, loop mode).
-template <bool UNIT, bool LOOP, typename LD>
+template <bool UNIT, bool LOOP, int ROWS, typename LD>
 __device__ __forceinline__ bool gf_evaluate(const GfCtx<LD>& X, double s_now, bool running, bool count_now,
-                                            const float (&pre)[kGfRows], double& s_next, bool& run_next GF_IT_ARG) {
+                                            const float (&pre)[ROWS], double& s_next, bool& run_next GF_IT_ARG) {
   const NllGeom& G = X.G;
   const GradFuseWs& W = X.W;
   const int w = X.w, lane = X.lane;
@@ -787,7 +791,7 @@ __device__ __forceinline__ bool gf_evaluate(const GfCtx<LD>& X, double s_now, bo
       bx[(w * 2 + 1) * 64 + lane] = bn.d;
     } else if (X.j < G.ncn) {
       ConvDual o;
-      nll_conv_chunk_dual<UNIT, kGfRows>(X.ld, X.len, KC, X.a_n, X.c_n, o, X.len >= kGfRows ? pre : nullptr);
+      nll_conv_chunk_dual<UNIT, ROWS>(X.ld, X.len, KC, X.a_n, X.c_n, o, X.len >= ROWS ? pre : nullptr);
       term = DualD(o.ell, o.dell);
       eta = DualD(o.eta, o.deta);
       Jc = DualD(o.J, o.dJ);
@@ -927,7 +931,7 @@ __device__ __forceinline__ bool gf_evaluate(const GfCtx<LD>& X, double s_now, bo
   return true;
 }
 
-template <bool UNIT, bool LOOP>
+template <bool UNIT, bool LOOP, int ROWS>
 __global__ __launch_bounds__(64 * kGfWaves) void diag_nll_grad_fused_kernel(NllGeom G, DiagModel M, GradFuseWs W,
                                                                            const float* __restrict__ y,
                                                                            const double* __restrict__ rconst,
@@ -964,14 +968,14 @@ __global__ __launch_bounds__(64 * kGfWaves) void diag_nll_grad_fused_kernel(NllG
   bool running = chain_ok;
   if (F.state != nullptr) running = chain_ok && adam_block_running(F.state, kb, F.cap);
   // the first rows of a converged-entry chunk do not depend on s: they are requested before the step is waited for
-  float pre[kGfRows];
+  float pre[ROWS];
   auto request_first_rows = [&]() {
-    if (j >= 1 && X.len >= kGfRows) {
+    if (j >= 1 && X.len >= ROWS) {
 #pragma unroll
-      for (int q = 0; q < kGfRows; ++q) pre[q] = ld(q);
+      for (int q = 0; q < ROWS; ++q) pre[q] = ld(q);
     } else {
 #pragma unroll
-      for (int q = 0; q < kGfRows; ++q) pre[q] = 0.f;
+      for (int q = 0; q < ROWS; ++q) pre[q] = 0.f;
     }
   };
   request_first_rows();
@@ -982,7 +986,7 @@ __global__ __launch_bounds__(64 * kGfWaves) void diag_nll_grad_fused_kernel(NllG
     GF_STAMP(0);
     double s_next = s_now;
     bool run_next = false;
-    const bool was_last = gf_evaluate<UNIT, LOOP>(X, s_now, running, !LOOP || it == L.n_iters - 1, pre, s_next, run_next GF_IT_PASS);
+    const bool was_last = gf_evaluate<UNIT, LOOP, ROWS>(X, s_now, running, !LOOP || it == L.n_iters - 1, pre, s_next, run_next GF_IT_PASS);
     if (!LOOP || it + 1 >= L.n_iters) return;
     request_first_rows();
     if (was_last) {
@@ -1831,10 +1835,21 @@ int32_t* nll_ws_tickets(void* ws, int T, int N, int n_cand) {
   return reinterpret_cast<int32_t*>(tail + align_up((size_t)N * sizeof(int32_t), 256));
 }
 
+// the instantiation of the loss kernel for a model class, mode and launch size
+using GfKernel = void (*)(NllGeom, DiagModel, GradFuseWs, const float*, const double*, const double*, double*, double*, AdamFuse,
+                          GfLoop);
+static GfKernel gf_kernel(bool unit, bool loop, bool few_blocks) {
+  if (few_blocks) {
+    if (unit) return loop ? diag_nll_grad_fused_kernel<true, true, kGfRowsFew> : diag_nll_grad_fused_kernel<true, false, kGfRowsFew>;
+    return loop ? diag_nll_grad_fused_kernel<false, true, kGfRowsFew> : diag_nll_grad_fused_kernel<false, false, kGfRowsFew>;
+  }
+  if (unit) return loop ? diag_nll_grad_fused_kernel<true, true, kGfRowsFull> : diag_nll_grad_fused_kernel<true, false, kGfRowsFull>;
+  return loop ? diag_nll_grad_fused_kernel<false, true, kGfRowsFull> : diag_nll_grad_fused_kernel<false, false, kGfRowsFull>;
+}
+
 // how many workgroups of the loop-mode kernel the current device holds at once (0: no cooperative launches)
-static long gf_resident_blocks(bool unit) {
-  const void* fn = unit ? reinterpret_cast<const void*>(&diag_nll_grad_fused_kernel<true, true>)
-                        : reinterpret_cast<const void*>(&diag_nll_grad_fused_kernel<false, true>);
+static long gf_resident_blocks(bool unit, bool few_blocks = false) {
+  const void* fn = reinterpret_cast<const void*>(gf_kernel(unit, true, few_blocks));
   int dev = 0, coop = 0, cus = 0, per_cu = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop ||
@@ -1859,7 +1874,7 @@ static int grad_fused_launch(const eks_dims_t& d, const NllGeom& G, const float*
   const size_t grp_bytes = (size_t)G.ntile * FW.ngroups * kGfFields * 64 * sizeof(double);
   if (grp_bytes > diag_nll_workspace_bytes(T, N, 1) - adam_extra_bytes(N)) return EKS_ERR_WORKSPACE;
   const dim3 grid((unsigned)(G.ntile * FW.ngroups)), block(64 * kGfWaves);
-  const bool unit = (d.flags & EKS_FLAG_UNIT_AC) != 0;
+  const bool unit = (d.flags & EKS_FLAG_UNIT_AC) != 0, few = (int)grid.x <= kGfFewBlocks;
   if (loop_iters <= 0) {
     if (!tickets_zeroed) {   // (eks_adam_run zeroes the tickets once; every evaluation leaves them zero)
       const hipError_t e = hipMemsetAsync(FW.tickets, 0, (size_t)G.ntile * sizeof(int32_t), st);
@@ -1870,24 +1885,12 @@ static int grad_fused_launch(const eks_dims_t& d, const NllGeom& G, const float*
     // (an optimiser iteration as its own launch runs the loop-mode code for one iteration: the same instructions as
     //  inside a longer call, so the two forms of eks_adam_run agree bit for bit - tests/test_gpu_kernels.py)
     const bool step = F.state != nullptr && F.step_in_kernel;
-    if (unit && step)
-      hipLaunchKernelGGL((diag_nll_grad_fused_kernel<true, true>), grid, block, 0, st, G, M, FW, y, rconst, s_kp, nll,
-                         dnll, F, L);
-    else if (unit)
-      hipLaunchKernelGGL((diag_nll_grad_fused_kernel<true, false>), grid, block, 0, st, G, M, FW, y, rconst, s_kp, nll,
-                         dnll, F, L);
-    else if (step)
-      hipLaunchKernelGGL((diag_nll_grad_fused_kernel<false, true>), grid, block, 0, st, G, M, FW, y, rconst, s_kp, nll,
-                         dnll, F, L);
-    else
-      hipLaunchKernelGGL((diag_nll_grad_fused_kernel<false, false>), grid, block, 0, st, G, M, FW, y, rconst, s_kp, nll,
-                         dnll, F, L);
+    hipLaunchKernelGGL(gf_kernel(unit, step, few), grid, block, 0, st, G, M, FW, y, rconst, s_kp, nll, dnll, F, L);
     return hip_status(hipGetLastError());
   }
   // ---- loop mode: every workgroup resident, hand-off words and the running count zeroed behind the stream
-  const void* fn = unit ? reinterpret_cast<const void*>(&diag_nll_grad_fused_kernel<true, true>)
-                        : reinterpret_cast<const void*>(&diag_nll_grad_fused_kernel<false, true>);
-  if (gf_resident_blocks(unit) < (long)grid.x) return EKS_ERR_UNSUPPORTED;
+  const void* fn = reinterpret_cast<const void*>(gf_kernel(unit, true, few));
+  if (gf_resident_blocks(unit, few) < (long)grid.x) return EKS_ERR_UNSUPPORTED;
   GfLoop L{loop_iters, reinterpret_cast<unsigned long long*>(nll_ws_hand(ws, T, N)),
            knob_int(KNOB_ADAM_LOOP_SPINS, kGfSpinLimit)};
   hipError_t e = hipMemsetAsync(L.hand, 0, (size_t)G.ntile * 64 * 2 * sizeof(unsigned long long), st);
@@ -1901,12 +1904,7 @@ static int grad_fused_launch(const eks_dims_t& d, const NllGeom& G, const float*
     // Under a rocprofiler-sdk tool (rocprofv3) a process that made a cooperative launch crashes when it EXITS (ROCm
     // 7.2: SIGSEGV in the tool's finalisation, after the run itself completed).  The same kernel as an ordinary launch:
     // its workgroups fit the device (checked above) and a profiled process runs its kernels one stream at a time.
-    if (unit)
-      hipLaunchKernelGGL((diag_nll_grad_fused_kernel<true, true>), grid, block, 0, st, Gc, Mc, FW, y, rconst, s_kp, nll,
-                         dnll, Fc, L);
-    else
-      hipLaunchKernelGGL((diag_nll_grad_fused_kernel<false, true>), grid, block, 0, st, Gc, Mc, FW, y, rconst, s_kp, nll,
-                         dnll, Fc, L);
+    hipLaunchKernelGGL(gf_kernel(unit, true, few), grid, block, 0, st, Gc, Mc, FW, y, rconst, s_kp, nll, dnll, Fc, L);
     return hip_status(hipGetLastError());
   }
   void* args[] = {&Gc, &Mc, &FW, &y, &rconst, &s_kp, &nll, &dnll, &Fc, &L};
@@ -1924,7 +1922,8 @@ bool diag_nll_adam_loop_ok(int T, int K, int D, int n_blocks) {
     return false;
   const NllGeom G = make_geom(T, N, D, 1, 1, true, pick_ncl(1, true));
   const long blocks = (long)G.ntile * ((G.ncn + kGfWaves - 1) / kGfWaves);
-  return gf_resident_blocks(true) >= blocks && gf_resident_blocks(false) >= blocks;
+  const bool few = blocks <= kGfFewBlocks;
+  return gf_resident_blocks(true, few) >= blocks && gf_resident_blocks(false, few) >= blocks;
 }
 
 // eks_adam_run's n_iters iterations in one launch (see GfLoop); EKS_ERR_UNSUPPORTED: take the per-iteration launches
