@@ -199,17 +199,15 @@ def test_host_code_is_clean_under_address_sanitizer(tmp_path):
     """The library's host code (CSV body reader, table writer, number formatter, column gather) built for the CPU with
     AddressSanitizer + UBSan and driven over well-formed and adversarial files (tools/host_asan/: truncated, ragged, CRLF,
     NUL bytes, 400-digit fields, random bytes, short output capacities): no memory error, no undefined behaviour, no
-    overrun guard touched."""
-    import shutil
+    overrun guard touched.  CPU only: tools/host_asan/ does not travel to the GPU boxes (.gpurunignore; sanitizer builds
+    are not allowed there)."""
     import subprocess
-    if shutil.which('g++') is None:
-        pytest.skip('no g++')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    probe = subprocess.run(['g++', '-fsanitize=address', '-x', 'c++', '-', '-o', str(tmp_path / 'probe')],
-                           input='int main(){return 0;}', text=True, capture_output=True)
-    if probe.returncode != 0:
-        pytest.skip('g++ has no AddressSanitizer runtime here')
-    r = subprocess.run(['bash', os.path.join(root, 'tools', 'host_asan', 'run.sh'), str(tmp_path / 'work')],
-                       capture_output=True, text=True, timeout=600)
+    script = os.path.join(root, 'tools', 'host_asan', 'run.sh')
+    if not os.path.exists(script):
+        pytest.skip('tools/host_asan is not in this copy of the tree')
+    r = subprocess.run(['bash', script, str(tmp_path / 'work')], capture_output=True, text=True, timeout=600)
+    if r.returncode == 77:
+        pytest.skip('no g++ with the sanitizer runtimes here')
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert ', 0 problems' in r.stdout
