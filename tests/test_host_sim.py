@@ -200,7 +200,7 @@ def sim_packed():
         pytest.skip('no clang++ under /opt/rocm')
     src = os.path.join(ROOT, 'tests', 'host_sim', 'diag_sim.cpp')
     lib = os.path.join(ROOT, 'tests', 'host_sim', 'libdiag_sim_packed.so')
-    subprocess.run([cxx, '-O2', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=fast', '-DEKS_NLL_PACKED=1', '-I',
+    subprocess.run([cxx, '-O0', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=fast', '-DEKS_NLL_PACKED=1', '-I',
                     os.path.join(ROOT, 'eks_amd', 'csrc'), src, '-o', lib], check=True)
     return ctypes.CDLL(lib)
 
