@@ -1,11 +1,11 @@
 """Per-iteration timeline of the in-launch optimiser loop (diag_nll_grad_fused_kernel<., true>, eks_diag_nll.hip: GfLoop)
 from in-kernel stamps (diagnostic build: tools/build_alt.sh gfstamps -DEKS_GF_STAMPS eks_diag_nll.hip; run with
-EKS_HIP_LIB=build_alt/gfstamps/libeks_hip.so).  C3 (T = 100 000, K = 256), one call of 32 iterations."""
+EKS_HIP_LIB=build_alt/gfstamps/libeks_hip.so).  C3 (T = 100 000, K = 256) unless `iterations T K` are given; one call."""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eks_amd import synth, hip_ops, _lib
-T, K = 100_000, 256
+T, K = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (100_000, 256)
 NI = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 dev = torch.device('cuda', 0)
 y, var = synth.singlecam_observations_torch(T, K, seed=3, device=dev)
@@ -29,7 +29,7 @@ st = np.array(buf, dtype=np.float64).reshape(256, 48, 8) * 0.01
 t0 = st[:, 0, 0].min()
 st = np.where(st > 0, st - t0, np.nan)
 names = ['start', 'chunk done', 'block sum', 'ticket', 'slots read (last)', 'tile sum (last)', 'stepped (last)', 'next s known']
-ntile = 8
+ntile = (2 * K + 63) // 64
 tile = np.arange(256) % ntile
 print('iteration: per phase the median over the blocks of tile 0 (us since the launch\'s first stamp); cycle = start(it+1) - start(it)')
 for it in range(min(NI, 12)):
