@@ -576,25 +576,33 @@ int ekf_smooth(const eks_dims_t& d, int n_data_keypoints, const float* y, const 
   const dim3 sgrid(K, nblk);
   hipError_t e = hipMemsetAsync(resid, 0, (kEkfMaxSweeps + 2) * 8, st);
   if (e != hipSuccess) return hip_status(e);
-  auto sweep = [&](const Gate& gate, double* resid_out, bool with_smoother) {
+  // (build_gate: the element / scan kernels of the sweep; replay_gate: its replay)
+  auto sweep = [&](const Gate& build_gate, const Gate& replay_gate, double* resid_out, bool with_smoother) {
     hipLaunchKernelGGL((dense_summarize_kernel<3, PinholeObs>), dim3((lanes_k1 + 63) / 64), dim3(64), 0,
-                       st, G, M, Mm.s, obs, elems, first, gate);
+                       st, G, M, Mm.s, obs, elems, first, build_gate);
     hipLaunchKernelGGL(dense_scan_kernel<3>, sgrid, dim3(2 * kDenseCB), 0, st, G, elems, pre, suf, agg,
-                       gate);
+                       build_gate);
     hipLaunchKernelGGL(dense_scan_blocks_kernel<3>, dim3(K), dim3(2 * kDenseCB), 0, st, G, nblk,
-                       first, agg, bprior, bsuffix, gate);
+                       first, agg, bprior, bsuffix, build_gate);
     hipLaunchKernelGGL((dense_replay_kernel<3, true, PinholeObs>), dim3((lanes + 63) / 64), dim3(64),
                        0, st, G, M, Mm.s, obs, pre, suf, bprior, bsuffix, with_smoother ? filt : nullptr,
-                       with_smoother ? ms : nullptr, Vs, vs_diag, xlin, ll_chunk, resid_out, gate);
+                       with_smoother ? ms : nullptr, Vs, vs_diag, xlin, ll_chunk, resid_out, replay_gate);
   };
   {
     ProfScope ps("ekf_filter_sweeps", st);
-    for (int i = 0; i < max_sweeps; ++i)
-      sweep(Gate{i > 0 ? resid + i - 1 : nullptr, tol}, resid + i, false);
+    for (int i = 0; i < max_sweeps; ++i) {
+      const Gate g{i > 0 ? resid + i - 1 : nullptr, tol};
+      sweep(g, g, resid + i, false);
+    }
   }
   if (smooth) {
+    // Once the filter sweeps have met the tolerance (the last sweep that ran moved no linearisation point by more
+    // than tol; the slots of the sweeps gated after it are still zero) the elements, prefixes and suffixes in the
+    // workspace ARE the converged ones - rebuilt at the new points they would differ by ~tol (1e-10 against 1e-5 bars) -
+    // so the smoothing sweep is its replay alone (round 5: three launches and a third of a sweep's time less); it
+    // rebuilds them only when the sweeps ran out unconverged.
     ProfScope ps("ekf_smooth_sweep", st);
-    sweep(Gate{nullptr, 0.0}, resid + kEkfMaxSweeps, true);
+    sweep(Gate{resid + max_sweeps - 1, tol}, Gate{nullptr, 0.0}, resid + kEkfMaxSweeps, true);
   }
   hipLaunchKernelGGL(ekf_finish_kernel, dim3(K), dim3(64), 0, st, K, G.nc, max_sweeps, tol, ll_chunk,
                      resid, nll, info);
