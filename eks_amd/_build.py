@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libeks_hip.so')
-SOURCES = ['eks_api.hip', 'eks_diag.hip', 'eks_diag_nll.hip', 'eks_dense.hip', 'eks_dense_wave.hip', 'eks_dense_wide.hip', 'eks_loss.hip',
+SOURCES = ['eks_api.hip', 'eks_diag.hip', 'eks_diag_nll.hip', 'eks_lag_adam.hip', 'eks_dense.hip', 'eks_dense_wave.hip', 'eks_dense_wide.hip', 'eks_loss.hip',
            'eks_loss_ar1.hip', 'eks_misc.hip', 'eks_multicam.hip', 'eks_profile.hip', 'eks_host.hip']
 ARCH = 'gfx950'
 
@@ -49,7 +49,7 @@ def _stamp(obj: str) -> str:
 # are pure overhead (MI355X_MICROARCH.md: 'an anti-lever ... when the compiler SLP-packs').
 # Measured on the NLL kernel (C3): 0.268 -> 0.245 ms; on the smoother's K1 / K3 the packed forms cost 90 / 340 extra
 # VALU instructions per wave for nothing (step 0.609 -> 0.604 ms, same box, alternating runs).
-PER_FILE_FLAGS = {'eks_diag_nll.hip': ['-fno-slp-vectorize'], 'eks_diag.hip': ['-fno-slp-vectorize']}
+PER_FILE_FLAGS = {'eks_diag_nll.hip': ['-fno-slp-vectorize'], 'eks_lag_adam.hip': ['-fno-slp-vectorize'], 'eks_diag.hip': ['-fno-slp-vectorize']}
 
 
 def build(force: bool = False, verbose: bool = False, prove: bool = True) -> str:

@@ -228,6 +228,15 @@ int eks_adam_run(const eks_dims_t* d, const float* y, const double* rconst, cons
     }
     const bool in_kernel = n_blocks == K && diag_nll_grad_tree(d->n_frames, K, d->state_dim);
     const DiagModel M{m0, S0, A, C, Q, nullptr, d->state_dim};
+    if (diag_lag_adam_ok(d->n_frames, K, d->state_dim, n_blocks)) {
+      // one keypoint per optimiser block, a session long enough for a head and 256 lags: one streaming pass for the lag
+      // sums, then all n_iters iterations in ONE launch, a workgroup per keypoint, no pass over y per iteration
+      // (eks_lag_adam.hip, round 6); n_active counts the keypoints still running
+      const AdamFuse F{block_offsets, block_members, kp_block, lr, lo, hi, tol, safety_cap, 1, state, s_keypoint,
+                       n_active, counter_b};
+      rc = diag_lag_adam(*d, y, rconst, M, n_iters, nll, dnll, F, workspace, workspace_bytes, st);
+      if (rc != EKS_ERR_UNSUPPORTED) return rc;
+    }
     if (diag_nll_adam_persist_ok(d->n_frames, K, d->state_dim, n_blocks)) {
       // short sessions, one keypoint per optimiser block: all n_iters iterations in ONE launch, a workgroup per
       // keypoint (eks_diag_nll.hip: diag_nll_adam_persist_kernel); n_active counts the keypoints still running
@@ -271,6 +280,7 @@ int eks_adam_run(const eks_dims_t* d, const float* y, const double* rconst, cons
 int32_t eks_adam_run_stride(const eks_dims_t* d, int32_t n_blocks) {
   if (check_dims(d) != EKS_OK || n_blocks <= 0) return 4;
   if (!(d->flags & EKS_FLAG_DIAG_MODEL)) return 4;
+  if (diag_lag_adam_ok(d->n_frames, d->n_keypoints, d->state_dim, n_blocks)) return 4096;
   if (diag_nll_adam_persist_ok(d->n_frames, d->n_keypoints, d->state_dim, n_blocks)) return 64;
   if (diag_nll_adam_loop_ok(d->n_frames, d->n_keypoints, d->state_dim, n_blocks)) return 128;
   return 16;
@@ -369,6 +379,7 @@ int eks_warmup(uint32_t units, float* ms_per_unit) {
     if (ms_per_unit)
       ms_per_unit[i] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
+  if (units & EKS_WARM_DIAG_NLL) eks::touch_lag_adam();        // (the search's own unit rides on the NLL bit)
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? EKS_OK : EKS_ERR_HIP_BASE - (int)e;
 }

@@ -1816,8 +1816,14 @@ size_t diag_nll_workspace_bytes(int T, int N, int n_cand) {
   const size_t fl = align_up((size_t)ncn * ncp * N * sizeof(float), 256);
   const size_t db = align_up((size_t)ncn * ncp * N * sizeof(double), 256);
   // 10 element planes + the chunk references (one candidate's worth is used) + the Adam loop's
-  // keypoint -> block map and its second counter (eks_adam_run)
-  return 11 * fl + 2 * db + adam_extra_bytes(N);
+  // keypoint -> block map and its second counter (eks_adam_run); the search from cached lag sums (eks_lag_adam.hip)
+  // keeps its partial sums and chain-major copies in the same bytes
+  size_t main = 11 * fl + 2 * db;
+  if (n_cand == 1) {
+    const size_t lag = diag_lag_adam_workspace_bytes(T, N);
+    if (lag > main) main = lag;
+  }
+  return main + adam_extra_bytes(N);
 }
 
 // [keypoint -> block map : N ints][tile tickets : ceil(N / 64) ints][hand-off words : ceil(N / 64) x 64 x 2 x 8 B]

@@ -30,7 +30,7 @@ enum Knob {
   KNOB_SMOOTH_UNFUSED, KNOB_SUMMARIZE_REVERSE, KNOB_REPLAY_FORWARD, KNOB_REPLAY_RECOMPUTE, KNOB_SCAN_CH,
   KNOB_SMOOTH_TILE, KNOB_DENSE_CHUNK, KNOB_NLL_NCL, KNOB_NLL_CHUNK, KNOB_NLL_CHUNK0, KNOB_NLL_WPB,
   KNOB_NLL_EXACT_ENTRY, KNOB_NLL_ASSEMBLE_SEQ, KNOB_DENSE_LEGACY, KNOB_NLL_GRAD_UNFUSED, KNOB_NLL_GRAD_CHUNK,
-  KNOB_DENSE_TREE_SCAN, KNOB_DENSE_DUAL_GRAD, KNOB_NLL_LEGACY, KNOB_MED_ROWS, KNOB_NLL_ASM_WAVES, KNOB_DW_CHUNK, KNOB_ADAM_PER_ITERATION, KNOB_MED_FINISH_THREADS, KNOB_MED_BRACKET_THREADS, KNOB_NLL_NOLAG, KNOB_NLL_GRAD_TREE, KNOB_ADAM_LOOP_SPINS, KNOB_COUNT
+  KNOB_DENSE_TREE_SCAN, KNOB_DENSE_DUAL_GRAD, KNOB_NLL_LEGACY, KNOB_MED_ROWS, KNOB_NLL_ASM_WAVES, KNOB_DW_CHUNK, KNOB_ADAM_PER_ITERATION, KNOB_MED_FINISH_THREADS, KNOB_MED_BRACKET_THREADS, KNOB_NLL_NOLAG, KNOB_NLL_GRAD_TREE, KNOB_ADAM_LOOP_SPINS, KNOB_ADAM_STREAM, KNOB_ADAM_LAG_RHO_PPM, KNOB_COUNT
 };
 bool knob_set(Knob k);               // the variable exists
 int knob_int(Knob k, int dflt);      // its integer value, or dflt when unset
@@ -56,6 +56,7 @@ void touch_dense_wide();
 void touch_loss();
 void touch_loss_ar1();
 void touch_multicam();
+void touch_lag_adam();
 
 // per-kernel timing scope (eks_profile.hip); a no-op unless eks_profile_enable(1) was called
 class ProfScope {
@@ -87,6 +88,11 @@ int diag_nll_adam_persist(const eks_dims_t& d, const float* y, const double* rco
 int diag_nll_adam_loop(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M, int n_iters,
                        double* nll, double* dnll, const AdamFuse& F, void* ws, size_t ws_bytes, hipStream_t st);
 bool diag_nll_adam_loop_ok(int T, int K, int D, int n_blocks);   // would eks_adam_run take the in-launch loop?
+// the search from cached lag sums (eks_lag_adam.hip): one pre-pass + one launch per eks_adam_run call
+bool diag_lag_adam_ok(int T, int K, int D, int n_blocks);
+size_t diag_lag_adam_workspace_bytes(int T, int N);
+int diag_lag_adam(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M, int n_iters, double* nll,
+                  double* dnll, const AdamFuse& F, void* ws, size_t ws_bytes, hipStream_t st);
 size_t adam_extra_bytes(int N);     // tail of the NLL workspace: keypoint -> block map, tile tickets, counter
 int32_t* nll_ws_tickets(void* ws, int T, int N, int n_cand);   // the tile tickets inside that tail
 int adam_prepare(int n_blocks, int K, const int32_t* offs, const int32_t* members, int32_t* kp_block,

@@ -1,0 +1,617 @@
+// The Adam search on log s (reference eks/core.py:562-699: one optimiser per keypoint, loss = constant-R filter NLL of
+// eks/core.py:640-650) WITHOUT a pass over the observations per iteration (round 6).
+//
+// On a scalar chain (x' = a x + N(0, s q), y = c x + N(0, r), r constant) the innovation obeys
+//     e_{t+1} = rho_t e_t + u_{t+1},     rho_t = a r / S_t,     u_t = y_t - a y_{t-1},
+// and the inputs u do NOT depend on s or r.  The predicted variance is a Moebius iteration with fixed points
+// P_inf > 0 > P_-:  (P_t - P_inf) / (P_t - P_-) = kappa^t w_0,  kappa = S_- / S_inf = rho^2 - so S_t is known in closed
+// form for every t at once - and past the head the variance has converged, d_t = Dz_t + rho^(t - B0) e_B0 with Dz the
+// zero-start recursion on the inputs from frame F = B0 + 1 on, whose sum of squares is a polynomial in the pole:
+//     sum_t Dz_t^2 = [ c_0 + 2 sum_{k>=1} rho^k c_k - rho^2 Dz_{T-1}^2 ] / (1 - rho^2),    c_k = sum_{t >= F + k} u_t u_{t-k}.
+//
+//   L1 lag_sums_kernel    one streaming pass per search: block = (64-chain tile, time chunk), wave w = lags 32 w .. 32 w + 31
+//                         as packed float32 products of the current inputs with a register ring of the inputs 32 w frames
+//                         back (33 v_pk_fma_f32 per frame pair and wave), float64 sums in LDS every 64 frames.
+//   L2 lag_reduce_kernel  the chunks' partial sums -> c[chain][256] (float64, lags >= 1 doubled).
+//   L3 lag_adam_kernel    block = KEYPOINT, wave = chain, the whole search in one launch with no exchange between
+//                         blocks: per iteration the head [0, B0) exactly and time-parallel (closed-form variances, a
+//                         64-lane DPP scan of the affine maps e -> rho e + u, four frames per lane), the rest from the
+//                         256 lag sums and the first / last 256 inputs, everything in float64 dual numbers
+//                         (d / d log s), then the optimiser step in registers.  A chain whose pole leaves the range the
+//                         lag sums cover (|rho|^256 <= 1e-10 (1 - |rho|): |rho| <= 0.906) is evaluated EXACTLY instead, by
+//                         streaming its own frames from a private chain-major copy (lane = time chunk, same scan):
+//                         slower (~30 us per iteration at T = 100 000), never wrong.
+// tools/lag_adam_proto.py is the NumPy statement of the same identities (CPU tests: tests/test_lag_identity.py).
+#include <hip/hip_runtime.h>
+
+#include "eks_adam.hpp"
+#include "eks_internal.hpp"
+#include "eks_nll_lane.hpp"
+
+namespace eks {
+
+constexpr int kLaB0 = 256;             // frames of the head: exact, time-parallel (64 lanes x 4 frames)
+constexpr int kLaF = kLaB0 + 1;        // first frame whose input enters the lag sums
+constexpr int kLaL = 256;              // lag sums c_0 .. c_255
+constexpr int kLaWaves = kLaL / 32;    // waves of a pre-pass block
+constexpr int kLaMinT = 1024;          // (shorter sessions: diag_nll_adam_persist_kernel)
+constexpr int kLaMaxD = 4;
+static_assert(kLaB0 == kLaL, "the delayed rings of the pre-pass reach back L + 1 frames from F: B0 >= L keeps them inside the array");
+
+// |rho| up to which 256 lag sums give the polynomial to 2e-10 (1 - |rho|)^-1 of itself WHATEVER the data (all lag sums
+// are bounded by c_0): |rho|^256 <= 1e-10 (1 - |rho|)
+static double lag_adam_rho_max() {
+  double lo = 0.0, hi = 0.999;
+  for (int it = 0; it < 60; ++it) {
+    const double m = 0.5 * (lo + hi);
+    if (pow(m, (double)kLaL) <= 1e-10 * (1.0 - m)) lo = m; else hi = m;
+  }
+  return lo;
+}
+
+// ---- rows through a buffer resource based `base_row` rows into the array (scalar row offsets: no VALU address
+// arithmetic); frames past the end read the last row again (their inputs are masked)
+struct LagRows {
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned voff, row_bytes;
+  int base_row, last_row;
+  __device__ __forceinline__ float operator()(int t) const {       // t: frame index (wave-uniform)
+    const int tc = t < last_row ? t : last_row;
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (unsigned)(tc - base_row) * row_bytes, 0));
+  }
+};
+
+struct LagPre {
+  int T, N, D, ntile, nch, CL;         // chunk j: frames [F + j CL, F + (j + 1) CL), CL a multiple of 64
+  const float* y;
+  const double* A;                     // [K][D][D]
+  double* part;                        // [nch][kLaL][N]
+  const double* state;                 // optimiser state: a tile none of whose keypoints still runs is skipped
+  const int32_t* kp_block;
+  int cap;
+};
+
+// One wave: lags 32 w .. 32 w + 31 of one (tile, chunk).  `acc`: this wave's [32][64] float64 sums in LDS, at the lane.
+template <bool UNIT, bool W0>
+__device__ __forceinline__ void lag_wave_body(const LagPre& P, const LagRows& ld, int ts0, int nss, int w, double a_d,
+                                              double* acc) {
+  const int delay = W0 ? 0 : 32 * w;
+  const int T = P.T;
+  auto input = [&](float yy, float yp) { return UNIT ? (yy - yp) : (float)((double)yy - a_d * (double)yp); };
+  f32x2 E[16], O[17], ring[32];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) E[i] = f32x2{0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 17; ++i) O[i] = f32x2{0.f, 0.f};
+  // ---- history: the 16 input pairs in front of the delayed stream's first frame (zero before frame F)
+  const int td0 = ts0 - delay;
+  float yd_prev, yc_prev;
+  {
+    float h[33];
+#pragma unroll
+    for (int i = 0; i < 33; ++i) h[i] = ld(td0 - 33 + i);
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int tA = td0 - 32 + 2 * p;
+      const float mA = tA >= kLaF ? 1.f : 0.f, mB = tA + 1 >= kLaF ? 1.f : 0.f;
+      ring[16 + p] = f32x2{input(h[2 * p + 1], h[2 * p]) * mA, input(h[2 * p + 2], h[2 * p + 1]) * mB};
+    }
+    yd_prev = h[32];
+    yc_prev = W0 ? h[32] : ld(ts0 - 1);
+  }
+  // rows: ONE set of 16 frames per stream, every register asked for again (the same frame of the next 16) as soon as
+  // it has been consumed - 16 frames (264 packed FMAs) of distance between a request and its use
+  float rc[16], rd[16];
+  auto half = [&](auto h_tag, auto edge_tag, int t) {
+    constexpr int H = decltype(h_tag)::value;
+    constexpr bool EDGE = decltype(edge_tag)::value != 0;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const int Pp = 8 * H + a;
+      const float y0 = rc[2 * a], y1 = rc[2 * a + 1];
+      rc[2 * a] = ld(t + 16 + 2 * a);
+      rc[2 * a + 1] = ld(t + 16 + 2 * a + 1);
+      f32x2 Xc = f32x2{input(y0, yc_prev), input(y1, y0)};
+      yc_prev = y1;
+      if constexpr (EDGE) {
+        const int tt = t + 2 * a;
+        Xc = Xc * f32x2{tt < T ? 1.f : 0.f, tt + 1 < T ? 1.f : 0.f};
+      }
+      if constexpr (W0) {
+        ring[Pp] = Xc;
+      } else {
+        const float z0 = rd[2 * a], z1 = rd[2 * a + 1];
+        rd[2 * a] = ld(t - delay + 16 + 2 * a);
+        rd[2 * a + 1] = ld(t - delay + 16 + 2 * a + 1);
+        f32x2 Xd = f32x2{input(z0, yd_prev), input(z1, z0)};
+        yd_prev = z1;
+        if constexpr (EDGE) {
+          const int tt = t - delay + 2 * a;
+          Xd = Xd * f32x2{tt >= kLaF ? 1.f : 0.f, tt + 1 >= kLaF ? 1.f : 0.f};
+        }
+        ring[Pp] = Xd;
+      }
+#pragma unroll
+      for (int dl = 0; dl < 16; ++dl) E[dl] = Xc * ring[(Pp - dl) & 31] + E[dl];
+#pragma unroll
+      for (int dl = 0; dl < 17; ++dl) {
+        const f32x2 xb = ring[(Pp - dl) & 31];
+        O[dl] = Xc * f32x2{xb[1], xb[0]} + O[dl];
+      }
+      EKS_SCHED_FENCE();
+    }
+  };
+  auto super_set = [&](auto edge_tag, int ts) {
+    half(IntTag<0>(), edge_tag, ts);
+    half(IntTag<1>(), edge_tag, ts + 16);
+    half(IntTag<2>(), edge_tag, ts + 32);
+    half(IntTag<3>(), edge_tag, ts + 48);
+    // float32 partial sums span 64 frames: into the float64 sums
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      acc[(2 * jj) * 64] += (double)(E[jj][0] + E[jj][1]);
+      acc[(2 * jj + 1) * 64] += (double)(O[jj][1] + O[jj + 1][0]);
+      E[jj] = f32x2{0.f, 0.f};
+    }
+#pragma unroll
+    for (int jj = 0; jj < 17; ++jj) O[jj] = f32x2{0.f, 0.f};
+  };
+#pragma unroll
+  for (int q = 0; q < 16; ++q) rc[q] = ld(ts0 + q);
+  if constexpr (!W0) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) rd[q] = ld(td0 + q);
+  }
+  for (int ss = 0; ss < nss; ++ss) {
+    const int ts = ts0 + 64 * ss;
+    const bool edge = ts - delay - 32 < kLaF || ts + 64 > T;          // (wave-uniform)
+    if (edge) super_set(IntTag<1>(), ts); else super_set(IntTag<0>(), ts);
+  }
+}
+
+template <bool UNIT>
+__global__ __launch_bounds__(64 * kLaWaves) void lag_sums_kernel(LagPre P) {
+  __shared__ double acc_all[kLaWaves * 32 * 64];
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int tile = blockIdx.x % P.ntile, j = blockIdx.x / P.ntile;
+  const int n_raw = tile * 64 + lane;
+  const int n = n_raw < P.N ? n_raw : P.N - 1;
+  const int k = n / P.D, d = n - k * P.D;
+  if (P.state != nullptr) {
+    const bool running = n_raw < P.N && adam_block_running(P.state, P.kp_block[k], P.cap);
+    if (!__any(running)) return;                      // (the same answer in every wave of the tile's blocks)
+  }
+  const double a_d = P.A[(size_t)k * P.D * P.D + (size_t)d * (P.D + 1)];
+  const int ts0 = kLaF + j * P.CL;
+  const int len = min(P.CL, P.T - ts0);
+  const int nss = (len + 63) / 64;
+  // the resource starts 257 rows in front of the chunk (the deepest ring's history)
+  const int base_row = ts0 - (kLaL + 1);
+  const LagRows ld{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.y + (size_t)base_row * P.N + (size_t)tile * 64), 0,
+                                                     0x7FFFFFFF, 0x00020000),
+                   (unsigned)((n - tile * 64) * 4), (unsigned)(P.N * 4), base_row, P.T - 1};
+  double* acc = acc_all + (size_t)w * 32 * 64 + lane;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i * 64] = 0.0;
+  if (w == 0) lag_wave_body<UNIT, true>(P, ld, ts0, nss, 0, a_d, acc);
+  else lag_wave_body<UNIT, false>(P, ld, ts0, nss, w, a_d, acc);
+  if (n_raw < P.N) {
+#pragma unroll 4
+    for (int i = 0; i < 32; ++i) P.part[((size_t)j * kLaL + w * 32 + i) * P.N + n] = acc[i * 64];
+  }
+}
+
+__global__ void lag_reduce_kernel(int N, int nch, const double* __restrict__ part, double* __restrict__ ck) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)N * kLaL) return;
+  const int lag = (int)(idx / N), n = (int)(idx - (long)lag * N);
+  double s = 0.0;
+  for (int j = 0; j < nch; ++j) s += part[((size_t)j * kLaL + lag) * N + n];
+  ck[(size_t)n * kLaL + lag] = lag ? 2.0 * s : s;
+}
+
+// ---- cross-lane pieces of the search kernel (DPP: row shifts inside rows of 16, row broadcasts across them) ----------
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double la_dpp(double old, double x) {
+  return __builtin_amdgcn_update_dpp(old, x, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ double la_readlane(double x, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+  return __hiloint2double(hi, lo);
+}
+// sum / product over the 64 lanes, the same value in every lane
+__device__ __forceinline__ double la_wave_sum(double x) {
+  x += la_dpp<0x111>(0.0, x);
+  x += la_dpp<0x112>(0.0, x);
+  x += la_dpp<0x114>(0.0, x);
+  x += la_dpp<0x118>(0.0, x);
+  x += la_dpp<0x142, 0xa>(0.0, x);        // row_bcast:15 into rows 1, 3
+  x += la_dpp<0x143, 0xc>(0.0, x);        // row_bcast:31 into rows 2, 3
+  return la_readlane(x, 63);
+}
+__device__ __forceinline__ double la_wave_prod(double x) {
+  x *= la_dpp<0x111>(1.0, x);
+  x *= la_dpp<0x112>(1.0, x);
+  x *= la_dpp<0x114>(1.0, x);
+  x *= la_dpp<0x118>(1.0, x);
+  x *= la_dpp<0x142, 0xa>(1.0, x);
+  x *= la_dpp<0x143, 0xc>(1.0, x);
+  return la_readlane(x, 63);
+}
+// e_out = A e_in + b with d / d log s riding along
+struct LaAff {
+  DualD A, b;
+};
+__device__ __forceinline__ LaAff la_then(const LaAff& first, const LaAff& second) {
+  return LaAff{second.A * first.A, second.A * first.b + second.b};
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ void la_scan_step(LaAff& x) {
+  LaAff e;
+  e.A.v = la_dpp<CTRL, ROW_MASK>(1.0, x.A.v);
+  e.A.d = la_dpp<CTRL, ROW_MASK>(0.0, x.A.d);
+  e.b.v = la_dpp<CTRL, ROW_MASK>(0.0, x.b.v);
+  e.b.d = la_dpp<CTRL, ROW_MASK>(0.0, x.b.d);
+  x = la_then(e, x);
+}
+// inclusive scan in lane order: afterwards lane i maps the innovation entering lane 0 to the one leaving lane i
+__device__ __forceinline__ void la_scan(LaAff& x) {
+  la_scan_step<0x111>(x);
+  la_scan_step<0x112>(x);
+  la_scan_step<0x114>(x);
+  la_scan_step<0x118>(x);
+  la_scan_step<0x142, 0xa>(x);
+  la_scan_step<0x143, 0xc>(x);
+}
+// x^e for a per-lane whole exponent below 2^NBITS
+template <int NBITS>
+__device__ __forceinline__ double la_pow_bits(double x, unsigned e) {
+  double r = 1.0, b = x;
+#pragma unroll
+  for (int i = 0; i < NBITS; ++i) {
+    r = (e >> i) & 1u ? r * b : r;
+    b *= b;
+  }
+  return r;
+}
+
+// steady-state constants of one chain at one s, with d / d log s
+struct LaConst {
+  double a, c, r, c2, P0;
+  DualD Sinf, g, rho, dS;      // dS = S_inf - S_-
+  double dlr;                  // d log rho / d log s = -g dS_inf
+  double kap, w0, dw0;         // kappa = S_- / S_inf, d log kappa = 2 dlr
+};
+__device__ __forceinline__ LaConst la_const(double a, double c, double q, double r, double P0, double s) {
+  LaConst K;
+  K.a = a; K.c = c; K.r = r; K.c2 = c * c; K.P0 = P0;
+  const double sq = s * q;
+  double Pinf, dPinf;
+  riccati_fixed_point(a, c, r, sq, Pinf, dPinf);
+  K.Sinf = DualD(r + K.c2 * Pinf, K.c2 * dPinf);
+  K.g = rcp(K.Sinf);
+  K.dlr = -K.g.v * K.Sinf.d;
+  K.rho = DualD(a * r * K.g.v, a * r * K.g.d);
+  const DualD Sm = DualD(a * r * K.rho.v, a * r * K.rho.d);
+  K.dS = K.Sinf - Sm;
+  K.kap = Sm.v * K.g.v;
+  const double Pm = (Sm.v - r) / K.c2, dPm = Sm.d / K.c2;
+  const double den = P0 - Pm, iden = 1.0 / den;
+  K.w0 = (P0 - Pinf) * iden;
+  K.dw0 = (-dPinf * den + (P0 - Pinf) * dPm) * iden * iden;
+  return K;
+}
+// innovation variance of frame t, its reciprocal and the frame's pole (w_t = w_0 kappa^t given as kt = kappa^t)
+__device__ __forceinline__ void la_frame(const LaConst& K, int t, double kt, DualD& St, DualD& gt, DualD& rt) {
+  const double dkt = (double)t * kt * 2.0 * K.dlr;
+  const DualD w(K.w0 * kt, K.dw0 * kt + K.w0 * dkt);
+  const double iom = 1.0 / (1.0 - w.v);
+  const DualD ratio(w.v * iom, w.d * iom * iom);
+  St = K.Sinf + K.dS * ratio;
+  if (t == 0) St = DualD(K.c2 * K.P0 + K.r, 0.0);
+  gt = rcp(St);
+  rt = DualD(K.a * K.r * gt.v, K.a * K.r * gt.d);
+}
+
+struct LagAdam {
+  int T, N, D;
+  const float* y;
+  const double* rconst;
+  const double *m0, *S0, *A, *C, *Q;
+  const double* ck;            // [N][kLaL]
+  float* yT;                   // [N][T] chain-major copies, made by a chain's wave the first time it needs one
+  const int32_t* kp_block;
+  double lr, lo, hi, tol;
+  int cap, n_iters;
+  double rho_max;
+  double *state, *s_keypoint, *nll, *dnll;
+  int32_t* n_active;
+};
+
+// what a chain's wave keeps in registers for the whole search (lane j: frames and lags 4 j .. 4 j + 3)
+struct LaLane {
+  double un[4];                // u_{t+1}: the input that follows frame t of the head
+  double c2k[4];               // lag sums (c_0, 2 c_k)
+  double uF[4], ut[4];         // first / last inputs of the lag region: u_{F+k}, u_{T-1-k}
+  double e0;                   // innovation of frame 0: y_0 - c m_0
+};
+
+// the chain's NLL and d / d log s from the lag sums (|rho| <= rho_max)
+__device__ __forceinline__ DualD la_nll_fast(const LaConst& K, const LaLane& L, int T, int lane) {
+  // ---- head: frames 4 lane .. 4 lane + 3
+  const double kap2 = K.kap * K.kap;
+  const double kbase = la_pow_bits<6>(kap2 * kap2, (unsigned)lane);
+  const double kf[4] = {kbase, kbase * K.kap, kbase * kap2, kbase * kap2 * K.kap};
+  DualD gt[4], rt[4];
+  LaAff el{DualD(1.0), DualD(0.0)};
+  double pprod = 1.0, dlog = 0.0;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    DualD St;
+    la_frame(K, 4 * lane + f, kf[f], St, gt[f], rt[f]);
+    pprod *= St.v * K.g.v;
+    dlog += St.d * gt[f].v;
+    el = la_then(el, LaAff{rt[f], DualD(L.un[f])});
+  }
+  la_scan(el);
+  const DualD e_first(L.e0);
+  const DualD e_out = el.A * e_first + el.b;
+  DualD e(__shfl_up(e_out.v, 1), __shfl_up(e_out.d, 1));
+  if (lane == 0) e = e_first;
+  DualD quad(0.0);
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    quad = quad + gt[f] * e * e;
+    e = rt[f] * e + DualD(L.un[f]);
+  }
+  const DualD E(la_readlane(e_out.v, 63), la_readlane(e_out.d, 63));     // innovation of frame B0
+  // ---- lags 4 lane .. 4 lane + 3
+  const double rho = K.rho.v, rho2 = rho * rho;
+  const double pbase = la_pow_bits<6>(rho2 * rho2, (unsigned)lane);
+  const double pf[4] = {pbase, pbase * rho, pbase * rho2, pbase * rho2 * rho};
+  double sp = 0.0, spk = 0.0, sz = 0.0, szk = 0.0, sd = 0.0, sdk = 0.0;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const double kk = (double)(4 * lane + f) * pf[f];
+    sp += pf[f] * L.c2k[f];  spk += kk * L.c2k[f];
+    sz += pf[f] * L.uF[f];   szk += kk * L.uF[f];
+    sd += pf[f] * L.ut[f];   sdk += kk * L.ut[f];
+  }
+  // ---- the wave's sums
+  const double q_v = la_wave_sum(quad.v), q_d = la_wave_sum(quad.d);
+  const double dl_sum = la_wave_sum(dlog), pp = la_wave_prod(pprod);
+  const DualD poly(la_wave_sum(sp), la_wave_sum(spk) * K.dlr);
+  const DualD Z(la_wave_sum(sz), la_wave_sum(szk) * K.dlr);
+  const DualD Dl(la_wave_sum(sd), la_wave_sum(sdk) * K.dlr);
+  // ---- assembly
+  const DualD one(1.0), two(2.0);
+  const DualD iom = rcp(one - K.rho * K.rho);
+  const DualD SS = (poly - K.rho * K.rho * Dl * Dl) * iom;
+  const DualD X1 = K.rho * Z * iom;
+  const DualD tot = SS + two * E * X1 + E * E * iom;          // (rho^(2 (T - B0)) is below 1e-60 in this range)
+  const DualD gq = K.g * tot;
+  const double n = (double)(T - kLaB0);
+  const double logS = log(K.Sinf.v);
+  const double v = 0.5 * ((double)T * kLog2Pi + (double)kLaB0 * logS + log(pp) + q_v + n * logS + gq.v);
+  const double dv = 0.5 * (dl_sum + q_d + n * K.Sinf.d * K.g.v + gq.d);
+  return DualD(v, dv);
+}
+
+// the chain's NLL and d / d log s by streaming its own frames (any pole): lane = time chunk of the chain-major copy
+__device__ __forceinline__ DualD la_nll_stream(const LaConst& K, const float* __restrict__ yc, int T, double e0, int lane) {
+  const int cl = (T + 63) / 64;
+  const int t0 = lane * cl, t1 = min(T, t0 + cl);
+  // kappa^t0 by squaring
+  double kt = 1.0;
+  {
+    double b = K.kap;
+    for (unsigned e = (unsigned)t0; e; e >>= 1) {
+      if (e & 1u) kt *= b;
+      b *= b;
+    }
+  }
+  DualD al(1.0), be(0.0), Qaa(0.0), Qab(0.0), Qbb(0.0);
+  double pprod = 1.0, dlog = 0.0;
+  constexpr int NB = 8;
+  float buf[NB + 1];
+  auto fetch = [&](int t) {                                   // rows t .. t + NB (clamped)
+#pragma unroll
+    for (int q = 0; q <= NB; ++q) buf[q] = yc[min(t + q, T - 1)];
+  };
+  for (int t = t0; t < t1; t += NB) {
+    fetch(t);
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int tt = t + q;
+      if (tt < t1) {
+        DualD St, gt, rt;
+        la_frame(K, tt, kt, St, gt, rt);
+        kt *= K.kap;
+        pprod *= St.v * K.g.v;
+        dlog += St.d * gt.v;
+        Qaa = Qaa + gt * al * al;
+        Qab = Qab + gt * al * be;
+        Qbb = Qbb + gt * be * be;
+        const double u = tt + 1 < T ? (double)buf[q + 1] - K.a * (double)buf[q] : 0.0;
+        al = rt * al;
+        be = rt * be + DualD(u);
+        if (fabs(al.v) < 1e-80) al = DualD(0.0);
+      }
+    }
+  }
+  LaAff el{al, be};
+  la_scan(el);
+  const DualD e_first(e0);
+  const DualD e_out = el.A * e_first + el.b;
+  DualD e(__shfl_up(e_out.v, 1), __shfl_up(e_out.d, 1));
+  if (lane == 0) e = e_first;
+  DualD contrib = Qaa * e * e + DualD(2.0) * Qab * e + Qbb;
+  if (t0 >= T) contrib = DualD(0.0);
+  const double q_v = la_wave_sum(contrib.v), q_d = la_wave_sum(contrib.d);
+  const double dl_sum = la_wave_sum(dlog), pp = la_wave_prod(pprod);
+  const double v = 0.5 * ((double)T * (kLog2Pi + log(K.Sinf.v)) + log(pp) + q_v);
+  return DualD(v, 0.5 * (dl_sum + q_d));
+}
+
+__global__ __launch_bounds__(64 * kLaMaxD) void lag_adam_kernel(LagAdam P) {
+  __shared__ double xch[2][kLaMaxD][2];
+  const int lane = threadIdx.x, d = threadIdx.y, D = P.D;
+  const int k = blockIdx.x;
+  const int kb = P.kp_block[k];
+  const int T = P.T, N = P.N;
+  double* st = P.state + (size_t)kb * kAdamState;
+  double u = st[0], mom = st[1], vel = st[2], prev = st[3], iters = st[4], done = st[5];
+  if (!(done == 0.0 && iters < (double)P.cap)) return;          // block-uniform
+  const int n = k * D + d;
+  const size_t dd = (size_t)k * D * D + (size_t)d * (D + 1);
+  const double a = P.A[dd], c = P.C[dd], q = P.Q[dd], r = P.rconst[n], P0 = P.S0[dd], m0 = P.m0[(size_t)k * D + d];
+  // ---- what does not change between iterations
+  LaLane L;
+  {
+    const float* yn = P.y + n;
+    float h[5];
+#pragma unroll
+    for (int f = 0; f < 5; ++f) h[f] = yn[(size_t)(4 * lane + f) * N];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) L.un[f] = (double)h[f + 1] - a * (double)h[f];
+    L.e0 = (double)yn[0] - c * m0;
+    const double* ckn = P.ck + (size_t)n * kLaL + 4 * lane;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) L.c2k[f] = ckn[f];
+    float hf[5], ht[5];
+#pragma unroll
+    for (int f = 0; f < 5; ++f) {
+      hf[f] = yn[(size_t)min(kLaF - 1 + 4 * lane + f, T - 1) * N];           // rows F - 1 + 4 lane ..
+      ht[f] = yn[(size_t)max(T - 1 - 4 * lane - f, 0) * N];                   // rows T - 1 - 4 lane, downwards
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int tF = kLaF + 4 * lane + f, tt = T - 1 - 4 * lane - f;
+      L.uF[f] = tF < T ? (double)hf[f + 1] - a * (double)hf[f] : 0.0;
+      L.ut[f] = tt >= kLaF ? (double)ht[f] - a * (double)ht[f + 1] : 0.0;
+    }
+  }
+  bool have_copy = false;
+  float* yc = P.yT + (size_t)n * T;
+  for (int it = 0; it < P.n_iters; ++it) {
+    const double s = exp(fmin(fmax(u, P.lo), P.hi));
+    const LaConst K = la_const(a, c, q, r, P0, s);
+    DualD v;
+    if (fabs(K.rho.v) <= P.rho_max) {                            // (wave-uniform: one chain per wave)
+      v = la_nll_fast(K, L, T, lane);
+    } else {
+      if (!have_copy) {
+        for (int t = lane; t < T; t += 64) yc[t] = P.y[(size_t)t * N + n];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        have_copy = true;
+      }
+      v = la_nll_stream(K, yc, T, L.e0, lane);
+    }
+    if (lane == 0) {
+      xch[it & 1][d][0] = v.v;
+      xch[it & 1][d][1] = v.d;
+    }
+    __syncthreads();
+    double Lv = 0.0, g = 0.0;
+    for (int dq = 0; dq < D; ++dq) {
+      Lv += xch[it & 1][dq][0];
+      g += xch[it & 1][dq][1];
+    }
+    // eks/core.py:650: a non-finite loss is 1e12 with zero gradient; then the step and the stop rule of :652-681
+    const bool fin = isfinite(Lv);
+    Lv = fin ? Lv : 1e12;
+    g = fin ? g : 0.0;
+    const double g_raw = g;
+    if (u < P.lo || u > P.hi) g = 0.0;
+    g *= P.lr;
+    const double cnt = iters + 1.0;
+    mom = 0.9 * mom + 0.1 * g;
+    vel = 0.999 * vel + 0.001 * g * g;
+    const double mhat = mom / (1.0 - adam_pow_count(0.9, cnt));
+    const double vhat = vel / (1.0 - adam_pow_count(0.999, cnt));
+    u = u - mhat / (sqrt(vhat) + 1e-8);
+    const bool stop = isfinite(prev) && fabs(Lv - prev) < P.tol * fabs(log(fmax(prev, 1e-12))) + 1e-6;
+    prev = Lv;
+    iters = cnt;
+    done = stop ? 1.0 : 0.0;
+    if (lane == 0 && d == 0) {
+      P.nll[k] = Lv;
+      P.dnll[k] = g_raw;
+    }
+    if (stop || !(iters < (double)P.cap)) break;
+  }
+  if (lane == 0 && d == 0) {
+    st[0] = u; st[1] = mom; st[2] = vel; st[3] = prev; st[4] = iters; st[5] = done;
+    P.s_keypoint[k] = exp(fmin(fmax(u, P.lo), P.hi));
+    if (done == 0.0 && iters < (double)P.cap) atomicAdd(P.n_active, 1);
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+bool diag_lag_adam_ok(int T, int K, int D, int n_blocks) {
+  return n_blocks == K && T >= kLaMinT && D >= 1 && D <= kLaMaxD && !knob_int(KNOB_ADAM_STREAM, 0);
+}
+
+static void lag_geometry(int T, int N, int* nch_out, int* cl_out) {
+  const long ntile = (N + 63) / 64;
+  const long frames = T - kLaF;
+  long nch = (512 + ntile - 1) / ntile;                // ~two blocks per compute unit
+  if (nch > (frames + 63) / 64) nch = (frames + 63) / 64;
+  if (nch < 1) nch = 1;
+  long cl = ((frames + nch - 1) / nch + 63) / 64 * 64;
+  nch = (frames + cl - 1) / cl;
+  *nch_out = (int)nch;
+  *cl_out = (int)cl;
+}
+
+// [part : nch x 256 x N doubles][ck : N x 256 doubles][yT : N x T floats]
+size_t diag_lag_adam_workspace_bytes(int T, int N) {
+  if (T < kLaMinT) return 0;
+  int nch, cl;
+  lag_geometry(T, N, &nch, &cl);
+  return align_up((size_t)nch * kLaL * N * sizeof(double), 256) + align_up((size_t)N * kLaL * sizeof(double), 256) +
+         align_up((size_t)N * T * sizeof(float), 256);
+}
+
+int diag_lag_adam(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M, int n_iters, double* nll,
+                  double* dnll, const AdamFuse& F, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int T = d.n_frames, D = d.state_dim, K = d.n_keypoints, N = K * D;
+  if (ws_bytes < diag_lag_adam_workspace_bytes(T, N)) return EKS_ERR_WORKSPACE;
+  int nch, cl;
+  lag_geometry(T, N, &nch, &cl);
+  if ((long)(cl + kLaL + 64 + 64) * N * 4 >= (1L << 31)) return EKS_ERR_UNSUPPORTED;   // 32-bit row offsets of a chunk
+  char* p = static_cast<char*>(ws);
+  double* part = reinterpret_cast<double*>(p);
+  p += align_up((size_t)nch * kLaL * N * sizeof(double), 256);
+  double* ck = reinterpret_cast<double*>(p);
+  p += align_up((size_t)N * kLaL * sizeof(double), 256);
+  float* yT = reinterpret_cast<float*>(p);
+  const int ntile = (N + 63) / 64;
+  {
+    ProfScope ps("lag_sums", st);
+    const LagPre P{T, N, D, ntile, nch, cl, y, M.A, part, F.state, F.kp_block, F.cap};
+    const dim3 grid((unsigned)(ntile * nch)), block(64 * kLaWaves);
+    if (d.flags & EKS_FLAG_UNIT_AC) hipLaunchKernelGGL(lag_sums_kernel<true>, grid, block, 0, st, P);
+    else hipLaunchKernelGGL(lag_sums_kernel<false>, grid, block, 0, st, P);
+  }
+  {
+    ProfScope ps("lag_reduce", st);
+    const long lanes = (long)N * kLaL;
+    hipLaunchKernelGGL(lag_reduce_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, N, nch, part, ck);
+  }
+  {
+    ProfScope ps("lag_adam", st);
+    static const double rho_max = lag_adam_rho_max();
+    const int rm = knob_int(KNOB_ADAM_LAG_RHO_PPM, -1);          // (tests: the pole beyond which a chain streams)
+    const LagAdam P{T, N, D, y, rconst, M.m0, M.S0, M.A, M.C, M.Q, ck, yT, F.kp_block, F.lr, F.lo, F.hi, F.tol, F.cap,
+                    n_iters, rm >= 0 ? 1e-6 * rm : rho_max, F.state, F.s_keypoint, nll, dnll, F.n_active_cur};
+    hipLaunchKernelGGL(lag_adam_kernel, dim3((unsigned)K), dim3(64, D), 0, st, P);
+  }
+  return hip_status(hipGetLastError());
+}
+
+}  // namespace eks
+
+EKS_DEFINE_TOUCH(lag_adam)
