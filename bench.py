@@ -58,6 +58,7 @@ WORKLOADS = {
 SMOOTH_BYTES_PER_UNIT = 40       # y 8 + var 8 in, ms 8 + Vs 16 out  
 NLL_BYTES_PER_UNIT = 8           # y read once regardless of candidate count
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 vector peak (packed FMAs)
 PARITY_BAR = 1e-5                # BASELINE.json: smoothed means / covariances (and the NLL table) within 1e-5 relative
 
 
@@ -80,6 +81,9 @@ def parse():
     p.add_argument('--regions', type=int, default=5,
                    help='how many back-to-back timed regions of --steps steps each; ms_per_step / value are the '
                         'MEDIAN region (max over ranks per region), min / max are reported beside it')
+    p.add_argument('--no-extras', action='store_true',
+                   help='headline line only: skip the short legs of the other BASELINE configurations that the default '
+                        'single-GPU run reports under `extras`')
     p.add_argument('--master-port', type=int, default=0,
                    help='self-launch (N > 1 without an outer torchrun): rendezvous port, 0 = pick a free one')
     return p.parse_args()
@@ -355,7 +359,7 @@ def bench_c3adam(args, T, K, dev, lib, ranks_info):
     """BASELINE configs[2]'s session in the reference's DEFAULT mode (smooth_param=None): one step = the whole
     run_kalman_smoother call on device tensors - initial guesses (eks/core.py:233-236), eks_const_r, the Adam
     search on log s per keypoint (eks/core.py:562-699: every iteration is ONE launch of
-    diag_nll_grad_fused_kernel - value, forward-mode gradient and the optimiser step), then the final fixed-s
+    lag_adam_kernel after one pass for the lag sums - eks_amd/csrc/eks_lag_adam.hip), then the final fixed-s
     smooth with the full ms / Vs contract.  Fresh optimiser state every step."""
     import torch
     from eks_amd import hip_ops, synth
@@ -412,32 +416,26 @@ def bench_c3adam(args, T, K, dev, lib, ranks_info):
                                           'calls_enqueued': int(last['info'].get('calls', 0)),
                                           'all_stopped_by_rule': bool(np.all(st[:, 5] == 1.0))}},
            'ranks': ranks_info}
-    if prof.get('diag_nll_grad_fused'):
-        d = np.array(prof['diag_nll_grad_fused'])                     # ms per launch, in launch order
-        # a 64-chain tile (32 keypoints) is read by a launch while any of its keypoints still runs
-        tile_iters = [int(iters[t0:t0 + 32].max()) for t0 in range(0, K, 32)]
-        algo = float(sum(tile_iters)) * T * 64 * 4                    # bytes of y the search has to read
-        in_launch_loop = len(d) < int(iters.max())                    # one launch per eks_adam_run CALL (round 5)
-        live = d[d > 0.2] if in_launch_loop else d[:int(iters.max())]   # (a call issued after the last stop: ~0.04 ms)
-        ach = algo / (float(live.sum()) * 1e-3) / 1e9
-        other = {k: float(np.sum(v)) for k, v in prof.items() if k != 'diag_nll_grad_fused'}
+    if prof.get('lag_sums'):
+        # round 6: the search is one streaming pass for 256 lag sums per chain (the step's longest kernel), a reduction
+        # of the chunks' partial sums, and ONE launch of a workgroup per keypoint that reads no frame per iteration
+        sums_ms, adam_ms = float(np.sum(prof['lag_sums'])), float(np.sum(prof.get('lag_adam', [0.0])))
+        flops = 2.0 * 256 * T * 2 * K                                 # one FMA per lag, chain and frame
+        other = {k: float(np.sum(v)) for k, v in prof.items() if k not in ('lag_sums', 'lag_adam')}
         out['roofline'] = {
-            'bound': 'hbm', 'kernel': 'diag_nll_grad_fused_kernel', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS,
-            'achieved': ach, 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
-            'algorithmic_bytes_per_launch': T * 2 * K * 4,
-            'algorithmic_bytes_per_search': algo,
-            'kernel_avg_ms': float(live.sum()) / float(iters.max()) if in_launch_loop else float(live.mean()),
-            'kernel_avg_ms_is': ('the live launches\' time / the longest keypoint\'s iterations (the launch loops inside)'
-                                 if in_launch_loop else 'per launch = per iteration'),
-            'kernel_first_launch_ms': float(d[0]),
-            'kernel_last_live_launch_ms': float(live[-1]), 'launches_timed': int(len(d)),
-            'launches_live': int(len(live)), 'search_kernel_ms': float(live.sum()),
+            'bound': 'valu', 'kernel': 'lag_sums_kernel', 'unit': 'TFLOP/s', 'peak': FP32_VECTOR_PEAK_TFLOPS,
+            'achieved': flops / (sums_ms * 1e-3) / 1e12, 'frac': flops / (sums_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+            'traffic': None, 'kernel_avg_ms': sums_ms,
+            'algorithmic_flops_per_launch': flops, 'algorithmic_bytes_per_launch': T * 2 * K * 4,
+            'hbm_view': {'achieved_GBps': T * 2 * K * 4 / (sums_ms * 1e-3) / 1e9,
+                         'frac': T * 2 * K * 4 / (sums_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            'search_kernel': 'lag_adam_kernel', 'search_kernel_ms': adam_ms,
+            'search_us_per_iteration_of_the_longest_keypoint': 1e3 * adam_ms / float(iters.max()),
             'other_stage_ms': other,
             'kernel_avg_ms_source': 'HIP events on the launch stream, one untimed step after the timed regions',
-            'note': 'one iteration = value + d/d log s + Adam step for every keypoint still running: y is read once '
-                    '(4 B per chain-frame of the 64-chain tiles that still have a running keypoint: ~25 us at HBM speed on '
-                    'C3), then ~11 us in which the tile\'s blocks meet (block sum, ticket, the last block\'s reads of the '
-                    'group slots, the step, the hand-off of s) that no byte count describes'}
+            'note': 'y is read ONCE per search (4 B per chain-frame) by the pass that forms 256 lag sums per chain: 512 '
+                    'flops per chain-frame in packed float32 FMAs, so the pass is bound by the vector pipe, not by HBM; '
+                    'the iterations that follow touch no frame (closed-form head + lag polynomial, float64 duals)'}
     if not args.no_cpu_baseline:
         try:
             out['cpu_baseline'] = cpu_baseline_adam(y, var, m0, S0, T, K, args.cpu_seconds, last)
@@ -508,7 +506,7 @@ def cpu_baseline_adam(y_dev, var_dev, m0, S0, T, K, budget_s, last):
         # strict comparison is at identical s (tests/test_gpu_configs.py); here the bar is 1e-3 * 1e-1
         par['ms_max_rel_err'] = float((np.abs(ms_g[same] - ms_o[same])
                                        / np.abs(ms_o[same]).max(axis=(1, 2), keepdims=True)).max())
-    par['ok'] = bool(same.mean() >= 0.9 and (par['max_abs_dlog_s'] or 0.0) <= 1e-3
+    par['ok'] = bool(same.mean() >= 0.99 and (par['max_abs_dlog_s'] or 0.0) <= 2e-6
                      and par.get('ms_max_rel_err', 0.0) <= 1e-4)
     return dict(value=T * Kc / dt, unit='frames*keypoints/s', cores=_physical_cores(cpus), threads=threads, kind='port',
                 cpu_model=_cpu_model(), parity=par,
@@ -978,12 +976,74 @@ def main():
                 out['host_boundary'] = host_boundary_rate(y, var, T, K, n_cand)
             except Exception as e:
                 out['host_boundary'] = {'value': None, 'note': f'failed: {e!r}'}
+        if headline and world == 1 and not args.no_extras and not args.no_cpu_baseline:
+            out['extras'] = collect_extras()
+            parity_failed = parity_failed or any(isinstance(v, dict) and v.get('exit_code') == 3
+                                                 for v in out['extras'].values())
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
     if parity_failed:                 # the line is out; a timed path that disagrees with the float64 port is an error
-        print(f'bench.py: parity_vs_cpu_port beyond {PARITY_BAR:g}: {out["parity_vs_cpu_port"]}', file=sys.stderr)
+        bad = {k: v.get('parity_vs_cpu_port') for k, v in (out.get('extras') or {}).items()
+               if isinstance(v, dict) and v.get('exit_code') == 3}
+        print(f'bench.py: parity beyond the bars ({PARITY_BAR:g} on outputs): headline {out.get("parity_vs_cpu_port")}; '
+              f'extras {bad}', file=sys.stderr)
         raise SystemExit(3)
+
+
+EXTRA_LEGS = (      # (workload, extra arguments): short runs of the other BASELINE configurations, each a child process
+    ('c3adam', ['--steps', '5', '--warmup', '2', '--regions', '3', '--cpu-seconds', '8']),
+    ('c2', ['--steps', '50', '--warmup', '5', '--regions', '3', '--cpu-seconds', '3']),
+    ('c4', ['--steps', '50', '--warmup', '5', '--regions', '3', '--cpu-seconds', '3']),
+    ('c5', ['--steps', '5', '--warmup', '2', '--regions', '3', '--cpu-seconds', '4']),
+)
+
+
+def collect_extras(budget_s=75.0, per_leg_s=45.0):
+    """The other BASELINE configurations beside the headline: `python bench.py --workload X` as a
+    CHILD process per leg (this process keeps its device context; nothing is exec'ed over it), its JSON line cut down
+    to what a reader of the headline line needs - time per step, rate, fraction of HBM, the parity block against the CPU
+    port on a bounded sample.  Never part of `value`; a leg that fails or runs out of time says so and the line goes out."""
+    import subprocess
+    keep = ('ms_per_step', 'ms_per_step_min', 'ms_per_step_max', 'value', 'unit', 'steps', 'regions', 'gpu_over_cpu')
+    extras, t_start = {}, time.perf_counter()
+    for wl, extra in EXTRA_LEGS:
+        left = budget_s - (time.perf_counter() - t_start)
+        if left < 10.0:
+            extras[wl] = {'skipped': f'the extras\' time budget ({budget_s:.0f} s) was used up by the legs before it'}
+            continue
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--workload', wl, '--no-extras'] + extra,
+                               capture_output=True, text=True, timeout=min(per_leg_s, left))
+            line = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith('{')]
+            if not line:
+                extras[wl] = {'failed': f'exit code {r.returncode}', 'stderr_tail': r.stderr[-300:]}
+                continue
+            d = json.loads(line[-1])
+            e = {k: d[k] for k in keep if k in d}
+            e['workload'] = d.get('config', {}).get('workload')
+            roof = d.get('roofline') or {}
+            for k in ('whole_step_frac', 'frac', 'kernel', 'bound', 'kernel_avg_ms', 'search_kernel_ms'):
+                if k in roof:
+                    e['roofline_' + k] = roof[k]
+            if 'adam_iterations' in d.get('config', {}):
+                e['adam_iterations'] = d['config']['adam_iterations']
+            par = d.get('parity_vs_cpu_port') or (d.get('cpu_baseline') or {}).get('parity')
+            if par is not None:
+                e['parity_vs_cpu_port'] = par
+            cb = d.get('cpu_baseline') or {}
+            e['cpu_baseline'] = {k: cb.get(k) for k in ('value', 'unit', 'cores', 'kind', 'sample')}
+            e['exit_code'] = r.returncode
+            e['wall_s'] = round(time.perf_counter() - t0, 1)
+            extras[wl] = e
+        except subprocess.TimeoutExpired:
+            extras[wl] = {'failed': f'no line within {min(per_leg_s, left):.0f} s'}
+        except Exception as ex:                        # noqa: BLE001 - the headline line must go out
+            extras[wl] = {'failed': repr(ex)}
+    extras['note'] = ('short legs run after the headline was timed, one child process each (`--workload X --no-extras`); '
+                      'never part of `value`; c3adam = BASELINE configs[2] in the reference\'s default mode (Adam on log s)')
+    return extras
 
 
 def host_boundary_rate(y, var, T, K, n_cand, reps=3):

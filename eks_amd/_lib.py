@@ -14,6 +14,8 @@ FLAG_DIAG_MODEL = 1
 FLAG_VS_DIAG = 2
 FLAG_UNIT_AC = 4
 FLAG_Q_PD = 8
+FLAG_ADAM_PREPARED = 16
+EKS_ERR_UNSUPPORTED = -3
 # eks_warmup units (include/eks_hip.h: EKS_WARM_*)
 WARM = dict(misc=1, diag=2, diag_nll=4, dense=8, dense_wave=16, dense_wide=32, loss=64, loss_ar1=128, multicam=256)
 WARM_ALL = 511
@@ -79,6 +81,7 @@ SIGNATURES = {
     'eks_host_gather_cols': (ctypes.c_int, [c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                             c_void_p, c_int32]),
     'eks_adam_run_stride': (c_int32, [c_void_p, c_int32]),
+    'eks_adam_prepare': (ctypes.c_int, [POINTER(EksDims), c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
     'eks_profile_drain': (ctypes.c_int, [c_void_p, c_size_t, c_void_p, c_int32]),
     'eks_ensemble': (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32,
                                     c_float, c_void_p, c_void_p]),

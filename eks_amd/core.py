@@ -264,49 +264,6 @@ def _block_csr(blocks, K):
     return offs, members.astype(np.int32), of_kp
 
 
-_ADAM_LOOP_FAILED = ('eks_adam_run: a workgroup of the in-launch optimiser loop gave up waiting for its tile\'s step '
-                     '(eks_diag_nll.hip: GfLoop); results are invalid.  EKS_ADAM_PER_ITERATION=1 runs one launch per '
-                     'iteration instead')
-
-
-def _finish_search(info) -> None:
-    """Waits for a search whose calls were all enqueued without looking at their counts and raises if one of them
-    reported that the in-launch loop gave up."""
-    un = info.pop('_unchecked', None) if isinstance(info, dict) else None
-    if un is None:
-        return
-    snap, r, ev = un
-    ev.synchronize()
-    if any(int(snap[i]) < 0 for i in range(r)):
-        raise _AdamLoopGaveUp(_ADAM_LOOP_FAILED)
-
-
-class _AdamLoopGaveUp(RuntimeError):
-    pass
-
-
-def _without_in_launch_loop(fn):
-    """The in-launch optimiser loop needs all of its workgroups on the device at once; something else holding compute
-    units for as long as it waits (another PROCESS's loop on the same GPU) makes it give up instead of hanging.  The
-    search is then repeated with a launch per iteration - for the rest of the process - and a warning."""
-    import functools
-
-    @functools.wraps(fn)
-    def wrapper(*a, **kw):
-        try:
-            return fn(*a, **kw)
-        except _AdamLoopGaveUp:
-            if kw.get('_s_on_device'):               # (a tile of a tiled call: the whole call is repeated)
-                raise
-            logger.warning('eks_adam_run: the in-launch optimiser loop gave up waiting (is another process using this '
-                           'GPU?); repeating the search with one launch per iteration, as will later calls')
-            os.environ['EKS_ADAM_PER_ITERATION'] = '1'
-            from . import _lib
-            _lib.load().eks_knobs_reload()
-            return fn(*a, **kw)
-    return wrapper
-
-
 def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, s_bounds_log, tol,
                         safety_cap, min_R_var, s_mode, n_grid, sync_every: int | None = None):
     """Returns (s per keypoint as a device float64 tensor, info dict)."""
@@ -328,6 +285,20 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
             nll, s, idx = hip_ops.nll_argmin(y_c, rconst, *P.params, cand, flags=P.flags)
         return s, dict(mode='grid', nll=nll, argmin=idx, candidates=cand)
     # Adam on u = log s (reference eks/core.py:612-613, :439-441: float32 initial value)
+    # The optimiser's buffers are allocated and the pass over y that does not depend on the starting point (the lag sums
+    # of eks_lag_adam.hip) is enqueued BEFORE the host asks for the initial guesses: their round trip (a device
+    # reduction, 2 K floats back, rounding, the state's upload) runs beside that pass instead of in front of it.
+    packed = torch.empty(nb * 6 + P.K, dtype=torch.float64, device=P.dev)
+    state, s_kp = packed[:nb * 6].view(nb, 6), packed[nb * 6:]
+    if nb == P.K and np.array_equal(members, np.arange(P.K)):
+        offs_d = torch.arange(P.K + 1, dtype=torch.int32, device=P.dev)
+        mem_d = torch.arange(P.K, dtype=torch.int32, device=P.dev)
+    else:
+        offs_d = torch.as_tensor(offs, device=P.dev)
+        mem_d = torch.as_tensor(members, device=P.dev)
+    loop = hip_ops.AdamLoop(y_c, rconst, *P.params, offs_d, mem_d, state, s_kp, lr, lo, hi, tol,
+                            safety_cap, flags=P.flags)
+    loop.prepare()
     # (block means by one segmented sum over the CSR member list: a Python loop over 256 blocks of np.mean / np.clip
     #  calls held the first launch back by 2 ms)
     if callable(s_guess_per_k):
@@ -341,20 +312,18 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
     u0 = np.log(np.clip(means, 1e-6, 1e3)).astype(np.float32).astype(np.float64)
     # optimiser state and starting point in ONE upload (four small pageable copies cost ~25 us each in front of the
     # first launch), the block lists generated on the device when every block is a keypoint in order
-    packed = np.zeros(nb * 6 + P.K)
-    packed[0:nb * 6:6] = u0
-    packed[3:nb * 6:6] = np.inf
-    packed[nb * 6:] = np.exp(np.clip(u0, lo, hi))[of_kp]
-    packed = torch.as_tensor(packed, device=P.dev)
-    state, s_kp = packed[:nb * 6].view(nb, 6), packed[nb * 6:]
-    if nb == P.K and np.array_equal(members, np.arange(P.K)):
-        offs_d = torch.arange(P.K + 1, dtype=torch.int32, device=P.dev)
-        mem_d = torch.arange(P.K, dtype=torch.int32, device=P.dev)
-    else:
-        offs_d = torch.as_tensor(offs, device=P.dev)
-        mem_d = torch.as_tensor(members, device=P.dev)
-    loop = hip_ops.AdamLoop(y_c, rconst, *P.params, offs_d, mem_d, state, s_kp, lr, lo, hi, tol,
-                            safety_cap, flags=P.flags)
+    # (from page-locked memory and without waiting: a pageable copy would hold the host until the stream - the pass over
+    #  y enqueued above included - had drained, and the search's launch would follow an idle gap)
+    try:
+        stage = _pinned_empty((nb * 6 + P.K,), torch.float64)
+    except RuntimeError:          # page-locked memory exhausted or unavailable: a blocking copy
+        stage = torch.empty(nb * 6 + P.K, dtype=torch.float64)
+    packed_h = stage.numpy()
+    packed_h[:] = 0.0
+    packed_h[0:nb * 6:6] = u0
+    packed_h[3:nb * 6:6] = np.inf
+    packed_h[nb * 6:] = np.exp(np.clip(u0, lo, hi))[of_kp]
+    packed.copy_(stage, non_blocking=True)
     iters, cap = 0, int(safety_cap)
     # several iterations per host round trip: a step enqueued after a block has stopped (or reached the
     # cap) leaves that block untouched (its loss waves exit at once), so over-issuing changes nothing.
@@ -371,26 +340,23 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
         sync_every = loop.stride()
     if os.environ.get('EKS_ADAM_SYNC_EVERY'):            # (A/B runs)
         sync_every = max(1, int(os.environ['EKS_ADAM_SYNC_EVERY']))
-    rounds = (cap + sync_every - 1) // sync_every
-    try:
-        snap = _pinned_empty((max(rounds, 1),), torch.int32)
-    except RuntimeError:          # page-locked memory exhausted or unavailable (as _to_host): blocking reads
-        snap = None
-    if sync_every >= 64 and snap is not None:
-        # One launch per call, and a call issued after the last block has stopped returns at once (~40 us on the device):
-        # every call the cap allows is enqueued now, nothing is waited for, and whatever the caller enqueues next (the
-        # final smoothing pass) follows the search without a host round trip in between.  The counts are looked at
-        # later (_finish_search): only a negative one matters - the in-launch loop gave up (eks_adam_run_stride).
+    if sync_every >= 64:
+        # One launch per call, and a call issued after the last block has stopped returns at once: every call the cap
+        # allows is enqueued now, nothing is waited for, and whatever the caller enqueues next (the final smoothing pass)
+        # follows the search without a host round trip in between.  (The search from cached lag sums asks for the whole
+        # cap in one call: eks_adam_run_stride.)
         r = 0
         while iters < cap:
             n = min(sync_every, cap - iters)
             loop.run(n)
             iters += n
-            snap[r:r + 1].copy_(loop.n_active, non_blocking=True)
             r += 1
-        ev = torch.cuda.Event()
-        ev.record()
-        return s_kp, dict(mode='adam', state=state, launches=iters, calls=r, deferred_count=True, _unchecked=(snap, r, ev))
+        return s_kp, dict(mode='adam', state=state, launches=iters, calls=r, deferred_count=True, _keep=stage)
+    rounds = (cap + sync_every - 1) // sync_every
+    try:
+        snap = _pinned_empty((max(rounds, 1),), torch.int32)
+    except RuntimeError:          # page-locked memory exhausted or unavailable (as _to_host): blocking reads
+        snap = None
     pending = None                                        # (round index, event) of the newest unread count
     r = 0
     while iters < cap:
@@ -399,8 +365,6 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
         iters += n
         if snap is None:
             left = int(loop.n_active.item())
-            if left < 0:
-                raise _AdamLoopGaveUp(_ADAM_LOOP_FAILED)
             if left == 0:
                 break
             continue
@@ -410,8 +374,6 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
         if pending is not None:
             pending[1].synchronize()
             left = int(snap[pending[0]])
-            if left < 0:
-                raise _AdamLoopGaveUp(_ADAM_LOOP_FAILED)
             if left == 0:
                 break
         pending = (r, ev)
@@ -421,7 +383,6 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
     return s_kp, dict(mode='adam', state=state, launches=iters, deferred_count=snap is not None)
 
 
-@_without_in_launch_loop
 def optimize_smooth_param(ys, m0s, S0s, As, Cs, Qs, Rs, blocks, s_finals, s_frames, s_guess_per_k,
                           lr: float = 0.25, s_bounds_log=(-8.0, 8.0), tol: float = 1e-3,
                           safety_cap: int = 300, min_R_var: float = 1e-4,
@@ -443,7 +404,6 @@ def optimize_smooth_param(ys, m0s, S0s, As, Cs, Qs, Rs, blocks, s_finals, s_fram
     P = _DeviceProblem(ys, m0s, S0s, As, Cs, Qs, np.swapaxes(Rd, 0, 1))
     s, info = _optimize_on_device(P, blocks, s_frames, np.asarray(s_guess_per_k, float), lr,
                                   s_bounds_log, tol, safety_cap, min_R_var, 'adam', 0)
-    _finish_search(info)
     s_finals[:] = s.cpu().numpy()
     _log_opt(blocks, s_finals, info)
 
@@ -717,12 +677,24 @@ def _run_tiled_from_host(tiles, ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frame
     import queue
     vq: queue.Queue = queue.Queue(maxsize=3)
 
+    stop = threading.Event()                 # set when the consumer leaves early: the producer must not wait on a full queue
+
+    def offer(item):
+        while not stop.is_set():
+            try:
+                vq.put(item, timeout=0.05)
+                return True
+            except queue.Full:
+                continue
+        return False
+
     def produce():
         try:
             for (a, b) in tiles:
-                vq.put(var_tile(a, b))
+                if not offer(var_tile(a, b)):
+                    return
         except BaseException as e:          # noqa: BLE001 - handed to the consumer
-            vq.put(e)
+            offer(e)
 
     if not whole:
         threading.Thread(target=produce, name='eks-var-tiles', daemon=True).start()
@@ -777,12 +749,20 @@ def _run_tiled_from_host(tiles, ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frame
                 # caching allocator hands a block back only to work enqueued on the same stream later (a call just over
                 # the tiling threshold then peaks at a few tiles' worth of device memory, not at the untiled footprint)
                 del y_t, v_t, res, ms_d, Vs_d, ms_c, Vs_c
+    except BaseException:
+        if pinned:                               # (the finalisers below were never attached: give the bytes back)
+            _release_pinned(nbytes)
+        raise
     finally:
+        stop.set()                               # a producer still gathering stops at its next tile ...
+        while True:                              # ... and the tiles it had queued (page-locked buffers) are dropped
+            try:
+                vq.get_nowait()
+            except queue.Empty:
+                break
         for st in streams:                       # (also when a tile raised: the side streams rejoin the caller's)
             cur.wait_stream(st)
     cur.synchronize()
-    for inf in infos:
-        _finish_search(inf)
     if trace:
         logger.warning(f'tiled boundary: {(t_loop - t_entry) * 1e3:.2f} ms before the first tile, {(time.perf_counter() - t_loop) * 1e3:.2f} ms '
                        'to the end of the downloads; per tile (k0, k1, ys upload ms, variance gather ms, variance upload enqueue ms): '
@@ -803,7 +783,6 @@ def _run_tiled_from_host(tiles, ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frame
     return out
 
 
-@_without_in_launch_loop
 def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list | None = None,
                         smooth_param: float | list | None = None,
                         blocks: list[list[int]] | None = None, lr: float = 0.25,
@@ -907,7 +886,6 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
     t2 = time.perf_counter()
     ms, Vs = hip_ops.smooth(P.y, P.var, *P.params, s_dev.contiguous(), flags=P.flags, vs_diag=vs_diag)
     if smooth_param is None and not _s_on_device:
-        _finish_search(info)
         if s_host is not None:
             s_ready.synchronize()
             s_finals[:] = s_host.numpy()

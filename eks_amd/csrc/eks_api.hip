@@ -244,13 +244,6 @@ int eks_adam_run(const eks_dims_t* d, const float* y, const double* rconst, cons
                        n_active, counter_b};
       return diag_nll_adam_persist(*d, y, rconst, M, n_iters, nll, dnll, F, n_active, st);
     }
-    if (in_kernel) {
-      // long sessions: the chip-wide loss kernel keeps its workgroups for all n_iters iterations (round 5: GfLoop)
-      const AdamFuse F{block_offsets, block_members, kp_block, lr, lo, hi, tol, safety_cap, 1, state, s_keypoint,
-                       n_active, counter_b};
-      rc = diag_nll_adam_loop(*d, y, rconst, M, n_iters, nll, dnll, F, workspace, workspace_bytes, st);
-      if (rc != EKS_ERR_UNSUPPORTED) return rc;
-    }
     for (int it = 0; it < n_iters; ++it) {
       // the LAST iteration of the call counts into n_active, the one before into the spare counter, ...
       const bool last_parity = ((n_iters - 1 - it) & 1) == 0;
@@ -277,12 +270,24 @@ int eks_adam_run(const eks_dims_t* d, const float* y, const double* rconst, cons
   return EKS_OK;
 }
 
+int eks_adam_prepare(const eks_dims_t* d, const float* y, const double* A, int32_t n_blocks, void* workspace,
+                     size_t workspace_bytes, eks_stream_t stream) {
+  const int rc = check_dims(d);
+  if (rc != EKS_OK) return rc;
+  if (n_blocks <= 0) return EKS_ERR_SHAPE;
+  if (!y || !A) return EKS_ERR_NULL;
+  if (!workspace) return EKS_ERR_WORKSPACE;
+  if (!(d->flags & EKS_FLAG_DIAG_MODEL) || !diag_lag_adam_ok(d->n_frames, d->n_keypoints, d->state_dim, n_blocks))
+    return EKS_ERR_UNSUPPORTED;
+  if (workspace_bytes < diag_nll_workspace_bytes(d->n_frames, d->n_keypoints * d->state_dim, 1)) return EKS_ERR_WORKSPACE;
+  return diag_lag_sums(*d, y, A, nullptr, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
 int32_t eks_adam_run_stride(const eks_dims_t* d, int32_t n_blocks) {
   if (check_dims(d) != EKS_OK || n_blocks <= 0) return 4;
   if (!(d->flags & EKS_FLAG_DIAG_MODEL)) return 4;
   if (diag_lag_adam_ok(d->n_frames, d->n_keypoints, d->state_dim, n_blocks)) return 4096;
   if (diag_nll_adam_persist_ok(d->n_frames, d->n_keypoints, d->state_dim, n_blocks)) return 64;
-  if (diag_nll_adam_loop_ok(d->n_frames, d->n_keypoints, d->state_dim, n_blocks)) return 128;
   return 16;
 }
 

@@ -600,9 +600,11 @@ int ekf_smooth(const eks_dims_t& d, int n_data_keypoints, const float* y, const 
     // than tol; the slots of the sweeps gated after it are still zero) the elements, prefixes and suffixes in the
     // workspace ARE the converged ones - rebuilt at the new points they would differ by ~tol (1e-10 against 1e-5 bars) -
     // so the smoothing sweep is its replay alone (round 5: three launches and a third of a sweep's time less); it
-    // rebuilds them only when the sweeps ran out unconverged.
+    // rebuilds them only when the sweeps ran out unconverged.  The shortcut is for tight tolerances only: with a loose
+    // caller tol (1e-2, say) "converged" points may still be 1e-2 from the elements in the workspace, so the rebuild is
+    // skipped only below 1e-8.
     ProfScope ps("ekf_smooth_sweep", st);
-    sweep(Gate{resid + max_sweeps - 1, tol}, Gate{nullptr, 0.0}, resid + kEkfMaxSweeps, true);
+    sweep(Gate{resid + max_sweeps - 1, tol < 1e-8 ? tol : 1e-8}, Gate{nullptr, 0.0}, resid + kEkfMaxSweeps, true);
   }
   hipLaunchKernelGGL(ekf_finish_kernel, dim3(K), dim3(64), 0, st, K, G.nc, max_sweeps, tol, ll_chunk,
                      resid, nll, info);

@@ -525,8 +525,8 @@ int diag_nll_adam_persist(const eks_dims_t& d, const float* y, const double* rco
 //     in time order by a 3-level tree through LDS; wave 0 stores ONE group summary (13 doubles per chain,
 //     [tile][group][field][lane]: coalesced);
 //   * the block that takes the LAST ticket of its tile (agent-scope release / acquire around an atomic
-//     counter - nobody waits for anybody inside one evaluation, so no co-residency assumption; the loop
-//     mode of round 5, GfLoop below, does wait and is launched cooperatively) reads the tile's group summaries back
+//     counter - nobody waits for anybody inside one evaluation, so no co-residency assumption) reads the tile's group
+//     summaries back
 //     (coalesced, a contiguous run of groups per wave), composes them the same way, pushes the prior
 //     through the result, sums the D chains of a keypoint with wave shuffles, writes nll / dnll and - when
 //     every optimiser block is one keypoint - applies the Adam step of its 64 / D keypoints on the spot;
@@ -534,35 +534,14 @@ int diag_nll_adam_persist(const eks_dims_t& d, const float* y, const double* rco
 //     block-uniform and the ticket count of a tile is all or nothing.
 // The chunk length is chosen so that the grid is a whole number of 256-CU rounds (C3: 8 tiles x 32 groups).
 // Round 5: where the tile's poles allow, the chunks past the first are summarised from a converged entry and their
-// terms SUMMED (gf_evaluate's first branch: no compositions at all); and all iterations of an eks_adam_run call run
-// inside one launch (GfLoop).  The form described above is what remains for slow poles and single evaluations.
+// terms SUMMED (gf_evaluate's first branch: no compositions at all); the form described above is what remains for slow
+// poles.  Round 6: the search of the reference's default mode no longer comes here (eks_lag_adam.hip: no pass over y per
+// iteration) - this kernel serves eks_nll with a gradient and the optimiser's iterations on the shapes the lag form does
+// not take (more than four chains per keypoint); round 5's in-launch loop over iterations (cooperative launch, tagged
+// hand-off words, give-up path) went with it.
 constexpr int kGfWaves = 8;
 constexpr int kGfFields = 13;          // (A, b, C, eta, J, ell) x (value, derivative) + reference state
 constexpr int kGfChunkMin = 256;      // (shorter chunks never leave the full recursion: nll_summarize_chunk)
-
-// Diagnostic build only (-DEKS_GF_STAMPS, tools/gf_stamps.py): lane 0 of every wave of the first 256 blocks
-// stamps the 100 MHz real-time counter at the phase boundaries.
-#ifdef EKS_GF_STAMPS
-__device__ unsigned long long g_gf_stamps[256][kGfWaves][8];
-__device__ unsigned long long g_gf_iter[256][48][8];     // loop mode: wave 0 of every block, per iteration
-#define GF_STAMP(ph)                                                                                         \
-  do {                                                                                                       \
-    if ((threadIdx.x & 63) == 0 && blockIdx.x < 256)                                                         \
-      g_gf_stamps[blockIdx.x][threadIdx.x >> 6][ph] = __builtin_amdgcn_s_memrealtime();                      \
-    if (threadIdx.x == 0 && blockIdx.x < 256 && gf_it < 48)                                                  \
-      g_gf_iter[blockIdx.x][gf_it][ph] = __builtin_amdgcn_s_memrealtime();                                   \
-  } while (0)
-#define GF_IT_DECL int gf_it = 0
-#define GF_IT_ARG , int gf_it
-#define GF_IT_PASS , gf_it
-#define GF_IT_SET(v) gf_it = (v)
-#else
-#define GF_STAMP(ph) do { } while (0)
-#define GF_IT_DECL
-#define GF_IT_ARG
-#define GF_IT_PASS
-#define GF_IT_SET(v)
-#endif
 
 struct GradFuseWs {
   double* grp;          // [ntile][ngroups][kGfFields][64]
@@ -637,79 +616,29 @@ __device__ __forceinline__ void gf_stores_acknowledged() {
 }
 
 
-// ---- round 5: several optimiser iterations in one launch (eks_adam_run, the step applied in the kernel) -------------
-// An iteration's launch ends ~6 us after its last wave (dispatch of 256 workgroups, end-of-kernel cache maintenance:
-// the kernel trace shows 42 us per launch for 36 us of in-kernel timeline), 118 times on C3.  In loop mode the launch's
-// workgroups stay: the tile's last block applies the step, stores the new s and optimiser state through to memory
-// (agent-scope stores, like the group slots) and hands s to the tile's other blocks (gf_hand_put), which
-// poll for it and start the next evaluation from the new s.  Tiles are independent - each runs until all of its
-// keypoints have stopped or the call's iterations are used up.  The launch is cooperative (all ntile x ngroups
-// workgroups resident; the runtime runs one cooperative launch at a time, so two host threads' loops cannot wait on
-// each other's unscheduled workgroups), and the poll is bounded: a workgroup that never sees its tile's counter move
-// gives up and marks the call as failed (n_active < 0, checked by the caller); the tile's other blocks follow.
-struct GfLoop {
-  int n_iters;            // iterations of this launch
-  unsigned long long* hand;   // [ntile][64][2], zero when the launch starts: the hand-off words (below)
-  int spin_limit;         // polls before a waiting workgroup gives up (kGfSpinLimit; EKS_ADAM_LOOP_SPINS for tests)
-};
-constexpr int kGfSpinLimit = 1 << 17;       // polls (each a trip to memory, ~1 us)
-constexpr int kGfFailed = -(1 << 30);
-// The step's hand-off to the tile's other blocks: s as two 64-bit words per lane, each (tag << 32) | half of s's bits
-// with tag = iteration + 1 (bit 31: the keypoint is still running).  A 64-bit store is indivisible, so a word whose tag
-// matches carries this iteration's half whatever order the stores land in: no acknowledgement wait between data and
-// flag on the writer's side, no second trip to memory after the flag on the readers'.
-__device__ __forceinline__ void gf_hand_put(unsigned long long* slot, int it, bool run, double s) {
-  const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
-  const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) | (run ? 0x80000000u : 0u)) << 32;
-  __hip_atomic_store(slot + 0, tag | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(slot + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ bool gf_hand_poll(const unsigned long long* slot, int it, bool& run, double& s) {
-  const unsigned long long w0 = __hip_atomic_load(slot + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long w1 = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned want = (unsigned)(it + 1);
-  const unsigned t0 = (unsigned)(w0 >> 32), t1 = (unsigned)(w1 >> 32);
-  if ((t0 & 0x7FFFFFFFu) != want || (t1 & 0x7FFFFFFFu) != want) return false;
-  run = (t0 >> 31) != 0;
-  s = __longlong_as_double((long long)((w0 & 0xFFFFFFFFull) | (w1 << 32)));
-  return true;
-}
-
 // a chain's log-likelihood and derivative (wave 0 of the tile's last block) -> the keypoint's loss, gradient and step.
-// `st`: the optimiser state of the lane's keypoint, requested beside the group slots.  Loop mode: also the lane's s for
-// the next evaluation and whether its keypoint is still running.
-template <bool LOOP>
+// `st`: the optimiser state of the lane's keypoint, requested beside the group slots.
 __device__ __forceinline__ void gf_finish(const NllGeom& G, const AdamFuse& F, int lane, int k, int d, int kb, bool running,
                                           double v, double g, const AdamRegs& st, double* __restrict__ nll,
-                                          double* __restrict__ dnll, bool count_now, double& s_next, bool& run_next) {
+                                          double* __restrict__ dnll) {
   for (int off = 1; off < G.D; off <<= 1) {          // the D chains of a keypoint sit in adjacent lanes
     v += __shfl_xor(v, off);
     g += __shfl_xor(g, off);
   }
   bool still = false;
-  double s_new = s_next;
   if (running && d == 0) {
     v = -v;
     const bool fin = isfinite(v);                    // eks/core.py:650
     const double L = fin ? v : 1e12, dL = fin ? -g : 0.0;
-    if (LOOP) {      // (another XCD's block wrote them an iteration ago: written through, or its stale line could land last)
-      gf_publish(nll + k, L);
-      gf_publish(dnll + k, dL);
-    } else {
-      nll[k] = L;
-      dnll[k] = dL;
-    }
+    nll[k] = L;
+    dnll[k] = dL;
+    double s_new;
     if (F.state != nullptr && F.step_in_kernel)
-      still = adam_step_single<LOOP>(kb, k, st, L, dL, F.lr, F.lo, F.hi, F.tol, F.cap, F.state, F.s_keypoint, &s_new);
+      still = adam_step_single<false>(kb, k, st, L, dL, F.lr, F.lo, F.hi, F.tol, F.cap, F.state, F.s_keypoint, &s_new);
   }
-  if (F.state != nullptr && F.step_in_kernel && count_now) {
+  if (F.state != nullptr && F.step_in_kernel) {
     const int cnt = __popcll(__ballot(still));
     if (lane == 0 && cnt) atomicAdd(F.n_active_cur, cnt);
-  }
-  if (LOOP) {
-    const int lead = lane & ~(G.D - 1);              // the keypoint's first chain holds its step
-    s_next = __shfl(s_new, lead);
-    run_next = __shfl((int)still, lead) != 0;
   }
 }
 // (wave 0 of the last block, behind the acquire fence) the state gf_finish will need
@@ -754,10 +683,9 @@ struct GfCtx {
 };
 
 // one evaluation at s_now.  Returns whether this block was its tile's last (block-uniform); in that block wave 0 has
-// written the keypoints' loss and gradient and applied the step (s_next / run_next: wave 0, loop mode).
-template <bool UNIT, bool LOOP, int ROWS, typename LD>
-__device__ __forceinline__ bool gf_evaluate(const GfCtx<LD>& X, double s_now, bool running, bool count_now,
-                                            const float (&pre)[ROWS], double& s_next, bool& run_next GF_IT_ARG) {
+// written the keypoints' loss and gradient and applied the step.
+template <bool UNIT, int ROWS, typename LD>
+__device__ __forceinline__ bool gf_evaluate(const GfCtx<LD>& X, double s_now, bool running, const float (&pre)[ROWS]) {
   const NllGeom& G = X.G;
   const GradFuseWs& W = X.W;
   const int w = X.w, lane = X.lane;
@@ -799,7 +727,6 @@ __device__ __forceinline__ bool gf_evaluate(const GfCtx<LD>& X, double s_now, bo
       bx[(w * 2 + 0) * 64 + lane] = o.b;
       bx[(w * 2 + 1) * 64 + lane] = o.db;
     }
-    GF_STAMP(1);
     __syncthreads();
     if (w > 0 && X.j < G.ncn) {
       const DualD mr = DualD(bx[((w - 1) * 2 + 0) * 64 + lane], bx[((w - 1) * 2 + 1) * 64 + lane]) - DualD(xr);
@@ -808,7 +735,6 @@ __device__ __forceinline__ bool gf_evaluate(const GfCtx<LD>& X, double s_now, bo
     part[(w * 2 + 0) * 64 + lane] = term.v;
     part[(w * 2 + 1) * 64 + lane] = term.d;
     __syncthreads();
-    GF_STAMP(2);
     if (w == 0) {
       double sv = 0.0, sd = 0.0;
 #pragma unroll
@@ -830,7 +756,6 @@ __device__ __forceinline__ bool gf_evaluate(const GfCtx<LD>& X, double s_now, bo
       if (lane == 0) *X.last_flag = (atomicAdd(W.tickets + X.tile, 1) + 1) % W.ngroups == 0;
     }
     __syncthreads();
-    GF_STAMP(3);
     if (!*X.last_flag) return false;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other blocks' slots (and, loop mode, the optimiser state)
     // ---- the tile's last block: every group's sum and deferred first term at once, wave w taking groups w, w + 8, ...
@@ -863,11 +788,9 @@ __device__ __forceinline__ bool gf_evaluate(const GfCtx<LD>& X, double s_now, bo
         }
       }
     }
-    GF_STAMP(4);
     part[(w * 2 + 0) * 64 + lane] = tot.v;             // (every wave is past its reads of `part`: the barrier above)
     part[(w * 2 + 1) * 64 + lane] = tot.d;
     __syncthreads();
-    GF_STAMP(5);
     if (w == 0) {
       double v = 0.0, g = 0.0;
 #pragma unroll
@@ -875,8 +798,7 @@ __device__ __forceinline__ bool gf_evaluate(const GfCtx<LD>& X, double s_now, bo
         v += part[(q * 2 + 0) * 64 + lane];
         g += part[(q * 2 + 1) * 64 + lane];
       }
-      gf_finish<LOOP>(G, X.F, lane, X.k, X.d, X.kb, running, v, g, st, X.nll, X.dnll, count_now, s_next, run_next);
-      GF_STAMP(6);
+      gf_finish(G, X.F, lane, X.k, X.d, X.kb, running, v, g, st, X.nll, X.dnll);
     }
     return true;
   }
@@ -894,16 +816,13 @@ __device__ __forceinline__ bool gf_evaluate(const GfCtx<LD>& X, double s_now, bo
     acc.ell = DualD(out[0].ell, out[0].dell);
     acc.xr = (double)out[0].xref;
   }
-  GF_STAMP(1);
   gf_block_tree(X.lds, w, lane, X.nvalid, acc);
-  GF_STAMP(2);
   if (w == 0) {
     gf_put_published(X.mine, acc);
     gf_stores_acknowledged();
     if (lane == 0) *X.last_flag = (atomicAdd(W.tickets + X.tile, 1) + 1) % W.ngroups == 0;
   }
   __syncthreads();
-  GF_STAMP(3);
   if (!*X.last_flag) return false;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other blocks' group summaries
   // ---- the tile's last block: compose its groups (a contiguous run per wave), finish, step
@@ -916,37 +835,31 @@ __device__ __forceinline__ bool gf_evaluate(const GfCtx<LD>& X, double s_now, bo
     acc = gf_take(base + (size_t)g0 * kGfFields * 64);
     for (int g = g0 + 1; g < g1; ++g) acc = nll_acc_combine(acc, gf_take(base + (size_t)g * kGfFields * 64));
   }
-  GF_STAMP(4);
   gf_block_tree(X.lds, w, lane, nlive, acc);
-  GF_STAMP(5);
   if (w == 0) {
     const DualD m = DualD(X.M.m0[(size_t)X.k * G.D + X.d] - acc.xr), P = DualD(X.M.S0[X.dd]);   // relative to the reference
     const DualD den = DualD(1.0) + acc.e.J * P;
     const DualD inv = rcp(den);
     const DualD ll = acc.ell - DualD(0.5) * log_with_rcp(den, inv) +
                      (acc.e.eta * m + DualD(0.5) * acc.e.eta * acc.e.eta * P - DualD(0.5) * acc.e.J * m * m) * inv;
-    gf_finish<LOOP>(G, X.F, lane, X.k, X.d, X.kb, running, ll.v, ll.d, st, X.nll, X.dnll, count_now, s_next, run_next);
-    GF_STAMP(6);
+    gf_finish(G, X.F, lane, X.k, X.d, X.kb, running, ll.v, ll.d, st, X.nll, X.dnll);
   }
   return true;
 }
 
-template <bool UNIT, bool LOOP, int ROWS>
+template <bool UNIT, int ROWS>
 __global__ __launch_bounds__(64 * kGfWaves) void diag_nll_grad_fused_kernel(NllGeom G, DiagModel M, GradFuseWs W,
                                                                            const float* __restrict__ y,
                                                                            const double* __restrict__ rconst,
                                                                            const double* s_kp,
                                                                            double* __restrict__ nll,
-                                                                           double* __restrict__ dnll, AdamFuse F, GfLoop L) {
+                                                                           double* __restrict__ dnll, AdamFuse F) {
   __shared__ double lds[kGfWaves * kGfFields * 64];
   __shared__ int last_flag;
-  __shared__ double next_s[64];
-  __shared__ int next_run[64];
-  __shared__ int wait_failed;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int tile = blockIdx.x % G.ntile, grp = blockIdx.x / G.ntile;
-  // (a launch of its own counts into alternating counters and zeroes the next one; a longer call's is zeroed by the host)
-  if ((!LOOP || L.hand == nullptr) && F.state != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *F.n_active_next = 0;
+  // (a launch counts into alternating counters and zeroes the next one)
+  if (F.state != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *F.n_active_next = 0;
   const int n_raw = tile * 64 + lane;
   const bool chain_ok = n_raw < G.N;
   const int n = chain_ok ? n_raw : G.N - 1;          // lanes past the last chain shadow it (results unused)
@@ -964,62 +877,19 @@ __global__ __launch_bounds__(64 * kGfWaves) void diag_nll_grad_fused_kernel(NllG
                             w, lane, tile, grp, j, min(kGfWaves, G.ncn - grp * kGfWaves), t0,
                             j < G.ncn ? min(j == 0 ? G.B0 : G.BN, G.T - t0) : 0, k, d, kb, dd,
                             rconst[n], M.A[dd], M.C[dd], M.Q[dd]};
-  double s_now = s_kp[k];
   bool running = chain_ok;
   if (F.state != nullptr) running = chain_ok && adam_block_running(F.state, kb, F.cap);
-  // the first rows of a converged-entry chunk do not depend on s: they are requested before the step is waited for
+  if (F.state != nullptr && !__any(running)) return;     // the same answer in every wave of the tile's blocks
+  // the first rows of a converged-entry chunk are requested before the constants of the evaluation are formed
   float pre[ROWS];
-  auto request_first_rows = [&]() {
-    if (j >= 1 && X.len >= ROWS) {
+  if (j >= 1 && X.len >= ROWS) {
 #pragma unroll
-      for (int q = 0; q < ROWS; ++q) pre[q] = ld(q);
-    } else {
+    for (int q = 0; q < ROWS; ++q) pre[q] = ld(q);
+  } else {
 #pragma unroll
-      for (int q = 0; q < ROWS; ++q) pre[q] = 0.f;
-    }
-  };
-  request_first_rows();
-  GF_IT_DECL;
-  for (int it = 0;; ++it) {
-    if (F.state != nullptr && !__any(running)) return;   // the same answer in every wave of the tile's blocks
-    GF_IT_SET(it);
-    GF_STAMP(0);
-    double s_next = s_now;
-    bool run_next = false;
-    const bool was_last = gf_evaluate<UNIT, LOOP, ROWS>(X, s_now, running, !LOOP || it == L.n_iters - 1, pre, s_next, run_next GF_IT_PASS);
-    if (!LOOP || it + 1 >= L.n_iters) return;
-    request_first_rows();
-    if (was_last) {
-      // this block applied the step: s and the running flags to the tile's other blocks and to its own other waves
-      if (w == 0) {
-        gf_hand_put(L.hand + ((size_t)tile * 64 + lane) * 2, it, run_next && chain_ok, s_next);
-        next_s[lane] = s_next;
-        next_run[lane] = run_next && chain_ok;
-      }
-    } else if (w == 0) {
-      const unsigned long long* slot = L.hand + ((size_t)tile * 64 + lane) * 2;
-      bool got = false, r = false;
-      double sv = s_now;
-      int spins = 0;
-      for (;;) {
-        if (!got) got = gf_hand_poll(slot, it, r, sv);
-        if (__all(got) || ++spins >= L.spin_limit) break;
-        __builtin_amdgcn_s_sleep(4);
-      }
-      const bool all_got = __all(got);
-      next_s[lane] = sv;
-      next_run[lane] = r;
-      if (lane == 0) wait_failed = all_got ? 0 : 1;
-    }
-    __syncthreads();
-    if (!was_last && wait_failed) {
-      if (threadIdx.x == 0) atomicAdd(F.n_active_cur, kGfFailed);
-      return;
-    }
-    s_now = next_s[lane];
-    running = next_run[lane] != 0;
-    GF_STAMP(7);
+    for (int q = 0; q < ROWS; ++q) pre[q] = 0.f;
   }
+  gf_evaluate<UNIT, ROWS>(X, s_kp[k], running, pre);
 }
 
 // N2'' chunk-parallel assembly for the grid search (value only, converged-entry summaries): a
@@ -1826,51 +1696,19 @@ size_t diag_nll_workspace_bytes(int T, int N, int n_cand) {
   return main + adam_extra_bytes(N);
 }
 
-// [keypoint -> block map : N ints][tile tickets : ceil(N / 64) ints][hand-off words : ceil(N / 64) x 64 x 2 x 8 B]
-// [second counter : 256 B]
+// [keypoint -> block map : N ints][tile tickets : ceil(N / 64) ints][second counter : 256 B]
 size_t adam_extra_bytes(int N) {
-  return align_up((size_t)N * sizeof(int32_t), 256) + align_up((size_t)((N + 63) / 64) * sizeof(int32_t), 256) +
-         (size_t)((N + 63) / 64) * 1024 + 256;
-}
-static void* nll_ws_hand(void* ws, int T, int N) {
-  char* tail = static_cast<char*>(ws) + diag_nll_workspace_bytes(T, N, 1) - adam_extra_bytes(N);
-  return tail + align_up((size_t)N * sizeof(int32_t), 256) + align_up((size_t)((N + 63) / 64) * sizeof(int32_t), 256);
+  return align_up((size_t)N * sizeof(int32_t), 256) + align_up((size_t)((N + 63) / 64) * sizeof(int32_t), 256) + 256;
 }
 int32_t* nll_ws_tickets(void* ws, int T, int N, int n_cand) {
   char* tail = static_cast<char*>(ws) + diag_nll_workspace_bytes(T, N, n_cand) - adam_extra_bytes(N);
   return reinterpret_cast<int32_t*>(tail + align_up((size_t)N * sizeof(int32_t), 256));
 }
 
-// the instantiation of the loss kernel for a model class, mode and launch size
-using GfKernel = void (*)(NllGeom, DiagModel, GradFuseWs, const float*, const double*, const double*, double*, double*, AdamFuse,
-                          GfLoop);
-static GfKernel gf_kernel(bool unit, bool loop, bool few_blocks) {
-  if (few_blocks) {
-    if (unit) return loop ? diag_nll_grad_fused_kernel<true, true, kGfRowsFew> : diag_nll_grad_fused_kernel<true, false, kGfRowsFew>;
-    return loop ? diag_nll_grad_fused_kernel<false, true, kGfRowsFew> : diag_nll_grad_fused_kernel<false, false, kGfRowsFew>;
-  }
-  if (unit) return loop ? diag_nll_grad_fused_kernel<true, true, kGfRowsFull> : diag_nll_grad_fused_kernel<true, false, kGfRowsFull>;
-  return loop ? diag_nll_grad_fused_kernel<false, true, kGfRowsFull> : diag_nll_grad_fused_kernel<false, false, kGfRowsFull>;
-}
-
-// how many workgroups of the loop-mode kernel the current device holds at once (0: no cooperative launches)
-static long gf_resident_blocks(bool unit, bool few_blocks = false) {
-  const void* fn = reinterpret_cast<const void*>(gf_kernel(unit, true, few_blocks));
-  int dev = 0, coop = 0, cus = 0, per_cu = 0;
-  if (hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop ||
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * kGfWaves, 0) != hipSuccess) {
-    (void)hipGetLastError();
-    return 0;
-  }
-  return (long)per_cu * cus;
-}
-
-// the single-launch gradient evaluation (loop_iters == 0) or loop_iters optimiser iterations in one cooperative launch
+// the single-launch gradient evaluation (and, with F.step_in_kernel, the optimiser step of its keypoints)
 static int grad_fused_launch(const eks_dims_t& d, const NllGeom& G, const float* y, const double* rconst, const DiagModel& M,
                              const double* s_kp, double* nll, double* dnll, void* ws, hipStream_t st, const AdamFuse& F,
-                             bool tickets_zeroed, int loop_iters) {
+                             bool tickets_zeroed) {
   const int T = d.n_frames, N = d.n_keypoints * d.state_dim;
   GradFuseWs FW;
   FW.ngroups = (G.ncn + kGfWaves - 1) / kGfWaves;
@@ -1881,66 +1719,20 @@ static int grad_fused_launch(const eks_dims_t& d, const NllGeom& G, const float*
   if (grp_bytes > diag_nll_workspace_bytes(T, N, 1) - adam_extra_bytes(N)) return EKS_ERR_WORKSPACE;
   const dim3 grid((unsigned)(G.ntile * FW.ngroups)), block(64 * kGfWaves);
   const bool unit = (d.flags & EKS_FLAG_UNIT_AC) != 0, few = (int)grid.x <= kGfFewBlocks;
-  if (loop_iters <= 0) {
-    if (!tickets_zeroed) {   // (eks_adam_run zeroes the tickets once; every evaluation leaves them zero)
-      const hipError_t e = hipMemsetAsync(FW.tickets, 0, (size_t)G.ntile * sizeof(int32_t), st);
-      if (e != hipSuccess) return hip_status(e);
-    }
-    ProfScope ps("diag_nll_grad_fused", st);
-    const GfLoop L{1, nullptr, kGfSpinLimit};
-    // (an optimiser iteration as its own launch runs the loop-mode code for one iteration: the same instructions as
-    //  inside a longer call, so the two forms of eks_adam_run agree bit for bit - tests/test_gpu_kernels.py)
-    const bool step = F.state != nullptr && F.step_in_kernel;
-    hipLaunchKernelGGL(gf_kernel(unit, step, few), grid, block, 0, st, G, M, FW, y, rconst, s_kp, nll, dnll, F, L);
-    return hip_status(hipGetLastError());
+  if (!tickets_zeroed) {     // (eks_adam_run zeroes the tickets once; every evaluation leaves them zero)
+    const hipError_t e = hipMemsetAsync(FW.tickets, 0, (size_t)G.ntile * sizeof(int32_t), st);
+    if (e != hipSuccess) return hip_status(e);
   }
-  // ---- loop mode: every workgroup resident, hand-off words and the running count zeroed behind the stream
-  const void* fn = reinterpret_cast<const void*>(gf_kernel(unit, true, few));
-  if (gf_resident_blocks(unit, few) < (long)grid.x) return EKS_ERR_UNSUPPORTED;
-  GfLoop L{loop_iters, reinterpret_cast<unsigned long long*>(nll_ws_hand(ws, T, N)),
-           knob_int(KNOB_ADAM_LOOP_SPINS, kGfSpinLimit)};
-  hipError_t e = hipMemsetAsync(L.hand, 0, (size_t)G.ntile * 64 * 2 * sizeof(unsigned long long), st);
-  if (e == hipSuccess) e = hipMemsetAsync(F.n_active_cur, 0, sizeof(int32_t), st);
-  if (e != hipSuccess) return hip_status(e);
   ProfScope ps("diag_nll_grad_fused", st);
-  NllGeom Gc = G;
-  DiagModel Mc = M;
-  AdamFuse Fc = F;
-  if (getenv("ROCP_TOOL_LIBRARIES") != nullptr) {
-    // Under a rocprofiler-sdk tool (rocprofv3) a process that made a cooperative launch crashes when it EXITS (ROCm
-    // 7.2: SIGSEGV in the tool's finalisation, after the run itself completed).  The same kernel as an ordinary launch:
-    // its workgroups fit the device (checked above) and a profiled process runs its kernels one stream at a time.
-    hipLaunchKernelGGL(gf_kernel(unit, true, few), grid, block, 0, st, Gc, Mc, FW, y, rconst, s_kp, nll, dnll, Fc, L);
-    return hip_status(hipGetLastError());
+#define EKS_GF_LAUNCH(UN, RW) \
+  hipLaunchKernelGGL((diag_nll_grad_fused_kernel<UN, RW>), grid, block, 0, st, G, M, FW, y, rconst, s_kp, nll, dnll, F)
+  if (few) {
+    if (unit) EKS_GF_LAUNCH(true, kGfRowsFew); else EKS_GF_LAUNCH(false, kGfRowsFew);
+  } else {
+    if (unit) EKS_GF_LAUNCH(true, kGfRowsFull); else EKS_GF_LAUNCH(false, kGfRowsFull);
   }
-  void* args[] = {&Gc, &Mc, &FW, &y, &rconst, &s_kp, &nll, &dnll, &Fc, &L};
-  e = hipLaunchCooperativeKernel(fn, grid, block, args, 0, st);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    return EKS_ERR_UNSUPPORTED;
-  }
-  return EKS_OK;
-}
-
-bool diag_nll_adam_loop_ok(int T, int K, int D, int n_blocks) {
-  const int N = K * D;
-  if (n_blocks != K || !diag_nll_grad_tree(T, K, D) || !grad_fused_ok(T, N, D, 1, 1) || knob_int(KNOB_ADAM_PER_ITERATION, 0))
-    return false;
-  const NllGeom G = make_geom(T, N, D, 1, 1, true, pick_ncl(1, true));
-  const long blocks = (long)G.ntile * ((G.ncn + kGfWaves - 1) / kGfWaves);
-  const bool few = blocks <= kGfFewBlocks;
-  return gf_resident_blocks(true, few) >= blocks && gf_resident_blocks(false, few) >= blocks;
-}
-
-// eks_adam_run's n_iters iterations in one launch (see GfLoop); EKS_ERR_UNSUPPORTED: take the per-iteration launches
-int diag_nll_adam_loop(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M, int n_iters,
-                       double* nll, double* dnll, const AdamFuse& F, void* ws, size_t ws_bytes, hipStream_t st) {
-  const int T = d.n_frames, D = d.state_dim, N = d.n_keypoints * D;
-  if (n_iters < 2 || !F.state || !F.step_in_kernel || !grad_fused_ok(T, N, D, 1, 1) ||
-      knob_int(KNOB_ADAM_PER_ITERATION, 0) || ws_bytes < diag_nll_workspace_bytes(T, N, 1))
-    return EKS_ERR_UNSUPPORTED;
-  const NllGeom G = make_geom(T, N, D, 1, 1, true, pick_ncl(1, true));
-  return grad_fused_launch(d, G, y, rconst, M, F.s_keypoint, nll, dnll, ws, st, F, true, n_iters);
+#undef EKS_GF_LAUNCH
+  return hip_status(hipGetLastError());
 }
 
 static int diag_nll_impl(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M,
@@ -1971,7 +1763,7 @@ static int diag_nll_impl(const eks_dims_t& d, const float* y, const double* rcon
   const int ncl = pick_ncl(n_cand, grad);
   NllGeom G = make_geom(T, N, D, n_cand, per_keypoint, grad, ncl);
   if (grad && grad_fused_ok(T, N, D, n_cand, per_keypoint))
-    return grad_fused_launch(d, G, y, rconst, M, s_cand, nll, dnll, ws, st, F, fuse != nullptr, 0);
+    return grad_fused_launch(d, G, y, rconst, M, s_cand, nll, dnll, ws, st, F, fuse != nullptr);
   // ---- grid search on whole 64-chain tiles: head + lean roles in one launch (round 4)
   if (!grad && !F.state && lean_grid_ok(T, N, D, n_cand)) {
     G.nt_log2 = 6;
@@ -2139,14 +1931,6 @@ static int diag_nll_impl(const eks_dims_t& d, const float* y, const double* rcon
 #ifdef EKS_GRID_STAMPS
 extern "C" int eks_debug_grid_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(eks::g_grid_stamps), sizeof(eks::g_grid_stamps));
-}
-#endif
-#ifdef EKS_GF_STAMPS
-extern "C" int eks_debug_gf_stamps(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(eks::g_gf_stamps), sizeof(eks::g_gf_stamps));
-}
-extern "C" int eks_debug_gf_iter_stamps(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(eks::g_gf_iter), sizeof(eks::g_gf_iter));
 }
 #endif
 

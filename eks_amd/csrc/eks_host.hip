@@ -106,7 +106,7 @@ bool pandas_to_double(const char* p, const char* end, double* out, bool* is_int)
     }
     int nd = 0, n = 0;
     while (nd < max_digits && p < end && is_digit(*p)) {
-      n = n * 10 + (*p - '0');
+      if (n < 100000) n = n * 10 + (*p - '0');    // (saturates: anything beyond +-616 is decided below, no signed overflow)
       ++nd;
       ++p;
     }
@@ -374,7 +374,7 @@ extern "C" int eks_csv_read_numeric(const char* path, int32_t skip_lines, double
           if (fe != nullptr) {
             if (!as_int) {
               if (isint[col]) isint[col] = 0;
-            } else if (std::fabs(v) > 9007199254740992.0) {
+            } else if (std::fabs(v) >= 9007199254740992.0) {
               status[(size_t)t] = EKS_CSV_FALLBACK;
               return;
             }
@@ -390,7 +390,7 @@ extern "C" int eks_csv_read_numeric(const char* path, int32_t skip_lines, double
             if (isint[col]) isint[col] = 0;        // (written once: the threads' flag arrays share cache lines)
           } else if (pandas_to_double(f, fe, &v, &as_int)) {
             if (!as_int && isint[col]) isint[col] = 0;
-            else if (std::fabs(v) > 9007199254740992.0) {
+            else if (std::fabs(v) >= 9007199254740992.0) {
               status[(size_t)t] = EKS_CSV_FALLBACK;  // an integer a double does not hold: pandas keeps it in int64
               return;
             }

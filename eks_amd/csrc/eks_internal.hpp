@@ -30,7 +30,7 @@ enum Knob {
   KNOB_SMOOTH_UNFUSED, KNOB_SUMMARIZE_REVERSE, KNOB_REPLAY_FORWARD, KNOB_REPLAY_RECOMPUTE, KNOB_SCAN_CH,
   KNOB_SMOOTH_TILE, KNOB_DENSE_CHUNK, KNOB_NLL_NCL, KNOB_NLL_CHUNK, KNOB_NLL_CHUNK0, KNOB_NLL_WPB,
   KNOB_NLL_EXACT_ENTRY, KNOB_NLL_ASSEMBLE_SEQ, KNOB_DENSE_LEGACY, KNOB_NLL_GRAD_UNFUSED, KNOB_NLL_GRAD_CHUNK,
-  KNOB_DENSE_TREE_SCAN, KNOB_DENSE_DUAL_GRAD, KNOB_NLL_LEGACY, KNOB_MED_ROWS, KNOB_NLL_ASM_WAVES, KNOB_DW_CHUNK, KNOB_ADAM_PER_ITERATION, KNOB_MED_FINISH_THREADS, KNOB_MED_BRACKET_THREADS, KNOB_NLL_NOLAG, KNOB_NLL_GRAD_TREE, KNOB_ADAM_LOOP_SPINS, KNOB_ADAM_STREAM, KNOB_ADAM_LAG_RHO_PPM, KNOB_COUNT
+  KNOB_DENSE_TREE_SCAN, KNOB_DENSE_DUAL_GRAD, KNOB_NLL_LEGACY, KNOB_MED_ROWS, KNOB_NLL_ASM_WAVES, KNOB_DW_CHUNK, KNOB_ADAM_PER_ITERATION, KNOB_MED_FINISH_THREADS, KNOB_MED_BRACKET_THREADS, KNOB_NLL_NOLAG, KNOB_NLL_GRAD_TREE, KNOB_ADAM_STREAM, KNOB_ADAM_LAG_RHO_PPM, KNOB_COUNT
 };
 bool knob_set(Knob k);               // the variable exists
 int knob_int(Knob k, int dflt);      // its integer value, or dflt when unset
@@ -85,12 +85,11 @@ bool diag_nll_grad_tree(int T, int K, int D);
 bool diag_nll_adam_persist_ok(int T, int K, int D, int n_blocks);
 int diag_nll_adam_persist(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M, int n_iters,
                           double* nll, double* dnll, const AdamFuse& F, int32_t* n_active, hipStream_t st);
-int diag_nll_adam_loop(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M, int n_iters,
-                       double* nll, double* dnll, const AdamFuse& F, void* ws, size_t ws_bytes, hipStream_t st);
-bool diag_nll_adam_loop_ok(int T, int K, int D, int n_blocks);   // would eks_adam_run take the in-launch loop?
 // the search from cached lag sums (eks_lag_adam.hip): one pre-pass + one launch per eks_adam_run call
 bool diag_lag_adam_ok(int T, int K, int D, int n_blocks);
 size_t diag_lag_adam_workspace_bytes(int T, int N);
+int diag_lag_sums(const eks_dims_t& d, const float* y, const double* A, const AdamFuse* F, void* ws, size_t ws_bytes,
+                  hipStream_t st);
 int diag_lag_adam(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M, int n_iters, double* nll,
                   double* dnll, const AdamFuse& F, void* ws, size_t ws_bytes, hipStream_t st);
 size_t adam_extra_bytes(int N);     // tail of the NLL workspace: keypoint -> block map, tile tickets, counter

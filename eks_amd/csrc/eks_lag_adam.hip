@@ -36,6 +36,10 @@ constexpr int kLaL = 256;              // lag sums c_0 .. c_255
 constexpr int kLaWaves = kLaL / 32;    // waves of a pre-pass block
 constexpr int kLaMinT = 1024;          // (shorter sessions: diag_nll_adam_persist_kernel)
 constexpr int kLaMaxD = 4;
+#ifndef EKS_LA_AHEAD
+#define EKS_LA_AHEAD 8
+#endif
+constexpr int kLaAhead = EKS_LA_AHEAD;   // frames between the request of a row and its use (pre-pass).  Measured on BASELINE configs[2]: 8 / 12 / 16 / 32 frames 388 / 399 / 447 / 920 us - beyond 8 the allocator spills loaded rows, whose stores wait for the loads
 static_assert(kLaB0 == kLaL, "the delayed rings of the pre-pass reach back L + 1 frames from F: B0 >= L keeps them inside the array");
 
 // |rho| up to which 256 lag sums give the polynomial to 2e-10 (1 - |rho|)^-1 of itself WHATEVER the data (all lag sums
@@ -50,13 +54,16 @@ static double lag_adam_rho_max() {
 }
 
 // ---- rows through a buffer resource based `base_row` rows into the array (scalar row offsets: no VALU address
-// arithmetic); frames past the end read the last row again (their inputs are masked)
+// arithmetic).  Frames in front of B0 read row B0 and frames past the end the last row: with a = 1 the inputs
+// u_t = y_t - y_{t-1} of all frames outside [F, T) are then exactly zero - what the lag sums want - without a mask
+// (other models multiply by one)
 struct LagRows {
   __amdgpu_buffer_rsrc_t rsrc;
   unsigned voff, row_bytes;
   int base_row, last_row;
   __device__ __forceinline__ float operator()(int t) const {       // t: frame index (wave-uniform)
-    const int tc = t < last_row ? t : last_row;
+    int tc = t < last_row ? t : last_row;
+    tc = tc > kLaB0 ? tc : kLaB0;
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (unsigned)(tc - base_row) * row_bytes, 0));
   }
 };
@@ -93,24 +100,24 @@ __device__ __forceinline__ void lag_wave_body(const LagPre& P, const LagRows& ld
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
       const int tA = td0 - 32 + 2 * p;
-      const float mA = tA >= kLaF ? 1.f : 0.f, mB = tA + 1 >= kLaF ? 1.f : 0.f;
-      ring[16 + p] = f32x2{input(h[2 * p + 1], h[2 * p]) * mA, input(h[2 * p + 2], h[2 * p + 1]) * mB};
+      ring[16 + p] = f32x2{input(h[2 * p + 1], h[2 * p]), input(h[2 * p + 2], h[2 * p + 1])};
+      if constexpr (!UNIT) ring[16 + p] = ring[16 + p] * f32x2{tA >= kLaF ? 1.f : 0.f, tA + 1 >= kLaF ? 1.f : 0.f};
     }
     yd_prev = h[32];
     yc_prev = W0 ? h[32] : ld(ts0 - 1);
   }
-  // rows: ONE set of 16 frames per stream, every register asked for again (the same frame of the next 16) as soon as
-  // it has been consumed - 16 frames (264 packed FMAs) of distance between a request and its use
-  float rc[16], rd[16];
-  auto half = [&](auto h_tag, auto edge_tag, int t) {
+  // rows: 32 frames per stream, every register asked for again (the same frame 32 further on) as soon as it has been
+  // consumed - 32 frames (528 packed FMAs, ~1 us) between a request and its use
+  float rc[kLaAhead], rd[kLaAhead];
+  auto half = [&](auto h_tag, int t) {
     constexpr int H = decltype(h_tag)::value;
-    constexpr bool EDGE = decltype(edge_tag)::value != 0;
+    constexpr bool EDGE = !UNIT;                       // (masks: see LagRows)
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
       const int Pp = 8 * H + a;
-      const float y0 = rc[2 * a], y1 = rc[2 * a + 1];
-      rc[2 * a] = ld(t + 16 + 2 * a);
-      rc[2 * a + 1] = ld(t + 16 + 2 * a + 1);
+      const float y0 = rc[(16 * H + 2 * a) % kLaAhead], y1 = rc[(16 * H + 2 * a + 1) % kLaAhead];
+      rc[(16 * H + 2 * a) % kLaAhead] = ld(t + kLaAhead + 2 * a);
+      rc[(16 * H + 2 * a + 1) % kLaAhead] = ld(t + kLaAhead + 2 * a + 1);
       f32x2 Xc = f32x2{input(y0, yc_prev), input(y1, y0)};
       yc_prev = y1;
       if constexpr (EDGE) {
@@ -120,9 +127,9 @@ __device__ __forceinline__ void lag_wave_body(const LagPre& P, const LagRows& ld
       if constexpr (W0) {
         ring[Pp] = Xc;
       } else {
-        const float z0 = rd[2 * a], z1 = rd[2 * a + 1];
-        rd[2 * a] = ld(t - delay + 16 + 2 * a);
-        rd[2 * a + 1] = ld(t - delay + 16 + 2 * a + 1);
+        const float z0 = rd[(16 * H + 2 * a) % kLaAhead], z1 = rd[(16 * H + 2 * a + 1) % kLaAhead];
+        rd[(16 * H + 2 * a) % kLaAhead] = ld(t - delay + kLaAhead + 2 * a);
+        rd[(16 * H + 2 * a + 1) % kLaAhead] = ld(t - delay + kLaAhead + 2 * a + 1);
         f32x2 Xd = f32x2{input(z0, yd_prev), input(z1, z0)};
         yd_prev = z1;
         if constexpr (EDGE) {
@@ -141,11 +148,11 @@ __device__ __forceinline__ void lag_wave_body(const LagPre& P, const LagRows& ld
       EKS_SCHED_FENCE();
     }
   };
-  auto super_set = [&](auto edge_tag, int ts) {
-    half(IntTag<0>(), edge_tag, ts);
-    half(IntTag<1>(), edge_tag, ts + 16);
-    half(IntTag<2>(), edge_tag, ts + 32);
-    half(IntTag<3>(), edge_tag, ts + 48);
+  auto super_set = [&](int ts) {
+    half(IntTag<0>(), ts);
+    half(IntTag<1>(), ts + 16);
+    half(IntTag<2>(), ts + 32);
+    half(IntTag<3>(), ts + 48);
     // float32 partial sums span 64 frames: into the float64 sums
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
@@ -155,18 +162,15 @@ __device__ __forceinline__ void lag_wave_body(const LagPre& P, const LagRows& ld
     }
 #pragma unroll
     for (int jj = 0; jj < 17; ++jj) O[jj] = f32x2{0.f, 0.f};
+    EKS_SCHED_FENCE();                                 // (the next super-set's sums reuse these registers: not beside them)
   };
 #pragma unroll
-  for (int q = 0; q < 16; ++q) rc[q] = ld(ts0 + q);
+  for (int q = 0; q < kLaAhead; ++q) rc[q] = ld(ts0 + q);
   if constexpr (!W0) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) rd[q] = ld(td0 + q);
+    for (int q = 0; q < kLaAhead; ++q) rd[q] = ld(td0 + q);
   }
-  for (int ss = 0; ss < nss; ++ss) {
-    const int ts = ts0 + 64 * ss;
-    const bool edge = ts - delay - 32 < kLaF || ts + 64 > T;          // (wave-uniform)
-    if (edge) super_set(IntTag<1>(), ts); else super_set(IntTag<0>(), ts);
-  }
+  for (int ss = 0; ss < nss; ++ss) super_set(ts0 + 64 * ss);
 }
 
 template <bool UNIT>
@@ -193,8 +197,9 @@ __global__ __launch_bounds__(64 * kLaWaves) void lag_sums_kernel(LagPre P) {
   double* acc = acc_all + (size_t)w * 32 * 64 + lane;
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i * 64] = 0.0;
-  if (w == 0) lag_wave_body<UNIT, true>(P, ld, ts0, nss, 0, a_d, acc);
-  else lag_wave_body<UNIT, false>(P, ld, ts0, nss, w, a_d, acc);
+  // (wave 0's "delayed" stream is the current one: the same code as the others - a variant of its own made the
+  //  register allocator spill in that variant: 1.16 against 0.66 ms on BASELINE configs[2])
+  lag_wave_body<UNIT, false>(P, ld, ts0, nss, w, a_d, acc);
   if (n_raw < P.N) {
 #pragma unroll 4
     for (int i = 0; i < 32; ++i) P.part[((size_t)j * kLaL + w * 32 + i) * P.N + n] = acc[i * 64];
@@ -410,35 +415,61 @@ __device__ __forceinline__ DualD la_nll_stream(const LaConst& K, const float* __
       b *= b;
     }
   }
-  DualD al(1.0), be(0.0), Qaa(0.0), Qab(0.0), Qbb(0.0);
+  // the innovations of the lane's frames as alpha e_in + beta (e_in: the innovation of its first frame): sums of
+  // g_t (alpha e_in + beta)^2 as three dual numbers.  Once w_t = w_0 kappa^t is below 1e-18 for every lane the variance
+  // IS the fixed point: constants instead of two reciprocals per frame, and the weights g come out of the sums.
+  DualD al(1.0), be(0.0), Qaa(0.0), Qab(0.0), Qbb(0.0), Saa(0.0), Sab(0.0), Sbb(0.0);
   double pprod = 1.0, dlog = 0.0;
+  int n_steady = 0;
   constexpr int NB = 8;
   float buf[NB + 1];
   auto fetch = [&](int t) {                                   // rows t .. t + NB (clamped)
 #pragma unroll
     for (int q = 0; q <= NB; ++q) buf[q] = yc[min(t + q, T - 1)];
   };
+  const double w0a = fabs(K.w0);
   for (int t = t0; t < t1; t += NB) {
     fetch(t);
+    const bool steady = __all(w0a * kt < 1e-18) != 0 && t > 0;
+    if (steady) {
 #pragma unroll
-    for (int q = 0; q < NB; ++q) {
-      const int tt = t + q;
-      if (tt < t1) {
-        DualD St, gt, rt;
-        la_frame(K, tt, kt, St, gt, rt);
-        kt *= K.kap;
-        pprod *= St.v * K.g.v;
-        dlog += St.d * gt.v;
-        Qaa = Qaa + gt * al * al;
-        Qab = Qab + gt * al * be;
-        Qbb = Qbb + gt * be * be;
-        const double u = tt + 1 < T ? (double)buf[q + 1] - K.a * (double)buf[q] : 0.0;
-        al = rt * al;
-        be = rt * be + DualD(u);
-        if (fabs(al.v) < 1e-80) al = DualD(0.0);
+      for (int q = 0; q < NB; ++q) {
+        if (t + q < t1) {
+          Saa = Saa + al * al;
+          Sab = Sab + al * be;
+          Sbb = Sbb + be * be;
+          const double u = t + q + 1 < T ? (double)buf[q + 1] - K.a * (double)buf[q] : 0.0;
+          al = K.rho * al;
+          be = K.rho * be + DualD(u);
+          if (fabs(al.v) < 1e-80) al = DualD(0.0);
+          ++n_steady;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
+        const int tt = t + q;
+        if (tt < t1) {
+          DualD St, gt, rt;
+          la_frame(K, tt, kt, St, gt, rt);
+          kt *= K.kap;
+          pprod *= St.v * K.g.v;
+          dlog += St.d * gt.v;
+          Qaa = Qaa + gt * al * al;
+          Qab = Qab + gt * al * be;
+          Qbb = Qbb + gt * be * be;
+          const double u = tt + 1 < T ? (double)buf[q + 1] - K.a * (double)buf[q] : 0.0;
+          al = rt * al;
+          be = rt * be + DualD(u);
+          if (fabs(al.v) < 1e-80) al = DualD(0.0);
+        }
       }
     }
   }
+  Qaa = Qaa + K.g * Saa;
+  Qab = Qab + K.g * Sab;
+  Qbb = Qbb + K.g * Sbb;
+  dlog += (double)n_steady * K.Sinf.d * K.g.v;
   LaAff el{al, be};
   la_scan(el);
   const DualD e_first(e0);
@@ -575,40 +606,65 @@ size_t diag_lag_adam_workspace_bytes(int T, int N) {
          align_up((size_t)N * T * sizeof(float), 256);
 }
 
-int diag_lag_adam(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M, int n_iters, double* nll,
-                  double* dnll, const AdamFuse& F, void* ws, size_t ws_bytes, hipStream_t st) {
-  const int T = d.n_frames, D = d.state_dim, K = d.n_keypoints, N = K * D;
-  if (ws_bytes < diag_lag_adam_workspace_bytes(T, N)) return EKS_ERR_WORKSPACE;
+struct LagWs {
+  double *part, *ck;
+  float* yT;
   int nch, cl;
-  lag_geometry(T, N, &nch, &cl);
-  if ((long)(cl + kLaL + 64 + 64) * N * 4 >= (1L << 31)) return EKS_ERR_UNSUPPORTED;   // 32-bit row offsets of a chunk
+};
+static int lag_ws(int T, int N, void* ws, size_t ws_bytes, LagWs* W) {
+  if (ws_bytes < diag_lag_adam_workspace_bytes(T, N)) return EKS_ERR_WORKSPACE;
+  lag_geometry(T, N, &W->nch, &W->cl);
+  if ((long)(W->cl + kLaL + 64 + 64) * N * 4 >= (1L << 31)) return EKS_ERR_UNSUPPORTED;   // 32-bit row offsets of a chunk
   char* p = static_cast<char*>(ws);
-  double* part = reinterpret_cast<double*>(p);
-  p += align_up((size_t)nch * kLaL * N * sizeof(double), 256);
-  double* ck = reinterpret_cast<double*>(p);
+  W->part = reinterpret_cast<double*>(p);
+  p += align_up((size_t)W->nch * kLaL * N * sizeof(double), 256);
+  W->ck = reinterpret_cast<double*>(p);
   p += align_up((size_t)N * kLaL * sizeof(double), 256);
-  float* yT = reinterpret_cast<float*>(p);
+  W->yT = reinterpret_cast<float*>(p);
+  return EKS_OK;
+}
+
+// the pass over y: lag sums into the workspace (eks_adam_prepare, or the first thing an eks_adam_run call does).  With an
+// optimiser state (F) the tiles none of whose keypoints still runs are skipped.
+int diag_lag_sums(const eks_dims_t& d, const float* y, const double* A, const AdamFuse* F, void* ws, size_t ws_bytes,
+                  hipStream_t st) {
+  const int T = d.n_frames, D = d.state_dim, N = d.n_keypoints * D;
+  LagWs W;
+  const int rc = lag_ws(T, N, ws, ws_bytes, &W);
+  if (rc != EKS_OK) return rc;
   const int ntile = (N + 63) / 64;
   {
     ProfScope ps("lag_sums", st);
-    const LagPre P{T, N, D, ntile, nch, cl, y, M.A, part, F.state, F.kp_block, F.cap};
-    const dim3 grid((unsigned)(ntile * nch)), block(64 * kLaWaves);
+    const LagPre P{T, N, D, ntile, W.nch, W.cl, y, A, W.part, F ? F->state : nullptr, F ? F->kp_block : nullptr,
+                   F ? F->cap : 0};
+    const dim3 grid((unsigned)(ntile * W.nch)), block(64 * kLaWaves);
     if (d.flags & EKS_FLAG_UNIT_AC) hipLaunchKernelGGL(lag_sums_kernel<true>, grid, block, 0, st, P);
     else hipLaunchKernelGGL(lag_sums_kernel<false>, grid, block, 0, st, P);
   }
   {
     ProfScope ps("lag_reduce", st);
     const long lanes = (long)N * kLaL;
-    hipLaunchKernelGGL(lag_reduce_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, N, nch, part, ck);
+    hipLaunchKernelGGL(lag_reduce_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, N, W.nch, W.part, W.ck);
   }
-  {
-    ProfScope ps("lag_adam", st);
-    static const double rho_max = lag_adam_rho_max();
-    const int rm = knob_int(KNOB_ADAM_LAG_RHO_PPM, -1);          // (tests: the pole beyond which a chain streams)
-    const LagAdam P{T, N, D, y, rconst, M.m0, M.S0, M.A, M.C, M.Q, ck, yT, F.kp_block, F.lr, F.lo, F.hi, F.tol, F.cap,
-                    n_iters, rm >= 0 ? 1e-6 * rm : rho_max, F.state, F.s_keypoint, nll, dnll, F.n_active_cur};
-    hipLaunchKernelGGL(lag_adam_kernel, dim3((unsigned)K), dim3(64, D), 0, st, P);
+  return hip_status(hipGetLastError());
+}
+
+int diag_lag_adam(const eks_dims_t& d, const float* y, const double* rconst, const DiagModel& M, int n_iters, double* nll,
+                  double* dnll, const AdamFuse& F, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int T = d.n_frames, D = d.state_dim, K = d.n_keypoints, N = K * D;
+  LagWs W;
+  int rc = lag_ws(T, N, ws, ws_bytes, &W);
+  if (rc != EKS_OK) return rc;
+  if (!(d.flags & EKS_FLAG_ADAM_PREPARED)) {
+    rc = diag_lag_sums(d, y, M.A, &F, ws, ws_bytes, st);
+    if (rc != EKS_OK) return rc;
   }
+  ProfScope ps("lag_adam", st);
+  static const double rho_max = lag_adam_rho_max();
+  const int rm = knob_int(KNOB_ADAM_LAG_RHO_PPM, -1);          // (tests: the pole beyond which a chain streams)
+  const LagAdam P{T, N, D, y, rconst, M.m0, M.S0, M.A, M.C, M.Q, W.ck, W.yT, F.kp_block, F.lr, F.lo, F.hi, F.tol, F.cap,
+                  n_iters, rm >= 0 ? 1e-6 * rm : rho_max, F.state, F.s_keypoint, nll, dnll, F.n_active_cur};
+  hipLaunchKernelGGL(lag_adam_kernel, dim3((unsigned)K), dim3(64, D), 0, st, P);
   return hip_status(hipGetLastError());
 }
 

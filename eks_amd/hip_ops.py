@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import FLAG_DIAG_MODEL, FLAG_Q_PD, FLAG_UNIT_AC, FLAG_VS_DIAG, EksDims
+from ._lib import FLAG_ADAM_PREPARED, FLAG_DIAG_MODEL, FLAG_Q_PD, FLAG_UNIT_AC, FLAG_VS_DIAG, EksDims
 
 
 _auto_warm = [False]
@@ -401,6 +401,19 @@ class AdamLoop:
         self.n_active = torch.zeros(1, dtype=torch.int32, device=dev)
         self.dims = _dims(K, T, D, O, flags)
         self.ws = _workspace(self.lib.eks_nll_workspace_bytes(ctypes.byref(self.dims), 1), dev)
+
+    def prepare(self) -> bool:
+        """eks_adam_prepare: the pass over y that does not depend on the optimiser's state, enqueued now - the caller may
+        fill `state` / `s_keypoint` (e.g. from initial guesses it is still waiting for) before the first run().  False:
+        this problem's search does not use such a pass (nothing was enqueued)."""
+        rc = self.lib.eks_adam_prepare(ctypes.byref(self.dims), _ptr(self.bufs[0]), _ptr(self.bufs[4]), self.nb,
+                                       _ptr(self.ws), self.ws.numel(), _stream())
+        if rc == _lib.EKS_ERR_UNSUPPORTED:
+            return False
+        _lib.check(rc, 'eks_adam_prepare')
+        self.dims = _dims(self.dims.n_keypoints, self.dims.n_frames, self.dims.state_dim, self.dims.obs_dim,
+                          self.dims.flags | FLAG_ADAM_PREPARED)
+        return True
 
     def stride(self) -> int:
         """eks_adam_run_stride: iterations to ask for per run() on this problem (the spacing of the caller's reads of

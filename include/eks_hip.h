@@ -55,6 +55,9 @@ typedef struct ihipStream_t* eks_stream_t; /* == hipStream_t */
                                   identity: exact, plain float64) instead of dual numbers through the scan.
                                   Without the flag the dual-number kernels run (any PSD Q). */
 
+#define EKS_FLAG_ADAM_PREPARED 16u /* eks_adam_run: eks_adam_prepare has run on this (dims, y, A, workspace) and nothing
+                                     has written the workspace since - the call skips its own pass over y */
+
 typedef struct {
   int32_t n_keypoints; /* K */
   int32_t n_frames;    /* T */
@@ -149,11 +152,13 @@ int eks_adam_step(int32_t n_blocks, const int32_t* block_offsets, const int32_t*
  * both the evaluation point and the step's output; nll, dnll [K] hold the last evaluation.
  * Iterations enqueued after a block has stopped leave it untouched, so the caller may issue
  * n_iters at a time and read *n_active in between.  workspace: eks_nll_workspace_bytes(dims, 1).
- * Scalar chains with one keypoint per block: all n_iters iterations are ONE launch - a workgroup per keypoint for
- * short sessions, the chip-wide loss kernel launched cooperatively for long ones (its workgroups wait for each other:
- * one that waits in vain - e.g. another process holds the compute units - gives up after a bounded number of polls
- * and the call reports *n_active < 0: its results are invalid; EKS_ADAM_PER_ITERATION=1 selects a launch per
- * iteration, with identical results). */
+ * Scalar chains with one keypoint per block (the reference's default, blocks = []): all n_iters iterations are ONE
+ * launch with a workgroup per keypoint and no exchange between workgroups.  Sessions of 1 024 frames and more (at most
+ * four chains per keypoint) do not read y per iteration at all: one streaming pass leaves 256 lag sums of the inputs
+ * u_t = y_t - a y_{t-1} per chain - they do not depend on s - and every iteration evaluates loss and gradient from those
+ * plus the first / last 257 rows (eks_amd/csrc/eks_lag_adam.hip); a chain whose pole leaves the range the sums cover
+ * (|rho| > 0.906) is evaluated exactly from a private copy of its frames instead.  eks_adam_prepare runs that pass ahead
+ * of time (see EKS_FLAG_ADAM_PREPARED). */
 int eks_adam_run(const eks_dims_t* dims, const float* y, const double* rconst, const double* m0,
                  const double* S0, const double* A, const double* C, const double* Q,
                  int32_t n_blocks, const int32_t* block_offsets, const int32_t* block_members,
@@ -161,14 +166,21 @@ int eks_adam_run(const eks_dims_t* dims, const float* y, const double* rconst, c
                  double* state, double* s_keypoint, double* nll, double* dnll, int32_t* n_active,
                  void* workspace, size_t workspace_bytes, eks_stream_t stream);
 
+/* ---- the pass over y of eks_adam_run's scalar-chain search, ahead of the optimiser's starting point: the reference
+ * computes its initial guesses from the ensemble variances on the host (eks/core.py:233-236), and this pass needs only
+ * y and A - a caller enqueues it, fetches the guesses while it runs, uploads the state and calls eks_adam_run with
+ * EKS_FLAG_ADAM_PREPARED set in dims->flags.  Returns EKS_ERR_UNSUPPORTED (nothing enqueued) where eks_adam_run would
+ * not use the sums (other model classes, blocks of several keypoints, short sessions): call eks_adam_run without the
+ * flag then.  workspace: the one eks_adam_run will be given. */
+int eks_adam_prepare(const eks_dims_t* dims, const float* y, const double* A, int32_t n_blocks, void* workspace,
+                     size_t workspace_bytes, eks_stream_t stream);
+
 /* ---- how many iterations one eks_adam_run call should ask for on this problem, device and library build: the calls
  * are what the caller's host round trips (reading *n_active) are spaced by, and what they cost differs by the form the
- * loop takes - 128 where the chip-wide loss kernel keeps its workgroups for the whole call (one cooperative launch,
- * ~70 us to start, an over-issued call returns at once), 64 for short sessions (one launch, a workgroup per keypoint),
- * 16 where every iteration is its own launch on scalar chains (an over-issued iteration is a launch that returns at
- * once), 4 on the general (D, O) path (an over-issued iteration is a full evaluation).  *n_active < 0 after a call:
- * the in-launch loop gave up waiting (the call's results are invalid).  No reference counterpart (the reference's
- * loop is one XLA while_loop, eks/core.py:654-681). */
+ * loop takes - 4 096 (i.e. the whole search in one call) where the search runs from cached lag sums, 64 for short sessions
+ * (one launch, a workgroup per keypoint), 16 where every iteration is its own launch on scalar chains (an over-issued
+ * iteration is a launch that returns at once), 4 on the general (D, O) path (an over-issued iteration is a full
+ * evaluation).  No reference counterpart (the reference's loop is one XLA while_loop, eks/core.py:654-681). */
 int32_t eks_adam_run_stride(const eks_dims_t* dims, int32_t n_blocks);
 
 /* ---- IBL pupil smoother, eks/ibl_pupil_smoother.py:363-607.

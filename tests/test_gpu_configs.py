@@ -136,7 +136,7 @@ def test_c3_singlecam_100k_x_256_adam():
     (eks/core.py:562-699), loss over all 100 000 frames.  The device loop (loss + forward-mode gradient,
     finished keypoints skipped, the step applied at the end of the loss assembly) against the oracle's
     optimiser (oracle/eks_oracle.py: adam_optimize_s) fed by the C port's complex-step gradient, on a
-    64-keypoint sample (16 on hosts with fewer than 64 cores): same stopping iteration, |d log s| <= 1e-3; then the smoothed outputs at the
+    64-keypoint sample (16 on hosts with fewer than 64 cores): same stopping iteration, |d log s| <= 2e-6; then the smoothed outputs at the
     device's s within 1e-5 of the C port on every frame."""
     from concurrent.futures import ThreadPoolExecutor
     from eks_amd import hip_ops, synth
@@ -180,7 +180,7 @@ def test_c3_singlecam_100k_x_256_adam():
         u_o, last_o, it_o = orc.adam_optimize_s(loss_and_grad, u0)
     s_o = np.exp(np.clip(u_o, -8.0, 8.0))
     np.testing.assert_array_equal(st[sel, 4].astype(int), it_o)        # same stopping iteration
-    assert np.abs(np.log(s[sel]) - np.log(s_o)).max() < 1e-3
+    assert np.abs(np.log(s[sel]) - np.log(s_o)).max() < 2e-6   # (round 6: the search from cached lag sums)
     assert (np.abs(st[sel, 3] - last_o) / np.abs(last_o)).max() < TOL   # the last loss each saw
 
     # ---- final pass at the device's s, sample against the C port on every frame

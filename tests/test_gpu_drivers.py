@@ -552,8 +552,8 @@ def _adam_session(T, K, seed):
 
 
 def test_adam_sessions_from_two_threads_share_the_device(set_knob):
-    """The in-launch optimiser loop (round 5) is a cooperative launch whose workgroups wait for each other: two threads
-    searching at once on two streams must neither hang nor change a bit of either result."""
+    """Two threads searching at once on two streams (each search: a pass for the lag sums, then one launch of a workgroup
+    per keypoint - nothing in it waits for another workgroup): neither changes a bit of the other's result."""
     import threading
     import torch
     from eks_amd.core import run_kalman_smoother
@@ -581,29 +581,6 @@ def test_adam_sessions_from_two_threads_share_the_device(set_knob):
     for got, ref in zip(results, serial):
         for g, r in zip(got, ref):
             np.testing.assert_array_equal(np.asarray(g), np.asarray(r))
-
-
-def test_adam_loop_that_gives_up_is_repeated_with_a_launch_per_iteration(set_knob, caplog):
-    """A workgroup of the in-launch loop that never sees its tile's step gives up instead of hanging (bounded polls) and
-    marks the call (n_active < 0); the host layer repeats the search with one launch per iteration and says so.
-    EKS_ADAM_LOOP_SPINS=1 makes every waiting workgroup give up at once."""
-    import logging
-    from eks_amd import hip_ops
-    from eks_amd.core import run_kalman_smoother
-    sess = _adam_session(30_000, 64, 53)
-    ref = run_kalman_smoother(*sess)
-    set_knob('EKS_ADAM_PER_ITERATION', None)
-    set_knob('EKS_ADAM_LOOP_SPINS', '1')
-    try:
-        with caplog.at_level(logging.WARNING):
-            got = run_kalman_smoother(*sess)
-        assert any('gave up' in r.getMessage() for r in caplog.records)
-        assert os.environ.get('EKS_ADAM_PER_ITERATION') == '1'
-        for g, r in zip(got, ref):
-            np.testing.assert_array_equal(np.asarray(g), np.asarray(r))
-    finally:
-        os.environ.pop('EKS_ADAM_PER_ITERATION', None)
-        hip_ops._lib.load().eks_knobs_reload()
 
 
 def test_first_call_of_a_fresh_process_is_bounded():

@@ -57,6 +57,28 @@ def test_kernel_matches_sequential_extended_smoother(T, K, V):
         assert abs(nll[k] + ll) < 1e-9 * abs(ll)
 
 
+def test_loose_tolerance_still_smooths_at_the_points_it_stopped_at():
+    """once the filter sweeps meet the caller's tolerance the smoothing sweep reuses the elements in the
+    workspace instead of rebuilding them at the final linearisation points - fine at 1e-10, not at a loose tolerance.
+    The shortcut is taken below 1e-8 only: a call with tol = 1e-2 that stops after n sweeps must return exactly what a
+    call that is GIVEN n sweeps and never converges (tol = 0: the rebuild always runs) returns."""
+    import torch
+    from eks_amd import hip_ops
+    T, K, V = 1200, 3, 3
+    prob = synth.calibrated_multicam(T, K, V, seed=77)
+    s = np.exp(np.linspace(-3, 4, K))
+    m0 = _dev(prob['m0s'])
+    common = (_dev(prob['y_tko'], torch.float32), _dev(prob['var_tko'], torch.float32), None, m0, _dev(prob['S0s']),
+              _dev(prob['As']), _dev(prob['Qs']), _dev(s), _dev(prob['cams_packed']))
+    x_a = m0[:, None, :].expand(K, T, 3).contiguous()
+    ms_a, Vs_a, _, info_a = hip_ops.ekf_smooth(*common, x_a, max_sweeps=16, tol=1e-2)
+    n = int(info_a[0].item())
+    assert 1 <= n < 16 and 1e-8 < info_a[1].item() <= 1e-2            # stopped early, between the two thresholds
+    x_b = m0[:, None, :].expand(K, T, 3).contiguous()
+    ms_b, Vs_b, _, _ = hip_ops.ekf_smooth(*common, x_b, max_sweeps=n, tol=0.0)
+    assert torch.equal(ms_a, ms_b) and torch.equal(Vs_a, Vs_b)
+
+
 def test_constant_r_loss_over_replicated_chains_and_vs_diag():
     import torch
     from eks_amd import hip_ops

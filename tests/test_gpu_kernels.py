@@ -1050,55 +1050,195 @@ def test_initial_guesses_reduced_on_the_device_equal_the_host_reduction():
     assert np.array_equal(core._initial_guesses_per_keypoint(sd=sd), core._initial_guesses_per_keypoint(ev))
 
 
+def _adam_search(y, rc, params, flags, K, u0, cap=300, stride=None, tol=1e-2, prepare=False, lo=-8.0, hi=8.0):
+    """One search through hip_ops.AdamLoop in calls of `stride` iterations (None: what the library asks for).  Returns the
+    library's stride, state, s, last loss / gradient and the running count after every call."""
+    from eks_amd import hip_ops
+    offs = torch.arange(K + 1, dtype=torch.int32, device='cuda')
+    mem = torch.arange(K, dtype=torch.int32, device='cuda')
+    state = np.zeros((K, 6))
+    state[:, 0] = u0
+    state[:, 3] = np.inf
+    state = _dev(state)
+    s_kp = _dev(np.exp(np.clip(u0, lo, hi)))
+    loop = hip_ops.AdamLoop(y, rc, *params, offs, mem, state, s_kp, 0.25, lo, hi, tol, cap, flags=flags)
+    if prepare:
+        assert loop.prepare()
+    n = stride or loop.stride()
+    left, it = [], 0
+    while it < cap:
+        loop.run(min(n, cap - it))
+        it += n
+        left.append(int(loop.n_active.item()))
+        assert left[-1] >= 0
+        if left[-1] == 0:
+            break
+    return loop.stride(), state.cpu().numpy(), s_kp.cpu().numpy(), loop.nll.cpu().numpy(), loop.dnll.cpu().numpy(), left
+
+
+def _oracle_adam(arrs, y_tk, rc, ks, u0, cap=300, tol=1e-2, lo=-8.0, hi=8.0):
+    """oracle/eks_oracle.py: adam_optimize_s fed by the C port's complex-step gradient, keypoints `ks`."""
+    from oracle import c_oracle
+    D = arrs['As'].shape[-1]
+    ys = np.transpose(y_tk, (1, 0, 2)).astype(np.float64)
+    Rc = rc.cpu().numpy()
+    zero = np.zeros((1, D, D))
+
+    def loss_and_grad(u):
+        out = []
+        for j, k in enumerate(ks):
+            sQ = np.exp(u[j]) * arrs['Qs'][k]
+            L, g = c_oracle.nll_directional(ys[k], Rc[k], arrs['m0s'][k], arrs['S0s'][k], arrs['As'][k], arrs['Cs'][k],
+                                            sQ, zero, sQ[None])
+            out.append((L, g[0]))
+        return np.array([o[0] for o in out]), np.array([o[1] for o in out])
+
+    u_o, last_o, it_o = orc.adam_optimize_s(loss_and_grad, u0[ks], tol=tol, safety_cap=cap, s_bounds_log=(lo, hi))
+    return np.clip(u_o, lo, hi), last_o, it_o
+
+
 @pytest.mark.parametrize('T,K,unit,stride,cap', [(30_000, 70, True, 24, 300), (20_011, 33, False, 7, 300),
-                                                 (50_000, 128, True, 128, 300), (12_345, 300, False, 50, 300),
-                                                 (4_500, 40, True, 9, 300), (30_000, 70, True, 5, 13)])
-def test_adam_chip_wide_loop_in_one_launch_is_the_per_iteration_loop_bit_for_bit(T, K, unit, stride, cap, set_knob):
-    """Long sessions, one keypoint per optimiser block: an eks_adam_run call keeps the chip-wide loss kernel's
-    workgroups for all of its iterations (round 5: GfLoop in eks_diag_nll.hip - the tile's last block applies the step
-    and hands s to the tile's other blocks through tagged words).  The arithmetic of an iteration is that of a launch
-    per iteration (EKS_ADAM_PER_ITERATION=1), so the optimiser state, s, and the last loss and gradient must agree
-    bit for bit - also when calls end mid-search (stride 7 / 24), with a partial last tile (K = 70 / 33), and when the
-    safety cap ends the search (cap 13: nobody has stopped by the rule)."""
+                                                 (50_000, 128, True, None, 300), (1_024, 3, True, None, 300),
+                                                 (4_500, 40, False, 9, 300), (30_000, 70, True, 5, 13)])
+def test_adam_from_cached_lag_sums_is_the_streaming_search_and_the_oracles(T, K, unit, stride, cap, set_knob):
+    """Round 6 (eks_lag_adam.hip): one keypoint per optimiser block and at least 1 024 frames - eks_adam_run makes ONE
+    pass over y (256 lag sums of the inputs u_t = y_t - a y_{t-1} per chain, which do not depend on s) and then runs all
+    of a call's iterations in one launch, a workgroup per keypoint, evaluating loss and d / d log s from those sums and
+    the first / last 257 rows.  Against the kernels that read y every iteration (EKS_ADAM_STREAM=1) on the same problem:
+    the same stopping iteration for every keypoint, the same count of running keypoints after every call - also when
+    calls end mid-search (stride 7 / 24), with a partial last tile and when the safety cap ends the search (cap 13) - and
+    log s within 2e-6 (the lag sums are sums of float32 products: 1e-8 of noise in the loss).  Against the oracle's
+    optimiser on the C port's complex-step gradient (three keypoints): the same stopping iteration, log s within 2e-6,
+    the last loss within 1e-7."""
     from eks_amd import hip_ops
     arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=31 + T, unit=unit)
     flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
     y, rc = _dev(y_tk), hip_ops.const_r(_dev(var_tk), 1e-4)
     params = _params_dev(arrs)
-    offs = torch.arange(K + 1, dtype=torch.int32, device='cuda')
-    mem = torch.arange(K, dtype=torch.int32, device='cuda')
     u0 = np.log(np.random.default_rng(T).uniform(0.05, 50.0, K))
-
-    def run():
-        state = np.zeros((K, 6))
-        state[:, 0] = u0
-        state[:, 3] = np.inf
-        state = _dev(state)
-        s_kp = _dev(np.exp(u0))
-        loop = hip_ops.AdamLoop(y, rc, *params, offs, mem, state, s_kp, 0.25, -8.0, 8.0, 1e-2, cap, flags=flags)
-        left = []
-        for _ in range((cap + stride - 1) // stride):
-            loop.run(stride)
-            left.append(int(loop.n_active.item()))
-            assert left[-1] >= 0
-            if left[-1] == 0:
-                break
-        return loop.stride(), state.cpu().numpy(), s_kp.cpu().numpy(), loop.nll.cpu().numpy(), loop.dnll.cpu().numpy(), left
-
-    n_loop, st_l, s_l, nll_l, g_l, left_l = run()
-    assert n_loop == 128                     # (the in-launch loop is what ran)
-    set_knob('EKS_ADAM_PER_ITERATION', '1')
-    n_it, st_i, s_i, nll_i, g_i, left_i = run()
-    assert n_it == 16
+    n_l, st_l, s_l, nll_l, g_l, left_l = _adam_search(y, rc, params, flags, K, u0, cap, stride)
+    assert n_l == 4096                       # (the lag-sum search is what ran: the whole search in one call)
+    set_knob('EKS_ADAM_STREAM', '1')
+    n_s, st_s, s_s, nll_s, g_s, left_s = _adam_search(y, rc, params, flags, K, u0, cap, stride or 16)
+    assert n_s in (16, 64)
     if cap == 300:
         assert st_l[:, 4].max() > 20 and np.all(st_l[:, 5] == 1.0)
     else:
         assert np.all(st_l[:, 4] == cap) and np.all(st_l[:, 5] == 0.0) and left_l[-1] == 0
-    np.testing.assert_array_equal(st_l, st_i)
-    np.testing.assert_array_equal(s_l, s_i)
-    np.testing.assert_array_equal(nll_l, nll_i)
-    np.testing.assert_array_equal(g_l, g_i)
-    assert left_l == left_i                   # keypoints still running after every call
+    np.testing.assert_array_equal(st_l[:, 4:], st_s[:, 4:])                  # iterations taken, stopped by the rule
+    if stride:
+        assert left_l == left_s                                              # keypoints still running after every call
+    assert np.abs(np.log(s_l) - np.log(s_s)).max() < 2e-6
+    assert np.abs(nll_l / nll_s - 1).max() < 1e-7
+    assert np.abs(g_l - g_s).max() <= 2e-5 * np.abs(g_s).max() + 1e-3
+    if cap == 300 and T <= 30_000:
+        ks = list(range(min(K, 3)))
+        u_o, last_o, it_o = _oracle_adam(arrs, y_tk, rc, ks, u0, cap)
+        np.testing.assert_array_equal(st_l[ks, 4].astype(int), it_o)
+        assert np.abs(np.log(s_l[ks]) - u_o).max() < 2e-6
+        assert np.abs(st_l[ks, 3] / last_o - 1).max() < 1e-7
+
+
+@pytest.mark.parametrize('T,K,unit,ppm', [(20_000, 40, True, 0), (9_000, 33, False, 0), (20_000, 40, True, 450_000),
+                                         (3_000, 5, False, 300_000)])
+def test_adam_chains_outside_the_lag_range_stream_their_own_frames_exactly(T, K, unit, ppm, set_knob):
+    """A chain whose pole leaves the range the 256 lag sums cover (|rho| > 0.906) is evaluated by its own wave from a
+    private chain-major copy of its frames - closed-form variances, lane = time chunk, the same 64-lane scan - in float64
+    throughout.  EKS_ADAM_LAG_RHO_PPM moves that bound: 0 streams every evaluation, 450 000 / 300 000 switch between the
+    two forms in the middle of most searches (poles of these problems run from 0.05 to 0.8).  Against the oracle's
+    optimiser: the same stopping iteration and log s within 1e-6 whatever the mixture (all-streamed: within 1e-9 - that
+    form rounds nothing to float32)."""
+    from eks_amd import hip_ops
+    arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=77 + T, unit=unit)
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    y, rc = _dev(y_tk), hip_ops.const_r(_dev(var_tk), 1e-4)
+    params = _params_dev(arrs)
+    u0 = np.log(np.random.default_rng(T).uniform(0.05, 50.0, K))
+    set_knob('EKS_ADAM_LAG_RHO_PPM', str(ppm))
+    n_f, st_f, s_f, nll_f, g_f, _ = _adam_search(y, rc, params, flags, K, u0)
+    assert n_f == 4096 and np.all(st_f[:, 5] == 1.0)
+    ks = list(range(min(K, 4)))
+    u_o, last_o, it_o = _oracle_adam(arrs, y_tk, rc, ks, u0)
+    np.testing.assert_array_equal(st_f[ks, 4].astype(int), it_o)
+    assert np.abs(np.log(s_f[ks]) - u_o).max() < (1e-9 if ppm == 0 else 1e-6)
+    assert np.abs(st_f[ks, 3] / last_o - 1).max() < (1e-11 if ppm == 0 else 1e-7)
+    set_knob('EKS_ADAM_LAG_RHO_PPM', None)
+    _, st_l, s_l, _, _, _ = _adam_search(y, rc, params, flags, K, u0)
+    np.testing.assert_array_equal(st_l[:, 4:], st_f[:, 4:])
+    assert np.abs(np.log(s_l) - np.log(s_f)).max() < 2e-6
+
+
+def _diag_problem(T, K, D, seed, slow=False):
+    """A diagonal model with D chains per keypoint (a, c, q per chain) on random-walk data; `slow`: little process noise
+    under a lot of observation noise - the optimum's pole sits above 0.93, outside the lag sums' range."""
+    rng = np.random.default_rng(seed)
+    q_true = (1e-3 if slow else 1.0) * np.exp(rng.uniform(-1.0, 1.0, (K, D)))
+    lat = np.cumsum(rng.standard_normal((T, K, D)) * np.sqrt(q_true), axis=0) + rng.uniform(50, 400, (1, K, D))
+    var_tk = ((2.0 if slow else 0.3) * rng.gamma(2.0, 1.0, (T, K, D)) + 0.02).astype(np.float32)
+    y_tk = (lat + rng.standard_normal((T, K, D)) * np.sqrt(var_tk)).astype(np.float32)
+    eye = np.tile(np.eye(D), (K, 1, 1))
+    a = rng.uniform(0.97, 1.0, (K, D)) if not slow else np.ones((K, D))
+    arrs = dict(m0s=y_tk[0].astype(np.float64) + rng.standard_normal((K, D)), S0s=eye * rng.uniform(5.0, 400.0, (K, D))[:, :, None],
+                As=eye * a[:, :, None], Cs=eye * (rng.uniform(0.7, 1.3, (K, D)) if not slow else np.ones((K, D)))[:, :, None],
+                Qs=eye * rng.uniform(0.5, 2.0, (K, D))[:, :, None])
+    return arrs, y_tk, var_tk
+
+
+@pytest.mark.parametrize('T,K,D,slow', [(6_000, 9, 1, False), (5_000, 7, 3, False), (4_096, 5, 4, False),
+                                       (12_000, 6, 2, True), (1_025, 2, 2, False)])
+def test_adam_from_lag_sums_other_chain_counts_and_slow_poles(T, K, D, slow):
+    """One to four chains per keypoint (a wave each), general diagonal (a, c, q), and a problem whose optimum has a pole
+    above 0.93 - there the search streams by itself for most of its iterations.  Against the oracle's optimiser on every
+    keypoint: the same stopping iteration, log s within 2e-6."""
+    from eks_amd import hip_ops
+    arrs, y_tk, var_tk = _diag_problem(T, K, D, seed=5 * T + D, slow=slow)
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    y, rc = _dev(y_tk), hip_ops.const_r(_dev(var_tk), 1e-4)
+    params = _params_dev(arrs)
+    u0 = np.log(np.random.default_rng(T).uniform(0.05, 20.0, K)) - (5.0 if slow else 0.0)
+    n_l, st_l, s_l, _, _, _ = _adam_search(y, rc, params, flags, K, u0)
+    assert n_l == 4096 and np.all(st_l[:, 5] == 1.0)
+    ks = list(range(K))
+    u_o, last_o, it_o = _oracle_adam(arrs, y_tk, rc, ks, u0)
+    np.testing.assert_array_equal(st_l[:, 4].astype(int), it_o)
+    assert np.abs(np.log(s_l) - u_o).max() < 2e-6
+    if slow:
+        a, r = 1.0, rc.cpu().numpy()
+        sq = s_l[:, None] * np.diagonal(arrs['Qs'], axis1=1, axis2=2)
+        Pinf = (sq + np.sqrt(sq * sq + 4 * sq * r)) / 2
+        assert (r / (r + Pinf)).min() > 0.92            # (the poles at the optimum: the lag form never applied there)
+
+
+def test_adam_from_lag_sums_nan_keypoint_bounds_and_prepared_pass(set_knob):
+    """(a) A keypoint with a NaN observation has a non-finite loss: 1e12 with zero gradient (eks/core.py:650) - it stops
+    at its second iteration, the others are untouched, exactly as with the streaming kernels.  (b) Starting points outside
+    [lo, hi] get a zero gradient (jnp.clip) until the bias-corrected momentum is all there is: same iterations as the
+    streaming form.  (c) eks_adam_prepare ahead of the state's upload + EKS_FLAG_ADAM_PREPARED: bit for bit the
+    unprepared call."""
+    from eks_amd import hip_ops
+    T, K = 8_000, 12
+    arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=4321, unit=True)
+    y_bad = y_tk.copy()
+    y_bad[5000, 3, 1] = np.nan
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    rc = hip_ops.const_r(_dev(var_tk), 1e-4)
+    params = _params_dev(arrs)
+    u0 = np.log(np.random.default_rng(1).uniform(0.05, 50.0, K))
+    u0[7], u0[8] = 9.5, -8.7                              # outside the bounds
+    ref = _adam_search(_dev(y_tk), rc, params, flags, K, u0)
+    bad = _adam_search(_dev(y_bad), rc, params, flags, K, u0)
+    assert bad[1][3, 3] == 1e12 and bad[1][3, 4] == 2 and bad[1][3, 5] == 1.0
+    others = [k for k in range(K) if k != 3]
+    np.testing.assert_array_equal(bad[1][others], ref[1][others])
+    prep = _adam_search(_dev(y_tk), rc, params, flags, K, u0, prepare=True)
+    np.testing.assert_array_equal(prep[1], ref[1])
+    np.testing.assert_array_equal(prep[2], ref[2])
+    set_knob('EKS_ADAM_STREAM', '1')
+    strm = _adam_search(_dev(y_tk), rc, params, flags, K, u0, stride=16)
+    bad_s = _adam_search(_dev(y_bad), rc, params, flags, K, u0, stride=16)
+    np.testing.assert_array_equal(ref[1][:, 4:], strm[1][:, 4:])
+    assert bad_s[1][3, 3] == 1e12 and bad_s[1][3, 4] == 2
+    assert np.abs(np.log(ref[2]) - np.log(strm[2])).max() < 2e-6
 
 
 @pytest.mark.parametrize('T,K,unit', [(2000, 4, True), (700, 3, False), (9000, 20, True), (16384, 2, False),

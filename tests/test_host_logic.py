@@ -511,35 +511,3 @@ def test_np_sum_program_is_numpys_pairwise_summation_order():
             for dst, x, y in ops:
                 slot[dst] = f(slot[x] + slot[y])
             assert f(0.0) + slot[-1] == np.sum(a), n
-
-
-def test_a_search_whose_in_launch_loop_gave_up_is_repeated_once_with_a_launch_per_iteration(monkeypatch, caplog):
-    """core._without_in_launch_loop (round 5): the wrapped call is repeated once after _AdamLoopGaveUp, with
-    EKS_ADAM_PER_ITERATION=1 set for the rest of the process and a warning; a tile of a tiled call (`_s_on_device`) lets
-    the exception through to the outer call; a second failure is not swallowed."""
-    import logging
-    from eks_amd import core
-    monkeypatch.delenv('EKS_ADAM_PER_ITERATION', raising=False)
-    calls = []
-
-    @core._without_in_launch_loop
-    def search(x, _s_on_device=False, fail=1):
-        calls.append(os.environ.get('EKS_ADAM_PER_ITERATION'))
-        if len(calls) <= fail:
-            raise core._AdamLoopGaveUp('gave up')
-        return x + 1
-
-    with caplog.at_level(logging.WARNING):
-        assert search(1) == 2
-    assert calls == [None, '1'] and any('gave up' in r.getMessage() for r in caplog.records)
-    calls.clear()
-    monkeypatch.delenv('EKS_ADAM_PER_ITERATION', raising=False)
-    with pytest.raises(core._AdamLoopGaveUp):
-        search(1, _s_on_device=True)
-    assert calls == [None]
-    calls.clear()
-    with pytest.raises(core._AdamLoopGaveUp):
-        search(1, fail=2)
-    os.environ.pop('EKS_ADAM_PER_ITERATION', None)
-    from eks_amd import _lib
-    _lib.load().eks_knobs_reload()
