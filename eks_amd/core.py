@@ -157,7 +157,21 @@ def _guess_std_on_device(ev_dev, lazy: bool = False):
     sd = hip_ops.np_nanstd_rows(d.reshape(d.shape[0], -1))
     if sd is None or not lazy:
         return None if sd is None else sd.cpu().numpy()
-    return lambda: sd.cpu().numpy()        # (the caller enqueues more work before it waits for these K floats)
+    # The K floats start their way back NOW, behind the reduction, into page-locked memory: whatever the caller enqueues
+    # next (eks_const_r, the lag sums' pass over y) runs beside the host's wait - a `.cpu()` at the time of asking would
+    # queue the copy behind all of that.
+    try:
+        host = _pinned_empty(sd.shape, sd.dtype)
+    except RuntimeError:
+        return lambda: sd.cpu().numpy()
+    host.copy_(sd, non_blocking=True)
+    ready = torch.cuda.Event()
+    ready.record()
+
+    def fetch():
+        ready.synchronize()
+        return host.numpy().copy()
+    return fetch
 
 
 def _initial_guesses_per_keypoint(ev_host: np.ndarray = None, rows: np.ndarray | None = None,
@@ -208,7 +222,15 @@ class _DeviceProblem:
         # the five parameter arrays go up as ONE copy (an upload of a few hundred bytes costs ~19 us of host time
         # whatever its size: five of them were a fifth of a 2 000-frame session's whole call)
         keys = ('m0', 'S0', 'A', 'C', 'Q')
-        flat = torch.as_tensor(np.concatenate([host[k].ravel() for k in keys]), device=self.dev)
+        # (page-locked and asynchronous: a pageable copy holds the host until the stream - the previous call's smoother
+        #  included - has drained, so back-to-back calls could not overlap their set-up with the device's work)
+        n_par = sum(host[k].size for k in keys)
+        try:
+            stage = _pinned_empty((n_par,), torch.float64)
+            np.concatenate([host[k].ravel() for k in keys], out=stage.numpy())
+            flat = stage.to(self.dev, non_blocking=True)
+        except RuntimeError:
+            flat = torch.as_tensor(np.concatenate([host[k].ravel() for k in keys]), device=self.dev)
         self.params, at = [], 0
         for k in keys:
             n = host[k].size
@@ -251,6 +273,9 @@ def _block_csr(blocks, K):
     """CSR form of `blocks` for the device optimiser.  The blocks must partition range(K): the
     reference (eks/core.py:553-554) would leave the s_finals of an uncovered keypoint unset, and a
     stray index would address device memory out of bounds here."""
+    if blocks is None:                 # the reference's default (eks/core.py:223-224): every keypoint its own block
+        ar = np.arange(K, dtype=np.int64)
+        return np.arange(K + 1, dtype=np.int32), ar.astype(np.int32), ar
     members = np.concatenate([np.asarray(b, dtype=np.int64).reshape(-1) for b in blocks]) \
         if len(blocks) else np.zeros(0, dtype=np.int64)
     if members.size != K or not np.array_equal(np.sort(members), np.arange(K)):
@@ -264,15 +289,44 @@ def _block_csr(blocks, K):
     return offs, members.astype(np.int32), of_kp
 
 
-def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, s_bounds_log, tol,
-                        safety_cap, min_R_var, s_mode, n_grid, sync_every: int | None = None):
-    """Returns (s per keypoint as a device float64 tensor, info dict)."""
+def _adam_setup(P: _DeviceProblem, blocks, s_frames, lr, s_bounds_log, tol, safety_cap):
+    """The optimiser's buffers, and the pass over y that does not depend on its starting point (the lag sums of
+    eks_lag_adam.hip) ENQUEUED - before the initial guesses are asked for, before eks_const_r, before the host has done
+    anything else for this search: the device has ~0.4 ms of work (BASELINE configs[2]) beside which the host prepares
+    the rest.  Returns what _optimize_on_device continues from."""
     torch = _torch()
     y_c, var_c = P.cropped(s_frames)
-    rconst = hip_ops.const_r(var_c, min_R_var)
     lo, hi = float(s_bounds_log[0]), float(s_bounds_log[1])
     offs, members, of_kp = _block_csr(blocks, P.K)
-    nb = len(blocks)
+    nb = len(offs) - 1
+    packed = torch.empty(nb * 6 + P.K, dtype=torch.float64, device=P.dev)
+    state, s_kp = packed[:nb * 6].view(nb, 6), packed[nb * 6:]
+    if nb == P.K and np.array_equal(members, np.arange(P.K)):
+        offs_d = torch.arange(P.K + 1, dtype=torch.int32, device=P.dev)
+        mem_d = torch.arange(P.K, dtype=torch.int32, device=P.dev)
+    else:
+        offs_d = torch.as_tensor(offs, device=P.dev)
+        mem_d = torch.as_tensor(members, device=P.dev)
+    loop = hip_ops.AdamLoop(y_c, None, *P.params, offs_d, mem_d, state, s_kp, lr, lo, hi, tol, safety_cap, flags=P.flags)
+    loop.prepare()
+    return dict(y_c=y_c, var_c=var_c, offs=offs, members=members, of_kp=of_kp, packed=packed, state=state, s_kp=s_kp,
+                loop=loop)
+
+
+def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, s_bounds_log, tol,
+                        safety_cap, min_R_var, s_mode, n_grid, sync_every: int | None = None, setup=None):
+    """Returns (s per keypoint as a device float64 tensor, info dict)."""
+    torch = _torch()
+    lo, hi = float(s_bounds_log[0]), float(s_bounds_log[1])
+    if s_mode != 'grid' and setup is None:
+        setup = _adam_setup(P, blocks, s_frames, lr, s_bounds_log, tol, safety_cap)
+    if setup is not None:
+        y_c, var_c, offs, members, of_kp = (setup[k] for k in ('y_c', 'var_c', 'offs', 'members', 'of_kp'))
+    else:
+        y_c, var_c = P.cropped(s_frames)
+        offs, members, of_kp = _block_csr(blocks, P.K)
+    rconst = hip_ops.const_r(var_c, min_R_var)
+    nb = len(offs) - 1
     if s_mode == 'grid':
         cand = torch.exp(torch.linspace(lo, hi, n_grid, dtype=torch.float64, device=P.dev))
         if nb != P.K:                                   # blocks share one s: sum member losses
@@ -285,20 +339,8 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
             nll, s, idx = hip_ops.nll_argmin(y_c, rconst, *P.params, cand, flags=P.flags)
         return s, dict(mode='grid', nll=nll, argmin=idx, candidates=cand)
     # Adam on u = log s (reference eks/core.py:612-613, :439-441: float32 initial value)
-    # The optimiser's buffers are allocated and the pass over y that does not depend on the starting point (the lag sums
-    # of eks_lag_adam.hip) is enqueued BEFORE the host asks for the initial guesses: their round trip (a device
-    # reduction, 2 K floats back, rounding, the state's upload) runs beside that pass instead of in front of it.
-    packed = torch.empty(nb * 6 + P.K, dtype=torch.float64, device=P.dev)
-    state, s_kp = packed[:nb * 6].view(nb, 6), packed[nb * 6:]
-    if nb == P.K and np.array_equal(members, np.arange(P.K)):
-        offs_d = torch.arange(P.K + 1, dtype=torch.int32, device=P.dev)
-        mem_d = torch.arange(P.K, dtype=torch.int32, device=P.dev)
-    else:
-        offs_d = torch.as_tensor(offs, device=P.dev)
-        mem_d = torch.as_tensor(members, device=P.dev)
-    loop = hip_ops.AdamLoop(y_c, rconst, *P.params, offs_d, mem_d, state, s_kp, lr, lo, hi, tol,
-                            safety_cap, flags=P.flags)
-    loop.prepare()
+    packed, state, s_kp, loop = (setup[k] for k in ('packed', 'state', 's_kp', 'loop'))
+    loop.set_rconst(rconst)
     # (block means by one segmented sum over the CSR member list: a Python loop over 256 blocks of np.mean / np.clip
     #  calls held the first launch back by 2 ms)
     if callable(s_guess_per_k):
@@ -555,6 +597,8 @@ def _log_opt(blocks, s_finals, info) -> None:
     if not logger.isEnabledFor(logging.DEBUG) or info.get('mode') != 'adam':
         return
     st = info['state'].cpu().numpy()
+    if blocks is None:
+        blocks = [[k] for k in range(st.shape[0])]
     for b, blk in enumerate(blocks):
         logger.debug(f'[opt s | block {list(blk)}] s={s_finals[blk[0]]:.6g}, '
                      f'iters={int(st[b, 4])}, NLL={st[b, 3]:.6f}')
@@ -830,8 +874,8 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
     P = _DeviceProblem(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, flags=_model_flags)
     K = P.K
     if not blocks:
-        blocks = [[k] for k in range(K)]
-    logger.debug(f'correlated keypoint blocks: {blocks}')
+        blocks = None                  # (= [[k] for k in range(K)], the reference's default: _block_csr's fast path)
+    logger.debug(f'correlated keypoint blocks: {blocks if blocks else "every keypoint its own"}')
     logger.debug(f'[profile]   build_R: {time.perf_counter() - t0:.3f}s')   # upload; R is never built
 
     # the reference computes the initial guesses before it looks at smooth_param (eks/core.py:
@@ -849,6 +893,8 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
     else:
         t1 = time.perf_counter()
         guesses = np.full(K, 2.0)
+        # the search's buffers and its pass over y FIRST (nothing it needs waits for the guesses or for eks_const_r)
+        setup = _adam_setup(P, blocks, s_frames, lr, s_bounds_log, tol, safety_cap) if s_mode == 'adam' else None
         if s_mode == 'adam':            # the starting point of the optimiser (reference :233-236)
             if hasattr(ensemble_vars, 'detach') and ensemble_vars.is_cuda and ensemble_vars.dtype == torch.float32:
                 ev_d = ensemble_vars.detach()
@@ -870,7 +916,7 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
                         else ensemble_vars[:2000].detach().cpu().numpy()
                     guesses = _initial_guesses_per_keypoint(ev_host)
         s_dev, info = _optimize_on_device(P, blocks, s_frames, guesses, lr, s_bounds_log, tol,
-                                          safety_cap, 1e-4, s_mode, n_grid)
+                                          safety_cap, 1e-4, s_mode, n_grid, setup=setup)
         if not _s_on_device:                     # (the tiled boundary reads s once, after the last tile is enqueued)
             # s travels to page-locked memory behind the search and is read after the final pass has been enqueued:
             # the device goes from the search straight into the smoother, the host wakes up beside it

@@ -528,6 +528,13 @@ __global__ __launch_bounds__(64) void ekf_finish_kernel(int K, int nc, int n_swe
   }
 }
 
+// the residual of the last filter sweep that ran (the slots of the sweeps gated after it are still zero) -> resid[slot]
+__global__ void ekf_last_resid_kernel(int n_sweeps, double tol, double* __restrict__ resid, int slot) {
+  int ran = 1;
+  while (ran < n_sweeps && !(resid[ran - 1] <= tol)) ++ran;
+  resid[slot] = resid[ran - 1];
+}
+
 static size_t ekf_ws_layout(int T, int K, bool smooth, double** ptrs, char* base) {
   constexpr int D = 3;
   const int B = dense_chunk(T, K, true), nc = (T + B - 1) / B;
@@ -604,7 +611,8 @@ int ekf_smooth(const eks_dims_t& d, int n_data_keypoints, const float* y, const 
     // caller tol (1e-2, say) "converged" points may still be 1e-2 from the elements in the workspace, so the rebuild is
     // skipped only below 1e-8.
     ProfScope ps("ekf_smooth_sweep", st);
-    sweep(Gate{resid + max_sweeps - 1, tol < 1e-8 ? tol : 1e-8}, Gate{nullptr, 0.0}, resid + kEkfMaxSweeps, true);
+    hipLaunchKernelGGL(ekf_last_resid_kernel, dim3(1), dim3(1), 0, st, max_sweeps, tol, resid, kEkfMaxSweeps + 1);
+    sweep(Gate{resid + kEkfMaxSweeps + 1, tol < 1e-8 ? tol : 1e-8}, Gate{nullptr, 0.0}, resid + kEkfMaxSweeps, true);
   }
   hipLaunchKernelGGL(ekf_finish_kernel, dim3(K), dim3(64), 0, st, K, G.nc, max_sweeps, tol, ll_chunk,
                      resid, nll, info);

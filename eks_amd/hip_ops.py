@@ -122,13 +122,22 @@ def model_flags(S0, A, C, Q) -> int:
     # normalised covariance of principal-component differences the multicam driver feeds can be - takes the
     # dual-number kernels, which do not invert Q (include/eks_hip.h: EKS_FLAG_Q_PD)
     Qh = np.asarray(Q, dtype=np.float64)
-    pd = 0
-    if np.all(np.isfinite(Qh)):
-        ev = np.linalg.eigvalsh(0.5 * (Qh + np.swapaxes(Qh, -1, -2)))
-        pd = FLAG_Q_PD if bool(np.all(ev[..., 0] > Q_PD_MIN_EIG_RATIO * np.maximum(ev[..., -1], 1e-300))) else 0
+    off = ~np.eye(D, dtype=bool)
 
     def is_diag(M):
-        return bool(np.all(M[..., ~np.eye(D, dtype=bool)] == 0))
+        return bool(np.all(M[..., off] == 0))
+
+    pd = 0
+    if np.all(np.isfinite(Qh)):
+        if Qh.shape[-1] == Qh.shape[-2] == D and is_diag(Qh):
+            # (a diagonal Q's eigenvalues are its diagonal: no batched LAPACK call - 0.1-0.2 ms at 256 keypoints, in front
+            #  of every call's first launch)
+            dg = np.diagonal(Qh, axis1=-2, axis2=-1)
+            lo_e, hi_e = dg.min(axis=-1), dg.max(axis=-1)
+        else:
+            ev = np.linalg.eigvalsh(0.5 * (Qh + np.swapaxes(Qh, -1, -2)))
+            lo_e, hi_e = ev[..., 0], ev[..., -1]
+        pd = FLAG_Q_PD if bool(np.all(lo_e > Q_PD_MIN_EIG_RATIO * np.maximum(hi_e, 1e-300))) else 0
 
     if D != O or not (is_diag(S0) and is_diag(A) and is_diag(C) and is_diag(Q)):
         return pd
@@ -385,7 +394,8 @@ class AdamLoop:
         self.lib = _lib.load()
         T, K, O = y.shape
         D = m0.shape[-1]
-        self.bufs = [_chk(y, torch.float32, 'y'), _chk(rconst, torch.float64, 'rconst', (K, O)),
+        # (rconst may be given later - set_rconst - by a caller that enqueues prepare() before eks_const_r)
+        self.bufs = [_chk(y, torch.float32, 'y'), None if rconst is None else _chk(rconst, torch.float64, 'rconst', (K, O)),
                      _chk(m0, torch.float64, 'm0', (K, D)), _chk(S0, torch.float64, 'S0', (K, D, D)),
                      _chk(A, torch.float64, 'A', (K, D, D)), _chk(C, torch.float64, 'C', (K, O, D)),
                      _chk(Q, torch.float64, 'Q', (K, D, D))]
@@ -401,6 +411,10 @@ class AdamLoop:
         self.n_active = torch.zeros(1, dtype=torch.int32, device=dev)
         self.dims = _dims(K, T, D, O, flags)
         self.ws = _workspace(self.lib.eks_nll_workspace_bytes(ctypes.byref(self.dims), 1), dev)
+
+    def set_rconst(self, rconst) -> None:
+        K, O = self.dims.n_keypoints, self.dims.obs_dim
+        self.bufs[1] = _chk(rconst, torch.float64, 'rconst', (K, O))
 
     def prepare(self) -> bool:
         """eks_adam_prepare: the pass over y that does not depend on the optimiser's state, enqueued now - the caller may
@@ -421,6 +435,8 @@ class AdamLoop:
         return int(self.lib.eks_adam_run_stride(ctypes.byref(self.dims), self.nb))
 
     def run(self, n_iters: int) -> None:
+        if self.bufs[1] is None:
+            raise ValueError('AdamLoop.run: rconst has not been set (set_rconst)')
         rc = self.lib.eks_adam_run(ctypes.byref(self.dims), *[_ptr(b) for b in self.bufs], self.nb,
                                    _ptr(self.offs), _ptr(self.members), *self.opt, int(n_iters),
                                    _ptr(self.state), _ptr(self.s_keypoint), _ptr(self.nll),
