@@ -718,14 +718,13 @@ int diag_smooth(const eks_dims_t& d, const float* y, const float* var, const Dia
   const int k1_reverse = knob_int(KNOB_SUMMARIZE_REVERSE, 0) == 1 ? 1 : 0;
   const int k3_reverse = knob_set(KNOB_REPLAY_FORWARD) ? (knob_int(KNOB_REPLAY_FORWARD, 0) == 1 ? 0 : 1) : !k1_reverse;
   if (fused) {
-    // Keypoint-tiled passes (round 3): y + var of a wide session do not fit the 256 MiB Infinity Cache,
-    // so K3 reads them from HBM a second time.  With `tp` 64-chain tiles per pass the three launches run
-    // per pass and a pass's rows (tp x 64 chains x T x 8 B) are still on chip when its K3 asks for them;
-    // the outputs leave non-temporally.  EKS_SMOOTH_TILE = tiles per pass (0 = one pass).
+    // (keypoint-tiled passes - the three launches per group of 64-chain tiles, so that a pass's rows are still in the
+    //  Infinity Cache when its K3 asks for them - were built and measured in round 3: 264 -> 290-425 us on C3, K3 is no
+    //  faster from the cache than from HBM and the group scan is paid per pass; the knob that selected them is gone, the
+    //  loop below makes one pass)
     const bool rc_all = knob_set(KNOB_REPLAY_RECOMPUTE) ? knob_int(KNOB_REPLAY_RECOMPUTE, 0) == 1
                                                         : 5 * pb >= ((size_t)16 << 20);
-    int tp = knob_int(KNOB_SMOOTH_TILE, 0);
-    if (tp <= 0 || tp > L.ntile) tp = L.ntile;
+    const int tp = L.ntile;
     for (int tile0 = 0; tile0 < L.ntile; tile0 += tp) {
     const int ntl = min(tp, L.ntile - tile0);
     const int n0 = tile0 * 64, Np = min(N - n0, ntl * 64);

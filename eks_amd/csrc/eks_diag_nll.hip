@@ -1669,7 +1669,7 @@ static inline int pick_ncl(int n_cand, bool grad) {
 
 // few (keypoint, candidate) pairs and many chunks: the chunk summaries are composed by a tree
 static bool nll_uses_tree(int K, int D, int n_cand, int ncn) {
-  return (long)K * n_cand * D <= 8192 && ncn >= 8 && D <= 16 && !knob_int(KNOB_NLL_ASSEMBLE_SEQ, 0);
+  return (long)K * n_cand * D <= 8192 && ncn >= 8 && D <= 16;
 }
 
 // does the gradient evaluation of a (T, K, D) problem (one value of s per keypoint) end in the tree
@@ -1828,7 +1828,7 @@ static int diag_nll_impl(const eks_dims_t& d, const float* y, const double* rcon
   // (the tree cannot take converged-entry summaries: they are only valid in sequential order)
   const bool tree = nll_uses_tree(K, D, n_cand, G.ncn);
   if (F.state && F.step_in_kernel && !(grad && tree)) return EKS_ERR_UNSUPPORTED;   // (caller asks diag_nll_grad_tree)
-  G.converged_entry = !grad && !tree && !knob_int(KNOB_NLL_EXACT_ENTRY, 0);
+  G.converged_entry = !grad && !tree;
   NllWs W;
   W.ncp = G.ngrp * ncl;
   const size_t fl = align_up((size_t)G.ncn * W.ncp * N * sizeof(float), 256);
@@ -1898,8 +1898,7 @@ static int diag_nll_impl(const eks_dims_t& d, const float* y, const double* rcon
                          nll, dnll, F);
     return hip_status(hipGetLastError());
   }
-  if (!grad && G.converged_entry && G.nt_log2 == 6 && (D & (D - 1)) == 0 && 64 % D == 0 && G.ncn >= 4 &&
-      !knob_int(KNOB_NLL_ASSEMBLE_SEQ, 0)) {
+  if (!grad && G.converged_entry && G.nt_log2 == 6 && (D & (D - 1)) == 0 && 64 % D == 0 && G.ncn >= 4) {
     const size_t shm = ((size_t)G.ncn + kAsmWaves) * 64 * sizeof(double);
     if (shm <= 60 * 1024) {
       hipLaunchKernelGGL(diag_nll_assemble_par_kernel, dim3((unsigned)(G.ntile * n_cand)), dim3(64 * kAsmWaves),

@@ -24,9 +24,9 @@ struct KnobTable {
   int load() {
     static const char* const names[KNOB_COUNT] = {
         "EKS_SMOOTH_UNFUSED", "EKS_SUMMARIZE_REVERSE", "EKS_REPLAY_FORWARD", "EKS_REPLAY_RECOMPUTE", "EKS_SCAN_CH",
-        "EKS_SMOOTH_TILE", "EKS_DENSE_CHUNK", "EKS_NLL_NCL", "EKS_NLL_CHUNK", "EKS_NLL_CHUNK0", "EKS_NLL_WPB",
-        "EKS_NLL_EXACT_ENTRY", "EKS_NLL_ASSEMBLE_SEQ", "EKS_DENSE_LEGACY", "EKS_NLL_GRAD_UNFUSED",
-        "EKS_NLL_GRAD_CHUNK", "EKS_DENSE_TREE_SCAN", "EKS_DENSE_DUAL_GRAD", "EKS_NLL_LEGACY", "EKS_MED_ROWS", "EKS_NLL_ASM_WAVES", "EKS_DW_CHUNK", "EKS_ADAM_PER_ITERATION", "EKS_MED_FINISH_THREADS", "EKS_MED_BRACKET_THREADS", "EKS_NLL_NOLAG", "EKS_NLL_GRAD_TREE", "EKS_ADAM_STREAM", "EKS_ADAM_LAG_RHO_PPM"};
+        "EKS_DENSE_CHUNK", "EKS_NLL_NCL", "EKS_NLL_CHUNK", "EKS_NLL_CHUNK0", "EKS_NLL_WPB",
+        "EKS_DENSE_LEGACY", "EKS_NLL_GRAD_UNFUSED",
+        "EKS_NLL_GRAD_CHUNK", "EKS_DENSE_TREE_SCAN", "EKS_DENSE_DUAL_GRAD", "EKS_NLL_LEGACY", "EKS_MED_ROWS", "EKS_DW_CHUNK", "EKS_ADAM_PER_ITERATION", "EKS_MED_FINISH_THREADS", "EKS_MED_BRACKET_THREADS", "EKS_NLL_NOLAG", "EKS_NLL_GRAD_TREE", "EKS_ADAM_STREAM", "EKS_ADAM_LAG_RHO_PPM"};
     int n = 0;
     for (int i = 0; i < KNOB_COUNT; ++i) {
       const char* v = getenv(names[i]);

@@ -16,25 +16,13 @@ from . import _lib
 from ._lib import FLAG_ADAM_PREPARED, FLAG_DIAG_MODEL, FLAG_Q_PD, FLAG_UNIT_AC, FLAG_VS_DIAG, EksDims
 
 
-_auto_warm = [False]
-
-
 def require_gpu() -> torch.device:
     if not torch.cuda.is_available():
         raise _lib.EksHipError('no ROCm device visible: eks_amd has no CPU fallback for the Kalman '
                                'path (the float64 oracle under oracle/ is test infrastructure only)')
-    if not _auto_warm[0]:
-        # first entry of the process into the accelerated path.  EKS_AUTO_WARMUP=1 starts loading every unit's code
-        # object on a background thread here.  OFF by default: measured (tools/first_call.py, profiles/r04_*_first_call
-        # .txt) the units load in 0.7-2.6 ms each when their first launch needs them, and a thread loading all nine at
-        # once competes with the first call for the runtime's loader lock - 44 / 33 ms against 23 / 24 ms without it.
-        _auto_warm[0] = True
-        import os
-        if os.environ.get('EKS_AUTO_WARMUP'):
-            try:
-                warmup('all', background=True)
-            except Exception:           # warming is an optimisation: never the reason a call fails
-                pass
+    # (a background warm-up of every unit's code object at the first entry was measured SLOWER than letting each unit
+    #  load at its first launch - 44 / 33 ms against 23 / 24 ms, tools/first_call.py - and its switch is gone; callers who
+    #  want the loads ahead of time call warmup())
     return torch.device('cuda', torch.cuda.current_device())
 
 

@@ -100,7 +100,12 @@ def test_c3_singlecam_100k_x_256_grid_search_and_smooth():
         Rd = np.clip(np.transpose(var[:, sel].cpu().numpy().astype(np.float64), (1, 0, 2)), 1e-12, None)
         Rc = orc.constant_R_from_timevarying(Rd)
         np.testing.assert_array_equal(rc_h[sel], Rc)                          # the exact median, bit for bit
-        nll_o = c_oracle.nll_grid(y_s, Rc, m0[sel], S0[sel], eye[sel], eye[sel], eye[sel], cand, nthreads=_threads())
+        # (the C port's scalar-chain form of the diagonal model - held to its general-matrix form to 1e-10 in
+        #  tests/test_oracle_core.py - takes a fifth of the time; the first 64 keypoints go through BOTH)
+        nll_o = c_oracle.nll_grid_diag(y_s, Rc, m0[sel], S0[sel], eye[sel], eye[sel], eye[sel], cand, nthreads=_threads())
+        if k0 == 0:
+            nll_g = c_oracle.nll_grid(y_s, Rc, m0[sel], S0[sel], eye[sel], eye[sel], eye[sel], cand, nthreads=_threads())
+            assert (np.abs(nll_g - nll_o) / np.abs(nll_g)).max() < 1e-9
         assert (np.abs(nll_h[sel] - nll_o) / np.abs(nll_o)).max() < TOL
         idx_o = nll_o.argmin(axis=1)
         srt = np.sort(nll_o, axis=1)
@@ -111,12 +116,13 @@ def test_c3_singlecam_100k_x_256_grid_search_and_smooth():
         pick = nll_o[np.arange(len(sel)), idx[sel]]
         assert (np.abs(pick - srt[:, 0]) <= 4 * TOL * np.abs(srt[:, 0])).all()
 
-        ms_o, Vs_o, _ = c_oracle.smooth(y_s, Rd, m0[sel], S0[sel], eye[sel], eye[sel], eye[sel], s[sel],
-                                        nthreads=_threads())
+        smooth_o = c_oracle.smooth if k0 == 0 else c_oracle.smooth_diag
+        ms_o, Vs_o, _ = smooth_o(y_s, Rd, m0[sel], S0[sel], eye[sel], eye[sel], eye[sel], s[sel], nthreads=_threads())
         ms_g = ms[k0:k0 + len(sel)].cpu().numpy().astype(np.float64)
         Vs_g = Vs[k0:k0 + len(sel)].cpu().numpy().astype(np.float64)
         assert _kp_rel(ms_g, ms_o) < TOL
-        Vd_g, Vd_o = np.diagonal(Vs_g, axis1=2, axis2=3), np.diagonal(Vs_o, axis1=2, axis2=3)
+        Vd_g = np.diagonal(Vs_g, axis1=2, axis2=3)
+        Vd_o = np.diagonal(Vs_o, axis1=2, axis2=3) if Vs_o.ndim == 4 else Vs_o   # (smooth_diag returns the diagonal)
         assert (np.abs(Vd_g - Vd_o) / Vd_o).max() < TOL                        # elementwise
         assert np.all(Vs_g[..., 0, 1] == 0) and np.all(Vs_g[..., 1, 0] == 0)
         del y_s, Rd, ms_o, Vs_o, ms_g, Vs_g

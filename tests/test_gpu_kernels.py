@@ -46,6 +46,27 @@ def _params_dev(arrs):
     return [_dev(arrs[k], torch.float64) for k in ('m0s', 'S0s', 'As', 'Cs', 'Qs')]
 
 
+_NLL_GRID_MEMO = {}
+
+
+def _nll_grid_oracle(ys, Rc, m0s, S0s, As, Cs, Qs, cand):
+    """c_oracle.nll_grid, remembered per input: several tests run the same problem through different kernels (the
+    EKS_NLL_LEGACY / EKS_NLL_NOLAG parametrisations, repeated calls) - the C port took most of their time."""
+    import hashlib
+    from oracle import c_oracle
+    h = hashlib.sha1()
+    for a in (ys, Rc, m0s, S0s, As, Cs, Qs, cand):
+        a = np.ascontiguousarray(a)
+        h.update(str(a.shape).encode())
+        h.update(a.tobytes())
+    key = h.hexdigest()
+    if key not in _NLL_GRID_MEMO:
+        if len(_NLL_GRID_MEMO) > 8:
+            _NLL_GRID_MEMO.clear()
+        _NLL_GRID_MEMO[key] = c_oracle.nll_grid(ys, Rc, m0s, S0s, As, Cs, Qs, cand)
+    return _NLL_GRID_MEMO[key]
+
+
 def test_smooth_diag_long_sequence_fused_and_unfused_scan_agree_with_oracle(set_knob):
     """T = 140 000 (4 375 chunks): the fused path's group scan re-reads its aggregates in batches
     (more than 16 per slot); both scan organisations against the C oracle on every frame."""
@@ -461,7 +482,7 @@ def test_nll_grid_staged_kernel_matches_c_oracle(T, K, unit, legacy, set_knob):
     flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
     rconst = hip_ops.const_r(_dev(var_tk), 1e-4)
     nll = hip_ops.nll(_dev(y_tk), rconst, *_params_dev(arrs), _dev(cand), flags=flags).cpu().numpy()
-    ref = c_oracle.nll_grid(arrs['ys'], rconst.cpu().numpy(), arrs['m0s'], arrs['S0s'], arrs['As'],
+    ref = _nll_grid_oracle(arrs['ys'], rconst.cpu().numpy(), arrs['m0s'], arrs['S0s'], arrs['As'],
                             arrs['Cs'], arrs['Qs'], cand)
     assert (np.abs(nll - ref) / np.abs(ref)).max() < 1e-5
     srt = np.sort(ref, axis=1)
@@ -491,7 +512,7 @@ def test_nll_grid_converged_entry_chunks_match_c_oracle(T, K, unit, var_scale, l
     flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
     rconst = hip_ops.const_r(_dev(var_tk), 1e-4)
     nll = hip_ops.nll(_dev(y_tk), rconst, *_params_dev(arrs), _dev(cand), flags=flags).cpu().numpy()
-    ref = c_oracle.nll_grid(arrs['ys'], rconst.cpu().numpy(), arrs['m0s'], arrs['S0s'], arrs['As'],
+    ref = _nll_grid_oracle(arrs['ys'], rconst.cpu().numpy(), arrs['m0s'], arrs['S0s'], arrs['As'],
                             arrs['Cs'], arrs['Qs'], cand)
     assert (np.abs(nll - ref) / np.abs(ref)).max() < (3e-6 if T == 20011 else 1e-5)
     srt = np.sort(ref, axis=1)
@@ -520,7 +541,7 @@ def test_nll_grid_slow_poles_keep_a_margin(unit, legacy, set_knob):
     flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
     rconst = hip_ops.const_r(_dev(var_tk), 1e-4)
     nll = hip_ops.nll(_dev(y_tk), rconst, *_params_dev(arrs), _dev(cand), flags=flags).cpu().numpy()
-    ref = c_oracle.nll_grid(arrs['ys'], rconst.cpu().numpy(), arrs['m0s'], arrs['S0s'], arrs['As'],
+    ref = _nll_grid_oracle(arrs['ys'], rconst.cpu().numpy(), arrs['m0s'], arrs['S0s'], arrs['As'],
                             arrs['Cs'], arrs['Qs'], cand)
     assert (np.abs(nll - ref) / np.abs(ref)).max() < 3e-6
     np.testing.assert_array_equal(nll.argmin(axis=1), ref.argmin(axis=1))
@@ -577,7 +598,7 @@ def test_nll_grid_lean_kernel_shapes_and_fallbacks(T, K, D, unit, n_cand, per_kp
                                           arrs['As'][k:k + 1], arrs['Cs'][k:k + 1], arrs['Qs'][k:k + 1], cand[k])[0]
                         for k in range(K)])
     else:
-        ref = c_oracle.nll_grid(arrs['ys'], Rc, arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], cand)
+        ref = _nll_grid_oracle(arrs['ys'], Rc, arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'], cand)
     assert np.isfinite(nll).all()
     assert (np.abs(nll - ref) / np.abs(ref)).max() < 1e-5
     srt = np.sort(ref, axis=1)
@@ -612,7 +633,7 @@ def test_nll_argmin_is_the_table_plus_numpys_argmin(T, K, unit, n_cand, var_scal
     for rep in range(3):                   # (the assembly's tickets must come back to zero)
         nll, s_sel, idx = hip_ops.nll_argmin(*args, flags=flags)
         nll, s_sel, idx = nll.cpu().numpy(), s_sel.cpu().numpy(), idx.cpu().numpy()
-        ref = c_oracle.nll_grid(arrs['ys'], rconst.cpu().numpy(), arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'],
+        ref = _nll_grid_oracle(arrs['ys'], rconst.cpu().numpy(), arrs['m0s'], arrs['S0s'], arrs['As'], arrs['Cs'],
                                 arrs['Qs'], cand)
         assert (np.abs(nll - ref) / np.abs(ref)).max() < 1e-5
         np.testing.assert_array_equal(idx, nll.argmin(axis=1))

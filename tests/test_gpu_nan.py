@@ -35,7 +35,7 @@ def _session(T, K, seed, dense):
     return [ys, np.zeros((K, 2)), eye * ys.var(axis=1)[:, :, None], eye, eye, eye, ev]
 
 
-@pytest.mark.parametrize('mode,T,K', [('fixed', 12_000, 70), ('grid', 12_000, 70), ('grid_nolag', 12_000, 70),
+@pytest.mark.parametrize('mode,T,K', [('fixed', 12_000, 70), ('grid', 7_000, 70), ('grid_nolag', 7_000, 70),
                                       ('adam', 6_000, 70), ('adam_small', 2_000, 6), ('dense_fixed', 4_000, 36),
                                       ('fixed_small', 700, 5)])
 def test_nan_observations_poison_only_their_keypoint(mode, T, K, set_knob):

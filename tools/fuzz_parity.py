@@ -75,7 +75,16 @@ for case in range(n_cases):
               f'a={np.diagonal(arrs["As"][k])} c={np.diagonal(arrs["Cs"][k])} q={np.diagonal(arrs["Qs"][k])}; '
               f'entries above 3e-6: {int((rel_ms > 3e-6).sum())}', flush=True)
     Vd = np.diagonal(Vo, axis1=2, axis2=3)
-    e_Vs = float((np.abs(Vs - Vd) / Vd).max())
+    rel_Vs = np.abs(Vs - Vd) / Vd
+    e_Vs = float(rel_Vs.max())
+    if os.environ.get('FUZZ_DETAIL') and e_Vs > 3e-6:
+        k, t, d_ = np.unravel_index(np.argmax(rel_Vs), rel_Vs.shape)
+        t0_, t1_ = max(0, t - 2), min(T, t + 3)
+        print(f'   detail Vs: case {case} T={T} K={K} keypoint {k} frame {t} coord {d_}: gpu {Vs[k, t, d_]:.9g} oracle {Vd[k, t, d_]:.9g} '
+              f's={s[k]:.6g} var[t-2..t+2]={var_tk[t0_:t1_, k, d_]} S0={np.diagonal(arrs["S0s"][k])} a={np.diagonal(arrs["As"][k])} '
+              f'c={np.diagonal(arrs["Cs"][k])} q={np.diagonal(arrs["Qs"][k])}; entries above 3e-6: {int((rel_Vs > 3e-6).sum())} '
+              f'in keypoints {sorted(set(np.nonzero(rel_Vs > 3e-6)[0].tolist()))[:8]} frames {sorted(set(np.nonzero(rel_Vs > 3e-6)[1].tolist()))[:12]}',
+              flush=True)
     worst['nll'] = max(worst['nll'], e_nll); worst['ms'] = max(worst['ms'], e_ms); worst['Vs'] = max(worst['Vs'], e_Vs)
     flag = '' if max(e_nll, e_ms, e_Vs) < 1e-5 else '   <-- above 1e-5'
     print(f'case {case}: T={T} K={K} unit={unit} var x{scale:.3g} n_cand={n_cand}: nll {e_nll:.1e} ms {e_ms:.1e} Vs {e_Vs:.1e}{flag}', flush=True)

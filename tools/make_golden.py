@@ -213,7 +213,10 @@ def csv_samples():
         texts.append(txt)
         names.append(os.path.relpath(f, REF))
         values.append(df.to_numpy(dtype=np.float64))
-    np.savez_compressed(os.path.join(OUT, 'csv_samples.npz'), names=np.array(names), texts=np.array(texts, dtype=object),
+    enc = [t.encode('utf-8') for t in texts]                 # (bytes + offsets: nothing in the fixture needs unpickling)
+    np.savez_compressed(os.path.join(OUT, 'csv_samples.npz'), names=np.array(names),
+                        texts_bytes=np.frombuffer(b''.join(enc), dtype=np.uint8),
+                        texts_offsets=np.cumsum([0] + [len(e) for e in enc]).astype(np.int64),
                         **{f'values_{i}': v for i, v in enumerate(values)})
     print('csv_samples:', len(names), 'files')
 
