@@ -38,6 +38,8 @@ EKS_HD ChainParams<float> load_chain_params(const DiagModel& M, int n) {
   const size_t dd = (size_t)k * M.D * M.D + (size_t)d * (M.D + 1);
   ChainParams<float> p;
   p.a = (float)M.A[dd];
+  p.oma = (float)(1.0 - M.A[dd]);
+  p.oma2 = (float)(1.0 - M.A[dd] * M.A[dd]);
   p.c = (float)M.C[dd];
   p.q_s = (float)(M.s[k] * M.Q[dd]);
   return p;

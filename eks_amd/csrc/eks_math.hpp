@@ -47,6 +47,12 @@ struct Elem {
 template <typename R>
 struct ChainParams {
   R a, c, q_s;  // transition, emission, s*q
+  // 1 - a and 1 - a^2, each rounded ONCE from float64.  A float32 `a` is off by up to 6e-8 of itself, and on a decaying
+  // chain under heavy smoothing the variances' fixed points divide by (1 - a^2 + gain terms) ~ 1e-2: a times a variance
+  // is formed as X - oma2 X, a times a mean as m - oma m (round 6: 4e-6 -> below 2e-6 on Vs at a = 0.988, s q / r = 4e-5)
+  R oma = R(0), oma2 = R(0);
+  EKS_HD R times_a(R x) const { return x - oma * x; }
+  EKS_HD R times_a2(R x) const { return x - oma2 * x; }
 };
 
 template <typename R>
@@ -96,9 +102,9 @@ EKS_HD void elem_append(Elem<R>& e, R y, R r, const ChainParams<R>& p, R& S, R& 
   const R Acg = UNIT ? e.A * g : e.A * c * g;
   e.eta = e.eta + Acg * d;
   e.J = e.J + (UNIT ? Acg * e.A : Acg * e.A * c);
-  e.b = UNIT ? (e.b + Cc * g * d) : a * (e.b + Cc * g * d);
-  e.A = UNIT ? e.A * rg : a * e.A * rg;
-  e.C = UNIT ? (e.C * rg + p.q_s) : (a * a * e.C * rg + p.q_s);
+  e.b = UNIT ? (e.b + Cc * g * d) : p.times_a(e.b + Cc * g * d);
+  e.A = UNIT ? e.A * rg : p.times_a(e.A * rg);
+  e.C = UNIT ? (e.C * rg + p.q_s) : (p.times_a2(e.C * rg) + p.q_s);
 }
 
 template <typename R, bool UNIT>
@@ -154,8 +160,8 @@ EKS_HD void filter_step(R& m, R& P, R y, R r, const ChainParams<R>& p, R& mf, R&
   const R d = UNIT ? (y - m) : (y - c * m);
   mf = m + Pc * g * d;
   Pf = P * r * g;
-  m = UNIT ? mf : a * mf;
-  P = UNIT ? (Pf + p.q_s) : (a * a * Pf + p.q_s);
+  m = UNIT ? mf : p.times_a(mf);
+  P = UNIT ? (Pf + p.q_s) : (p.times_a2(Pf) + p.q_s);
 }
 
 // Combine the predicted belief on x (from the past) with information (eta, J) from the future.
@@ -167,15 +173,33 @@ EKS_HD void fuse_info(R& m, R& P, R eta, R J) {
 }
 
 // One RTS frame: (ms, Ps) is the smoothed belief on x_{t+1} on entry, on x_t on exit.
-// Ps_t = Pf s q / Pp + G^2 Ps_{t+1}  (product form of Pf + G^2 (Ps - Pp)).
+// With Pp = a^2 Pf + s q and h = s q / Pp the smoother gain is G = a Pf / Pp = (1 - h) / a, i.e. 1 - G = (h - (1 - a)) / a
+// =: g exactly.  Under heavy smoothing (s q << Pf: h ~ 1e-2, and 1 - a of that size on a decaying chain) a float32 G
+// sits within 1e-2 of one: it carries 1 - G to only 6e-8 / g of itself, and the variance recursion's fixed point is
+// Pf h / (1 - G^2) - 6.5e-6 on Vs in round 5's fuzz sweeps (s ~ 5e-4, profiles/r05_fuzz3.txt).  Round 6: where g is small
+// the step is taken in the DEVIATION form
+//     Ps_t = Pf h + G^2 Ps_{t+1} = Ps_{t+1} + ( Pf h - g (2 - g) Ps_{t+1} )
+// in which the small quantity multiplies a difference instead of being formed as a complement of one (1 - a arrives
+// rounded once from float64: ChainParams::oma); elsewhere (|g| >= 1/4: light smoothing, or a frame in front of an
+// occluded one whose Ps_{t+1} dwarfs Pf, where the deviation form would cancel) the products of non-negative terms of
+// rounds 1-5 stand.  Per lane, by select.
 template <typename R, bool UNIT>
 EKS_HD void rts_step(R& ms, R& Ps, R mf, R Pf, const ChainParams<R>& p) {
-  const R a = UNIT ? R(1) : p.a;
-  const R Pp = UNIT ? (Pf + p.q_s) : (a * a * Pf + p.q_s);
+  const R Pp = UNIT ? (Pf + p.q_s) : (p.times_a2(Pf) + p.q_s);
   const R ig = rcp(Pp);
-  const R G = UNIT ? Pf * ig : a * Pf * ig;
-  ms = mf + G * (ms - (UNIT ? mf : a * mf));
-  Ps = Pf * p.q_s * ig + G * G * Ps;
+  const R h = p.q_s * ig;
+  const R G = UNIT ? Pf * ig : p.a * Pf * ig;
+  const R amf = UNIT ? mf : p.times_a(mf);
+  const R g = UNIT ? h : (h - p.oma) * rcp(p.a);
+  ms = mf + G * (ms - amf);                // (the mean is not divided by 1 - G^2: its product form holds 1e-6 everywhere)
+  const R Ps_prod = Pf * h + G * G * Ps;
+#ifdef EKS_RTS_PRODUCT_ONLY                 // (A/B builds: rounds 1-5's step)
+  (void)g;
+  Ps = Ps_prod;
+#else
+  const R Ps_dev = Ps + (Pf * h - g * (R(2) - g) * Ps);
+  Ps = (g < R(0.25) && g > R(-0.25)) ? Ps_dev : Ps_prod;
+#endif
 }
 
 }  // namespace eks

@@ -385,6 +385,8 @@ EKS_HD void nll_lane_init(NllLane<R, NCL, UNIT>& L, double r_d, double a_d, doub
 #pragma unroll
   for (int k = 0; k < NCL; ++k) {
     L.pc[k].a = R(af);
+    L.pc[k].oma = R((float)(1.0 - a_d));
+    L.pc[k].oma2 = R((float)(1.0 - a_d * a_d));
     L.pc[k].c = R(cf);
     L.pc[k].q_s = make_real(R(), (float)sq_d[k], (float)sq_d[k]);
     double Ci, dCi;
