@@ -9,9 +9,10 @@
 // zero-start recursion on the inputs from frame F = B0 + 1 on, whose sum of squares is a polynomial in the pole:
 //     sum_t Dz_t^2 = [ c_0 + 2 sum_{k>=1} rho^k c_k - rho^2 Dz_{T-1}^2 ] / (1 - rho^2),    c_k = sum_{t >= F + k} u_t u_{t-k}.
 //
-//   L1 lag_sums_kernel    one streaming pass per search: block = (64-chain tile, time chunk), wave w = lags 32 w .. 32 w + 31
-//                         as packed float32 products of the current inputs with a register ring of the inputs 32 w frames
-//                         back (33 v_pk_fma_f32 per frame pair and wave), float64 sums in LDS every 64 frames.
+//   L1 lag_sums_kernel    one streaming pass per search: block = (64-chain tile, time chunk), wave w = lags 16 w .. 16 w + 15
+//                         as packed float32 products of the current inputs with the inputs 16 w frames back (17
+//                         v_pk_fma_f32 per frame pair and wave), the inputs through one ring in LDS, float64 sums in
+//                         registers every 64 frames.
 //   L2 lag_reduce_kernel  the chunks' partial sums -> c[chain][256] (float64, lags >= 1 doubled).
 //   L3 lag_adam_kernel    block = KEYPOINT, wave = chain, the whole search in one launch with no exchange between
 //                         blocks: per iteration the head [0, B0) exactly and time-parallel (closed-form variances, a
@@ -33,14 +34,9 @@ namespace eks {
 constexpr int kLaB0 = 256;             // frames of the head: exact, time-parallel (64 lanes x 4 frames)
 constexpr int kLaF = kLaB0 + 1;        // first frame whose input enters the lag sums
 constexpr int kLaL = 256;              // lag sums c_0 .. c_255
-constexpr int kLaWaves = kLaL / 32;    // waves of a pre-pass block
 constexpr int kLaMinT = 1024;          // (shorter sessions: diag_nll_adam_persist_kernel)
 constexpr int kLaMaxD = 4;
-#ifndef EKS_LA_AHEAD
-#define EKS_LA_AHEAD 8
-#endif
-constexpr int kLaAhead = EKS_LA_AHEAD;   // frames between the request of a row and its use (pre-pass).  Measured on BASELINE configs[2]: 8 / 12 / 16 / 32 frames 388 / 399 / 447 / 920 us - beyond 8 the allocator spills loaded rows, whose stores wait for the loads
-static_assert(kLaB0 == kLaL, "the delayed rings of the pre-pass reach back L + 1 frames from F: B0 >= L keeps them inside the array");
+static_assert(kLaB0 == kLaL, "the search kernel deals four head frames and four lags to every lane");
 
 // |rho| up to which 256 lag sums give the polynomial to 2e-10 (1 - |rho|)^-1 of itself WHATEVER the data (all lag sums
 // are bounded by c_0): |rho|^256 <= 1e-10 (1 - |rho|)
@@ -78,104 +74,22 @@ struct LagPre {
   int cap;
 };
 
-// One wave: lags 32 w .. 32 w + 31 of one (tile, chunk).  `acc`: this wave's [32][64] float64 sums in LDS, at the lane.
-template <bool UNIT, bool W0>
-__device__ __forceinline__ void lag_wave_body(const LagPre& P, const LagRows& ld, int ts0, int nss, int w, double a_d,
-                                              double* acc) {
-  const int delay = W0 ? 0 : 32 * w;
-  const int T = P.T;
-  auto input = [&](float yy, float yp) { return UNIT ? (yy - yp) : (float)((double)yy - a_d * (double)yp); };
-  f32x2 E[16], O[17], ring[32];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) E[i] = f32x2{0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 17; ++i) O[i] = f32x2{0.f, 0.f};
-  // ---- history: the 16 input pairs in front of the delayed stream's first frame (zero before frame F)
-  const int td0 = ts0 - delay;
-  float yd_prev, yc_prev;
-  {
-    float h[33];
-#pragma unroll
-    for (int i = 0; i < 33; ++i) h[i] = ld(td0 - 33 + i);
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {
-      const int tA = td0 - 32 + 2 * p;
-      ring[16 + p] = f32x2{input(h[2 * p + 1], h[2 * p]), input(h[2 * p + 2], h[2 * p + 1])};
-      if constexpr (!UNIT) ring[16 + p] = ring[16 + p] * f32x2{tA >= kLaF ? 1.f : 0.f, tA + 1 >= kLaF ? 1.f : 0.f};
-    }
-    yd_prev = h[32];
-    yc_prev = W0 ? h[32] : ld(ts0 - 1);
-  }
-  // rows: 32 frames per stream, every register asked for again (the same frame 32 further on) as soon as it has been
-  // consumed - 32 frames (528 packed FMAs, ~1 us) between a request and its use
-  float rc[kLaAhead], rd[kLaAhead];
-  auto half = [&](auto h_tag, int t) {
-    constexpr int H = decltype(h_tag)::value;
-    constexpr bool EDGE = !UNIT;                       // (masks: see LagRows)
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      const int Pp = 8 * H + a;
-      const float y0 = rc[(16 * H + 2 * a) % kLaAhead], y1 = rc[(16 * H + 2 * a + 1) % kLaAhead];
-      rc[(16 * H + 2 * a) % kLaAhead] = ld(t + kLaAhead + 2 * a);
-      rc[(16 * H + 2 * a + 1) % kLaAhead] = ld(t + kLaAhead + 2 * a + 1);
-      f32x2 Xc = f32x2{input(y0, yc_prev), input(y1, y0)};
-      yc_prev = y1;
-      if constexpr (EDGE) {
-        const int tt = t + 2 * a;
-        Xc = Xc * f32x2{tt < T ? 1.f : 0.f, tt + 1 < T ? 1.f : 0.f};
-      }
-      if constexpr (W0) {
-        ring[Pp] = Xc;
-      } else {
-        const float z0 = rd[(16 * H + 2 * a) % kLaAhead], z1 = rd[(16 * H + 2 * a + 1) % kLaAhead];
-        rd[(16 * H + 2 * a) % kLaAhead] = ld(t - delay + kLaAhead + 2 * a);
-        rd[(16 * H + 2 * a + 1) % kLaAhead] = ld(t - delay + kLaAhead + 2 * a + 1);
-        f32x2 Xd = f32x2{input(z0, yd_prev), input(z1, z0)};
-        yd_prev = z1;
-        if constexpr (EDGE) {
-          const int tt = t - delay + 2 * a;
-          Xd = Xd * f32x2{tt >= kLaF ? 1.f : 0.f, tt + 1 >= kLaF ? 1.f : 0.f};
-        }
-        ring[Pp] = Xd;
-      }
-#pragma unroll
-      for (int dl = 0; dl < 16; ++dl) E[dl] = Xc * ring[(Pp - dl) & 31] + E[dl];
-#pragma unroll
-      for (int dl = 0; dl < 17; ++dl) {
-        const f32x2 xb = ring[(Pp - dl) & 31];
-        O[dl] = Xc * f32x2{xb[1], xb[0]} + O[dl];
-      }
-      EKS_SCHED_FENCE();
-    }
-  };
-  auto super_set = [&](int ts) {
-    half(IntTag<0>(), ts);
-    half(IntTag<1>(), ts + 16);
-    half(IntTag<2>(), ts + 32);
-    half(IntTag<3>(), ts + 48);
-    // float32 partial sums span 64 frames: into the float64 sums
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-      acc[(2 * jj) * 64] += (double)(E[jj][0] + E[jj][1]);
-      acc[(2 * jj + 1) * 64] += (double)(O[jj][1] + O[jj + 1][0]);
-      E[jj] = f32x2{0.f, 0.f};
-    }
-#pragma unroll
-    for (int jj = 0; jj < 17; ++jj) O[jj] = f32x2{0.f, 0.f};
-    EKS_SCHED_FENCE();                                 // (the next super-set's sums reuse these registers: not beside them)
-  };
-#pragma unroll
-  for (int q = 0; q < kLaAhead; ++q) rc[q] = ld(ts0 + q);
-  if constexpr (!W0) {
-#pragma unroll
-    for (int q = 0; q < kLaAhead; ++q) rd[q] = ld(td0 + q);
-  }
-  for (int ss = 0; ss < nss; ++ss) super_set(ts0 + 64 * ss);
-}
+// The pre-pass (second form, round 6): block = (64-chain tile, time chunk), 16 waves, wave w = lags 16 w .. 16 w + 15.
+// The inputs u of the chunk go through ONE ring in LDS (512 frames x 64 chains, float32): every 32 frames each wave loads
+// three rows, forms two frames' inputs and stores them - two sets ahead of their use - and every wave reads its current
+// pair and its pair 16 w frames back from the ring (two ds_read2st64_b32 per 17 packed FMAs, one pair ahead of their
+// use), keeping the 9 delayed pairs a step needs in a register ring of 16; the float64 sums stay in registers.
+// Measured on BASELINE configs[2] (profiles/r06_probes.txt): the first form - 8 waves x 32 lags, every wave loading and
+// subtracting both streams itself (8 loads and 4 subtractions per 33 FMAs, 640 scalar instructions per 64 frames for the
+// clamped row offsets), float64 sums in LDS - 388 us; this one 333 us as first written, the same with 8 waves x 32 lags
+// (two waves per SIMD behind a barrier per step) 525 us.
+constexpr int kRgWaves = 16;
+constexpr int kRgCap = 512;              // frames in the ring: 240 of delay + 32 of history + the set in use + two in flight
+constexpr int kRgHist = 288;             // frames in front of the chunk that the prologue fills (a multiple of 32 >= 272)
 
 template <bool UNIT>
-__global__ __launch_bounds__(64 * kLaWaves) void lag_sums_kernel(LagPre P) {
-  __shared__ double acc_all[kLaWaves * 32 * 64];
+__global__ __launch_bounds__(64 * kRgWaves) void lag_sums_kernel(LagPre P) {
+  __shared__ float uring[kRgCap][64];
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int tile = blockIdx.x % P.ntile, j = blockIdx.x / P.ntile;
   const int n_raw = tile * 64 + lane;
@@ -186,23 +100,103 @@ __global__ __launch_bounds__(64 * kLaWaves) void lag_sums_kernel(LagPre P) {
     if (!__any(running)) return;                      // (the same answer in every wave of the tile's blocks)
   }
   const double a_d = P.A[(size_t)k * P.D * P.D + (size_t)d * (P.D + 1)];
-  const int ts0 = kLaF + j * P.CL;
-  const int len = min(P.CL, P.T - ts0);
-  const int nss = (len + 63) / 64;
-  // the resource starts 257 rows in front of the chunk (the deepest ring's history)
-  const int base_row = ts0 - (kLaL + 1);
+  const int T = P.T;
+  const int ts0 = kLaF + j * P.CL;                    // (ts0 - 1 is a multiple of 64: ring slots of a set never wrap)
+  const int len = min(P.CL, T - ts0);
+  const int nsets = (len + 31) / 32;
+  const int base_row = max(ts0 - kRgHist - 1, 0);
   const LagRows ld{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.y + (size_t)base_row * P.N + (size_t)tile * 64), 0,
                                                      0x7FFFFFFF, 0x00020000),
-                   (unsigned)((n - tile * 64) * 4), (unsigned)(P.N * 4), base_row, P.T - 1};
-  double* acc = acc_all + (size_t)w * 32 * 64 + lane;
+                   (unsigned)((n - tile * 64) * 4), (unsigned)(P.N * 4), base_row, T - 1};
+  auto input = [&](float yy, float yp) { return UNIT ? (yy - yp) : (float)((double)yy - a_d * (double)yp); };
+  // ---- producers: of every 32 frames from t, wave w owns frames t + 2 w, t + 2 w + 1 (three rows)
+  auto rows_of = [&](int t, float (&r)[3]) {
 #pragma unroll
-  for (int i = 0; i < 32; ++i) acc[i * 64] = 0.0;
-  // (wave 0's "delayed" stream is the current one: the same code as the others - a variant of its own made the
-  //  register allocator spill in that variant: 1.16 against 0.66 ms on BASELINE configs[2])
-  lag_wave_body<UNIT, false>(P, ld, ts0, nss, w, a_d, acc);
+    for (int q = 0; q < 3; ++q) r[q] = ld(t + 2 * w - 1 + q);
+  };
+  auto store_u = [&](int t, const float (&r)[3]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int f = t + 2 * w + q;
+      float u = input(r[q + 1], r[q]);
+      if (!UNIT) u = (f >= kLaF && f < T) ? u : 0.f;  // (with a = 1 the clamped rows give zero by themselves: LagRows)
+      uring[(f - 1) & (kRgCap - 1)][lane] = u;         // frame f lives in slot f - 1: pairs start on even slots
+    }
+  };
+  {
+    // prologue: the history in front of the chunk and its first two sets - every row requested before any is used
+    constexpr int NP = (kRgHist + 64) / 32;
+    float r[NP][3];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) rows_of(ts0 - kRgHist + 32 * i, r[i]);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) store_u(ts0 - kRgHist + 32 * i, r[i]);
+  }
+  float nxt[3];
+  rows_of(ts0 + 64, nxt);                             // the third set's rows: stored at the start of the first
+  __syncthreads();
+  // ---- consumers
+  const int delay = 16 * w;
+  f32x2 E[8], O[9], X[16];
+  double acc[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) E[i] = f32x2{0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) O[i] = f32x2{0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+  auto pair_at = [&](int slot) {                      // frames (slot + 1, slot + 2): slot even, so the rows are neighbours
+    return f32x2{uring[slot][lane], uring[slot + 1][lane]};
+  };
+  {
+    const int h0 = (ts0 - 1 - delay - 32) & (kRgCap - 1), h1 = (ts0 - 1 - delay - 16) & (kRgCap - 1);
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      X[a] = pair_at(h0 + 2 * a);
+      X[8 + a] = pair_at(h1 + 2 * a);
+    }
+  }
+  for (int s = 0; s < nsets; ++s) {
+    const int t = ts0 + 32 * s;
+    // the rows asked for a set ago become inputs two sets ahead (those slots held frames t - 448 .. t - 417: behind what
+    // any wave still reads), and their registers take the next request
+    store_u(t + 64, nxt);
+    rows_of(t + 96, nxt);
+    const int c0 = (t - 1) & (kRgCap - 1);
+    const int d0 = (t - 1 - delay) & (kRgCap - 1), d1 = (t - 1 - delay + 16) & (kRgCap - 1);
+    // the ring's reads run one pair ahead of the products
+    f32x2 Xc = pair_at(c0), Xd = pair_at(d0);
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+      const f32x2 Xc_n = a + 1 < 16 ? pair_at(c0 + 2 * (a + 1)) : Xc;
+      const f32x2 Xd_n = a + 1 < 16 ? pair_at((a + 1 < 8 ? d0 : d1) + 2 * ((a + 1) & 7)) : Xd;
+      X[a] = Xd;
+#pragma unroll
+      for (int dl = 0; dl < 8; ++dl) E[dl] = Xc * X[(a - dl) & 15] + E[dl];
+#pragma unroll
+      for (int dl = 0; dl < 9; ++dl) {
+        const f32x2 xb = X[(a - dl) & 15];
+        O[dl] = Xc * f32x2{xb[1], xb[0]} + O[dl];
+      }
+      Xc = Xc_n;
+      Xd = Xd_n;
+      EKS_SCHED_FENCE();
+    }
+    if ((s & 1) || s + 1 == nsets) {                  // float32 partial sums span 64 frames
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        acc[2 * jj] += (double)(E[jj][0] + E[jj][1]);
+        acc[2 * jj + 1] += (double)(O[jj][1] + O[jj + 1][0]);
+        E[jj] = f32x2{0.f, 0.f};
+      }
+#pragma unroll
+      for (int jj = 0; jj < 9; ++jj) O[jj] = f32x2{0.f, 0.f};
+    }
+    __syncthreads();
+  }
   if (n_raw < P.N) {
-#pragma unroll 4
-    for (int i = 0; i < 32; ++i) P.part[((size_t)j * kLaL + w * 32 + i) * P.N + n] = acc[i * 64];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) P.part[((size_t)j * kLaL + 16 * w + i) * P.N + n] = acc[i];
   }
 }
 
@@ -588,7 +582,7 @@ bool diag_lag_adam_ok(int T, int K, int D, int n_blocks) {
 static void lag_geometry(int T, int N, int* nch_out, int* cl_out) {
   const long ntile = (N + 63) / 64;
   const long frames = T - kLaF;
-  long nch = (512 + ntile - 1) / ntile;                // ~two blocks per compute unit
+  long nch = (256 + ntile - 1) / ntile;                // one 16-wave block per compute unit (its ring fills the LDS)
   if (nch > (frames + 63) / 64) nch = (frames + 63) / 64;
   if (nch < 1) nch = 1;
   long cl = ((frames + nch - 1) / nch + 63) / 64 * 64;
@@ -614,7 +608,7 @@ struct LagWs {
 static int lag_ws(int T, int N, void* ws, size_t ws_bytes, LagWs* W) {
   if (ws_bytes < diag_lag_adam_workspace_bytes(T, N)) return EKS_ERR_WORKSPACE;
   lag_geometry(T, N, &W->nch, &W->cl);
-  if ((long)(W->cl + kLaL + 64 + 64) * N * 4 >= (1L << 31)) return EKS_ERR_UNSUPPORTED;   // 32-bit row offsets of a chunk
+  if ((long)(W->cl + kRgHist + 160) * N * 4 >= (1L << 31)) return EKS_ERR_UNSUPPORTED;   // 32-bit row offsets of a chunk
   char* p = static_cast<char*>(ws);
   W->part = reinterpret_cast<double*>(p);
   p += align_up((size_t)W->nch * kLaL * N * sizeof(double), 256);
@@ -637,7 +631,7 @@ int diag_lag_sums(const eks_dims_t& d, const float* y, const double* A, const Ad
     ProfScope ps("lag_sums", st);
     const LagPre P{T, N, D, ntile, W.nch, W.cl, y, A, W.part, F ? F->state : nullptr, F ? F->kp_block : nullptr,
                    F ? F->cap : 0};
-    const dim3 grid((unsigned)(ntile * W.nch)), block(64 * kLaWaves);
+    const dim3 grid((unsigned)(ntile * W.nch)), block(64 * kRgWaves);
     if (d.flags & EKS_FLAG_UNIT_AC) hipLaunchKernelGGL(lag_sums_kernel<true>, grid, block, 0, st, P);
     else hipLaunchKernelGGL(lag_sums_kernel<false>, grid, block, 0, st, P);
   }
