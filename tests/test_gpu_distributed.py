@@ -25,6 +25,8 @@ def test_two_ranks_smooth_their_session_shards():
     assert 'rank 0: sessions [0, 2, 4] ok' in r.stdout and 'rank 1: sessions [1, 3] ok' in r.stdout
     assert 'rank 0: batched sessions [0, 2, 4] ok' in r.stdout and 'rank 1: batched sessions [1, 3] ok' in r.stdout
     assert r.stdout.count('keypoint shard') == 2
+    # (the reference's default mode on both ranks at once, sharing the GPU: tools/dist_smoke.py)
+    assert 'rank 0: adam sessions [0, 2] ok' in r.stdout and 'rank 1: adam sessions [1, 3] ok' in r.stdout
 
 
 def test_two_ranks_over_rccl_when_two_gpus_are_visible():

@@ -61,5 +61,28 @@ so2, ms_o2, _, _ = orc.run_kalman_smoother(big['ys'], big['m0s'], big['S0s'], bi
                                            big['ensemble_vars'], smooth_param=list(s_k))
 assert rel(ms_k, ms_o2[own]) < 1e-5
 print(f'rank {rank}: keypoint shard {list(own)} ok ({backend})', flush=True)
+
+# the reference's default mode on every rank at once: sessions long enough for the search from
+# cached lag sums - a pass over y, then ONE launch of a workgroup per keypoint in which nothing waits for another
+# workgroup - while the other rank's search shares the device; every session equals its own single-process result
+from eks_amd.core import run_kalman_smoother
+
+
+def load_long(i):
+    return load(200 + i, T=3000, K=5)
+
+
+adam_local, adam_s = smooth_sessions(load_long, 4)
+assert sorted(adam_local) == list(range(rank, 4, world)) and len(adam_s) == 4
+dist.barrier()                                          # (the single-process repeats run after both ranks' searches)
+for i, (s, ms, Vs) in adam_local.items():
+    a = load_long(i)
+    s1, ms1, Vs1 = run_kalman_smoother(a['ys'], a['m0s'], a['S0s'], a['As'], a['Cs'], a['Qs'], a['ensemble_vars'])
+    np.testing.assert_array_equal(s, s1)
+    np.testing.assert_array_equal(ms, ms1)
+    np.testing.assert_array_equal(s, adam_s[i])
+    s_o = orc.run_kalman_smoother(a['ys'], a['m0s'], a['S0s'], a['As'], a['Cs'], a['Qs'], a['ensemble_vars'])[0]
+    np.testing.assert_allclose(np.log(s), np.log(s_o), atol=2e-6)
+print(f'rank {rank}: adam sessions {sorted(adam_local)} ok', flush=True)
 dist.barrier()
 dist.destroy_process_group()

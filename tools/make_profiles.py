@@ -27,14 +27,13 @@ for r in rows:
         tot += float(r['AverageNs']) / 1e3
 out.append(f"# sum of per-kernel averages = {tot:.1f} us per step (bench.py wall clock: {b['ms_per_step']*1e3:.1f} us per step)")
 open(os.path.join(prof, f'{tag}_kernel_stats.txt'), 'w').write('\n'.join(out) + '\n')
-# the Adam-mode session (c3adam): every eks_adam_run call is ONE launch of the loss kernel (round 5)
+# the Adam-mode session (c3adam): one pass for the lag sums, then the whole search in ONE launch (round 6)
 try:
     rows_a = list(csv.DictReader(open(newest(os.path.join(ev, 'stats_c3adam', '*', '*_kernel_stats.csv')))))
     out_a = [f'# {tag}: rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --workload c3adam --steps 5 '
              '--warmup 2 --no-cpu-baseline --no-kernel-events',
-             '# singlecam T=100000 x K=256, smooth_param=None: 7 steps, each 3 eks_adam_run calls (128 + 128 + 44 iterations:',
-             '# the first runs the whole search - 118 iterations - inside one launch, the others return at once) + final smooth.',
-             '# (under a rocprofiler tool the launch is an ordinary one instead of a cooperative one: same kernel)',
+             '# singlecam T=100000 x K=256, smooth_param=None: 7 steps, each = eks_adam_prepare (lag_sums + lag_reduce), ONE',
+             '# eks_adam_run call (lag_adam_kernel: the whole search, 55-118 iterations per keypoint) and the final smooth.',
              f"{'kernel':92s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>7s}"]
     for r in rows_a:
         if 'eks::' in r['Name']:
@@ -76,13 +75,14 @@ json.dump({'source': f'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate p
                          'coalesced stream, MI355X_MICROARCH.md HBM section)',
            'kernel_sources_sha16': open(os.path.join(ev, 'kernel_sources_sha16.txt')).read().strip(),
            'hbm_bytes_per_launch': traffic}, open(os.path.join(prof, f"{tag.split('_')[0]}_traffic.json"), 'w'), indent=1)
-for name in ('c3', 'c3adam', 'c3adam_per_iteration', 'c3adam_per_iteration_tree', 'c3_legacy_nll', 'c3_nolag', 'c4', 'c4w', 'c4adam', 'c5', 'c2', 'pupil', 'ekf', 'c3_2ranks_gloo', 'c3_2ranks_gloo_strong'):
+for name in ('c3', 'c3_default_run', 'c3adam', 'c3adam_streaming', 'c3adam_all_chains_streamed', 'c3_legacy_nll', 'c3_nolag', 'c4', 'c4w', 'c4adam', 'c5', 'c2', 'pupil', 'ekf', 'c3_2ranks_gloo', 'c3_2ranks_gloo_strong'):
     src = os.path.join(ev, f'bench_{name}.json')
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(prof, f'{tag}_bench_{name}.json'))
 for name in ('pytest_gpu.txt', 'smoke.txt', 'adam_time.txt', 'dense_adam_time.txt', 'dense_adam_time_d.txt',
              'pupil_time.txt', 'ekf_time.txt', 'driver_time.txt', 'host_path_time.txt', 'first_call.txt', 'nll_lean2.txt', 'nll_lag.txt',
-             'fit_time.txt', 'host_boundary_ab.txt', 'grid_stamps.txt', 'gf_loop_stamps.txt'):
+             'fit_time.txt', 'host_boundary_ab.txt', 'grid_stamps.txt', 'lag_adam_check.txt', 'lag_prepass_time.txt',
+             'ekf_chunk_trade.txt', 'c3adam_timeline.txt'):
     src = os.path.join(ev, name)
     if os.path.exists(src):
         shutil.copy(src, os.path.join(prof, f'{tag}_{name}'))
