@@ -417,16 +417,31 @@ __device__ __forceinline__ DualD la_nll_stream(const LaConst& K, const float* __
   double pprod = 1.0, dlog = 0.0;
   int n_steady = 0;
   constexpr int NB = 8;
-  float buf[NB + 1];
-  auto fetch = [&](int t) {                                   // rows t .. t + NB (clamped)
+  float buf[NB + 1], nbuf[NB + 1];
+  auto fetch = [&](int t, float (&b)[NB + 1]) {               // rows t .. t + NB (clamped)
 #pragma unroll
-    for (int q = 0; q <= NB; ++q) buf[q] = yc[min(t + q, T - 1)];
+    for (int q = 0; q <= NB; ++q) b[q] = yc[min(t + q, T - 1)];
   };
   const double w0a = fabs(K.w0);
+  fetch(t0, nbuf);
   for (int t = t0; t < t1; t += NB) {
-    fetch(t);
+#pragma unroll
+    for (int q = 0; q <= NB; ++q) buf[q] = nbuf[q];
+    fetch(t + NB, nbuf);                                       // the next block's rows travel beside this block's arithmetic
     const bool steady = __all(w0a * kt < 1e-18) != 0 && t > 0;
-    if (steady) {
+    const bool al_dead = __all(al.v == 0.0 && al.d == 0.0) != 0;
+    if (steady && al_dead) {
+      // the variance is the fixed point and the memory of the lane's first innovation has died: sum beta^2 alone
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
+        if (t + q < t1) {
+          Sbb = Sbb + be * be;
+          const double u = t + q + 1 < T ? (double)buf[q + 1] - K.a * (double)buf[q] : 0.0;
+          be = K.rho * be + DualD(u);
+          ++n_steady;
+        }
+      }
+    } else if (steady) {
 #pragma unroll
       for (int q = 0; q < NB; ++q) {
         if (t + q < t1) {
@@ -436,7 +451,7 @@ __device__ __forceinline__ DualD la_nll_stream(const LaConst& K, const float* __
           const double u = t + q + 1 < T ? (double)buf[q + 1] - K.a * (double)buf[q] : 0.0;
           al = K.rho * al;
           be = K.rho * be + DualD(u);
-          if (fabs(al.v) < 1e-80) al = DualD(0.0);
+          if (fabs(al.v) < 1e-20) al = DualD(0.0);   // (its terms are below 1e-20 of the sums)
           ++n_steady;
         }
       }
@@ -456,7 +471,7 @@ __device__ __forceinline__ DualD la_nll_stream(const LaConst& K, const float* __
           const double u = tt + 1 < T ? (double)buf[q + 1] - K.a * (double)buf[q] : 0.0;
           al = rt * al;
           be = rt * be + DualD(u);
-          if (fabs(al.v) < 1e-80) al = DualD(0.0);
+          if (fabs(al.v) < 1e-20) al = DualD(0.0);   // (its terms are below 1e-20 of the sums)
         }
       }
     }
