@@ -308,9 +308,23 @@ def _adam_setup(P: _DeviceProblem, blocks, s_frames, lr, s_bounds_log, tol, safe
         offs_d = torch.as_tensor(offs, device=P.dev)
         mem_d = torch.as_tensor(members, device=P.dev)
     loop = hip_ops.AdamLoop(y_c, None, *P.params, offs_d, mem_d, state, s_kp, lr, lo, hi, tol, safety_cap, flags=P.flags)
-    loop.prepare()
+    prep_ev = None
+    if os.environ.get('EKS_ADAM_PREPARE_INLINE'):            # (A/B runs: the pass on the caller's stream)
+        loop.prepare()
+    else:
+        # ... on a SIDE stream: the pass is bound by the vector pipe (0.07 of HBM), eks_const_r and the guesses' reduction
+        # by memory latency and bandwidth - side by side they take the time of the pass alone.  The search waits for both.
+        cur = torch.cuda.current_stream(P.dev)
+        side = _prepare_stream(P.dev)
+        side.wait_stream(cur)                                # (y, and whatever produced it, is ready)
+        with torch.cuda.stream(side):
+            if loop.prepare():
+                prep_ev = torch.cuda.Event()
+                prep_ev.record(side)
+        for t in (y_c, loop.ws, *P.params):
+            t.record_stream(side)
     return dict(y_c=y_c, var_c=var_c, offs=offs, members=members, of_kp=of_kp, packed=packed, state=state, s_kp=s_kp,
-                loop=loop)
+                loop=loop, prep_ev=prep_ev)
 
 
 def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, s_bounds_log, tol,
@@ -366,6 +380,8 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
     packed_h[3:nb * 6:6] = np.inf
     packed_h[nb * 6:] = np.exp(np.clip(u0, lo, hi))[of_kp]
     packed.copy_(stage, non_blocking=True)
+    if setup.get('prep_ev') is not None:
+        torch.cuda.current_stream(P.dev).wait_event(setup['prep_ev'])
     iters, cap = 0, int(safety_cap)
     # several iterations per host round trip: a step enqueued after a block has stopped (or reached the
     # cap) leaves that block untouched (its loss waves exit at once), so over-issuing changes nothing.
@@ -619,6 +635,18 @@ def _tile_streams(dev):
         if key not in _TILE_STREAMS:
             _TILE_STREAMS[key] = [_torch().cuda.Stream(device=dev) for _ in range(4)]
         return _TILE_STREAMS[key]
+
+
+_PREPARE_STREAMS: dict = {}
+
+
+def _prepare_stream(dev):
+    """The side stream of the search's pass over y (_adam_setup), one per device and calling thread, created once."""
+    key = (dev.index if dev.index is not None else _torch().cuda.current_device(), threading.get_ident())
+    with _state_lock:
+        if key not in _PREPARE_STREAMS:
+            _PREPARE_STREAMS[key] = _torch().cuda.Stream(device=dev)
+        return _PREPARE_STREAMS[key]
 
 
 _TILE_ADAM = False
