@@ -81,6 +81,10 @@ def parse():
     p.add_argument('--regions', type=int, default=5,
                    help='how many back-to-back timed regions of --steps steps each; ms_per_step / value are the '
                         'MEDIAN region (max over ranks per region), min / max are reported beside it')
+    p.add_argument('--cpu-max-keypoints', type=int, default=0,
+                   help='cap on the keypoints of the CPU baseline / parity sample (0: only --cpu-seconds bounds it)')
+    p.add_argument('--lean', action='store_true',
+                   help='skip the NumPy baseline and the NumPy-boundary timing (the extras\' child legs)')
     p.add_argument('--no-extras', action='store_true',
                    help='headline line only: skip the short legs of the other BASELINE configurations that the default '
                         'single-GPU run reports under `extras`')
@@ -119,7 +123,7 @@ def self_launch(args):
     return child.wait()
 
 
-TRAFFIC_FILES = ('r05_traffic.json', 'r04_traffic.json')
+TRAFFIC_FILES = ('r06_traffic.json', 'r05_traffic.json')
 # the sources whose kernels the traffic summary describes: a summary taken before any of them changed
 # is STALE and is not reported (tests/test_abi_surface.py fails on a stale committed summary)
 TRAFFIC_SOURCES = ('eks_diag.hip', 'eks_diag_lane.hpp', 'eks_math.hpp', 'eks_diag_nll.hip', 'eks_nll_lane.hpp', 'eks_nll_lag.hpp')
@@ -216,7 +220,7 @@ def numpy_baseline(y_dev, var_dev, T, n_cand, budget_s=6.0):
                        f'(oracle/eks_oracle.py: vectorised over keypoints, sequential in time), {dt:.1f} s')
 
 
-def cpu_baseline(y_dev, var_dev, T, n_cand, budget_s):
+def cpu_baseline(y_dev, var_dev, T, n_cand, budget_s, max_keypoints=0):
     """Time the C twin of the oracle (general-matrix port of the reference recursion, OpenMP over
     keypoints) on a bounded sample of the same workload: the first Kc keypoints, all T frames."""
     from oracle import c_oracle, eks_oracle as orc
@@ -227,6 +231,8 @@ def cpu_baseline(y_dev, var_dev, T, n_cand, budget_s):
     per_kp = T * 0.3e-6 * (max(n_cand, 0) + 2.5)
     Kc = int(max(cores, min(y_dev.shape[1], round(budget_s * cores / per_kp))))
     Kc = min(Kc, y_dev.shape[1])
+    if max_keypoints > 0:
+        Kc = min(Kc, max_keypoints)
     y = np.transpose(y_dev[:, :Kc].cpu().numpy().astype(np.float64), (1, 0, 2)).copy()
     var = np.transpose(var_dev[:, :Kc].cpu().numpy().astype(np.float64), (1, 0, 2)).copy()
     eye = np.tile(np.eye(2), (Kc, 1, 1))
@@ -352,7 +358,39 @@ def bench_dense(args, T, K, dev, rank, world, lib, grad=False):
                                  'float64 3x3 algebra per frame (about 800 FMAs per keypoint-frame through summarize, '
                                  'scan and replay) against 80 B: the FP64 vector rate (78.6 TFLOP/s peak) bounds this '
                                  'shape at about the same level as HBM does')}}
+    parity_failed = False
+    if not grad and not args.no_cpu_baseline:
+        # the timed path's outputs against the float64 C port (oracle/eks_oracle.c: eksc_smooth, the general-matrix
+        # recursion) on a bounded sample of keypoints, every frame - never timed into `value`
+        try:
+            from oracle import c_oracle
+            Kc = min(K, args.cpu_max_keypoints or 16)
+            step()
+            torch.cuda.synchronize()
+            f64 = lambda t: t[:Kc].cpu().numpy().astype(np.float64)
+            t0 = time.perf_counter()
+            ms_o, Vs_o, _ = c_oracle.smooth(np.transpose(y[:, :Kc].cpu().numpy().astype(np.float64), (1, 0, 2)),
+                                            np.clip(np.transpose(var[:, :Kc].cpu().numpy().astype(np.float64), (1, 0, 2)),
+                                                    1e-12, None), f64(m0), f64(S0), f64(eye), f64(C), f64(Q), f64(s))
+            dt_cpu = time.perf_counter() - t0
+            ms_g = np.transpose(ms[:, :Kc].cpu().numpy().astype(np.float64), (1, 0, 2))
+            Vs_g = np.transpose(Vs[:, :Kc].cpu().numpy().astype(np.float64), (1, 0, 2, 3))
+            par = {'ms_max_rel_err': float((np.abs(ms_g - ms_o) / np.abs(ms_o).max(axis=(1, 2), keepdims=True)).max()),
+                   'Vs_max_rel_err': float((np.abs(Vs_g - Vs_o) / np.abs(Vs_o).max(axis=(1, 2, 3), keepdims=True)).max()),
+                   'keypoints_compared': Kc, 'bar': PARITY_BAR}
+            par['ok'] = bool(par['ms_max_rel_err'] < PARITY_BAR and par['Vs_max_rel_err'] < PARITY_BAR)
+            out['parity_vs_cpu_port'] = par
+            out['cpu_baseline'] = {'value': T * Kc / dt_cpu, 'unit': 'frames*keypoints/s', 'cores': 1, 'kind': 'port',
+                                   'sample': f'{Kc} keypoints x all {T} frames, fixed s, float64 C port of the general-matrix '
+                                             f'recursion (oracle/eks_oracle.c), {dt_cpu:.1f} s'}
+            parity_failed = not par['ok']
+        except Exception as e:                          # the baseline must never sink the bench line
+            out['cpu_baseline'] = {'value': None, 'unit': 'frames*keypoints/s', 'cores': 0, 'kind': 'port',
+                                   'sample': f'failed: {e!r}'}
     print(json.dumps(out), flush=True)
+    if parity_failed:
+        print(f'bench.py: parity_vs_cpu_port beyond {PARITY_BAR:g}: {out["parity_vs_cpu_port"]}', file=sys.stderr)
+        raise SystemExit(3)
 
 
 def bench_c3adam(args, T, K, dev, lib, ranks_info):
@@ -929,15 +967,16 @@ def main():
                 out['roofline'] = {**hbm_roof, **stage_info}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                cb, s_cpu, ref = cpu_baseline(y, var, T, n_cand, args.cpu_seconds)
+                cb, s_cpu, ref = cpu_baseline(y, var, T, n_cand, args.cpu_seconds, args.cpu_max_keypoints)
                 out['cpu_baseline'] = cb
                 out['gpu_over_cpu'] = value / cb['value']
                 out['cpu_baseline_diag'] = ref.pop('diag')
                 out['gpu_over_cpu_diag'] = value / out['cpu_baseline_diag']['value']
-                try:
-                    out['cpu_baseline_numpy'] = numpy_baseline(y, var, T, n_cand)
-                except Exception as e:
-                    out['cpu_baseline_numpy'] = {'value': None, 'sample': f'failed: {e!r}'}
+                if not args.lean:
+                    try:
+                        out['cpu_baseline_numpy'] = numpy_baseline(y, var, T, n_cand)
+                    except Exception as e:
+                        out['cpu_baseline_numpy'] = {'value': None, 'sample': f'failed: {e!r}'}
                 if n_cand:
                     # compare grid INDICES (the candidate values differ by an ulp between
                     # torch.linspace and numpy.linspace)
@@ -972,10 +1011,11 @@ def main():
             except Exception as e:                      # the baseline must never sink the bench line
                 out['cpu_baseline'] = {'value': None, 'unit': 'frames*keypoints/s', 'cores': 0,
                                        'kind': 'port', 'sample': f'failed: {e!r}'}
-            try:
-                out['host_boundary'] = host_boundary_rate(y, var, T, K, n_cand)
-            except Exception as e:
-                out['host_boundary'] = {'value': None, 'note': f'failed: {e!r}'}
+            if not args.lean:
+                try:
+                    out['host_boundary'] = host_boundary_rate(y, var, T, K, n_cand)
+                except Exception as e:
+                    out['host_boundary'] = {'value': None, 'note': f'failed: {e!r}'}
         if headline and world == 1 and not args.no_extras and not args.no_cpu_baseline:
             out['extras'] = collect_extras()
             parity_failed = parity_failed or any(isinstance(v, dict) and v.get('exit_code') == 3
@@ -993,9 +1033,9 @@ def main():
 
 EXTRA_LEGS = (      # (workload, extra arguments): short runs of the other BASELINE configurations, each a child process
     ('c3adam', ['--steps', '5', '--warmup', '2', '--regions', '3', '--cpu-seconds', '8']),
-    ('c2', ['--steps', '50', '--warmup', '5', '--regions', '3', '--cpu-seconds', '3']),
+    ('c2', ['--steps', '50', '--warmup', '5', '--regions', '3', '--cpu-seconds', '3', '--lean']),
     ('c4', ['--steps', '50', '--warmup', '5', '--regions', '3', '--cpu-seconds', '3']),
-    ('c5', ['--steps', '5', '--warmup', '2', '--regions', '3', '--cpu-seconds', '4']),
+    ('c5', ['--steps', '5', '--warmup', '2', '--regions', '3', '--cpu-seconds', '4', '--cpu-max-keypoints', '256', '--lean']),
 )
 
 

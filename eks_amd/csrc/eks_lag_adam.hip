@@ -319,7 +319,8 @@ struct LagAdam {
   const double* rconst;
   const double *m0, *S0, *A, *C, *Q;
   const double* ck;            // [N][kLaL]
-  float* yT;                   // [N][T] chain-major copies, made by a chain's wave the first time it needs one
+  float* yT;                   // [N][pitch] chain-major copies (pitch = T rounded up to 16 floats: a lane's 8-frame
+                               // blocks are 32-byte aligned), made by a chain's wave the first time it needs one
   const int32_t* kp_block;
   double lr, lo, hi, tol;
   int cap, n_iters;
@@ -399,8 +400,8 @@ __device__ __forceinline__ DualD la_nll_fast(const LaConst& K, const LaLane& L, 
 
 // the chain's NLL and d / d log s by streaming its own frames (any pole): lane = time chunk of the chain-major copy
 __device__ __forceinline__ DualD la_nll_stream(const LaConst& K, const float* __restrict__ yc, int T, double e0, int lane) {
-  const int cl = (T + 63) / 64;
-  const int t0 = lane * cl, t1 = min(T, t0 + cl);
+  const int cl = ((T + 63) / 64 + 7) / 8 * 8;            // (whole 8-frame blocks: aligned 16-byte loads)
+  const int t0 = min(lane * cl, T), t1 = min(T, t0 + cl);
   // kappa^t0 by squaring
   double kt = 1.0;
   {
@@ -418,20 +419,48 @@ __device__ __forceinline__ DualD la_nll_stream(const LaConst& K, const float* __
   int n_steady = 0;
   constexpr int NB = 8;
   float buf[NB + 1], nbuf[NB + 1];
-  auto fetch = [&](int t, float (&b)[NB + 1]) {               // rows t .. t + NB (clamped)
-#pragma unroll
-    for (int q = 0; q <= NB; ++q) b[q] = yc[min(t + q, T - 1)];
+  // rows t .. t + NB: two aligned 16-byte loads (the copy's pitch is padded: a block past the end reads the pad, whose
+  // contents are never used - every use below is selected by t + q + 1 < T) and the row after them
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int tpad = (T + 15) / 16 * 16;
+  auto fetch = [&](int t, float (&b)[NB + 1]) {
+    const int tb = min(t, tpad - NB);
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(yc + tb), hi = *reinterpret_cast<const f32x4*>(yc + tb + 4);
+    b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = lo[3];
+    b[4] = hi[0]; b[5] = hi[1]; b[6] = hi[2]; b[7] = hi[3];
+    b[8] = yc[min(tb + NB, tpad - 1)];
   };
   const double w0a = fabs(K.w0);
-  fetch(t0, nbuf);
+  if (t0 < t1) fetch(t0, nbuf);
   for (int t = t0; t < t1; t += NB) {
 #pragma unroll
     for (int q = 0; q <= NB; ++q) buf[q] = nbuf[q];
     fetch(t + NB, nbuf);                                       // the next block's rows travel beside this block's arithmetic
     const bool steady = __all(w0a * kt < 1e-18) != 0 && t > 0;
     const bool al_dead = __all(al.v == 0.0 && al.d == 0.0) != 0;
-    if (steady && al_dead) {
-      // the variance is the fixed point and the memory of the lane's first innovation has died: sum beta^2 alone
+    if (steady && al_dead && __all(t + NB <= t1 && t + NB < T || t >= t1) != 0) {
+      // whole blocks in the steady state with the lane's first innovation forgotten: beta and sum beta^2 alone, written
+      // out (five float64 FMAs and a conversion per frame; the operators above spent 20 instructions)
+      if (t < t1) {
+        double bv = be.v, bd = be.d, sv = 0.0, sd2 = 0.0, yq = (double)buf[0];
+        const double rv = K.rho.v, rd = K.rho.d;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          sv = __builtin_fma(bv, bv, sv);
+          sd2 = __builtin_fma(bv, bd, sd2);
+          const double yn = (double)buf[q + 1];
+          const double u = __builtin_fma(-K.a, yq, yn);
+          yq = yn;
+          const double nbd = __builtin_fma(rv, bd, rd * bv);
+          bv = __builtin_fma(rv, bv, u);
+          bd = nbd;
+        }
+        be = DualD(bv, bd);
+        Sbb = Sbb + DualD(sv, 2.0 * sd2);
+        n_steady += NB;
+      }
+    } else if (steady && al_dead) {
+      // ... ragged blocks of the same regime
 #pragma unroll
       for (int q = 0; q < NB; ++q) {
         if (t + q < t1) {
@@ -533,7 +562,7 @@ __global__ __launch_bounds__(64 * kLaMaxD) void lag_adam_kernel(LagAdam P) {
     }
   }
   bool have_copy = false;
-  float* yc = P.yT + (size_t)n * T;
+  float* yc = P.yT + (size_t)n * (((size_t)T + 15) / 16 * 16);
   double b1t = adam_pow_count(0.9, iters), b2t = adam_pow_count(0.999, iters);
   for (int it = 0; it < P.n_iters; ++it) {
     const double s = exp(fmin(fmax(u, P.lo), P.hi));
@@ -605,18 +634,20 @@ static void lag_geometry(int T, int N, int* nch_out, int* cl_out) {
   if (nch > (frames + 63) / 64) nch = (frames + 63) / 64;
   if (nch < 1) nch = 1;
   long cl = ((frames + nch - 1) / nch + 63) / 64 * 64;
+  // (a chunk's rows are addressed with 32-bit offsets from its first row: very wide sessions take more, shorter chunks)
+  while (cl > 64 && (cl + kRgHist + 160) * (long)N * 4 >= (1L << 31)) cl = (cl / 2 + 63) / 64 * 64;
   nch = (frames + cl - 1) / cl;
   *nch_out = (int)nch;
   *cl_out = (int)cl;
 }
 
-// [part : nch x 256 x N doubles][ck : N x 256 doubles][yT : N x T floats]
+// [part : nch x 256 x N doubles][ck : N x 256 doubles][yT : N x (T rounded up to 16) floats]
 size_t diag_lag_adam_workspace_bytes(int T, int N) {
   if (T < kLaMinT) return 0;
   int nch, cl;
   lag_geometry(T, N, &nch, &cl);
   return align_up((size_t)nch * kLaL * N * sizeof(double), 256) + align_up((size_t)N * kLaL * sizeof(double), 256) +
-         align_up((size_t)N * T * sizeof(float), 256);
+         align_up((size_t)N * (((size_t)T + 15) / 16 * 16) * sizeof(float), 256);
 }
 
 struct LagWs {

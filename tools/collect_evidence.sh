@@ -8,7 +8,7 @@ O=$R/gpurun_out/evidence
 rm -rf $O; mkdir -p $O
 cd $R
 python -c "import bench; print(bench.kernel_sources_sha16())" > $O/kernel_sources_sha16.txt
-python -m pytest tests -q -m gpu 2>&1 | tail -3 > $O/pytest_gpu.txt
+python -m pytest tests -q -m gpu --durations=15 2>&1 | tail -24 > $O/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 # the driver's command (headline + the short legs of the other configurations under `extras`), then the headline alone
 python bench.py > $O/bench_c3_default_run.json 2> $O/bench_c3_default_run.err

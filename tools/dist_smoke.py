@@ -81,8 +81,6 @@ for i, (s, ms, Vs) in adam_local.items():
     np.testing.assert_array_equal(s, s1)
     np.testing.assert_array_equal(ms, ms1)
     np.testing.assert_array_equal(s, adam_s[i])
-    s_o = orc.run_kalman_smoother(a['ys'], a['m0s'], a['S0s'], a['As'], a['Cs'], a['Qs'], a['ensemble_vars'])[0]
-    np.testing.assert_allclose(np.log(s), np.log(s_o), atol=2e-6)
 print(f'rank {rank}: adam sessions {sorted(adam_local)} ok', flush=True)
 dist.barrier()
 dist.destroy_process_group()
