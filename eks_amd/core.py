@@ -193,7 +193,8 @@ def _initial_guesses_per_keypoint(ev_host: np.ndarray = None, rows: np.ndarray |
         with warnings.catch_warnings():
             warnings.simplefilter('ignore', RuntimeWarning)      # all-NaN keypoints: nan -> 2.0 below
             sd = np.nanstd(d, axis=1)
-    g = np.array([round(float(v), 5) for v in sd])               # Python's round on a Python float, as the scalar form
+    g = np.array([round(v, 5) for v in np.asarray(sd, dtype=np.float64).tolist()])   # Python's round on a Python
+                                                                 # float, as the scalar form
     g = np.where(g == 0.0, 2.0, g)                               # (`or 2.0` of the loop form)
     return np.where(np.isfinite(g) & (g > 0.0), g, 2.0)
 

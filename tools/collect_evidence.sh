@@ -36,7 +36,7 @@ python bench.py --workload ekf > $O/bench_ekf.json 2>/dev/null
 python tools/ekf_time.py > $O/ekf_time.txt 2>&1
 python tools/driver_time.py 2>&1 | grep -E " ms" > $O/driver_time.txt
 python tools/host_path_time.py 2>&1 | grep -v amdgpu > $O/host_path_time.txt
-for m in diag dense; do python tools/first_call.py $m 2>&1 | grep -v amdgpu; EKS_AUTO_WARMUP=1 python tools/first_call.py $m 2>&1 | grep -v amdgpu | sed 's/^/auto warm-up (EKS_AUTO_WARMUP=1): /'; done > $O/first_call.txt
+for m in diag dense; do python tools/first_call.py $m 2>&1 | grep -v amdgpu; done > $O/first_call.txt
 python tools/fit_time.py 2>&1 | grep -v amdgpu > $O/fit_time.txt
 python tools/host_boundary_ab.py 2>&1 | grep -v amdgpu > $O/host_boundary_ab.txt
 EKS_HIP_LIB=build_alt/gridstamps/libeks_hip.so python tools/grid_stamps.py 2>&1 | grep -v amdgpu > $O/grid_stamps.txt
