@@ -30,7 +30,7 @@ enum Knob {
   KNOB_SMOOTH_UNFUSED, KNOB_SUMMARIZE_REVERSE, KNOB_REPLAY_FORWARD, KNOB_REPLAY_RECOMPUTE, KNOB_SCAN_CH,
   KNOB_DENSE_CHUNK, KNOB_NLL_NCL, KNOB_NLL_CHUNK, KNOB_NLL_CHUNK0, KNOB_NLL_WPB,
   KNOB_DENSE_LEGACY, KNOB_NLL_GRAD_UNFUSED, KNOB_NLL_GRAD_CHUNK,
-  KNOB_DENSE_TREE_SCAN, KNOB_DENSE_DUAL_GRAD, KNOB_NLL_LEGACY, KNOB_MED_ROWS, KNOB_DW_CHUNK, KNOB_ADAM_PER_ITERATION, KNOB_MED_FINISH_THREADS, KNOB_MED_BRACKET_THREADS, KNOB_NLL_NOLAG, KNOB_NLL_GRAD_TREE, KNOB_ADAM_STREAM, KNOB_ADAM_LAG_RHO_PPM, KNOB_COUNT
+  KNOB_DENSE_TREE_SCAN, KNOB_DENSE_DUAL_GRAD, KNOB_NLL_LEGACY, KNOB_MED_ROWS, KNOB_DW_CHUNK, KNOB_ADAM_PER_ITERATION, KNOB_MED_FINISH_THREADS, KNOB_MED_BRACKET_THREADS, KNOB_NLL_NOLAG, KNOB_NLL_GRAD_TREE, KNOB_ADAM_STREAM, KNOB_ADAM_LAG_RHO_PPM, KNOB_ADAM_LAG_HEAD, KNOB_COUNT
 };
 bool knob_set(Knob k);               // the variable exists
 int knob_int(Knob k, int dflt);      // its integer value, or dflt when unset

@@ -218,14 +218,22 @@ __device__ __forceinline__ double la_readlane(double x, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
   return __hiloint2double(hi, lo);
 }
-// sum / product over the 64 lanes, the same value in every lane
+// the same with zeros where a lane has no source (bound_ctrl): every lane is written, so no register is set up to
+// hold the `old` value (two v_mov per 64-bit value and step otherwise)
+template <int CTRL>
+__device__ __forceinline__ double la_dpp_z(double x) {
+  return __builtin_amdgcn_update_dpp(0.0, x, CTRL, 0xf, 0xf, true);
+}
+// sum / product over the 64 lanes, the same value in every lane.  The sum only has to be right in lane 63: the row
+// broadcasts go to every row (row 1 takes row 0's total, row 2 row 1's, row 3 row 2's; then rows 2, 3 take lane 31's
+// R0 + R1), which leaves R0 + R1 + R2 + R3 in the last row and needs no row mask, hence no `old`
 __device__ __forceinline__ double la_wave_sum(double x) {
-  x += la_dpp<0x111>(0.0, x);
-  x += la_dpp<0x112>(0.0, x);
-  x += la_dpp<0x114>(0.0, x);
-  x += la_dpp<0x118>(0.0, x);
-  x += la_dpp<0x142, 0xa>(0.0, x);        // row_bcast:15 into rows 1, 3
-  x += la_dpp<0x143, 0xc>(0.0, x);        // row_bcast:31 into rows 2, 3
+  x += la_dpp_z<0x111>(x);
+  x += la_dpp_z<0x112>(x);
+  x += la_dpp_z<0x114>(x);
+  x += la_dpp_z<0x118>(x);
+  x += la_dpp_z<0x142>(x);                // row_bcast:15
+  x += la_dpp_z<0x143>(x);                // row_bcast:31
   return la_readlane(x, 63);
 }
 __device__ __forceinline__ double la_wave_prod(double x) {
@@ -253,12 +261,25 @@ __device__ __forceinline__ void la_scan_step(LaAff& x) {
   e.b.d = la_dpp<CTRL, ROW_MASK>(0.0, x.b.d);
   x = la_then(e, x);
 }
+// a shift inside the rows of 16: lanes without a source read zeros, which IS the identity map but for the high word
+// of A = 1.0 (one select instead of eight moves)
+template <int SH>
+__device__ __forceinline__ void la_scan_row_step(LaAff& x, int lane) {
+  LaAff e;
+  const double av = la_dpp_z<0x110 + SH>(x.A.v);
+  const int hi = (lane & 15) < SH ? 0x3FF00000 : __double2hiint(av);
+  e.A.v = __hiloint2double(hi, __double2loint(av));
+  e.A.d = la_dpp_z<0x110 + SH>(x.A.d);
+  e.b.v = la_dpp_z<0x110 + SH>(x.b.v);
+  e.b.d = la_dpp_z<0x110 + SH>(x.b.d);
+  x = la_then(e, x);
+}
 // inclusive scan in lane order: afterwards lane i maps the innovation entering lane 0 to the one leaving lane i
-__device__ __forceinline__ void la_scan(LaAff& x) {
-  la_scan_step<0x111>(x);
-  la_scan_step<0x112>(x);
-  la_scan_step<0x114>(x);
-  la_scan_step<0x118>(x);
+__device__ __forceinline__ void la_scan(LaAff& x, int lane) {
+  la_scan_row_step<1>(x, lane);
+  la_scan_row_step<2>(x, lane);
+  la_scan_row_step<4>(x, lane);
+  la_scan_row_step<8>(x, lane);
   la_scan_step<0x142, 0xa>(x);
   la_scan_step<0x143, 0xc>(x);
 }
@@ -280,6 +301,7 @@ struct LaConst {
   DualD Sinf, g, rho, dS;      // dS = S_inf - S_-
   double dlr;                  // d log rho / d log s = -g dS_inf
   double kap, w0, dw0;         // kappa = S_- / S_inf, d log kappa = 2 dlr
+  double om0;                  // 1 - w_0 = (P_inf - P_-) / (P_0 - P_-), formed without the cancellation of 1 - w_0
 };
 __device__ __forceinline__ LaConst la_const(double a, double c, double q, double r, double P0, double s) {
   LaConst K;
@@ -298,6 +320,7 @@ __device__ __forceinline__ LaConst la_const(double a, double c, double q, double
   const double Pm = (Sm.v - r) * ic2, dPm = Sm.d * ic2;
   const double den = P0 - Pm, iden = rcp(den);
   K.w0 = (P0 - Pinf) * iden;
+  K.om0 = (Pinf - Pm) * iden;
   K.dw0 = (-dPinf * den + (P0 - Pinf) * dPm) * iden * iden;
   return K;
 }
@@ -325,76 +348,136 @@ struct LagAdam {
   double lr, lo, hi, tol;
   int cap, n_iters;
   double rho_max;
+  int head_frames;             // 0: by the pole | 64, 128, 256 (tests, A/B)
   double *state, *s_keypoint, *nll, *dnll;
   int32_t* n_active;
 };
 
-// what a chain's wave keeps in registers for the whole search (lane j: frames and lags 4 j .. 4 j + 3)
+// what a chain's wave keeps for the whole search (lane j: lags 4 j .. 4 j + 3).  The HEAD - the frames evaluated one by
+// one from the prior, before the lag sums take over - is 64, 128 or 256 frames long (1, 2 or 4 per lane), chosen per
+// evaluation from the pole: the variance's transient w_t = w_0 kappa^t must be dead at its end, and the searches spend
+// most of their iterations at poles below 0.7 where 64 frames do.  A set holds what depends on the head's length H:
+// the inputs that follow the head's frames, the lag sums over t >= H + 1 + k and the first inputs of that region.
+struct LaSet {
+  double un[4];                // u_{t+1} for the lane's frames t = NF lane + f (NF = H / 64 of them)
+  double c2k[4];               // lag sums (c_0, 2 c_k) over the region that starts at F = H + 1
+  double uF[4];                // its first inputs u_{F+k}
+};
 struct LaLane {
-  double un[4];                // u_{t+1}: the input that follows frame t of the head
-  double c2k[4];               // lag sums (c_0, 2 c_k)
-  double uF[4], ut[4];         // first / last inputs of the lag region: u_{F+k}, u_{T-1-k}
+  LaSet full;                  // H = 256 (kLaB0, the region lag_sums_kernel summed); the shorter ones live in LDS
+  double ut[4];                // last inputs u_{T-1-k}
   double e0;                   // innovation of frame 0: y_0 - c m_0
 };
+constexpr int kLaStage = 576;               // u_0 .. u_575 of a chain while its sets are formed (lags up to 255 past 256)
+constexpr int kLaSetRows = 19;              // H = 64: un[1] c2k[4] uF[4] | H = 128: un[2] c2k[4] uF[4]; [row][lane]
+constexpr int kLaDynPerChain = kLaStage + kLaSetRows * 64;
 
-// the chain's NLL and d / d log s from the lag sums (|rho| <= rho_max)
-__device__ __forceinline__ DualD la_nll_fast(const LaConst& K, const LaLane& L, int T, int lane) {
-  // ---- head: frames 4 lane .. 4 lane + 3
-  const double kap2 = K.kap * K.kap;
-  const double kbase = la_pow_bits<6>(kap2 * kap2, (unsigned)lane);
-  const double kf[4] = {kbase, kbase * K.kap, kbase * kap2, kbase * kap2 * K.kap};
-  DualD gt[4], rt[4];
-  LaAff el{DualD(1.0), DualD(0.0)};
-  double pprod = 1.0, dlog = 0.0;
+template <int NF>
+__device__ __forceinline__ LaSet la_load_set(const double* sets, int lane) {
+  static_assert(NF == 1 || NF == 2, "the 256-frame set stays in registers");
+  constexpr int r0 = NF == 1 ? 0 : 9;
+  LaSet S;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) S.un[f] = f < NF ? sets[(r0 + f) * 64 + lane] : 0.0;
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
-    DualD St;
-    la_frame(K, 4 * lane + f, kf[f], St, gt[f], rt[f]);
-    pprod *= St.v * K.g.v;
-    dlog += St.d * gt[f].v;
-    el = la_then(el, LaAff{rt[f], DualD(L.un[f])});
+    S.c2k[f] = sets[(r0 + NF + f) * 64 + lane];
+    S.uF[f] = sets[(r0 + NF + 4 + f) * 64 + lane];
   }
-  la_scan(el);
-  const DualD e_first(L.e0);
+  return S;
+}
+
+// the chain's NLL and d / d log s from the lag sums (|rho| <= rho_max), head of 64 NF frames.  k64 = kappa^64.
+template <int NF>
+__device__ __forceinline__ DualD la_nll_fast(const LaConst& K, const LaSet& S, const double (&ut)[4], double e0, double k64,
+                                             int T, int lane) {
+  constexpr int H = 64 * NF;
+  // ---- head: frames NF lane .. NF lane + NF - 1.  One power per evaluation: rho^(NF lane); the head's
+  // kappa^(NF lane) is its square (kappa = rho^2), the lags' rho^(4 lane) its (4 / NF)-th power
+  const double rho = K.rho.v, rho2 = rho * rho;
+  const double hb = la_pow_bits<6>(NF == 1 ? rho : NF == 2 ? rho2 : rho2 * rho2, (unsigned)lane);
+  double pbase = hb;
+  if (NF <= 2) pbase *= pbase;
+  if (NF == 1) pbase *= pbase;
+  // S_t = S_inf (1 - w_{t+1}) / (1 - w_t): the frame's 1 / S_t and pole are g and rho times m_t = (1 - w_t) / (1 - w_{t+1}),
+  // d log m_t = h_{t+1} - h_t with h_t = dw_t / (1 - w_t) - one reciprocal per frame (and one more per lane)
+  double om[NF + 1], h[NF + 1], inv[NF + 1];
+  {
+    const double c2w = 2.0 * K.w0 * K.dlr;
+    const double base = K.dw0 + (double)(NF * lane) * c2w;
+    double kf = hb * hb;
+#pragma unroll
+    for (int j = 0; j <= NF; ++j) {
+      om[j] = 1.0 - K.w0 * kf;
+      if (j == 0) om[0] = lane == 0 ? K.om0 : om[0];
+      inv[j] = rcp(om[j]);
+      h[j] = kf * (base + (double)j * c2w) * inv[j];
+      kf *= K.kap;
+    }
+  }
+  const double ar = K.a * K.r;
+  DualD gt[NF], rt[NF];
+  LaAff el{DualD(1.0), DualD(0.0)};
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    const double m = om[f] * inv[f + 1];
+    double dd = K.dlr + (h[f + 1] - h[f]);                    // d log g_t = d log rho_t
+    if (f == 0) dd = lane == 0 ? 0.0 : dd;                    // frame 0: S_0 = c^2 P_0 + r does not depend on s
+    const double gv = K.g.v * m;
+    gt[f] = DualD(gv, gv * dd);
+    rt[f] = DualD(ar * gt[f].v, ar * gt[f].d);
+    el = la_then(el, LaAff{rt[f], DualD(S.un[f])});
+  }
+  la_scan(el, lane);
+  const DualD e_first(e0);
   const DualD e_out = el.A * e_first + el.b;
-  DualD e(__shfl_up(e_out.v, 1), __shfl_up(e_out.d, 1));
-  if (lane == 0) e = e_first;
+  // the innovation entering the lane's first frame: the previous lane's e_out (wave_shr:1; lane 0 keeps `old`)
+  DualD e(la_dpp<0x138>(e_first.v, e_out.v), la_dpp<0x138>(0.0, e_out.d));
   DualD quad(0.0);
 #pragma unroll
-  for (int f = 0; f < 4; ++f) {
+  for (int f = 0; f < NF; ++f) {
     quad = quad + gt[f] * e * e;
-    e = rt[f] * e + DualD(L.un[f]);
+    if (f + 1 < NF) e = rt[f] * e + DualD(S.un[f]);
   }
-  const DualD E(la_readlane(e_out.v, 63), la_readlane(e_out.d, 63));     // innovation of frame B0
+  const DualD E(la_readlane(e_out.v, 63), la_readlane(e_out.d, 63));     // innovation of frame H
   // ---- lags 4 lane .. 4 lane + 3
-  const double rho = K.rho.v, rho2 = rho * rho;
-  const double pbase = la_pow_bits<6>(rho2 * rho2, (unsigned)lane);
   const double pf[4] = {pbase, pbase * rho, pbase * rho2, pbase * rho2 * rho};
   double sp = 0.0, spk = 0.0, sz = 0.0, szk = 0.0, sd = 0.0, sdk = 0.0;
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
     const double kk = (double)(4 * lane + f) * pf[f];
-    sp += pf[f] * L.c2k[f];  spk += kk * L.c2k[f];
-    sz += pf[f] * L.uF[f];   szk += kk * L.uF[f];
-    sd += pf[f] * L.ut[f];   sdk += kk * L.ut[f];
+    sp += pf[f] * S.c2k[f];  spk += kk * S.c2k[f];
+    sz += pf[f] * S.uF[f];   szk += kk * S.uF[f];
+    sd += pf[f] * ut[f];     sdk += kk * ut[f];
   }
   // ---- the wave's sums.  The loss is LINEAR in the head's quadratic term, in the lag polynomial and in Z, with
   // coefficients known before any sum is taken (E, rho, g): those three - and their derivatives - are combined in the
   // lane and reduced as ONE value and ONE derivative; only the last inputs' sum Dl enters squared and travels alone.
-  // Five reductions instead of ten (each six DPP steps on a 64-bit value: a quarter of the iteration's instructions).
+  // Four reductions (each six DPP steps on a 64-bit value) instead of ten.
   const DualD one(1.0);
   const DualD iom = rcp(one - K.rho * K.rho);
   const DualD ca = K.g * iom;                                  // coefficient of the lag polynomial
   const DualD cb = DualD(2.0) * ca * E * K.rho;                // ... of Z  (2 g E X1, X1 = rho Z / (1 - rho^2))
   const double lin_v = quad.v + ca.v * sp + cb.v * sz;
-  const double lin_d = quad.d + dlog + ca.d * sp + ca.v * K.dlr * spk + cb.d * sz + cb.v * K.dlr * szk;
-  const double LV = la_wave_sum(lin_v), LD = la_wave_sum(lin_d), pp = la_wave_prod(pprod);
+  const double lin_d = quad.d + ca.d * sp + ca.v * K.dlr * spk + cb.d * sz + cb.v * K.dlr * szk;
+  const double LV = la_wave_sum(lin_v), LD = la_wave_sum(lin_d);
   const DualD Dl(la_wave_sum(sd), la_wave_sum(sdk) * K.dlr);
-  // ---- assembly:  g [ (poly - rho^2 Dl^2) / (1 - rho^2) + 2 E X1 + E^2 / (1 - rho^2) ]  (rho^(2 (T - B0)) < 1e-60 here)
+  // ---- the head's log-determinant in closed form: prod_{t=1}^{H-1} S_t / S_inf telescopes to (1 - w_H) / (1 - w_1);
+  // frame 0 is S_0 itself
+  double kH = k64;
+  if (NF >= 2) kH *= kH;
+  if (NF == 4) kH *= kH;
+  const double w1 = K.w0 * K.kap, dw1 = K.kap * (K.dw0 + K.w0 * 2.0 * K.dlr);
+  const double wH = K.w0 * kH, dwH = kH * (K.dw0 + K.w0 * (double)H * 2.0 * K.dlr);
+  const double i1 = rcp(1.0 - w1), iH = rcp(1.0 - wH);
+  const double S0 = K.c2 * K.P0 + K.r;
+  const double logdet_head = log(S0 * K.g.v * (1.0 - wH) * i1);          // sum_{t < H} log(S_t / S_inf)
+  const double dlogdet_head = dw1 * i1 - dwH * iH - K.Sinf.d * K.g.v;    // its derivative (frame 0: -d log S_inf)
+  // ---- assembly:  g [ (poly - rho^2 Dl^2) / (1 - rho^2) + 2 E X1 + E^2 / (1 - rho^2) ]  (rho^(2 (T - H)) < 1e-60 here)
   const DualD rest = ca * (E * E - K.rho * K.rho * Dl * Dl);
   const double logS = log(K.Sinf.v);
-  const double v = 0.5 * ((double)T * (kLog2Pi + logS) + log(pp) + LV + rest.v);
-  const double dv = 0.5 * (LD + (double)(T - kLaB0) * K.Sinf.d * K.g.v + rest.d);
+  const double v = 0.5 * ((double)T * (kLog2Pi + logS) + logdet_head + LV + rest.v);
+  const double dv = 0.5 * (LD + (double)T * K.Sinf.d * K.g.v + dlogdet_head + rest.d);
   return DualD(v, dv);
 }
 
@@ -510,7 +593,7 @@ __device__ __forceinline__ DualD la_nll_stream(const LaConst& K, const float* __
   Qbb = Qbb + K.g * Sbb;
   dlog += (double)n_steady * K.Sinf.d * K.g.v;
   LaAff el{al, be};
-  la_scan(el);
+  la_scan(el, lane);
   const DualD e_first(e0);
   const DualD e_out = el.A * e_first + el.b;
   DualD e(__shfl_up(e_out.v, 1), __shfl_up(e_out.d, 1));
@@ -522,6 +605,20 @@ __device__ __forceinline__ DualD la_nll_stream(const LaConst& K, const float* __
   const double v = 0.5 * ((double)T * (kLog2Pi + log(K.Sinf.v)) + log(pp) + q_v);
   return DualD(v, 0.5 * (dl_sum + q_d));
 }
+
+// Diagnostic build only (-DEKS_LAG_STAMPS, tools/lag_stamps.py): lane 0 of every chain's wave adds up the shader-clock
+// cycles of an iteration's sections (constants | evaluation | exchange + barrier | step) and its iterations.
+#ifdef EKS_LAG_STAMPS
+__device__ unsigned long long g_lag_stamps[1024][8];
+#define LAG_STAMP(i)                                                     \
+  do {                                                                   \
+    const unsigned long long now_ = __builtin_readcyclecounter();        \
+    lag_acc_[i] += now_ - lag_t_;                                        \
+    lag_t_ = now_;                                                       \
+  } while (0)
+#else
+#define LAG_STAMP(i) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(64 * kLaMaxD) void lag_adam_kernel(LagAdam P) {
   __shared__ double xch[2][kLaMaxD][2];
@@ -536,40 +633,102 @@ __global__ __launch_bounds__(64 * kLaMaxD) void lag_adam_kernel(LagAdam P) {
   const size_t dd = (size_t)k * D * D + (size_t)d * (D + 1);
   const double a = P.A[dd], c = P.C[dd], q = P.Q[dd], r = P.rconst[n], P0 = P.S0[dd], m0 = P.m0[(size_t)k * D + d];
   // ---- what does not change between iterations
+  extern __shared__ double la_dyn[];                                  // [D][kLaStage] inputs, then [D][19][64] sets
+  double* ush = la_dyn + (size_t)d * kLaStage;
+  double* sets = la_dyn + (size_t)D * kLaStage + (size_t)d * kLaSetRows * 64;
   LaLane L;
   {
     const float* yn = P.y + n;
-    float h[5];
+    // the chain's first inputs u_t = y_t - a y_{t-1}, t < 576, through LDS (u_0 is never used)
 #pragma unroll
-    for (int f = 0; f < 5; ++f) h[f] = yn[(size_t)(4 * lane + f) * N];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) L.un[f] = (double)h[f + 1] - a * (double)h[f];
+    for (int i = 0; i < kLaStage / 64; ++i) {
+      const int t = 64 * i + lane;
+      const float y1 = yn[(size_t)t * N], y0 = yn[(size_t)max(t - 1, 0) * N];
+      ush[t] = (double)y1 - a * (double)y0;
+    }
     L.e0 = (double)yn[0] - c * m0;
     const double* ckn = P.ck + (size_t)n * kLaL + 4 * lane;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) L.c2k[f] = ckn[f];
-    float hf[5], ht[5];
+    for (int f = 0; f < 4; ++f) L.full.c2k[f] = ckn[f];
+    float ht[5];
 #pragma unroll
-    for (int f = 0; f < 5; ++f) {
-      hf[f] = yn[(size_t)min(kLaF - 1 + 4 * lane + f, T - 1) * N];           // rows F - 1 + 4 lane ..
-      ht[f] = yn[(size_t)max(T - 1 - 4 * lane - f, 0) * N];                   // rows T - 1 - 4 lane, downwards
-    }
+    for (int f = 0; f < 5; ++f) ht[f] = yn[(size_t)max(T - 1 - 4 * lane - f, 0) * N];   // rows T - 1 - 4 lane, downwards
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-      const int tF = kLaF + 4 * lane + f, tt = T - 1 - 4 * lane - f;
-      L.uF[f] = tF < T ? (double)hf[f + 1] - a * (double)hf[f] : 0.0;
+      const int tt = T - 1 - 4 * lane - f;
       L.ut[f] = tt >= kLaF ? (double)ht[f] - a * (double)ht[f + 1] : 0.0;
+    }
+  }
+  __syncthreads();
+  {
+    // the 256-frame head's set, and the two shorter ones: the lag sums of a region that starts at F = H + 1 are the
+    // cached ones (F = 257) plus the products of the frames in between,
+    //   c_k(H) = c_k(256) + sum_{t = H + 1 + k}^{256 + k} u_t u_{t-k}      (u_{t-k} = u_{H+1+i}: the same for every lane)
+    // 128 + 64 products per lag, once per search
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      L.full.un[f] = ush[4 * lane + f + 1];
+      L.full.uF[f] = ush[kLaF + 4 * lane + f];
+    }
+    double acc128[4] = {0.0, 0.0, 0.0, 0.0}, acc64[4] = {0.0, 0.0, 0.0, 0.0};
+    {
+      const double* ua = ush + 129 + 4 * lane;                       // u_{129 + k + i}, k = 4 lane + f
+      double w0 = ua[0], w1 = ua[1], w2 = ua[2];
+#pragma unroll 8
+      for (int i = 0; i < 128; ++i) {
+        const double w3 = ua[i + 3], ub = ush[129 + i];
+        acc128[0] += w0 * ub; acc128[1] += w1 * ub; acc128[2] += w2 * ub; acc128[3] += w3 * ub;
+        w0 = w1; w1 = w2; w2 = w3;
+      }
+    }
+    {
+      const double* ua = ush + 65 + 4 * lane;
+      double w0 = ua[0], w1 = ua[1], w2 = ua[2];
+#pragma unroll 8
+      for (int i = 0; i < 64; ++i) {
+        const double w3 = ua[i + 3], ub = ush[65 + i];
+        acc64[0] += w0 * ub; acc64[1] += w1 * ub; acc64[2] += w2 * ub; acc64[3] += w3 * ub;
+        w0 = w1; w1 = w2; w2 = w3;
+      }
+    }
+    sets[0 * 64 + lane] = ush[lane + 1];                              // H = 64: un
+    sets[9 * 64 + lane] = ush[2 * lane + 1];                          // H = 128: un[0], un[1]
+    sets[10 * 64 + lane] = ush[2 * lane + 2];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const double mult = 4 * lane + f == 0 ? 1.0 : 2.0;             // (c_0, 2 c_k)
+      const double c128 = L.full.c2k[f] + mult * acc128[f];
+      sets[(11 + f) * 64 + lane] = c128;
+      sets[(1 + f) * 64 + lane] = c128 + mult * acc64[f];
+      sets[(15 + f) * 64 + lane] = ush[129 + 4 * lane + f];
+      sets[(5 + f) * 64 + lane] = ush[65 + 4 * lane + f];
     }
   }
   bool have_copy = false;
   float* yc = P.yT + (size_t)n * (((size_t)T + 15) / 16 * 16);
   double b1t = adam_pow_count(0.9, iters), b2t = adam_pow_count(0.999, iters);
+#ifdef EKS_LAG_STAMPS
+  unsigned long long lag_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lag_t_ = __builtin_readcyclecounter();
+  const unsigned long long lag_start_ = lag_t_;
+#endif
   for (int it = 0; it < P.n_iters; ++it) {
+    LAG_STAMP(4);
     const double s = exp(fmin(fmax(u, P.lo), P.hi));
     const LaConst K = la_const(a, c, q, r, P0, s);
+    LAG_STAMP(0);
     DualD v;
     if (fabs(K.rho.v) <= P.rho_max) {                            // (wave-uniform: one chain per wave)
-      v = la_nll_fast(K, L, T, lane);
+      // the head: as short as the variance's transient allows (|w_H| H = |w_0| kappa^H H below 1e-17 at its end)
+      const double kap2 = K.kap * K.kap, k4 = kap2 * kap2, k16 = (k4 * k4) * (k4 * k4), k64 = (k16 * k16) * (k16 * k16);
+      const double aw = fabs(K.w0);
+      int nf = 4;
+      if (aw * k64 * k64 * 128.0 <= 1e-17) nf = 2;
+      if (aw * k64 * 64.0 <= 1e-17) nf = 1;
+      if (P.head_frames) nf = P.head_frames / 64;                // (tests)
+      nf = __builtin_amdgcn_readfirstlane(nf);
+      if (nf == 1) v = la_nll_fast<1>(K, la_load_set<1>(sets, lane), L.ut, L.e0, k64, T, lane);
+      else if (nf == 2) v = la_nll_fast<2>(K, la_load_set<2>(sets, lane), L.ut, L.e0, k64, T, lane);
+      else v = la_nll_fast<4>(K, L.full, L.ut, L.e0, k64, T, lane);
     } else {
       if (!have_copy) {
         for (int t = lane; t < T; t += 64) yc[t] = P.y[(size_t)t * N + n];
@@ -580,6 +739,7 @@ __global__ __launch_bounds__(64 * kLaMaxD) void lag_adam_kernel(LagAdam P) {
       }
       v = la_nll_stream(K, yc, T, L.e0, lane);
     }
+    LAG_STAMP(1);
     if (lane == 0) {
       xch[it & 1][d][0] = v.v;
       xch[it & 1][d][1] = v.d;
@@ -591,6 +751,7 @@ __global__ __launch_bounds__(64 * kLaMaxD) void lag_adam_kernel(LagAdam P) {
       g += xch[it & 1][dq][1];
     }
     // eks/core.py:650: a non-finite loss is 1e12 with zero gradient; then the step and the stop rule of :652-681
+    LAG_STAMP(2);
     const bool fin = isfinite(Lv);
     Lv = fin ? Lv : 1e12;
     g = fin ? g : 0.0;
@@ -602,10 +763,18 @@ __global__ __launch_bounds__(64 * kLaMaxD) void lag_adam_kernel(LagAdam P) {
     vel = 0.999 * vel + 0.001 * g * g;
     b1t *= 0.9;                                                // (0.9^cnt, 0.999^cnt: carried, not recomputed)
     b2t *= 0.999;
-    const double mhat = mom / (1.0 - b1t);
-    const double vhat = vel / (1.0 - b2t);
-    u = u - mhat / (sqrt(vhat) + 1e-8);
-    const bool stop = isfinite(prev) && fabs(Lv - prev) < P.tol * fabs(log(fmax(prev, 1e-12))) + 1e-6;
+    const double mhat = mom * rcp(1.0 - b1t);                   // (Newton reciprocals: within an ulp of the quotients)
+    const double vhat = vel * rcp(1.0 - b2t);
+    u = u - mhat * rcp(sqrt(vhat) + 1e-8);
+    // the stop rule's logarithm only when it can matter: |log p| <= (|e| + 1) ln 2 for p = m 2^e, so a change of the
+    // loss above tol times that bound cannot stop the search (all but the last one or two iterations)
+    bool stop = false;
+    if (isfinite(prev)) {
+      const double dL = fabs(Lv - prev), pc = fmax(prev, 1e-12);
+      const int ex = ((__double2hiint(pc) >> 20) & 0x7ff) - 1023;
+      const double bound = (double)(abs(ex) + 1) * 0.6931471805599453;
+      if (!(P.tol >= 0.0) || dL < P.tol * bound + 1e-6) stop = dL < P.tol * fabs(log(pc)) + 1e-6;
+    }
     prev = Lv;
     iters = cnt;
     done = stop ? 1.0 : 0.0;
@@ -613,8 +782,19 @@ __global__ __launch_bounds__(64 * kLaMaxD) void lag_adam_kernel(LagAdam P) {
       P.nll[k] = Lv;
       P.dnll[k] = g_raw;
     }
+    LAG_STAMP(3);
+#ifdef EKS_LAG_STAMPS
+    lag_acc_[5] += 1;
+#endif
     if (stop || !(iters < (double)P.cap)) break;
   }
+#ifdef EKS_LAG_STAMPS
+  if (lane == 0 && n < 1024) {
+    lag_acc_[6] = __builtin_readcyclecounter() - lag_start_;
+    lag_acc_[7] = lag_start_;
+    for (int i = 0; i < 8; ++i) g_lag_stamps[n][i] = lag_acc_[i];
+  }
+#endif
   if (lane == 0 && d == 0) {
     st[0] = u; st[1] = mom; st[2] = vel; st[3] = prev; st[4] = iters; st[5] = done;
     P.s_keypoint[k] = exp(fmin(fmax(u, P.lo), P.hi));
@@ -706,12 +886,19 @@ int diag_lag_adam(const eks_dims_t& d, const float* y, const double* rconst, con
   ProfScope ps("lag_adam", st);
   static const double rho_max = lag_adam_rho_max();
   const int rm = knob_int(KNOB_ADAM_LAG_RHO_PPM, -1);          // (tests: the pole beyond which a chain streams)
+  int head = knob_int(KNOB_ADAM_LAG_HEAD, 0);                  // (tests, A/B: the head's length for every evaluation)
+  if (head != 64 && head != 128 && head != 256) head = 0;
   const LagAdam P{T, N, D, y, rconst, M.m0, M.S0, M.A, M.C, M.Q, W.ck, W.yT, F.kp_block, F.lr, F.lo, F.hi, F.tol, F.cap,
-                  n_iters, rm >= 0 ? 1e-6 * rm : rho_max, F.state, F.s_keypoint, nll, dnll, F.n_active_cur};
-  hipLaunchKernelGGL(lag_adam_kernel, dim3((unsigned)K), dim3(64, D), 0, st, P);
+                  n_iters, rm >= 0 ? 1e-6 * rm : rho_max, head, F.state, F.s_keypoint, nll, dnll, F.n_active_cur};
+  hipLaunchKernelGGL(lag_adam_kernel, dim3((unsigned)K), dim3(64, D), (size_t)D * kLaDynPerChain * sizeof(double), st, P);
   return hip_status(hipGetLastError());
 }
 
 }  // namespace eks
 
 EKS_DEFINE_TOUCH(lag_adam)
+#ifdef EKS_LAG_STAMPS
+extern "C" int eks_debug_lag_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(eks::g_lag_stamps), sizeof(eks::g_lag_stamps));
+}
+#endif

@@ -26,7 +26,7 @@ struct KnobTable {
         "EKS_SMOOTH_UNFUSED", "EKS_SUMMARIZE_REVERSE", "EKS_REPLAY_FORWARD", "EKS_REPLAY_RECOMPUTE", "EKS_SCAN_CH",
         "EKS_DENSE_CHUNK", "EKS_NLL_NCL", "EKS_NLL_CHUNK", "EKS_NLL_CHUNK0", "EKS_NLL_WPB",
         "EKS_DENSE_LEGACY", "EKS_NLL_GRAD_UNFUSED",
-        "EKS_NLL_GRAD_CHUNK", "EKS_DENSE_TREE_SCAN", "EKS_DENSE_DUAL_GRAD", "EKS_NLL_LEGACY", "EKS_MED_ROWS", "EKS_DW_CHUNK", "EKS_ADAM_PER_ITERATION", "EKS_MED_FINISH_THREADS", "EKS_MED_BRACKET_THREADS", "EKS_NLL_NOLAG", "EKS_NLL_GRAD_TREE", "EKS_ADAM_STREAM", "EKS_ADAM_LAG_RHO_PPM"};
+        "EKS_NLL_GRAD_CHUNK", "EKS_DENSE_TREE_SCAN", "EKS_DENSE_DUAL_GRAD", "EKS_NLL_LEGACY", "EKS_MED_ROWS", "EKS_DW_CHUNK", "EKS_ADAM_PER_ITERATION", "EKS_MED_FINISH_THREADS", "EKS_MED_BRACKET_THREADS", "EKS_NLL_NOLAG", "EKS_NLL_GRAD_TREE", "EKS_ADAM_STREAM", "EKS_ADAM_LAG_RHO_PPM", "EKS_ADAM_LAG_HEAD"};
     int n = 0;
     for (int i = 0; i < KNOB_COUNT; ++i) {
       const char* v = getenv(names[i]);

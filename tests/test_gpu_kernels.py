@@ -1183,6 +1183,39 @@ def test_adam_from_cached_lag_sums_is_the_streaming_search_and_the_oracles(T, K,
         assert np.abs(st_l[ks, 3] / last_o - 1).max() < 1e-7
 
 
+@pytest.mark.parametrize('T,K,unit', [(12_000, 48, True), (6_011, 21, False)])
+def test_adam_from_lag_sums_head_length_follows_the_pole(T, K, unit, set_knob):
+    """The frames evaluated one by one from the prior (the head) are 64, 128 or 256 per evaluation, as many as the
+    variance's transient w_0 kappa^t needs to die; the lag sums of the region behind a shorter head are the cached
+    ones plus the products of the frames in between (formed once per search in LDS).  With the head forced to 256
+    frames for every evaluation (EKS_ADAM_LAG_HEAD=256: round 6's first form) the searches stop at the same iteration and
+    end within 1e-9 in log s; forcing 128 is as good on these poles; both within 1e-6 of the in-kernel float64
+    fallback that streams every frame (EKS_ADAM_LAG_RHO_PPM=0)."""
+    from eks_amd import hip_ops
+    arrs, y_tk, var_tk = _singlecam_problem(T, K, seed=5 + T, unit=unit)
+    flags = hip_ops.model_flags(arrs['S0s'], arrs['As'], arrs['Cs'], arrs['Qs'])
+    y, rc = _dev(y_tk), hip_ops.const_r(_dev(var_tk), 1e-4)
+    params = _params_dev(arrs)
+    u0 = np.log(np.random.default_rng(T).uniform(0.05, 50.0, K))
+    _, st_a, s_a, nll_a, g_a, _ = _adam_search(y, rc, params, flags, K, u0)
+    set_knob('EKS_ADAM_LAG_HEAD', '256')
+    _, st_f, s_f, nll_f, g_f, _ = _adam_search(y, rc, params, flags, K, u0)
+    set_knob('EKS_ADAM_LAG_HEAD', '128')
+    _, st_h, s_h, _, _, _ = _adam_search(y, rc, params, flags, K, u0)
+    set_knob('EKS_ADAM_LAG_HEAD', None)
+    set_knob('EKS_ADAM_LAG_RHO_PPM', '0')
+    _, st_x, s_x, _, _, _ = _adam_search(y, rc, params, flags, K, u0)
+    assert np.all(st_a[:, 5] == 1.0) and st_a[:, 4].max() > 20
+    np.testing.assert_array_equal(st_a[:, 4:], st_f[:, 4:])
+    np.testing.assert_array_equal(st_a[:, 4:], st_x[:, 4:])
+    assert np.abs(np.log(s_a) - np.log(s_f)).max() < 1e-9
+    assert np.abs(nll_a / nll_f - 1).max() < 1e-12
+    assert np.abs(g_a - g_f).max() <= 1e-9 * np.abs(g_f).max() + 1e-9
+    assert np.abs(np.log(s_a) - np.log(s_x)).max() < 1e-6
+    # (a 128-frame head everywhere is NOT exact for the slowest poles these searches visit: it only has to stay close)
+    assert np.abs(np.log(s_h) - np.log(s_x)).max() < 1e-4 and np.abs(st_h[:, 4] - st_x[:, 4]).max() <= 1
+
+
 @pytest.mark.parametrize('T,K,unit,ppm', [(20_000, 40, True, 0), (9_000, 33, False, 0), (20_000, 40, True, 450_000),
                                          (3_000, 5, False, 300_000)])
 def test_adam_chains_outside_the_lag_range_stream_their_own_frames_exactly(T, K, unit, ppm, set_knob):
