@@ -58,7 +58,7 @@ WORKLOADS = {
 SMOOTH_BYTES_PER_UNIT = 40       # y 8 + var 8 in, ms 8 + Vs 16 out  
 NLL_BYTES_PER_UNIT = 8           # y read once regardless of candidate count
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
-FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 vector peak (packed FMAs)
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 peak, packed vector FMAs and f32-input MFMA alike
 PARITY_BAR = 1e-5                # BASELINE.json: smoothed means / covariances (and the NLL table) within 1e-5 relative
 
 
@@ -461,7 +461,7 @@ def bench_c3adam(args, T, K, dev, lib, ranks_info):
         flops = 2.0 * 256 * T * 2 * K                                 # one FMA per lag, chain and frame
         other = {k: float(np.sum(v)) for k, v in prof.items() if k not in ('lag_sums', 'lag_adam')}
         out['roofline'] = {
-            'bound': 'valu', 'kernel': 'lag_sums_kernel', 'unit': 'TFLOP/s', 'peak': FP32_VECTOR_PEAK_TFLOPS,
+            'bound': 'mfma', 'kernel': 'lag_sums_kernel', 'unit': 'TFLOP/s', 'peak': FP32_VECTOR_PEAK_TFLOPS,
             'achieved': flops / (sums_ms * 1e-3) / 1e12, 'frac': flops / (sums_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
             'traffic': None, 'kernel_avg_ms': sums_ms,
             'algorithmic_flops_per_launch': flops, 'algorithmic_bytes_per_launch': T * 2 * K * 4,
@@ -471,9 +471,11 @@ def bench_c3adam(args, T, K, dev, lib, ranks_info):
             'search_us_per_iteration_of_the_longest_keypoint': 1e3 * adam_ms / float(iters.max()),
             'other_stage_ms': other,
             'kernel_avg_ms_source': 'HIP events on the launch stream, one untimed step after the timed regions',
-            'note': 'y is read ONCE per search (4 B per chain-frame) by the pass that forms 256 lag sums per chain: 512 '
-                    'flops per chain-frame in packed float32 FMAs, so the pass is bound by the vector pipe, not by HBM; '
-                    'the iterations that follow touch no frame (closed-form head + lag polynomial, float64 duals)'}
+            'note': 'y is read ONCE per search (4 B per chain-frame) by the pass that forms 256 lag sums per chain: a '
+                    '16 x 16 x T matrix product per chain on v_mfma_f32_16x16x4_f32 (exact float32, 512 flops per '
+                    'chain-frame; dense f32-input MFMA peak = the fp32 vector peak), so the pass is bound by the matrix '
+                    'pipe, not by HBM; the iterations that follow touch no frame (closed-form head + lag polynomial, '
+                    'float64 duals)'}
     if not args.no_cpu_baseline:
         try:
             out['cpu_baseline'] = cpu_baseline_adam(y, var, m0, S0, T, K, args.cpu_seconds, last)

@@ -45,6 +45,8 @@ SIGNATURES = {
                                     c_void_p]),
     'eks_np_nanstd_rows': (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p,
                                           c_void_p]),
+    'eks_np_nanstd_diff_rows': (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32,
+                                               c_void_p, c_void_p]),
     'eks_order_stats': (ctypes.c_int, [c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                        c_void_p]),
     'eks_adam_step': (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_double,
@@ -80,6 +82,7 @@ SIGNATURES = {
     'eks_host_thread_speedup': (c_double, [c_int32]),
     'eks_host_gather_cols': (ctypes.c_int, [c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                             c_void_p, c_int32]),
+    'eks_host_model_flags': (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_double]),
     'eks_adam_run_stride': (c_int32, [c_void_p, c_int32]),
     'eks_adam_prepare': (ctypes.c_int, [POINTER(EksDims), c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
     'eks_profile_drain': (ctypes.c_int, [c_void_p, c_size_t, c_void_p, c_int32]),

@@ -153,8 +153,11 @@ def _guess_std_on_device(ev_dev, lazy: bool = False):
         raise ValueError('Not enough frames to compute temporal differences.')
     if ev.dtype != torch.float32 or not ev.is_cuda:
         return None
-    d = (ev[1:] - ev[:-1]).transpose(0, 1).contiguous()
-    sd = hip_ops.np_nanstd_rows(d.reshape(d.shape[0], -1))
+    if ev.dim() == 3 and ev.is_contiguous():
+        sd = hip_ops.np_nanstd_diff_rows(ev)                    # (differences formed inside the reduction's launch)
+    else:
+        d = (ev[1:] - ev[:-1]).transpose(0, 1).contiguous()
+        sd = hip_ops.np_nanstd_rows(d.reshape(d.shape[0], -1))
     if sd is None or not lazy:
         return None if sd is None else sd.cpu().numpy()
     # The K floats start their way back NOW, behind the reduction, into page-locked memory: whatever the caller enqueues
@@ -290,7 +293,7 @@ def _block_csr(blocks, K):
     return offs, members.astype(np.int32), of_kp
 
 
-def _adam_setup(P: _DeviceProblem, blocks, s_frames, lr, s_bounds_log, tol, safety_cap):
+def _adam_setup(P: _DeviceProblem, blocks, s_frames, lr, s_bounds_log, tol, safety_cap, min_R_var=1e-4):
     """The optimiser's buffers, and the pass over y that does not depend on its starting point (the lag sums of
     eks_lag_adam.hip) ENQUEUED - before the initial guesses are asked for, before eks_const_r, before the host has done
     anything else for this search: the device has ~0.4 ms of work (BASELINE configs[2]) beside which the host prepares
@@ -302,28 +305,32 @@ def _adam_setup(P: _DeviceProblem, blocks, s_frames, lr, s_bounds_log, tol, safe
     nb = len(offs) - 1
     packed = torch.empty(nb * 6 + P.K, dtype=torch.float64, device=P.dev)
     state, s_kp = packed[:nb * 6].view(nb, 6), packed[nb * 6:]
-    if nb == P.K and np.array_equal(members, np.arange(P.K)):
-        offs_d = torch.arange(P.K + 1, dtype=torch.int32, device=P.dev)
-        mem_d = torch.arange(P.K, dtype=torch.int32, device=P.dev)
+    if blocks is None or (nb == P.K and np.array_equal(members, np.arange(P.K))):
+        offs_d, mem_d = _identity_blocks(P.K, P.dev)
     else:
         offs_d = torch.as_tensor(offs, device=P.dev)
         mem_d = torch.as_tensor(members, device=P.dev)
     loop = hip_ops.AdamLoop(y_c, None, *P.params, offs_d, mem_d, state, s_kp, lr, lo, hi, tol, safety_cap, flags=P.flags)
     prep_ev = None
-    if os.environ.get('EKS_ADAM_PREPARE_INLINE'):            # (A/B runs: the pass on the caller's stream)
+    mode = os.environ.get('EKS_ADAM_PREPARE', 'side')        # (A/B runs: 'after_const_r' | 'first')
+    if mode == 'first':                                      # the pass on the caller's stream, in front of everything
         loop.prepare()
-    else:
-        # ... on a SIDE stream: the pass is bound by the vector pipe (0.07 of HBM), eks_const_r and the guesses' reduction
-        # by memory latency and bandwidth - side by side they take the time of the pass alone.  The search waits for both.
+    elif mode == 'side':
+        # on a SIDE stream beside the guesses' reduction and eks_const_r.  The pass fills every compute unit (140 KB of
+        # LDS per workgroup) and what runs beside it crawls - the median's sampling kernels take 90-290 us for 12, its
+        # full pass (40 KB of LDS) only fits where a workgroup of the pass has gone - so the overlap is worth little:
+        # 0.946 ms per C3 step against 0.969 for ONE queue in the order guesses, median, pass ('after_const_r'), 1.02
+        # with the pass in front of everything ('first'), and 1.11 with eks_const_r enqueued in front of the pass (its
+        # full pass then starves for 298 us and the guesses behind it arrive late).
         cur = torch.cuda.current_stream(P.dev)
         side = _prepare_stream(P.dev)
         side.wait_stream(cur)                                # (y, and whatever produced it, is ready)
-        with torch.cuda.stream(side):
-            if loop.prepare():
-                prep_ev = torch.cuda.Event()
-                prep_ev.record(side)
-        for t in (y_c, loop.ws, *P.params):
-            t.record_stream(side)
+        if loop.prepare(side):                               # (the stream by its handle: no context manager to enter)
+            prep_ev = torch.cuda.Event()
+            prep_ev.record(side)
+            for t in (y_c, loop.ws, P.params[2]):            # what the pass reads and writes: y, the workspace, A
+                t.record_stream(side)
+    # ('after_const_r': _optimize_on_device enqueues the pass right behind eks_const_r)
     return dict(y_c=y_c, var_c=var_c, offs=offs, members=members, of_kp=of_kp, packed=packed, state=state, s_kp=s_kp,
                 loop=loop, prep_ev=prep_ev)
 
@@ -334,13 +341,15 @@ def _optimize_on_device(P: _DeviceProblem, blocks, s_frames, s_guess_per_k, lr, 
     torch = _torch()
     lo, hi = float(s_bounds_log[0]), float(s_bounds_log[1])
     if s_mode != 'grid' and setup is None:
-        setup = _adam_setup(P, blocks, s_frames, lr, s_bounds_log, tol, safety_cap)
+        setup = _adam_setup(P, blocks, s_frames, lr, s_bounds_log, tol, safety_cap, min_R_var)
     if setup is not None:
         y_c, var_c, offs, members, of_kp = (setup[k] for k in ('y_c', 'var_c', 'offs', 'members', 'of_kp'))
     else:
         y_c, var_c = P.cropped(s_frames)
         offs, members, of_kp = _block_csr(blocks, P.K)
     rconst = hip_ops.const_r(var_c, min_R_var)
+    if setup is not None and not setup['loop'].prepared:
+        setup['loop'].prepare()                              # the pass over y behind the median, in front of the host's wait
     nb = len(offs) - 1
     if s_mode == 'grid':
         cand = torch.exp(torch.linspace(lo, hi, n_grid, dtype=torch.float64, device=P.dev))
@@ -641,6 +650,23 @@ def _tile_streams(dev):
 _PREPARE_STREAMS: dict = {}
 
 
+_IDENTITY_BLOCKS: dict = {}
+
+
+def _identity_blocks(K, dev):
+    """(offsets 0..K, members 0..K-1) of the reference's default blocks on the device, made once per K and device (two
+    torch.arange launches in front of every search otherwise); read-only to every caller."""
+    key = (int(K), str(dev))
+    hit = _IDENTITY_BLOCKS.get(key)
+    if hit is None:
+        torch = _torch()
+        ar = torch.arange(K + 1, dtype=torch.int32, device=dev)
+        hit = _IDENTITY_BLOCKS[key] = (ar, ar[:K])
+        if len(_IDENTITY_BLOCKS) > 16:
+            _IDENTITY_BLOCKS.pop(next(iter(_IDENTITY_BLOCKS)))
+    return hit
+
+
 def _prepare_stream(dev):
     """The side stream of the search's pass over y (_adam_setup), one per device and calling thread, created once."""
     key = (dev.index if dev.index is not None else _torch().cuda.current_device(), threading.get_ident())
@@ -923,7 +949,7 @@ def run_kalman_smoother(ys, m0s, S0s, As, Cs, Qs, ensemble_vars, s_frames: list 
         t1 = time.perf_counter()
         guesses = np.full(K, 2.0)
         # the search's buffers and its pass over y FIRST (nothing it needs waits for the guesses or for eks_const_r)
-        setup = _adam_setup(P, blocks, s_frames, lr, s_bounds_log, tol, safety_cap) if s_mode == 'adam' else None
+        setup = _adam_setup(P, blocks, s_frames, lr, s_bounds_log, tol, safety_cap, 1e-4) if s_mode == 'adam' else None
         if s_mode == 'adam':            # the starting point of the optimiser (reference :233-236)
             if hasattr(ensemble_vars, 'detach') and ensemble_vars.is_cuda and ensemble_vars.dtype == torch.float32:
                 ev_d = ensemble_vars.detach()

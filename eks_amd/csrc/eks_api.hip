@@ -140,6 +140,14 @@ int eks_np_nanstd_rows(int32_t n_rows, int32_t n_cols, const float* x, const int
   return np_nanstd_rows(n_rows, n_cols, x, leaves, n_leaves, ops, n_ops, out, reinterpret_cast<hipStream_t>(stream));
 }
 
+int eks_np_nanstd_diff_rows(int32_t n_frames, int32_t n_keypoints, int32_t obs_dim, const float* x, const int32_t* leaves,
+                            int32_t n_leaves, const int32_t* ops, int32_t n_ops, float* out, eks_stream_t stream) {
+  if (n_frames < 2 || n_keypoints <= 0 || obs_dim <= 0 || n_leaves <= 0 || n_ops != n_leaves - 1) return EKS_ERR_SHAPE;
+  if (!x || !leaves || !out || (n_ops > 0 && !ops)) return EKS_ERR_NULL;
+  return np_nanstd_diff_rows(n_frames, n_keypoints, obs_dim, x, leaves, n_leaves, ops, n_ops, out,
+                             reinterpret_cast<hipStream_t>(stream));
+}
+
 int eks_argmin_s(int32_t n_keypoints, int32_t n_cand, const double* nll, const double* s_cand,
                  double* s_out, int32_t* idx_out, eks_stream_t stream) {
   if (n_keypoints <= 0 || n_cand <= 0) return EKS_ERR_SHAPE;

@@ -12,6 +12,8 @@
 //                          checker there, never the path).  Anything pandas would treat differently from "a number or
 //                          a missing value" (quotes, a text field, ragged lines) makes the call return EKS_CSV_FALLBACK and
 //                          the Python wrapper hands that file to pandas.
+//   eks_host_model_flags   which EKS_FLAG_* a set of host parameter arrays allows (diagonal model, A = C = I, Q positive
+//                          definite with a margin): one pass instead of a dozen NumPy calls in front of every call.
 //   eks_host_gather_cols   a column block of a row-major host matrix into a contiguous buffer, threaded: the ensemble
 //                          variances arrive (T, K, O) and a keypoint tile of them is a strided view (run_kalman_smoother's
 //                          pipelined NumPy boundary, eks_amd/core.py).
@@ -452,6 +454,50 @@ extern "C" int eks_host_gather_cols(const void* src, int64_t n_rows, int64_t src
   work(0);
   for (auto& x : th) x.join();
   return EKS_OK;
+}
+
+// eks_host_model_flags: what the Python wrapper's model_flags decided with a dozen NumPy calls (0.08 ms in front of
+// every call's first launch at 256 keypoints), as one pass over the host copies of the parameters.
+extern "C" int eks_host_model_flags(int32_t K, int32_t D, int32_t O, const double* S0, const double* A, const double* C,
+                                    const double* Q, double min_eig_ratio) {
+  if (!S0 || !A || !C || !Q) return EKS_ERR_NULL;
+  if (K < 0 || D < 1 || O < 1) return EKS_ERR_SHAPE;
+  const int64_t dd = (int64_t)D * D;
+  bool q_finite = true, q_diag = true;
+  for (int64_t i = 0; i < (int64_t)K * dd && q_finite; ++i) q_finite = std::isfinite(Q[i]);
+  auto is_diag = [&](const double* M, int rows) {              // (a NaN off the diagonal is not a zero)
+    for (int64_t k = 0; k < K; ++k)
+      for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < D; ++c)
+          if (r != c && !(M[(k * rows + r) * D + c] == 0.0)) return false;
+    return true;
+  };
+  q_diag = is_diag(Q, D);
+  uint32_t pd = 0;
+  if (q_finite) {
+    if (!q_diag) return EKS_ERR_UNSUPPORTED;                   // (Q's eigenvalues decide: the caller asks LAPACK)
+    bool ok = true;
+    for (int64_t k = 0; k < K && ok; ++k) {
+      double lo = Q[k * dd], hi = Q[k * dd];
+      for (int d = 1; d < D; ++d) {
+        const double v = Q[k * dd + (int64_t)d * (D + 1)];
+        lo = std::min(lo, v);
+        hi = std::max(hi, v);
+      }
+      ok = lo > min_eig_ratio * std::max(hi, 1e-300);
+    }
+    pd = ok ? EKS_FLAG_Q_PD : 0u;
+  }
+  if (D != O || !q_diag || !is_diag(S0, D) || !is_diag(A, D) || !is_diag(C, O)) return (int)pd;
+  uint32_t flags = EKS_FLAG_DIAG_MODEL | pd;
+  bool unit = true;
+  for (int64_t k = 0; k < K && unit; ++k)
+    for (int d = 0; d < D; ++d) {
+      const int64_t o = k * dd + (int64_t)d * (D + 1);
+      if (!(A[o] == 1.0) || !(C[o] == 1.0)) { unit = false; break; }
+    }
+  if (unit) flags |= EKS_FLAG_UNIT_AC;
+  return (int)flags;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

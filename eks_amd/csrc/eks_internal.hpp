@@ -162,6 +162,8 @@ int const_r(int T, int N, const float* var, double min_var, double* rconst, void
             size_t ws_bytes, hipStream_t st);
 int np_nanstd_rows(int K, int n, const float* d, const int32_t* leaves, int n_leaves, const int32_t* ops, int n_ops,
                    float* out, hipStream_t st);
+int np_nanstd_diff_rows(int n_frames, int K, int O, const float* x, const int32_t* leaves, int n_leaves, const int32_t* ops,
+                        int n_ops, float* out, hipStream_t st);
 int order_stats(int T, int N, const float* x, int r_lo, int r_hi, float* out, int32_t* nan_count,
                 hipStream_t st);
 int argmin_s(int K, int n_cand, const double* nll, const double* s_cand, double* s_out,

@@ -68,28 +68,48 @@ struct LagPre {
   int T, N, D, ntile, nch, CL;         // chunk j: frames [F + j CL, F + (j + 1) CL), CL a multiple of 64
   const float* y;
   const double* A;                     // [K][D][D]
-  double* part;                        // [nch][kLaL][N]
+  double* part;                        // [nch][N][kLaL]
   const double* state;                 // optimiser state: a tile none of whose keypoints still runs is skipped
   const int32_t* kp_block;
   int cap;
 };
 
-// The pre-pass (second form, round 6): block = (64-chain tile, time chunk), 16 waves, wave w = lags 16 w .. 16 w + 15.
-// The inputs u of the chunk go through ONE ring in LDS (512 frames x 64 chains, float32): every 32 frames each wave loads
-// three rows, forms two frames' inputs and stores them - two sets ahead of their use - and every wave reads its current
-// pair and its pair 16 w frames back from the ring (two ds_read2st64_b32 per 17 packed FMAs, one pair ahead of their
-// use), keeping the 9 delayed pairs a step needs in a register ring of 16; the float64 sums stay in registers.
-// Measured on BASELINE configs[2] (profiles/r06_probes.txt): the first form - 8 waves x 32 lags, every wave loading and
-// subtracting both streams itself (8 loads and 4 subtractions per 33 FMAs, 640 scalar instructions per 64 frames for the
-// clamped row offsets), float64 sums in LDS - 388 us; this one 333 us as first written, the same with 8 waves x 32 lags
-// (two waves per SIMD behind a barrier per step) 525 us.
-constexpr int kRgWaves = 16;
-constexpr int kRgCap = 512;              // frames in the ring: 240 of delay + 32 of history + the set in use + two in flight
 constexpr int kRgHist = 288;             // frames in front of the chunk that the prologue fills (a multiple of 32 >= 272)
 
+// The pre-pass, on the matrix cores (third form of round 6).  The 256 lag sums of a chain are ONE 16 x 16 matrix product
+// with the frames as its inner dimension, no entry computed twice:
+//     C[i][j] = sum_t u_{t+i} u_{t-16 j} = c_{i + 16 j},     A[i][t] = u_{t+i},  B[t][j] = u_{t-16 j}
+// (every pair (tau, tau - k) appears once: tau = t + i for the one i = k mod 16), so v_mfma_f32_16x16x4_f32 - exact
+// float32 FMA chains at the vector rate - takes four frames of one chain per instruction.  A group of 16 frames from T0
+// is four instructions p = 0 .. 3 whose inner index kq stands for frame T0 + 4 kq + p: lane (kq, x) feeds
+// A = u_{T0+4kq+p+x} and B = u_{T0+4kq+p-16x}; the accumulator's register r of lane l is lag 16 (l & 15) + 4 (l >> 4) + r.
+// Block = (64-chain tile, time chunk), 8 waves, wave w = chains 8 w .. 8 w + 7 of the tile (two waves per SIMD: the eight
+// chains of a wave share a lane's ring addresses).  The chunk's inputs go through one ring in LDS (every 32 frames each
+// wave loads five rows and stores four frames' inputs, two sets ahead of their use; lane = chain), chain-major in time
+// order with four words of padding per 64 frames: a lane's B operands of a group are four consecutive words on a 16-byte
+// boundary - ONE ds_read_b128, the sixteen lanes of a quarter wave (frames 16 apart) in sixteen different bank quads -
+// its A operands four ds_read_b32 of nineteen consecutive words per quarter wave.  The operands of the next pair of chains
+// are requested before the current pair's eight instructions issue.  Float32 accumulators span 64 frames and are added
+// into float64 registers.
+// Measured on BASELINE configs[2] (profiles/r06_probes.txt section 8; us per pass on the same box): the packed-FMA forms
+// of this round (8 waves x 32 lags, every wave loading and subtracting both streams: 388; 16 waves x 16 lags behind one
+// ring of inputs, 17 v_pk_fma_f32 per frame pair: 313-330, 0.54 of the vector rate under its power limit); matrix
+// cores with (t mod 16, t / 16) planes in LDS and eight ds_read_b32 per four instructions: 279 (half of the LDS pipe's
+// cycles bank conflicts); this layout with 16 waves x 4 chains: 299; 8 waves x 8 chains: 280.  The matrix instructions
+// alone (no operand reads, no producers, no barrier) take 206, with producers and barrier 224: the instruction holds its
+// SIMD's vector issue while it runs, so every address, conversion and float64 addition beside it is added time.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kMfRing = 512;                  // frames in the ring
+constexpr int kMfChP = kMfRing + 4 * (kMfRing / 64) + 4;     // floats per chain: 4 words of padding per 64 frames (548)
+static_assert(kMfChP % 4 == 0, "a chain's ring starts on a 16-byte boundary");
+
+constexpr int kMfWaves = 8;                   // two per SIMD: 8 chains per wave share a lane's ring addresses
+constexpr int kMfCh = 64 / kMfWaves;          // chains per wave
+constexpr int kMfFr = 32 / kMfWaves;          // frames of a 32-frame set a wave produces
+
 template <bool UNIT>
-__global__ __launch_bounds__(64 * kRgWaves) void lag_sums_kernel(LagPre P) {
-  __shared__ float uring[kRgCap][64];
+__global__ __launch_bounds__(64 * kMfWaves) void lag_sums_kernel(LagPre P) {
+  __shared__ __attribute__((aligned(16))) float ring[64 * kMfChP];
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int tile = blockIdx.x % P.ntile, j = blockIdx.x / P.ntile;
   const int n_raw = tile * 64 + lane;
@@ -101,7 +121,7 @@ __global__ __launch_bounds__(64 * kRgWaves) void lag_sums_kernel(LagPre P) {
   }
   const double a_d = P.A[(size_t)k * P.D * P.D + (size_t)d * (P.D + 1)];
   const int T = P.T;
-  const int ts0 = kLaF + j * P.CL;                    // (ts0 - 1 is a multiple of 64: ring slots of a set never wrap)
+  const int ts0 = kLaF + j * P.CL;                    // (ts0 - 1 is a multiple of 64)
   const int len = min(P.CL, T - ts0);
   const int nsets = (len + 31) / 32;
   const int base_row = max(ts0 - kRgHist - 1, 0);
@@ -109,104 +129,134 @@ __global__ __launch_bounds__(64 * kRgWaves) void lag_sums_kernel(LagPre P) {
                                                      0x7FFFFFFF, 0x00020000),
                    (unsigned)((n - tile * 64) * 4), (unsigned)(P.N * 4), base_row, T - 1};
   auto input = [&](float yy, float yp) { return UNIT ? (yy - yp) : (float)((double)yy - a_d * (double)yp); };
-  // ---- producers: of every 32 frames from t, wave w owns frames t + 2 w, t + 2 w + 1 (three rows)
-  auto rows_of = [&](int t, float (&r)[3]) {
-#pragma unroll
-    for (int q = 0; q < 3; ++q) r[q] = ld(t + 2 * w - 1 + q);
+  auto slot = [](int f) {                             // frame f in a chain's ring (f - 1: groups start on multiples of 16)
+    const int r = (f - 1) & (kMfRing - 1);
+    return r + 4 * (r >> 6);
   };
-  auto store_u = [&](int t, const float (&r)[3]) {
+  // ---- producers: of every 32 frames from t, wave w owns frames t + 4 w .. t + 4 w + 3 (five rows); lane = chain
+  auto rows_of = [&](int t, float (&r)[kMfFr + 1]) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int f = t + 2 * w + q;
+    for (int q = 0; q <= kMfFr; ++q) r[q] = ld(t + kMfFr * w - 1 + q);
+  };
+  float* mine = ring + lane * kMfChP;
+  auto store_u = [&](int t, const float (&r)[kMfFr + 1]) {
+#pragma unroll
+    for (int q = 0; q < kMfFr; ++q) {
+      const int f = t + kMfFr * w + q;
       float u = input(r[q + 1], r[q]);
       if (!UNIT) u = (f >= kLaF && f < T) ? u : 0.f;  // (with a = 1 the clamped rows give zero by themselves: LagRows)
-      uring[(f - 1) & (kRgCap - 1)][lane] = u;         // frame f lives in slot f - 1: pairs start on even slots
+      mine[slot(f)] = u;
     }
   };
   {
-    // prologue: the history in front of the chunk and its first two sets - every row requested before any is used
     constexpr int NP = (kRgHist + 64) / 32;
-    float r[NP][3];
+    float r[NP][kMfFr + 1];
 #pragma unroll
     for (int i = 0; i < NP; ++i) rows_of(ts0 - kRgHist + 32 * i, r[i]);
 #pragma unroll
     for (int i = 0; i < NP; ++i) store_u(ts0 - kRgHist + 32 * i, r[i]);
   }
-  float nxt[3];
-  rows_of(ts0 + 64, nxt);                             // the third set's rows: stored at the start of the first
+  float nxt[kMfFr + 1];
+  rows_of(ts0 + 64, nxt);
   __syncthreads();
-  // ---- consumers
-  const int delay = 16 * w;
-  f32x2 E[8], O[9], X[16];
-  double acc[16];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) E[i] = f32x2{0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 9; ++i) O[i] = f32x2{0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.0;
-  auto pair_at = [&](int slot) {                      // frames (slot + 1, slot + 2): slot even, so the rows are neighbours
-    return f32x2{uring[slot][lane], uring[slot + 1][lane]};
+  // ---- consumers: lane = (kq, x) of the operands; chains kMfCh w + cc at + cc kMfChP words (an immediate of the read)
+  const int kq = lane >> 4, x = lane & 15;
+  const float* mych = ring + kMfCh * w * kMfChP;
+  struct Ops {
+    float a[2][4];
+    f32x4 b[2];
   };
-  {
-    const int h0 = (ts0 - 1 - delay - 32) & (kRgCap - 1), h1 = (ts0 - 1 - delay - 16) & (kRgCap - 1);
+  struct Addr {
+    int ib, ia[4];
+  };
+  auto address = [&](int T0) {                         // a lane's five ring offsets for the group of 16 frames from T0
+    Addr q;
+    const int g0 = (T0 - 1) & (kMfRing - 1);          // a multiple of 16 (wave-uniform)
+    const int fb = (g0 + 4 * kq - 16 * x) & (kMfRing - 1);
+    q.ib = fb + 4 * (fb >> 6);
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      X[a] = pair_at(h0 + 2 * a);
-      X[8 + a] = pair_at(h1 + 2 * a);
+    for (int p = 0; p < 4; ++p) {
+      const int fa = (g0 + 4 * kq + x + p) & (kMfRing - 1);
+      q.ia[p] = fa + 4 * (fa >> 6);
     }
+    return q;
+  };
+  auto request = [&](const Addr& q, int h, Ops& o) {   // operands of the chains 2 h, 2 h + 1
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float* ch = mych + (2 * h + c) * kMfChP;
+      o.b[c] = *reinterpret_cast<const f32x4*>(ch + q.ib);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) o.a[c][p] = ch[q.ia[p]];
+    }
+  };
+  f32x4 acc[kMfCh];
+  double sum[kMfCh][4];
+#pragma unroll
+  for (int cc = 0; cc < kMfCh; ++cc) {
+    acc[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sum[cc][r] = 0.0;
   }
+  auto multiply = [&](int h, const Ops& o) {          // eight instructions alternating between the pair's accumulators
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        acc[2 * h + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[c][p], o.b[c][p], acc[2 * h + c], 0, 0, 0);
+    }
+  };
+  // the pairs of a group in turn, the next pair's operands (the next group's first pair behind the last) requested before
+  // the current pair's instructions issue
+  constexpr int NH = kMfCh / 2;
+  Ops ops[2];
+  Addr qa = address(ts0);
+  request(qa, 0, ops[0]);
   for (int s = 0; s < nsets; ++s) {
     const int t = ts0 + 32 * s;
-    // the rows asked for a set ago become inputs two sets ahead (those slots held frames t - 448 .. t - 417: behind what
-    // any wave still reads), and their registers take the next request
     store_u(t + 64, nxt);
     rows_of(t + 96, nxt);
-    const int c0 = (t - 1) & (kRgCap - 1);
-    const int d0 = (t - 1 - delay) & (kRgCap - 1), d1 = (t - 1 - delay + 16) & (kRgCap - 1);
-    // the ring's reads run one pair ahead of the products
-    f32x2 Xc = pair_at(c0), Xd = pair_at(d0);
+    // (the frames a group reads reach 33 past its first: group 0 of the NEXT set reads frames stored a set ago, visible
+    //  since the last barrier, so its first request may be issued before this set's barrier)
 #pragma unroll
-    for (int a = 0; a < 16; ++a) {
-      const f32x2 Xc_n = a + 1 < 16 ? pair_at(c0 + 2 * (a + 1)) : Xc;
-      const f32x2 Xd_n = a + 1 < 16 ? pair_at((a + 1 < 8 ? d0 : d1) + 2 * ((a + 1) & 7)) : Xd;
-      X[a] = Xd;
+    for (int g = 0; g < 2; ++g) {
+      const Addr qn = address(t + 16 * (g + 1));
 #pragma unroll
-      for (int dl = 0; dl < 8; ++dl) E[dl] = Xc * X[(a - dl) & 15] + E[dl];
-#pragma unroll
-      for (int dl = 0; dl < 9; ++dl) {
-        const f32x2 xb = X[(a - dl) & 15];
-        O[dl] = Xc * f32x2{xb[1], xb[0]} + O[dl];
+      for (int h = 0; h < NH; ++h) {
+        if (h + 1 < NH) request(qa, h + 1, ops[(h + 1) & 1]);
+        else request(qn, 0, ops[(h + 1) & 1]);
+        multiply(h, ops[h & 1]);
       }
-      Xc = Xc_n;
-      Xd = Xd_n;
-      EKS_SCHED_FENCE();
+      qa = qn;
     }
-    if ((s & 1) || s + 1 == nsets) {                  // float32 partial sums span 64 frames
+    if ((s & 1) || s + 1 == nsets) {
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
-        acc[2 * jj] += (double)(E[jj][0] + E[jj][1]);
-        acc[2 * jj + 1] += (double)(O[jj][1] + O[jj + 1][0]);
-        E[jj] = f32x2{0.f, 0.f};
+      for (int cc = 0; cc < kMfCh; ++cc) {              // float32 partial sums span 64 frames
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[cc][r] += (double)acc[cc][r];
+        acc[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-#pragma unroll
-      for (int jj = 0; jj < 9; ++jj) O[jj] = f32x2{0.f, 0.f};
     }
     __syncthreads();
   }
-  if (n_raw < P.N) {
+  // lane (kq, x) holds lags 16 x + 4 kq + r of its chains: 32 consecutive bytes each
 #pragma unroll
-    for (int i = 0; i < 16; ++i) P.part[((size_t)j * kLaL + 16 * w + i) * P.N + n] = acc[i];
+  for (int cc = 0; cc < kMfCh; ++cc) {
+    const int nn = tile * 64 + kMfCh * w + cc;
+    if (nn >= P.N) break;                              // (wave-uniform)
+    double* o = P.part + ((size_t)j * P.N + nn) * kLaL + 16 * x + 4 * kq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = sum[cc][r];
   }
 }
 
 __global__ void lag_reduce_kernel(int N, int nch, const double* __restrict__ part, double* __restrict__ ck) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;           // = n * 256 + lag
   if (idx >= (long)N * kLaL) return;
-  const int lag = (int)(idx / N), n = (int)(idx - (long)lag * N);
+  const int lag = (int)(idx & (kLaL - 1));
   double s = 0.0;
-  for (int j = 0; j < nch; ++j) s += part[((size_t)j * kLaL + lag) * N + n];
-  ck[(size_t)n * kLaL + lag] = lag ? 2.0 * s : s;
+  for (int j = 0; j < nch; ++j) s += part[(size_t)j * N * kLaL + idx];
+  ck[idx] = lag ? 2.0 * s : s;
 }
 
 // ---- cross-lane pieces of the search kernel (DPP: row shifts inside rows of 16, row broadcasts across them) ----------
@@ -504,7 +554,6 @@ __device__ __forceinline__ DualD la_nll_stream(const LaConst& K, const float* __
   float buf[NB + 1], nbuf[NB + 1];
   // rows t .. t + NB: two aligned 16-byte loads (the copy's pitch is padded: a block past the end reads the pad, whose
   // contents are never used - every use below is selected by t + q + 1 < T) and the row after them
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int tpad = (T + 15) / 16 * 16;
   auto fetch = [&](int t, float (&b)[NB + 1]) {
     const int tb = min(t, tpad - NB);
@@ -861,7 +910,7 @@ int diag_lag_sums(const eks_dims_t& d, const float* y, const double* A, const Ad
     ProfScope ps("lag_sums", st);
     const LagPre P{T, N, D, ntile, W.nch, W.cl, y, A, W.part, F ? F->state : nullptr, F ? F->kp_block : nullptr,
                    F ? F->cap : 0};
-    const dim3 grid((unsigned)(ntile * W.nch)), block(64 * kRgWaves);
+    const dim3 grid((unsigned)(ntile * W.nch)), block(64 * kMfWaves);
     if (d.flags & EKS_FLAG_UNIT_AC) hipLaunchKernelGGL(lag_sums_kernel<true>, grid, block, 0, st, P);
     else hipLaunchKernelGGL(lag_sums_kernel<false>, grid, block, 0, st, P);
   }

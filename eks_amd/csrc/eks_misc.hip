@@ -861,7 +861,12 @@ int const_r(int T, int N, const float* var, double min_var, double* rconst, void
 // in LDS, thread i sums leaf i of numpy's pairwise recursion, thread 0 walks the combine program - both tables are
 // a function of n alone and come from the caller (hip_ops.np_nanstd_rows builds them once per n).
 // ==========================================================================================
-__global__ __launch_bounds__(256) void np_nanstd_rows_kernel(int K, int n, const float* __restrict__ d,
+// DIFF: row k is not read but formed - element t O + o = x[t + 1][k][o] - x[t][k][o] of a frame-major [.][K][O] tensor
+// (the frame-to-frame differences of the ensemble variances, reference eks/core.py:128-129; the float32 subtraction is
+// the same IEEE operation as NumPy's, so the row is the host's bit for bit without the subtraction and the transposing
+// copy as launches of their own)
+template <bool DIFF>
+__global__ __launch_bounds__(256) void np_nanstd_rows_kernel(int K, int n, const float* __restrict__ d, int O,
                                                             const int32_t* __restrict__ leaves, int n_leaves,
                                                             const int32_t* __restrict__ ops, int n_ops,
                                                             float* __restrict__ out) {
@@ -875,7 +880,14 @@ __global__ __launch_bounds__(256) void np_nanstd_rows_kernel(int K, int n, const
   __syncthreads();
   int mine = 0;
   for (int i = threadIdx.x; i < n; i += 256) {
-    const float v = d[(size_t)k * n + i];
+    float v;
+    if constexpr (DIFF) {
+      const int t = i / O, o = i - t * O;
+      const size_t at = ((size_t)t * K + k) * O + o;
+      v = np_sub(d[at + (size_t)K * O], d[at]);
+    } else {
+      v = d[(size_t)k * n + i];
+    }
     row[i] = v;
     mine += v != v;
   }
@@ -919,7 +931,19 @@ int np_nanstd_rows(int K, int n, const float* d, const int32_t* leaves, int n_le
                    float* out, hipStream_t st) {
   const size_t shm = ((size_t)n + n_leaves + n_ops) * sizeof(float);
   if (shm > 64 * 1024) return EKS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(np_nanstd_rows_kernel, dim3(K), dim3(256), shm, st, K, n, d, leaves, n_leaves, ops, n_ops, out);
+  hipLaunchKernelGGL(np_nanstd_rows_kernel<false>, dim3(K), dim3(256), shm, st, K, n, d, 1, leaves, n_leaves, ops, n_ops,
+                     out);
+  return hip_status(hipGetLastError());
+}
+
+// x [n_frames][K][O] frame-major: rows of (n_frames - 1) O differences per keypoint
+int np_nanstd_diff_rows(int n_frames, int K, int O, const float* x, const int32_t* leaves, int n_leaves,
+                        const int32_t* ops, int n_ops, float* out, hipStream_t st) {
+  const int n = (n_frames - 1) * O;
+  const size_t shm = ((size_t)n + n_leaves + n_ops) * sizeof(float);
+  if (shm > 64 * 1024) return EKS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(np_nanstd_rows_kernel<true>, dim3(K), dim3(256), shm, st, K, n, x, O, leaves, n_leaves, ops, n_ops,
+                     out);
   return hip_status(hipGetLastError());
 }
 

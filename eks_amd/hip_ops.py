@@ -74,7 +74,15 @@ def _ptr(t: torch.Tensor | None):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_raw_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def _stream():
+    """torch's current stream of the current device as a hipStream_t.  (torch.cuda.current_stream() builds a Stream
+    object through three Python layers, ~8 us a call - ten calls a search; the raw accessor is one C call.)"""
+    if _raw_stream is not None and _raw_device is not None:
+        return ctypes.c_void_p(_raw_stream(_raw_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -103,6 +111,15 @@ def model_flags(S0, A, C, Q) -> int:
     """Inspect HOST copies of the parameters (numpy) and return DIAG_MODEL / UNIT_AC / Q_PD flags."""
     import numpy as np
     D, O = A.shape[-1], C.shape[-2]
+    # one pass in the library when the arrays are what run_kalman_smoother hands over (C-contiguous float64 (K, D, D) /
+    # (K, O, D)); a finite Q that is not diagonal needs eigenvalues and takes the NumPy route below
+    arrs = (S0, A, C, Q)
+    if all(isinstance(a, np.ndarray) and a.dtype == np.float64 and a.ndim == 3 and a.flags.c_contiguous for a in arrs) \
+            and S0.shape == A.shape == Q.shape == (A.shape[0], D, D) and C.shape == (A.shape[0], O, D):
+        rc = _lib.load().eks_host_model_flags(A.shape[0], D, O, S0.ctypes.data, A.ctypes.data, C.ctypes.data, Q.ctypes.data,
+                                              Q_PD_MIN_EIG_RATIO)
+        if rc >= 0:
+            return int(rc)
     # Q positive definite with a margin: the smoothing-distribution gradient forms tr((sQ)^-1 E[w w']) - D, a
     # cancellation whose error grows with Q's condition number and is summed over T frames, so it is only taken for
     # cond(Q) <= 1e6 per keypoint (measured against the dual-number kernels at the threshold and T = 50 000:
@@ -268,6 +285,31 @@ def np_nanstd_rows(x):
     return out
 
 
+def np_nanstd_diff_rows(x):
+    """eks_np_nanstd_diff_rows: numpy.nanstd over (frames, coordinates) of the frame-to-frame differences of a frame-major
+    device float32 tensor (T', K, O), per keypoint, bit for bit - what np_nanstd_rows gives for the transposed matrix of
+    differences, without making it.  None where that function returns None (the caller reduces on the host)."""
+    lib = _lib.load()
+    x = _chk(x, torch.float32, 'x')
+    Tn, K, O = x.shape
+    n = (Tn - 1) * O
+    key = (n, x.device)
+    hit = _NP_SUM_DEVICE.get(key)
+    if hit is None:
+        # first use of this row length on this device: the row-matrix form checks the summation order against this
+        # NumPy once (one row) and leaves the tables behind
+        d = (x[1:] - x[:-1]).transpose(0, 1).contiguous()
+        return np_nanstd_rows(d.reshape(K, -1))
+    lv, op = hit
+    if lv is None:
+        return None
+    out = torch.empty(K, dtype=torch.float32, device=x.device)
+    rc = lib.eks_np_nanstd_diff_rows(Tn, K, O, _ptr(x), _ptr(lv), lv.numel() // 2, _ptr(op) if op.numel() else None,
+                                     op.numel() // 3, _ptr(out), _stream())
+    _lib.check(rc, 'eks_np_nanstd_diff_rows')
+    return out
+
+
 def order_stats(x, rank_lo: int, rank_hi: int):
     """eks_order_stats: x (T, N) float32 -> (vals (N, 2) float32 = the order statistics rank_lo and rank_hi of
     every column with NaNs sorted last, nan_count (N,) int32), device tensors."""
@@ -399,17 +441,21 @@ class AdamLoop:
         self.n_active = torch.zeros(1, dtype=torch.int32, device=dev)
         self.dims = _dims(K, T, D, O, flags)
         self.ws = _workspace(self.lib.eks_nll_workspace_bytes(ctypes.byref(self.dims), 1), dev)
+        self.prepared = False
 
     def set_rconst(self, rconst) -> None:
         K, O = self.dims.n_keypoints, self.dims.obs_dim
         self.bufs[1] = _chk(rconst, torch.float64, 'rconst', (K, O))
 
-    def prepare(self) -> bool:
-        """eks_adam_prepare: the pass over y that does not depend on the optimiser's state, enqueued now - the caller may
-        fill `state` / `s_keypoint` (e.g. from initial guesses it is still waiting for) before the first run().  False:
-        this problem's search does not use such a pass (nothing was enqueued)."""
+    def prepare(self, stream=None) -> bool:
+        """eks_adam_prepare: the pass over y that does not depend on the optimiser's state, enqueued now (on `stream`, a
+        torch stream; default: the current one) - the caller may fill `state` / `s_keypoint` (e.g. from initial guesses
+        it is still waiting for) before the first run().  False: this problem's search does not use such a pass
+        (nothing was enqueued)."""
+        st = _stream() if stream is None else ctypes.c_void_p(stream.cuda_stream)
         rc = self.lib.eks_adam_prepare(ctypes.byref(self.dims), _ptr(self.bufs[0]), _ptr(self.bufs[4]), self.nb,
-                                       _ptr(self.ws), self.ws.numel(), _stream())
+                                       _ptr(self.ws), self.ws.numel(), st)
+        self.prepared = True                                     # (asked once, whatever the answer)
         if rc == _lib.EKS_ERR_UNSUPPORTED:
             return False
         _lib.check(rc, 'eks_adam_prepare')

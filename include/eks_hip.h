@@ -116,6 +116,13 @@ int eks_order_stats(int32_t n_rows, int32_t n_cols, const float* x, int32_t rank
 int eks_np_nanstd_rows(int32_t n_rows, int32_t n_cols, const float* x, const int32_t* leaves, int32_t n_leaves,
                        const int32_t* ops, int32_t n_ops, float* out, eks_stream_t stream);
 
+/* ---- the same for the rows compute_initial_guesses actually reduces (eks/core.py:128-130), formed on the fly: row k,
+ * element t * obs_dim + o = x[t + 1][k][o] - x[t][k][o] of a frame-major [n_frames][n_keypoints][obs_dim] float32
+ * tensor (the first n_frames <= 2 000 frames of the ensemble variances) - one launch instead of a subtraction, a
+ * transposing copy and the reduction.  leaves / ops: the tables for n_cols = (n_frames - 1) * obs_dim. ------------- */
+int eks_np_nanstd_diff_rows(int32_t n_frames, int32_t n_keypoints, int32_t obs_dim, const float* x, const int32_t* leaves,
+                            int32_t n_leaves, const int32_t* ops, int32_t n_ops, float* out, eks_stream_t stream);
+
 /* ---- argmin over candidates + gather: s_out[k] = s_cand[argmin_c nll[k][c]] (first minimum,
  * like numpy.argmin).  idx_out (optional) receives the int32 indices. ---------------------- */
 int eks_argmin_s(int32_t n_keypoints, int32_t n_cand, const double* nll, const double* s_cand,
@@ -348,6 +355,15 @@ int eks_format_repr(const double* values, int64_t n, char* out, int64_t capacity
  * one thread finishes one (a ~1 ms measurement; a sandbox may expose several CPUs and still run a process's threads
  * one at a time).  The Python wrapper asks once and takes the threaded writer only where threads run side by side. -- */
 double eks_host_thread_speedup(int32_t n_threads);
+
+/* eks_host_model_flags: the EKS_FLAG_DIAG_MODEL / EKS_FLAG_UNIT_AC / EKS_FLAG_Q_PD bits that HOST copies of the parameters
+ * S0, A, Q [K][D][D] and C [K][O][D] allow (what run_kalman_smoother decides before its first launch; the reference has
+ * no counterpart - eks/core.py:159-177 hands whatever it is given to dynamax): DIAG_MODEL when D == O and every matrix
+ * is diagonal, UNIT_AC when also A = C = I, Q_PD when every Q[k] is finite with lambda_min > min_eig_ratio x lambda_max.
+ * Returns the flags (>= 0); EKS_ERR_UNSUPPORTED when Q is finite but NOT diagonal (its eigenvalues decide Q_PD: the
+ * caller asks LAPACK). ---------------------------------------------------------------------------------------------- */
+int eks_host_model_flags(int32_t n_keypoints, int32_t state_dim, int32_t obs_dim, const double* S0, const double* A,
+                         const double* C, const double* Q, double min_eig_ratio);
 
 /* eks_host_gather_cols: dst[r][0 .. width) = src[r][col_offset .. col_offset + width) (bytes) for n_rows rows of a
  * row-major HOST matrix with rows of src_row_bytes, on n_threads threads: a keypoint tile of the frame-major ensemble

@@ -1075,6 +1075,28 @@ def test_np_nanstd_rows_is_numpys_value_bit_for_bit(K, n):
     assert got.dtype == np.float32 and np.array_equal(got, ref, equal_nan=True)
 
 
+@pytest.mark.parametrize('Tn,K,O', [(2000, 64, 2), (2, 5, 2), (777, 33, 3), (2000, 7, 4)])
+def test_np_nanstd_diff_rows_is_numpys_value_of_the_frame_differences(Tn, K, O):
+    """eks_np_nanstd_diff_rows - compute_initial_guesses' reduction (reference eks/core.py:128-130) with the frame-to-frame
+    differences formed inside the launch from the frame-major (T', K, O) tensor - against numpy.nanstd of
+    ev[1:, k] - ev[:-1, k] per keypoint: identical bits, NaN frames and an all-NaN keypoint included, on the first call
+    (which goes through the row-matrix form and checks the summation order) and on the second (the fused launch)."""
+    import warnings
+    from eks_amd import hip_ops
+    rng = np.random.default_rng(Tn * 31 + K)
+    ev = (rng.gamma(2.0, 0.25, (Tn, K, O)) * np.exp(rng.uniform(-3, 4, (1, K, 1)))).astype(np.float32)
+    ev[rng.random((Tn, K, O)) < 0.02] = np.nan
+    if K > 3:
+        ev[:, 1] = np.nan
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        ref = np.array([np.nanstd(ev[1:, k] - ev[:-1, k]) for k in range(K)], dtype=np.float32)
+    x = _dev(ev)
+    for _ in range(2):
+        got = hip_ops.np_nanstd_diff_rows(x).cpu().numpy()
+        assert got.dtype == np.float32 and np.array_equal(got, ref, equal_nan=True)
+
+
 def test_np_nanstd_rows_declines_rows_numpy_would_reduce_in_buffered_pieces():
     from eks_amd import hip_ops
     assert hip_ops.np_nanstd_rows(_dev(np.ones((2, 8193), np.float32))) is None
