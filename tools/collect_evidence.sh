@@ -20,6 +20,8 @@ EKS_ADAM_STREAM=1 python bench.py --workload c3adam --no-cpu-baseline > $O/bench
 EKS_ADAM_LAG_RHO_PPM=0 python bench.py --workload c3adam --steps 3 --warmup 1 --regions 2 --no-cpu-baseline > $O/bench_c3adam_all_chains_streamed.json 2>/dev/null
 python tools/lag_adam_check.py > $O/lag_adam_check.txt 2>&1
 python tools/lag_prepass_time.py 2>&1 | grep -v amdgpu > $O/lag_prepass_time.txt
+python tools/lag_adam_shapes.py 2>&1 | grep -v amdgpu > $O/lag_adam_shapes.txt
+for m in side after_const_r first; do EKS_ADAM_PREPARE=$m python bench.py --workload c3adam --no-extras --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('EKS_ADAM_PREPARE=$m', d['ms_per_step'])"; done > $O/c3adam_prepare_order.txt
 for c in 8 16 32 64 128; do echo "== EKS_DENSE_CHUNK=$c"; EKS_DENSE_CHUNK=$c python tools/ekf_time.py 2>&1 | grep "cold start\|run_kalman"; done > $O/ekf_chunk_trade.txt
 EKS_NLL_LEGACY=1 python bench.py --no-cpu-baseline > $O/bench_c3_legacy_nll.json 2>/dev/null
 EKS_NLL_NOLAG=1 python bench.py --no-cpu-baseline > $O/bench_c3_nolag.json 2>/dev/null

@@ -81,7 +81,7 @@ for name in ('c3', 'c3_default_run', 'c3adam', 'c3adam_streaming', 'c3adam_all_c
         shutil.copy(src, os.path.join(prof, f'{tag}_bench_{name}.json'))
 for name in ('pytest_gpu.txt', 'smoke.txt', 'adam_time.txt', 'dense_adam_time.txt', 'dense_adam_time_d.txt',
              'pupil_time.txt', 'ekf_time.txt', 'driver_time.txt', 'host_path_time.txt', 'first_call.txt', 'nll_lean2.txt', 'nll_lag.txt',
-             'fit_time.txt', 'host_boundary_ab.txt', 'grid_stamps.txt', 'lag_adam_check.txt', 'lag_prepass_time.txt',
+             'fit_time.txt', 'host_boundary_ab.txt', 'grid_stamps.txt', 'lag_adam_check.txt', 'lag_prepass_time.txt', 'lag_adam_shapes.txt', 'c3adam_prepare_order.txt',
              'ekf_chunk_trade.txt', 'c3adam_timeline.txt'):
     src = os.path.join(ev, name)
     if os.path.exists(src):
