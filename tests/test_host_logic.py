@@ -511,3 +511,46 @@ def test_np_sum_program_is_numpys_pairwise_summation_order():
             for dst, x, y in ops:
                 slot[dst] = f(slot[x] + slot[y])
             assert f(0.0) + slot[-1] == np.sum(a), n
+
+
+def test_model_flags_in_one_c_pass_decides_what_the_numpy_route_decides():
+    """hip_ops.model_flags asks the library (eks_host_model_flags: one pass over the host arrays, in front of every
+    call's first launch) when the arrays are C-contiguous float64, and NumPy otherwise (and for a finite Q that is not
+    diagonal, whose eigenvalues decide EKS_FLAG_Q_PD).  Both routes, the same answers: diagonal / unit / decaying
+    models, an ill-conditioned and a non-finite Q, off-diagonal entries and NaNs in each array, D != O."""
+    from eks_amd import hip_ops
+    rng = np.random.default_rng(11)
+
+    def both(S0, A, C, Q):
+        fast = hip_ops.model_flags(*(np.ascontiguousarray(a, dtype=np.float64) for a in (S0, A, C, Q)))
+        slow = hip_ops.model_flags(*(np.asarray(a, dtype=np.float32) for a in (S0, A, C, Q)))   # (not float64: NumPy)
+        return fast, slow
+
+    for K, D in ((1, 1), (7, 2), (40, 3)):
+        eye = np.tile(np.eye(D), (K, 1, 1))
+        S0 = eye * rng.uniform(0.5, 4.0, (K, 1, 1))
+        diagQ = eye * rng.uniform(0.5, 2.0, (K, D, 1))
+        cases = {
+            'unit': (S0, eye, eye, eye),
+            'decaying': (S0, eye * 0.5, eye * 0.75, diagQ),
+            'ill-conditioned Q': (S0, eye, eye, eye * np.where(np.arange(D) == 0, 1.0, 1e-7 if D > 1 else 1.0)[None, :, None]),
+            'Q with a NaN on the diagonal': (S0, eye, eye, np.where(eye > 0, np.nan, 0.0)),
+        }
+        if D > 1:
+            off = np.zeros_like(eye)
+            off[K // 2, 0, 1] = off[K // 2, 1, 0] = 0.25
+            nan_off = np.zeros_like(eye)
+            nan_off[0, 1, 0] = np.nan
+            cases.update({
+                'S0 off-diagonal': (S0 + off, eye, eye, eye), 'A off-diagonal': (S0, eye + off, eye, eye),
+                'C off-diagonal': (S0, eye, eye + off, eye), 'Q off-diagonal (PD)': (S0, eye, eye, eye + off),
+                'Q off-diagonal (indefinite)': (S0, eye, eye, eye + 8.0 * off), 'A with a NaN off the diagonal': (S0, eye + nan_off, eye, eye),
+                'Q with a NaN off the diagonal': (S0, eye, eye, eye + nan_off),
+            })
+            C_tall = np.tile(np.vstack([np.eye(D), np.ones((1, D))]), (K, 1, 1))
+            cases['D != O'] = (S0, eye, C_tall, eye)
+        for name, arrs in cases.items():
+            fast, slow = both(*arrs)
+            assert fast == slow, (K, D, name, fast, slow)
+    fast, _ = both(np.ones((3, 1, 1)), np.ones((3, 1, 1)), np.ones((3, 1, 1)), np.ones((3, 1, 1)))
+    assert fast == hip_ops.FLAG_DIAG_MODEL | hip_ops.FLAG_UNIT_AC | hip_ops.FLAG_Q_PD
