@@ -84,7 +84,8 @@ constexpr int kRgHist = 288;             // frames in front of the chunk that th
 // is four instructions p = 0 .. 3 whose inner index kq stands for frame T0 + 4 kq + p: lane (kq, x) feeds
 // A = u_{T0+4kq+p+x} and B = u_{T0+4kq+p-16x}; the accumulator's register r of lane l is lag 16 (l & 15) + 4 (l >> 4) + r.
 // Block = (64-chain tile, time chunk), 8 waves, wave w = chains 8 w .. 8 w + 7 of the tile (two waves per SIMD: the eight
-// chains of a wave share a lane's ring addresses).  The chunk's inputs go through one ring in LDS (every 32 frames each
+// chains of a wave share a lane's ring addresses, which come from a small table in LDS).  The chunk's inputs go through one
+// ring of 384 frames in LDS (every 32 frames each
 // wave loads five rows and stores four frames' inputs, two sets ahead of their use; lane = chain), chain-major in time
 // order with four words of padding per 64 frames: a lane's B operands of a group are four consecutive words on a 16-byte
 // boundary - ONE ds_read_b128, the sixteen lanes of a quarter wave (frames 16 apart) in sixteen different bank quads -
@@ -95,13 +96,15 @@ constexpr int kRgHist = 288;             // frames in front of the chunk that th
 // of this round (8 waves x 32 lags, every wave loading and subtracting both streams: 388; 16 waves x 16 lags behind one
 // ring of inputs, 17 v_pk_fma_f32 per frame pair: 313-330, 0.54 of the vector rate under its power limit); matrix
 // cores with (t mod 16, t / 16) planes in LDS and eight ds_read_b32 per four instructions: 279 (half of the LDS pipe's
-// cycles bank conflicts); this layout with 16 waves x 4 chains: 299; 8 waves x 8 chains: 280.  The matrix instructions
+// cycles bank conflicts); this layout with 16 waves x 4 chains: 299; 8 waves x 8 chains: 280; the lanes' addresses from a
+// table instead of twenty vector instructions per group: 272.  The matrix instructions
 // alone (no operand reads, no producers, no barrier) take 206, with producers and barrier 224: the instruction holds its
 // SIMD's vector issue while it runs, so every address, conversion and float64 addition beside it is added time.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kMfRing = 512;                  // frames in the ring
-constexpr int kMfChP = kMfRing + 4 * (kMfRing / 64) + 4;     // floats per chain: 4 words of padding per 64 frames (548)
-static_assert(kMfChP % 4 == 0, "a chain's ring starts on a 16-byte boundary");
+constexpr int kMfRing = 384;                  // frames in the ring: 240 of delay + the set in use + two in flight + 18 ahead
+constexpr int kMfGroups = kMfRing / 16;
+constexpr int kMfChP = kMfRing + 4 * (kMfRing / 64) + 4;     // floats per chain: 4 words of padding per 64 frames (412)
+static_assert(kMfChP % 4 == 0 && kMfRing % 64 == 0, "a chain's ring starts on a 16-byte boundary");
 
 constexpr int kMfWaves = 8;                   // two per SIMD: 8 chains per wave share a lane's ring addresses
 constexpr int kMfCh = 64 / kMfWaves;          // chains per wave
@@ -110,6 +113,10 @@ constexpr int kMfFr = 32 / kMfWaves;          // frames of a 32-frame set a wave
 template <bool UNIT>
 __global__ __launch_bounds__(64 * kMfWaves) void lag_sums_kernel(LagPre P) {
   __shared__ __attribute__((aligned(16))) float ring[64 * kMfChP];
+  // a lane's ring offsets (B, then A of the four instructions) for a group that starts in ring column g: the wrap of the
+  // ring and its padding make them lane-dependent functions of g - twenty vector instructions per group if computed,
+  // five LDS reads from this table (an f32 MFMA holds its SIMD's vector issue: vector instructions beside it are added time)
+  __shared__ int tab[kMfGroups][5][64];
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int tile = blockIdx.x % P.ntile, j = blockIdx.x / P.ntile;
   const int n_raw = tile * 64 + lane;
@@ -129,8 +136,12 @@ __global__ __launch_bounds__(64 * kMfWaves) void lag_sums_kernel(LagPre P) {
                                                      0x7FFFFFFF, 0x00020000),
                    (unsigned)((n - tile * 64) * 4), (unsigned)(P.N * 4), base_row, T - 1};
   auto input = [&](float yy, float yp) { return UNIT ? (yy - yp) : (float)((double)yy - a_d * (double)yp); };
-  auto slot = [](int f) {                             // frame f in a chain's ring (f - 1: groups start on multiples of 16)
-    const int r = (f - 1) & (kMfRing - 1);
+  auto ringpos = [](int f) {                          // (f - 1: groups start on multiples of 16; f may be negative)
+    const int r = (f - 1) % kMfRing;
+    return r < 0 ? r + kMfRing : r;
+  };
+  auto slot = [&](int f) {                            // frame f (wave-uniform) in a chain's ring
+    const int r = ringpos(f);
     return r + 4 * (r >> 6);
   };
   // ---- producers: of every 32 frames from t, wave w owns frames t + 4 w .. t + 4 w + 3 (five rows); lane = chain
@@ -158,9 +169,16 @@ __global__ __launch_bounds__(64 * kMfWaves) void lag_sums_kernel(LagPre P) {
   }
   float nxt[kMfFr + 1];
   rows_of(ts0 + 64, nxt);
+  const int kq = lane >> 4, x = lane & 15;
+  for (int e = w; e < kMfGroups * 5; e += kMfWaves) {  // (wave-uniform e)
+    const int g = e / 5, a = e - 5 * g;
+    int r = 16 * g + 4 * kq + (a == 0 ? -16 * x : x + a - 1);
+    r = r < 0 ? r + kMfRing : r;
+    r = r >= kMfRing ? r - kMfRing : r;
+    tab[g][a][lane] = r + 4 * (r >> 6);
+  }
   __syncthreads();
   // ---- consumers: lane = (kq, x) of the operands; chains kMfCh w + cc at + cc kMfChP words (an immediate of the read)
-  const int kq = lane >> 4, x = lane & 15;
   const float* mych = ring + kMfCh * w * kMfChP;
   struct Ops {
     float a[2][4];
@@ -171,14 +189,10 @@ __global__ __launch_bounds__(64 * kMfWaves) void lag_sums_kernel(LagPre P) {
   };
   auto address = [&](int T0) {                         // a lane's five ring offsets for the group of 16 frames from T0
     Addr q;
-    const int g0 = (T0 - 1) & (kMfRing - 1);          // a multiple of 16 (wave-uniform)
-    const int fb = (g0 + 4 * kq - 16 * x) & (kMfRing - 1);
-    q.ib = fb + 4 * (fb >> 6);
+    const int g = ringpos(T0) >> 4;                   // (wave-uniform; ringpos(T0) is a multiple of 16)
+    q.ib = tab[g][0][lane];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int fa = (g0 + 4 * kq + x + p) & (kMfRing - 1);
-      q.ia[p] = fa + 4 * (fa >> 6);
-    }
+    for (int p = 0; p < 4; ++p) q.ia[p] = tab[g][1 + p][lane];
     return q;
   };
   auto request = [&](const Addr& q, int h, Ops& o) {   // operands of the chains 2 h, 2 h + 1
