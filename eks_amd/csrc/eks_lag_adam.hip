@@ -220,26 +220,30 @@ __global__ __launch_bounds__(64 * kMfWaves) void lag_sums_kernel(LagPre P) {
         acc[2 * h + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[c][p], o.b[c][p], acc[2 * h + c], 0, 0, 0);
     }
   };
-  // the pairs of a group in turn, the next pair's operands (the next group's first pair behind the last) requested before
-  // the current pair's instructions issue
+  // the pairs of a group in turn; the operands of the pair kMfAhead steps on (into the next group, and from a set's second
+  // group into the next set's first, whose frames are visible since the last barrier) are requested before the current
+  // pair's instructions issue
   constexpr int NH = kMfCh / 2;
-  Ops ops[2];
+  constexpr int kMfAhead = 1;                         // (three pairs ahead, four operand buffers: 272 us against 266)
+  static_assert(kMfAhead >= 1 && kMfAhead <= NH && (2 * NH) % (kMfAhead + 1) == 0,
+                "requests stay within the next group; the operand buffers take turns with the period of a set");
+  Ops ops[kMfAhead + 1];
   Addr qa = address(ts0);
-  request(qa, 0, ops[0]);
+#pragma unroll
+  for (int h = 0; h < kMfAhead; ++h) request(qa, h, ops[h]);
   for (int s = 0; s < nsets; ++s) {
     const int t = ts0 + 32 * s;
     store_u(t + 64, nxt);
     rows_of(t + 96, nxt);
-    // (the frames a group reads reach 33 past its first: group 0 of the NEXT set reads frames stored a set ago, visible
-    //  since the last barrier, so its first request may be issued before this set's barrier)
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const Addr qn = address(t + 16 * (g + 1));
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
-        if (h + 1 < NH) request(qa, h + 1, ops[(h + 1) & 1]);
-        else request(qn, 0, ops[(h + 1) & 1]);
-        multiply(h, ops[h & 1]);
+        const int step = g * NH + h, ahead = h + kMfAhead;
+        if (ahead < NH) request(qa, ahead, ops[(step + kMfAhead) % (kMfAhead + 1)]);
+        else request(qn, ahead - NH, ops[(step + kMfAhead) % (kMfAhead + 1)]);
+        multiply(h, ops[step % (kMfAhead + 1)]);
       }
       qa = qn;
     }
