@@ -1165,7 +1165,8 @@ def _oracle_adam(arrs, y_tk, rc, ks, u0, cap=300, tol=1e-2, lo=-8.0, hi=8.0):
 
 @pytest.mark.parametrize('T,K,unit,stride,cap', [(30_000, 70, True, 24, 300), (20_011, 33, False, 7, 300),
                                                  (50_000, 128, True, None, 300), (1_024, 3, True, None, 300),
-                                                 (4_500, 40, False, 9, 300), (30_000, 70, True, 5, 13)])
+                                                 (4_500, 40, False, 9, 300), (30_000, 70, True, 5, 13),
+                                                 (3_000, 600, True, None, 300)])
 def test_adam_from_cached_lag_sums_is_the_streaming_search_and_the_oracles(T, K, unit, stride, cap, set_knob):
     """Round 6 (eks_lag_adam.hip): one keypoint per optimiser block and at least 1 024 frames - eks_adam_run makes ONE
     pass over y (256 lag sums of the inputs u_t = y_t - a y_{t-1} per chain, which do not depend on s) and then runs all
@@ -1184,9 +1185,17 @@ def test_adam_from_cached_lag_sums_is_the_streaming_search_and_the_oracles(T, K,
     u0 = np.log(np.random.default_rng(T).uniform(0.05, 50.0, K))
     n_l, st_l, s_l, nll_l, g_l, left_l = _adam_search(y, rc, params, flags, K, u0, cap, stride)
     assert n_l == 4096                       # (the lag-sum search is what ran: the whole search in one call)
-    set_knob('EKS_ADAM_STREAM', '1')
-    n_s, st_s, s_s, nll_s, g_s, left_s = _adam_search(y, rc, params, flags, K, u0, cap, stride or 16)
-    assert n_s in (16, 64)
+    if K >= 256:
+        # (the wide session: 19 tiles x 14 chunks.  Its reference is the in-kernel float64 evaluation of every frame -
+        #  EKS_ADAM_LAG_RHO_PPM=0 - which the lag form follows to 1e-6 with the same stopping iteration on 600 of 600
+        #  keypoints; round 5's streaming kernels are the noisier of the two there: 2e-5, one keypoint 30 iterations off)
+        set_knob('EKS_ADAM_LAG_RHO_PPM', '0')
+        n_s, st_s, s_s, nll_s, g_s, left_s = _adam_search(y, rc, params, flags, K, u0, cap, stride)
+        assert n_s == 4096
+    else:
+        set_knob('EKS_ADAM_STREAM', '1')
+        n_s, st_s, s_s, nll_s, g_s, left_s = _adam_search(y, rc, params, flags, K, u0, cap, stride or 16)
+        assert n_s in (16, 64)
     if cap == 300:
         assert st_l[:, 4].max() > 20 and np.all(st_l[:, 5] == 1.0)
     else:
