@@ -17,19 +17,19 @@ def _run(script, *args):
     return r.stdout
 
 
-@pytest.mark.parametrize('seed', [101, 202])
+@pytest.mark.parametrize('seed', [303, 202])
 def test_scalar_chain_kernels_random_shapes(seed):
-    out = _run('fuzz_parity.py', 11, seed)
+    out = _run('fuzz_parity.py', 14, seed)
     assert 'above 1e-5' not in out and "'med': 0.0" in out, out[-2000:]
 
 
 def test_gradient_path_and_general_kernels_random_shapes():
-    out = _run('fuzz_parity2.py', 25, 303)
+    out = _run('fuzz_parity2.py', 18, 303)
     assert 'above 1e-5' not in out and 'worst' in out, out[-2000:]
 
 
 def test_drivers_random_configurations():
-    out = _run('fuzz_drivers.py', 10, 404)
+    out = _run('fuzz_drivers.py', 7, 404)
     assert 'above 1e-5' not in out and 'worst' in out, out[-2000:]
 
 
@@ -49,5 +49,5 @@ def test_exact_median_adversarial_inputs():
 
 
 def test_extended_filter_random_calibrated_rigs():
-    out = _run('fuzz_ekf.py', 10, 808)
+    out = _run('fuzz_ekf.py', 7, 808)
     assert 'above 1e-5' not in out and 'cases above tolerance 0' in out, out[-2000:]
