@@ -426,47 +426,42 @@ struct LagAdam {
 // evaluation from the pole: the variance's transient w_t = w_0 kappa^t must be dead at its end, and the searches spend
 // most of their iterations at poles below 0.7 where 64 frames do.  A set holds what depends on the head's length H:
 // the inputs that follow the head's frames, the lag sums over t >= H + 1 + k and the first inputs of that region.
-struct LaSet {
-  double un[4];                // u_{t+1} for the lane's frames t = NF lane + f (NF = H / 64 of them)
-  double c2k[4];               // lag sums (c_0, 2 c_k) over the region that starts at F = H + 1
-  double uF[4];                // its first inputs u_{F+k}
-};
 struct LaLane {
-  LaSet full;                  // H = 256 (kLaB0, the region lag_sums_kernel summed); the shorter ones live in LDS
-  double ut[4];                // last inputs u_{T-1-k}
+  double un[4];                // HEAD wave: u_{t+1} for the lane's frames t = 4 lane + f of the 256-frame head
+  double c2k[4], uF[4];        // LAG wave: lag sums (c_0, 2 c_k) of the region from F = 257 and its first inputs u_{F+k}
+  double ut[4];                // LAG wave: last inputs u_{T-1-k}
   double e0;                   // innovation of frame 0: y_0 - c m_0
 };
 constexpr int kLaStage = 576;               // u_0 .. u_575 of a chain while its sets are formed (lags up to 255 past 256)
 constexpr int kLaSetRows = 19;              // H = 64: un[1] c2k[4] uF[4] | H = 128: un[2] c2k[4] uF[4]; [row][lane]
 constexpr int kLaDynPerChain = kLaStage + kLaSetRows * 64;
 
-template <int NF>
-__device__ __forceinline__ LaSet la_load_set(const double* sets, int lane) {
-  static_assert(NF == 1 || NF == 2, "the 256-frame set stays in registers");
-  constexpr int r0 = NF == 1 ? 0 : 9;
-  LaSet S;
-#pragma unroll
-  for (int f = 0; f < 4; ++f) S.un[f] = f < NF ? sets[(r0 + f) * 64 + lane] : 0.0;
-#pragma unroll
-  for (int f = 0; f < 4; ++f) {
-    S.c2k[f] = sets[(r0 + NF + f) * 64 + lane];
-    S.uF[f] = sets[(r0 + NF + 4 + f) * 64 + lane];
-  }
-  return S;
+// ---- the evaluation, on the TWO waves of a chain (on different SIMDs: float64 instructions issue at half the float32
+// rate, the evaluation is ~350 of them and one wave per chain left half of the chip's SIMDs idle).  The HEAD wave walks
+// the head's frames and takes log S_inf; the LAG wave forms the lag polynomial, Z, the tail sum and the head's
+// log-determinant.  What each hands over is a few numbers; the loss is
+//     v  = [ Hv + Bv + E (Zv + ca E) ] / 2,   dv = [ Hd + Bd + E (Zd + ca' E) + E' (Zv + 2 ca E) ] / 2
+// with (E, E') the innovation of frame H and its derivative, (Hv, Hd) the head's quadratic term + T log(2 pi S_inf),
+// (Bv, Bd) = ca x polynomial - ca rho^2 Dl^2 + log-determinant of the head, (Zv, Zd) the coefficients of E from
+// 2 ca rho E Z, and ca = g / (1 - rho^2).
+struct LaHeadOut {
+  double Hv, Hd, Ev, Ed;
+};
+struct LaLagOut {
+  double Bv, Bd, Zv, Zd, cav, cad;
+};
+__device__ __forceinline__ DualD la_combine(const LaHeadOut& h, const LaLagOut& l) {
+  const double v = 0.5 * (h.Hv + l.Bv + h.Ev * (l.Zv + l.cav * h.Ev));
+  const double dv = 0.5 * (h.Hd + l.Bd + h.Ev * (l.Zd + l.cad * h.Ev) + h.Ed * (l.Zv + 2.0 * l.cav * h.Ev));
+  return DualD(v, dv);
 }
 
-// the chain's NLL and d / d log s from the lag sums (|rho| <= rho_max), head of 64 NF frames.  k64 = kappa^64.
+// the head's frames NF lane .. NF lane + NF - 1 (un: the inputs that follow them); H = 64 NF
 template <int NF>
-__device__ __forceinline__ DualD la_nll_fast(const LaConst& K, const LaSet& S, const double (&ut)[4], double e0, double k64,
-                                             int T, int lane) {
-  constexpr int H = 64 * NF;
-  // ---- head: frames NF lane .. NF lane + NF - 1.  One power per evaluation: rho^(NF lane); the head's
-  // kappa^(NF lane) is its square (kappa = rho^2), the lags' rho^(4 lane) its (4 / NF)-th power
+__device__ __forceinline__ LaHeadOut la_head(const LaConst& K, const double (&un)[4], double e0, int T, int lane) {
+  // rho^(NF lane) by squaring; kappa^(NF lane) is its square (kappa = rho^2)
   const double rho = K.rho.v, rho2 = rho * rho;
   const double hb = la_pow_bits<6>(NF == 1 ? rho : NF == 2 ? rho2 : rho2 * rho2, (unsigned)lane);
-  double pbase = hb;
-  if (NF <= 2) pbase *= pbase;
-  if (NF == 1) pbase *= pbase;
   // S_t = S_inf (1 - w_{t+1}) / (1 - w_t): the frame's 1 / S_t and pole are g and rho times m_t = (1 - w_t) / (1 - w_{t+1}),
   // d log m_t = h_{t+1} - h_t with h_t = dw_t / (1 - w_t) - one reciprocal per frame (and one more per lane)
   double om[NF + 1], h[NF + 1], inv[NF + 1];
@@ -494,7 +489,7 @@ __device__ __forceinline__ DualD la_nll_fast(const LaConst& K, const LaSet& S, c
     const double gv = K.g.v * m;
     gt[f] = DualD(gv, gv * dd);
     rt[f] = DualD(ar * gt[f].v, ar * gt[f].d);
-    el = la_then(el, LaAff{rt[f], DualD(S.un[f])});
+    el = la_then(el, LaAff{rt[f], DualD(un[f])});
   }
   la_scan(el, lane);
   const DualD e_first(e0);
@@ -505,32 +500,44 @@ __device__ __forceinline__ DualD la_nll_fast(const LaConst& K, const LaSet& S, c
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
     quad = quad + gt[f] * e * e;
-    if (f + 1 < NF) e = rt[f] * e + DualD(S.un[f]);
+    if (f + 1 < NF) e = rt[f] * e + DualD(un[f]);
   }
-  const DualD E(la_readlane(e_out.v, 63), la_readlane(e_out.d, 63));     // innovation of frame H
-  // ---- lags 4 lane .. 4 lane + 3
+  LaHeadOut o;
+  o.Ev = la_readlane(e_out.v, 63);                            // innovation of frame H
+  o.Ed = la_readlane(e_out.d, 63);
+  o.Hv = la_wave_sum(quad.v) + (double)T * (kLog2Pi + log(K.Sinf.v));
+  o.Hd = la_wave_sum(quad.d) + (double)T * K.Sinf.d * K.g.v;
+  return o;
+}
+
+// lags 4 lane .. 4 lane + 3 of the region behind a head of H = 64 NF frames (c2k, uF: that region's sums and first
+// inputs; ut: the last inputs).  k64 = kappa^64.
+template <int NF>
+__device__ __forceinline__ LaLagOut la_lags(const LaConst& K, const double (&c2k)[4], const double (&uF)[4],
+                                            const double (&ut)[4], double k64, int lane) {
+  constexpr int H = 64 * NF;
+  const double rho = K.rho.v, rho2 = rho * rho;
+  const double pbase = la_pow_bits<6>(rho2 * rho2, (unsigned)lane);
   const double pf[4] = {pbase, pbase * rho, pbase * rho2, pbase * rho2 * rho};
   double sp = 0.0, spk = 0.0, sz = 0.0, szk = 0.0, sd = 0.0, sdk = 0.0;
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
     const double kk = (double)(4 * lane + f) * pf[f];
-    sp += pf[f] * S.c2k[f];  spk += kk * S.c2k[f];
-    sz += pf[f] * S.uF[f];   szk += kk * S.uF[f];
-    sd += pf[f] * ut[f];     sdk += kk * ut[f];
+    sp += pf[f] * c2k[f];  spk += kk * c2k[f];
+    sz += pf[f] * uF[f];   szk += kk * uF[f];
+    sd += pf[f] * ut[f];   sdk += kk * ut[f];
   }
-  // ---- the wave's sums.  The loss is LINEAR in the head's quadratic term, in the lag polynomial and in Z, with
-  // coefficients known before any sum is taken (E, rho, g): those three - and their derivatives - are combined in the
-  // lane and reduced as ONE value and ONE derivative; only the last inputs' sum Dl enters squared and travels alone.
-  // Four reductions (each six DPP steps on a 64-bit value) instead of ten.
+  // the loss is linear in the lag polynomial and in Z with coefficients known before any sum is taken: those two - and
+  // their derivatives - are combined in the lane; only the last inputs' sum Dl enters squared and travels alone
   const DualD one(1.0);
   const DualD iom = rcp(one - K.rho * K.rho);
   const DualD ca = K.g * iom;                                  // coefficient of the lag polynomial
-  const DualD cb = DualD(2.0) * ca * E * K.rho;                // ... of Z  (2 g E X1, X1 = rho Z / (1 - rho^2))
-  const double lin_v = quad.v + ca.v * sp + cb.v * sz;
-  const double lin_d = quad.d + ca.d * sp + ca.v * K.dlr * spk + cb.d * sz + cb.v * K.dlr * szk;
-  const double LV = la_wave_sum(lin_v), LD = la_wave_sum(lin_d);
+  const DualD M = DualD(2.0) * ca * K.rho;                     // ... of E Z  (2 g E X1, X1 = rho Z / (1 - rho^2))
+  const double bv = la_wave_sum(ca.v * sp), bd = la_wave_sum(ca.d * sp + ca.v * K.dlr * spk);
+  const double zv = la_wave_sum(M.v * sz), zd = la_wave_sum(M.d * sz + M.v * K.dlr * szk);
   const DualD Dl(la_wave_sum(sd), la_wave_sum(sdk) * K.dlr);
-  // ---- the head's log-determinant in closed form: prod_{t=1}^{H-1} S_t / S_inf telescopes to (1 - w_H) / (1 - w_1);
+  const DualD Nn = ca * K.rho * K.rho * Dl * Dl;               // (rho^(2 (T - H)) < 1e-60 here)
+  // the head's log-determinant in closed form: prod_{t=1}^{H-1} S_t / S_inf telescopes to (1 - w_H) / (1 - w_1);
   // frame 0 is S_0 itself
   double kH = k64;
   if (NF >= 2) kH *= kH;
@@ -541,12 +548,14 @@ __device__ __forceinline__ DualD la_nll_fast(const LaConst& K, const LaSet& S, c
   const double S0 = K.c2 * K.P0 + K.r;
   const double logdet_head = log(S0 * K.g.v * (1.0 - wH) * i1);          // sum_{t < H} log(S_t / S_inf)
   const double dlogdet_head = dw1 * i1 - dwH * iH - K.Sinf.d * K.g.v;    // its derivative (frame 0: -d log S_inf)
-  // ---- assembly:  g [ (poly - rho^2 Dl^2) / (1 - rho^2) + 2 E X1 + E^2 / (1 - rho^2) ]  (rho^(2 (T - H)) < 1e-60 here)
-  const DualD rest = ca * (E * E - K.rho * K.rho * Dl * Dl);
-  const double logS = log(K.Sinf.v);
-  const double v = 0.5 * ((double)T * (kLog2Pi + logS) + logdet_head + LV + rest.v);
-  const double dv = 0.5 * (LD + (double)T * K.Sinf.d * K.g.v + dlogdet_head + rest.d);
-  return DualD(v, dv);
+  LaLagOut o;
+  o.Bv = bv - Nn.v + logdet_head;
+  o.Bd = bd - Nn.d + dlogdet_head;
+  o.Zv = zv;
+  o.Zd = zd;
+  o.cav = ca.v;
+  o.cad = ca.d;
+  return o;
 }
 
 // the chain's NLL and d / d log s by streaming its own frames (any pole): lane = time chunk of the chain-major copy
@@ -687,9 +696,11 @@ __device__ unsigned long long g_lag_stamps[1024][8];
 #define LAG_STAMP(i) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(64 * kLaMaxD) void lag_adam_kernel(LagAdam P) {
-  __shared__ double xch[2][kLaMaxD][2];
-  const int lane = threadIdx.x, d = threadIdx.y, D = P.D;
+__global__ __launch_bounds__(128 * kLaMaxD) void lag_adam_kernel(LagAdam P) {
+  // block = keypoint; wave 2 d + h: chain d, h = 0 the HEAD wave, h = 1 the LAG wave (la_head / la_lags)
+  __shared__ double xch[2][kLaMaxD][10];
+  const int lane = threadIdx.x, D = P.D;
+  const int d = __builtin_amdgcn_readfirstlane((int)threadIdx.y >> 1), half = __builtin_amdgcn_readfirstlane((int)threadIdx.y & 1);
   const int k = blockIdx.x;
   const int kb = P.kp_block[k];
   const int T = P.T, N = P.N;
@@ -706,37 +717,43 @@ __global__ __launch_bounds__(64 * kLaMaxD) void lag_adam_kernel(LagAdam P) {
   LaLane L;
   {
     const float* yn = P.y + n;
-    // the chain's first inputs u_t = y_t - a y_{t-1}, t < 576, through LDS (u_0 is never used)
-#pragma unroll
-    for (int i = 0; i < kLaStage / 64; ++i) {
+    // the chain's first inputs u_t = y_t - a y_{t-1}, t < 576, through LDS (u_0 is never used); its two waves share them
+    for (int i = half; i < kLaStage / 64; i += 2) {
       const int t = 64 * i + lane;
       const float y1 = yn[(size_t)t * N], y0 = yn[(size_t)max(t - 1, 0) * N];
       ush[t] = (double)y1 - a * (double)y0;
     }
     L.e0 = (double)yn[0] - c * m0;
-    const double* ckn = P.ck + (size_t)n * kLaL + 4 * lane;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) L.full.c2k[f] = ckn[f];
-    float ht[5];
+    for (int f = 0; f < 4; ++f) L.c2k[f] = L.uF[f] = L.ut[f] = L.un[f] = 0.0;
+    if (half == 1) {
+      const double* ckn = P.ck + (size_t)n * kLaL + 4 * lane;
 #pragma unroll
-    for (int f = 0; f < 5; ++f) ht[f] = yn[(size_t)max(T - 1 - 4 * lane - f, 0) * N];   // rows T - 1 - 4 lane, downwards
+      for (int f = 0; f < 4; ++f) L.c2k[f] = ckn[f];
+      float ht[5];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const int tt = T - 1 - 4 * lane - f;
-      L.ut[f] = tt >= kLaF ? (double)ht[f] - a * (double)ht[f + 1] : 0.0;
+      for (int f = 0; f < 5; ++f) ht[f] = yn[(size_t)max(T - 1 - 4 * lane - f, 0) * N];   // rows T - 1 - 4 lane, downwards
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int tt = T - 1 - 4 * lane - f;
+        L.ut[f] = tt >= kLaF ? (double)ht[f] - a * (double)ht[f + 1] : 0.0;
+      }
     }
   }
   __syncthreads();
-  {
-    // the 256-frame head's set, and the two shorter ones: the lag sums of a region that starts at F = H + 1 are the
-    // cached ones (F = 257) plus the products of the frames in between,
-    //   c_k(H) = c_k(256) + sum_{t = H + 1 + k}^{256 + k} u_t u_{t-k}      (u_{t-k} = u_{H+1+i}: the same for every lane)
-    // 128 + 64 products per lag, once per search
+  if (half == 0) {
+    // the inputs that follow the frames of a head of 256 / 64 / 128 frames
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      L.full.un[f] = ush[4 * lane + f + 1];
-      L.full.uF[f] = ush[kLaF + 4 * lane + f];
-    }
+    for (int f = 0; f < 4; ++f) L.un[f] = ush[4 * lane + f + 1];
+    sets[0 * 64 + lane] = ush[lane + 1];                              // H = 64: un
+    sets[9 * 64 + lane] = ush[2 * lane + 1];                          // H = 128: un[0], un[1]
+    sets[10 * 64 + lane] = ush[2 * lane + 2];
+  } else {
+    // the lag sums of a region that starts at F = H + 1 are the cached ones (F = 257) plus the products of the frames in
+    // between,  c_k(H) = c_k(256) + sum_{t = H + 1 + k}^{256 + k} u_t u_{t-k}   (u_{t-k} = u_{H+1+i}: the same for every
+    // lane): 128 + 64 products per lag, once per search
+#pragma unroll
+    for (int f = 0; f < 4; ++f) L.uF[f] = ush[kLaF + 4 * lane + f];
     double acc128[4] = {0.0, 0.0, 0.0, 0.0}, acc64[4] = {0.0, 0.0, 0.0, 0.0};
     {
       const double* ua = ush + 129 + 4 * lane;                       // u_{129 + k + i}, k = 4 lane + f
@@ -758,19 +775,17 @@ __global__ __launch_bounds__(64 * kLaMaxD) void lag_adam_kernel(LagAdam P) {
         w0 = w1; w1 = w2; w2 = w3;
       }
     }
-    sets[0 * 64 + lane] = ush[lane + 1];                              // H = 64: un
-    sets[9 * 64 + lane] = ush[2 * lane + 1];                          // H = 128: un[0], un[1]
-    sets[10 * 64 + lane] = ush[2 * lane + 2];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const double mult = 4 * lane + f == 0 ? 1.0 : 2.0;             // (c_0, 2 c_k)
-      const double c128 = L.full.c2k[f] + mult * acc128[f];
+      const double c128 = L.c2k[f] + mult * acc128[f];
       sets[(11 + f) * 64 + lane] = c128;
       sets[(1 + f) * 64 + lane] = c128 + mult * acc64[f];
       sets[(15 + f) * 64 + lane] = ush[129 + 4 * lane + f];
       sets[(5 + f) * 64 + lane] = ush[65 + 4 * lane + f];
     }
   }
+  // (each wave reads back only what it wrote itself - the head wave the un rows, the lag wave the others - so no barrier)
   bool have_copy = false;
   float* yc = P.yT + (size_t)n * (((size_t)T + 15) / 16 * 16);
   double b1t = adam_pow_count(0.9, iters), b2t = adam_pow_count(0.999, iters);
@@ -781,10 +796,11 @@ __global__ __launch_bounds__(64 * kLaMaxD) void lag_adam_kernel(LagAdam P) {
   for (int it = 0; it < P.n_iters; ++it) {
     LAG_STAMP(4);
     const double s = exp(fmin(fmax(u, P.lo), P.hi));
+    // (both waves of a chain run the SAME instructions up to the branch on `half`: the same constants, the same head)
     const LaConst K = la_const(a, c, q, r, P0, s);
     LAG_STAMP(0);
-    DualD v;
-    if (fabs(K.rho.v) <= P.rho_max) {                            // (wave-uniform: one chain per wave)
+    double* mine = xch[it & 1][d];
+    if (fabs(K.rho.v) <= P.rho_max) {                            // (wave-uniform: one chain per pair of waves)
       // the head: as short as the variance's transient allows (|w_H| H = |w_0| kappa^H H below 1e-17 at its end)
       const double kap2 = K.kap * K.kap, k4 = kap2 * kap2, k16 = (k4 * k4) * (k4 * k4), k64 = (k16 * k16) * (k16 * k16);
       const double aw = fabs(K.w0);
@@ -793,10 +809,40 @@ __global__ __launch_bounds__(64 * kLaMaxD) void lag_adam_kernel(LagAdam P) {
       if (aw * k64 * 64.0 <= 1e-17) nf = 1;
       if (P.head_frames) nf = P.head_frames / 64;                // (tests)
       nf = __builtin_amdgcn_readfirstlane(nf);
-      if (nf == 1) v = la_nll_fast<1>(K, la_load_set<1>(sets, lane), L.ut, L.e0, k64, T, lane);
-      else if (nf == 2) v = la_nll_fast<2>(K, la_load_set<2>(sets, lane), L.ut, L.e0, k64, T, lane);
-      else v = la_nll_fast<4>(K, L.full, L.ut, L.e0, k64, T, lane);
-    } else {
+      if (half == 0) {
+        LaHeadOut o;
+        if (nf == 1) {
+          const double un1[4] = {sets[0 * 64 + lane], 0.0, 0.0, 0.0};
+          o = la_head<1>(K, un1, L.e0, T, lane);
+        } else if (nf == 2) {
+          const double un2[4] = {sets[9 * 64 + lane], sets[10 * 64 + lane], 0.0, 0.0};
+          o = la_head<2>(K, un2, L.e0, T, lane);
+        } else {
+          o = la_head<4>(K, L.un, L.e0, T, lane);
+        }
+        if (lane == 0) {
+          mine[0] = o.Hv; mine[1] = o.Hd; mine[2] = o.Ev; mine[3] = o.Ed;
+        }
+      } else {
+        LaLagOut o;
+        if (nf == 4) {
+          o = la_lags<4>(K, L.c2k, L.uF, L.ut, k64, lane);
+        } else {
+          const int r0 = nf == 1 ? 1 : 11;
+          double c2k[4], uF[4];
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            c2k[f] = sets[(r0 + f) * 64 + lane];
+            uF[f] = sets[(r0 + 4 + f) * 64 + lane];
+          }
+          o = nf == 1 ? la_lags<1>(K, c2k, uF, L.ut, k64, lane) : la_lags<2>(K, c2k, uF, L.ut, k64, lane);
+        }
+        if (lane == 0) {
+          mine[4] = o.Bv; mine[5] = o.Bd; mine[6] = o.Zv; mine[7] = o.Zd; mine[8] = o.cav; mine[9] = o.cad;
+        }
+      }
+    } else if (half == 0) {
+      // the pole is beyond the lags' range: the head wave streams the chain's frames (float64, exact); nothing from lags
       if (!have_copy) {
         for (int t = lane; t < T; t += 64) yc[t] = P.y[(size_t)t * N + n];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -804,18 +850,24 @@ __global__ __launch_bounds__(64 * kLaMaxD) void lag_adam_kernel(LagAdam P) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         have_copy = true;
       }
-      v = la_nll_stream(K, yc, T, L.e0, lane);
+      const DualD v = la_nll_stream(K, yc, T, L.e0, lane);
+      if (lane == 0) {
+        mine[0] = 2.0 * v.v; mine[1] = 2.0 * v.d; mine[2] = 0.0; mine[3] = 0.0;
+      }
+    } else {
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 4; i < 10; ++i) mine[i] = 0.0;
+      }
     }
     LAG_STAMP(1);
-    if (lane == 0) {
-      xch[it & 1][d][0] = v.v;
-      xch[it & 1][d][1] = v.d;
-    }
     __syncthreads();
     double Lv = 0.0, g = 0.0;
     for (int dq = 0; dq < D; ++dq) {
-      Lv += xch[it & 1][dq][0];
-      g += xch[it & 1][dq][1];
+      const double* x = xch[it & 1][dq];
+      const DualD v = la_combine(LaHeadOut{x[0], x[1], x[2], x[3]}, LaLagOut{x[4], x[5], x[6], x[7], x[8], x[9]});
+      Lv += v.v;
+      g += v.d;
     }
     // eks/core.py:650: a non-finite loss is 1e12 with zero gradient; then the step and the stop rule of :652-681
     LAG_STAMP(2);
@@ -845,7 +897,7 @@ __global__ __launch_bounds__(64 * kLaMaxD) void lag_adam_kernel(LagAdam P) {
     prev = Lv;
     iters = cnt;
     done = stop ? 1.0 : 0.0;
-    if (lane == 0 && d == 0) {
+    if (lane == 0 && d == 0 && half == 0) {
       P.nll[k] = Lv;
       P.dnll[k] = g_raw;
     }
@@ -856,13 +908,13 @@ __global__ __launch_bounds__(64 * kLaMaxD) void lag_adam_kernel(LagAdam P) {
     if (stop || !(iters < (double)P.cap)) break;
   }
 #ifdef EKS_LAG_STAMPS
-  if (lane == 0 && n < 1024) {
+  if (lane == 0 && 2 * n + half < 1024) {
     lag_acc_[6] = __builtin_readcyclecounter() - lag_start_;
     lag_acc_[7] = lag_start_;
-    for (int i = 0; i < 8; ++i) g_lag_stamps[n][i] = lag_acc_[i];
+    for (int i = 0; i < 8; ++i) g_lag_stamps[2 * n + half][i] = lag_acc_[i];
   }
 #endif
-  if (lane == 0 && d == 0) {
+  if (lane == 0 && d == 0 && half == 0) {
     st[0] = u; st[1] = mom; st[2] = vel; st[3] = prev; st[4] = iters; st[5] = done;
     P.s_keypoint[k] = exp(fmin(fmax(u, P.lo), P.hi));
     if (done == 0.0 && iters < (double)P.cap) atomicAdd(P.n_active, 1);
@@ -957,7 +1009,7 @@ int diag_lag_adam(const eks_dims_t& d, const float* y, const double* rconst, con
   if (head != 64 && head != 128 && head != 256) head = 0;
   const LagAdam P{T, N, D, y, rconst, M.m0, M.S0, M.A, M.C, M.Q, W.ck, W.yT, F.kp_block, F.lr, F.lo, F.hi, F.tol, F.cap,
                   n_iters, rm >= 0 ? 1e-6 * rm : rho_max, head, F.state, F.s_keypoint, nll, dnll, F.n_active_cur};
-  hipLaunchKernelGGL(lag_adam_kernel, dim3((unsigned)K), dim3(64, D), (size_t)D * kLaDynPerChain * sizeof(double), st, P);
+  hipLaunchKernelGGL(lag_adam_kernel, dim3((unsigned)K), dim3(64, 2 * D), (size_t)D * kLaDynPerChain * sizeof(double), st, P);
   return hip_status(hipGetLastError());
 }
 
