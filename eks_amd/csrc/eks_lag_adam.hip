@@ -421,11 +421,12 @@ struct LagAdam {
   int32_t* n_active;
 };
 
-// what a chain's wave keeps for the whole search (lane j: lags 4 j .. 4 j + 3).  The HEAD - the frames evaluated one by
+// what a chain's two waves keep for the whole search (lane j: lags 4 j .. 4 j + 3).  The HEAD - the frames evaluated one by
 // one from the prior, before the lag sums take over - is 64, 128 or 256 frames long (1, 2 or 4 per lane), chosen per
 // evaluation from the pole: the variance's transient w_t = w_0 kappa^t must be dead at its end, and the searches spend
-// most of their iterations at poles below 0.7 where 64 frames do.  A set holds what depends on the head's length H:
-// the inputs that follow the head's frames, the lag sums over t >= H + 1 + k and the first inputs of that region.
+// most of their iterations at poles below 0.7 where 64 frames do.  What depends on the head's length H - the inputs that
+// follow the head's frames, the lag sums over t >= H + 1 + k and the first inputs of that region - is kept in registers
+// for H = 256 and in LDS rows (`sets`) for the two shorter heads.
 struct LaLane {
   double un[4];                // HEAD wave: u_{t+1} for the lane's frames t = 4 lane + f of the 256-frame head
   double c2k[4], uF[4];        // LAG wave: lag sums (c_0, 2 c_k) of the region from F = 257 and its first inputs u_{F+k}
